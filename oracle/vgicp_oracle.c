@@ -1,0 +1,1136 @@
+/*
+ * vgicp_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * A plain-C (C11 + OpenMP) restatement of the reference's CPU VGICP / GICP path
+ * (koide3/gtsam_points v1.2.1, mounted read-only at /root/reference).  It is the
+ * checker the HIP path is compared with.  Nothing under gtsam_points_amd/ may
+ * link, import or call this file: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py do.
+ *
+ * PARITY STATUS: "parity unpinned" in the strict sense -- the reference cannot
+ * be compiled here (needs GTSAM >= 4.2, Eigen3, Boost; none are on the image,
+ * SURVEY.md section 8c) and its test-suite holds no golden vectors for this
+ * path.  The restatement is anchored instead on (i) an independent numpy
+ * restatement (oracle/vgicp_oracle_np.py) that must agree to <= 1e-10,
+ * (ii) finite-difference checks of b/H, (iii) the reference's own test gates
+ * (alignment < 0.015 rad / 0.15 m on kitti_07_dump; test_matching_cost_factors.cpp:227)
+ * and (iv) oracle/_ref, the reference's own headers compiled against stand-in
+ * Eigen/GTSAM headers when /root/reference is present (see oracle/Makefile).
+ *
+ * Every function cites the reference file:line it follows.  All paths are
+ * relative to /root/reference.
+ *
+ * Third-party arithmetic restated (absent from /root/reference):
+ *   - GTSAM 4.2a9/4.3a0 Pose3::inverse()*Pose3, SO3::Hat (textbook SE(3)/so(3)).
+ *   - Eigen 3.4.0 fixed-size 3x3 inverse (cofactor closed form) and
+ *     SelfAdjointEigenSolver<Matrix3d>::computeDirect (closed-form trigonometric).
+ *
+ * Conventions: matrices are COLUMN-MAJOR (Eigen default).  4x4 poses are
+ * double[16], M(r,c) = m[c*4+r].  6x6 blocks are double[36], H(r,c) = h[c*6+r].
+ * Inputs at the boundary are the GPU API's float arrays (points float[N][3],
+ * covariances float[N][9] column-major); they are up-cast to double exactly as
+ * PointCloudCPU would hold them (Vector4d with w=1, Matrix4d with zero 4th
+ * row/column; include/gtsam_points/types/point_cloud.hpp:103-118).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* small dense helpers                                                        */
+/* ------------------------------------------------------------------------- */
+
+#define M4(m, r, c) ((m)[(c) * 4 + (r)])
+#define M6(m, r, c) ((m)[(c) * 6 + (r)])
+#define M3(m, r, c) ((m)[(c) * 3 + (r)])
+
+/* include/gtsam_points/util/fast_floor.hpp:12-15 : int(x) - (x < int(x)) */
+static inline int orc_fast_floor(double x) {
+  const int n = (int)x;
+  return n - (x < (double)n);
+}
+
+/* Eigen 3.4 compute_inverse<Matrix3d>: cofactors / determinant
+ * (call sites: integrated_vgicp_factor_impl.hpp:140, integrated_gicp_factor_impl.hpp:199). */
+static void orc_inverse3(const double* a /*3x3 col-major*/, double* inv /*3x3 col-major*/) {
+  const double c00 = M3(a, 1, 1) * M3(a, 2, 2) - M3(a, 1, 2) * M3(a, 2, 1);
+  const double c10 = M3(a, 1, 2) * M3(a, 2, 0) - M3(a, 1, 0) * M3(a, 2, 2);
+  const double c20 = M3(a, 1, 0) * M3(a, 2, 1) - M3(a, 1, 1) * M3(a, 2, 0);
+  const double det = M3(a, 0, 0) * c00 + M3(a, 0, 1) * c10 + M3(a, 0, 2) * c20;
+  const double invdet = 1.0 / det;
+  M3(inv, 0, 0) = c00 * invdet;
+  M3(inv, 1, 0) = c10 * invdet;
+  M3(inv, 2, 0) = c20 * invdet;
+  M3(inv, 0, 1) = (M3(a, 0, 2) * M3(a, 2, 1) - M3(a, 0, 1) * M3(a, 2, 2)) * invdet;
+  M3(inv, 1, 1) = (M3(a, 0, 0) * M3(a, 2, 2) - M3(a, 0, 2) * M3(a, 2, 0)) * invdet;
+  M3(inv, 2, 1) = (M3(a, 0, 1) * M3(a, 2, 0) - M3(a, 0, 0) * M3(a, 2, 1)) * invdet;
+  M3(inv, 0, 2) = (M3(a, 0, 1) * M3(a, 1, 2) - M3(a, 0, 2) * M3(a, 1, 1)) * invdet;
+  M3(inv, 1, 2) = (M3(a, 0, 2) * M3(a, 1, 0) - M3(a, 0, 0) * M3(a, 1, 2)) * invdet;
+  M3(inv, 2, 2) = (M3(a, 0, 0) * M3(a, 1, 1) - M3(a, 0, 1) * M3(a, 1, 0)) * invdet;
+}
+
+static void orc_mul44(const double* a, const double* b, double* out) {
+  double tmp[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += M4(a, r, k) * M4(b, k, c);
+      M4(tmp, r, c) = s;
+    }
+  memcpy(out, tmp, sizeof(tmp));
+}
+
+/* GTSAM Pose3::inverse(): (R^T, -R^T t) */
+static void orc_pose_inverse(const double* T, double* out) {
+  double tmp[16] = {0};
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) M4(tmp, r, c) = M4(T, c, r);
+  for (int r = 0; r < 3; r++) {
+    double s = 0.0;
+    for (int k = 0; k < 3; k++) s += M4(T, k, r) * M4(T, k, 3);
+    M4(tmp, r, 3) = -s;
+  }
+  M4(tmp, 3, 3) = 1.0;
+  memcpy(out, tmp, sizeof(tmp));
+}
+
+/* src/gtsam_points/factors/integrated_matching_cost_factor.cpp:57-69 :
+ * delta = target_pose.inverse() * source_pose  (4x4 double) */
+ORC_API void orc_calc_delta(const double* T_target, const double* T_source, double* delta) {
+  double inv[16];
+  orc_pose_inverse(T_target, inv);
+  orc_mul44(inv, T_source, delta);
+}
+
+/* GTSAM Pose3::Expmap(xi), xi = [omega, v] (Rot3::Expmap = Rodrigues; used by the
+ * reference tests to perturb poses, src/test/test_matching_cost_factors.cpp:104-108) */
+ORC_API void orc_pose_expmap(const double* xi, double* T) {
+  const double wx = xi[0], wy = xi[1], wz = xi[2];
+  const double v[3] = {xi[3], xi[4], xi[5]};
+  const double theta2 = wx * wx + wy * wy + wz * wz;
+  double R[9]; /* col-major 3x3 */
+  double W[9] = {0, wz, -wy, -wz, 0, wx, wy, -wx, 0}; /* Hat(w), col-major */
+  double W2[9];
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += M3(W, r, k) * M3(W, k, c);
+      M3(W2, r, c) = s;
+    }
+  double A, B;
+  if (theta2 > 1e-20) {
+    const double theta = sqrt(theta2);
+    A = sin(theta) / theta;
+    B = (1.0 - cos(theta)) / theta2;
+  } else {
+    A = 1.0;
+    B = 0.5;
+  }
+  for (int i = 0; i < 9; i++) R[i] = A * W[i] + B * W2[i];
+  R[0] += 1.0;
+  R[4] += 1.0;
+  R[8] += 1.0;
+  double t[3];
+  if (theta2 > 1e-20) {
+    /* t = (w x v - R (w x v) + w (w.v)) / theta^2 */
+    const double w[3] = {wx, wy, wz};
+    const double wxv[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+    const double wdv = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
+    for (int r = 0; r < 3; r++) {
+      double Rw = 0;
+      for (int k = 0; k < 3; k++) Rw += M3(R, r, k) * wxv[k];
+      t[r] = (wxv[r] - Rw + w[r] * wdv) / theta2;
+    }
+  } else {
+    t[0] = v[0];
+    t[1] = v[1];
+    t[2] = v[2];
+  }
+  memset(T, 0, sizeof(double) * 16);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) M4(T, r, c) = M3(R, r, c);
+    M4(T, r, 3) = t[r];
+  }
+  M4(T, 3, 3) = 1.0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GaussianVoxelMapCPU                                                        */
+/*   src/gtsam_points/types/gaussian_voxelmap_cpu.cpp:23-77                   */
+/*   include/gtsam_points/ann/impl/incremental_voxelmap_impl.hpp:31-68        */
+/* ------------------------------------------------------------------------- */
+
+typedef struct orc_voxelmap {
+  double inv_leaf_size; /* incremental_voxelmap_impl.hpp:14 : 1.0 / leaf_size */
+  double leaf_size;
+  int num_voxels;
+  int cap_voxels;
+  int* coords;         /* [cap][3]  VoxelInfo::coord */
+  int64_t* num_points; /* GaussianVoxel::num_points */
+  uint8_t* finalized;  /* GaussianVoxel::finalized */
+  double* mean;        /* [cap][4]  GaussianVoxel::mean (Vector4d; w accumulates the count) */
+  double* cov;         /* [cap][16] GaussianVoxel::cov  (Matrix4d, col-major) */
+  double* intensity;   /* GaussianVoxel::intensity */
+  /* exact open-addressing hash (stands in for std::unordered_map<Vector3i,size_t,XORVector3iHash>;
+   * the hash function does not affect results) */
+  int hcap; /* power of two */
+  int* hslots;
+} orc_voxelmap;
+
+static inline uint64_t orc_coord_hash(int x, int y, int z) {
+  uint64_t h = (uint64_t)(uint32_t)x * 73856093ull ^ (uint64_t)(uint32_t)y * 19349669ull ^ (uint64_t)(uint32_t)z * 83492791ull;
+  h ^= h >> 29;
+  h *= 0xbf58476d1ce4e5b9ull;
+  h ^= h >> 32;
+  return h;
+}
+
+static int orc_hash_find(const orc_voxelmap* m, int x, int y, int z) {
+  uint64_t h = orc_coord_hash(x, y, z) & (uint64_t)(m->hcap - 1);
+  for (;;) {
+    const int v = m->hslots[h];
+    if (v < 0) return -1;
+    const int* c = m->coords + 3 * (size_t)v;
+    if (c[0] == x && c[1] == y && c[2] == z) return v;
+    h = (h + 1) & (uint64_t)(m->hcap - 1);
+  }
+}
+
+static void orc_hash_put(orc_voxelmap* m, int v) {
+  const int* c = m->coords + 3 * (size_t)v;
+  uint64_t h = orc_coord_hash(c[0], c[1], c[2]) & (uint64_t)(m->hcap - 1);
+  while (m->hslots[h] >= 0) h = (h + 1) & (uint64_t)(m->hcap - 1);
+  m->hslots[h] = v;
+}
+
+static void orc_hash_grow(orc_voxelmap* m) {
+  m->hcap *= 2;
+  free(m->hslots);
+  m->hslots = (int*)malloc(sizeof(int) * (size_t)m->hcap);
+  for (int i = 0; i < m->hcap; i++) m->hslots[i] = -1;
+  for (int v = 0; v < m->num_voxels; v++) orc_hash_put(m, v);
+}
+
+ORC_API orc_voxelmap* orc_voxelmap_create(double resolution) {
+  orc_voxelmap* m = (orc_voxelmap*)calloc(1, sizeof(orc_voxelmap));
+  m->leaf_size = resolution;
+  m->inv_leaf_size = 1.0 / resolution;
+  m->cap_voxels = 1024;
+  m->coords = (int*)malloc(sizeof(int) * 3 * (size_t)m->cap_voxels);
+  m->num_points = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap_voxels);
+  m->finalized = (uint8_t*)malloc((size_t)m->cap_voxels);
+  m->mean = (double*)malloc(sizeof(double) * 4 * (size_t)m->cap_voxels);
+  m->cov = (double*)malloc(sizeof(double) * 16 * (size_t)m->cap_voxels);
+  m->intensity = (double*)malloc(sizeof(double) * (size_t)m->cap_voxels);
+  m->hcap = 4096;
+  m->hslots = (int*)malloc(sizeof(int) * (size_t)m->hcap);
+  for (int i = 0; i < m->hcap; i++) m->hslots[i] = -1;
+  return m;
+}
+
+ORC_API void orc_voxelmap_destroy(orc_voxelmap* m) {
+  if (!m) return;
+  free(m->coords);
+  free(m->num_points);
+  free(m->finalized);
+  free(m->mean);
+  free(m->cov);
+  free(m->intensity);
+  free(m->hslots);
+  free(m);
+}
+
+/* GaussianVoxelMapCPU::voxel_coord, gaussian_voxelmap_cpu.cpp:59-61 :
+ * fast_floor(x * inv_leaf_size).head<3>() */
+static inline void orc_voxel_coord(const orc_voxelmap* m, const double* p, int* c) {
+  c[0] = orc_fast_floor(p[0] * m->inv_leaf_size);
+  c[1] = orc_fast_floor(p[1] * m->inv_leaf_size);
+  c[2] = orc_fast_floor(p[2] * m->inv_leaf_size);
+}
+
+/* IncrementalVoxelMap::insert (incremental_voxelmap_impl.hpp:31-68) with
+ * GaussianVoxel::add / finalize (gaussian_voxelmap_cpu.cpp:23-47).  The LRU
+ * eviction branch (:49-62) only fires on every 10th insert() call with the
+ * default lru_clear_cycle=10 and horizon=100; one-shot maps never reach it, and
+ * it is not restated. */
+ORC_API void orc_voxelmap_insert(orc_voxelmap* m, const float* points, const float* covs, const float* intensities, int n) {
+  for (int i = 0; i < n; i++) {
+    const double p[4] = {(double)points[3 * i], (double)points[3 * i + 1], (double)points[3 * i + 2], 1.0};
+    int c[3];
+    orc_voxel_coord(m, p, c);
+    int v = orc_hash_find(m, c[0], c[1], c[2]);
+    if (v < 0) {
+      if (m->num_voxels == m->cap_voxels) {
+        m->cap_voxels *= 2;
+        m->coords = (int*)realloc(m->coords, sizeof(int) * 3 * (size_t)m->cap_voxels);
+        m->num_points = (int64_t*)realloc(m->num_points, sizeof(int64_t) * (size_t)m->cap_voxels);
+        m->finalized = (uint8_t*)realloc(m->finalized, (size_t)m->cap_voxels);
+        m->mean = (double*)realloc(m->mean, sizeof(double) * 4 * (size_t)m->cap_voxels);
+        m->cov = (double*)realloc(m->cov, sizeof(double) * 16 * (size_t)m->cap_voxels);
+        m->intensity = (double*)realloc(m->intensity, sizeof(double) * (size_t)m->cap_voxels);
+      }
+      v = m->num_voxels++;
+      m->coords[3 * v] = c[0];
+      m->coords[3 * v + 1] = c[1];
+      m->coords[3 * v + 2] = c[2];
+      m->num_points[v] = 0;
+      m->finalized[v] = 0;
+      memset(m->mean + 4 * (size_t)v, 0, sizeof(double) * 4);
+      memset(m->cov + 16 * (size_t)v, 0, sizeof(double) * 16);
+      m->intensity[v] = 0.0;
+      if (m->num_voxels * 2 > m->hcap) {
+        orc_hash_grow(m);
+      } else {
+        orc_hash_put(m, v);
+      }
+    }
+    double* mean = m->mean + 4 * (size_t)v;
+    double* cov = m->cov + 16 * (size_t)v;
+    /* GaussianVoxel::add */
+    if (m->finalized[v]) {
+      m->finalized[v] = 0;
+      for (int k = 0; k < 4; k++) mean[k] *= (double)m->num_points[v];
+      for (int k = 0; k < 16; k++) cov[k] *= (double)m->num_points[v];
+    }
+    m->num_points[v]++;
+    for (int k = 0; k < 4; k++) mean[k] += p[k];
+    for (int cc = 0; cc < 3; cc++)
+      for (int r = 0; r < 3; r++) M4(cov, r, cc) += (double)covs[9 * (size_t)i + cc * 3 + r];
+    if (intensities) {
+      const double it = (double)intensities[i];
+      if (it > m->intensity[v]) m->intensity[v] = it;
+    }
+  }
+  /* GaussianVoxel::finalize for every voxel */
+  for (int v = 0; v < m->num_voxels; v++) {
+    if (m->finalized[v]) continue;
+    double* mean = m->mean + 4 * (size_t)v;
+    double* cov = m->cov + 16 * (size_t)v;
+    for (int k = 0; k < 4; k++) mean[k] /= (double)m->num_points[v];
+    for (int k = 0; k < 16; k++) cov[k] /= (double)m->num_points[v];
+    m->finalized[v] = 1;
+  }
+}
+
+ORC_API int orc_voxelmap_num_voxels(const orc_voxelmap* m) { return m->num_voxels; }
+ORC_API double orc_voxelmap_resolution(const orc_voxelmap* m) { return m->leaf_size; }
+
+/* GaussianVoxelMapCPU::lookup_voxel_index(voxel_coord(x)), gaussian_voxelmap_cpu.cpp:59-73 */
+ORC_API int orc_voxelmap_lookup(const orc_voxelmap* m, const double* xyz) {
+  int c[3];
+  orc_voxel_coord(m, xyz, c);
+  return orc_hash_find(m, c[0], c[1], c[2]);
+}
+
+ORC_API int orc_voxelmap_lookup_coord(const orc_voxelmap* m, int x, int y, int z) { return orc_hash_find(m, x, y, z); }
+
+/* flat export in voxel-creation order: coords int[V][3], num_points int[V],
+ * means double[V][3], covs double[V][9] (col-major 3x3), intensities double[V] */
+ORC_API void orc_voxelmap_export(const orc_voxelmap* m, int* coords, int* num_points, double* means, double* covs, double* intensities) {
+  for (int v = 0; v < m->num_voxels; v++) {
+    if (coords) memcpy(coords + 3 * (size_t)v, m->coords + 3 * (size_t)v, sizeof(int) * 3);
+    if (num_points) num_points[v] = (int)m->num_points[v];
+    if (means)
+      for (int k = 0; k < 3; k++) means[3 * (size_t)v + k] = m->mean[4 * (size_t)v + k];
+    if (covs)
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) covs[9 * (size_t)v + c * 3 + r] = M4(m->cov + 16 * (size_t)v, r, c);
+    if (intensities) intensities[v] = m->intensity[v];
+  }
+}
+
+/* overlap(): fraction of source points whose transformed position hits a voxel
+ * (src/gtsam_points/types/gaussian_voxelmap_cpu.cpp overlap(); the count the GPU
+ * overlap_gpu is tested against, src/test/test_voxelmap.cpp:231-239) */
+ORC_API double orc_voxelmap_overlap(const orc_voxelmap* m, const float* points, int n, const double* delta) {
+  long hits = 0;
+#pragma omp parallel for reduction(+ : hits) schedule(static)
+  for (int i = 0; i < n; i++) {
+    const double p[3] = {(double)points[3 * i], (double)points[3 * i + 1], (double)points[3 * i + 2]};
+    double q[3];
+    for (int r = 0; r < 3; r++) q[r] = M4(delta, r, 0) * p[0] + M4(delta, r, 1) * p[1] + M4(delta, r, 2) * p[2] + M4(delta, r, 3);
+    if (orc_voxelmap_lookup(m, q) >= 0) hits++;
+  }
+  return n > 0 ? (double)hits / (double)n : 0.0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* result record                                                              */
+/* ------------------------------------------------------------------------- */
+
+typedef struct orc_linearized6 {
+  int num_inliers; /* IntegratedVGICPFactor::num_inliers(), integrated_vgicp_factor.hpp:78 */
+  int pad_;
+  double error;
+  double H_target[36];
+  double H_source[36];
+  double H_target_source[36];
+  double b_target[6];
+  double b_source[6];
+} orc_linearized6;
+
+/* per-point H/b contribution shared by VGICP and GICP evaluate():
+ *   include/gtsam_points/factors/impl/integrated_vgicp_factor_impl.hpp:205-249
+ *   include/gtsam_points/factors/impl/integrated_gicp_factor_impl.hpp:255-290
+ * All quantities are the reference's 4-vectors / 4x4 / 4x6 matrices. */
+static double orc_point_terms(
+  const double* delta, const double* mean_A /*4*/, const double* mean_B /*4*/, const double* maha /*4x4*/, double* H_target, double* H_source,
+  double* H_target_source, double* b_target, double* b_source) {
+  double transed[4], residual[4];
+  for (int r = 0; r < 4; r++) {
+    double s = 0.0;
+    for (int k = 0; k < 4; k++) s += M4(delta, r, k) * mean_A[k];
+    transed[r] = s;
+  }
+  for (int r = 0; r < 4; r++) residual[r] = mean_B[r] - transed[r];
+
+  double Mr[4];
+  for (int r = 0; r < 4; r++) {
+    double s = 0.0;
+    for (int k = 0; k < 4; k++) s += M4(maha, r, k) * residual[k];
+    Mr[r] = s;
+  }
+  double error = 0.0;
+  for (int r = 0; r < 4; r++) error += residual[r] * Mr[r];
+  if (!H_target) return error;
+
+  /* J_target (4x6): block(0,0) = -Hat(transed.head3), block(0,3) = I  (:232-234) */
+  double Jt[24] = {0}, Js[24] = {0};
+#define J46(j, r, c) ((j)[(c) * 4 + (r)])
+  const double x = transed[0], y = transed[1], z = transed[2];
+  /* Hat(v) = [0 -z y; z 0 -x; -y x 0] */
+  J46(Jt, 0, 1) = z;
+  J46(Jt, 0, 2) = -y;
+  J46(Jt, 1, 0) = -z;
+  J46(Jt, 1, 2) = x;
+  J46(Jt, 2, 0) = y;
+  J46(Jt, 2, 1) = -x;
+  J46(Jt, 0, 3) = 1.0;
+  J46(Jt, 1, 4) = 1.0;
+  J46(Jt, 2, 5) = 1.0;
+  /* J_source (4x6): block(0,0) = R * Hat(mean_A.head3), block(0,3) = -R  (:236-238) */
+  const double ax = mean_A[0], ay = mean_A[1], az = mean_A[2];
+  const double hatA[9] = {0, az, -ay, -az, 0, ax, ay, -ax, 0}; /* col-major */
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += M4(delta, r, k) * M3(hatA, k, c);
+      J46(Js, r, c) = s;
+      J46(Js, r, c + 3) = -M4(delta, r, c);
+    }
+
+  /* J^T * mahalanobis (6x4) */
+  double JtM[24], JsM[24];
+#define J64(j, r, c) ((j)[(c) * 6 + (r)])
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 4; c++) {
+      double s = 0.0, u = 0.0;
+      for (int k = 0; k < 4; k++) {
+        s += J46(Jt, k, r) * M4(maha, k, c);
+        u += J46(Js, k, r) * M4(maha, k, c);
+      }
+      J64(JtM, r, c) = s;
+      J64(JsM, r, c) = u;
+    }
+  for (int r = 0; r < 6; r++) {
+    for (int c = 0; c < 6; c++) {
+      double ht = 0.0, hs = 0.0, hts = 0.0;
+      for (int k = 0; k < 4; k++) {
+        ht += J64(JtM, r, k) * J46(Jt, k, c);
+        hs += J64(JsM, r, k) * J46(Js, k, c);
+        hts += J64(JtM, r, k) * J46(Js, k, c);
+      }
+      M6(H_target, r, c) += ht;
+      M6(H_source, r, c) += hs;
+      M6(H_target_source, r, c) += hts;
+    }
+    double bt = 0.0, bs = 0.0;
+    for (int k = 0; k < 4; k++) {
+      bt += J64(JtM, r, k) * residual[k];
+      bs += J64(JsM, r, k) * residual[k];
+    }
+    b_target[r] += bt;
+    b_source[r] += bs;
+  }
+  return error;
+}
+
+/* fused covariance inverse, FULL cache mode:
+ *   RCR = cov_B + delta.matrix() * cov_A * delta.matrix().transpose()   (4x4)
+ *   mahalanobis = 0; mahalanobis.topLeftCorner<3,3>() = RCR.topLeftCorner<3,3>().inverse()
+ * integrated_vgicp_factor_impl.hpp:138-140 ; integrated_gicp_factor_impl.hpp:197-200 */
+static void orc_fused_mahalanobis(const double* delta, const double* cov_A /*4x4*/, const double* cov_B /*4x4*/, double* maha /*4x4*/) {
+  double DC[16], RCR[16];
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += M4(delta, r, k) * M4(cov_A, k, c);
+      M4(DC, r, c) = s;
+    }
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += M4(DC, r, k) * M4(delta, c, k);
+      M4(RCR, r, c) = M4(cov_B, r, c) + s;
+    }
+  double a[9], inv[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) M3(a, r, c) = M4(RCR, r, c);
+  orc_inverse3(a, inv);
+  memset(maha, 0, sizeof(double) * 16);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) M4(maha, r, c) = M3(inv, r, c);
+}
+
+static inline void orc_load_point(const float* points, const float* covs, int i, double* mean_A, double* cov_A) {
+  mean_A[0] = (double)points[3 * (size_t)i];
+  mean_A[1] = (double)points[3 * (size_t)i + 1];
+  mean_A[2] = (double)points[3 * (size_t)i + 2];
+  mean_A[3] = 1.0;
+  if (cov_A) {
+    memset(cov_A, 0, sizeof(double) * 16);
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) M4(cov_A, r, c) = (double)covs[9 * (size_t)i + c * 3 + r];
+  }
+}
+
+/* scan_matching_reduce_omp, include/gtsam_points/factors/impl/scan_matching_reduction.hpp:16-68.
+ * per-thread accumulators indexed by omp_get_thread_num(), summed serially 0..T-1. */
+typedef struct orc_accum {
+  double H_target[36], H_source[36], H_target_source[36], b_target[6], b_source[6];
+} orc_accum;
+
+/* ------------------------------------------------------------------------- */
+/* IntegratedVGICPFactor (CPU)                                                */
+/* ------------------------------------------------------------------------- */
+
+typedef struct orc_vgicp_factor {
+  const orc_voxelmap* target;
+  const float* points; /* borrowed */
+  const float* covs;   /* borrowed */
+  int n;
+  int num_threads;          /* integrated_vgicp_factor_impl.hpp:27 (default 1) */
+  int has_correspondences;  /* correspondences.size() == frame::size(source) */
+  double linearization_point[16];
+  int* correspondences;     /* voxel index or -1 (reference stores GaussianVoxel*) */
+  double* mahalanobis_full; /* [n][16], FusedCovCacheMode::FULL (default, :28) */
+} orc_vgicp_factor;
+
+ORC_API orc_vgicp_factor* orc_vgicp_create(const orc_voxelmap* target, const float* points, const float* covs, int n, int num_threads) {
+  orc_vgicp_factor* f = (orc_vgicp_factor*)calloc(1, sizeof(orc_vgicp_factor));
+  f->target = target;
+  f->points = points;
+  f->covs = covs;
+  f->n = n;
+  f->num_threads = num_threads > 0 ? num_threads : 1;
+  f->correspondences = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  f->mahalanobis_full = (double*)malloc(sizeof(double) * 16 * (size_t)(n > 0 ? n : 1));
+  return f;
+}
+
+ORC_API void orc_vgicp_destroy(orc_vgicp_factor* f) {
+  if (!f) return;
+  free(f->correspondences);
+  free(f->mahalanobis_full);
+  free(f);
+}
+
+/* IntegratedVGICPFactor_::update_correspondences, integrated_vgicp_factor_impl.hpp:99-172 */
+ORC_API void orc_vgicp_update_correspondences(orc_vgicp_factor* f, const double* delta) {
+  memcpy(f->linearization_point, delta, sizeof(double) * 16);
+  f->has_correspondences = 1;
+  const orc_voxelmap* m = f->target;
+#pragma omp parallel for num_threads(f->num_threads) schedule(guided, 8)
+  for (int i = 0; i < f->n; i++) {
+    double mean_A[4], cov_A[16], pt[4];
+    orc_load_point(f->points, f->covs, i, mean_A, cov_A);
+    for (int r = 0; r < 4; r++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += M4(delta, r, k) * mean_A[k];
+      pt[r] = s;
+    }
+    const int voxel_id = orc_voxelmap_lookup(m, pt);
+    double* maha = f->mahalanobis_full + 16 * (size_t)i;
+    if (voxel_id < 0) {
+      f->correspondences[i] = -1;
+      memset(maha, 0, sizeof(double) * 16);
+    } else {
+      f->correspondences[i] = voxel_id;
+      orc_fused_mahalanobis(delta, cov_A, m->cov + 16 * (size_t)voxel_id, maha);
+    }
+  }
+}
+
+/* IntegratedVGICPFactor_::evaluate, integrated_vgicp_factor_impl.hpp:175-257, reduced by
+ * scan_matching_reduce_omp.  out == NULL -> error only. */
+ORC_API double orc_vgicp_evaluate(orc_vgicp_factor* f, const double* delta, orc_linearized6* out) {
+  if (!f->has_correspondences) orc_vgicp_update_correspondences(f, delta); /* :183-185 */
+  const int T = f->num_threads;
+  orc_accum* acc = out ? (orc_accum*)calloc((size_t)T, sizeof(orc_accum)) : NULL;
+  double sum_errors = 0.0;
+  const orc_voxelmap* m = f->target;
+#pragma omp parallel for num_threads(T) schedule(guided, 8) reduction(+ : sum_errors)
+  for (int i = 0; i < f->n; i++) {
+    int thread_num = 0;
+#ifdef _OPENMP
+    thread_num = omp_get_thread_num();
+#endif
+    const int v = f->correspondences[i];
+    if (v < 0) continue; /* returns 0.0 */
+    double mean_A[4];
+    orc_load_point(f->points, f->covs, i, mean_A, NULL);
+    const double* mean_B = m->mean + 4 * (size_t)v;
+    const double* maha = f->mahalanobis_full + 16 * (size_t)i;
+    if (acc) {
+      orc_accum* a = acc + thread_num;
+      sum_errors += orc_point_terms(delta, mean_A, mean_B, maha, a->H_target, a->H_source, a->H_target_source, a->b_target, a->b_source);
+    } else {
+      sum_errors += orc_point_terms(delta, mean_A, mean_B, maha, NULL, NULL, NULL, NULL, NULL);
+    }
+  }
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    for (int t = 0; t < T; t++) {
+      for (int k = 0; k < 36; k++) {
+        out->H_target[k] += acc[t].H_target[k];
+        out->H_source[k] += acc[t].H_source[k];
+        out->H_target_source[k] += acc[t].H_target_source[k];
+      }
+      for (int k = 0; k < 6; k++) {
+        out->b_target[k] += acc[t].b_target[k];
+        out->b_source[k] += acc[t].b_source[k];
+      }
+    }
+    out->error = sum_errors;
+    int inl = 0;
+    for (int i = 0; i < f->n; i++) inl += (f->correspondences[i] >= 0);
+    out->num_inliers = inl;
+    free(acc);
+  }
+  return sum_errors;
+}
+
+/* IntegratedMatchingCostFactor::linearize, integrated_matching_cost_factor.cpp:37-55 :
+ * update_correspondences(delta) then evaluate(delta, H...).  The HessianFactor sign
+ * convention (H_t, H_ts, -b_t, H_s, -b_s, err) is applied by the caller. */
+ORC_API void orc_vgicp_linearize(orc_vgicp_factor* f, const double* delta, orc_linearized6* out) {
+  orc_vgicp_update_correspondences(f, delta);
+  orc_vgicp_evaluate(f, delta, out);
+}
+
+/* IntegratedMatchingCostFactor::error, integrated_matching_cost_factor.cpp:32-35 :
+ * evaluate(delta) with the correspondences and Mahalanobis matrices frozen at the
+ * last linearization point. */
+ORC_API double orc_vgicp_error(orc_vgicp_factor* f, const double* delta) { return orc_vgicp_evaluate(f, delta, NULL); }
+
+ORC_API int orc_vgicp_num_inliers(const orc_vgicp_factor* f) {
+  int inl = 0;
+  for (int i = 0; i < f->n; i++) inl += (f->correspondences[i] >= 0);
+  return inl;
+}
+
+ORC_API const int* orc_vgicp_correspondences(const orc_vgicp_factor* f) { return f->correspondences; }
+
+/* ------------------------------------------------------------------------- */
+/* KdTree (include/gtsam_points/ann/small_kdtree.hpp:124-186 build,           */
+/*         :437-474 knn_search; KnnResult::push knn_result.hpp:89-109)        */
+/* ------------------------------------------------------------------------- */
+
+typedef struct orc_kdnode {
+  /* leaf: first/last ; non-leaf: axis/thresh */
+  uint32_t first, last;
+  int axis;
+  double thresh;
+  uint32_t left, right;
+} orc_kdnode;
+
+#define ORC_INVALID_NODE 0xffffffffu
+
+typedef struct orc_kdtree {
+  const double* points; /* [n][4] double, owned */
+  double* points_owned;
+  int n;
+  uint32_t* indices;
+  orc_kdnode* nodes;
+  uint32_t node_count;
+  uint32_t root;
+} orc_kdtree;
+
+/* AxisAlignedProjection::find_axis, small_kdtree.hpp:64-87 */
+static int orc_find_axis(const double* pts, const uint32_t* first, size_t N) {
+  const size_t max_scan_count = 128;
+  double sum_pt[4] = {0, 0, 0, 0}, sum_sq[4] = {0, 0, 0, 0};
+  const size_t step = N < max_scan_count ? 1 : N / max_scan_count;
+  const size_t num_steps = N / step;
+  for (size_t i = 0; i < num_steps; i++) {
+    const double* p = pts + 4 * (size_t)first[step * i];
+    for (int k = 0; k < 4; k++) {
+      sum_pt[k] += p[k];
+      sum_sq[k] += p[k] * p[k];
+    }
+  }
+  double var[3];
+  for (int k = 0; k < 3; k++) {
+    const double mean = sum_pt[k] / sum_pt[3];
+    var[k] = sum_sq[k] - mean * sum_pt[k];
+  }
+  return var[0] > var[1] ? (var[0] > var[2] ? 0 : 2) : (var[1] > var[2] ? 1 : 2);
+}
+
+/* std::nth_element stand-in (quickselect, median-of-three).  The arrangement inside
+ * each half is implementation-defined in the reference too. */
+static void orc_nth_element(uint32_t* a, size_t n, size_t nth, const double* pts, int axis) {
+  long lo = 0, hi = (long)n - 1; /* inclusive range */
+  while (lo < hi) {
+    const long mid = lo + (hi - lo) / 2;
+    const double x = pts[4 * (size_t)a[lo] + axis], y = pts[4 * (size_t)a[mid] + axis], z = pts[4 * (size_t)a[hi] + axis];
+    const double pivot = (x < y) ? ((y < z) ? y : (x < z ? z : x)) : ((x < z) ? x : (y < z ? z : y));
+    long i = lo, j = hi;
+    while (i <= j) {
+      while (pts[4 * (size_t)a[i] + axis] < pivot) i++;
+      while (pts[4 * (size_t)a[j] + axis] > pivot) j--;
+      if (i <= j) {
+        const uint32_t t = a[i];
+        a[i] = a[j];
+        a[j] = t;
+        i++;
+        j--;
+      }
+    }
+    /* [lo..j] <= pivot, [i..hi] >= pivot, (j, i) == pivot */
+    if ((long)nth <= j) {
+      hi = j;
+    } else if ((long)nth >= i) {
+      lo = i;
+    } else {
+      return;
+    }
+  }
+}
+
+static uint32_t orc_kd_create_node(orc_kdtree* t, uint32_t* first, uint32_t* last) {
+  const size_t N = (size_t)(last - first);
+  const uint32_t node_index = t->node_count++;
+  orc_kdnode* node = &t->nodes[node_index];
+  node->left = node->right = ORC_INVALID_NODE;
+  if (N <= 20) { /* max_leaf_size = 20, small_kdtree.hpp:185 */
+    node->first = (uint32_t)(first - t->indices);
+    node->last = (uint32_t)(last - t->indices);
+    return node_index;
+  }
+  const int axis = orc_find_axis(t->points, first, N);
+  uint32_t* median = first + N / 2;
+  orc_nth_element(first, N, N / 2, t->points, axis);
+  t->nodes[node_index].axis = axis;
+  t->nodes[node_index].thresh = t->points[4 * (size_t)*median + axis];
+  const uint32_t l = orc_kd_create_node(t, first, median);
+  const uint32_t r = orc_kd_create_node(t, median, last);
+  t->nodes[node_index].left = l;
+  t->nodes[node_index].right = r;
+  return node_index;
+}
+
+ORC_API orc_kdtree* orc_kdtree_create(const float* points, int n) {
+  orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(orc_kdtree));
+  t->n = n;
+  t->points_owned = (double*)malloc(sizeof(double) * 4 * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) {
+    t->points_owned[4 * (size_t)i] = (double)points[3 * (size_t)i];
+    t->points_owned[4 * (size_t)i + 1] = (double)points[3 * (size_t)i + 1];
+    t->points_owned[4 * (size_t)i + 2] = (double)points[3 * (size_t)i + 2];
+    t->points_owned[4 * (size_t)i + 3] = 1.0;
+  }
+  t->points = t->points_owned;
+  t->indices = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) t->indices[i] = (uint32_t)i;
+  t->nodes = (orc_kdnode*)malloc(sizeof(orc_kdnode) * (size_t)(n > 0 ? n : 1));
+  t->node_count = 0;
+  t->root = n > 0 ? orc_kd_create_node(t, t->indices, t->indices + n) : ORC_INVALID_NODE;
+  return t;
+}
+
+ORC_API void orc_kdtree_destroy(orc_kdtree* t) {
+  if (!t) return;
+  free(t->points_owned);
+  free(t->indices);
+  free(t->nodes);
+  free(t);
+}
+
+typedef struct orc_knn_result {
+  int capacity;
+  int num_found;
+  int64_t* indices;
+  double* distances;
+} orc_knn_result;
+
+/* KnnResult::push, knn_result.hpp:89-109 (strict '<' : earlier-visited ties win) */
+static inline void orc_knn_push(orc_knn_result* r, int64_t index, double distance) {
+  if (distance >= r->distances[r->capacity - 1]) return;
+  int insert_loc = r->num_found < r->capacity - 1 ? r->num_found : r->capacity - 1;
+  for (; insert_loc > 0 && distance < r->distances[insert_loc - 1]; insert_loc--) {
+    r->indices[insert_loc] = r->indices[insert_loc - 1];
+    r->distances[insert_loc] = r->distances[insert_loc - 1];
+  }
+  r->indices[insert_loc] = index;
+  r->distances[insert_loc] = distance;
+  r->num_found = r->num_found + 1 < r->capacity ? r->num_found + 1 : r->capacity;
+}
+
+/* UnsafeKdTree::knn_search (recursive), small_kdtree.hpp:437-474 (KnnSetting epsilon = 0) */
+static void orc_kd_search(const orc_kdtree* t, const double* query, uint32_t node_index, orc_knn_result* result) {
+  const orc_kdnode* node = &t->nodes[node_index];
+  if (node->left == ORC_INVALID_NODE) {
+    for (uint32_t i = node->first; i < node->last; i++) {
+      const double* p = t->points + 4 * (size_t)t->indices[i];
+      const double dx = p[0] - query[0], dy = p[1] - query[1], dz = p[2] - query[2], dw = p[3] - query[3];
+      orc_knn_push(result, (int64_t)t->indices[i], dx * dx + dy * dy + dz * dz + dw * dw);
+    }
+    return;
+  }
+  const double diff = query[node->axis] - node->thresh;
+  const double cut_sq_dist = diff * diff;
+  const uint32_t best = diff < 0.0 ? node->left : node->right;
+  const uint32_t other = diff < 0.0 ? node->right : node->left;
+  orc_kd_search(t, query, best, result);
+  if (result->distances[result->capacity - 1] > cut_sq_dist) orc_kd_search(t, query, other, result);
+}
+
+/* knn_search(query, k, k_indices, k_sq_dists) -> num_found; buffers pre-filled with
+ * INVALID / max_sq_dist like KnnResult's ctor (knn_result.hpp:66-67) */
+ORC_API int orc_kdtree_knn(const orc_kdtree* t, const double* query3, int k, int64_t* k_indices, double* k_sq_dists, double max_sq_dist) {
+  orc_knn_result r = {k, 0, k_indices, k_sq_dists};
+  for (int i = 0; i < k; i++) {
+    k_indices[i] = -1;
+    k_sq_dists[i] = max_sq_dist;
+  }
+  if (t->n == 0) return 0;
+  const double q[4] = {query3[0], query3[1], query3[2], 1.0};
+  orc_kd_search(t, q, t->root, &r);
+  return r.num_found;
+}
+
+/* batch kNN over float queries (OpenMP), for tests and the C5 baseline */
+ORC_API void orc_kdtree_knn_batch(const orc_kdtree* t, const float* queries, int nq, int k, int64_t* indices, double* sq_dists, double max_sq_dist, int num_threads) {
+#pragma omp parallel for num_threads(num_threads > 0 ? num_threads : 1) schedule(guided, 8)
+  for (int i = 0; i < nq; i++) {
+    const double q[3] = {(double)queries[3 * (size_t)i], (double)queries[3 * (size_t)i + 1], (double)queries[3 * (size_t)i + 2]};
+    orc_kdtree_knn(t, q, k, indices + (size_t)k * (size_t)i, sq_dists + (size_t)k * (size_t)i, max_sq_dist);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Eigen 3.4.0 SelfAdjointEigenSolver<Matrix3d>::computeDirect                */
+/* (Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h, direct_selfadjoint_eigenvalues<.,3,false>; */
+/*  call site src/gtsam_points/features/covariance_estimation.cpp:49-53).     */
+/* Restated from the published closed-form algorithm.                          */
+/* ------------------------------------------------------------------------- */
+
+static void orc_eig3_roots(const double* m /*sym 3x3 col-major*/, double* roots) {
+  const double s_inv3 = 1.0 / 3.0;
+  const double s_sqrt3 = sqrt(3.0);
+  const double c0 = M3(m, 0, 0) * M3(m, 1, 1) * M3(m, 2, 2) + 2.0 * M3(m, 1, 0) * M3(m, 2, 0) * M3(m, 2, 1) - M3(m, 0, 0) * M3(m, 2, 1) * M3(m, 2, 1) -
+                    M3(m, 1, 1) * M3(m, 2, 0) * M3(m, 2, 0) - M3(m, 2, 2) * M3(m, 1, 0) * M3(m, 1, 0);
+  const double c1 = M3(m, 0, 0) * M3(m, 1, 1) - M3(m, 1, 0) * M3(m, 1, 0) + M3(m, 0, 0) * M3(m, 2, 2) - M3(m, 2, 0) * M3(m, 2, 0) + M3(m, 1, 1) * M3(m, 2, 2) -
+                    M3(m, 2, 1) * M3(m, 2, 1);
+  const double c2 = M3(m, 0, 0) + M3(m, 1, 1) + M3(m, 2, 2);
+  const double c2_over_3 = c2 * s_inv3;
+  double a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+  if (a_over_3 < 0.0) a_over_3 = 0.0;
+  const double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+  double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  if (q < 0.0) q = 0.0;
+  const double rho = sqrt(a_over_3);
+  const double theta = atan2(sqrt(q), half_b) * s_inv3;
+  const double cos_theta = cos(theta);
+  const double sin_theta = sin(theta);
+  roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 + 2.0 * rho * cos_theta;
+}
+
+static int orc_eig3_extract_kernel(double* mat /*3x3, modified*/, double* res, double* representative) {
+  /* find the diagonal entry with largest magnitude */
+  int i0 = 0;
+  double best = fabs(M3(mat, 0, 0));
+  for (int i = 1; i < 3; i++)
+    if (fabs(M3(mat, i, i)) > best) {
+      best = fabs(M3(mat, i, i));
+      i0 = i;
+    }
+  for (int r = 0; r < 3; r++) representative[r] = M3(mat, r, i0);
+  const int i1 = (i0 + 1) % 3, i2 = (i0 + 2) % 3;
+  double c0[3], c1[3];
+  /* c0 = rep x col(i1), c1 = rep x col(i2) */
+  const double* a = representative;
+  const double b1[3] = {M3(mat, 0, i1), M3(mat, 1, i1), M3(mat, 2, i1)};
+  const double b2[3] = {M3(mat, 0, i2), M3(mat, 1, i2), M3(mat, 2, i2)};
+  c0[0] = a[1] * b1[2] - a[2] * b1[1];
+  c0[1] = a[2] * b1[0] - a[0] * b1[2];
+  c0[2] = a[0] * b1[1] - a[1] * b1[0];
+  c1[0] = a[1] * b2[2] - a[2] * b2[1];
+  c1[1] = a[2] * b2[0] - a[0] * b2[2];
+  c1[2] = a[0] * b2[1] - a[1] * b2[0];
+  const double n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+  const double n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+  if (n0 > n1) {
+    const double s = 1.0 / sqrt(n0);
+    for (int r = 0; r < 3; r++) res[r] = c0[r] * s;
+  } else {
+    const double s = 1.0 / sqrt(n1);
+    for (int r = 0; r < 3; r++) res[r] = c1[r] * s;
+  }
+  return 1;
+}
+
+/* eigenvalues ascending in evals, eigenvectors as columns of evecs (col-major) */
+ORC_API void orc_eig3_direct(const double* mat, double* evals, double* evecs) {
+  const double eps = 2.220446049250313e-16;
+  const double shift = (M3(mat, 0, 0) + M3(mat, 1, 1) + M3(mat, 2, 2)) / 3.0;
+  double scaled[9];
+  memcpy(scaled, mat, sizeof(scaled));
+  /* only the lower triangle is referenced by Eigen; symmetrise from lower */
+  M3(scaled, 0, 1) = M3(scaled, 1, 0);
+  M3(scaled, 0, 2) = M3(scaled, 2, 0);
+  M3(scaled, 1, 2) = M3(scaled, 2, 1);
+  M3(scaled, 0, 0) -= shift;
+  M3(scaled, 1, 1) -= shift;
+  M3(scaled, 2, 2) -= shift;
+  double scale = 0.0;
+  for (int i = 0; i < 9; i++)
+    if (fabs(scaled[i]) > scale) scale = fabs(scaled[i]);
+  if (scale > 0.0)
+    for (int i = 0; i < 9; i++) scaled[i] /= scale;
+  orc_eig3_roots(scaled, evals);
+  if ((evals[2] - evals[0]) <= eps) {
+    memset(evecs, 0, sizeof(double) * 9);
+    evecs[0] = evecs[4] = evecs[8] = 1.0;
+  } else {
+    double tmp[9];
+    memcpy(tmp, scaled, sizeof(tmp));
+    double d0 = evals[2] - evals[1];
+    double d1 = evals[1] - evals[0];
+    int k = 0, l = 2;
+    if (d0 > d1) {
+      const int t = k;
+      k = l;
+      l = t;
+      d0 = d1;
+    }
+    double* colk = evecs + 3 * k;
+    double* coll = evecs + 3 * l;
+    tmp[0] -= evals[k];
+    tmp[4] -= evals[k];
+    tmp[8] -= evals[k];
+    orc_eig3_extract_kernel(tmp, colk, coll);
+    if (d0 <= 2.0 * eps * d1) {
+      /* col(l) -= col(k).dot(col(l)) * col(l); normalize */
+      const double dot = colk[0] * coll[0] + colk[1] * coll[1] + colk[2] * coll[2];
+      for (int r = 0; r < 3; r++) coll[r] -= dot * coll[r];
+      const double nn = sqrt(coll[0] * coll[0] + coll[1] * coll[1] + coll[2] * coll[2]);
+      for (int r = 0; r < 3; r++) coll[r] /= nn;
+    } else {
+      double dummy[3];
+      memcpy(tmp, scaled, sizeof(tmp));
+      tmp[0] -= evals[l];
+      tmp[4] -= evals[l];
+      tmp[8] -= evals[l];
+      orc_eig3_extract_kernel(tmp, coll, dummy);
+    }
+    /* col(1) = col(2).cross(col(0)).normalized() */
+    const double* c2 = evecs + 6;
+    const double* c0 = evecs;
+    double c1[3] = {c2[1] * c0[2] - c2[2] * c0[1], c2[2] * c0[0] - c2[0] * c0[2], c2[0] * c0[1] - c2[1] * c0[0]};
+    const double nn = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+    for (int r = 0; r < 3; r++) evecs[3 + r] = c1[r] / nn;
+  }
+  for (int i = 0; i < 3; i++) evals[i] = evals[i] * scale + shift;
+}
+
+/* estimate_covariances(points, n, k, threads), src/gtsam_points/features/covariance_estimation.cpp:18-77
+ * with CovarianceEstimationParams defaults: EIG regularisation, eigen_values (1e-3, 1, 1).
+ * Output: double[n][9] column-major 3x3 (the 4x4's top-left block). Returns #points with < k neighbours. */
+ORC_API int orc_estimate_covariances(const float* points, int n, int k, int num_threads, double* covs_out) {
+  orc_kdtree* tree = orc_kdtree_create(points, n);
+  int num_short = 0;
+#pragma omp parallel for num_threads(num_threads > 0 ? num_threads : 1) schedule(guided, 8) reduction(+ : num_short)
+  for (int i = 0; i < n; i++) {
+    int64_t k_indices[64];
+    double k_sq_dists[64];
+    const double q[3] = {(double)points[3 * (size_t)i], (double)points[3 * (size_t)i + 1], (double)points[3 * (size_t)i + 2]};
+    const int num_found = orc_kdtree_knn(tree, q, k, k_indices, k_sq_dists, 1.7976931348623157e308);
+    double* out = covs_out + 9 * (size_t)i;
+    if (num_found < k) { /* :27-31 identity */
+      num_short++;
+      memset(out, 0, sizeof(double) * 9);
+      out[0] = out[4] = out[8] = 1.0;
+      continue;
+    }
+    double sum_points[4] = {0, 0, 0, 0}, sum_covs[16] = {0};
+    for (int j = 0; j < num_found; j++) {
+      const double* pt = tree->points + 4 * (size_t)k_indices[j];
+      for (int r = 0; r < 4; r++) sum_points[r] += pt[r];
+      for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) M4(sum_covs, r, c) += pt[r] * pt[c];
+    }
+    double mean[4], cov3[9];
+    for (int r = 0; r < 4; r++) mean[r] = sum_points[r] / (double)num_found;
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) M3(cov3, r, c) = (M4(sum_covs, r, c) - mean[r] * sum_points[c]) / (double)num_found; /* :43 */
+    double evals[3], V[9], Vinv[9];
+    orc_eig3_direct(cov3, evals, V);
+    orc_inverse3(V, Vinv);
+    const double lam[3] = {1e-3, 1.0, 1.0};
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) {
+        double s = 0.0;
+        for (int kk = 0; kk < 3; kk++) s += M3(V, r, kk) * lam[kk] * M3(Vinv, kk, c);
+        M3(out, r, c) = s;
+      }
+  }
+  orc_kdtree_destroy(tree);
+  return num_short;
+}
+
+/* ------------------------------------------------------------------------- */
+/* IntegratedGICPFactor (CPU), include/gtsam_points/factors/impl/integrated_gicp_factor_impl.hpp:132-296 */
+/* ------------------------------------------------------------------------- */
+
+typedef struct orc_gicp_factor {
+  const float* target_points;
+  const float* target_covs;
+  int n_target;
+  const float* points;
+  const float* covs;
+  int n;
+  int num_threads;
+  double max_correspondence_distance_sq; /* :30 default 1.0 */
+  orc_kdtree* target_tree;
+  int has_correspondences;
+  int64_t* correspondences;
+  double* mahalanobis_full;
+} orc_gicp_factor;
+
+ORC_API orc_gicp_factor* orc_gicp_create(const float* target_points, const float* target_covs, int n_target, const float* points, const float* covs, int n, int num_threads, double max_corr_dist_sq) {
+  orc_gicp_factor* f = (orc_gicp_factor*)calloc(1, sizeof(orc_gicp_factor));
+  f->target_points = target_points;
+  f->target_covs = target_covs;
+  f->n_target = n_target;
+  f->points = points;
+  f->covs = covs;
+  f->n = n;
+  f->num_threads = num_threads > 0 ? num_threads : 1;
+  f->max_correspondence_distance_sq = max_corr_dist_sq;
+  f->target_tree = orc_kdtree_create(target_points, n_target);
+  f->correspondences = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+  f->mahalanobis_full = (double*)malloc(sizeof(double) * 16 * (size_t)(n > 0 ? n : 1));
+  return f;
+}
+
+ORC_API void orc_gicp_destroy(orc_gicp_factor* f) {
+  if (!f) return;
+  orc_kdtree_destroy(f->target_tree);
+  free(f->correspondences);
+  free(f->mahalanobis_full);
+  free(f);
+}
+
+/* IntegratedGICPFactor_::update_correspondences, integrated_gicp_factor_impl.hpp:132-215
+ * (correspondence_update_tolerance = 0 : always refreshed) */
+ORC_API void orc_gicp_update_correspondences(orc_gicp_factor* f, const double* delta) {
+  f->has_correspondences = 1;
+#pragma omp parallel for num_threads(f->num_threads) schedule(guided, 8)
+  for (int i = 0; i < f->n; i++) {
+    double mean_A[4], cov_A[16], pt[4];
+    orc_load_point(f->points, f->covs, i, mean_A, cov_A);
+    for (int r = 0; r < 4; r++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += M4(delta, r, k) * mean_A[k];
+      pt[r] = s;
+    }
+    int64_t k_index = -1;
+    double k_sq_dist = -1.0;
+    const int num_found = orc_kdtree_knn(f->target_tree, pt, 1, &k_index, &k_sq_dist, f->max_correspondence_distance_sq);
+    double* maha = f->mahalanobis_full + 16 * (size_t)i;
+    if (num_found == 0 || !(k_sq_dist < f->max_correspondence_distance_sq)) { /* :170 */
+      f->correspondences[i] = -1;
+      memset(maha, 0, sizeof(double) * 16);
+    } else {
+      f->correspondences[i] = k_index;
+      double cov_B[16];
+      memset(cov_B, 0, sizeof(cov_B));
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) M4(cov_B, r, c) = (double)f->target_covs[9 * (size_t)k_index + c * 3 + r];
+      orc_fused_mahalanobis(delta, cov_A, cov_B, maha);
+    }
+  }
+}
+
+/* IntegratedGICPFactor_::evaluate, integrated_gicp_factor_impl.hpp:218-296 */
+ORC_API double orc_gicp_evaluate(orc_gicp_factor* f, const double* delta, orc_linearized6* out) {
+  if (!f->has_correspondences) orc_gicp_update_correspondences(f, delta);
+  const int T = f->num_threads;
+  orc_accum* acc = out ? (orc_accum*)calloc((size_t)T, sizeof(orc_accum)) : NULL;
+  double sum_errors = 0.0;
+#pragma omp parallel for num_threads(T) schedule(guided, 8) reduction(+ : sum_errors)
+  for (int i = 0; i < f->n; i++) {
+    int thread_num = 0;
+#ifdef _OPENMP
+    thread_num = omp_get_thread_num();
+#endif
+    const int64_t j = f->correspondences[i];
+    if (j < 0) continue;
+    double mean_A[4];
+    orc_load_point(f->points, f->covs, i, mean_A, NULL);
+    const double mean_B[4] = {(double)f->target_points[3 * (size_t)j], (double)f->target_points[3 * (size_t)j + 1], (double)f->target_points[3 * (size_t)j + 2], 1.0};
+    const double* maha = f->mahalanobis_full + 16 * (size_t)i;
+    if (acc) {
+      orc_accum* a = acc + thread_num;
+      sum_errors += orc_point_terms(delta, mean_A, mean_B, maha, a->H_target, a->H_source, a->H_target_source, a->b_target, a->b_source);
+    } else {
+      sum_errors += orc_point_terms(delta, mean_A, mean_B, maha, NULL, NULL, NULL, NULL, NULL);
+    }
+  }
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    for (int t = 0; t < T; t++) {
+      for (int k = 0; k < 36; k++) {
+        out->H_target[k] += acc[t].H_target[k];
+        out->H_source[k] += acc[t].H_source[k];
+        out->H_target_source[k] += acc[t].H_target_source[k];
+      }
+      for (int k = 0; k < 6; k++) {
+        out->b_target[k] += acc[t].b_target[k];
+        out->b_source[k] += acc[t].b_source[k];
+      }
+    }
+    out->error = sum_errors;
+    int inl = 0;
+    for (int i = 0; i < f->n; i++) inl += (f->correspondences[i] >= 0);
+    out->num_inliers = inl;
+    free(acc);
+  }
+  return sum_errors;
+}
+
+ORC_API void orc_gicp_linearize(orc_gicp_factor* f, const double* delta, orc_linearized6* out) {
+  orc_gicp_update_correspondences(f, delta);
+  orc_gicp_evaluate(f, delta, out);
+}
+
+ORC_API const int64_t* orc_gicp_correspondences(const orc_gicp_factor* f) { return f->correspondences; }
+
+ORC_API int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
