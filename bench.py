@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- VGICP linearise throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE.json configs[1] -- ONE VGICP factor per GPU, 1 M synthetic source points vs a
+2 M-point GaussianVoxelMap at 0.5 m (gtsam_points_amd.synthetic.make_c2_workload; rank r uses seed 42 + r).
+A "step" is one linearize() pass as the optimizer sees it: pose upload (128 B) -> tiled HIP kernel -> finalize kernel
+-> [N > 1: RCCL all-reduce of the stacked [N x 122] f64 record buffer over xGMI] -> D2H of the stacked records -> sync.
+Inputs (source cloud, voxel map) are resident in HBM before the timed region.  value = N * 1e6 * K / elapsed.
+Weak scaling: per-GPU work is fixed as N grows.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (vgicp_tile_kernel<false>): algorithmic bytes (SURVEY.md 8(d):
+                  48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration measured with HIP events on the
+                  stream it is launched on; peak 8 TB/s HBM3E.
+  cpu_baseline -- the CPU oracle (restated reference CPU path, OpenMP guided schedule) timed on this box's cores on the
+                  same workload (kind "port"), rank 0 / N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--source-points", type=int, default=1_000_000)
+    ap.add_argument("--target-points", type=int, default=2_000_000)
+    ap.add_argument("--resolution", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--kernel-iters", type=int, default=50)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import gtsam_points_amd as gpa
+    from gtsam_points_amd import _capi, synthetic
+
+    lib = gpa.load()
+    _capi.check(lib.gp_set_device(local_rank), "gp_set_device")
+
+    # ---- workload, resident in HBM before timing ----
+    t_gen = time.time()
+    d = synthetic.make_c2_workload(args.source_points, args.target_points, seed=42 + rank)
+    t_gen = time.time() - t_gen
+    tgt = gpa.PointCloudGPU(d["target_points"], d["target_covs"], device=device)
+    src = gpa.PointCloudGPU(d["source_points"], d["source_covs"], device=device)
+    torch.cuda.synchronize()
+    t_map = time.time()
+    vm = gpa.GaussianVoxelMapGPU(args.resolution, target_points_drop_rate=0.0)
+    vm.insert(tgt)
+    t_map = time.time() - t_map
+    info = vm.voxelmap_info
+    stream = torch.cuda.current_stream(device)
+    factor = gpa.IntegratedVGICPFactorGPU(0, 1, vm, src, stream=C.c_void_p(stream.cuda_stream))
+    arr = (C.c_void_p * 1)(factor._h.value)
+    batch = C.c_void_p()
+    _capi.check(lib.gp_vgicp_batch_create(arr, 1, C.c_void_p(stream.cuda_stream), C.byref(batch)), "gp_vgicp_batch_create")
+    delta = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
+
+    REC = _capi.LINEARIZED6_DOUBLES
+    stacked = torch.zeros((world, REC), dtype=torch.float64, device=device)
+    host_out = torch.zeros((world, REC), dtype=torch.float64).pin_memory()
+    my_slot = C.c_void_p(stacked.data_ptr() + rank * REC * 8)
+
+    def step():
+        if world > 1:
+            stacked.zero_()
+        _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, pose.ctypes.data, my_slot), "gp_vgicp_batch_issue_linearize")
+        if world > 1:
+            dist.all_reduce(stacked, op=dist.ReduceOp.SUM)  # RCCL over xGMI: every slot is written by exactly one rank
+        host_out.copy_(stacked, non_blocking=True)
+        stream.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.source_points * args.steps / elapsed
+
+    # ---- dominant-kernel roofline: HIP events on the launch stream ----
+    ms_total, ms_main, ms_fin = C.c_float(), C.c_float(), C.c_float()
+    _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pose.ctypes.data, args.kernel_iters, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
+    alg_bytes = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+    achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
+    roofline = dict(
+        bound="hbm",
+        kernel="vgicp_tile_kernel<false>",
+        achieved=round(achieved, 2),
+        peak=HBM_PEAK_GBS,
+        unit="GB/s",
+        frac=round(achieved / HBM_PEAK_GBS, 5),
+        traffic=None,
+        algorithmic_bytes=alg_bytes,
+        kernel_ms=round(ms_main.value, 5),
+        finalize_kernel_ms=round(ms_fin.value, 5),
+        device_pass_ms=round(ms_total.value, 5),
+    )
+
+    rec = gpa.LinearizedSystem6.from_doubles(host_out[rank].numpy())
+    result = None
+    if rank == 0:
+        cpu_baseline = None
+        parity = None
+        if not args.no_cpu_baseline and world == 1:
+            import oracle  # checker / baseline only -- never on the product path
+
+            om = oracle.OracleVoxelMap(args.resolution)
+            om.insert(d["target_points"], d["target_covs"])
+            cores = oracle.max_threads()
+            fo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], cores)
+            Lo = fo.linearize(delta)  # warm-up + parity reference
+            parity = {}
+            for k in ["H_target", "H_source", "H_target_source", "b_target", "b_source"]:
+                parity[k] = float(np.linalg.norm(getattr(rec, k) - getattr(Lo, k)) / np.linalg.norm(getattr(Lo, k)))
+            parity["error"] = abs(rec.error - Lo.error) / abs(Lo.error)
+            parity["num_inliers_equal"] = bool(rec.num_inliers == Lo.num_inliers)
+            times = []
+            t_start = time.perf_counter()
+            while time.perf_counter() - t_start < args.cpu_seconds * 0.7 or len(times) < 3:
+                t = time.perf_counter()
+                fo.linearize(delta)
+                times.append(time.perf_counter() - t)
+            f1 = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], 1)
+            t1 = []
+            t_start = time.perf_counter()
+            while time.perf_counter() - t_start < args.cpu_seconds * 0.3 or len(t1) < 2:
+                t = time.perf_counter()
+                f1.linearize(delta)
+                t1.append(time.perf_counter() - t)
+            med = float(np.median(times))
+            cpu_baseline = dict(
+                value=round(args.source_points / med, 1),
+                unit="point-correspondences/s",
+                cores=cores,
+                kind="port",
+                sample=f"{len(times)} full linearize() passes of the same 1M-pt factor, {cores} OpenMP threads (median {med*1e3:.2f} ms); "
+                f"1 thread: {np.median(t1)*1e3:.2f} ms",
+                ms_per_linearize=round(med * 1e3, 3),
+                ms_per_linearize_1thread=round(float(np.median(t1)) * 1e3, 3),
+            )
+        result = dict(
+            metric="point-correspondences/sec (VGICP linearize, 1M-pt source vs 2M-pt voxel map)",
+            value=round(value, 1),
+            unit="point-correspondences/s",
+            n_gpus=world,
+            steps=args.steps,
+            warmup=args.warmup,
+            ms_per_step=round(ms_per_step, 5),
+            higher_is_better=True,
+            scaling="weak",
+            vs_baseline=None,
+            dtype="f64",
+            data="synthetic",
+            config=dict(
+                workload="BASELINE configs[1]: single VGICP factor per GPU, 1M synthetic source pts vs 2M-pt GaussianVoxelMap @0.5 m",
+                source_points=args.source_points,
+                target_points=args.target_points,
+                resolution=args.resolution,
+                num_voxels=info.num_voxels,
+                num_buckets=info.num_buckets,
+                inlier_fraction=round(rec.num_inliers / args.source_points, 4),
+                parallelism=f"{world} x 1 factor/GPU; RCCL all-reduce of stacked [N x 122] f64 records" if world > 1 else "1 GPU",
+                step="pose H2D + tile kernel + finalize kernel + (all-reduce) + D2H of records + sync",
+            ),
+            roofline=roofline,
+            cpu_baseline=cpu_baseline,
+            parity_vs_oracle=parity,
+            setup=dict(generate_s=round(t_gen, 2), voxelmap_build_s=round(t_map, 4)),
+        )
+        print(json.dumps(result), flush=True)
+    lib.gp_vgicp_batch_destroy(batch)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

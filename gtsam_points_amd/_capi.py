@@ -1,0 +1,157 @@
+"""ctypes binding of libgtsam_points_hip.so (include/gtsam_points_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, importing
+it raises.  torch is imported first so that the process shares ONE HIP runtime (the library's
+NEEDED libamdhip64.so.7 resolves to the copy torch already loaded).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgtsam_points_hip.so")
+_LIB = None
+
+
+class GPError(RuntimeError):
+    pass
+
+
+class VoxelMapInfo(C.Structure):
+    """VoxelMapInfo, types/gaussian_voxelmap_gpu.hpp:20-25"""
+
+    _fields_ = [("num_voxels", C.c_int), ("num_buckets", C.c_int), ("max_bucket_scan_count", C.c_int), ("voxel_resolution", C.c_float)]
+
+
+class VoxelMapViews(C.Structure):
+    _fields_ = [
+        ("buckets", C.c_void_p),
+        ("num_points", C.c_void_p),
+        ("voxel_means", C.c_void_p),
+        ("voxel_covs", C.c_void_p),
+        ("voxel_intensities", C.c_void_p),
+    ]
+
+
+class Linearized6(C.Structure):
+    """gp_linearized6: LinearizedSystem6 (cuda/kernels/linearized_system.cuh:10-71) in double."""
+
+    _fields_ = [
+        ("num_inliers", C.c_double),
+        ("error", C.c_double),
+        ("H_target", C.c_double * 36),
+        ("H_source", C.c_double * 36),
+        ("H_target_source", C.c_double * 36),
+        ("b_target", C.c_double * 6),
+        ("b_source", C.c_double * 6),
+    ]
+
+
+LINEARIZED6_DOUBLES = 122
+assert C.sizeof(Linearized6) == LINEARIZED6_DOUBLES * 8
+
+_SIGNATURES = {
+    # runtime
+    "gp_last_error": (C.c_char_p, []),
+    "gp_version": (C.c_char_p, []),
+    "gp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gp_set_device": (C.c_int, [C.c_int]),
+    "gp_get_device": (C.c_int, [C.POINTER(C.c_int)]),
+    "gp_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "gp_device_synchronize": (C.c_int, []),
+    "gp_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gp_stream_destroy": (C.c_int, [C.c_void_p]),
+    "gp_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "gp_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "gp_free": (C.c_int, [C.c_void_p]),
+    "gp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gp_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gp_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "gp_host_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "gp_host_free": (C.c_int, [C.c_void_p]),
+    # temp buffer / stream pool
+    "gp_temp_buffer_create": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gp_temp_buffer_get": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gp_temp_buffer_clear": (C.c_int, [C.c_void_p]),
+    "gp_temp_buffer_clear_all": (C.c_int, [C.c_void_p]),
+    "gp_temp_buffer_destroy": (C.c_int, [C.c_void_p]),
+    "gp_stream_pool_create": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gp_stream_pool_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "gp_stream_pool_sync_all": (C.c_int, [C.c_void_p]),
+    "gp_stream_pool_clear": (C.c_int, [C.c_void_p]),
+    "gp_stream_pool_clear_all": (C.c_int, [C.c_void_p]),
+    "gp_stream_pool_destroy": (C.c_int, [C.c_void_p]),
+    # voxel map
+    "gp_voxelmap_create": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_voxelmap_destroy": (C.c_int, [C.c_void_p]),
+    "gp_voxelmap_insert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "gp_voxelmap_info_get": (C.c_int, [C.c_void_p, C.POINTER(VoxelMapInfo)]),
+    "gp_voxelmap_resolution": (C.c_double, [C.c_void_p]),
+    "gp_voxelmap_views_get": (C.c_int, [C.c_void_p, C.POINTER(VoxelMapViews)]),
+    "gp_voxelmap_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_voxelmap_download_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_voxelmap_assign": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_voxelmap_save_compact": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "gp_voxelmap_load": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_voxelmap_memory_usage_gpu": (C.c_size_t, [C.c_void_p]),
+    "gp_voxelmap_loaded_on_gpu": (C.c_int, [C.c_void_p]),
+    "gp_voxelmap_offload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gp_voxelmap_reload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gp_voxelmap_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
+    "gp_voxelmap_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]),
+    # factor
+    "gp_vgicp_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_vgicp_factor_destroy": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_factor_set_surface_validation": (C.c_int, [C.c_void_p, C.c_int]),
+    "gp_vgicp_factor_set_inlier_update_thresh": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "gp_vgicp_factor_num_points": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_factor_stream": (C.c_void_p, [C.c_void_p]),
+    "gp_vgicp_linearization_input_size": (C.c_size_t, []),
+    "gp_vgicp_linearization_output_size": (C.c_size_t, []),
+    "gp_vgicp_evaluation_input_size": (C.c_size_t, []),
+    "gp_vgicp_evaluation_output_size": (C.c_size_t, []),
+    "gp_vgicp_factor_issue_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_factor_issue_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_factor_sync": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_factor_linearize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(Linearized6)]),
+    "gp_vgicp_factor_compute_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    # batch
+    "gp_vgicp_batch_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_vgicp_batch_destroy": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_batch_size": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_batch_total_points": (C.c_int64, [C.c_void_p]),
+    "gp_vgicp_batch_algorithmic_bytes": (C.c_int64, [C.c_void_p]),
+    "gp_vgicp_batch_issue_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_batch_issue_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_batch_sync": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_batch_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_batch_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES.keys()) + ["gp_linearized6_to_f32"])
+
+
+def load():
+    """Load libgtsam_points_hip.so; raise loudly when it is absent (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GPError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gtsam_points_amd/csrc`. gtsam_points_amd has no CPU fallback."
+            )
+        import torch  # noqa: F401  (one HIP runtime per process: torch's libamdhip64 first)
+
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().gp_last_error()
+        raise GPError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,127 @@
+// gp_host.hpp -- host-side internals shared by the translation units of libgtsam_points_hip.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gp_device.hpp"
+
+namespace gp {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t err, const char* expr, const char* file, int line);
+
+#define GP_HIP(expr)                                                      \
+  do {                                                                    \
+    hipError_t gp_err__ = (expr);                                         \
+    if (gp_err__ != hipSuccess) return gp::hip_fail(gp_err__, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define GP_TRY(expr)                 \
+  do {                               \
+    int gp_rc__ = (expr);            \
+    if (gp_rc__ != GP_OK) return gp_rc__; \
+  } while (0)
+
+// RAII device allocation used for library-owned arrays
+struct DeviceArray {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  DeviceArray() = default;
+  DeviceArray(const DeviceArray&) = delete;
+  DeviceArray& operator=(const DeviceArray&) = delete;
+  ~DeviceArray() { release(); }
+  int alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&ptr, n);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    }
+    bytes = n;
+    return GP_OK;
+  }
+  int ensure(size_t n) { return (n <= bytes && ptr) ? GP_OK : alloc(n + n / 5); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(ptr);
+  }
+};
+
+struct PinnedArray {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  PinnedArray() = default;
+  PinnedArray(const PinnedArray&) = delete;
+  PinnedArray& operator=(const PinnedArray&) = delete;
+  ~PinnedArray() { release(); }
+  int ensure(size_t n) {
+    if (n <= bytes && ptr) return GP_OK;
+    release();
+    if (n == 0) n = 16;
+    n += n / 5;
+    hipError_t e = hipHostMalloc(&ptr, n, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
+    bytes = n;
+    return GP_OK;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(ptr);
+  }
+};
+
+}  // namespace gp
+
+// TempBufferManager (cuda/stream_temp_buffer_roundrobin.cu:11-47)
+struct gp_temp_buffer {
+  struct Buffer {
+    size_t size = 0;
+    char* buffer = nullptr;
+  };
+  std::vector<Buffer> buffers;
+};
+
+// GaussianVoxelMapGPU device state
+struct gp_voxelmap {
+  double resolution = 0.0;
+  int init_num_buckets = 16384;
+  double target_points_drop_rate = 1e-3;
+  hipStream_t stream = nullptr;
+  gp_voxelmap_info info{};
+
+  gp::DeviceArray buckets;      // gp_voxel_bucket[num_buckets]
+  gp::DeviceArray records;      // gp::VoxelRecord[num_voxels]   (kernel gather layout)
+  gp::DeviceArray num_points;   // int[num_voxels]               (reference-visible arrays below)
+  gp::DeviceArray voxel_means;  // float[num_voxels][3]
+  gp::DeviceArray voxel_covs;   // float[num_voxels][9]
+  gp::DeviceArray voxel_intensities;  // float[num_voxels]
+  gp::DeviceArray voxel_coords; // int[num_voxels][3] voxel coordinate of each voxel index
+
+  // offloaded copies (OffloadableGPU)
+  bool offloaded = false;
+  std::vector<char> h_buckets, h_records, h_num_points, h_means, h_covs, h_intensities, h_coords;
+
+  bool loaded() const { return buckets.ptr != nullptr && !offloaded; }
+  gp::VoxelMapView view() const;
+};

@@ -1,0 +1,672 @@
+// gp_vgicp.hip -- fused VGICP linearisation / error evaluation for gfx950, single-factor and batched.
+//
+// Replaces (reference):
+//   include/gtsam_points/cuda/kernels/{lookup_voxels,vgicp_derivatives,linearized_system}.cuh  (device functors)
+//   src/gtsam_points/factors/integrated_vgicp_derivatives{,_linearize,_compute,_inliers}.cu       (CUB reduce / select)
+//   the per-factor launch loop of src/gtsam_points/cuda/nonlinear_factor_set_gpu.cpp:64-218
+//
+// Shape of the computation:
+//   main kernel    : one 256-thread workgroup per TILE of kTilePoints consecutive source points of one factor.
+//                    per point: q = R p + t (f64) -> floor -> hash probe (16-B bucket) -> 64-B voxel record ->
+//                    M = (C_B + R C_A R^T)^-1 -> 29 target-side sums; 64-lane shuffle reduce, LDS cross-wave
+//                    reduce, ONE 32-double partial per tile.  No atomics, no inlier list, no CUB temp storage.
+//   finalize kernel: one workgroup per factor sums its tiles' partials in a fixed order (deterministic) and
+//                    expands them to the LinearizedSystem6 blocks through the adjoint identity
+//                    J_s = -J_t Ad(delta):  H_s = Ad^T H_t Ad, H_ts = -H_t Ad, b_s = -Ad^T b_t.
+//   The workgroup -> tile map is XCD-aware: workgroup b runs on XCD b % 8, so XCD x is handed the x-th contiguous
+//   eighth of the tile list and the voxel tables of "its" factors stay in that XCD's 4 MiB L2.
+#include <algorithm>
+#include <cstring>
+
+#include "gp_host.hpp"
+
+namespace gp {
+
+constexpr int kBlockThreads = 256;
+constexpr int kPointsPerThread = 4;
+constexpr int kTilePoints = kBlockThreads * kPointsPerThread;  // 1024 source points per workgroup
+constexpr int kNumXCD = 8;
+
+struct FactorDesc {
+  const float* points;   // [n][3]
+  const float* covs;     // [n][9]
+  const float* normals;  // [n][3] or null
+  VoxelMapView map;
+  int n;
+  int surface_validation;
+  int tile_begin;
+  int tile_count;
+};
+
+struct TileDesc {
+  int factor;
+  int begin;  // first point
+  int count;  // <= kTilePoints
+};
+
+__device__ __forceinline__ int xcd_swizzle(int b, int num_tiles) {
+  // workgroup b -> tile index; tiles [x*per, (x+1)*per) go to XCD x (dispatcher places workgroup b on XCD b % 8)
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  return (b % kNumXCD) * per + b / kNumXCD;
+}
+
+template <bool ERROR_ONLY>
+__device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose& Tl, const Pose& Te, int i, double* acc) {
+  const float* __restrict__ pp = f.points + 3 * (size_t)i;
+  const double px = (double)pp[0], py = (double)pp[1], pz = (double)pp[2];
+  // correspondence at the LINEARISATION pose (lookup kernel is built with d_xl, integrated_vgicp_derivatives_compute.cu:25)
+  const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
+  const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
+  const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
+  if (f.surface_validation && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (size_t)i)) return;
+  const int cx = fast_floor(lx * f.map.inv_leaf), cy = fast_floor(ly * f.map.inv_leaf), cz = fast_floor(lz * f.map.inv_leaf);
+  const int v = lookup_voxel(f.map, cx, cy, cz);
+  if (v < 0) return;
+
+  // one 64-B gather: {mean_local f32x3, n, cov f64x6}
+  const VoxelRecord* __restrict__ rec = f.map.records + v;
+  const float4 head = *reinterpret_cast<const float4*>(rec);
+  const double2 c01 = *reinterpret_cast<const double2*>(rec->cov);
+  const double2 c23 = *reinterpret_cast<const double2*>(rec->cov + 2);
+  const double2 c45 = *reinterpret_cast<const double2*>(rec->cov + 4);
+  const double cb[6] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y};
+
+  const float* __restrict__ cp = f.covs + 9 * (size_t)i;
+  const double ca[6] = {(double)cp[0], (double)cp[3], (double)cp[6], (double)cp[4], (double)cp[7], (double)cp[8]};
+
+  double m[6];
+  fused_mahalanobis(Tl, ca, cb, m);
+
+  double ox, oy, oz;
+  voxel_center(f.map, cx, cy, cz, ox, oy, oz);
+  double qx, qy, qz;
+  if (ERROR_ONLY) {
+    qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
+    qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
+    qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
+  } else {
+    qx = lx;
+    qy = ly;
+    qz = lz;
+  }
+  // r = mu_B - q, with mu_B = centre + mean_local
+  const double rx = (ox - qx) + (double)head.x;
+  const double ry = (oy - qy) + (double)head.y;
+  const double rz = (oz - qz) + (double)head.z;
+  const double mrx = m[0] * rx + m[1] * ry + m[2] * rz;
+  const double mry = m[1] * rx + m[3] * ry + m[4] * rz;
+  const double mrz = m[2] * rx + m[4] * ry + m[5] * rz;
+  acc[ACC_COUNT] += 1.0;
+  acc[ACC_ERR] += rx * mrx + ry * mry + rz * mrz;
+  if constexpr (!ERROR_ONLY) {
+  for (int k = 0; k < 6; k++) acc[ACC_M + k] += m[k];
+  // K = M S, S = [q]x ; columns: K[:,0] = M[:,1] qz - M[:,2] qy ; K[:,1] = M[:,2] qx - M[:,0] qz ; K[:,2] = M[:,0] qy - M[:,1] qx
+  const double k00 = m[1] * qz - m[2] * qy, k01 = m[2] * qx - m[0] * qz, k02 = m[0] * qy - m[1] * qx;
+  const double k10 = m[3] * qz - m[4] * qy, k11 = m[4] * qx - m[1] * qz, k12 = m[1] * qy - m[3] * qx;
+  const double k20 = m[4] * qz - m[5] * qy, k21 = m[5] * qx - m[2] * qz, k22 = m[2] * qy - m[4] * qx;
+  acc[ACC_K + 0] += k00;
+  acc[ACC_K + 1] += k01;
+  acc[ACC_K + 2] += k02;
+  acc[ACC_K + 3] += k10;
+  acc[ACC_K + 4] += k11;
+  acc[ACC_K + 5] += k12;
+  acc[ACC_K + 6] += k20;
+  acc[ACC_K + 7] += k21;
+  acc[ACC_K + 8] += k22;
+  // TL = -S K (= S^T M S), rows of -S: [0, qz, -qy], [-qz, 0, qx], [qy, -qx, 0]; upper triangle
+  acc[ACC_TL + 0] += qz * k10 - qy * k20;
+  acc[ACC_TL + 1] += qz * k11 - qy * k21;
+  acc[ACC_TL + 2] += qz * k12 - qy * k22;
+  acc[ACC_TL + 3] += qx * k21 - qz * k01;
+  acc[ACC_TL + 4] += qx * k22 - qz * k02;
+  acc[ACC_TL + 5] += qy * k02 - qx * k12;
+  // b_t = [q x (M r); M r]
+  acc[ACC_QXMR + 0] += qy * mrz - qz * mry;
+  acc[ACC_QXMR + 1] += qz * mrx - qx * mrz;
+  acc[ACC_QXMR + 2] += qx * mry - qy * mrx;
+  acc[ACC_MR + 0] += mrx;
+  acc[ACC_MR + 1] += mry;
+  acc[ACC_MR + 2] += mrz;
+  }
+}
+
+// main kernel: one workgroup per tile; writes partials[tile][ACC_STRIDE]
+template <bool ERROR_ONLY>
+__global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                                   const double* __restrict__ poses_lin, const double* __restrict__ poses_eval,
+                                                                   double* __restrict__ partials) {
+  constexpr int NACC = ERROR_ONLY ? 2 : ACC_SIZE;
+  const int tile_idx = xcd_swizzle(blockIdx.x, num_tiles);
+  if (tile_idx >= num_tiles) return;
+  const TileDesc tile = tiles[tile_idx];
+  const FactorDesc f = factors[tile.factor];
+  const Pose Tl = load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = ERROR_ONLY ? load_pose(poses_eval + 16 * (size_t)tile.factor) : Tl;
+
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+
+#pragma unroll
+  for (int it = 0; it < kPointsPerThread; it++) {
+    const int local = it * kBlockThreads + threadIdx.x;
+    if (local < tile.count) accumulate_point<ERROR_ONLY>(f, Tl, Te, tile.begin + local, acc);
+  }
+
+  // 64-lane wavefront reduction
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    acc[k] = v;
+  }
+  __shared__ double lds[kBlockThreads / 64][ACC_STRIDE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NACC; k++) lds[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double s = 0.0;
+    if (threadIdx.x < NACC) {
+#pragma unroll
+      for (int w = 0; w < kBlockThreads / 64; w++) s += lds[w][threadIdx.x];
+    }
+    partials[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
+  }
+}
+
+// finalize: one workgroup per factor; deterministic ordered sum of the factor's tile partials, then expansion
+__global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
+                                                                       const double* __restrict__ partials, gp_linearized6* __restrict__ out) {
+  const int fi = blockIdx.x;
+  const int tile_begin = factors[fi].tile_begin, tile_count = factors[fi].tile_count;
+  __shared__ double lds[kBlockThreads / ACC_STRIDE][ACC_STRIDE];
+  __shared__ double sum[ACC_STRIDE];
+  const int comp = threadIdx.x % ACC_STRIDE, slice = threadIdx.x / ACC_STRIDE;
+  constexpr int kSlices = kBlockThreads / ACC_STRIDE;
+  double s = 0.0;
+  for (int t = slice; t < tile_count; t += kSlices) s += partials[(size_t)(tile_begin + t) * ACC_STRIDE + comp];
+  lds[slice][comp] = s;
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSlices; k++) a += lds[k][threadIdx.x];
+    sum[threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  // ---- expansion (single lane; 6x6 algebra, negligible) ----
+  const Pose T = load_pose(poses + 16 * (size_t)fi);
+  double Ht[6][6], bt[6];
+  const double* M = sum + ACC_M;
+  const double* K = sum + ACC_K;
+  const double* TL = sum + ACC_TL;
+  const double Mf[3][3] = {{M[0], M[1], M[2]}, {M[1], M[3], M[4]}, {M[2], M[4], M[5]}};
+  const double TLf[3][3] = {{TL[0], TL[1], TL[2]}, {TL[1], TL[3], TL[4]}, {TL[2], TL[4], TL[5]}};
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      Ht[r][c] = TLf[r][c];
+      Ht[3 + r][c] = -K[r * 3 + c];
+      Ht[c][3 + r] = -K[r * 3 + c];
+      Ht[3 + r][3 + c] = Mf[r][c];
+    }
+  for (int k = 0; k < 3; k++) {
+    bt[k] = sum[ACC_QXMR + k];
+    bt[3 + k] = sum[ACC_MR + k];
+  }
+  // Ad(delta) = [[R, 0], [[t]x R, R]]   ([omega, v] ordering, GTSAM Pose3::AdjointMap)
+  const double R[3][3] = {{T.r00, T.r01, T.r02}, {T.r10, T.r11, T.r12}, {T.r20, T.r21, T.r22}};
+  const double tx[3][3] = {{0.0, -T.tz, T.ty}, {T.tz, 0.0, -T.tx}, {-T.ty, T.tx, 0.0}};
+  double Ad[6][6];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      Ad[r][c] = R[r][c];
+      Ad[r][3 + c] = 0.0;
+      Ad[3 + r][3 + c] = R[r][c];
+      double a = 0.0;
+      for (int k = 0; k < 3; k++) a += tx[r][k] * R[k][c];
+      Ad[3 + r][c] = a;
+    }
+  double HtA[6][6];  // H_t Ad
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      double a = 0.0;
+      for (int k = 0; k < 6; k++) a += Ht[r][k] * Ad[k][c];
+      HtA[r][c] = a;
+    }
+  gp_linearized6 o;
+  o.num_inliers = sum[ACC_COUNT];
+  o.error = sum[ACC_ERR];
+  for (int r = 0; r < 6; r++) {
+    for (int c = 0; c < 6; c++) {
+      double hs = 0.0;
+      for (int k = 0; k < 6; k++) hs += Ad[k][r] * HtA[k][c];
+      o.H_target[c * 6 + r] = Ht[r][c];
+      o.H_source[c * 6 + r] = hs;
+      o.H_target_source[c * 6 + r] = -HtA[r][c];
+    }
+    double bs = 0.0;
+    for (int k = 0; k < 6; k++) bs += Ad[k][r] * bt[k];
+    o.b_target[r] = bt[r];
+    o.b_source[r] = -bs;
+  }
+  // out may be only 8-byte aligned (sub-range of a staging buffer, integrated_vgicp_factor_gpu.cpp:219-220)
+  double* dst = reinterpret_cast<double*>(out + fi);
+  const double* src = reinterpret_cast<const double*>(&o);
+  for (int k = 0; k < (int)(sizeof(gp_linearized6) / sizeof(double)); k++) dst[k] = src[k];
+}
+
+__global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
+                                                                             double* __restrict__ out) {
+  const int fi = blockIdx.x;
+  const int tile_begin = factors[fi].tile_begin, tile_count = factors[fi].tile_count;
+  __shared__ double lds[kBlockThreads / 64];
+  double s = 0.0;
+  for (int t = threadIdx.x; t < tile_count; t += kBlockThreads) s += partials[(size_t)(tile_begin + t) * ACC_STRIDE + ACC_ERR];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int w = 0; w < kBlockThreads / 64; w++) a += lds[w];
+    out[fi] = a;
+  }
+}
+
+}  // namespace gp
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+struct gp_vgicp_batch;
+
+struct gp_vgicp_factor {
+  const gp_voxelmap* target = nullptr;
+  const float* points = nullptr;
+  const float* covs = nullptr;
+  const float* normals = nullptr;
+  int n = 0;
+  bool surface_validation = false;
+  double inlier_thresh_trans = 1e-6, inlier_thresh_angle = 1e-6;  // integrated_vgicp_derivatives.cu:26-27 (kept for API parity)
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  gp_temp_buffer* temp_buffer = nullptr;
+  bool owns_temp_buffer = false;
+  gp_vgicp_batch* self_batch = nullptr;  // lazily built batch of one, used by the per-factor entry points
+  gp::PinnedArray staging;               // poses in / results out for the synchronous fall-backs
+  gp::DeviceArray dev_io;                // device pose(s) + result for the synchronous fall-backs
+};
+
+struct gp_vgicp_batch {
+  std::vector<gp_vgicp_factor*> factors;
+  hipStream_t stream = nullptr;
+  gp_temp_buffer* temp_buffer = nullptr;  // partials arena when provided (per-stream scratch), else own
+  int num_tiles = 0;
+  int64_t total_points = 0;
+  gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
+  gp::PinnedArray h_poses;
+  gp::PinnedArray h_out;
+  gp::DeviceArray d_out;
+  bool table_dirty = true;
+};
+
+namespace {
+
+int build_table(gp_vgicp_batch* b) {
+  const int F = (int)b->factors.size();
+  std::vector<gp::FactorDesc> descs((size_t)F);
+  std::vector<gp::TileDesc> tiles;
+  b->total_points = 0;
+  for (int i = 0; i < F; i++) {
+    const gp_vgicp_factor* f = b->factors[i];
+    if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
+    gp::FactorDesc& d = descs[i];
+    d.points = f->points;
+    d.covs = f->covs;
+    d.normals = f->normals;
+    d.map = f->target->view();
+    d.n = f->n;
+    d.surface_validation = (f->surface_validation && f->normals) ? 1 : 0;
+    d.tile_begin = (int)tiles.size();
+    for (int p = 0; p < f->n; p += gp::kTilePoints) tiles.push_back(gp::TileDesc{i, p, std::min(gp::kTilePoints, f->n - p)});
+    d.tile_count = (int)tiles.size() - d.tile_begin;
+    b->total_points += f->n;
+  }
+  b->num_tiles = (int)tiles.size();
+  GP_TRY(b->d_factors.ensure(sizeof(gp::FactorDesc) * (size_t)std::max(F, 1)));
+  GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
+  GP_TRY(b->d_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
+  GP_TRY(b->h_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
+  if (!b->temp_buffer) GP_TRY(b->d_partials.ensure(sizeof(double) * gp::ACC_STRIDE * (size_t)std::max(b->num_tiles, 1)));
+  // the table upload is synchronous (pageable source); it happens once per factor-set change, not per linearise
+  if (F) GP_HIP(hipMemcpy(b->d_factors.ptr, descs.data(), sizeof(gp::FactorDesc) * (size_t)F, hipMemcpyHostToDevice));
+  if (b->num_tiles) GP_HIP(hipMemcpy(b->d_tiles.ptr, tiles.data(), sizeof(gp::TileDesc) * (size_t)b->num_tiles, hipMemcpyHostToDevice));
+  b->table_dirty = false;
+  return GP_OK;
+}
+
+int partials_ptr(gp_vgicp_batch* b, double** out) {
+  if (b->temp_buffer) {
+    void* p = nullptr;
+    GP_TRY(gp_temp_buffer_get(b->temp_buffer, sizeof(double) * gp::ACC_STRIDE * (size_t)std::max(b->num_tiles, 1), &p));
+    *out = reinterpret_cast<double*>(p);
+  } else {
+    *out = b->d_partials.as<double>();
+  }
+  return GP_OK;
+}
+
+inline int grid_tiles(int num_tiles) {
+  const int per = (num_tiles + gp::kNumXCD - 1) / gp::kNumXCD;
+  return per * gp::kNumXCD;
+}
+
+// device work of one linearisation pass; poses already on the device
+int launch_linearize(gp_vgicp_batch* b, const double* d_poses, gp_linearized6* out_dev) {
+  const int F = (int)b->factors.size();
+  if (F == 0) return GP_OK;
+  double* partials = nullptr;
+  GP_TRY(partials_ptr(b, &partials));
+  if (b->num_tiles > 0) {
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<false>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
+                       b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
+    GP_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gp::vgicp_finalize_kernel, dim3(F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials, out_dev);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
+int launch_error(gp_vgicp_batch* b, const double* d_poses_lin, const double* d_poses_eval, double* out_dev) {
+  const int F = (int)b->factors.size();
+  if (F == 0) return GP_OK;
+  double* partials = nullptr;
+  GP_TRY(partials_ptr(b, &partials));
+  if (b->num_tiles > 0) {
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<true>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
+                       b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses_lin, d_poses_eval, partials);
+    GP_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3(F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), partials, out_dev);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
+int ensure_self_batch(gp_vgicp_factor* f) {
+  if (!f->self_batch) {
+    gp_vgicp_batch_t* b = nullptr;
+    gp_vgicp_factor_t* one = f;
+    GP_TRY(gp_vgicp_batch_create(&one, 1, f->stream, &b));
+    b->temp_buffer = f->temp_buffer;
+    f->self_batch = b;
+  }
+  if (f->self_batch->table_dirty) GP_TRY(build_table(f->self_batch));
+  return GP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gp_vgicp_linearization_input_size(void) { return sizeof(double) * 16; }
+size_t gp_vgicp_linearization_output_size(void) { return sizeof(gp_linearized6); }
+size_t gp_vgicp_evaluation_input_size(void) { return sizeof(double) * 16; }
+size_t gp_vgicp_evaluation_output_size(void) { return sizeof(double); }
+
+int gp_vgicp_factor_create(const gp_voxelmap_t* target, const float* points_dev, const float* covs_dev, const float* normals_dev, int num_points,
+                           gp_stream_t stream, gp_temp_buffer_t* temp_buffer, gp_vgicp_factor_t** out) {
+  if (!out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_create: null out");
+  // the reference abort()s on these (integrated_vgicp_factor_gpu.cpp:33-46); the C++ mirror keeps that, the C-ABI reports
+  if (!points_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "error: GPU source points have not been allocated!!");
+  if (!covs_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "error: GPU source covs have not been allocated!!");
+  if (!target) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "error: GPU target voxels have not been created!!");
+  if (num_points < 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_create: negative size");
+  auto* f = new gp_vgicp_factor;
+  f->target = target;
+  f->points = points_dev;
+  f->covs = covs_dev;
+  f->normals = normals_dev;
+  f->n = num_points;
+  if (stream) {
+    f->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);  // integrated_vgicp_derivatives.cu:36-39
+    if (e != hipSuccess) {
+      delete f;
+      return gp::hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+    }
+    f->owns_stream = true;
+  }
+  if (temp_buffer) {
+    f->temp_buffer = temp_buffer;
+  } else {
+    int rc = gp_temp_buffer_create(0, &f->temp_buffer);  // :41-43
+    if (rc != GP_OK) {
+      if (f->owns_stream) (void)hipStreamDestroy(f->stream);
+      delete f;
+      return rc;
+    }
+    f->owns_temp_buffer = true;
+  }
+  *out = f;
+  return GP_OK;
+}
+
+int gp_vgicp_factor_destroy(gp_vgicp_factor_t* f) {
+  if (!f) return GP_OK;
+  if (f->self_batch) gp_vgicp_batch_destroy(f->self_batch);
+  if (f->owns_stream) {
+    (void)hipStreamSynchronize(f->stream);
+    (void)hipStreamDestroy(f->stream);
+  }
+  if (f->owns_temp_buffer) gp_temp_buffer_destroy(f->temp_buffer);
+  delete f;
+  return GP_OK;
+}
+
+int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable) {
+  if (!f) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "null factor");
+  if (enable && !f->normals) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "surface validation needs source normals (integrated_vgicp_factor_gpu.hpp:84-86)");
+  f->surface_validation = enable != 0;
+  if (f->self_batch) f->self_batch->table_dirty = true;
+  return GP_OK;
+}
+
+int gp_vgicp_factor_set_inlier_update_thresh(gp_vgicp_factor_t* f, double trans, double angle) {
+  if (!f) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "null factor");
+  f->inlier_thresh_trans = trans;
+  f->inlier_thresh_angle = angle;
+  return GP_OK;
+}
+
+int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f) { return f ? f->n : 0; }
+gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f) { return f ? (gp_stream_t)f->stream : nullptr; }
+
+int gp_vgicp_factor_issue_linearize(gp_vgicp_factor_t* f, const double* pose_host, const double* pose_dev, gp_linearized6* out_dev) {
+  (void)pose_host;
+  if (!f || !pose_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_linearize: null");
+  GP_TRY(ensure_self_batch(f));
+  return launch_linearize(f->self_batch, pose_dev, out_dev);
+}
+
+int gp_vgicp_factor_issue_compute_error(gp_vgicp_factor_t* f, const double* pose_lin_host, const double* pose_eval_host, const double* pose_lin_dev,
+                                        const double* pose_eval_dev, double* out_dev) {
+  (void)pose_lin_host;
+  (void)pose_eval_host;
+  if (!f || !pose_lin_dev || !pose_eval_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_compute_error: null");
+  GP_TRY(ensure_self_batch(f));
+  return launch_error(f->self_batch, pose_lin_dev, pose_eval_dev, out_dev);
+}
+
+int gp_vgicp_factor_sync(gp_vgicp_factor_t* f) {
+  if (!f) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "null factor");
+  GP_HIP(hipStreamSynchronize(f->stream));
+  return GP_OK;
+}
+
+int gp_vgicp_factor_linearize(gp_vgicp_factor_t* f, const double pose[16], gp_linearized6* out_host) {
+  if (!f || !pose || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_linearize: null");
+  GP_TRY(ensure_self_batch(f));
+  return gp_vgicp_batch_linearize(f->self_batch, pose, out_host);
+}
+
+int gp_vgicp_factor_compute_error(gp_vgicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host) {
+  if (!f || !pose_lin || !pose_eval || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_compute_error: null");
+  GP_TRY(ensure_self_batch(f));
+  return gp_vgicp_batch_compute_error(f->self_batch, pose_lin, pose_eval, out_host);
+}
+
+// ---- batch ----------------------------------------------------------------------------------------------------
+
+int gp_vgicp_batch_create(gp_vgicp_factor_t* const* factors, int num_factors, gp_stream_t stream, gp_vgicp_batch_t** out) {
+  if (!out || num_factors < 0 || (num_factors > 0 && !factors)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_create: bad arguments");
+  auto* b = new gp_vgicp_batch;
+  for (int i = 0; i < num_factors; i++) {
+    if (!factors[i]) {
+      delete b;
+      return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_create: null factor");
+    }
+    b->factors.push_back(factors[i]);
+  }
+  b->stream = (hipStream_t)stream;
+  int rc = build_table(b);
+  if (rc != GP_OK) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return GP_OK;
+}
+
+int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch) {
+  if (!batch) return GP_OK;
+  (void)hipStreamSynchronize(batch->stream);
+  delete batch;
+  return GP_OK;
+}
+
+int gp_vgicp_batch_size(const gp_vgicp_batch_t* batch) { return batch ? (int)batch->factors.size() : 0; }
+int64_t gp_vgicp_batch_total_points(const gp_vgicp_batch_t* batch) { return batch ? batch->total_points : 0; }
+
+int64_t gp_vgicp_batch_algorithmic_bytes(const gp_vgicp_batch_t* batch) {
+  if (!batch) return 0;
+  int64_t bytes = 0;
+  for (const auto* f : batch->factors)
+    bytes += 48ll * f->n + 16ll * f->target->info.num_buckets + 52ll * f->target->info.num_voxels + 560ll + (f->surface_validation ? 12ll * f->n : 0ll);
+  return bytes;
+}
+
+static int upload_poses(gp_vgicp_batch* b, const double* lin, const double* eval) {
+  const size_t F = b->factors.size();
+  double* h = b->h_poses.as<double>();
+  memcpy(h, lin, sizeof(double) * 16 * F);
+  if (eval) memcpy(h + 16 * F, eval, sizeof(double) * 16 * F);
+  GP_HIP(hipMemcpyAsync(b->d_poses.ptr, h, sizeof(double) * 16 * F * (eval ? 2 : 1), hipMemcpyHostToDevice, b->stream));
+  return GP_OK;
+}
+
+int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_dev) {
+  if (!b || !poses_host || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_linearize: null");
+  if (b->table_dirty) GP_TRY(build_table(b));
+  if (b->factors.empty()) return GP_OK;
+  GP_TRY(upload_poses(b, poses_host, nullptr));
+  return launch_linearize(b, b->d_poses.as<double>(), out_dev);
+}
+
+int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_host, const double* poses_eval_host, double* out_dev) {
+  if (!b || !poses_lin_host || !poses_eval_host || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_compute_error: null");
+  if (b->table_dirty) GP_TRY(build_table(b));
+  if (b->factors.empty()) return GP_OK;
+  GP_TRY(upload_poses(b, poses_lin_host, poses_eval_host));
+  return launch_error(b, b->d_poses.as<double>(), b->d_poses.as<double>() + 16 * b->factors.size(), out_dev);
+}
+
+int gp_vgicp_batch_sync(gp_vgicp_batch_t* b) {
+  if (!b) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "null batch");
+  GP_HIP(hipStreamSynchronize(b->stream));
+  return GP_OK;
+}
+
+int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host) {
+  if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
+  const size_t F = b->factors.size();
+  if (F == 0) return GP_OK;
+  GP_TRY(b->d_out.ensure(sizeof(gp_linearized6) * F));
+  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * F));
+  GP_TRY(gp_vgicp_batch_issue_linearize(b, poses_host, b->d_out.as<gp_linearized6>()));
+  GP_HIP(hipMemcpyAsync(b->h_out.ptr, b->d_out.ptr, sizeof(gp_linearized6) * F, hipMemcpyDeviceToHost, b->stream));
+  GP_HIP(hipStreamSynchronize(b->stream));
+  memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
+  return GP_OK;
+}
+
+int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_host, const double* poses_eval_host, double* out_host) {
+  if (!b || !poses_lin_host || !poses_eval_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_compute_error: null");
+  const size_t F = b->factors.size();
+  if (F == 0) return GP_OK;
+  GP_TRY(b->d_out.ensure(sizeof(gp_linearized6) * F));
+  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * F));
+  GP_TRY(gp_vgicp_batch_issue_compute_error(b, poses_lin_host, poses_eval_host, b->d_out.as<double>()));
+  GP_HIP(hipMemcpyAsync(b->h_out.ptr, b->d_out.ptr, sizeof(double) * F, hipMemcpyDeviceToHost, b->stream));
+  GP_HIP(hipStreamSynchronize(b->stream));
+  memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
+  return GP_OK;
+}
+
+int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel) {
+  if (!b || !poses_host || iters <= 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_time_linearize: bad arguments");
+  if (b->table_dirty) GP_TRY(build_table(b));
+  const size_t F = b->factors.size();
+  if (F == 0) return GP_OK;
+  GP_TRY(b->d_out.ensure(sizeof(gp_linearized6) * F));
+  GP_TRY(upload_poses(b, poses_host, nullptr));
+  double* partials = nullptr;
+  GP_TRY(partials_ptr(b, &partials));
+  hipEvent_t e0, e1, e2;
+  GP_HIP(hipEventCreate(&e0));
+  GP_HIP(hipEventCreate(&e1));
+  GP_HIP(hipEventCreate(&e2));
+  const double* d_poses = b->d_poses.as<double>();
+  // warm-up
+  GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>()));
+  GP_HIP(hipStreamSynchronize(b->stream));
+  // whole pass, back to back
+  GP_HIP(hipEventRecord(e0, b->stream));
+  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>()));
+  GP_HIP(hipEventRecord(e1, b->stream));
+  GP_HIP(hipEventSynchronize(e1));
+  float t_total = 0.f;
+  GP_HIP(hipEventElapsedTime(&t_total, e0, e1));
+  // main kernel alone, then finalize alone (same stream the product path launches on)
+  GP_HIP(hipEventRecord(e0, b->stream));
+  for (int i = 0; i < iters; i++) {
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<false>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
+                       b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
+  }
+  GP_HIP(hipEventRecord(e1, b->stream));
+  for (int i = 0; i < iters; i++) {
+    hipLaunchKernelGGL(gp::vgicp_finalize_kernel, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials,
+                       b->d_out.as<gp_linearized6>());
+  }
+  GP_HIP(hipEventRecord(e2, b->stream));
+  GP_HIP(hipEventSynchronize(e2));
+  float t_main = 0.f, t_fin = 0.f;
+  GP_HIP(hipEventElapsedTime(&t_main, e0, e1));
+  GP_HIP(hipEventElapsedTime(&t_fin, e1, e2));
+  if (ms_total) *ms_total = t_total / (float)iters;
+  if (ms_main_kernel) *ms_main_kernel = t_main / (float)iters;
+  if (ms_finalize_kernel) *ms_finalize_kernel = t_fin / (float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  return GP_OK;
+}
+
+}  // extern "C"

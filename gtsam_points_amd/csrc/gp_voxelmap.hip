@@ -1,0 +1,598 @@
+// gp_voxelmap.hip -- GaussianVoxelMapGPU for gfx950.
+//
+// Replaces src/gtsam_points/types/gaussian_voxelmap_gpu.cu (thrust::for_each functors :25-172, insert :211-251,
+// create_bucket_table :253-307, save/load :309-467, offload/reload :469-535, download_* :537-571) and the
+// overlap/lookup half of gaussian_voxelmap_gpu_funcs.cu:156-236.
+//
+// Differences by design:
+//   * voxel coordinates are floor(double(p) * (1.0/leaf)) -- the CPU map's rule (gaussian_voxelmap_cpu.cpp:59-61)
+//   * statistics are accumulated with native f64 atomics relative to the voxel centre, not unordered f32 atomics
+//   * besides the reference-visible arrays (num_points / voxel_means / voxel_covs / voxel_intensities) the map
+//     keeps one aligned 64-B gather record per voxel (gp::VoxelRecord) that the VGICP kernels read
+//   * no intermediate coordinate array: a bucket's representative point is re-floored when compared
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+
+#include "gp_host.hpp"
+
+namespace gp {
+
+__device__ __forceinline__ void point_coord(const float* __restrict__ points, int i, double inv_leaf, int& cx, int& cy, int& cz) {
+  cx = fast_floor((double)points[3 * (size_t)i] * inv_leaf);
+  cy = fast_floor((double)points[3 * (size_t)i + 1] * inv_leaf);
+  cz = fast_floor((double)points[3 * (size_t)i + 2] * inv_leaf);
+}
+
+// voxel_bucket_assignment_kernel (gaussian_voxelmap_gpu.cu:37-75): claim a bucket per distinct voxel coordinate.
+// rep[b] = index of the first point that claimed bucket b, or -1.
+__global__ void __launch_bounds__(256) claim_buckets_kernel(const float* __restrict__ points, int n, int* __restrict__ rep, uint32_t num_buckets,
+                                                            uint32_t mask, int max_scan, double inv_leaf, int* __restrict__ failures) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cx, cy, cz;
+  point_coord(points, i, inv_leaf, cx, cy, cz);
+  const uint64_t hash = coord_hash(cx, cy, cz);
+  for (int j = 0; j < max_scan; j++) {
+    const uint32_t b = bucket_index(hash, j, num_buckets, mask);
+    const int old = atomicCAS(&rep[b], -1, i);
+    if (old < 0) return;  // claimed an empty bucket
+    int ox, oy, oz;
+    point_coord(points, old, inv_leaf, ox, oy, oz);
+    if (ox == cx && oy == cy && oz == cz) return;  // voxel already present
+  }
+  atomicAdd(failures, 1);  // probe chain exhausted: this point is dropped (gaussian_voxelmap_gpu.cu:67)
+}
+
+// voxel_coord_select_kernel (:77-90) + voxel id allocation (:57-60)
+__global__ void __launch_bounds__(256) assign_voxels_kernel(const float* __restrict__ points, const int* __restrict__ rep, uint32_t num_buckets,
+                                                            double inv_leaf, gp_voxel_bucket* __restrict__ buckets, int* __restrict__ voxel_coords,
+                                                            int* __restrict__ num_voxels) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= num_buckets) return;
+  const int r = rep[b];
+  int4 out = make_int4(0, 0, 0, -1);
+  if (r >= 0) {
+    int cx, cy, cz;
+    point_coord(points, r, inv_leaf, cx, cy, cz);
+    const int v = atomicAdd(num_voxels, 1);
+    out = make_int4(cx, cy, cz, v);
+    voxel_coords[3 * (size_t)v] = cx;
+    voxel_coords[3 * (size_t)v + 1] = cy;
+    voxel_coords[3 * (size_t)v + 2] = cz;
+  }
+  reinterpret_cast<int4*>(buckets)[b] = out;
+}
+
+// accumulate_points_kernel (:92-152): sums[v] = { sum(p - centre) (3), sum upper(C) (6) } in double, count, max intensity
+__global__ void __launch_bounds__(256) accumulate_kernel(const float* __restrict__ points, const float* __restrict__ covs,
+                                                         const float* __restrict__ intensities, int n, VoxelMapView map, double* __restrict__ sums,
+                                                         int* __restrict__ counts, unsigned int* __restrict__ intensity_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double px = (double)points[3 * (size_t)i], py = (double)points[3 * (size_t)i + 1], pz = (double)points[3 * (size_t)i + 2];
+  const int cx = fast_floor(px * map.inv_leaf), cy = fast_floor(py * map.inv_leaf), cz = fast_floor(pz * map.inv_leaf);
+  const int v = lookup_voxel(map, cx, cy, cz);
+  if (v < 0) return;  // dropped at table build
+  double ox, oy, oz;
+  voxel_center(map, cx, cy, cz, ox, oy, oz);
+  const float* c = covs + 9 * (size_t)i;
+  double* s = sums + 9 * (size_t)v;
+  unsafeAtomicAdd(s + 0, px - ox);
+  unsafeAtomicAdd(s + 1, py - oy);
+  unsafeAtomicAdd(s + 2, pz - oz);
+  unsafeAtomicAdd(s + 3, (double)c[0]);  // xx
+  unsafeAtomicAdd(s + 4, (double)c[3]);  // xy  (column-major (0,1))
+  unsafeAtomicAdd(s + 5, (double)c[6]);  // xz
+  unsafeAtomicAdd(s + 6, (double)c[4]);  // yy
+  unsafeAtomicAdd(s + 7, (double)c[7]);  // yz
+  unsafeAtomicAdd(s + 8, (double)c[8]);  // zz
+  atomicAdd(counts + v, 1);
+  if (intensities) atomicMax(intensity_bits + v, __float_as_uint(intensities[i]));  // max intensity (:138-139)
+}
+
+// finalize_voxels_kernel (:154-172): divide by the count; emit the gather record and the reference-visible arrays
+__global__ void __launch_bounds__(256) finalize_kernel(int num_voxels, double leaf, const int* __restrict__ voxel_coords, const double* __restrict__ sums,
+                                                       const int* __restrict__ counts, VoxelRecord* __restrict__ records,
+                                                       float* __restrict__ voxel_means, float* __restrict__ voxel_covs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_voxels) return;
+  const int n = counts[v];
+  const double inv_n = 1.0 / (double)n;
+  const double* s = sums + 9 * (size_t)v;
+  const double lx = s[0] * inv_n, ly = s[1] * inv_n, lz = s[2] * inv_n;
+  VoxelRecord rec;
+  rec.mean_local[0] = (float)lx;
+  rec.mean_local[1] = (float)ly;
+  rec.mean_local[2] = (float)lz;
+  rec.num_points = n;
+  for (int k = 0; k < 6; k++) rec.cov[k] = s[3 + k] / (double)n;
+  records[v] = rec;
+  const double ox = ((double)voxel_coords[3 * (size_t)v] + 0.5) * leaf;
+  const double oy = ((double)voxel_coords[3 * (size_t)v + 1] + 0.5) * leaf;
+  const double oz = ((double)voxel_coords[3 * (size_t)v + 2] + 0.5) * leaf;
+  voxel_means[3 * (size_t)v] = (float)(ox + lx);
+  voxel_means[3 * (size_t)v + 1] = (float)(oy + ly);
+  voxel_means[3 * (size_t)v + 2] = (float)(oz + lz);
+  float* c = voxel_covs + 9 * (size_t)v;
+  c[0] = (float)rec.cov[0];
+  c[1] = c[3] = (float)rec.cov[1];
+  c[2] = c[6] = (float)rec.cov[2];
+  c[4] = (float)rec.cov[3];
+  c[5] = c[7] = (float)rec.cov[4];
+  c[8] = (float)rec.cov[5];
+}
+
+// lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
+__global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ points, const float* __restrict__ normals, int n, VoxelMapView map,
+                                                     const double* __restrict__ pose, int* __restrict__ out, int* __restrict__ hit_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int v = -1;
+  if (i < n) {
+    const Pose T = load_pose(pose);
+    const double px = (double)points[3 * (size_t)i], py = (double)points[3 * (size_t)i + 1], pz = (double)points[3 * (size_t)i + 2];
+    const double qx = T.r00 * px + T.r01 * py + T.r02 * pz + T.tx;
+    const double qy = T.r10 * px + T.r11 * py + T.r12 * pz + T.ty;
+    const double qz = T.r20 * px + T.r21 * py + T.r22 * pz + T.tz;
+    bool rejected = false;
+    if (normals) rejected = surface_rejected(T, qx, qy, qz, normals + 3 * (size_t)i);
+    if (!rejected) v = lookup_voxel(map, fast_floor(qx * map.inv_leaf), fast_floor(qy * map.inv_leaf), fast_floor(qz * map.inv_leaf));
+    if (out) out[i] = v;
+  }
+  if (hit_count) {
+    const unsigned long long hits = __ballot(v >= 0);
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(hit_count, __popcll(hits));
+  }
+}
+
+}  // namespace gp
+
+gp::VoxelMapView gp_voxelmap::view() const {
+  gp::VoxelMapView v;
+  v.buckets = buckets.as<gp_voxel_bucket>();
+  v.records = records.as<gp::VoxelRecord>();
+  v.num_buckets = (uint32_t)info.num_buckets;
+  v.bucket_mask = (info.num_buckets > 0 && (info.num_buckets & (info.num_buckets - 1)) == 0) ? (uint32_t)(info.num_buckets - 1) : 0u;
+  v.max_scan = info.max_bucket_scan_count;
+  v.num_voxels = info.num_voxels;
+  v.inv_leaf = 1.0 / resolution;
+  v.leaf = resolution;
+  return v;
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(size_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+// GaussianVoxelData (types/gaussian_voxel_data.hpp:11-54): 56-byte on-disk record
+struct VoxelDataRecord {
+  int coord[3];
+  int num_points;
+  float mean[3];
+  float cov[6];  // xx xy xz yy yz zz
+  float intensity;
+};
+static_assert(sizeof(VoxelDataRecord) == 56, "GaussianVoxelData must be 56 B");
+
+int alloc_voxel_arrays(gp_voxelmap* m, int V) {
+  GP_TRY(m->records.alloc(sizeof(gp::VoxelRecord) * (size_t)V));
+  GP_TRY(m->num_points.alloc(sizeof(int) * (size_t)V));
+  GP_TRY(m->voxel_means.alloc(sizeof(float) * 3 * (size_t)V));
+  GP_TRY(m->voxel_covs.alloc(sizeof(float) * 9 * (size_t)V));
+  GP_TRY(m->voxel_intensities.alloc(sizeof(float) * (size_t)V));
+  return GP_OK;
+}
+
+}  // namespace
+
+static inline gp_voxelmap* ext(gp_voxelmap* m) { return m; }
+static inline const gp_voxelmap* ext(const gp_voxelmap* m) { return m; }
+
+extern "C" {
+
+int gp_voxelmap_create(double resolution, int init_num_buckets, int max_bucket_scan_count, double target_points_drop_rate, gp_stream_t stream,
+                       gp_voxelmap_t** out) {
+  if (!out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_create: null out");
+  if (!(resolution > 0.0) || init_num_buckets <= 0 || max_bucket_scan_count <= 0)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_create: resolution, init_num_buckets and max_bucket_scan_count must be positive");
+  auto* m = new gp_voxelmap;
+  m->resolution = resolution;
+  m->init_num_buckets = init_num_buckets;
+  m->target_points_drop_rate = target_points_drop_rate;
+  m->stream = (hipStream_t)stream;
+  m->info.num_voxels = 0;
+  m->info.num_buckets = init_num_buckets;
+  m->info.max_bucket_scan_count = max_bucket_scan_count;
+  m->info.voxel_resolution = (float)resolution;
+  *out = m;
+  return GP_OK;
+}
+
+int gp_voxelmap_destroy(gp_voxelmap_t* map) {
+  delete ext(map);
+  return GP_OK;
+}
+
+int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float* covs_dev, const float* intensities_dev, int n) {
+  if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: null map");
+  if (!points_dev || !covs_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "error: GPU points/covs not allocated!!");  // gaussian_voxelmap_gpu.cu:212-215
+  if (n < 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: negative size");
+  auto* m = ext(map);
+  hipStream_t s = m->stream;
+  const double inv_leaf = 1.0 / m->resolution;
+  m->offloaded = false;
+
+  // ---- create_bucket_table (:253-307): double the table until the drop rate is met ----
+  gp::DeviceArray rep, counters;
+  GP_TRY(counters.alloc(sizeof(int) * 2));
+  int h_counters[2] = {0, 0};
+  int64_t num_buckets = m->init_num_buckets;
+  for (;; num_buckets *= 2) {
+    if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
+    GP_TRY(rep.ensure(sizeof(int) * (size_t)num_buckets));
+    GP_HIP(hipMemsetAsync(rep.ptr, 0xff, sizeof(int) * (size_t)num_buckets, s));
+    GP_HIP(hipMemsetAsync(counters.ptr, 0, sizeof(int) * 2, s));
+    const uint32_t mask = ((num_buckets & (num_buckets - 1)) == 0) ? (uint32_t)(num_buckets - 1) : 0u;
+    if (n > 0) {
+      hipLaunchKernelGGL(gp::claim_buckets_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, points_dev, n, rep.as<int>(), (uint32_t)num_buckets, mask,
+                         m->info.max_bucket_scan_count, inv_leaf, counters.as<int>() + 1);
+      GP_HIP(hipGetLastError());
+    }
+    GP_HIP(hipMemcpyAsync(h_counters, counters.ptr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    if (h_counters[1] == 0 || (double)h_counters[1] / (double)n <= m->target_points_drop_rate) break;  // :288
+  }
+  m->info.num_buckets = (int)num_buckets;
+  GP_TRY(m->buckets.alloc(sizeof(gp_voxel_bucket) * (size_t)num_buckets));
+  // upper bound of the voxel count = number of claimed buckets <= min(n, num_buckets)
+  const size_t max_voxels = (size_t)std::min<int64_t>(std::max(n, 1), num_buckets);
+  GP_TRY(m->voxel_coords.alloc(sizeof(int) * 3 * max_voxels));
+  hipLaunchKernelGGL(gp::assign_voxels_kernel, dim3(grid_for((size_t)num_buckets)), dim3(kBlock), 0, s, points_dev, rep.as<int>(), (uint32_t)num_buckets,
+                     inv_leaf, m->buckets.as<gp_voxel_bucket>(), m->voxel_coords.as<int>(), counters.as<int>());
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipMemcpyAsync(h_counters, counters.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  const int V = h_counters[0];
+  m->info.num_voxels = V;
+
+  // ---- accumulate + finalize (:218-250) ----
+  GP_TRY(alloc_voxel_arrays(m, V));
+  gp::DeviceArray sums;
+  GP_TRY(sums.alloc(sizeof(double) * 9 * (size_t)std::max(V, 1)));
+  GP_HIP(hipMemsetAsync(sums.ptr, 0, sizeof(double) * 9 * (size_t)std::max(V, 1), s));
+  GP_HIP(hipMemsetAsync(m->num_points.ptr, 0, sizeof(int) * (size_t)std::max(V, 1), s));
+  GP_HIP(hipMemsetAsync(m->voxel_intensities.ptr, 0, sizeof(float) * (size_t)std::max(V, 1), s));
+  if (n > 0 && V > 0) {
+    hipLaunchKernelGGL(gp::accumulate_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, points_dev, covs_dev, intensities_dev, n, m->view(), sums.as<double>(),
+                       m->num_points.as<int>(), m->voxel_intensities.as<unsigned int>());
+    GP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gp::finalize_kernel, dim3(grid_for(V)), dim3(kBlock), 0, s, V, m->resolution, m->voxel_coords.as<int>(), sums.as<double>(),
+                       m->num_points.as<int>(), m->records.as<gp::VoxelRecord>(), m->voxel_means.as<float>(), m->voxel_covs.as<float>());
+    GP_HIP(hipGetLastError());
+  }
+  GP_HIP(hipStreamSynchronize(s));  // :250
+  return GP_OK;
+}
+
+int gp_voxelmap_info_get(const gp_voxelmap_t* map, gp_voxelmap_info* info) {
+  if (!map || !info) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_info_get: null");
+  *info = map->info;
+  return GP_OK;
+}
+
+double gp_voxelmap_resolution(const gp_voxelmap_t* map) { return map ? map->resolution : 0.0; }
+
+int gp_voxelmap_views_get(const gp_voxelmap_t* map, gp_voxelmap_views* views) {
+  if (!map || !views) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_views_get: null");
+  const bool on = map->loaded();
+  views->buckets = on ? map->buckets.as<gp_voxel_bucket>() : nullptr;
+  views->num_points = on ? map->num_points.as<int>() : nullptr;
+  views->voxel_means = on ? map->voxel_means.as<float>() : nullptr;
+  views->voxel_covs = on ? map->voxel_covs.as<float>() : nullptr;
+  views->voxel_intensities = on ? map->voxel_intensities.as<float>() : nullptr;
+  return GP_OK;
+}
+
+int gp_voxelmap_download(const gp_voxelmap_t* map, gp_voxel_bucket* buckets, int* num_points, float* means, float* covs, float* intensities) {
+  if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_download: null map");
+  if (!map->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "gp_voxelmap_download: voxel map is not on the GPU");
+  const size_t V = (size_t)map->info.num_voxels, B = (size_t)map->info.num_buckets;
+  hipStream_t s = map->stream;
+  if (buckets) GP_HIP(hipMemcpyAsync(buckets, map->buckets.ptr, sizeof(gp_voxel_bucket) * B, hipMemcpyDeviceToHost, s));
+  if (num_points && V) GP_HIP(hipMemcpyAsync(num_points, map->num_points.ptr, sizeof(int) * V, hipMemcpyDeviceToHost, s));
+  if (means && V) GP_HIP(hipMemcpyAsync(means, map->voxel_means.ptr, sizeof(float) * 3 * V, hipMemcpyDeviceToHost, s));
+  if (covs && V) GP_HIP(hipMemcpyAsync(covs, map->voxel_covs.ptr, sizeof(float) * 9 * V, hipMemcpyDeviceToHost, s));
+  if (intensities && V) GP_HIP(hipMemcpyAsync(intensities, map->voxel_intensities.ptr, sizeof(float) * V, hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  return GP_OK;
+}
+
+int gp_voxelmap_download_f64(const gp_voxelmap_t* map, int* coords, int* num_points, double* means, double* covs) {
+  if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_download_f64: null map");
+  if (!map->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "gp_voxelmap_download_f64: voxel map is not on the GPU");
+  const size_t V = (size_t)map->info.num_voxels;
+  if (V == 0) return GP_OK;
+  std::vector<gp::VoxelRecord> recs(V);
+  std::vector<int> h_coords(3 * V);
+  hipStream_t s = map->stream;
+  GP_HIP(hipMemcpyAsync(recs.data(), map->records.ptr, sizeof(gp::VoxelRecord) * V, hipMemcpyDeviceToHost, s));
+  GP_HIP(hipMemcpyAsync(h_coords.data(), ext(map)->voxel_coords.ptr, sizeof(int) * 3 * V, hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  for (size_t v = 0; v < V; v++) {
+    if (coords) memcpy(coords + 3 * v, h_coords.data() + 3 * v, sizeof(int) * 3);
+    if (num_points) num_points[v] = recs[v].num_points;
+    if (means)
+      for (int k = 0; k < 3; k++) means[3 * v + k] = ((double)h_coords[3 * v + k] + 0.5) * map->resolution + (double)recs[v].mean_local[k];
+    if (covs) {
+      double* c = covs + 9 * v;
+      const double* r = recs[v].cov;
+      c[0] = r[0];
+      c[1] = c[3] = r[1];
+      c[2] = c[6] = r[2];
+      c[4] = r[3];
+      c[5] = c[7] = r[4];
+      c[8] = r[5];
+    }
+  }
+  return GP_OK;
+}
+
+// host half of GaussianVoxelMapGPU::load (gaussian_voxelmap_gpu.cu:413-466): probe limit = max_bucket_scan_count,
+// table starts at 8192*4 buckets and doubles until every voxel fits
+int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, const int* num_points, const float* means, const float* covs6,
+                       const float* intensities) {
+  if (!map || num_voxels < 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_assign: bad arguments");
+  if (num_voxels > 0 && (!coords || !num_points || !means || !covs6)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_assign: null arrays");
+  auto* m = ext(map);
+  const size_t V = (size_t)num_voxels;
+  std::vector<gp_voxel_bucket> h_buckets;
+  const int max_scan = m->info.max_bucket_scan_count;
+  auto assign_buckets = [&](int64_t nb) {
+    h_buckets.assign((size_t)nb, gp_voxel_bucket{{0, 0, 0}, -1});
+    const uint32_t mask = ((nb & (nb - 1)) == 0) ? (uint32_t)(nb - 1) : 0u;
+    for (size_t i = 0; i < V; i++) {
+      const uint64_t hash = gp::coord_hash(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
+      bool inserted = false;
+      for (int j = 0; j < max_scan; j++) {
+        auto& b = h_buckets[gp::bucket_index(hash, j, (uint32_t)nb, mask)];
+        if (b.voxel_index < 0) {
+          b.coord[0] = coords[3 * i];
+          b.coord[1] = coords[3 * i + 1];
+          b.coord[2] = coords[3 * i + 2];
+          b.voxel_index = (int)i;
+          inserted = true;
+          break;
+        }
+      }
+      if (!inserted) return false;
+    }
+    return true;
+  };
+  int64_t nb = 8192 * 4;
+  for (; nb < (int64_t(1) << 30); nb *= 2)
+    if (assign_buckets(nb)) break;
+  if (nb >= (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_assign: could not build the bucket table");
+
+  std::vector<gp::VoxelRecord> recs(V);
+  std::vector<float> h_covs(9 * V), h_int(V, 0.0f);
+  for (size_t v = 0; v < V; v++) {
+    for (int k = 0; k < 3; k++) {
+      const double centre = ((double)coords[3 * v + k] + 0.5) * m->resolution;
+      recs[v].mean_local[k] = (float)((double)means[3 * v + k] - centre);
+    }
+    recs[v].num_points = num_points[v];
+    for (int k = 0; k < 6; k++) recs[v].cov[k] = (double)covs6[6 * v + k];
+    float* c = h_covs.data() + 9 * v;
+    const float* r = covs6 + 6 * v;
+    c[0] = r[0];
+    c[1] = c[3] = r[1];
+    c[2] = c[6] = r[2];
+    c[4] = r[3];
+    c[5] = c[7] = r[4];
+    c[8] = r[5];
+    if (intensities) h_int[v] = intensities[v];
+  }
+  m->info.num_voxels = num_voxels;
+  m->info.num_buckets = (int)nb;
+  m->offloaded = false;
+  hipStream_t s = m->stream;
+  GP_TRY(m->buckets.alloc(sizeof(gp_voxel_bucket) * (size_t)nb));
+  GP_TRY(alloc_voxel_arrays(m, num_voxels));
+  GP_TRY(m->voxel_coords.alloc(sizeof(int) * 3 * std::max<size_t>(V, 1)));
+  GP_HIP(hipMemcpyAsync(m->buckets.ptr, h_buckets.data(), sizeof(gp_voxel_bucket) * (size_t)nb, hipMemcpyHostToDevice, s));
+  if (V) {
+    GP_HIP(hipMemcpyAsync(m->records.ptr, recs.data(), sizeof(gp::VoxelRecord) * V, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(m->num_points.ptr, num_points, sizeof(int) * V, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(m->voxel_means.ptr, means, sizeof(float) * 3 * V, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(m->voxel_covs.ptr, h_covs.data(), sizeof(float) * 9 * V, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(m->voxel_intensities.ptr, h_int.data(), sizeof(float) * V, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(m->voxel_coords.ptr, coords, sizeof(int) * 3 * V, hipMemcpyHostToDevice, s));
+  }
+  GP_HIP(hipStreamSynchronize(s));
+  return GP_OK;
+}
+
+int gp_voxelmap_save_compact(const gp_voxelmap_t* map, const char* path) {
+  if (!map || !path) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_save_compact: null");
+  if (!map->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "gp_voxelmap_save_compact: voxel map is not on the GPU");
+  const size_t V = (size_t)map->info.num_voxels;
+  std::vector<int> h_coords(3 * V), h_np(V);
+  std::vector<float> h_means(3 * V), h_covs(9 * V), h_int(V);
+  hipStream_t s = map->stream;
+  if (V) {
+    GP_HIP(hipMemcpyAsync(h_coords.data(), ext(map)->voxel_coords.ptr, sizeof(int) * 3 * V, hipMemcpyDeviceToHost, s));
+    GP_TRY(gp_voxelmap_download(map, nullptr, h_np.data(), h_means.data(), h_covs.data(), h_int.data()));
+  }
+  std::vector<VoxelDataRecord> serial(V);
+  for (size_t v = 0; v < V; v++) {
+    auto& r = serial[v];
+    memcpy(r.coord, h_coords.data() + 3 * v, sizeof(int) * 3);
+    r.num_points = h_np[v];
+    memcpy(r.mean, h_means.data() + 3 * v, sizeof(float) * 3);
+    const float* c = h_covs.data() + 9 * v;
+    r.cov[0] = c[0];
+    r.cov[1] = c[3];
+    r.cov[2] = c[6];
+    r.cov[3] = c[4];
+    r.cov[4] = c[7];
+    r.cov[5] = c[8];
+    r.intensity = h_int[v];
+  }
+  std::ofstream ofs(path, std::ios::binary);
+  if (!ofs) return gp::fail(GP_ERROR_IO, std::string("error: failed to open ") + path);
+  // header of gaussian_voxelmap_gpu.cu:358-366
+  ofs << "compact " << 1 << std::endl;
+  ofs << "resolution " << map->resolution << std::endl;
+  ofs << "lru_count " << 0 << std::endl;
+  ofs << "lru_cycle " << 1 << std::endl;
+  ofs << "lru_thresh " << 1 << std::endl;
+  ofs << "voxel_bytes " << sizeof(VoxelDataRecord) << std::endl;
+  ofs << "num_voxels " << serial.size() << std::endl;
+  ofs.write(reinterpret_cast<const char*>(serial.data()), (std::streamsize)(sizeof(VoxelDataRecord) * serial.size()));
+  return ofs ? GP_OK : gp::fail(GP_ERROR_IO, std::string("error: failed to write ") + path);
+}
+
+int gp_voxelmap_load(const char* path, gp_stream_t stream, gp_voxelmap_t** out) {
+  if (!path || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_load: null");
+  std::ifstream ifs(path, std::ios::binary);
+  if (!ifs) return gp::fail(GP_ERROR_IO, std::string("error: failed to open ") + path);
+  std::string token;
+  bool compact = false;
+  double resolution = 0.0;
+  int lru = 0, voxel_bytes = 0, num_voxels = 0;
+  ifs >> token >> compact;
+  ifs >> token >> resolution;
+  ifs >> token >> lru;
+  ifs >> token >> lru;
+  ifs >> token >> lru;
+  ifs >> token >> voxel_bytes;
+  ifs >> token >> num_voxels;
+  std::getline(ifs, token);
+  if (!ifs || voxel_bytes != (int)sizeof(VoxelDataRecord) || num_voxels < 0) return gp::fail(GP_ERROR_IO, std::string("error: malformed voxel map file ") + path);
+  std::vector<VoxelDataRecord> flat((size_t)num_voxels);
+  ifs.read(reinterpret_cast<char*>(flat.data()), (std::streamsize)(sizeof(VoxelDataRecord) * flat.size()));
+  if (!ifs && num_voxels > 0) return gp::fail(GP_ERROR_IO, std::string("error: truncated voxel map file ") + path);
+  const size_t V = flat.size();
+  std::vector<int> coords(3 * V), np(V);
+  std::vector<float> means(3 * V), covs6(6 * V), ints(V);
+  for (size_t v = 0; v < V; v++) {
+    memcpy(coords.data() + 3 * v, flat[v].coord, sizeof(int) * 3);
+    np[v] = flat[v].num_points;
+    memcpy(means.data() + 3 * v, flat[v].mean, sizeof(float) * 3);
+    memcpy(covs6.data() + 6 * v, flat[v].cov, sizeof(float) * 6);
+    ints[v] = flat[v].intensity;
+  }
+  gp_voxelmap_t* m = nullptr;
+  GP_TRY(gp_voxelmap_create(resolution, 8192, 10, 0.1, stream, &m));  // :451
+  int rc = gp_voxelmap_assign(m, num_voxels, coords.data(), np.data(), means.data(), covs6.data(), ints.data());
+  if (rc != GP_OK) {
+    gp_voxelmap_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return GP_OK;
+}
+
+size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
+  if (!map) return 0;
+  // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records and coordinates this implementation adds
+  return (size_t)map->info.num_voxels * (sizeof(int) + sizeof(float) * 3 + sizeof(float) * 9 + sizeof(gp::VoxelRecord) + sizeof(int) * 3) +
+         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket);
+}
+
+int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map) { return map && map->loaded() ? 1 : 0; }
+
+static int to_host(std::vector<char>& dst, const gp::DeviceArray& src, size_t bytes, hipStream_t s) {
+  dst.resize(bytes);
+  if (bytes) GP_HIP(hipMemcpyAsync(dst.data(), src.ptr, bytes, hipMemcpyDeviceToHost, s));
+  return GP_OK;
+}
+
+static int to_device(gp::DeviceArray& dst, const std::vector<char>& src, hipStream_t s) {
+  GP_TRY(dst.alloc(src.size()));
+  if (!src.empty()) GP_HIP(hipMemcpyAsync(dst.ptr, src.data(), src.size(), hipMemcpyHostToDevice, s));
+  return GP_OK;
+}
+
+int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
+  if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_offload: null");
+  auto* m = ext(map);
+  if (!m->loaded()) return GP_ERROR_NOT_LOADED;  // reference returns false (:477-479)
+  hipStream_t s = (hipStream_t)stream;
+  const size_t V = (size_t)m->info.num_voxels, B = (size_t)m->info.num_buckets;
+  GP_TRY(to_host(m->h_buckets, m->buckets, sizeof(gp_voxel_bucket) * B, s));
+  GP_TRY(to_host(m->h_records, m->records, sizeof(gp::VoxelRecord) * V, s));
+  GP_TRY(to_host(m->h_num_points, m->num_points, sizeof(int) * V, s));
+  GP_TRY(to_host(m->h_means, m->voxel_means, sizeof(float) * 3 * V, s));
+  GP_TRY(to_host(m->h_covs, m->voxel_covs, sizeof(float) * 9 * V, s));
+  GP_TRY(to_host(m->h_intensities, m->voxel_intensities, sizeof(float) * V, s));
+  GP_TRY(to_host(m->h_coords, m->voxel_coords, sizeof(int) * 3 * V, s));
+  GP_HIP(hipStreamSynchronize(s));
+  m->buckets.release();
+  m->records.release();
+  m->num_points.release();
+  m->voxel_means.release();
+  m->voxel_covs.release();
+  m->voxel_intensities.release();
+  m->voxel_coords.release();
+  m->offloaded = true;
+  return GP_OK;
+}
+
+int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream) {
+  if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_reload: null");
+  auto* m = ext(map);
+  if (!m->offloaded) return GP_ERROR_INVALID_ARGUMENT;  // already on the GPU: reference returns false (:509-511)
+  hipStream_t s = (hipStream_t)stream;
+  GP_TRY(to_device(m->buckets, m->h_buckets, s));
+  GP_TRY(to_device(m->records, m->h_records, s));
+  GP_TRY(to_device(m->num_points, m->h_num_points, s));
+  GP_TRY(to_device(m->voxel_means, m->h_means, s));
+  GP_TRY(to_device(m->voxel_covs, m->h_covs, s));
+  GP_TRY(to_device(m->voxel_intensities, m->h_intensities, s));
+  GP_TRY(to_device(m->voxel_coords, m->h_coords, s));
+  GP_HIP(hipStreamSynchronize(s));
+  m->offloaded = false;
+  return GP_OK;
+}
+
+int gp_voxelmap_lookup(const gp_voxelmap_t* map, const float* points_dev, const float* normals_dev, int n, const double delta[16], int* voxel_indices_dev,
+                       gp_stream_t stream) {
+  if (!map || !points_dev || !delta || !voxel_indices_dev || n < 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_lookup: bad arguments");
+  if (!map->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "gp_voxelmap_lookup: voxel map is not on the GPU");
+  if (n == 0) return GP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gp::DeviceArray pose;
+  GP_TRY(pose.alloc(sizeof(double) * 16));
+  GP_HIP(hipMemcpyAsync(pose.ptr, delta, sizeof(double) * 16, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gp::lookup_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, points_dev, normals_dev, n, map->view(), pose.as<double>(), voxel_indices_dev,
+                     (int*)nullptr);
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipStreamSynchronize(s));
+  return GP_OK;
+}
+
+int gp_voxelmap_overlap(const gp_voxelmap_t* map, const float* points_dev, int n, const double delta[16], int* num_hits, gp_stream_t stream) {
+  if (!map || !points_dev || !delta || !num_hits || n < 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_overlap: bad arguments");
+  if (!map->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "gp_voxelmap_overlap: voxel map is not on the GPU");
+  *num_hits = 0;
+  if (n == 0) return GP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gp::DeviceArray scratch;
+  GP_TRY(scratch.alloc(sizeof(double) * 16 + sizeof(int) * 4));
+  int* d_count = reinterpret_cast<int*>(scratch.as<double>() + 16);
+  GP_HIP(hipMemcpyAsync(scratch.ptr, delta, sizeof(double) * 16, hipMemcpyHostToDevice, s));
+  GP_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
+  hipLaunchKernelGGL(gp::lookup_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, points_dev, (const float*)nullptr, n, map->view(), scratch.as<double>(),
+                     (int*)nullptr, d_count);
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipMemcpyAsync(num_hits, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  return GP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+/*
+ * gtsam_points_hip.h -- C-ABI of libgtsam_points_hip.so
+ *
+ * MI355X (gfx950) native replacement for the CUDA half of koide3/gtsam_points' VGICP
+ * path.  This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * reference tree, v1.2.1).  The reference-side binding a maintainer would add is shown
+ * in INTEGRATION.md; gtsam_points_amd/host/ holds a C++ mirror of the reference classes
+ * written against this header.
+ *
+ * Conventions
+ *   - All functions return 0 (GP_OK) on success, non-zero otherwise; gp_last_error()
+ *     returns a thread-local message.  (The reference logs CUDA errors to stderr and
+ *     continues, cuda/check_error.cu:8-18; the C++ mirror reproduces that on top of the
+ *     status codes.)
+ *   - Matrices are COLUMN-MAJOR (Eigen default).  A pose is double[16], the 4x4
+ *     T_target^-1 * T_source ("delta") -- the double-precision analogue of the
+ *     Eigen::Isometry3f the reference uploads (integrated_vgicp_factor_gpu.cpp:136-164).
+ *     Double is required for <=1e-5 parity with the CPU IntegratedVGICPFactor.
+ *   - Source clouds are caller-owned device arrays in the reference's GPU layout
+ *     (types/point_cloud.hpp:114-118): points float[N][3], covs float[N][9] (3x3,
+ *     symmetric), normals float[N][3] (optional).  The library never frees them.
+ *   - gp_stream_t is a hipStream_t (the reference's CUstream_st*).  NULL = default stream.
+ *   - Handles are thread-compatible (external synchronisation per handle).
+ */
+#ifndef GTSAM_POINTS_HIP_H
+#define GTSAM_POINTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GP_OK 0
+#define GP_ERROR_INVALID_ARGUMENT 1
+#define GP_ERROR_HIP 2
+#define GP_ERROR_NOT_LOADED 3 /* voxel map / cloud offloaded from the GPU */
+#define GP_ERROR_IO 4
+
+typedef void* gp_stream_t; /* hipStream_t */
+
+/* ---- runtime (replaces cuda/check_error, cuda/cuda_stream, cuda/cuda_memory, cuda_device_*) ---- */
+
+const char* gp_last_error(void);
+const char* gp_version(void);
+int gp_device_count(int* count);                                /* cuda/cuda_device_names */
+int gp_set_device(int device);
+int gp_get_device(int* device);
+int gp_device_name(int device, char* name, size_t name_len);    /* cuda_device_names() */
+int gp_device_synchronize(void);                                /* cuda/cuda_device_sync.cu */
+int gp_stream_create(gp_stream_t* stream);                      /* cuda/cuda_stream.cu (cudaStreamNonBlocking) */
+int gp_stream_destroy(gp_stream_t stream);
+int gp_stream_synchronize(gp_stream_t stream);
+int gp_malloc(void** ptr, size_t bytes);                        /* cuda/cuda_malloc_async.hpp */
+int gp_free(void* ptr);
+int gp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, gp_stream_t stream); /* async; caller syncs */
+int gp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, gp_stream_t stream); /* async; caller syncs */
+int gp_memset(void* dst_dev, int value, size_t bytes, gp_stream_t stream);
+int gp_host_malloc(void** ptr, size_t bytes);                   /* pinned staging, cuda/cuda_buffer.cu */
+int gp_host_free(void* ptr);
+
+/* ---- StreamRoundRobin / TempBufferManager / StreamTempBufferRoundRobin ----
+ * cuda/stream_roundrobin.hpp:14-31, cuda/stream_temp_buffer_roundrobin.hpp:19-65 */
+
+typedef struct gp_temp_buffer gp_temp_buffer_t;
+typedef struct gp_stream_pool gp_stream_pool_t;
+
+int gp_temp_buffer_create(size_t init_buffer_size, gp_temp_buffer_t** out);  /* TempBufferManager(size) */
+int gp_temp_buffer_get(gp_temp_buffer_t* tb, size_t size, void** dev_ptr);   /* get_buffer(): grow-only, x1.2 */
+int gp_temp_buffer_clear(gp_temp_buffer_t* tb);                              /* keep the newest buffer */
+int gp_temp_buffer_clear_all(gp_temp_buffer_t* tb);
+int gp_temp_buffer_destroy(gp_temp_buffer_t* tb);
+
+int gp_stream_pool_create(int num_streams, size_t init_buffer_size, gp_stream_pool_t** out); /* defaults 4, 512 KiB */
+int gp_stream_pool_get(gp_stream_pool_t* pool, gp_stream_t* stream, gp_temp_buffer_t** buffer); /* get_stream_buffer() */
+int gp_stream_pool_sync_all(gp_stream_pool_t* pool);
+int gp_stream_pool_clear(gp_stream_pool_t* pool);
+int gp_stream_pool_clear_all(gp_stream_pool_t* pool);
+int gp_stream_pool_destroy(gp_stream_pool_t* pool);
+
+/* ---- GaussianVoxelMapGPU : types/gaussian_voxelmap_gpu.hpp:20-114, .cu:25-573 ---- */
+
+/* VoxelMapInfo, gaussian_voxelmap_gpu.hpp:20-25 */
+typedef struct gp_voxelmap_info {
+  int num_voxels;
+  int num_buckets;
+  int max_bucket_scan_count;
+  float voxel_resolution;
+} gp_voxelmap_info;
+
+/* VoxelBucket {Eigen::Vector3i first; int second}, gaussian_voxelmap_gpu.hpp:30-33 (16 B) */
+typedef struct gp_voxel_bucket {
+  int coord[3];
+  int voxel_index; /* < 0 : empty */
+} gp_voxel_bucket;
+
+/* raw device views = the reference's public data members (gaussian_voxelmap_gpu.hpp:86-101) */
+typedef struct gp_voxelmap_views {
+  const gp_voxel_bucket* buckets; /* [num_buckets] */
+  const int* num_points;          /* [num_voxels] */
+  const float* voxel_means;       /* [num_voxels][3] */
+  const float* voxel_covs;        /* [num_voxels][9] column-major */
+  const float* voxel_intensities; /* [num_voxels] */
+} gp_voxelmap_views;
+
+typedef struct gp_voxelmap gp_voxelmap_t;
+
+/* GaussianVoxelMapGPU(resolution, init_num_buckets=16384, max_bucket_scan_count=10,
+ *                     target_points_drop_rate=1e-3, stream), gaussian_voxelmap_gpu.cu:176-198.
+ * resolution is double so that voxel coordinates are computed exactly as the CPU map does
+ * (fast_floor(x * (1.0/leaf)), gaussian_voxelmap_cpu.cpp:59-61). */
+int gp_voxelmap_create(double resolution, int init_num_buckets, int max_bucket_scan_count, double target_points_drop_rate, gp_stream_t stream, gp_voxelmap_t** out);
+int gp_voxelmap_destroy(gp_voxelmap_t* map);
+/* insert(const PointCloud&): one-shot build from device arrays, gaussian_voxelmap_gpu.cu:211-307.
+ * intensities_dev may be NULL (voxel intensities = 0, :232-240).  Synchronises the map's stream. */
+int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float* covs_dev, const float* intensities_dev, int num_points);
+int gp_voxelmap_info_get(const gp_voxelmap_t* map, gp_voxelmap_info* info);
+double gp_voxelmap_resolution(const gp_voxelmap_t* map);                       /* voxel_resolution() */
+int gp_voxelmap_views_get(const gp_voxelmap_t* map, gp_voxelmap_views* views);
+/* download_buckets / download_voxel_num_points / _means / _covs / _intensities, gaussian_voxelmap_gpu.cu:537-571.
+ * Host buffers sized from gp_voxelmap_info. Any pointer may be NULL. Synchronous. */
+int gp_voxelmap_download(const gp_voxelmap_t* map, gp_voxel_bucket* buckets, int* num_points, float* means, float* covs, float* intensities);
+/* full-precision voxel statistics (double means[V][3], covs[V][9] col-major) for parity tests */
+int gp_voxelmap_download_f64(const gp_voxelmap_t* map, int* coords, int* num_points, double* means, double* covs);
+/* rebuild from flat voxel records (the host half of GaussianVoxelMapGPU::load, gaussian_voxelmap_gpu.cu:372-467):
+ * coords int[V][3], num_points int[V], means float[V][3], covs6 float[V][6] (xx,xy,xz,yy,yz,zz), intensities float[V] */
+int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, const int* num_points, const float* means, const float* covs6, const float* intensities);
+/* save_compact(path) / load(path): text header + GaussianVoxelData records, types/gaussian_voxel_data.hpp:11-54,
+ * gaussian_voxelmap_gpu.cu:309-370, :372-467; interoperable with GaussianVoxelMapCPU::save_compact/load. */
+int gp_voxelmap_save_compact(const gp_voxelmap_t* map, const char* path);
+int gp_voxelmap_load(const char* path, gp_stream_t stream, gp_voxelmap_t** out);
+/* OffloadableGPU: memory_usage_gpu / loaded_on_gpu / offload_gpu / reload_gpu, gaussian_voxelmap_gpu.cu:469-535 */
+size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map);
+int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map);
+int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream);
+int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream);
+/* correspondence lookup of delta * p for every source point -> voxel index or -1
+ * (lookup_voxels_kernel, cuda/kernels/lookup_voxels.cuh:19-97); normals_dev!=NULL enables surface validation */
+int gp_voxelmap_lookup(const gp_voxelmap_t* map, const float* points_dev, const float* normals_dev, int num_points, const double delta[16], int* voxel_indices_dev, gp_stream_t stream);
+/* overlap_gpu(target, source, delta): number of source points that hit a voxel,
+ * types/gaussian_voxelmap_gpu_funcs.cu:192-236.  Synchronous. */
+int gp_voxelmap_overlap(const gp_voxelmap_t* map, const float* points_dev, int num_points, const double delta[16], int* num_hits, gp_stream_t stream);
+
+/* ---- LinearizedSystem6 : cuda/kernels/linearized_system.cuh:10-71 ----
+ * Same fields, double precision, no Eigen alignment padding; num_inliers is carried as a double so
+ * that a stack of records is a homogeneous f64 array (sum-reducible with one RCCL all-reduce).
+ * HessianFactor convention (applied by the caller): (H_target, H_target_source, -b_target, H_source, -b_source, error),
+ * integrated_vgicp_factor_gpu.cpp:199-213. */
+typedef struct gp_linearized6 {
+  double num_inliers;
+  double error;
+  double H_target[36];
+  double H_source[36];
+  double H_target_source[36];
+  double b_target[6];
+  double b_source[6];
+} gp_linearized6; /* 122 doubles = 976 B */
+
+/* the reference's own float record layout (496 B with Eigen's 16-B alignment), for callers that kept it */
+typedef struct gp_linearized6_f32 {
+  int num_inliers;
+  float error;
+  float pad_[2];
+  float H_target[36];
+  float H_source[36];
+  float H_target_source[36];
+  float b_target[6];
+  float b_source[6];
+} gp_linearized6_f32;
+void gp_linearized6_to_f32(const gp_linearized6* in, gp_linearized6_f32* out);
+
+/* ---- IntegratedVGICPDerivatives / IntegratedVGICPFactorGPU device half ----
+ * factors/integrated_vgicp_derivatives.cuh, integrated_vgicp_derivatives*.cu,
+ * factors/integrated_vgicp_factor_gpu.cpp:136-272 */
+
+typedef struct gp_vgicp_factor gp_vgicp_factor_t;
+
+/* IntegratedVGICPDerivatives(target, source, stream, temp_buffer), integrated_vgicp_derivatives.cu:19-47.
+ * Borrows the map handle and the three device arrays (normals_dev may be NULL).  stream==NULL -> the factor
+ * creates and owns a non-blocking stream (:36-39); temp_buffer==NULL -> it owns its scratch (:41-43). */
+int gp_vgicp_factor_create(const gp_voxelmap_t* target, const float* points_dev, const float* covs_dev, const float* normals_dev, int num_points, gp_stream_t stream, gp_temp_buffer_t* temp_buffer, gp_vgicp_factor_t** out);
+int gp_vgicp_factor_destroy(gp_vgicp_factor_t* f);
+int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable); /* set_enable_surface_validation */
+int gp_vgicp_factor_set_inlier_update_thresh(gp_vgicp_factor_t* f, double trans, double angle); /* kept for API parity; every linearise rescans all points */
+int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f);
+gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f);
+/* sizes the factor reports through NonlinearFactorGPU (integrated_vgicp_factor_gpu.cpp:136-150):
+ * 128 (pose, double[16]) / 976 (gp_linearized6) / 128 / 8 (double error) */
+size_t gp_vgicp_linearization_input_size(void);
+size_t gp_vgicp_linearization_output_size(void);
+size_t gp_vgicp_evaluation_input_size(void);
+size_t gp_vgicp_evaluation_output_size(void);
+/* issue_linearize(lin_input_cpu, lin_input_gpu, lin_output_gpu), integrated_vgicp_factor_gpu.cpp:229-237 +
+ * integrated_vgicp_derivatives_linearize.cu:23-55.  Asynchronous on the factor's stream.  pose_dev is the device
+ * copy of the pose (double[16]); out_dev receives one gp_linearized6.  No alignment beyond 8 B is assumed. */
+int gp_vgicp_factor_issue_linearize(gp_vgicp_factor_t* f, const double* pose_host, const double* pose_dev, gp_linearized6* out_dev);
+/* issue_compute_error(lin cpu, eval cpu, lin gpu, eval gpu, out gpu), integrated_vgicp_factor_gpu.cpp:247-263 +
+ * integrated_vgicp_derivatives_compute.cu:23-39: correspondences and fused covariance at pose_lin, residual at pose_eval. */
+int gp_vgicp_factor_issue_compute_error(gp_vgicp_factor_t* f, const double* pose_lin_host, const double* pose_eval_host, const double* pose_lin_dev, const double* pose_eval_dev, double* out_dev);
+int gp_vgicp_factor_sync(gp_vgicp_factor_t* f);                               /* sync_stream() */
+/* synchronous fall-backs (IntegratedVGICPDerivatives::linearize / compute_error, integrated_vgicp_derivatives.cu:80-109) */
+int gp_vgicp_factor_linearize(gp_vgicp_factor_t* f, const double pose[16], gp_linearized6* out_host);
+int gp_vgicp_factor_compute_error(gp_vgicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host);
+
+/* ---- NonlinearFactorSetGPU fast path: one batched launch over a factor table ----
+ * replaces the per-factor loop of cuda/nonlinear_factor_set_gpu.cpp:64-218 (F x {reduce, select} launches,
+ * 2F stream syncs) by: one H2D of all poses, one tiled kernel over all factors' points, one finalize kernel,
+ * one D2H. */
+
+typedef struct gp_vgicp_batch gp_vgicp_batch_t;
+
+int gp_vgicp_batch_create(gp_vgicp_factor_t* const* factors, int num_factors, gp_stream_t stream, gp_vgicp_batch_t** out);
+int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch);
+int gp_vgicp_batch_size(const gp_vgicp_batch_t* batch);
+int64_t gp_vgicp_batch_total_points(const gp_vgicp_batch_t* batch);
+int64_t gp_vgicp_batch_algorithmic_bytes(const gp_vgicp_batch_t* batch); /* sum 48 N + 16 buckets + 52 voxels + 560 */
+/* asynchronous on the batch stream; poses_host = double[F][16]; out_dev = gp_linearized6[F] in device memory */
+int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_dev);
+int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* batch, const double* poses_lin_host, const double* poses_eval_host, double* out_dev);
+int gp_vgicp_batch_sync(gp_vgicp_batch_t* batch);
+/* synchronous: upload poses, compute, download F records into out_host */
+int gp_vgicp_batch_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_host);
+int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* batch, const double* poses_lin_host, const double* poses_eval_host, double* out_host);
+/* timing hook for bench.py: re-runs only the device work (pose upload excluded) `iters` times on the batch stream
+ * between two hipEvents and returns the average milliseconds per pass, and separately the two kernels' times */
+int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* batch, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTSAM_POINTS_HIP_H */

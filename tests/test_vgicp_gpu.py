@@ -1,0 +1,281 @@
+"""GPU parity tests of the VGICP hot path: HIP (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerance: the north-star gate is <= 1e-5 relative on H and b; the HIP path computes in f64 and stores only the voxel
+mean offset in f32, so these tests hold it to 1e-7 (PARITY_TOL) -- two orders tighter than required."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import BLOCKS, assert_linearized_close, expmap, lm_optimize, pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+PARITY_TOL = 1e-7
+
+
+def _build(gpu, d, res, drop_rate=0.0, **kw):
+    tgt = gpu.PointCloudGPU(d["target_points"], d["target_covs"])
+    src = gpu.PointCloudGPU(d["source_points"], d["source_covs"], normals=d.get("source_normals"))
+    vm = gpu.GaussianVoxelMapGPU(res, target_points_drop_rate=drop_rate, **kw)
+    vm.insert(tgt)
+    return tgt, src, vm
+
+
+def _oracle(d, res, threads=4):
+    vm = oracle.OracleVoxelMap(res)
+    vm.insert(d["target_points"], d["target_covs"])
+    return vm, oracle.OracleVGICPFactor(vm, d["source_points"], d["source_covs"], threads)
+
+
+def _sync_linearize(gpu, factor, delta):
+    rec = gpu._capi.Linearized6()
+    gpu._capi.check(factor._lib.gp_vgicp_factor_linearize(factor._h, gpu.types._pose16(delta), C.byref(rec)), "linearize")
+    return gpu.LinearizedSystem6(rec)
+
+
+@pytest.mark.parametrize("name,res", [("kitti00_dec8_r0.5_identity", 0.5), ("kitti00_dec8_r0.5_c1b", 0.5), ("kitti00_dec8_r1.0_c1b", 1.0)])
+def test_linearize_matches_golden_and_oracle(gpu, kitti00, golden, name, res):
+    g = golden[name]
+    tgt, src, vm = _build(gpu, kitti00, res)
+    assert vm.voxelmap_info.num_voxels == g["num_voxels"]
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    L = _sync_linearize(gpu, f, np.array(g["delta"]))
+    assert_linearized_close(L, g, PARITY_TOL, name + " vs golden")
+    _, fo = _oracle(kitti00, res)
+    assert_linearized_close(L, fo.linearize(np.array(g["delta"])), PARITY_TOL, name + " vs oracle")
+    if "delta_eval" in g:
+        out = C.c_double()
+        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(np.array(g["delta"])), gpu.types._pose16(np.array(g["delta_eval"])), C.byref(out)), "error")
+        assert abs(out.value - g["error_eval"]) <= PARITY_TOL * abs(g["error_eval"])
+
+
+def test_kitti07_pairs_match_golden(gpu, kitti07, golden):
+    for i in range(4):
+        g = golden[f"kitti07_dec4_{i}_{i+1}_r1.0"]
+        d = dict(target_points=kitti07[f"points_{i}"], target_covs=kitti07[f"covs_{i}"], source_points=kitti07[f"points_{i+1}"], source_covs=kitti07[f"covs_{i+1}"])
+        _, src, vm = _build(gpu, d, 1.0)
+        f = gpu.IntegratedVGICPFactorGPU(i, i + 1, vm, src)
+        assert_linearized_close(_sync_linearize(gpu, f, np.array(g["delta"])), g, PARITY_TOL, g["name"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1023, 1024, 1025, 4097])
+def test_ragged_sizes(gpu, kitti00, n):
+    """empty, single-point, wave/tile boundary sizes"""
+    d = dict(kitti00)
+    d["source_points"] = kitti00["source_points"][:n]
+    d["source_covs"] = kitti00["source_covs"][:n]
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    _, src, vm = _build(gpu, d, 0.5)
+    if n == 0:
+        src = gpu.PointCloudGPU(np.zeros((1, 3), np.float32), np.zeros((1, 3, 3), np.float32))
+        src.num_points = 0
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    L = _sync_linearize(gpu, f, delta)
+    _, fo = _oracle(d, 0.5, 1)
+    Lo = fo.linearize(delta)
+    assert L.num_inliers == Lo.num_inliers
+    if Lo.num_inliers == 0:
+        assert L.error == 0.0 and np.abs(L.H_source).max() == 0.0
+    else:
+        assert_linearized_close(L, Lo, PARITY_TOL, f"n={n}")
+
+
+def test_factor_set_batch_equals_per_factor_and_oracle(gpu, kitti07):
+    """NonlinearFactorSetGPU fast path (one batched launch) == per-factor sync path == oracle; error() after linearize()"""
+    poses = kitti07["poses"]
+    rng = np.random.default_rng(8191)
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(5)]
+    maps = []
+    for c in clouds:
+        vm = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        vm.insert(c)
+        maps.append(vm)
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4), (0, 3), (1, 4), (0, 4)]
+    pool = gpu.StreamTempBufferRoundRobin(8)
+    factors = []
+    for i, j in pairs:
+        s, b = pool.get_stream_buffer()
+        factors.append(gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j], s, b))
+    values = {k: poses[k] @ expmap(rng.uniform(-0.05, 0.05, 6)) for k in range(5)}
+    values2 = {k: values[k] @ expmap(rng.uniform(-0.01, 0.01, 6)) for k in range(5)}
+
+    fset = gpu.NonlinearFactorSetGPU()
+    fset.add(factors)
+    assert fset.size() == len(pairs)
+    lin = fset.calc_linear_factors(values)
+    assert fset.linearization_count() == len(pairs)
+    fset.error(values2)
+    errs = [f.error(values2) for f in factors]
+    assert fset.evaluation_count() == len(pairs)
+
+    for (i, j), f, hf, e in zip(pairs, factors, lin, errs):
+        delta = oracle.calc_delta(values[i], values[j])
+        omap = oracle.OracleVoxelMap(1.0)
+        omap.insert(kitti07[f"points_{i}"], kitti07[f"covs_{i}"])
+        fo = oracle.OracleVGICPFactor(omap, kitti07[f"points_{j}"], kitti07[f"covs_{j}"], 2)
+        Lo = fo.linearize(delta)
+        assert rel_err(hf.G[(0, 0)], Lo.H_target) < PARITY_TOL
+        assert rel_err(hf.G[(0, 1)], Lo.H_target_source) < PARITY_TOL
+        assert rel_err(hf.G[(1, 1)], Lo.H_source) < PARITY_TOL
+        assert rel_err(hf.g[0], -Lo.b_target) < PARITY_TOL and rel_err(hf.g[1], -Lo.b_source) < PARITY_TOL
+        assert abs(hf.f - Lo.error) < PARITY_TOL * Lo.error
+        assert f.num_inliers() == Lo.num_inliers
+        eo = fo.error(oracle.calc_delta(values2[i], values2[j]))
+        assert abs(e - eo) < PARITY_TOL * eo
+        # the synchronous per-factor fall-back gives the same record bit-for-bit (same kernels, same order)
+        Ls = _sync_linearize(gpu, f, delta)
+        for k in BLOCKS:
+            assert np.array_equal(getattr(Ls, k), {"H_target": hf.G[(0, 0)], "H_source": hf.G[(1, 1)], "H_target_source": hf.G[(0, 1)], "b_target": -hf.g[0], "b_source": -hf.g[1]}[k])
+    pool.sync_all()
+
+
+def test_generic_nonlinear_factor_gpu_protocol(gpu, kitti00):
+    """third-party NonlinearFactorGPU subclasses still work through the generic staging-buffer protocol
+    (cuda/nonlinear_factor_set_gpu.cpp:64-139): wrap the VGICP factor so that the set cannot take its fast path"""
+
+    class Wrapped(gpu.NonlinearFactorGPU):
+        def __init__(self, inner):
+            super().__init__(inner.keys())
+            self.inner = inner
+
+        def __getattr__(self, name):
+            return getattr(self.inner, name)
+
+        linearization_input_size = lambda self: self.inner.linearization_input_size()
+        linearization_output_size = lambda self: self.inner.linearization_output_size()
+        evaluation_input_size = lambda self: self.inner.evaluation_input_size()
+        evaluation_output_size = lambda self: self.inner.evaluation_output_size()
+        set_linearization_point = lambda self, v, b: self.inner.set_linearization_point(v, b)
+        issue_linearize = lambda self, a, b, c: self.inner.issue_linearize(a, b, c)
+        store_linearized = lambda self, b: self.inner.store_linearized(b)
+        set_evaluation_point = lambda self, v, b: self.inner.set_evaluation_point(v, b)
+        issue_compute_error = lambda self, a, b, c, d, e: self.inner.issue_compute_error(a, b, c, d, e)
+        store_computed_error = lambda self, b: self.inner.store_computed_error(b)
+        sync = lambda self: self.inner.sync()
+
+    _, src, vm = _build(gpu, kitti00, 0.5)
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    values = {0: np.eye(4), 1: expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])}
+    values2 = {0: np.eye(4), 1: expmap([0.012, -0.018, 0.013, 0.12, -0.04, 0.02])}
+    fset = gpu.NonlinearFactorSetGPU()
+    fset.add(Wrapped(f))
+    fset.linearize(values)
+    hf = f.linearize(values)
+    fset.error(values2)
+    e = f.error(values2)
+    _, fo = _oracle(kitti00, 0.5)
+    Lo = fo.linearize(values[1])
+    assert rel_err(hf.G[(1, 1)], Lo.H_source) < PARITY_TOL and rel_err(hf.g[1], -Lo.b_source) < PARITY_TOL
+    assert abs(e - fo.error(values2[1])) < PARITY_TOL * e
+
+
+def test_unary_factor_and_caching_protocol(gpu, kitti00, capsys):
+    _, src, vm = _build(gpu, kitti00, 0.5)
+    T_fixed = expmap([0.0, 0.0, 0.1, 1.0, 2.0, 0.0])
+    f = gpu.IntegratedVGICPFactorGPU.unary(T_fixed, 7, vm, src)
+    assert f.keys() == [7] and f.dim() == 6
+    values = {7: T_fixed @ expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])}
+    hf = f.linearize(values)  # no hook -> sync path + the reference's warning (integrated_vgicp_factor_gpu.cpp:195)
+    assert "sync mode" in capsys.readouterr().err
+    _, fo = _oracle(kitti00, 0.5)
+    Lo = fo.linearize(np.linalg.inv(T_fixed) @ values[7])
+    assert rel_err(hf.G[(0, 0)], Lo.H_source) < PARITY_TOL and rel_err(hf.g[0], -Lo.b_source) < PARITY_TOL
+    assert f.num_inliers() == Lo.num_inliers and abs(f.inlier_fraction() - Lo.num_inliers / src.size()) < 1e-12
+    c = f.clone()
+    assert c.keys() == [7] and not c.is_binary
+
+
+def test_surface_validation(gpu):
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_pair(20000, 40000, seed=5)
+    _, src, vm = _build(gpu, d, 0.5)
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    delta = d["T_true"]
+    L0 = _sync_linearize(gpu, f, delta)
+    f.set_enable_surface_validation(True)
+    L1 = _sync_linearize(gpu, f, delta)
+    # restate lookup_voxels.cuh:41-50 in numpy and linearise the surviving subset with the oracle
+    p = d["source_points"].astype(np.float64)
+    n = d["source_normals"].astype(np.float64)
+    q = p @ delta[:3, :3].T + delta[:3, 3]
+    tn = n @ delta[:3, :3].T
+    keep = ~(((q / np.linalg.norm(q, axis=1, keepdims=True)) * tn).sum(1) > 0.174)
+    omap = oracle.OracleVoxelMap(0.5)
+    omap.insert(d["target_points"], d["target_covs"])
+    Lo = oracle.OracleVGICPFactor(omap, d["source_points"][keep], d["source_covs"][keep], 2).linearize(delta)
+    assert_linearized_close(L1, Lo, PARITY_TOL, "surface validation")
+    assert L1.num_inliers <= L0.num_inliers
+    # a cloud without normals refuses the switch (integrated_vgicp_factor_gpu.hpp:84-86)
+    src2 = gpu.PointCloudGPU(d["source_points"], d["source_covs"])
+    f2 = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src2)
+    with pytest.raises(gpu.GPError):
+        f2.set_enable_surface_validation(True)
+
+
+def test_linearity_and_determinism_at_1m(gpu):
+    """BASELINE configs[1] size: 1 M source points vs a 2 M-point voxel map.  Size-independent properties:
+    (i) two launches give bit-identical records (no atomics in the reduction); (ii) the record of the whole cloud equals
+    the sum of the records of its two halves; (iii) H blocks symmetric PSD and tied by the adjoint identities;
+    plus (iv) direct parity with the oracle (it finishes a 1 M linearise in well under a second)."""
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_c2_workload()
+    _, src, vm = _build(gpu, d, 0.5)
+    delta = d["T_true"] @ expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    L = _sync_linearize(gpu, f, delta)
+    L2 = _sync_linearize(gpu, f, delta)
+    for k in BLOCKS:
+        assert np.array_equal(getattr(L, k), getattr(L2, k))
+    h = len(d["source_points"]) // 2 + 12345
+    halves = []
+    for sl in [slice(0, h), slice(h, None)]:
+        s = gpu.PointCloudGPU(d["source_points"][sl], d["source_covs"][sl])
+        halves.append((_sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, s), delta), s))
+    for k in BLOCKS:
+        assert rel_err(getattr(halves[0][0], k) + getattr(halves[1][0], k), getattr(L, k)) < 1e-12
+    assert halves[0][0].num_inliers + halves[1][0].num_inliers == L.num_inliers
+    assert rel_err(L.H_source, L.H_source.T) < 1e-12 and np.linalg.eigvalsh(L.H_source).min() > 0
+    vo, fo = _oracle(d, 0.5, oracle.max_threads())
+    assert vm.voxelmap_info.num_voxels == vo.num_voxels
+    assert_linearized_close(L, fo.linearize(delta), PARITY_TOL, "1M")
+    assert L.num_inliers > 0.5 * len(d["source_points"])
+
+
+def test_alignment_gate_gpu(gpu, kitti07):
+    """the reference's VGICP_CUDA end-to-end gate (test_matching_cost_factors.cpp:196-230): LM through the
+    linearisation hook, rot < 0.015 rad, trans < 0.15 m"""
+    poses = kitti07["poses"]
+    rng = np.random.default_rng(8191)
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(5)]
+    maps = []
+    for c in clouds:
+        vm = gpu.GaussianVoxelMapGPU(1.0)  # reference defaults, incl. target_points_drop_rate = 1e-3
+        vm.insert(c)
+        maps.append(vm)
+    pool = gpu.StreamTempBufferRoundRobin(32)
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4)]
+    factors = []
+    for i, j in pairs:
+        s, b = pool.get_stream_buffer()
+        factors.append(gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j], s, b))
+    gpu.LinearizationHook.hook_constructors.clear()
+    gpu.LinearizationHook.register_hook(gpu.create_nonlinear_factor_set_gpu)
+    hook = gpu.LinearizationHook(factors)
+    values = {k: poses[k] @ expmap(rng.uniform(-0.1, 0.1, 6)) if k > 0 else poses[0].copy() for k in range(5)}
+
+    def lin(vals):
+        hook.linearize(vals)
+        return [f.linearize(vals) for f in factors]
+
+    def err(vals):
+        hook.error(vals)
+        return sum(f.error(vals) for f in factors)
+
+    est = lm_optimize(lin, err, values, list(range(5)), fixed=(0,))
+    for k in range(1, 5):
+        ang, trans = pose_error(np.linalg.inv(est[0]) @ est[k], np.linalg.inv(poses[0]) @ poses[k])
+        assert ang < 0.015 and trans < 0.15, (k, ang, trans)
+    assert hook.linearization_count() > 0 and hook.evaluation_count() > 0

@@ -1,0 +1,167 @@
+"""GPU tests of GaussianVoxelMapGPU against the CPU map (oracle) -- modelled on the reference's
+src/test/test_voxelmap.cpp (VoxelMapGPU :211-259, _Intensity :261-299, _IO :301-432)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import expmap
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(gpu, points, covs, res, intensities=None, **kw):
+    cloud = gpu.PointCloudGPU(points, covs, intensities=intensities)
+    vm = gpu.GaussianVoxelMapGPU(res, target_points_drop_rate=0.0, **kw)
+    vm.insert(cloud)
+    om = oracle.OracleVoxelMap(res)
+    om.insert(points, covs, intensities)
+    return cloud, vm, om
+
+
+def _reference_lookup(buckets, info, coord):
+    """lookup_voxel of cuda/kernels/vector3_hash.cuh:53-76 restated on the downloaded table"""
+    M, mask = 0xC6A4A7935BD1E995, (1 << 64) - 1
+
+    def combine(h, k):
+        k = (k * M) & mask
+        k ^= k >> 47
+        k = (k * M) & mask
+        h ^= k
+        h = (h * M) & mask
+        return (h + 0xE6546B64) & mask
+
+    h = 0
+    for c in coord:
+        h = combine(h, int(c) & mask)
+    for i in range(info.max_bucket_scan_count):
+        b = buckets[((h + i) & mask) % info.num_buckets]
+        if b[3] < 0:
+            return -1
+        if tuple(b[:3]) == tuple(int(c) for c in coord):
+            return int(b[3])
+    return -1
+
+
+@pytest.mark.parametrize("res", [0.5, 1.0, 0.3])
+def test_voxel_statistics_match_cpu_map(gpu, kitti00, res):
+    _, vm, om = _maps(gpu, kitti00["target_points"], kitti00["target_covs"], res)
+    info = vm.voxelmap_info
+    assert info.num_voxels == om.num_voxels
+    assert abs(info.voxel_resolution - res) < 1e-7 and vm.voxel_resolution() == res
+    coords, num_points, means, covs = vm.download_f64()
+    oc, on, omean, ocov, _ = om.export()
+    order = {tuple(c): i for i, c in enumerate(oc.tolist())}
+    idx = np.array([order[tuple(c)] for c in coords.tolist()])
+    assert len(set(idx.tolist())) == om.num_voxels  # same voxel set, each exactly once
+    np.testing.assert_array_equal(num_points, on[idx])
+    assert np.abs(means - omean[idx]).max() < 1e-7 * max(res, 1.0)  # f32 offset from the voxel centre
+    assert np.abs(covs - ocov[idx]).max() < 1e-13
+    dl = vm.download()
+    assert np.isfinite(dl["means"]).all() and np.isfinite(dl["covs"]).all()  # test_voxelmap.cpp:242-250
+    assert np.abs(dl["means"] - omean[idx]).max() < 1e-5 and np.abs(dl["covs"] - ocov[idx]).max() < 1e-6
+    assert (dl["intensities"] == 0).all()  # no intensities given (test_voxelmap.cpp:271-277)
+
+
+def test_buckets_unique_in_range_and_findable(gpu, kitti00):
+    """test_voxelmap.cpp:352-408: bucket entries unique + in range, every mean findable via its floor coord"""
+    _, vm, _ = _maps(gpu, kitti00["target_points"], kitti00["target_covs"], 0.5)
+    info = vm.voxelmap_info
+    dl = vm.download()
+    b = dl["buckets"]
+    used = b[b[:, 3] >= 0]
+    assert len(used) == info.num_voxels
+    assert sorted(used[:, 3].tolist()) == list(range(info.num_voxels))
+    assert len({tuple(r[:3]) for r in used.tolist()}) == info.num_voxels
+    coords, _, means64, _ = vm.download_f64()
+    for v in list(range(0, info.num_voxels, 97)) + [info.num_voxels - 1]:
+        c = np.floor(means64[v] / 0.5).astype(int)
+        assert tuple(c) == tuple(coords[v])
+        assert _reference_lookup(b, info, c) == v
+
+
+def test_overlap_matches_cpu(gpu, kitti00):
+    """self-overlap >= 0.99; |overlap_cpu - overlap_gpu| < 0.01 under a random pose (test_voxelmap.cpp:226-239) --
+    here the hit COUNT is identical because both floor in double"""
+    _, vm, om = _maps(gpu, kitti00["target_points"], kitti00["target_covs"], 0.5)
+    tgt = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"])
+    src = gpu.PointCloudGPU(kitti00["source_points"], kitti00["source_covs"])
+    assert gpu.overlap_gpu(vm, tgt) >= 0.99
+    for xi in [np.zeros(6), [0.01, -0.02, 0.015, 0.10, -0.05, 0.03], [0.2, -0.1, 0.3, 1.0, -2.0, 0.5]]:
+        T = expmap(xi)
+        n = len(kitti00["source_points"])
+        assert round(gpu.overlap_gpu(vm, src, T) * n) == round(om.overlap(kitti00["source_points"], T) * n)
+    idx = vm.lookup(src, np.eye(4))
+    oidx = np.array([om.lookup_coord(np.floor(p.astype(np.float64) / 0.5).astype(int)) for p in kitti00["source_points"][:500]])
+    assert ((idx[:500] >= 0) == (oidx >= 0)).all()
+
+
+def test_intensity_max_semantics(gpu, kitti00):
+    """voxel intensity = max of the inserted intensities (atomicMax on the bits, gaussian_voxelmap_gpu.cu:138-139;
+    test_voxelmap.cpp:279-298: within [128, 255])"""
+    rng = np.random.default_rng(3)
+    p, c = kitti00["target_points"][:8000], kitti00["target_covs"][:8000]
+    it = rng.uniform(128.0, 255.0, len(p)).astype(np.float32)
+    _, vm, om = _maps(gpu, p, c, 1.0, intensities=it)
+    coords, _, _, _ = vm.download_f64()
+    oc, _, _, _, oint = om.export()
+    order = {tuple(k): i for i, k in enumerate(oc.tolist())}
+    got = vm.download()["intensities"]
+    assert (got >= 128.0).all() and (got <= 255.0).all()
+    np.testing.assert_array_equal(got, np.array([oint[order[tuple(k)]] for k in coords.tolist()], dtype=np.float32))
+
+
+def test_save_load_roundtrip_and_offload(gpu, kitti00, tmp_path):
+    """save_compact -> load: same voxel count, means/covs within 1e-3, overlap within 1e-3 (test_voxelmap.cpp:326-431);
+    offload_gpu -> device views null -> reload_gpu restores (OffloadableGPU)"""
+    _, vm, _ = _maps(gpu, kitti00["target_points"], kitti00["target_covs"], 0.5)
+    src = gpu.PointCloudGPU(kitti00["source_points"], kitti00["source_covs"])
+    path = os.path.join(tmp_path, "voxelmap.bin")
+    vm.save_compact(path)
+    header = open(path, "rb").read(200).split(b"\n")
+    assert header[0] == b"compact 1" and header[1] == b"resolution 0.5" and header[5] == b"voxel_bytes 56"
+    vm2 = gpu.GaussianVoxelMapGPU.load(path)
+    assert vm2 is not None and vm2.voxelmap_info.num_voxels == vm.voxelmap_info.num_voxels and vm2.voxel_resolution() == 0.5
+    c1, n1, m1, v1 = vm.download_f64()
+    c2, n2, m2, v2 = vm2.download_f64()
+    o1 = {tuple(c): i for i, c in enumerate(c1.tolist())}
+    idx = np.array([o1[tuple(c)] for c in c2.tolist()])
+    np.testing.assert_array_equal(n2, n1[idx])
+    assert np.abs(m2 - m1[idx]).max() < 1e-3 and np.abs(v2 - v1[idx]).max() < 1e-3
+    T = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    assert abs(gpu.overlap_gpu(vm, src, T) - gpu.overlap_gpu(vm2, src, T)) < 1e-3
+    assert gpu.GaussianVoxelMapGPU.load(os.path.join(tmp_path, "missing.bin")) is None
+    # offload / reload
+    before = gpu.overlap_gpu(vm, src, T)
+    assert vm.loaded_on_gpu() and vm.memory_usage_gpu() > 0
+    assert vm.offload_gpu() and not vm.loaded_on_gpu() and not vm.offload_gpu()
+    assert vm.views().buckets is None
+    with pytest.raises(gpu.GPError):
+        gpu.overlap_gpu(vm, src, T)
+    assert vm.reload_gpu() and vm.loaded_on_gpu() and not vm.reload_gpu()
+    assert gpu.overlap_gpu(vm, src, T) == before
+
+
+def test_table_growth_drop_rate_and_empty(gpu, kitti00):
+    """tiny initial table: grows by doubling until nothing is dropped; default drop rate 1e-3 may drop <= 0.1 % of
+    points (gaussian_voxelmap_gpu.cu:269-291); empty cloud gives an empty map"""
+    p, c = kitti00["target_points"], kitti00["target_covs"]
+    _, vm, om = _maps(gpu, p, c, 0.5, init_num_buckets=64, max_bucket_scan_count=4)
+    info = vm.voxelmap_info
+    assert info.num_voxels == om.num_voxels and info.num_buckets >= info.num_voxels and info.num_buckets % 64 == 0
+    _, vm3, _ = _maps(gpu, p, c, 0.5, init_num_buckets=1000)  # non power-of-two table: modulo path
+    assert vm3.voxelmap_info.num_voxels == om.num_voxels and vm3.voxelmap_info.num_buckets % 1000 == 0
+    cloud = gpu.PointCloudGPU(p, c)
+    vmd = gpu.GaussianVoxelMapGPU(0.5, init_num_buckets=8192, target_points_drop_rate=1e-3)
+    vmd.insert(cloud)
+    kept = vmd.download()["num_points"].sum()
+    assert kept >= (1 - 1e-3) * len(p) and vmd.voxelmap_info.num_voxels <= om.num_voxels
+    empty = gpu.PointCloudGPU(np.zeros((1, 3), np.float32), np.zeros((1, 3, 3), np.float32))
+    empty.num_points = 0
+    vme = gpu.GaussianVoxelMapGPU(0.5)
+    vme.insert(empty)
+    assert vme.voxelmap_info.num_voxels == 0
+    assert gpu.overlap_gpu(vme, cloud) == 0.0
+    with pytest.raises(gpu.GPError):
+        vme.insert(gpu.PointCloudGPU(p))  # no covs: the reference abort()s (gaussian_voxelmap_gpu.cu:212-215)
