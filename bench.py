@@ -131,7 +131,7 @@ def main():
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_tile_kernel<false>",
+        kernel="vgicp_tile_kernel<MODE_LIN>",
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",

@@ -129,11 +129,17 @@ enum : int {
   ACC_QXMR = 23, // 3
   ACC_MR = 26,   // 3
   ACC_SIZE = 29,
-  ACC_STRIDE = 32
-};
-
-struct PointTerms {
-  double v[ACC_SIZE];
+  ACC_STRIDE = 32,
+  // GENERAL mode (pose whose 3x3 block is not orthonormal to 1e-9, e.g. built from a 6-digit quaternion as
+  // src/test/test_matching_cost_factors.cpp:50-55 does): the adjoint identity no longer holds exactly, so the
+  // source-side and cross blocks are accumulated explicitly like the reference (92 sums).
+  ACCG_HS_TL = 29,  // 6: upper triangle of G^T M G,  G = R [p]x
+  ACCG_HS_BL = 35,  // 9: row-major -(R^T M G)
+  ACCG_HS_BR = 44,  // 6: upper triangle of R^T M R
+  ACCG_HTS = 50,    // 36: row-major J_t^T M J_s
+  ACCG_BS = 86,     // 6
+  ACCG_SIZE = 92,
+  ACCG_STRIDE = 96
 };
 
 // symmetric 3x3 inverse by cofactors (Eigen's fixed-size 3x3 inverse; vgicp_derivatives.cuh:49,

@@ -50,7 +50,15 @@ __device__ __forceinline__ int xcd_swizzle(int b, int num_tiles) {
   return (b % kNumXCD) * per + b / kNumXCD;
 }
 
-template <bool ERROR_ONLY>
+enum : int { MODE_LIN = 0, MODE_ERR = 1, MODE_LIN_GENERAL = 2 };
+
+template <int MODE>
+struct ModeTraits {
+  static constexpr int kAcc = MODE == MODE_ERR ? 2 : (MODE == MODE_LIN ? ACC_SIZE : ACCG_SIZE);
+  static constexpr int kStride = MODE == MODE_LIN_GENERAL ? ACCG_STRIDE : ACC_STRIDE;
+};
+
+template <int MODE>
 __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose& Tl, const Pose& Te, int i, double* acc) {
   const float* __restrict__ pp = f.points + 3 * (size_t)i;
   const double px = (double)pp[0], py = (double)pp[1], pz = (double)pp[2];
@@ -80,7 +88,7 @@ __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose
   double ox, oy, oz;
   voxel_center(f.map, cx, cy, cz, ox, oy, oz);
   double qx, qy, qz;
-  if (ERROR_ONLY) {
+  if constexpr (MODE == MODE_ERR) {
     qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
     qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
     qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
@@ -98,50 +106,107 @@ __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose
   const double mrz = m[2] * rx + m[4] * ry + m[5] * rz;
   acc[ACC_COUNT] += 1.0;
   acc[ACC_ERR] += rx * mrx + ry * mry + rz * mrz;
-  if constexpr (!ERROR_ONLY) {
-  for (int k = 0; k < 6; k++) acc[ACC_M + k] += m[k];
-  // K = M S, S = [q]x ; columns: K[:,0] = M[:,1] qz - M[:,2] qy ; K[:,1] = M[:,2] qx - M[:,0] qz ; K[:,2] = M[:,0] qy - M[:,1] qx
-  const double k00 = m[1] * qz - m[2] * qy, k01 = m[2] * qx - m[0] * qz, k02 = m[0] * qy - m[1] * qx;
-  const double k10 = m[3] * qz - m[4] * qy, k11 = m[4] * qx - m[1] * qz, k12 = m[1] * qy - m[3] * qx;
-  const double k20 = m[4] * qz - m[5] * qy, k21 = m[5] * qx - m[2] * qz, k22 = m[2] * qy - m[4] * qx;
-  acc[ACC_K + 0] += k00;
-  acc[ACC_K + 1] += k01;
-  acc[ACC_K + 2] += k02;
-  acc[ACC_K + 3] += k10;
-  acc[ACC_K + 4] += k11;
-  acc[ACC_K + 5] += k12;
-  acc[ACC_K + 6] += k20;
-  acc[ACC_K + 7] += k21;
-  acc[ACC_K + 8] += k22;
-  // TL = -S K (= S^T M S), rows of -S: [0, qz, -qy], [-qz, 0, qx], [qy, -qx, 0]; upper triangle
-  acc[ACC_TL + 0] += qz * k10 - qy * k20;
-  acc[ACC_TL + 1] += qz * k11 - qy * k21;
-  acc[ACC_TL + 2] += qz * k12 - qy * k22;
-  acc[ACC_TL + 3] += qx * k21 - qz * k01;
-  acc[ACC_TL + 4] += qx * k22 - qz * k02;
-  acc[ACC_TL + 5] += qy * k02 - qx * k12;
-  // b_t = [q x (M r); M r]
-  acc[ACC_QXMR + 0] += qy * mrz - qz * mry;
-  acc[ACC_QXMR + 1] += qz * mrx - qx * mrz;
-  acc[ACC_QXMR + 2] += qx * mry - qy * mrx;
-  acc[ACC_MR + 0] += mrx;
-  acc[ACC_MR + 1] += mry;
-  acc[ACC_MR + 2] += mrz;
+  if constexpr (MODE != MODE_ERR) {
+    for (int k = 0; k < 6; k++) acc[ACC_M + k] += m[k];
+    // K = M S, S = [q]x ; K[:,0] = M[:,1] qz - M[:,2] qy ; K[:,1] = M[:,2] qx - M[:,0] qz ; K[:,2] = M[:,0] qy - M[:,1] qx
+    const double k00 = m[1] * qz - m[2] * qy, k01 = m[2] * qx - m[0] * qz, k02 = m[0] * qy - m[1] * qx;
+    const double k10 = m[3] * qz - m[4] * qy, k11 = m[4] * qx - m[1] * qz, k12 = m[1] * qy - m[3] * qx;
+    const double k20 = m[4] * qz - m[5] * qy, k21 = m[5] * qx - m[2] * qz, k22 = m[2] * qy - m[4] * qx;
+    acc[ACC_K + 0] += k00;
+    acc[ACC_K + 1] += k01;
+    acc[ACC_K + 2] += k02;
+    acc[ACC_K + 3] += k10;
+    acc[ACC_K + 4] += k11;
+    acc[ACC_K + 5] += k12;
+    acc[ACC_K + 6] += k20;
+    acc[ACC_K + 7] += k21;
+    acc[ACC_K + 8] += k22;
+    // TL = -S K (= S^T M S), rows of -S: [0, qz, -qy], [-qz, 0, qx], [qy, -qx, 0]; upper triangle
+    acc[ACC_TL + 0] += qz * k10 - qy * k20;
+    acc[ACC_TL + 1] += qz * k11 - qy * k21;
+    acc[ACC_TL + 2] += qz * k12 - qy * k22;
+    acc[ACC_TL + 3] += qx * k21 - qz * k01;
+    acc[ACC_TL + 4] += qx * k22 - qz * k02;
+    acc[ACC_TL + 5] += qy * k02 - qx * k12;
+    // b_t = [q x (M r); M r]
+    acc[ACC_QXMR + 0] += qy * mrz - qz * mry;
+    acc[ACC_QXMR + 1] += qz * mrx - qx * mrz;
+    acc[ACC_QXMR + 2] += qx * mry - qy * mrx;
+    acc[ACC_MR + 0] += mrx;
+    acc[ACC_MR + 1] += mry;
+    acc[ACC_MR + 2] += mrz;
+
+    if constexpr (MODE == MODE_LIN_GENERAL) {
+      // explicit source side, vgicp_derivatives.cuh:57-70: J_s = [R [p]x, -R] = [G, -R]
+      const double Mf[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+      const double Rf[3][3] = {{Tl.r00, Tl.r01, Tl.r02}, {Tl.r10, Tl.r11, Tl.r12}, {Tl.r20, Tl.r21, Tl.r22}};
+      const double Kf[3][3] = {{k00, k01, k02}, {k10, k11, k12}, {k20, k21, k22}};
+      double G[3][3], Js[3][6], JtM[6][3], JsM[6][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        G[r][0] = Rf[r][1] * pz - Rf[r][2] * py;
+        G[r][1] = Rf[r][2] * px - Rf[r][0] * pz;
+        G[r][2] = Rf[r][0] * py - Rf[r][1] * px;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          Js[r][c] = G[r][c];
+          Js[r][3 + c] = -Rf[r][c];
+        }
+      }
+      // JtM = J_t^T M = [S M; M] = [-K^T; M] ;  JsM = J_s^T M
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          JtM[r][c] = -Kf[c][r];
+          JtM[3 + r][c] = Mf[r][c];
+        }
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) JsM[r][c] = Js[0][r] * Mf[0][c] + Js[1][r] * Mf[1][c] + Js[2][r] * Mf[2][c];
+      // H_s = JsM J_s : TL (0..2 x 0..2, upper), BL (3..5 x 0..2), BR (3..5 x 3..5, upper)
+      int idx = ACCG_HS_TL;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = r; c < 3; c++) acc[idx++] += JsM[r][0] * Js[0][c] + JsM[r][1] * Js[1][c] + JsM[r][2] * Js[2][c];
+      idx = ACCG_HS_BL;
+#pragma unroll
+      for (int r = 3; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[idx++] += JsM[r][0] * Js[0][c] + JsM[r][1] * Js[1][c] + JsM[r][2] * Js[2][c];
+      idx = ACCG_HS_BR;
+#pragma unroll
+      for (int r = 3; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) acc[idx++] += JsM[r][0] * Js[0][c] + JsM[r][1] * Js[1][c] + JsM[r][2] * Js[2][c];
+      // H_ts = JtM J_s (6x6, row-major)
+      idx = ACCG_HTS;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[idx++] += JtM[r][0] * Js[0][c] + JtM[r][1] * Js[1][c] + JtM[r][2] * Js[2][c];
+      // b_s = JsM r
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[ACCG_BS + r] += JsM[r][0] * rx + JsM[r][1] * ry + JsM[r][2] * rz;
+    }
   }
 }
 
-// main kernel: one workgroup per tile; writes partials[tile][ACC_STRIDE]
-template <bool ERROR_ONLY>
+// main kernel: one workgroup per tile; writes partials[tile][kStride]
+template <int MODE>
 __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                    const double* __restrict__ poses_lin, const double* __restrict__ poses_eval,
                                                                    double* __restrict__ partials) {
-  constexpr int NACC = ERROR_ONLY ? 2 : ACC_SIZE;
+  constexpr int NACC = ModeTraits<MODE>::kAcc;
+  constexpr int STRIDE = ModeTraits<MODE>::kStride;
   const int tile_idx = xcd_swizzle(blockIdx.x, num_tiles);
   if (tile_idx >= num_tiles) return;
   const TileDesc tile = tiles[tile_idx];
   const FactorDesc f = factors[tile.factor];
   const Pose Tl = load_pose(poses_lin + 16 * (size_t)tile.factor);
-  const Pose Te = ERROR_ONLY ? load_pose(poses_eval + 16 * (size_t)tile.factor) : Tl;
+  const Pose Te = MODE == MODE_ERR ? load_pose(poses_eval + 16 * (size_t)tile.factor) : Tl;
 
   double acc[NACC];
 #pragma unroll
@@ -150,7 +215,7 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorD
 #pragma unroll
   for (int it = 0; it < kPointsPerThread; it++) {
     const int local = it * kBlockThreads + threadIdx.x;
-    if (local < tile.count) accumulate_point<ERROR_ONLY>(f, Tl, Te, tile.begin + local, acc);
+    if (local < tile.count) accumulate_point<MODE>(f, Tl, Te, tile.begin + local, acc);
   }
 
   // 64-lane wavefront reduction
@@ -161,104 +226,135 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorD
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     acc[k] = v;
   }
-  __shared__ double lds[kBlockThreads / 64][ACC_STRIDE];
+  __shared__ double lds[kBlockThreads / 64][STRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < NACC; k++) lds[wave][k] = acc[k];
   }
   __syncthreads();
-  if (threadIdx.x < ACC_STRIDE) {
+  if (threadIdx.x < STRIDE) {
     double s = 0.0;
     if (threadIdx.x < NACC) {
 #pragma unroll
       for (int w = 0; w < kBlockThreads / 64; w++) s += lds[w][threadIdx.x];
     }
-    partials[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
+    partials[(size_t)tile_idx * STRIDE + threadIdx.x] = s;
   }
 }
 
-// finalize: one workgroup per factor; deterministic ordered sum of the factor's tile partials, then expansion
+// finalize: one workgroup per factor; deterministic ordered sum of the factor's tile partials, then expansion to the
+// LinearizedSystem6 blocks.  GENERAL = false: source-side blocks through the adjoint identity; true: read directly.
+template <bool GENERAL>
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
                                                                        const double* __restrict__ partials, gp_linearized6* __restrict__ out) {
+  constexpr int STRIDE = GENERAL ? ACCG_STRIDE : ACC_STRIDE;
+  constexpr int NACC = GENERAL ? ACCG_SIZE : ACC_SIZE;
+  constexpr int kSlices = GENERAL ? 2 : kBlockThreads / ACC_STRIDE;  // 256 threads = 8 x 32 or 2 x 96 (+ idle)
   const int fi = blockIdx.x;
   const int tile_begin = factors[fi].tile_begin, tile_count = factors[fi].tile_count;
-  __shared__ double lds[kBlockThreads / ACC_STRIDE][ACC_STRIDE];
-  __shared__ double sum[ACC_STRIDE];
-  const int comp = threadIdx.x % ACC_STRIDE, slice = threadIdx.x / ACC_STRIDE;
-  constexpr int kSlices = kBlockThreads / ACC_STRIDE;
-  double s = 0.0;
-  for (int t = slice; t < tile_count; t += kSlices) s += partials[(size_t)(tile_begin + t) * ACC_STRIDE + comp];
-  lds[slice][comp] = s;
+  __shared__ double lds[kSlices][STRIDE];
+  __shared__ double sum[STRIDE];
+  __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
+  const int comp = threadIdx.x % STRIDE, slice = threadIdx.x / STRIDE;
+  if (slice < kSlices) {
+    double s = 0.0;
+    for (int t = slice; t < tile_count; t += kSlices) s += partials[(size_t)(tile_begin + t) * STRIDE + comp];
+    lds[slice][comp] = s;
+  }
   __syncthreads();
-  if (threadIdx.x < ACC_STRIDE) {
+  if (threadIdx.x < STRIDE) {
     double a = 0.0;
 #pragma unroll
     for (int k = 0; k < kSlices; k++) a += lds[k][threadIdx.x];
     sum[threadIdx.x] = a;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-
-  // ---- expansion (single lane; 6x6 algebra, negligible) ----
+  (void)NACC;
+  const int t = threadIdx.x;
+  const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
+  double* dst = reinterpret_cast<double*>(out + fi);  // may be only 8-byte aligned (integrated_vgicp_factor_gpu.cpp:219-220)
+  constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
   const Pose T = load_pose(poses + 16 * (size_t)fi);
-  double Ht[6][6], bt[6];
-  const double* M = sum + ACC_M;
-  const double* K = sum + ACC_K;
-  const double* TL = sum + ACC_TL;
-  const double Mf[3][3] = {{M[0], M[1], M[2]}, {M[1], M[3], M[4]}, {M[2], M[4], M[5]}};
-  const double TLf[3][3] = {{TL[0], TL[1], TL[2]}, {TL[1], TL[3], TL[4]}, {TL[2], TL[4], TL[5]}};
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) {
-      Ht[r][c] = TLf[r][c];
-      Ht[3 + r][c] = -K[r * 3 + c];
-      Ht[c][3 + r] = -K[r * 3 + c];
-      Ht[3 + r][3 + c] = Mf[r][c];
+  if (t < 36) {
+    // H_t = [[TL, -K^T], [-K, M]]
+    const int sym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    double h;
+    if (r < 3 && c < 3) {
+      h = sum[ACC_TL + sym3[r][c]];
+    } else if (r >= 3 && c < 3) {
+      h = -sum[ACC_K + (r - 3) * 3 + c];
+    } else if (r < 3) {
+      h = -sum[ACC_K + (c - 3) * 3 + r];
+    } else {
+      h = sum[ACC_M + sym3[r - 3][c - 3]];
     }
-  for (int k = 0; k < 3; k++) {
-    bt[k] = sum[ACC_QXMR + k];
-    bt[3 + k] = sum[ACC_MR + k];
+    Ht[r][c] = h;
+    dst[OFF_HT + c * 6 + r] = h;
+    // Ad(delta) = [[R, 0], [[t]x R, R]]   ([omega, v] ordering, GTSAM Pose3::AdjointMap)
+    const double R[3][3] = {{T.r00, T.r01, T.r02}, {T.r10, T.r11, T.r12}, {T.r20, T.r21, T.r22}};
+    const double tx[3][3] = {{0.0, -T.tz, T.ty}, {T.tz, 0.0, -T.tx}, {-T.ty, T.tx, 0.0}};
+    double a;
+    if (r < 3 && c < 3) {
+      a = R[r][c];
+    } else if (r < 3) {
+      a = 0.0;
+    } else if (c >= 3) {
+      a = R[r - 3][c - 3];
+    } else {
+      a = tx[r - 3][0] * R[0][c] + tx[r - 3][1] * R[1][c] + tx[r - 3][2] * R[2][c];
+    }
+    Ad[r][c] = a;
   }
-  // Ad(delta) = [[R, 0], [[t]x R, R]]   ([omega, v] ordering, GTSAM Pose3::AdjointMap)
-  const double R[3][3] = {{T.r00, T.r01, T.r02}, {T.r10, T.r11, T.r12}, {T.r20, T.r21, T.r22}};
-  const double tx[3][3] = {{0.0, -T.tz, T.ty}, {T.tz, 0.0, -T.tx}, {-T.ty, T.tx, 0.0}};
-  double Ad[6][6];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) {
-      Ad[r][c] = R[r][c];
-      Ad[r][3 + c] = 0.0;
-      Ad[3 + r][3 + c] = R[r][c];
+  if (t < 6) {
+    const double b = t < 3 ? sum[ACC_QXMR + t] : sum[ACC_MR + t - 3];
+    bt[t] = b;
+    dst[OFF_BT + t] = b;
+  }
+  if (t == 0) {
+    dst[0] = sum[ACC_COUNT];
+    dst[1] = sum[ACC_ERR];
+  }
+  __syncthreads();
+  if constexpr (!GENERAL) {
+    if (t < 36) {
       double a = 0.0;
-      for (int k = 0; k < 3; k++) a += tx[r][k] * R[k][c];
-      Ad[3 + r][c] = a;
-    }
-  double HtA[6][6];  // H_t Ad
-  for (int r = 0; r < 6; r++)
-    for (int c = 0; c < 6; c++) {
-      double a = 0.0;
+#pragma unroll
       for (int k = 0; k < 6; k++) a += Ht[r][k] * Ad[k][c];
       HtA[r][c] = a;
+      dst[OFF_HTS + c * 6 + r] = -a;  // H_ts = -H_t Ad
     }
-  gp_linearized6 o;
-  o.num_inliers = sum[ACC_COUNT];
-  o.error = sum[ACC_ERR];
-  for (int r = 0; r < 6; r++) {
-    for (int c = 0; c < 6; c++) {
-      double hs = 0.0;
-      for (int k = 0; k < 6; k++) hs += Ad[k][r] * HtA[k][c];
-      o.H_target[c * 6 + r] = Ht[r][c];
-      o.H_source[c * 6 + r] = hs;
-      o.H_target_source[c * 6 + r] = -HtA[r][c];
+    __syncthreads();
+    if (t < 36) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) a += Ad[k][r] * HtA[k][c];
+      dst[OFF_HS + c * 6 + r] = a;  // H_s = Ad^T H_t Ad
     }
-    double bs = 0.0;
-    for (int k = 0; k < 6; k++) bs += Ad[k][r] * bt[k];
-    o.b_target[r] = bt[r];
-    o.b_source[r] = -bs;
+    if (t < 6) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) a += Ad[k][t] * bt[k];
+      dst[OFF_BS + t] = -a;  // b_s = -Ad^T b_t
+    }
+  } else {
+    if (t < 36) {
+      const int sym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+      double h;
+      if (r < 3 && c < 3) {
+        h = sum[ACCG_HS_TL + sym3[r][c]];
+      } else if (r >= 3 && c < 3) {
+        h = sum[ACCG_HS_BL + (r - 3) * 3 + c];
+      } else if (r < 3) {
+        h = sum[ACCG_HS_BL + (c - 3) * 3 + r];
+      } else {
+        h = sum[ACCG_HS_BR + sym3[r - 3][c - 3]];
+      }
+      dst[OFF_HS + c * 6 + r] = h;
+      dst[OFF_HTS + c * 6 + r] = sum[ACCG_HTS + r * 6 + c];
+    }
+    if (t < 6) dst[OFF_BS + t] = sum[ACCG_BS + t];
   }
-  // out may be only 8-byte aligned (sub-range of a staging buffer, integrated_vgicp_factor_gpu.cpp:219-220)
-  double* dst = reinterpret_cast<double*>(out + fi);
-  const double* src = reinterpret_cast<const double*>(&o);
-  for (int k = 0; k < (int)(sizeof(gp_linearized6) / sizeof(double)); k++) dst[k] = src[k];
 }
 
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
@@ -344,7 +440,7 @@ int build_table(gp_vgicp_batch* b) {
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
   GP_TRY(b->d_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
   GP_TRY(b->h_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
-  if (!b->temp_buffer) GP_TRY(b->d_partials.ensure(sizeof(double) * gp::ACC_STRIDE * (size_t)std::max(b->num_tiles, 1)));
+  if (!b->temp_buffer) GP_TRY(b->d_partials.ensure(sizeof(double) * gp::ACCG_STRIDE * (size_t)std::max(b->num_tiles, 1)));
   // the table upload is synchronous (pageable source); it happens once per factor-set change, not per linearise
   if (F) GP_HIP(hipMemcpy(b->d_factors.ptr, descs.data(), sizeof(gp::FactorDesc) * (size_t)F, hipMemcpyHostToDevice));
   if (b->num_tiles) GP_HIP(hipMemcpy(b->d_tiles.ptr, tiles.data(), sizeof(gp::TileDesc) * (size_t)b->num_tiles, hipMemcpyHostToDevice));
@@ -355,7 +451,7 @@ int build_table(gp_vgicp_batch* b) {
 int partials_ptr(gp_vgicp_batch* b, double** out) {
   if (b->temp_buffer) {
     void* p = nullptr;
-    GP_TRY(gp_temp_buffer_get(b->temp_buffer, sizeof(double) * gp::ACC_STRIDE * (size_t)std::max(b->num_tiles, 1), &p));
+    GP_TRY(gp_temp_buffer_get(b->temp_buffer, sizeof(double) * gp::ACCG_STRIDE * (size_t)std::max(b->num_tiles, 1), &p));
     *out = reinterpret_cast<double*>(p);
   } else {
     *out = b->d_partials.as<double>();
@@ -368,18 +464,43 @@ inline int grid_tiles(int num_tiles) {
   return per * gp::kNumXCD;
 }
 
-// device work of one linearisation pass; poses already on the device
-int launch_linearize(gp_vgicp_batch* b, const double* d_poses, gp_linearized6* out_dev) {
+// is the 3x3 block of every pose orthonormal to 1e-9?  (GTSAM Pose3 values are; poses parsed from 6-digit text are not)
+bool poses_are_rigid(const double* poses_host, size_t F) {
+  if (!poses_host) return false;
+  for (size_t i = 0; i < F; i++) {
+    const double* m = poses_host + 16 * i;
+    for (int a = 0; a < 3; a++)
+      for (int c = a; c < 3; c++) {
+        const double d = m[4 * a] * m[4 * c] + m[4 * a + 1] * m[4 * c + 1] + m[4 * a + 2] * m[4 * c + 2] - (a == c ? 1.0 : 0.0);
+        if (!(d < 1e-9 && d > -1e-9)) return false;
+      }
+    const double det = m[0] * (m[5] * m[10] - m[9] * m[6]) - m[4] * (m[1] * m[10] - m[9] * m[2]) + m[8] * (m[1] * m[6] - m[5] * m[2]);
+    if (!(det > 0.0)) return false;
+  }
+  return true;
+}
+
+// device work of one linearisation pass; poses already on the device.  rigid == true: 29-sum kernel + adjoint
+// expansion; false: 92-sum kernel (exact for any 3x3 block, like the reference's explicit J_s).
+int launch_linearize(gp_vgicp_batch* b, const double* d_poses, gp_linearized6* out_dev, bool rigid) {
   const int F = (int)b->factors.size();
   if (F == 0) return GP_OK;
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
-  if (b->num_tiles > 0) {
-    hipLaunchKernelGGL(gp::vgicp_tile_kernel<false>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
-                       b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
+  const dim3 grid(grid_tiles(b->num_tiles)), block(gp::kBlockThreads);
+  if (rigid) {
+    if (b->num_tiles > 0)
+      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN>, grid, block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(),
+                         b->num_tiles, d_poses, d_poses, partials);
     GP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gp::vgicp_finalize_kernel<false>, dim3(F), block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials, out_dev);
+  } else {
+    if (b->num_tiles > 0)
+      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN_GENERAL>, grid, block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
+                         b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
+    GP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3(F), block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials, out_dev);
   }
-  hipLaunchKernelGGL(gp::vgicp_finalize_kernel, dim3(F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials, out_dev);
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
@@ -390,7 +511,7 @@ int launch_error(gp_vgicp_batch* b, const double* d_poses_lin, const double* d_p
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
   if (b->num_tiles > 0) {
-    hipLaunchKernelGGL(gp::vgicp_tile_kernel<true>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_ERR>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
                        b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses_lin, d_poses_eval, partials);
     GP_HIP(hipGetLastError());
   }
@@ -490,10 +611,9 @@ int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f) { return f ? f->n : 0
 gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f) { return f ? (gp_stream_t)f->stream : nullptr; }
 
 int gp_vgicp_factor_issue_linearize(gp_vgicp_factor_t* f, const double* pose_host, const double* pose_dev, gp_linearized6* out_dev) {
-  (void)pose_host;
   if (!f || !pose_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_linearize: null");
   GP_TRY(ensure_self_batch(f));
-  return launch_linearize(f->self_batch, pose_dev, out_dev);
+  return launch_linearize(f->self_batch, pose_dev, out_dev, poses_are_rigid(pose_host, 1));
 }
 
 int gp_vgicp_factor_issue_compute_error(gp_vgicp_factor_t* f, const double* pose_lin_host, const double* pose_eval_host, const double* pose_lin_dev,
@@ -577,7 +697,7 @@ int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* b, const double* poses_host
   if (b->table_dirty) GP_TRY(build_table(b));
   if (b->factors.empty()) return GP_OK;
   GP_TRY(upload_poses(b, poses_host, nullptr));
-  return launch_linearize(b, b->d_poses.as<double>(), out_dev);
+  return launch_linearize(b, b->d_poses.as<double>(), out_dev, poses_are_rigid(poses_host, b->factors.size()));
 }
 
 int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_host, const double* poses_eval_host, double* out_dev) {
@@ -635,11 +755,12 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host,
   GP_HIP(hipEventCreate(&e2));
   const double* d_poses = b->d_poses.as<double>();
   // warm-up
-  GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>()));
+  const bool rigid = poses_are_rigid(poses_host, F);
+  GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>(), rigid));
   GP_HIP(hipStreamSynchronize(b->stream));
   // whole pass, back to back
   GP_HIP(hipEventRecord(e0, b->stream));
-  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>()));
+  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>(), rigid));
   GP_HIP(hipEventRecord(e1, b->stream));
   GP_HIP(hipEventSynchronize(e1));
   float t_total = 0.f;
@@ -647,13 +768,21 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host,
   // main kernel alone, then finalize alone (same stream the product path launches on)
   GP_HIP(hipEventRecord(e0, b->stream));
   for (int i = 0; i < iters; i++) {
-    hipLaunchKernelGGL(gp::vgicp_tile_kernel<false>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
-                       b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
+    if (rigid)
+      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
+                         b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
+    else
+      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN_GENERAL>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
+                         b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
   }
   GP_HIP(hipEventRecord(e1, b->stream));
   for (int i = 0; i < iters; i++) {
-    hipLaunchKernelGGL(gp::vgicp_finalize_kernel, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials,
-                       b->d_out.as<gp_linearized6>());
+    if (rigid)
+      hipLaunchKernelGGL(gp::vgicp_finalize_kernel<false>, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses,
+                         partials, b->d_out.as<gp_linearized6>());
+    else
+      hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses,
+                         partials, b->d_out.as<gp_linearized6>());
   }
   GP_HIP(hipEventRecord(e2, b->stream));
   GP_HIP(hipEventSynchronize(e2));

@@ -59,6 +59,20 @@ def test_kitti07_pairs_match_golden(gpu, kitti07, golden):
         assert_linearized_close(_sync_linearize(gpu, f, np.array(g["delta"])), g, PARITY_TOL, g["name"])
 
 
+def test_rigid_and_general_pose_paths(gpu, kitti00):
+    """a pose whose 3x3 block is orthonormal takes the 29-sum kernel + adjoint expansion; one that is not (here: off by
+    1e-6, like the reference test's 6-digit quaternions, test_matching_cost_factors.cpp:50-55) takes the 92-sum kernel
+    with explicit J_s.  Both must match the oracle, which uses R as given."""
+    _, src, vm = _build(gpu, kitti00, 0.5)
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    _, fo = _oracle(kitti00, 0.5)
+    rigid = expmap([0.03, -0.02, 0.05, 0.4, -0.3, 0.1])
+    skew = rigid.copy()
+    skew[:3, :3] = skew[:3, :3] @ (np.eye(3) + 1e-6 * np.array([[1.0, 0.3, 0.0], [0.0, -0.5, 0.2], [0.1, 0.0, 0.7]]))
+    for name, delta in [("rigid", rigid), ("general", skew)]:
+        assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), PARITY_TOL, name)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1023, 1024, 1025, 4097])
 def test_ragged_sizes(gpu, kitti00, n):
     """empty, single-point, wave/tile boundary sizes"""
