@@ -91,18 +91,26 @@ def main():
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
 
     REC = _capi.LINEARIZED6_DOUBLES
-    stacked = torch.zeros((world, REC), dtype=torch.float64, device=device)
     host_out = torch.zeros((world, REC), dtype=torch.float64).pin_memory()
-    my_slot = C.c_void_p(stacked.data_ptr() + rank * REC * 8)
+    out_np = host_out.numpy()
 
-    def step():
-        if world > 1:
-            stacked.zero_()
-        _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, pose.ctypes.data, my_slot), "gp_vgicp_batch_issue_linearize")
-        if world > 1:
-            dist.all_reduce(stacked, op=dist.ReduceOp.SUM)  # RCCL over xGMI: every slot is written by exactly one rank
-        host_out.copy_(stacked, non_blocking=True)
-        stream.synchronize()
+    if world == 1:
+        # the product's synchronous entry point: pose in host memory -> records in host memory
+        def step():
+            _capi.check(lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out_np.ctypes.data), "gp_vgicp_batch_linearize")
+
+    else:
+        from gtsam_points_amd.distributed import ShardedLinearizer
+
+        def issue(poses_local, view):
+            _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses_local.ctypes.data, C.c_void_p(view.data_ptr())), "gp_vgicp_batch_issue_linearize")
+
+        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue)
+
+        def step():
+            stacked = sharded.linearize(pose)  # zero, local kernels, RCCL all-reduce over xGMI
+            host_out.copy_(stacked, non_blocking=True)
+            stream.synchronize()
 
     def barrier():
         if world > 1:
@@ -207,7 +215,7 @@ def main():
                 num_buckets=info.num_buckets,
                 inlier_fraction=round(rec.num_inliers / args.source_points, 4),
                 parallelism=f"{world} x 1 factor/GPU; RCCL all-reduce of stacked [N x 122] f64 records" if world > 1 else "1 GPU",
-                step="pose H2D + tile kernel + finalize kernel + (all-reduce) + D2H of records + sync",
+                step="poses (host) -> tile kernel -> finalize kernel -> [N>1: RCCL all-reduce of the stacked records] -> records in host memory, synchronised",
             ),
             roofline=roofline,
             cpu_baseline=cpu_baseline,

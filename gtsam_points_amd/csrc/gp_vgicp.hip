@@ -38,6 +38,13 @@ struct FactorDesc {
   int tile_count;
 };
 
+// poses of a single-factor launch travel in the kernel arguments (no H2D copy on the latency path)
+struct InlinePoses {
+  double lin[16];
+  double eval[16];
+  int use;
+};
+
 struct TileDesc {
   int factor;
   int begin;  // first point
@@ -51,6 +58,10 @@ __device__ __forceinline__ int xcd_swizzle(int b, int num_tiles) {
 }
 
 enum : int { MODE_LIN = 0, MODE_ERR = 1, MODE_LIN_GENERAL = 2 };
+
+}  // namespace gp
+#include "gp_vgicp_tile.hpp"
+namespace gp {
 
 template <int MODE>
 struct ModeTraits {
@@ -198,25 +209,21 @@ __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose
 template <int MODE>
 __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                    const double* __restrict__ poses_lin, const double* __restrict__ poses_eval,
-                                                                   double* __restrict__ partials) {
+                                                                   const InlinePoses inl, double* __restrict__ partials) {
   constexpr int NACC = ModeTraits<MODE>::kAcc;
   constexpr int STRIDE = ModeTraits<MODE>::kStride;
   const int tile_idx = xcd_swizzle(blockIdx.x, num_tiles);
   if (tile_idx >= num_tiles) return;
   const TileDesc tile = tiles[tile_idx];
   const FactorDesc f = factors[tile.factor];
-  const Pose Tl = load_pose(poses_lin + 16 * (size_t)tile.factor);
-  const Pose Te = MODE == MODE_ERR ? load_pose(poses_eval + 16 * (size_t)tile.factor) : Tl;
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
 
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
 
-#pragma unroll
-  for (int it = 0; it < kPointsPerThread; it++) {
-    const int local = it * kBlockThreads + threadIdx.x;
-    if (local < tile.count) accumulate_point<MODE>(f, Tl, Te, tile.begin + local, acc);
-  }
+  for (int local = threadIdx.x; local < tile.count; local += kBlockThreads) accumulate_point<MODE>(f, Tl, Te, tile.begin + local, acc);
 
   // 64-lane wavefront reduction
 #pragma unroll
@@ -245,12 +252,15 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorD
 
 // finalize: one workgroup per factor; deterministic ordered sum of the factor's tile partials, then expansion to the
 // LinearizedSystem6 blocks.  GENERAL = false: source-side blocks through the adjoint identity; true: read directly.
+constexpr int kFinalizeThreads = 1024;
+
 template <bool GENERAL>
-__global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
-                                                                       const double* __restrict__ partials, gp_linearized6* __restrict__ out) {
+__global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
+                                                                          const InlinePoses inl, const double* __restrict__ partials,
+                                                                          gp_linearized6* __restrict__ out) {
   constexpr int STRIDE = GENERAL ? ACCG_STRIDE : ACC_STRIDE;
   constexpr int NACC = GENERAL ? ACCG_SIZE : ACC_SIZE;
-  constexpr int kSlices = GENERAL ? 2 : kBlockThreads / ACC_STRIDE;  // 256 threads = 8 x 32 or 2 x 96 (+ idle)
+  constexpr int kSlices = kFinalizeThreads / STRIDE;  // 1024 threads = 32 slices x 32 sums, or 10 x 96 (+ idle)
   const int fi = blockIdx.x;
   const int tile_begin = factors[fi].tile_begin, tile_count = factors[fi].tile_count;
   __shared__ double lds[kSlices][STRIDE];
@@ -275,7 +285,7 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_kernel(const Fac
   const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
   double* dst = reinterpret_cast<double*>(out + fi);  // may be only 8-byte aligned (integrated_vgicp_factor_gpu.cpp:219-220)
   constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
-  const Pose T = load_pose(poses + 16 * (size_t)fi);
+  const Pose T = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);
   if (t < 36) {
     // H_t = [[TL, -K^T], [-K, M]]
     const int sym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
@@ -396,8 +406,6 @@ struct gp_vgicp_factor {
   gp_temp_buffer* temp_buffer = nullptr;
   bool owns_temp_buffer = false;
   gp_vgicp_batch* self_batch = nullptr;  // lazily built batch of one, used by the per-factor entry points
-  gp::PinnedArray staging;               // poses in / results out for the synchronous fall-backs
-  gp::DeviceArray dev_io;                // device pose(s) + result for the synchronous fall-backs
 };
 
 struct gp_vgicp_batch {
@@ -405,21 +413,37 @@ struct gp_vgicp_batch {
   hipStream_t stream = nullptr;
   gp_temp_buffer* temp_buffer = nullptr;  // partials arena when provided (per-stream scratch), else own
   int num_tiles = 0;
+  int variant = -1;       // kernel variant the tile table was built for
+  int tile_points = 0;
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
   gp::PinnedArray h_poses;
-  gp::PinnedArray h_out;
-  gp::DeviceArray d_out;
+  gp::PinnedArray h_out;  // results land here straight from the finalize kernel (host-mapped, no D2H copy op)
+  void* h_out_dev = nullptr;
   bool table_dirty = true;
 };
 
 namespace {
+
+// Kernel variant (tuning hook, gp_debug_set_variant): 0 = v1 reference kernel; 1..5 = phased kernel
+//   1: f64, 4 points/lane   2: f64, 2 points/lane   3: f64, 8 points/lane   4: f32 outer products, 4/lane   5: f32 outer, 8/lane
+int g_variant = 1;
+inline int variant_ppt(int v) { return v == 2 ? 2 : (v == 3 || v == 5) ? 8 : 4; }
+
+// where a launch takes its poses from
+struct PoseSource {
+  const double* d_lin = nullptr;
+  const double* d_eval = nullptr;
+  gp::InlinePoses inl{};
+};
 
 int build_table(gp_vgicp_batch* b) {
   const int F = (int)b->factors.size();
   std::vector<gp::FactorDesc> descs((size_t)F);
   std::vector<gp::TileDesc> tiles;
   b->total_points = 0;
+  b->variant = g_variant;
+  b->tile_points = gp::kBlockThreads * variant_ppt(g_variant);
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -431,7 +455,7 @@ int build_table(gp_vgicp_batch* b) {
     d.n = f->n;
     d.surface_validation = (f->surface_validation && f->normals) ? 1 : 0;
     d.tile_begin = (int)tiles.size();
-    for (int p = 0; p < f->n; p += gp::kTilePoints) tiles.push_back(gp::TileDesc{i, p, std::min(gp::kTilePoints, f->n - p)});
+    for (int p = 0; p < f->n; p += b->tile_points) tiles.push_back(gp::TileDesc{i, p, std::min(b->tile_points, f->n - p)});
     d.tile_count = (int)tiles.size() - d.tile_begin;
     b->total_points += f->n;
   }
@@ -440,6 +464,8 @@ int build_table(gp_vgicp_batch* b) {
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
   GP_TRY(b->d_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
   GP_TRY(b->h_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
+  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * (size_t)std::max(F, 1)));
+  GP_HIP(hipHostGetDevicePointer(&b->h_out_dev, b->h_out.ptr, 0));
   if (!b->temp_buffer) GP_TRY(b->d_partials.ensure(sizeof(double) * gp::ACCG_STRIDE * (size_t)std::max(b->num_tiles, 1)));
   // the table upload is synchronous (pageable source); it happens once per factor-set change, not per linearise
   if (F) GP_HIP(hipMemcpy(b->d_factors.ptr, descs.data(), sizeof(gp::FactorDesc) * (size_t)F, hipMemcpyHostToDevice));
@@ -480,43 +506,94 @@ bool poses_are_rigid(const double* poses_host, size_t F) {
   return true;
 }
 
-// device work of one linearisation pass; poses already on the device.  rigid == true: 29-sum kernel + adjoint
-// expansion; false: 92-sum kernel (exact for any 3x3 block, like the reference's explicit J_s).
-int launch_linearize(gp_vgicp_batch* b, const double* d_poses, gp_linearized6* out_dev, bool rigid) {
-  const int F = (int)b->factors.size();
-  if (F == 0) return GP_OK;
-  double* partials = nullptr;
-  GP_TRY(partials_ptr(b, &partials));
+template <int MODE>
+int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
+  if (b->num_tiles <= 0) return GP_OK;
   const dim3 grid(grid_tiles(b->num_tiles)), block(gp::kBlockThreads);
-  if (rigid) {
-    if (b->num_tiles > 0)
-      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN>, grid, block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(),
-                         b->num_tiles, d_poses, d_poses, partials);
-    GP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gp::vgicp_finalize_kernel<false>, dim3(F), block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials, out_dev);
+  const gp::FactorDesc* fd = b->d_factors.as<gp::FactorDesc>();
+  const gp::TileDesc* td = b->d_tiles.as<gp::TileDesc>();
+#define GP_LAUNCH2(F32, PPT) \
+  hipLaunchKernelGGL((gp::vgicp_tile_kernel2<MODE, F32, PPT>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials)
+  if constexpr (MODE == gp::MODE_LIN_GENERAL) {
+    // the general (non-orthonormal pose) path always uses the reference-shaped kernel; its tiles hold tile_points points,
+    // walked in strides of kBlockThreads
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials);
   } else {
-    if (b->num_tiles > 0)
-      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN_GENERAL>, grid, block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
-                         b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
-    GP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3(F), block, 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses, partials, out_dev);
+    switch (b->variant) {
+      case 0:
+        hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials);
+        break;
+      case 2:
+        GP_LAUNCH2(false, 2);
+        break;
+      case 3:
+        GP_LAUNCH2(false, 8);
+        break;
+      case 4:
+        GP_LAUNCH2(true, 4);
+        break;
+      case 5:
+        GP_LAUNCH2(true, 8);
+        break;
+      default:
+        GP_LAUNCH2(false, 4);
+        break;
+    }
   }
+#undef GP_LAUNCH2
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
 
-int launch_error(gp_vgicp_batch* b, const double* d_poses_lin, const double* d_poses_eval, double* out_dev) {
-  const int F = (int)b->factors.size();
-  if (F == 0) return GP_OK;
+template <bool GENERAL>
+int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev) {
+  hipLaunchKernelGGL(gp::vgicp_finalize_kernel<GENERAL>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream,
+                     b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
+// device work of one linearisation pass.  rigid == true: 29-sum kernel + adjoint expansion; false: 92-sum kernel
+// (exact for any 3x3 block, like the reference's explicit J_s).
+int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid) {
+  if (b->factors.empty()) return GP_OK;
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
-  if (b->num_tiles > 0) {
-    hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_ERR>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
-                       b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses_lin, d_poses_eval, partials);
-    GP_HIP(hipGetLastError());
+  if (rigid) {
+    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+    return launch_finalize<false>(b, ps, partials, out_dev);
   }
-  hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3(F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), partials, out_dev);
+  GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
+  return launch_finalize<true>(b, ps, partials, out_dev);
+}
+
+int launch_error(gp_vgicp_batch* b, const PoseSource& ps, double* out_dev) {
+  if (b->factors.empty()) return GP_OK;
+  double* partials = nullptr;
+  GP_TRY(partials_ptr(b, &partials));
+  GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
+  hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3((int)b->factors.size()), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
+                     partials, out_dev);
   GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
+// poses for a launch: a single factor carries them in the kernel arguments; a batch uploads them with one H2D
+int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSource* ps) {
+  const size_t F = b->factors.size();
+  if (F == 1) {
+    memcpy(ps->inl.lin, lin, sizeof(double) * 16);
+    if (eval) memcpy(ps->inl.eval, eval, sizeof(double) * 16);
+    ps->inl.use = 1;
+    return GP_OK;
+  }
+  double* h = b->h_poses.as<double>();
+  memcpy(h, lin, sizeof(double) * 16 * F);
+  if (eval) memcpy(h + 16 * F, eval, sizeof(double) * 16 * F);
+  GP_HIP(hipMemcpyAsync(b->d_poses.ptr, h, sizeof(double) * 16 * F * (eval ? 2 : 1), hipMemcpyHostToDevice, b->stream));
+  ps->d_lin = b->d_poses.as<double>();
+  ps->d_eval = eval ? b->d_poses.as<double>() + 16 * F : nullptr;
+  ps->inl.use = 0;
   return GP_OK;
 }
 
@@ -528,13 +605,19 @@ int ensure_self_batch(gp_vgicp_factor* f) {
     b->temp_buffer = f->temp_buffer;
     f->self_batch = b;
   }
-  if (f->self_batch->table_dirty) GP_TRY(build_table(f->self_batch));
+  if (f->self_batch->table_dirty || f->self_batch->variant != g_variant) GP_TRY(build_table(f->self_batch));
   return GP_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+int gp_debug_set_variant(int variant) {
+  if (variant < 0 || variant > 5) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..5");
+  g_variant = variant;
+  return GP_OK;
+}
 
 size_t gp_vgicp_linearization_input_size(void) { return sizeof(double) * 16; }
 size_t gp_vgicp_linearization_output_size(void) { return sizeof(gp_linearized6); }
@@ -611,18 +694,34 @@ int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f) { return f ? f->n : 0
 gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f) { return f ? (gp_stream_t)f->stream : nullptr; }
 
 int gp_vgicp_factor_issue_linearize(gp_vgicp_factor_t* f, const double* pose_host, const double* pose_dev, gp_linearized6* out_dev) {
-  if (!f || !pose_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_linearize: null");
+  if (!f || (!pose_dev && !pose_host) || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_linearize: null");
   GP_TRY(ensure_self_batch(f));
-  return launch_linearize(f->self_batch, pose_dev, out_dev, poses_are_rigid(pose_host, 1));
+  PoseSource ps;
+  if (pose_host) {  // the host copy rides in the kernel arguments; the device copy is not even read
+    memcpy(ps.inl.lin, pose_host, sizeof(double) * 16);
+    ps.inl.use = 1;
+  } else {
+    ps.d_lin = pose_dev;
+  }
+  return launch_linearize(f->self_batch, ps, out_dev, poses_are_rigid(pose_host, 1));
 }
 
 int gp_vgicp_factor_issue_compute_error(gp_vgicp_factor_t* f, const double* pose_lin_host, const double* pose_eval_host, const double* pose_lin_dev,
                                         const double* pose_eval_dev, double* out_dev) {
-  (void)pose_lin_host;
-  (void)pose_eval_host;
-  if (!f || !pose_lin_dev || !pose_eval_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_compute_error: null");
+  if (!f || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_compute_error: null");
   GP_TRY(ensure_self_batch(f));
-  return launch_error(f->self_batch, pose_lin_dev, pose_eval_dev, out_dev);
+  PoseSource ps;
+  if (pose_lin_host && pose_eval_host) {
+    memcpy(ps.inl.lin, pose_lin_host, sizeof(double) * 16);
+    memcpy(ps.inl.eval, pose_eval_host, sizeof(double) * 16);
+    ps.inl.use = 1;
+  } else if (pose_lin_dev && pose_eval_dev) {
+    ps.d_lin = pose_lin_dev;
+    ps.d_eval = pose_eval_dev;
+  } else {
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_issue_compute_error: poses missing");
+  }
+  return launch_error(f->self_batch, ps, out_dev);
 }
 
 int gp_vgicp_factor_sync(gp_vgicp_factor_t* f) {
@@ -683,29 +782,22 @@ int64_t gp_vgicp_batch_algorithmic_bytes(const gp_vgicp_batch_t* batch) {
   return bytes;
 }
 
-static int upload_poses(gp_vgicp_batch* b, const double* lin, const double* eval) {
-  const size_t F = b->factors.size();
-  double* h = b->h_poses.as<double>();
-  memcpy(h, lin, sizeof(double) * 16 * F);
-  if (eval) memcpy(h + 16 * F, eval, sizeof(double) * 16 * F);
-  GP_HIP(hipMemcpyAsync(b->d_poses.ptr, h, sizeof(double) * 16 * F * (eval ? 2 : 1), hipMemcpyHostToDevice, b->stream));
-  return GP_OK;
-}
-
 int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_dev) {
   if (!b || !poses_host || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_linearize: null");
-  if (b->table_dirty) GP_TRY(build_table(b));
+  if (b->table_dirty || b->variant != g_variant) GP_TRY(build_table(b));
   if (b->factors.empty()) return GP_OK;
-  GP_TRY(upload_poses(b, poses_host, nullptr));
-  return launch_linearize(b, b->d_poses.as<double>(), out_dev, poses_are_rigid(poses_host, b->factors.size()));
+  PoseSource ps;
+  GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
+  return launch_linearize(b, ps, out_dev, poses_are_rigid(poses_host, b->factors.size()));
 }
 
 int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_host, const double* poses_eval_host, double* out_dev) {
   if (!b || !poses_lin_host || !poses_eval_host || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_compute_error: null");
-  if (b->table_dirty) GP_TRY(build_table(b));
+  if (b->table_dirty || b->variant != g_variant) GP_TRY(build_table(b));
   if (b->factors.empty()) return GP_OK;
-  GP_TRY(upload_poses(b, poses_lin_host, poses_eval_host));
-  return launch_error(b, b->d_poses.as<double>(), b->d_poses.as<double>() + 16 * b->factors.size(), out_dev);
+  PoseSource ps;
+  GP_TRY(stage_poses(b, poses_lin_host, poses_eval_host, &ps));
+  return launch_error(b, ps, out_dev);
 }
 
 int gp_vgicp_batch_sync(gp_vgicp_batch_t* b) {
@@ -714,14 +806,12 @@ int gp_vgicp_batch_sync(gp_vgicp_batch_t* b) {
   return GP_OK;
 }
 
+// synchronous: the finalize kernel stores the records straight into host-mapped pinned memory (no D2H copy op)
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host) {
   if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
-  GP_TRY(b->d_out.ensure(sizeof(gp_linearized6) * F));
-  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * F));
-  GP_TRY(gp_vgicp_batch_issue_linearize(b, poses_host, b->d_out.as<gp_linearized6>()));
-  GP_HIP(hipMemcpyAsync(b->h_out.ptr, b->d_out.ptr, sizeof(gp_linearized6) * F, hipMemcpyDeviceToHost, b->stream));
+  GP_TRY(gp_vgicp_batch_issue_linearize(b, poses_host, reinterpret_cast<gp_linearized6*>(b->h_out_dev)));
   GP_HIP(hipStreamSynchronize(b->stream));
   memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
   return GP_OK;
@@ -731,10 +821,7 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
   if (!b || !poses_lin_host || !poses_eval_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_compute_error: null");
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
-  GP_TRY(b->d_out.ensure(sizeof(gp_linearized6) * F));
-  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * F));
-  GP_TRY(gp_vgicp_batch_issue_compute_error(b, poses_lin_host, poses_eval_host, b->d_out.as<double>()));
-  GP_HIP(hipMemcpyAsync(b->h_out.ptr, b->d_out.ptr, sizeof(double) * F, hipMemcpyDeviceToHost, b->stream));
+  GP_TRY(gp_vgicp_batch_issue_compute_error(b, poses_lin_host, poses_eval_host, reinterpret_cast<double*>(b->h_out_dev)));
   GP_HIP(hipStreamSynchronize(b->stream));
   memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
   return GP_OK;
@@ -742,48 +829,35 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
 
 int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel) {
   if (!b || !poses_host || iters <= 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_time_linearize: bad arguments");
-  if (b->table_dirty) GP_TRY(build_table(b));
+  if (b->table_dirty || b->variant != g_variant) GP_TRY(build_table(b));
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
-  GP_TRY(b->d_out.ensure(sizeof(gp_linearized6) * F));
-  GP_TRY(upload_poses(b, poses_host, nullptr));
+  gp::DeviceArray d_out;
+  GP_TRY(d_out.alloc(sizeof(gp_linearized6) * F));
+  PoseSource ps;
+  GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
+  const bool rigid = poses_are_rigid(poses_host, F);
   hipEvent_t e0, e1, e2;
   GP_HIP(hipEventCreate(&e0));
   GP_HIP(hipEventCreate(&e1));
   GP_HIP(hipEventCreate(&e2));
-  const double* d_poses = b->d_poses.as<double>();
-  // warm-up
-  const bool rigid = poses_are_rigid(poses_host, F);
-  GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>(), rigid));
+  GP_TRY(launch_linearize(b, ps, d_out.as<gp_linearized6>(), rigid));  // warm-up
   GP_HIP(hipStreamSynchronize(b->stream));
   // whole pass, back to back
   GP_HIP(hipEventRecord(e0, b->stream));
-  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, d_poses, b->d_out.as<gp_linearized6>(), rigid));
+  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, ps, d_out.as<gp_linearized6>(), rigid));
   GP_HIP(hipEventRecord(e1, b->stream));
   GP_HIP(hipEventSynchronize(e1));
   float t_total = 0.f;
   GP_HIP(hipEventElapsedTime(&t_total, e0, e1));
   // main kernel alone, then finalize alone (same stream the product path launches on)
   GP_HIP(hipEventRecord(e0, b->stream));
-  for (int i = 0; i < iters; i++) {
-    if (rigid)
-      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
-                         b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
-    else
-      hipLaunchKernelGGL(gp::vgicp_tile_kernel<gp::MODE_LIN_GENERAL>, dim3(grid_tiles(b->num_tiles)), dim3(gp::kBlockThreads), 0, b->stream,
-                         b->d_factors.as<gp::FactorDesc>(), b->d_tiles.as<gp::TileDesc>(), b->num_tiles, d_poses, d_poses, partials);
-  }
+  for (int i = 0; i < iters; i++) GP_TRY(rigid ? launch_tiles<gp::MODE_LIN>(b, ps, partials) : launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
   GP_HIP(hipEventRecord(e1, b->stream));
-  for (int i = 0; i < iters; i++) {
-    if (rigid)
-      hipLaunchKernelGGL(gp::vgicp_finalize_kernel<false>, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses,
-                         partials, b->d_out.as<gp_linearized6>());
-    else
-      hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), d_poses,
-                         partials, b->d_out.as<gp_linearized6>());
-  }
+  for (int i = 0; i < iters; i++)
+    GP_TRY(rigid ? launch_finalize<false>(b, ps, partials, d_out.as<gp_linearized6>()) : launch_finalize<true>(b, ps, partials, d_out.as<gp_linearized6>()));
   GP_HIP(hipEventRecord(e2, b->stream));
   GP_HIP(hipEventSynchronize(e2));
   float t_main = 0.f, t_fin = 0.f;

@@ -1,0 +1,305 @@
+// gp_vgicp_tile.hpp -- the tuned tile kernel of the VGICP path (rigid poses; MODE_LIN / MODE_ERR).
+//
+// Same arithmetic as accumulate_point<> in gp_vgicp.hip, restructured for the memory system of gfx950:
+//   phase A  all kPointsPerThread source points of a lane are loaded first (independent, coalesced across the wave:
+//            64 lanes x 12 B points / 36 B covariances are contiguous in memory)
+//   phase B  f64 transform + floor + hash, then the FIRST bucket probe of every point is issued back to back
+//   phase C  probes are resolved (the rare collision chain walks on), then every hit's 64-B voxel record is requested
+//   phase D  f64 fused-covariance inverse and the 29 target-side sums per hit
+//   so a lane has up to 4 dependent-load chains in flight instead of one (the v1 kernel was latency-bound:
+//   3 serial round trips per point).
+//   All pointers are cast to the global address space (descriptors loaded from memory would otherwise make hipcc emit
+//   flat_load, which also ties up lgkmcnt).
+//   The 64-lane reduction is a transposing butterfly: 32 xor-shuffles of doubles instead of 29 x 6.
+#pragma once
+
+#include "gp_device.hpp"
+
+namespace gp {
+
+#define GP_GLOBAL __attribute__((address_space(1)))
+
+template <typename T>
+__device__ __forceinline__ const GP_GLOBAL T* as_global(const T* p) {
+  return (const GP_GLOBAL T*)p;
+}
+
+// builtin vector types: loads through an address-space-qualified pointer compile on the host pass too
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+struct f3 {
+  float x, y, z;
+};
+
+// cheap reciprocal: v_rcp_f64 (~2^-23) + two Newton steps (-> ~1 ulp); replaces the ~30-instruction IEEE division
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = x * (2.0 - d * x);
+  x = x * (2.0 - d * x);
+  return x;
+}
+
+// transposing butterfly over a 64-lane wavefront: in v[0..31] per lane, out: lane L holds the wave-wide sum of
+// component comp(L) = bitrev5(L >> 1) in v[0] (both lanes of a pair hold the same value).
+__device__ __forceinline__ int butterfly_component(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
+template <int D, int C>
+__device__ __forceinline__ void butterfly_step(double* v, int lane) {
+  const bool upper = (lane & D) != 0;
+#pragma unroll
+  for (int k = 0; k < C; k++) {
+    const double send = upper ? v[k] : v[k + C];
+    const double keep = upper ? v[k + C] : v[k];
+    v[k] = keep + __shfl_xor(send, D, 64);
+  }
+}
+
+__device__ __forceinline__ double butterfly_reduce32(double* v, int lane) {
+  butterfly_step<32, 16>(v, lane);
+  butterfly_step<16, 8>(v, lane);
+  butterfly_step<8, 4>(v, lane);
+  butterfly_step<4, 2>(v, lane);
+  butterfly_step<2, 1>(v, lane);
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
+template <int MODE, bool OUTER_F32, int PPT>
+__global__ void __launch_bounds__(256) vgicp_tile_kernel2(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                          const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                          double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  if (tile_idx >= num_tiles) return;
+  const TileDesc tile = tiles[tile_idx];      // kernel-argument pointers are already known to be global
+  const FactorDesc f = factors[tile.factor];  // (uniform -> scalar loads)
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const GP_GLOBAL v4i* buckets = (const GP_GLOBAL v4i*)f.map.buckets;
+  const GP_GLOBAL VoxelRecord* records = as_global(f.map.records);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // ---- phase A: source points and covariances ----
+  f3 p[PPT];
+  float cov[PPT][6];
+  bool active[PPT];
+#pragma unroll
+  for (int it = 0; it < PPT; it++) {
+    const int local = it * 256 + threadIdx.x;
+    active[it] = local < tile.count;
+    const size_t i = (size_t)tile.begin + (active[it] ? local : 0);
+    p[it].x = points[3 * i];
+    p[it].y = points[3 * i + 1];
+    p[it].z = points[3 * i + 2];
+    const GP_GLOBAL float* cp = covs + 9 * i;
+    cov[it][0] = cp[0];  // xx
+    cov[it][1] = cp[3];  // xy
+    cov[it][3] = cp[4];  // yy
+    cov[it][2] = cp[6];  // xz
+    cov[it][4] = cp[7];  // yz
+    cov[it][5] = cp[8];  // zz
+  }
+
+  // ---- phase B: transform, voxel coordinate, hash, first probe ----
+  int cx[PPT], cy[PPT], cz[PPT];
+  uint64_t hash[PPT];
+  v4i bk[PPT];
+#pragma unroll
+  for (int it = 0; it < PPT; it++) {
+    const double px = (double)p[it].x, py = (double)p[it].y, pz = (double)p[it].z;
+    const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
+    const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
+    const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
+    cx[it] = fast_floor(lx * f.map.inv_leaf);
+    cy[it] = fast_floor(ly * f.map.inv_leaf);
+    cz[it] = fast_floor(lz * f.map.inv_leaf);
+    if (f.surface_validation && active[it] && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * ((size_t)tile.begin + it * 256 + threadIdx.x))) active[it] = false;
+    hash[it] = coord_hash(cx[it], cy[it], cz[it]);
+    bk[it] = buckets[bucket_index(hash[it], 0, f.map.num_buckets, f.map.bucket_mask)];
+  }
+
+  // ---- phase C: resolve probes, request the voxel records ----
+  int vid[PPT];
+  v4f head[PPT];
+  v2d c01[PPT], c23[PPT], c45[PPT];
+#pragma unroll
+  for (int it = 0; it < PPT; it++) {
+    int v = -1;
+    if (active[it]) {
+      v4i b = bk[it];
+      for (int i = 0;;) {
+        if (b.w < 0) break;
+        if (b.x == cx[it] && b.y == cy[it] && b.z == cz[it]) {
+          v = b.w;
+          break;
+        }
+        if (++i >= f.map.max_scan) break;
+        b = buckets[bucket_index(hash[it], i, f.map.num_buckets, f.map.bucket_mask)];
+      }
+    }
+    vid[it] = v;
+    if (v >= 0) {
+      const GP_GLOBAL char* rec = (const GP_GLOBAL char*)(records + v);
+      head[it] = *(const GP_GLOBAL v4f*)rec;
+      c01[it] = *(const GP_GLOBAL v2d*)(rec + 16);
+      c23[it] = *(const GP_GLOBAL v2d*)(rec + 32);
+      c45[it] = *(const GP_GLOBAL v2d*)(rec + 48);
+    }
+  }
+
+  // ---- phase D: per-hit arithmetic ----
+  double acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = 0.0;
+  float accf[OUTER_F32 ? 32 : 1];
+  if constexpr (OUTER_F32) {
+#pragma unroll
+    for (int k = 0; k < 32; k++) accf[k] = 0.0f;
+  }
+#pragma unroll
+  for (int it = 0; it < PPT; it++) {
+    if (vid[it] < 0) continue;
+    const double px = (double)p[it].x, py = (double)p[it].y, pz = (double)p[it].z;
+    const double ca[6] = {(double)cov[it][0], (double)cov[it][1], (double)cov[it][2], (double)cov[it][3], (double)cov[it][4], (double)cov[it][5]};
+    const double cb[6] = {c01[it].x, c01[it].y, c23[it].x, c23[it].y, c45[it].x, c45[it].y};
+    // M = (C_B + R C_A R^T)^-1 in f64 (condition number up to 1e3: f32 here would cost ~1e-4 per point, systematic)
+    double m[6];
+    {
+      const double a00 = ca[0], a01 = ca[1], a02 = ca[2], a11 = ca[3], a12 = ca[4], a22 = ca[5];
+      const double rc00 = Tl.r00 * a00 + Tl.r01 * a01 + Tl.r02 * a02, rc01 = Tl.r00 * a01 + Tl.r01 * a11 + Tl.r02 * a12, rc02 = Tl.r00 * a02 + Tl.r01 * a12 + Tl.r02 * a22;
+      const double rc10 = Tl.r10 * a00 + Tl.r11 * a01 + Tl.r12 * a02, rc11 = Tl.r10 * a01 + Tl.r11 * a11 + Tl.r12 * a12, rc12 = Tl.r10 * a02 + Tl.r11 * a12 + Tl.r12 * a22;
+      const double rc20 = Tl.r20 * a00 + Tl.r21 * a01 + Tl.r22 * a02, rc21 = Tl.r20 * a01 + Tl.r21 * a11 + Tl.r22 * a12, rc22 = Tl.r20 * a02 + Tl.r21 * a12 + Tl.r22 * a22;
+      const double s00 = cb[0] + rc00 * Tl.r00 + rc01 * Tl.r01 + rc02 * Tl.r02;
+      const double s01 = cb[1] + rc00 * Tl.r10 + rc01 * Tl.r11 + rc02 * Tl.r12;
+      const double s02 = cb[2] + rc00 * Tl.r20 + rc01 * Tl.r21 + rc02 * Tl.r22;
+      const double s11 = cb[3] + rc10 * Tl.r10 + rc11 * Tl.r11 + rc12 * Tl.r12;
+      const double s12 = cb[4] + rc10 * Tl.r20 + rc11 * Tl.r21 + rc12 * Tl.r22;
+      const double s22 = cb[5] + rc20 * Tl.r20 + rc21 * Tl.r21 + rc22 * Tl.r22;
+      const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
+      const double invdet = fast_rcp(s00 * i00 + s01 * i01 + s02 * i02);
+      m[0] = i00 * invdet;
+      m[1] = i01 * invdet;
+      m[2] = i02 * invdet;
+      m[3] = (s00 * s22 - s02 * s02) * invdet;
+      m[4] = (s01 * s02 - s00 * s12) * invdet;
+      m[5] = (s00 * s11 - s01 * s01) * invdet;
+    }
+    // q at the evaluation pose (== linearisation pose for MODE_LIN), residual against centre + mean_local in f64
+    const double qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
+    const double qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
+    const double qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
+    const double rx = (((double)cx[it] + 0.5) * f.map.leaf - qx) + (double)head[it].x;
+    const double ry = (((double)cy[it] + 0.5) * f.map.leaf - qy) + (double)head[it].y;
+    const double rz = (((double)cz[it] + 0.5) * f.map.leaf - qz) + (double)head[it].z;
+
+    if constexpr (!OUTER_F32) {
+      const double mrx = m[0] * rx + m[1] * ry + m[2] * rz;
+      const double mry = m[1] * rx + m[3] * ry + m[4] * rz;
+      const double mrz = m[2] * rx + m[4] * ry + m[5] * rz;
+      acc[ACC_COUNT] += 1.0;
+      acc[ACC_ERR] += rx * mrx + ry * mry + rz * mrz;
+      if constexpr (MODE == MODE_LIN) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[ACC_M + k] += m[k];
+        const double k00 = m[1] * qz - m[2] * qy, k01 = m[2] * qx - m[0] * qz, k02 = m[0] * qy - m[1] * qx;
+        const double k10 = m[3] * qz - m[4] * qy, k11 = m[4] * qx - m[1] * qz, k12 = m[1] * qy - m[3] * qx;
+        const double k20 = m[4] * qz - m[5] * qy, k21 = m[5] * qx - m[2] * qz, k22 = m[2] * qy - m[4] * qx;
+        acc[ACC_K + 0] += k00;
+        acc[ACC_K + 1] += k01;
+        acc[ACC_K + 2] += k02;
+        acc[ACC_K + 3] += k10;
+        acc[ACC_K + 4] += k11;
+        acc[ACC_K + 5] += k12;
+        acc[ACC_K + 6] += k20;
+        acc[ACC_K + 7] += k21;
+        acc[ACC_K + 8] += k22;
+        acc[ACC_TL + 0] += qz * k10 - qy * k20;
+        acc[ACC_TL + 1] += qz * k11 - qy * k21;
+        acc[ACC_TL + 2] += qz * k12 - qy * k22;
+        acc[ACC_TL + 3] += qx * k21 - qz * k01;
+        acc[ACC_TL + 4] += qx * k22 - qz * k02;
+        acc[ACC_TL + 5] += qy * k02 - qx * k12;
+        acc[ACC_QXMR + 0] += qy * mrz - qz * mry;
+        acc[ACC_QXMR + 1] += qz * mrx - qx * mrz;
+        acc[ACC_QXMR + 2] += qx * mry - qy * mrx;
+        acc[ACC_MR + 0] += mrx;
+        acc[ACC_MR + 1] += mry;
+        acc[ACC_MR + 2] += mrz;
+      }
+    } else {
+      // outer products in f32 on f64-accurate M, r, q (experimental variant)
+      const float M0 = (float)m[0], M1 = (float)m[1], M2 = (float)m[2], M3 = (float)m[3], M4 = (float)m[4], M5 = (float)m[5];
+      const float RX = (float)rx, RY = (float)ry, RZ = (float)rz, QX = (float)qx, QY = (float)qy, QZ = (float)qz;
+      const float mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+      accf[ACC_COUNT] += 1.0f;
+      accf[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+      if constexpr (MODE == MODE_LIN) {
+        accf[ACC_M + 0] += M0;
+        accf[ACC_M + 1] += M1;
+        accf[ACC_M + 2] += M2;
+        accf[ACC_M + 3] += M3;
+        accf[ACC_M + 4] += M4;
+        accf[ACC_M + 5] += M5;
+        const float k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
+        const float k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
+        const float k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+        accf[ACC_K + 0] += k00;
+        accf[ACC_K + 1] += k01;
+        accf[ACC_K + 2] += k02;
+        accf[ACC_K + 3] += k10;
+        accf[ACC_K + 4] += k11;
+        accf[ACC_K + 5] += k12;
+        accf[ACC_K + 6] += k20;
+        accf[ACC_K + 7] += k21;
+        accf[ACC_K + 8] += k22;
+        accf[ACC_TL + 0] += QZ * k10 - QY * k20;
+        accf[ACC_TL + 1] += QZ * k11 - QY * k21;
+        accf[ACC_TL + 2] += QZ * k12 - QY * k22;
+        accf[ACC_TL + 3] += QX * k21 - QZ * k01;
+        accf[ACC_TL + 4] += QX * k22 - QZ * k02;
+        accf[ACC_TL + 5] += QY * k02 - QX * k12;
+        accf[ACC_QXMR + 0] += QY * mrz - QZ * mry;
+        accf[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
+        accf[ACC_QXMR + 2] += QX * mry - QY * mrx;
+        accf[ACC_MR + 0] += mrx;
+        accf[ACC_MR + 1] += mry;
+        accf[ACC_MR + 2] += mrz;
+      }
+    }
+  }
+  if constexpr (OUTER_F32) {
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] = (double)accf[k];
+  }
+
+  // ---- wavefront reduction (transposing butterfly), then LDS across the 4 waves ----
+  __shared__ double lds[4][ACC_STRIDE];
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+  } else {
+    const double s = butterfly_reduce32(acc, lane);
+    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double s = 0.0;
+    if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
+  }
+}
+
+}  // namespace gp

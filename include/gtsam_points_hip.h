@@ -227,6 +227,9 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* batch, const double* poses_li
  * between two hipEvents and returns the average milliseconds per pass, and separately the two kernels' times */
 int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* batch, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel);
 
+/* tuning hook (not part of the reference API): selects the tile-kernel variant, see gp_vgicp.hip */
+int gp_debug_set_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

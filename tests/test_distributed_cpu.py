@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharded linearise (partition -> per-rank records into the stacked
+buffer -> one all_reduce).  The per-rank compute is the oracle here (test stand-in; on GPUs it is the HIP batch)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gtsam_points_amd.distributed import RECORD_DOUBLES, ShardedLinearizer, partition_factors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_contiguous_balanced_and_complete():
+    w = [100, 200, 50, 50, 300, 100, 100, 100]
+    for world in [1, 2, 3, 4, 8, 16]:
+        parts = partition_factors(w, world)
+        assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == len(w)
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+        assert all(b <= e for b, e in parts)
+    loads = [sum(w[b:e]) for b, e in partition_factors(w, 2)]
+    assert abs(loads[0] - loads[1]) <= max(w)
+    assert partition_factors([], 4) == [(0, 0)] * 4
+
+
+def _records_for(pairs, ids):
+    """oracle records of the listed factor ids as [len(ids) x 122] doubles in gp_linearized6 layout"""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "kitti07_dec4.npz"))
+    out = np.zeros((len(ids), RECORD_DOUBLES))
+    for row, fid in enumerate(ids):
+        i, j = pairs[fid]
+        vm = oracle.OracleVoxelMap(1.0)
+        vm.insert(d[f"points_{i}"], d[f"covs_{i}"])
+        L = oracle.OracleVGICPFactor(vm, d[f"points_{j}"], d[f"covs_{j}"], 1).linearize(oracle.calc_delta(d["poses"][i], d["poses"][j]))
+        out[row] = np.concatenate([[L.num_inliers, L.error], L.H_target.T.ravel(), L.H_source.T.ravel(), L.H_target_source.T.ravel(), L.b_target, L.b_source])
+    return out
+
+
+PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4)]
+WEIGHTS = [6176, 6144, 4228, 4968, 6144, 4228, 4968]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    begin, end = partition_factors(WEIGHTS, world)[rank]
+
+    def issue(_poses, view):
+        view.copy_(torch.from_numpy(_records_for(PAIRS, list(range(begin, end)))))
+
+    lin = ShardedLinearizer(len(PAIRS), (begin, end), "cpu", issue)
+    stacked = lin.linearize(None).clone()
+    stacked2 = lin.linearize(None)  # second pass: the buffer is re-zeroed, not accumulated
+    assert torch.equal(stacked, stacked2)
+    ret[rank] = stacked.numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_linearize_gloo_world2():
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    ref = _records_for(PAIRS, list(range(len(PAIRS))))
+    for r in range(world):
+        assert np.array_equal(ret[r], ref), f"rank {r}: stacked records differ from the single-process result"

@@ -138,7 +138,7 @@ def test_factor_set_batch_equals_per_factor_and_oracle(gpu, kitti07):
         eo = fo.error(oracle.calc_delta(values2[i], values2[j]))
         assert abs(e - eo) < PARITY_TOL * eo
         # the synchronous per-factor fall-back gives the same record bit-for-bit (same kernels, same order)
-        Ls = _sync_linearize(gpu, f, delta)
+        Ls = _sync_linearize(gpu, f, f.calc_delta(values))
         for k in BLOCKS:
             assert np.array_equal(getattr(Ls, k), {"H_target": hf.G[(0, 0)], "H_source": hf.G[(1, 1)], "H_target_source": hf.G[(0, 1)], "b_target": -hf.g[0], "b_source": -hf.g[1]}[k])
     pool.sync_all()
