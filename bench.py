@@ -34,6 +34,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
 
 
+def _load_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), or None.
+    bench.py cannot collect PMC counters itself; scripts/gpu_check.sh does, in separate rocprofv3 --pmc passes,
+    and scripts/pmc_summary.py applies the calibration."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("tile_kernel_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,12 +156,15 @@ def main():
         peak=HBM_PEAK_GBS,
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 5),
-        traffic=None,
+        traffic=_load_traffic(),
         algorithmic_bytes=alg_bytes,
         kernel_ms=round(ms_main.value, 5),
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
     )
+
+    if os.environ.get("GP_BENCH_CALIBRATE"):  # PMC passes only: known-byte-count stream for FETCH_SIZE calibration
+        _capi.check(lib.gp_debug_calibration_stream(src.ptr(src.points_gpu), src.ptr(src.covs_gpu), args.source_points, 5, C.c_void_p(stream.cuda_stream)), "calibration")
 
     rec = gpa.LinearizedSystem6.from_doubles(host_out[rank].numpy())
     result = None

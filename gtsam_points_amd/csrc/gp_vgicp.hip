@@ -385,6 +385,19 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(con
   }
 }
 
+// HBM-counter calibration: streams points (12 B) and covariances (36 B) with exactly the per-lane access pattern of the
+// tile kernel and nothing else, so that rocprofv3's FETCH_SIZE can be scaled on a known byte count (48 * n)
+// (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is uncalibrated for non-16-B-per-lane patterns).
+__global__ void __launch_bounds__(256) calibration_stream_kernel(const float* __restrict__ points, const float* __restrict__ covs, int n, float* __restrict__ sink) {
+  float s = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float* pp = points + 3 * (size_t)i;
+    const float* cp = covs + 9 * (size_t)i;
+    s += pp[0] + pp[1] + pp[2] + cp[0] + cp[3] + cp[4] + cp[6] + cp[7] + cp[8];
+  }
+  if (s == 123.456f) sink[0] = s;  // never true for real data; keeps the loads alive
+}
+
 }  // namespace gp
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -612,6 +625,17 @@ int ensure_self_batch(gp_vgicp_factor* f) {
 }  // namespace
 
 extern "C" {
+
+int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream) {
+  if (!points_dev || !covs_dev || n <= 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_calibration_stream: bad arguments");
+  gp::DeviceArray sink;
+  GP_TRY(sink.alloc(16));
+  for (int i = 0; i < iters; i++)
+    hipLaunchKernelGGL(gp::calibration_stream_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, points_dev, covs_dev, n, sink.as<float>());
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return GP_OK;
+}
 
 int gp_debug_set_variant(int variant) {
   if (variant < 0 || variant > 5) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..5");

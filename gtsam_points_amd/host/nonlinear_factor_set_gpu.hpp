@@ -1,0 +1,227 @@
+// nonlinear_factor_set_gpu.hpp -- NonlinearFactorSet / LinearizationHook / NonlinearFactorSetGPU
+// (optimizers/linearization_hook.{hpp,cpp}, cuda/nonlinear_factor_set_gpu.{hpp,cpp}) over the C-ABI.
+// An all-VGICP set issues ONE batched launch per linearize()/error(); any other NonlinearFactorGPU goes through the
+// reference's staging-buffer protocol with the same byte cursors.
+#pragma once
+#include <gtsam_points_hip.h>
+
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "check_error.hpp"
+#include "integrated_vgicp_factor_gpu.hpp"
+
+namespace gtsam_points {
+
+class NonlinearFactorSet {  // linearization_hook.hpp:11-29
+public:
+  virtual ~NonlinearFactorSet() {}
+  virtual int size() const = 0;
+  virtual void clear() = 0;
+  virtual void clear_counts() = 0;
+  virtual int linearization_count() const = 0;
+  virtual int evaluation_count() const = 0;
+  virtual bool add(gtsam::NonlinearFactor::shared_ptr factor) = 0;
+  virtual void add(const gtsam::NonlinearFactorGraph& factors) = 0;
+  virtual void linearize(const gtsam::Values& values) = 0;
+  virtual void error(const gtsam::Values& values) = 0;
+  virtual std::vector<gtsam::GaussianFactor::shared_ptr> calc_linear_factors(const gtsam::Values& linearization_point) = 0;
+};
+
+class NonlinearFactorSetGPU : public NonlinearFactorSet {
+public:
+  NonlinearFactorSetGPU() { check_error << gp_stream_create(&stream); }
+  ~NonlinearFactorSetGPU() override {
+    drop_batch();
+    check_error << gp_free(d_lin_in);
+    check_error << gp_free(d_lin_out);
+    check_error << gp_free(d_eval_in);
+    check_error << gp_free(d_eval_out);
+    check_error << gp_stream_destroy(stream);
+  }
+
+  int size() const override { return static_cast<int>(factors.size()); }
+  void clear() override {
+    factors.clear();
+    drop_batch();
+  }
+  void clear_counts() override { num_linearizations = num_evaluations = 0; }
+  int linearization_count() const override { return num_linearizations; }
+  int evaluation_count() const override { return num_evaluations; }
+
+  bool add(gtsam::NonlinearFactor::shared_ptr factor) override {  // keeps only NonlinearFactorGPU instances (:48-56)
+    auto gpu_factor = gtsam_points::dynamic_pointer_cast<NonlinearFactorGPU>(factor);
+    if (!gpu_factor) return false;
+    factors.push_back(gpu_factor);
+    drop_batch();
+    return true;
+  }
+  void add(const gtsam::NonlinearFactorGraph& graph) override {
+    for (const auto& f : graph) add(f);
+  }
+
+  void linearize(const gtsam::Values& values) override {  // :64-139
+    if (factors.empty()) return;
+    num_linearizations += size();
+    size_t in_size = 0, out_size = 0;
+    for (const auto& f : factors) {
+      in_size += f->linearization_input_size();
+      out_size += f->linearization_output_size();
+    }
+    lin_in_cpu.resize(in_size);
+    lin_out_cpu.resize(out_size);
+    size_t cur = 0;
+    for (auto& f : factors) {
+      f->set_linearization_point(values, lin_in_cpu.data() + cur);
+      cur += f->linearization_input_size();
+    }
+    if (ensure_batch()) {  // fast path: every factor is an IntegratedVGICPFactorGPU (input = 128-B pose, output = 976-B record)
+      check_error << gp_vgicp_batch_linearize(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<gp_linearized6*>(lin_out_cpu.data()));
+    } else {
+      resize(&d_lin_in, &d_lin_in_size, in_size);
+      resize(&d_lin_out, &d_lin_out_size, out_size);
+      check_error << gp_memcpy_h2d(d_lin_in, lin_in_cpu.data(), in_size, stream);
+      check_error << gp_stream_synchronize(stream);
+      size_t ci = 0, co = 0;
+      for (auto& f : factors) {
+        f->issue_linearize(lin_in_cpu.data() + ci, static_cast<char*>(d_lin_in) + ci, static_cast<char*>(d_lin_out) + co);
+        ci += f->linearization_input_size();
+        co += f->linearization_output_size();
+      }
+      for (auto& f : factors) f->sync();
+      check_error << gp_memcpy_d2h(lin_out_cpu.data(), d_lin_out, out_size, stream);
+      check_error << gp_stream_synchronize(stream);
+    }
+    cur = 0;
+    for (auto& f : factors) {
+      f->store_linearized(lin_out_cpu.data() + cur);
+      cur += f->linearization_output_size();
+    }
+  }
+
+  void error(const gtsam::Values& values) override {  // :141-218; valid only after linearize() with the same factor order (:180-181)
+    if (factors.empty()) return;
+    num_evaluations += size();
+    size_t in_size = 0, out_size = 0;
+    for (const auto& f : factors) {
+      in_size += f->evaluation_input_size();
+      out_size += f->evaluation_output_size();
+    }
+    eval_in_cpu.resize(in_size);
+    eval_out_cpu.resize(out_size);
+    size_t cur = 0;
+    for (auto& f : factors) {
+      f->set_evaluation_point(values, eval_in_cpu.data() + cur);
+      cur += f->evaluation_input_size();
+    }
+    if (ensure_batch()) {
+      check_error << gp_vgicp_batch_compute_error(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<const double*>(eval_in_cpu.data()),
+                                                  reinterpret_cast<double*>(eval_out_cpu.data()));
+    } else {
+      resize(&d_eval_in, &d_eval_in_size, in_size);
+      resize(&d_eval_out, &d_eval_out_size, out_size);
+      check_error << gp_memcpy_h2d(d_eval_in, eval_in_cpu.data(), in_size, stream);
+      check_error << gp_stream_synchronize(stream);
+      size_t cl = 0, ci = 0, co = 0;
+      for (auto& f : factors) {
+        f->issue_compute_error(lin_in_cpu.data() + cl, eval_in_cpu.data() + ci, static_cast<char*>(d_lin_in) + cl, static_cast<char*>(d_eval_in) + ci, static_cast<char*>(d_eval_out) + co);
+        cl += f->linearization_input_size();
+        ci += f->evaluation_input_size();
+        co += f->evaluation_output_size();
+      }
+      for (auto& f : factors) f->sync();
+      check_error << gp_memcpy_d2h(eval_out_cpu.data(), d_eval_out, out_size, stream);
+      check_error << gp_stream_synchronize(stream);
+    }
+    cur = 0;
+    for (auto& f : factors) {
+      f->store_computed_error(eval_out_cpu.data() + cur);
+      cur += f->evaluation_output_size();
+    }
+  }
+
+  std::vector<gtsam::GaussianFactor::shared_ptr> calc_linear_factors(const gtsam::Values& linearization_point) override {  // :220-228
+    linearize(linearization_point);
+    std::vector<gtsam::GaussianFactor::shared_ptr> linear_factors(factors.size());
+    for (size_t i = 0; i < factors.size(); i++) linear_factors[i] = factors[i]->linearize(linearization_point);
+    return linear_factors;
+  }
+
+private:
+  bool ensure_batch() {
+    if (batch) return true;
+    if (batch_checked) return false;
+    batch_checked = true;
+    std::vector<gp_vgicp_factor_t*> handles;
+    for (const auto& f : factors) {
+      auto v = std::dynamic_pointer_cast<IntegratedVGICPFactorGPU>(f);
+      if (!v) return false;
+      handles.push_back(v->handle());
+    }
+    check_error << gp_vgicp_batch_create(handles.data(), static_cast<int>(handles.size()), stream, &batch);
+    return batch != nullptr;
+  }
+  void drop_batch() {
+    if (batch) check_error << gp_vgicp_batch_destroy(batch);
+    batch = nullptr;
+    batch_checked = false;
+  }
+  void resize(void** buf, size_t* cap, size_t size) {  // grow-only DeviceBuffer::resize (:20-28)
+    if (*cap >= size) return;
+    check_error << gp_free(*buf);
+    check_error << gp_malloc(buf, size);
+    *cap = size;
+  }
+
+  gp_stream_t stream = nullptr;
+  int num_linearizations = 0, num_evaluations = 0;
+  std::vector<NonlinearFactorGPU::shared_ptr> factors;
+  std::vector<unsigned char> lin_in_cpu, lin_out_cpu, eval_in_cpu, eval_out_cpu;
+  void *d_lin_in = nullptr, *d_lin_out = nullptr, *d_eval_in = nullptr, *d_eval_out = nullptr;
+  size_t d_lin_in_size = 0, d_lin_out_size = 0, d_eval_in_size = 0, d_eval_out_size = 0;
+  gp_vgicp_batch_t* batch = nullptr;
+  bool batch_checked = false;
+};
+
+inline std::shared_ptr<NonlinearFactorSet> create_nonlinear_factor_set_gpu() { return std::make_shared<NonlinearFactorSetGPU>(); }  // nonlinear_factor_set_gpu_create.hpp:10
+
+class LinearizationHook {  // linearization_hook.hpp:31-57, .cpp:10-90
+public:
+  LinearizationHook() {
+    for (const auto& ctor : hook_constructors()) hooks.push_back(ctor());
+  }
+  explicit LinearizationHook(const gtsam::NonlinearFactorGraph& factors) : LinearizationHook() { add(factors); }
+  int size() const { int n = 0; for (auto& h : hooks) n += h->size(); return n; }
+  void clear() { for (auto& h : hooks) h->clear(); }
+  void clear_counts() { for (auto& h : hooks) h->clear_counts(); }
+  int linearization_count() const { int n = 0; for (auto& h : hooks) n += h->linearization_count(); return n; }
+  int evaluation_count() const { int n = 0; for (auto& h : hooks) n += h->evaluation_count(); return n; }
+  bool add(gtsam::NonlinearFactor::shared_ptr factor) {
+    bool inserted = false;
+    for (auto& h : hooks) inserted |= h->add(factor);
+    return inserted;
+  }
+  void add(const gtsam::NonlinearFactorGraph& factors) { for (auto& h : hooks) h->add(factors); }
+  void linearize(const gtsam::Values& values) { for (auto& h : hooks) h->linearize(values); }
+  void error(const gtsam::Values& values) { for (auto& h : hooks) h->error(values); }
+  std::vector<gtsam::GaussianFactor::shared_ptr> calc_linear_factors(const gtsam::Values& p) {
+    std::vector<gtsam::GaussianFactor::shared_ptr> out;
+    for (auto& h : hooks) {
+      auto l = h->calc_linear_factors(p);
+      out.insert(out.end(), l.begin(), l.end());
+    }
+    return out;
+  }
+  static void register_hook(const std::function<std::shared_ptr<NonlinearFactorSet>()>& hook) { hook_constructors().push_back(hook); }
+
+private:
+  static std::vector<std::function<std::shared_ptr<NonlinearFactorSet>()>>& hook_constructors() {
+    static std::vector<std::function<std::shared_ptr<NonlinearFactorSet>()>> ctors;
+    return ctors;
+  }
+  std::vector<std::shared_ptr<NonlinearFactorSet>> hooks;
+};
+
+}  // namespace gtsam_points

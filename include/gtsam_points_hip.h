@@ -229,6 +229,8 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* batch, const double* poses_h
 
 /* tuning hook (not part of the reference API): selects the tile-kernel variant, see gp_vgicp.hip */
 int gp_debug_set_variant(int variant);
+/* profiling hook: streams 48*n bytes with the tile kernel's access pattern (calibrates rocprofv3 FETCH_SIZE) */
+int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
 
 #ifdef __cplusplus
 }

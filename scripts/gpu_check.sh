@@ -17,6 +17,7 @@ find gpurun_out/prof -name "*kernel_stats*" | head -3
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$ctr
-  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel-iters 5 > gpurun_out/pmc_$ctr.log 2>&1
-  f=$(find gpurun_out/pmc_$ctr -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python scripts/pmc_summary.py "$f" $ctr | tee gpurun_out/pmc_${ctr}_summary.txt
+  GP_BENCH_CALIBRATE=1 timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o pmc -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel-iters 5 > gpurun_out/pmc_$ctr.log 2>&1
 done
+ff=$(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+[ -n "$ff" ] && [ -n "$fw" ] && python scripts/pmc_summary.py "$ff" "$fw" 1000000 gpurun_out/hbm_traffic.json | tee gpurun_out/pmc_summary.txt
