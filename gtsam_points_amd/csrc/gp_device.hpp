@@ -32,6 +32,15 @@ struct __attribute__((aligned(64))) VoxelRecord {
 static_assert(sizeof(VoxelRecord) == 64, "VoxelRecord must be 64 B");
 
 struct VoxelMapView {
+  // private lookup structure of the VGICP kernels (built from the voxel list after insert / assign / reload):
+  //   pkeys[s] = {coord, voxel_index or -1}, pfat[s] = the voxel's 64-B record stored AT ITS SLOT, so the key and the
+  //   record of the home slot are requested together (no bucket -> record dependency), cheap 32-bit hash, power-of-two table
+  //   at load factor <= 0.5, unbounded linear probing (every voxel is always found).
+  const gp_voxel_bucket* pkeys;
+  const VoxelRecord* pfat;
+  uint32_t pmask;
+  uint32_t pad_;
+  // reference-visible table (reference hash + max_bucket_scan_count probe rule) and compact records
   const gp_voxel_bucket* buckets;
   const VoxelRecord* records;
   uint32_t num_buckets;
@@ -84,6 +93,17 @@ __host__ __device__ __forceinline__ uint64_t coord_hash(int x, int y, int z) {
   hash_combine(seed, (uint64_t)(int64_t)y);
   hash_combine(seed, (uint64_t)(int64_t)z);
   return seed;
+}
+
+// private 32-bit hash of the kernels' own table (3 + 2 v_mul_lo_u32 instead of nine 64-bit multiplies)
+__host__ __device__ __forceinline__ uint32_t coord_hash32(int x, int y, int z) {
+  uint32_t h = (uint32_t)x * 73856093u ^ (uint32_t)y * 19349669u ^ (uint32_t)z * 83492791u;
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  h *= 0x297a2d39u;
+  h ^= h >> 15;
+  return h;
 }
 
 // fast_floor in DOUBLE, util/fast_floor.hpp:12-15 (the CPU map's rule; the reference GPU map floors

@@ -440,8 +440,16 @@ namespace {
 
 // Kernel variant (tuning hook, gp_debug_set_variant): 0 = v1 reference kernel; 1..5 = phased kernel
 //   1: f64, 4 points/lane   2: f64, 2 points/lane   3: f64, 8 points/lane   4: f32 outer products, 4/lane   5: f32 outer, 8/lane
+//   6..13: kernel3 (private slot table, prefetch): {f32 outer?, points/lane/step, steps}
+//   6: f64 2x1   7: f64 2x2   8: f64 1x4   9: f32 2x1   10: f32 2x2   11: f32 4x1   12: f32 1x4   13: f32 2x4
 int g_variant = 1;
-inline int variant_ppt(int v) { return v == 2 ? 2 : (v == 3 || v == 5) ? 8 : 4; }
+inline int variant_ppt(int v) {
+  switch (v) {
+    case 2: case 6: case 9: return 2;
+    case 3: case 5: case 13: return 8;
+    default: return 4;  // 0,1,4 and 7,8,10,11,12 (2x2, 1x4, 4x1)
+  }
+}
 
 // where a launch takes its poses from
 struct PoseSource {
@@ -548,6 +556,33 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       case 5:
         GP_LAUNCH2(true, 8);
         break;
+#define GP_LAUNCH3(F32, PPT, ITERS) \
+  hipLaunchKernelGGL((gp::vgicp_tile_kernel3<MODE, F32, PPT, ITERS>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials)
+      case 6:
+        GP_LAUNCH3(false, 2, 1);
+        break;
+      case 7:
+        GP_LAUNCH3(false, 2, 2);
+        break;
+      case 8:
+        GP_LAUNCH3(false, 1, 4);
+        break;
+      case 9:
+        GP_LAUNCH3(true, 2, 1);
+        break;
+      case 10:
+        GP_LAUNCH3(true, 2, 2);
+        break;
+      case 11:
+        GP_LAUNCH3(true, 4, 1);
+        break;
+      case 12:
+        GP_LAUNCH3(true, 1, 4);
+        break;
+      case 13:
+        GP_LAUNCH3(true, 2, 4);
+        break;
+#undef GP_LAUNCH3
       default:
         GP_LAUNCH2(false, 4);
         break;
@@ -638,7 +673,7 @@ int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, 
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 5) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..5");
+  if (variant < 0 || variant > 13) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..13");
   g_variant = variant;
   return GP_OK;
 }

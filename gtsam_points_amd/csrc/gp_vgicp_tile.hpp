@@ -13,6 +13,8 @@
 //   The 64-lane reduction is a transposing butterfly: 32 xor-shuffles of doubles instead of 29 x 6.
 #pragma once
 
+#include <type_traits>
+
 #include "gp_device.hpp"
 
 namespace gp {
@@ -292,6 +294,230 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel2(const FactorDesc* __re
     }
   } else {
     const double s = butterfly_reduce32(acc, lane);
+    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double s = 0.0;
+    if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
+  }
+}
+
+
+// =====================================================================================================================
+// vgicp_tile_kernel3 -- as kernel2, plus:
+//   * the map's PRIVATE slot table (VoxelMapView::pkeys/pfat): cheap 32-bit hash, and the 64-B record of the home slot is
+//     requested together with its key -> 2 dependent round trips per point (source stream, table) instead of 3
+//   * a tile is ITERS steps of 256*PPT points; the source points/covariances of step k+1 are requested before step k is
+//     processed (register double buffer), with non-temporal loads so that the one-pass source stream does not evict the
+//     voxel table from the XCD's L2
+//   * OUTER_F32: f64 transform / floor / fused-covariance inverse / residual, f32 outer products and per-lane f32 partial
+//     sums over the <= PPT*ITERS points of a lane, f64 from the wavefront reduction on.
+// =====================================================================================================================
+template <int PPT>
+struct SourceRegs {
+  float px[PPT], py[PPT], pz[PPT];
+  float c[PPT][6];
+};
+
+template <int PPT>
+__device__ __forceinline__ void load_source(SourceRegs<PPT>& r, const GP_GLOBAL float* points, const GP_GLOBAL float* covs, int tile_begin, int tile_count, int step) {
+#pragma unroll
+  for (int j = 0; j < PPT; j++) {
+    const int local = (step * PPT + j) * 256 + (int)threadIdx.x;
+    const size_t i = (size_t)tile_begin + (local < tile_count ? local : 0);
+    const GP_GLOBAL float* pp = points + 3 * i;
+    const GP_GLOBAL float* cp = covs + 9 * i;
+    r.px[j] = __builtin_nontemporal_load(pp);
+    r.py[j] = __builtin_nontemporal_load(pp + 1);
+    r.pz[j] = __builtin_nontemporal_load(pp + 2);
+    r.c[j][0] = __builtin_nontemporal_load(cp);      // xx
+    r.c[j][1] = __builtin_nontemporal_load(cp + 3);  // xy
+    r.c[j][3] = __builtin_nontemporal_load(cp + 4);  // yy
+    r.c[j][2] = __builtin_nontemporal_load(cp + 6);  // xz
+    r.c[j][4] = __builtin_nontemporal_load(cp + 7);  // yz
+    r.c[j][5] = __builtin_nontemporal_load(cp + 8);  // zz
+  }
+}
+
+template <int MODE, bool OUTER_F32, int PPT, int ITERS>
+__global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                          const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                          double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  if (tile_idx >= num_tiles) return;
+  const TileDesc tile = tiles[tile_idx];
+  const FactorDesc f = factors[tile.factor];
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const GP_GLOBAL v4i* pkeys = (const GP_GLOBAL v4i*)f.map.pkeys;
+  const GP_GLOBAL char* pfat = (const GP_GLOBAL char*)f.map.pfat;
+  const uint32_t pmask = f.map.pmask;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  using acc_t = typename std::conditional<OUTER_F32, float, double>::type;
+  acc_t acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = (acc_t)0;
+
+  SourceRegs<PPT> cur, nxt;
+  load_source<PPT>(cur, points, covs, tile.begin, tile.count, 0);
+
+#pragma unroll
+  for (int step = 0; step < ITERS; step++) {
+    if (step + 1 < ITERS) {
+      // uniform early-out for short tiles keeps the prefetch in bounds (index clamped inside) and cheap
+      load_source<PPT>(nxt, points, covs, tile.begin, tile.count, step + 1);
+    }
+    // ---- phase B: transform, voxel coordinate, cheap hash; key + record of the home slot requested together ----
+    int cx[PPT], cy[PPT], cz[PPT];
+    uint32_t slot[PPT];
+    bool active[PPT];
+    v4i key[PPT];
+    v4f head[PPT];
+    v2d c01[PPT], c23[PPT], c45[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      const int local = (step * PPT + j) * 256 + (int)threadIdx.x;
+      active[j] = local < tile.count;
+      const double px = (double)cur.px[j], py = (double)cur.py[j], pz = (double)cur.pz[j];
+      const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
+      const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
+      const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
+      cx[j] = fast_floor(lx * f.map.inv_leaf);
+      cy[j] = fast_floor(ly * f.map.inv_leaf);
+      cz[j] = fast_floor(lz * f.map.inv_leaf);
+      if (f.surface_validation && active[j] && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * ((size_t)tile.begin + local))) active[j] = false;
+      slot[j] = coord_hash32(cx[j], cy[j], cz[j]) & pmask;
+      key[j] = pkeys[slot[j]];
+      const GP_GLOBAL char* rec = pfat + 64 * (size_t)slot[j];
+      head[j] = *(const GP_GLOBAL v4f*)rec;
+      c01[j] = *(const GP_GLOBAL v2d*)(rec + 16);
+      c23[j] = *(const GP_GLOBAL v2d*)(rec + 32);
+      c45[j] = *(const GP_GLOBAL v2d*)(rec + 48);
+    }
+    // ---- phase C: resolve; the collision chain (rare at load factor <= 0.5) walks on and re-fetches the record ----
+    bool hit[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      bool h = false;
+      if (active[j]) {
+        v4i k = key[j];
+        uint32_t s = slot[j];
+        bool moved = false;
+        while (k.w >= 0) {
+          if (k.x == cx[j] && k.y == cy[j] && k.z == cz[j]) {
+            h = true;
+            break;
+          }
+          s = (s + 1) & pmask;
+          k = pkeys[s];
+          moved = true;
+        }
+        if (h && moved) {
+          const GP_GLOBAL char* rec = pfat + 64 * (size_t)s;
+          head[j] = *(const GP_GLOBAL v4f*)rec;
+          c01[j] = *(const GP_GLOBAL v2d*)(rec + 16);
+          c23[j] = *(const GP_GLOBAL v2d*)(rec + 32);
+          c45[j] = *(const GP_GLOBAL v2d*)(rec + 48);
+        }
+      }
+      hit[j] = h;
+    }
+    // ---- phase D ----
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      if (!hit[j]) continue;
+      const double px = (double)cur.px[j], py = (double)cur.py[j], pz = (double)cur.pz[j];
+      double m[6];
+      {
+        const double a00 = (double)cur.c[j][0], a01 = (double)cur.c[j][1], a02 = (double)cur.c[j][2], a11 = (double)cur.c[j][3], a12 = (double)cur.c[j][4], a22 = (double)cur.c[j][5];
+        const double rc00 = Tl.r00 * a00 + Tl.r01 * a01 + Tl.r02 * a02, rc01 = Tl.r00 * a01 + Tl.r01 * a11 + Tl.r02 * a12, rc02 = Tl.r00 * a02 + Tl.r01 * a12 + Tl.r02 * a22;
+        const double rc10 = Tl.r10 * a00 + Tl.r11 * a01 + Tl.r12 * a02, rc11 = Tl.r10 * a01 + Tl.r11 * a11 + Tl.r12 * a12, rc12 = Tl.r10 * a02 + Tl.r11 * a12 + Tl.r12 * a22;
+        const double rc20 = Tl.r20 * a00 + Tl.r21 * a01 + Tl.r22 * a02, rc21 = Tl.r20 * a01 + Tl.r21 * a11 + Tl.r22 * a12, rc22 = Tl.r20 * a02 + Tl.r21 * a12 + Tl.r22 * a22;
+        const double s00 = c01[j].x + rc00 * Tl.r00 + rc01 * Tl.r01 + rc02 * Tl.r02;
+        const double s01 = c01[j].y + rc00 * Tl.r10 + rc01 * Tl.r11 + rc02 * Tl.r12;
+        const double s02 = c23[j].x + rc00 * Tl.r20 + rc01 * Tl.r21 + rc02 * Tl.r22;
+        const double s11 = c23[j].y + rc10 * Tl.r10 + rc11 * Tl.r11 + rc12 * Tl.r12;
+        const double s12 = c45[j].x + rc10 * Tl.r20 + rc11 * Tl.r21 + rc12 * Tl.r22;
+        const double s22 = c45[j].y + rc20 * Tl.r20 + rc21 * Tl.r21 + rc22 * Tl.r22;
+        const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
+        const double invdet = fast_rcp(s00 * i00 + s01 * i01 + s02 * i02);
+        m[0] = i00 * invdet;
+        m[1] = i01 * invdet;
+        m[2] = i02 * invdet;
+        m[3] = (s00 * s22 - s02 * s02) * invdet;
+        m[4] = (s01 * s02 - s00 * s12) * invdet;
+        m[5] = (s00 * s11 - s01 * s01) * invdet;
+      }
+      const double qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
+      const double qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
+      const double qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
+      const double rxd = (((double)cx[j] + 0.5) * f.map.leaf - qx) + (double)head[j].x;
+      const double ryd = (((double)cy[j] + 0.5) * f.map.leaf - qy) + (double)head[j].y;
+      const double rzd = (((double)cz[j] + 0.5) * f.map.leaf - qz) + (double)head[j].z;
+      const acc_t M0 = (acc_t)m[0], M1 = (acc_t)m[1], M2 = (acc_t)m[2], M3 = (acc_t)m[3], M4 = (acc_t)m[4], M5 = (acc_t)m[5];
+      const acc_t RX = (acc_t)rxd, RY = (acc_t)ryd, RZ = (acc_t)rzd, QX = (acc_t)qx, QY = (acc_t)qy, QZ = (acc_t)qz;
+      const acc_t mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+      acc[ACC_COUNT] += (acc_t)1;
+      acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+      if constexpr (MODE == MODE_LIN) {
+        acc[ACC_M + 0] += M0;
+        acc[ACC_M + 1] += M1;
+        acc[ACC_M + 2] += M2;
+        acc[ACC_M + 3] += M3;
+        acc[ACC_M + 4] += M4;
+        acc[ACC_M + 5] += M5;
+        const acc_t k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
+        const acc_t k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
+        const acc_t k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+        acc[ACC_K + 0] += k00;
+        acc[ACC_K + 1] += k01;
+        acc[ACC_K + 2] += k02;
+        acc[ACC_K + 3] += k10;
+        acc[ACC_K + 4] += k11;
+        acc[ACC_K + 5] += k12;
+        acc[ACC_K + 6] += k20;
+        acc[ACC_K + 7] += k21;
+        acc[ACC_K + 8] += k22;
+        acc[ACC_TL + 0] += QZ * k10 - QY * k20;
+        acc[ACC_TL + 1] += QZ * k11 - QY * k21;
+        acc[ACC_TL + 2] += QZ * k12 - QY * k22;
+        acc[ACC_TL + 3] += QX * k21 - QZ * k01;
+        acc[ACC_TL + 4] += QX * k22 - QZ * k02;
+        acc[ACC_TL + 5] += QY * k02 - QX * k12;
+        acc[ACC_QXMR + 0] += QY * mrz - QZ * mry;
+        acc[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
+        acc[ACC_QXMR + 2] += QX * mry - QY * mrx;
+        acc[ACC_MR + 0] += mrx;
+        acc[ACC_MR + 1] += mry;
+        acc[ACC_MR + 2] += mrz;
+      }
+    }
+    if (step + 1 < ITERS) cur = nxt;
+  }
+
+  // ---- wavefront reduction in f64 (transposing butterfly), LDS across the 4 waves ----
+  double accd[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) accd[k] = (double)acc[k];
+  __shared__ double lds[4][ACC_STRIDE];
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = accd[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+  } else {
+    const double s = butterfly_reduce32(accd, lane);
     if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
   }
   __syncthreads();

@@ -126,6 +126,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(int num_voxels, double le
   c[8] = (float)rec.cov[5];
 }
 
+// private slot table: claim a slot per voxel (cheap hash, unbounded linear probing), then store key + record at the slot
+__global__ void __launch_bounds__(256) private_claim_kernel(int num_voxels, const int* __restrict__ voxel_coords, const VoxelRecord* __restrict__ records,
+                                                            gp_voxel_bucket* __restrict__ pkeys, VoxelRecord* __restrict__ pfat, uint32_t pmask) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_voxels) return;
+  const int cx = voxel_coords[3 * (size_t)v], cy = voxel_coords[3 * (size_t)v + 1], cz = voxel_coords[3 * (size_t)v + 2];
+  uint32_t s = coord_hash32(cx, cy, cz) & pmask;
+  for (;;) {
+    if (atomicCAS(&pkeys[s].voxel_index, -1, v) == -1) break;  // voxel coordinates are distinct: no equality case
+    s = (s + 1) & pmask;
+  }
+  pkeys[s].coord[0] = cx;
+  pkeys[s].coord[1] = cy;
+  pkeys[s].coord[2] = cz;
+  pfat[s] = records[v];
+}
+
 // lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
 __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ points, const float* __restrict__ normals, int n, VoxelMapView map,
                                                      const double* __restrict__ pose, int* __restrict__ out, int* __restrict__ hit_count) {
@@ -152,6 +169,10 @@ __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ p
 
 gp::VoxelMapView gp_voxelmap::view() const {
   gp::VoxelMapView v;
+  v.pkeys = pkeys.as<gp_voxel_bucket>();
+  v.pfat = pfat.as<gp::VoxelRecord>();
+  v.pmask = pmask;
+  v.pad_ = 0;
   v.buckets = buckets.as<gp_voxel_bucket>();
   v.records = records.as<gp::VoxelRecord>();
   v.num_buckets = (uint32_t)info.num_buckets;
@@ -188,6 +209,24 @@ int alloc_voxel_arrays(gp_voxelmap* m, int V) {
 }
 
 }  // namespace
+
+// (re)build the kernels' private slot table from the voxel list; called at the end of insert / assign / reload
+static int build_private_table(gp_voxelmap* m, hipStream_t s) {
+  const int V = m->info.num_voxels;
+  uint32_t slots = 1024;
+  while (slots < 2u * (uint32_t)std::max(V, 1)) slots <<= 1;
+  m->pmask = slots - 1;
+  GP_TRY(m->pkeys.alloc(sizeof(gp_voxel_bucket) * (size_t)slots));
+  GP_TRY(m->pfat.alloc(sizeof(gp::VoxelRecord) * (size_t)slots));
+  GP_HIP(hipMemsetAsync(m->pkeys.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)slots, s));
+  GP_HIP(hipMemsetAsync(m->pfat.ptr, 0, sizeof(gp::VoxelRecord) * (size_t)slots, s));
+  if (V > 0) {
+    hipLaunchKernelGGL(gp::private_claim_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), m->records.as<gp::VoxelRecord>(),
+                       m->pkeys.as<gp_voxel_bucket>(), m->pfat.as<gp::VoxelRecord>(), m->pmask);
+    GP_HIP(hipGetLastError());
+  }
+  return GP_OK;
+}
 
 static inline gp_voxelmap* ext(gp_voxelmap* m) { return m; }
 static inline const gp_voxelmap* ext(const gp_voxelmap* m) { return m; }
@@ -274,6 +313,7 @@ int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float*
                        m->num_points.as<int>(), m->records.as<gp::VoxelRecord>(), m->voxel_means.as<float>(), m->voxel_covs.as<float>());
     GP_HIP(hipGetLastError());
   }
+  GP_TRY(build_private_table(m, s));
   GP_HIP(hipStreamSynchronize(s));  // :250
   return GP_OK;
 }
@@ -412,6 +452,8 @@ int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, co
     GP_HIP(hipMemcpyAsync(m->voxel_intensities.ptr, h_int.data(), sizeof(float) * V, hipMemcpyHostToDevice, s));
     GP_HIP(hipMemcpyAsync(m->voxel_coords.ptr, coords, sizeof(int) * 3 * V, hipMemcpyHostToDevice, s));
   }
+  GP_HIP(hipStreamSynchronize(s));  // the staging vectors die with this scope
+  GP_TRY(build_private_table(m, s));
   GP_HIP(hipStreamSynchronize(s));
   return GP_OK;
 }
@@ -501,7 +543,7 @@ size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
   if (!map) return 0;
   // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records and coordinates this implementation adds
   return (size_t)map->info.num_voxels * (sizeof(int) + sizeof(float) * 3 + sizeof(float) * 9 + sizeof(gp::VoxelRecord) + sizeof(int) * 3) +
-         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket);
+         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + ((size_t)map->pmask + 1) * (sizeof(gp_voxel_bucket) + sizeof(gp::VoxelRecord));
 }
 
 int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map) { return map && map->loaded() ? 1 : 0; }
@@ -539,6 +581,8 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   m->voxel_covs.release();
   m->voxel_intensities.release();
   m->voxel_coords.release();
+  m->pkeys.release();
+  m->pfat.release();
   m->offloaded = true;
   return GP_OK;
 }
@@ -555,6 +599,7 @@ int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream) {
   GP_TRY(to_device(m->voxel_covs, m->h_covs, s));
   GP_TRY(to_device(m->voxel_intensities, m->h_intensities, s));
   GP_TRY(to_device(m->voxel_coords, m->h_coords, s));
+  GP_TRY(build_private_table(m, s));
   GP_HIP(hipStreamSynchronize(s));
   m->offloaded = false;
   return GP_OK;
