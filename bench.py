@@ -151,7 +151,7 @@ def main():
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_tile_kernel<MODE_LIN>",
+        kernel="vgicp_tile_kernel2<MODE_LIN, f64, 2 points/lane>",
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",

@@ -126,6 +126,8 @@ _SIGNATURES = {
     "gp_vgicp_batch_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_debug_set_variant": (C.c_int, [C.c_int]),
+    "gp_debug_set_trace_buffer": (C.c_int, [C.c_void_p]),
+    "gp_debug_stream_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gp_debug_calibration_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }

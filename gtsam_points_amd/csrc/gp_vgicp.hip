@@ -38,11 +38,15 @@ struct FactorDesc {
   int tile_count;
 };
 
-// poses of a single-factor launch travel in the kernel arguments (no H2D copy on the latency path)
+
+// a single-factor launch carries its poses AND its factor descriptor in the kernel arguments: no H2D copy and no
+// dependent descriptor loads on the latency path (2.8 us per workgroup in the timeline traces)
 struct InlinePoses {
   double lin[16];
   double eval[16];
+  FactorDesc factor;
   int use;
+  int tile_points;
 };
 
 struct TileDesc {
@@ -214,8 +218,15 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorD
   constexpr int STRIDE = ModeTraits<MODE>::kStride;
   const int tile_idx = xcd_swizzle(blockIdx.x, num_tiles);
   if (tile_idx >= num_tiles) return;
-  const TileDesc tile = tiles[tile_idx];
-  const FactorDesc f = factors[tile.factor];
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
   const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
   const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
 
@@ -262,15 +273,32 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   constexpr int NACC = GENERAL ? ACCG_SIZE : ACC_SIZE;
   constexpr int kSlices = kFinalizeThreads / STRIDE;  // 1024 threads = 32 slices x 32 sums, or 10 x 96 (+ idle)
   const int fi = blockIdx.x;
-  const int tile_begin = factors[fi].tile_begin, tile_count = factors[fi].tile_count;
+  const int tile_begin = inl.use ? inl.factor.tile_begin : factors[fi].tile_begin;
+  const int tile_count = inl.use ? inl.factor.tile_count : factors[fi].tile_count;
   __shared__ double lds[kSlices][STRIDE];
   __shared__ double sum[STRIDE];
   __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
   const int comp = threadIdx.x % STRIDE, slice = threadIdx.x / STRIDE;
   if (slice < kSlices) {
-    double s = 0.0;
-    for (int t = slice; t < tile_count; t += kSlices) s += partials[(size_t)(tile_begin + t) * STRIDE + comp];
-    lds[slice][comp] = s;
+    // fixed summation order (deterministic); 8 independent loads in flight per lane instead of a serial load->add chain
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    const double* base = partials + (size_t)tile_begin * STRIDE + comp;
+    int t = slice;
+    for (; t + 7 * kSlices < tile_count; t += 8 * kSlices) {
+      const double v0 = base[(size_t)(t) * STRIDE], v1 = base[(size_t)(t + kSlices) * STRIDE], v2 = base[(size_t)(t + 2 * kSlices) * STRIDE],
+                   v3 = base[(size_t)(t + 3 * kSlices) * STRIDE], v4 = base[(size_t)(t + 4 * kSlices) * STRIDE], v5 = base[(size_t)(t + 5 * kSlices) * STRIDE],
+                   v6 = base[(size_t)(t + 6 * kSlices) * STRIDE], v7 = base[(size_t)(t + 7 * kSlices) * STRIDE];
+      s0 += v0;
+      s1 += v1;
+      s2 += v2;
+      s3 += v3;
+      s4 += v4;
+      s5 += v5;
+      s6 += v6;
+      s7 += v7;
+    }
+    for (; t < tile_count; t += kSlices) s0 += base[(size_t)t * STRIDE];
+    lds[slice][comp] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
   __syncthreads();
   if (threadIdx.x < STRIDE) {
@@ -398,6 +426,32 @@ __global__ void __launch_bounds__(256) calibration_stream_kernel(const float* __
   if (s == 123.456f) sink[0] = s;  // never true for real data; keeps the loads alive
 }
 
+// stream micro-benchmarks (what does it cost just to READ the 48*n source bytes at this problem size?)
+//   mode 1: coalesced 16 B per lane, grid-stride;  mode 2: LDS-DMA, 12 KB per wave like kernel5
+__global__ void __launch_bounds__(256) stream_float4_kernel(const float4* __restrict__ a, size_t n16, float* __restrict__ sink) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const float4 v = a[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  if (s == 123.456f) sink[0] = s;
+}
+
+__global__ void __launch_bounds__(256) stream_ldsdma_kernel(const char* __restrict__ a, size_t bytes, float* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 12288];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t base = ((size_t)blockIdx.x * 4 + wave) * 12288;
+  if (base + 12288 > bytes) return;
+  char* wbase = smem + wave * 12288;
+  const GP_GLOBAL char* g = (const GP_GLOBAL char*)a + base + lane * 16;
+#pragma unroll
+  for (int k = 0; k < 12; k++) __builtin_amdgcn_global_load_lds((const GP_GLOBAL void*)(g + k * 1024), (GP_LDS void*)(wbase + k * 1024), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float v = reinterpret_cast<float*>(wbase)[lane * 3] + reinterpret_cast<float*>(wbase)[2048 + lane];
+  if (v == 123.456f) sink[0] = v;
+}
+
 }  // namespace gp
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -430,6 +484,7 @@ struct gp_vgicp_batch {
   int tile_points = 0;
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
+  std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
   gp::PinnedArray h_out;  // results land here straight from the finalize kernel (host-mapped, no D2H copy op)
   void* h_out_dev = nullptr;
@@ -442,11 +497,13 @@ namespace {
 //   1: f64, 4 points/lane   2: f64, 2 points/lane   3: f64, 8 points/lane   4: f32 outer products, 4/lane   5: f32 outer, 8/lane
 //   6..13: kernel3 (private slot table, prefetch): {f32 outer?, points/lane/step, steps}
 //   6: f64 2x1   7: f64 2x2   8: f64 1x4   9: f32 2x1   10: f32 2x2   11: f32 4x1   12: f32 1x4   13: f32 2x4
-int g_variant = 1;
+int g_variant = 2;  // default: phased kernel, f64, 2 points per lane (512-point tiles): best all-round in the round-1 A/B (profiles/)
 inline int variant_ppt(int v) {
   switch (v) {
     case 2: case 6: case 9: return 2;
-    case 3: case 5: case 13: return 8;
+    case 3: case 5: case 13: case 20: case 21: return 8;
+    case 22: return 2;
+    case 14: case 15: case 16: case 17: return 4;
     default: return 4;  // 0,1,4 and 7,8,10,11,12 (2x2, 1x4, 4x1)
   }
 }
@@ -481,6 +538,7 @@ int build_table(gp_vgicp_batch* b) {
     b->total_points += f->n;
   }
   b->num_tiles = (int)tiles.size();
+  b->h_descs = descs;
   GP_TRY(b->d_factors.ensure(sizeof(gp::FactorDesc) * (size_t)std::max(F, 1)));
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
   GP_TRY(b->d_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
@@ -582,6 +640,45 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       case 13:
         GP_LAUNCH3(true, 2, 4);
         break;
+#define GP_LAUNCH3A(F32, PPT, ITERS, ABL) \
+  hipLaunchKernelGGL((gp::vgicp_tile_kernel3<MODE, F32, PPT, ITERS, ABL>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials)
+      case 14:  // ablations of variant 12 (f32 1x4): timing experiments only
+        GP_LAUNCH3A(true, 1, 4, 1);
+        break;
+      case 15:
+        GP_LAUNCH3A(true, 1, 4, 2);
+        break;
+      case 16:
+        GP_LAUNCH3A(true, 1, 4, 3);
+        break;
+      case 17:
+        GP_LAUNCH3A(true, 1, 4, 4);
+        break;
+#undef GP_LAUNCH3A
+#define GP_LAUNCH4(F32, ITERS) \
+  hipLaunchKernelGGL((gp::vgicp_tile_kernel4<MODE, F32, ITERS>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials)
+      case 18:  // kernel4 (software pipeline): f64, 4 steps
+        GP_LAUNCH4(false, 4);
+        break;
+      case 19:  // f32 outer, 4 steps
+        GP_LAUNCH4(true, 4);
+        break;
+      case 20:  // f32 outer, 8 steps
+        GP_LAUNCH4(true, 8);
+        break;
+      case 21:  // f64, 8 steps
+        GP_LAUNCH4(false, 8);
+        break;
+      case 22:  // f32 outer, 2 steps
+        GP_LAUNCH4(true, 2);
+        break;
+#undef GP_LAUNCH4
+      case 23:  // kernel5: LDS-DMA staged source, f64
+        hipLaunchKernelGGL((gp::vgicp_tile_kernel5<MODE, false>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials);
+        break;
+      case 24:  // kernel5, f32 outer products
+        hipLaunchKernelGGL((gp::vgicp_tile_kernel5<MODE, true>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials);
+        break;
 #undef GP_LAUNCH3
       default:
         GP_LAUNCH2(false, 4);
@@ -632,6 +729,8 @@ int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSo
   if (F == 1) {
     memcpy(ps->inl.lin, lin, sizeof(double) * 16);
     if (eval) memcpy(ps->inl.eval, eval, sizeof(double) * 16);
+    ps->inl.factor = b->h_descs[0];
+    ps->inl.tile_points = b->tile_points;
     ps->inl.use = 1;
     return GP_OK;
   }
@@ -672,8 +771,54 @@ int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, 
   return GP_OK;
 }
 
+// mode 0: per-lane strided dword pattern (calibration kernel), 1: coalesced float4 grid-stride, 2: LDS-DMA 12 KB per wave.
+// Reads the points array then the covs array (48*n bytes); returns the mean milliseconds per pass (HIP events).
+int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n, int mode, int iters, float* ms) {
+  if (!points_dev || !covs_dev || n <= 0 || iters <= 0 || !ms) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_stream_bench: bad arguments");
+  gp::DeviceArray sink;
+  GP_TRY(sink.alloc(16));
+  hipStream_t s;
+  GP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1;
+  GP_HIP(hipEventCreate(&e0));
+  GP_HIP(hipEventCreate(&e1));
+  auto launch = [&]() {
+    if (mode == 0) {
+      hipLaunchKernelGGL(gp::calibration_stream_kernel, dim3(2048), dim3(256), 0, s, points_dev, covs_dev, n, sink.as<float>());
+    } else if (mode == 1) {
+      // one kernel over both arrays would need them contiguous; two launches back to back measure the same bytes
+      hipLaunchKernelGGL(gp::stream_float4_kernel, dim3(2048), dim3(256), 0, s, (const float4*)covs_dev, (size_t)n * 36 / 16, sink.as<float>());
+      hipLaunchKernelGGL(gp::stream_float4_kernel, dim3(1024), dim3(256), 0, s, (const float4*)points_dev, (size_t)n * 12 / 16, sink.as<float>());
+    } else {
+      const size_t bc = (size_t)n * 36, bp = (size_t)n * 12;
+      hipLaunchKernelGGL(gp::stream_ldsdma_kernel, dim3((unsigned)(bc / 49152)), dim3(256), 0, s, (const char*)covs_dev, bc, sink.as<float>());
+      hipLaunchKernelGGL(gp::stream_ldsdma_kernel, dim3((unsigned)(bp / 49152)), dim3(256), 0, s, (const char*)points_dev, bp, sink.as<float>());
+    }
+  };
+  launch();
+  GP_HIP(hipStreamSynchronize(s));
+  GP_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; i++) launch();
+  GP_HIP(hipEventRecord(e1, s));
+  GP_HIP(hipEventSynchronize(e1));
+  float t = 0.f;
+  GP_HIP(hipEventElapsedTime(&t, e0, e1));
+  *ms = t / (float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(s);
+  return GP_OK;
+}
+
+// timeline hook: kernel5 stores 8 s_memtime stamps per workgroup into dev_buffer ([num_tiles][8] uint64); NULL disables
+int gp_debug_set_trace_buffer(void* dev_buffer) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buffer);
+  GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gp::g_trace), &p, sizeof(p)));
+  return GP_OK;
+}
+
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 13) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..13");
+  if (variant < 0 || variant > 24) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..24");
   g_variant = variant;
   return GP_OK;
 }
@@ -758,6 +903,8 @@ int gp_vgicp_factor_issue_linearize(gp_vgicp_factor_t* f, const double* pose_hos
   PoseSource ps;
   if (pose_host) {  // the host copy rides in the kernel arguments; the device copy is not even read
     memcpy(ps.inl.lin, pose_host, sizeof(double) * 16);
+    ps.inl.factor = f->self_batch->h_descs[0];
+    ps.inl.tile_points = f->self_batch->tile_points;
     ps.inl.use = 1;
   } else {
     ps.d_lin = pose_dev;
@@ -773,6 +920,8 @@ int gp_vgicp_factor_issue_compute_error(gp_vgicp_factor_t* f, const double* pose
   if (pose_lin_host && pose_eval_host) {
     memcpy(ps.inl.lin, pose_lin_host, sizeof(double) * 16);
     memcpy(ps.inl.eval, pose_eval_host, sizeof(double) * 16);
+    ps.inl.factor = f->self_batch->h_descs[0];
+    ps.inl.tile_points = f->self_batch->tile_points;
     ps.inl.use = 1;
   } else if (pose_lin_dev && pose_eval_dev) {
     ps.d_lin = pose_lin_dev;

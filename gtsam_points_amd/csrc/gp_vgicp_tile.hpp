@@ -79,8 +79,15 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel2(const FactorDesc* __re
   const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
   const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
   if (tile_idx >= num_tiles) return;
-  const TileDesc tile = tiles[tile_idx];      // kernel-argument pointers are already known to be global
-  const FactorDesc f = factors[tile.factor];  // (uniform -> scalar loads)
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];  // kernel-argument pointers are already known to be global (uniform -> scalar loads)
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
   const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
   const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
   const GP_GLOBAL float* points = as_global(f.points);
@@ -341,7 +348,7 @@ __device__ __forceinline__ void load_source(SourceRegs<PPT>& r, const GP_GLOBAL 
   }
 }
 
-template <int MODE, bool OUTER_F32, int PPT, int ITERS>
+template <int MODE, bool OUTER_F32, int PPT, int ITERS, int ABLATE = 0>
 __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                           const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                           double* __restrict__ partials) {
@@ -350,8 +357,15 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __re
   const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
   const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
   if (tile_idx >= num_tiles) return;
-  const TileDesc tile = tiles[tile_idx];
-  const FactorDesc f = factors[tile.factor];
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
   const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
   const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
   const GP_GLOBAL float* points = as_global(f.points);
@@ -366,15 +380,25 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __re
 #pragma unroll
   for (int k = 0; k < 32; k++) acc[k] = (acc_t)0;
 
+  // ABLATE (timing experiments only; results are wrong): 1 = no arithmetic, 2 = no table loads, 3 = no source loads, 4 = no butterfly
   SourceRegs<PPT> cur, nxt;
-  load_source<PPT>(cur, points, covs, tile.begin, tile.count, 0);
+  if constexpr (ABLATE == 3) {
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      cur.px[j] = 0.01f * (float)(threadIdx.x + tile_idx);
+      cur.py[j] = 0.02f * (float)threadIdx.x;
+      cur.pz[j] = -1.7f;
+      cur.c[j][0] = cur.c[j][3] = 1.f;
+      cur.c[j][5] = 0.001f;
+      cur.c[j][1] = cur.c[j][2] = cur.c[j][4] = 0.f;
+    }
+    nxt = cur;
+  } else {
+    load_source<PPT>(cur, points, covs, tile.begin, tile.count, 0);
+  }
 
 #pragma unroll
   for (int step = 0; step < ITERS; step++) {
-    if (step + 1 < ITERS) {
-      // uniform early-out for short tiles keeps the prefetch in bounds (index clamped inside) and cheap
-      load_source<PPT>(nxt, points, covs, tile.begin, tile.count, step + 1);
-    }
     // ---- phase B: transform, voxel coordinate, cheap hash; key + record of the home slot requested together ----
     int cx[PPT], cy[PPT], cz[PPT];
     uint32_t slot[PPT];
@@ -395,13 +419,24 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __re
       cz[j] = fast_floor(lz * f.map.inv_leaf);
       if (f.surface_validation && active[j] && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * ((size_t)tile.begin + local))) active[j] = false;
       slot[j] = coord_hash32(cx[j], cy[j], cz[j]) & pmask;
-      key[j] = pkeys[slot[j]];
-      const GP_GLOBAL char* rec = pfat + 64 * (size_t)slot[j];
-      head[j] = *(const GP_GLOBAL v4f*)rec;
-      c01[j] = *(const GP_GLOBAL v2d*)(rec + 16);
-      c23[j] = *(const GP_GLOBAL v2d*)(rec + 32);
-      c45[j] = *(const GP_GLOBAL v2d*)(rec + 48);
+      if constexpr (ABLATE == 2) {
+        key[j] = v4i{cx[j], cy[j], cz[j], (int)slot[j]};
+        head[j] = v4f{0.1f, 0.05f, -0.02f, 1.f};
+        c01[j] = v2d{1.0, 0.0};
+        c23[j] = v2d{0.0, 1.0};
+        c45[j] = v2d{0.0, 0.001};
+      } else {
+        key[j] = pkeys[slot[j]];
+        const GP_GLOBAL char* rec = pfat + 64 * (size_t)slot[j];
+        head[j] = *(const GP_GLOBAL v4f*)rec;
+        c01[j] = *(const GP_GLOBAL v2d*)(rec + 16);
+        c23[j] = *(const GP_GLOBAL v2d*)(rec + 32);
+        c45[j] = *(const GP_GLOBAL v2d*)(rec + 48);
+      }
     }
+    // prefetch the NEXT step's source points now: vmcnt retires in issue order, so these (HBM-latency) loads must be
+    // younger than the table loads above, or waiting for the table data would also wait for the prefetch
+    if (step + 1 < ITERS && ABLATE != 3) load_source<PPT>(nxt, points, covs, tile.begin, tile.count, step + 1);
     // ---- phase C: resolve; the collision chain (rare at load factor <= 0.5) walks on and re-fetches the record ----
     bool hit[PPT];
 #pragma unroll
@@ -434,6 +469,10 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __re
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
       if (!hit[j]) continue;
+      if constexpr (ABLATE == 1) {
+        acc[0] += (acc_t)(cur.px[j] + cur.c[j][0] + cur.c[j][1] + cur.c[j][2] + cur.c[j][3] + cur.c[j][4] + cur.c[j][5] + head[j].x) + (acc_t)(c01[j].x + c23[j].y + c45[j].y);
+        continue;
+      }
       const double px = (double)cur.px[j], py = (double)cur.py[j], pz = (double)cur.pz[j];
       double m[6];
       {
@@ -517,6 +556,224 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __re
       if (lane == 0) lds[wave][k] = v;
     }
   } else {
+    if constexpr (ABLATE == 4) {
+      if (lane < 32) lds[wave][lane] = accd[0] + accd[lane & 1];
+    } else {
+      const double s = butterfly_reduce32(accd, lane);
+      if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double s = 0.0;
+    if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
+  }
+}
+
+
+// =====================================================================================================================
+// vgicp_tile_kernel4 -- software-pipelined version of kernel3 (one point per lane per step, ITERS steps per tile):
+//   while step s is being computed, the table loads of step s+1 and the source loads of step s+2 are in flight.
+//   vmcnt retires in issue order, so the issue order is pinned with compiler barriers: at the top of step s everything
+//   outstanding (T_s, S_{s+1}) was issued a full compute phase earlier; then T_{s+1} and S_{s+2} are issued, then step s is
+//   computed from registers.  Ablation of kernel3 showed source latency (9.0 us), table latency (8.1 us) and arithmetic
+//   (2.7 us) adding up serially at 1 M points; this overlaps all three.
+// =====================================================================================================================
+#define GP_PIN_ORDER() asm volatile("" ::: "memory")
+
+struct TableRegs {
+  int cx, cy, cz;
+  uint32_t slot;
+  bool active;
+  v4i key;
+  v4f head;
+  v2d c01, c23, c45;
+};
+
+template <int MODE, bool OUTER_F32, int ITERS>
+__global__ void __launch_bounds__(256) vgicp_tile_kernel4(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                          const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                          double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  if (tile_idx >= num_tiles) return;
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const GP_GLOBAL v4i* pkeys = (const GP_GLOBAL v4i*)f.map.pkeys;
+  const GP_GLOBAL char* pfat = (const GP_GLOBAL char*)f.map.pfat;
+  const uint32_t pmask = f.map.pmask;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  using acc_t = typename std::conditional<OUTER_F32, float, double>::type;
+  acc_t acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = (acc_t)0;
+
+  // issue the table loads of one step from its (arrived) source registers
+  auto issue_table = [&](const SourceRegs<1>& src, int step, TableRegs& t) {
+    const int local = step * 256 + (int)threadIdx.x;
+    t.active = local < tile.count;
+    const double px = (double)src.px[0], py = (double)src.py[0], pz = (double)src.pz[0];
+    const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
+    const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
+    const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
+    t.cx = fast_floor(lx * f.map.inv_leaf);
+    t.cy = fast_floor(ly * f.map.inv_leaf);
+    t.cz = fast_floor(lz * f.map.inv_leaf);
+    if (f.surface_validation && t.active && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * ((size_t)tile.begin + local))) t.active = false;
+    t.slot = coord_hash32(t.cx, t.cy, t.cz) & pmask;
+    t.key = pkeys[t.slot];
+    const GP_GLOBAL char* rec = pfat + 64 * (size_t)t.slot;
+    t.head = *(const GP_GLOBAL v4f*)rec;
+    t.c01 = *(const GP_GLOBAL v2d*)(rec + 16);
+    t.c23 = *(const GP_GLOBAL v2d*)(rec + 32);
+    t.c45 = *(const GP_GLOBAL v2d*)(rec + 48);
+  };
+
+  SourceRegs<1> s_cur, s_nxt, s_nn;
+  TableRegs t_cur, t_nxt;
+  // prologue: S_0 -> T_0 ; S_1
+  load_source<1>(s_cur, points, covs, tile.begin, tile.count, 0);
+  GP_PIN_ORDER();
+  issue_table(s_cur, 0, t_cur);
+  GP_PIN_ORDER();
+  if (ITERS > 1) load_source<1>(s_nxt, points, covs, tile.begin, tile.count, 1);
+  GP_PIN_ORDER();
+
+#pragma unroll
+  for (int step = 0; step < ITERS; step++) {
+    // everything outstanding here (T_step, S_{step+1}) was issued one compute phase ago
+    if (step + 1 < ITERS) {
+      issue_table(s_nxt, step + 1, t_nxt);  // needs S_{step+1}; in-order vmcnt => T_step has arrived as well
+      GP_PIN_ORDER();
+      if (step + 2 < ITERS) load_source<1>(s_nn, points, covs, tile.begin, tile.count, step + 2);
+      GP_PIN_ORDER();
+    }
+    // ---- resolve step `step` (collision chain is rare at load factor <= 0.5) ----
+    bool hit = false;
+    if (t_cur.active) {
+      v4i k = t_cur.key;
+      uint32_t s = t_cur.slot;
+      bool moved = false;
+      while (k.w >= 0) {
+        if (k.x == t_cur.cx && k.y == t_cur.cy && k.z == t_cur.cz) {
+          hit = true;
+          break;
+        }
+        s = (s + 1) & pmask;
+        k = pkeys[s];
+        moved = true;
+      }
+      if (hit && moved) {
+        const GP_GLOBAL char* rec = pfat + 64 * (size_t)s;
+        t_cur.head = *(const GP_GLOBAL v4f*)rec;
+        t_cur.c01 = *(const GP_GLOBAL v2d*)(rec + 16);
+        t_cur.c23 = *(const GP_GLOBAL v2d*)(rec + 32);
+        t_cur.c45 = *(const GP_GLOBAL v2d*)(rec + 48);
+      }
+    }
+    if (hit) {
+      const double px = (double)s_cur.px[0], py = (double)s_cur.py[0], pz = (double)s_cur.pz[0];
+      double m[6];
+      {
+        const double a00 = (double)s_cur.c[0][0], a01 = (double)s_cur.c[0][1], a02 = (double)s_cur.c[0][2], a11 = (double)s_cur.c[0][3], a12 = (double)s_cur.c[0][4], a22 = (double)s_cur.c[0][5];
+        const double rc00 = Tl.r00 * a00 + Tl.r01 * a01 + Tl.r02 * a02, rc01 = Tl.r00 * a01 + Tl.r01 * a11 + Tl.r02 * a12, rc02 = Tl.r00 * a02 + Tl.r01 * a12 + Tl.r02 * a22;
+        const double rc10 = Tl.r10 * a00 + Tl.r11 * a01 + Tl.r12 * a02, rc11 = Tl.r10 * a01 + Tl.r11 * a11 + Tl.r12 * a12, rc12 = Tl.r10 * a02 + Tl.r11 * a12 + Tl.r12 * a22;
+        const double rc20 = Tl.r20 * a00 + Tl.r21 * a01 + Tl.r22 * a02, rc21 = Tl.r20 * a01 + Tl.r21 * a11 + Tl.r22 * a12, rc22 = Tl.r20 * a02 + Tl.r21 * a12 + Tl.r22 * a22;
+        const double s00 = t_cur.c01.x + rc00 * Tl.r00 + rc01 * Tl.r01 + rc02 * Tl.r02;
+        const double s01 = t_cur.c01.y + rc00 * Tl.r10 + rc01 * Tl.r11 + rc02 * Tl.r12;
+        const double s02 = t_cur.c23.x + rc00 * Tl.r20 + rc01 * Tl.r21 + rc02 * Tl.r22;
+        const double s11 = t_cur.c23.y + rc10 * Tl.r10 + rc11 * Tl.r11 + rc12 * Tl.r12;
+        const double s12 = t_cur.c45.x + rc10 * Tl.r20 + rc11 * Tl.r21 + rc12 * Tl.r22;
+        const double s22 = t_cur.c45.y + rc20 * Tl.r20 + rc21 * Tl.r21 + rc22 * Tl.r22;
+        const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
+        const double invdet = fast_rcp(s00 * i00 + s01 * i01 + s02 * i02);
+        m[0] = i00 * invdet;
+        m[1] = i01 * invdet;
+        m[2] = i02 * invdet;
+        m[3] = (s00 * s22 - s02 * s02) * invdet;
+        m[4] = (s01 * s02 - s00 * s12) * invdet;
+        m[5] = (s00 * s11 - s01 * s01) * invdet;
+      }
+      const double qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
+      const double qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
+      const double qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
+      const double rxd = (((double)t_cur.cx + 0.5) * f.map.leaf - qx) + (double)t_cur.head.x;
+      const double ryd = (((double)t_cur.cy + 0.5) * f.map.leaf - qy) + (double)t_cur.head.y;
+      const double rzd = (((double)t_cur.cz + 0.5) * f.map.leaf - qz) + (double)t_cur.head.z;
+      const acc_t M0 = (acc_t)m[0], M1 = (acc_t)m[1], M2 = (acc_t)m[2], M3 = (acc_t)m[3], M4 = (acc_t)m[4], M5 = (acc_t)m[5];
+      const acc_t RX = (acc_t)rxd, RY = (acc_t)ryd, RZ = (acc_t)rzd, QX = (acc_t)qx, QY = (acc_t)qy, QZ = (acc_t)qz;
+      const acc_t mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+      acc[ACC_COUNT] += (acc_t)1;
+      acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+      if constexpr (MODE == MODE_LIN) {
+        acc[ACC_M + 0] += M0;
+        acc[ACC_M + 1] += M1;
+        acc[ACC_M + 2] += M2;
+        acc[ACC_M + 3] += M3;
+        acc[ACC_M + 4] += M4;
+        acc[ACC_M + 5] += M5;
+        const acc_t k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
+        const acc_t k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
+        const acc_t k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+        acc[ACC_K + 0] += k00;
+        acc[ACC_K + 1] += k01;
+        acc[ACC_K + 2] += k02;
+        acc[ACC_K + 3] += k10;
+        acc[ACC_K + 4] += k11;
+        acc[ACC_K + 5] += k12;
+        acc[ACC_K + 6] += k20;
+        acc[ACC_K + 7] += k21;
+        acc[ACC_K + 8] += k22;
+        acc[ACC_TL + 0] += QZ * k10 - QY * k20;
+        acc[ACC_TL + 1] += QZ * k11 - QY * k21;
+        acc[ACC_TL + 2] += QZ * k12 - QY * k22;
+        acc[ACC_TL + 3] += QX * k21 - QZ * k01;
+        acc[ACC_TL + 4] += QX * k22 - QZ * k02;
+        acc[ACC_TL + 5] += QY * k02 - QX * k12;
+        acc[ACC_QXMR + 0] += QY * mrz - QZ * mry;
+        acc[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
+        acc[ACC_QXMR + 2] += QX * mry - QY * mrx;
+        acc[ACC_MR + 0] += mrx;
+        acc[ACC_MR + 1] += mry;
+        acc[ACC_MR + 2] += mrz;
+      }
+    }
+    GP_PIN_ORDER();
+    if (step + 1 < ITERS) {
+      s_cur = s_nxt;
+      t_cur = t_nxt;
+      s_nxt = s_nn;
+    }
+  }
+
+  double accd[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) accd[k] = (double)acc[k];
+  __shared__ double lds[4][ACC_STRIDE];
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = accd[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+  } else {
     const double s = butterfly_reduce32(accd, lane);
     if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
   }
@@ -526,6 +783,270 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel3(const FactorDesc* __re
     if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
     ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
   }
+}
+
+
+// =====================================================================================================================
+// vgicp_tile_kernel5 -- source stream staged through LDS with the gfx950 LDS-DMA (global_load_lds_dwordx4).
+//
+// Why: the ablations of kernel3 showed the pass is bound by memory-level parallelism, not arithmetic: in-flight loads
+// cost VGPRs (9 per source point, 20 per voxel record), so a CU could keep only ~30 point-loads in flight (2.5 TB/s).
+// LDS-DMA data never touches a VGPR while in flight: each wave requests its 256 points (3 KB) and covariances (9 KB) with
+// 12 perfectly coalesced 1-KB instructions at kernel start, i.e. 36-48 KB outstanding per workgroup, ~10 MB per chip.
+// The copy is wave-private (a wave DMAs exactly the 256 consecutive points its own lanes will process), so no barrier is
+// needed: only the wave's own vmcnt.  Lanes then read their point (stride 3 dwords) and covariance (stride 9 dwords)
+// from LDS -- both odd strides, bank-conflict free.  Table gathers (private slot table) stay register based, 4 in flight.
+// A partial last wave of a factor falls back to per-lane loads + ds_write into the same LDS image (never reads past n).
+// =====================================================================================================================
+#define GP_LDS __attribute__((address_space(3)))
+
+template <int MODE, typename acc_t>
+__device__ __forceinline__ void accumulate_terms(const Pose& Tl, const Pose& Te, double leaf, float pxf, float pyf, float pzf, const float* cA, int cx, int cy, int cz,
+                                                 const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45, acc_t* acc) {
+  const double px = (double)pxf, py = (double)pyf, pz = (double)pzf;
+  double m[6];
+  {
+    const double a00 = (double)cA[0], a01 = (double)cA[1], a02 = (double)cA[2], a11 = (double)cA[3], a12 = (double)cA[4], a22 = (double)cA[5];
+    const double rc00 = Tl.r00 * a00 + Tl.r01 * a01 + Tl.r02 * a02, rc01 = Tl.r00 * a01 + Tl.r01 * a11 + Tl.r02 * a12, rc02 = Tl.r00 * a02 + Tl.r01 * a12 + Tl.r02 * a22;
+    const double rc10 = Tl.r10 * a00 + Tl.r11 * a01 + Tl.r12 * a02, rc11 = Tl.r10 * a01 + Tl.r11 * a11 + Tl.r12 * a12, rc12 = Tl.r10 * a02 + Tl.r11 * a12 + Tl.r12 * a22;
+    const double rc20 = Tl.r20 * a00 + Tl.r21 * a01 + Tl.r22 * a02, rc21 = Tl.r20 * a01 + Tl.r21 * a11 + Tl.r22 * a12, rc22 = Tl.r20 * a02 + Tl.r21 * a12 + Tl.r22 * a22;
+    const double s00 = c01.x + rc00 * Tl.r00 + rc01 * Tl.r01 + rc02 * Tl.r02;
+    const double s01 = c01.y + rc00 * Tl.r10 + rc01 * Tl.r11 + rc02 * Tl.r12;
+    const double s02 = c23.x + rc00 * Tl.r20 + rc01 * Tl.r21 + rc02 * Tl.r22;
+    const double s11 = c23.y + rc10 * Tl.r10 + rc11 * Tl.r11 + rc12 * Tl.r12;
+    const double s12 = c45.x + rc10 * Tl.r20 + rc11 * Tl.r21 + rc12 * Tl.r22;
+    const double s22 = c45.y + rc20 * Tl.r20 + rc21 * Tl.r21 + rc22 * Tl.r22;
+    const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
+    const double invdet = fast_rcp(s00 * i00 + s01 * i01 + s02 * i02);
+    m[0] = i00 * invdet;
+    m[1] = i01 * invdet;
+    m[2] = i02 * invdet;
+    m[3] = (s00 * s22 - s02 * s02) * invdet;
+    m[4] = (s01 * s02 - s00 * s12) * invdet;
+    m[5] = (s00 * s11 - s01 * s01) * invdet;
+  }
+  const double qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
+  const double qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
+  const double qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
+  const double rxd = (((double)cx + 0.5) * leaf - qx) + (double)head.x;
+  const double ryd = (((double)cy + 0.5) * leaf - qy) + (double)head.y;
+  const double rzd = (((double)cz + 0.5) * leaf - qz) + (double)head.z;
+  const acc_t M0 = (acc_t)m[0], M1 = (acc_t)m[1], M2 = (acc_t)m[2], M3 = (acc_t)m[3], M4 = (acc_t)m[4], M5 = (acc_t)m[5];
+  const acc_t RX = (acc_t)rxd, RY = (acc_t)ryd, RZ = (acc_t)rzd, QX = (acc_t)qx, QY = (acc_t)qy, QZ = (acc_t)qz;
+  const acc_t mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+  acc[ACC_COUNT] += (acc_t)1;
+  acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+  if constexpr (MODE == MODE_LIN) {
+    acc[ACC_M + 0] += M0;
+    acc[ACC_M + 1] += M1;
+    acc[ACC_M + 2] += M2;
+    acc[ACC_M + 3] += M3;
+    acc[ACC_M + 4] += M4;
+    acc[ACC_M + 5] += M5;
+    const acc_t k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
+    const acc_t k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
+    const acc_t k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+    acc[ACC_K + 0] += k00;
+    acc[ACC_K + 1] += k01;
+    acc[ACC_K + 2] += k02;
+    acc[ACC_K + 3] += k10;
+    acc[ACC_K + 4] += k11;
+    acc[ACC_K + 5] += k12;
+    acc[ACC_K + 6] += k20;
+    acc[ACC_K + 7] += k21;
+    acc[ACC_K + 8] += k22;
+    acc[ACC_TL + 0] += QZ * k10 - QY * k20;
+    acc[ACC_TL + 1] += QZ * k11 - QY * k21;
+    acc[ACC_TL + 2] += QZ * k12 - QY * k22;
+    acc[ACC_TL + 3] += QX * k21 - QZ * k01;
+    acc[ACC_TL + 4] += QX * k22 - QZ * k02;
+    acc[ACC_TL + 5] += QY * k02 - QX * k12;
+    acc[ACC_QXMR + 0] += QY * mrz - QZ * mry;
+    acc[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
+    acc[ACC_QXMR + 2] += QX * mry - QY * mrx;
+    acc[ACC_MR + 0] += mrx;
+    acc[ACC_MR + 1] += mry;
+    acc[ACC_MR + 2] += mrz;
+  }
+}
+
+// optional per-workgroup phase timestamps (s_memtime) for timeline analysis: [num_tiles][8] uint64, enabled by the host
+__device__ unsigned long long* g_trace = nullptr;
+#define GP_TRACE(slot)                                                                   \
+  do {                                                                                   \
+    if (trace && threadIdx.x == 0) trace[(size_t)tile_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+constexpr int kWavePoints = 256;                      // points one wave stages and processes (4 per lane)
+constexpr int kWaveLdsBytes = kWavePoints * (12 + 36);  // 12 KB: [256][3] floats then [256][9] floats
+
+template <int MODE, bool OUTER_F32>
+__global__ void __launch_bounds__(256) vgicp_tile_kernel5(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                          const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                          double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  constexpr int PPT = 4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * kWaveLdsBytes];
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  if (tile_idx >= num_tiles) return;
+  unsigned long long* trace = g_trace;
+  GP_TRACE(0);
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const size_t first = (size_t)tile.begin + (size_t)wave * kWavePoints;  // the wave's first point
+  int wcount = tile.count - wave * kWavePoints;
+  wcount = wcount < 0 ? 0 : (wcount > kWavePoints ? kWavePoints : wcount);
+  char* wbase = smem + wave * kWaveLdsBytes;
+  float* lds_p = reinterpret_cast<float*>(wbase);
+  float* lds_c = reinterpret_cast<float*>(wbase + kWavePoints * 12);
+
+  // ---- stage the wave's source slice into LDS ----
+  if (wcount == kWavePoints) {
+    const GP_GLOBAL char* gp = (const GP_GLOBAL char*)(points + 3 * first) + lane * 16;
+    const GP_GLOBAL char* gc = (const GP_GLOBAL char*)(covs + 9 * first) + lane * 16;
+#pragma unroll
+    for (int k = 0; k < 3; k++) __builtin_amdgcn_global_load_lds((const GP_GLOBAL void*)(gp + k * 1024), (GP_LDS void*)(wbase + k * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 9; k++) __builtin_amdgcn_global_load_lds((const GP_GLOBAL void*)(gc + k * 1024), (GP_LDS void*)(wbase + 3072 + k * 1024), 16, 0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      const int idx = j * 64 + lane;
+      if (idx < wcount) {
+        const GP_GLOBAL float* pp = points + 3 * (first + idx);
+        const GP_GLOBAL float* cp = covs + 9 * (first + idx);
+        lds_p[3 * idx] = pp[0];
+        lds_p[3 * idx + 1] = pp[1];
+        lds_p[3 * idx + 2] = pp[2];
+#pragma unroll
+        for (int k = 0; k < 9; k++) lds_c[9 * idx + k] = cp[k];
+      }
+    }
+  }
+  GP_TRACE(1);  // descriptors loaded, DMA issued
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+  const GP_GLOBAL v4i* pkeys = (const GP_GLOBAL v4i*)f.map.pkeys;
+  const GP_GLOBAL char* pfat = (const GP_GLOBAL char*)f.map.pfat;
+  const uint32_t pmask = f.map.pmask;
+  // the LDS-DMA writes retire on vmcnt; the data is wave-private, so no workgroup barrier is needed
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  GP_TRACE(2);  // source slice in LDS
+
+  using acc_t = typename std::conditional<OUTER_F32, float, double>::type;
+  acc_t acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = (acc_t)0;
+
+  // ---- phase B: read the 4 points of this lane from LDS, hash, request key + record of the home slot ----
+  float px[PPT], py[PPT], pz[PPT];
+  int cx[PPT], cy[PPT], cz[PPT];
+  uint32_t slot[PPT];
+  bool active[PPT];
+  v4i key[PPT];
+  v4f head[PPT];
+  v2d c01[PPT], c23[PPT], c45[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; j++) {
+    const int idx = j * 64 + lane;
+    active[j] = idx < wcount;
+    const int ri = active[j] ? idx : 0;
+    px[j] = lds_p[3 * ri];
+    py[j] = lds_p[3 * ri + 1];
+    pz[j] = lds_p[3 * ri + 2];
+    const double dx = (double)px[j], dy = (double)py[j], dz = (double)pz[j];
+    const double lx = Tl.r00 * dx + Tl.r01 * dy + Tl.r02 * dz + Tl.tx;
+    const double ly = Tl.r10 * dx + Tl.r11 * dy + Tl.r12 * dz + Tl.ty;
+    const double lz = Tl.r20 * dx + Tl.r21 * dy + Tl.r22 * dz + Tl.tz;
+    cx[j] = fast_floor(lx * f.map.inv_leaf);
+    cy[j] = fast_floor(ly * f.map.inv_leaf);
+    cz[j] = fast_floor(lz * f.map.inv_leaf);
+    if (f.surface_validation && active[j] && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + idx))) active[j] = false;
+    slot[j] = coord_hash32(cx[j], cy[j], cz[j]) & pmask;
+    key[j] = pkeys[slot[j]];
+    const GP_GLOBAL char* rec = pfat + 64 * (size_t)slot[j];
+    head[j] = *(const GP_GLOBAL v4f*)rec;
+    c01[j] = *(const GP_GLOBAL v2d*)(rec + 16);
+    c23[j] = *(const GP_GLOBAL v2d*)(rec + 32);
+    c45[j] = *(const GP_GLOBAL v2d*)(rec + 48);
+  }
+  GP_TRACE(3);  // table loads issued
+  if (trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP_TRACE(4);  // table data arrived
+  }
+  // ---- phase C/D ----
+#pragma unroll
+  for (int j = 0; j < PPT; j++) {
+    bool hit = false;
+    if (active[j]) {
+      v4i k = key[j];
+      uint32_t s = slot[j];
+      bool moved = false;
+      while (k.w >= 0) {
+        if (k.x == cx[j] && k.y == cy[j] && k.z == cz[j]) {
+          hit = true;
+          break;
+        }
+        s = (s + 1) & pmask;
+        k = pkeys[s];
+        moved = true;
+      }
+      if (hit && moved) {
+        const GP_GLOBAL char* rec = pfat + 64 * (size_t)s;
+        head[j] = *(const GP_GLOBAL v4f*)rec;
+        c01[j] = *(const GP_GLOBAL v2d*)(rec + 16);
+        c23[j] = *(const GP_GLOBAL v2d*)(rec + 32);
+        c45[j] = *(const GP_GLOBAL v2d*)(rec + 48);
+      }
+    }
+    if (hit) {
+      const int idx = j * 64 + lane;
+      const float* cp = lds_c + 9 * idx;
+      const float cA[6] = {cp[0], cp[3], cp[6], cp[4], cp[7], cp[8]};
+      accumulate_terms<MODE, acc_t>(Tl, Te, f.map.leaf, px[j], py[j], pz[j], cA, cx[j], cy[j], cz[j], head[j], c01[j], c23[j], c45[j], acc);
+    }
+  }
+
+  GP_TRACE(5);  // arithmetic done
+  // ---- reduction: butterfly within the wave, then across the 4 waves through LDS (the staging area is free now) ----
+  double accd[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) accd[k] = (double)acc[k];
+  __syncthreads();
+  double(*lds)[ACC_STRIDE] = reinterpret_cast<double(*)[ACC_STRIDE]>(smem);
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = accd[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+  } else {
+    const double s = butterfly_reduce32(accd, lane);
+    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double s = 0.0;
+    if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
+  }
+  GP_TRACE(6);
 }
 
 }  // namespace gp

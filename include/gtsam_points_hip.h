@@ -229,7 +229,11 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* batch, const double* poses_h
 
 /* tuning hook (not part of the reference API): selects the tile-kernel variant, see gp_vgicp.hip */
 int gp_debug_set_variant(int variant);
+/* timeline hook: per-workgroup phase timestamps of the LDS-DMA tile kernel into dev_buffer ([num_tiles][8] uint64) */
+int gp_debug_set_trace_buffer(void* dev_buffer);
 /* profiling hook: streams 48*n bytes with the tile kernel's access pattern (calibrates rocprofv3 FETCH_SIZE) */
+/* profiling hook: time to just read the 48*n source bytes (mode 0 strided dwords, 1 coalesced float4, 2 LDS-DMA) */
+int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n, int mode, int iters, float* ms);
 int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
 
 #ifdef __cplusplus
