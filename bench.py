@@ -174,10 +174,18 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             import oracle  # checker / baseline only -- never on the product path
 
-            om = oracle.OracleVoxelMap(args.resolution)
-            om.insert(d["target_points"], d["target_covs"])
+            from oracle import refcapi
+
             cores = oracle.max_threads()
-            fo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], cores)
+            use_ref = refcapi.available()  # the reference's own CPU sources (oracle/_ref/libref.so) when they were built
+            if use_ref:
+                om = refcapi.RefVoxelMap(args.resolution)
+                om.insert(d["target_points"], d["target_covs"])
+                fo = refcapi.RefVGICPFactor(om, d["source_points"], d["source_covs"], cores)
+            else:
+                om = oracle.OracleVoxelMap(args.resolution)
+                om.insert(d["target_points"], d["target_covs"])
+                fo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], cores)
             Lo = fo.linearize(delta)  # warm-up + parity reference
             parity = {}
             for k in ["H_target", "H_source", "H_target_source", "b_target", "b_source"]:
@@ -190,7 +198,7 @@ def main():
                 t = time.perf_counter()
                 fo.linearize(delta)
                 times.append(time.perf_counter() - t)
-            f1 = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], 1)
+            f1 = (refcapi.RefVGICPFactor if use_ref else oracle.OracleVGICPFactor)(om, d["source_points"], d["source_covs"], 1)
             t1 = []
             t_start = time.perf_counter()
             while time.perf_counter() - t_start < args.cpu_seconds * 0.3 or len(t1) < 2:
@@ -202,7 +210,7 @@ def main():
                 value=round(args.source_points / med, 1),
                 unit="point-correspondences/s",
                 cores=cores,
-                kind="port",
+                kind="reference" if use_ref else "port",
                 sample=f"{len(times)} full linearize() passes of the same 1M-pt factor, {cores} OpenMP threads (median {med*1e3:.2f} ms); "
                 f"1 thread: {np.median(t1)*1e3:.2f} ms",
                 ms_per_linearize=round(med * 1e3, 3),

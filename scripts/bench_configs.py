@@ -1,0 +1,121 @@
+"""Measures the BASELINE.json parity-test configurations that are not the bench.py headline:
+  C1  two kitti_00-style scans (fixture kitti00_dec8), 0.5 m voxels, single linearise
+  C3  256-factor submap graph (64 submaps x ~25k pts, 1.0 m voxels, factors i -> i+1..i+4), ONE batched linearise
+  C4  one GPU's shard of the 4096-factor / 8-GPU configuration: 512 factors x 32768 pts, 1.0 m voxels
+For each: ms per linearise (synchronous product call), corr/s, algorithmic roofline fraction of the tile kernel
+(HIP events), parity vs the oracle (all factors for C1/C3, a sample for C4) and the oracle's own time.
+Output: one JSON object per config on stdout (copied to profiles/rNN_configs.jsonl)."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gtsam_points_amd as gpa  # noqa: E402
+import oracle  # noqa: E402
+from gtsam_points_amd import _capi, synthetic  # noqa: E402
+
+lib = gpa.load()
+BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
+
+
+def run(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iters=20):
+    factors = [gpa.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
+    F = len(factors)
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch, s = C.c_void_p(), C.c_void_p()
+    lib.gp_stream_create(C.byref(s))
+    _capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+    poses = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas]).copy()
+    out = np.zeros((F, 122))
+    for _ in range(3):
+        _capi.check(lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data), "lin")
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data)
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    _capi.check(lib.gp_vgicp_batch_time_linearize(batch, poses.ctypes.data, iters, C.byref(a), C.byref(b), C.byref(c)), "time")
+    npts = int(lib.gp_vgicp_batch_total_points(batch))
+    alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+    worst, t_cpu = 0.0, 0.0
+    omaps = {}
+    for k in oracle_sample:
+        i, j = pairs[k]
+        if i not in omaps:
+            om = oracle.OracleVoxelMap(res)
+            om.insert(*host_clouds[i])
+            omaps[i] = om
+        fo = oracle.OracleVGICPFactor(omaps[i], host_clouds[j][0], host_clouds[j][1], oracle.max_threads())
+        t = time.perf_counter()
+        Lo = fo.linearize(deltas[k])
+        t_cpu += time.perf_counter() - t
+        L = gpa.LinearizedSystem6.from_doubles(out[k])
+        assert L.num_inliers == Lo.num_inliers, (name, k)
+        for blk in BLOCKS:
+            worst = max(worst, float(np.linalg.norm(getattr(L, blk) - getattr(Lo, blk)) / np.linalg.norm(getattr(Lo, blk))))
+    res_d = dict(
+        config=name, factors=F, points=npts, ms_per_linearize=round(ms, 4), corr_per_s=round(npts / ms * 1e3, 1), tile_kernel_ms=round(b.value, 5),
+        finalize_kernel_ms=round(c.value, 5), device_pass_ms=round(a.value, 5), algorithmic_bytes=alg, roofline_frac=round(alg / (b.value * 1e-3) / 8e12, 4),
+        parity_max_rel_err=worst, parity_factors_checked=len(oracle_sample),
+        cpu_oracle_ms_per_factor=round(t_cpu / max(len(oracle_sample), 1) * 1e3, 3), cpu_threads=oracle.max_threads(),
+        inlier_fraction=round(float(out[:, 0].sum()) / npts, 4),
+    )
+    print(json.dumps(res_d), flush=True)
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+
+
+# ---- C1 ----
+k = np.load(os.path.join(ROOT, "tests/golden/kitti00_dec8.npz"))
+tgt = gpa.PointCloudGPU(k["target_points"], k["target_covs"])
+src = gpa.PointCloudGPU(k["source_points"], k["source_covs"])
+vm = gpa.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+vm.insert(tgt)
+run("C1 kitti00 (every 8th point), 0.5 m, single linearise", [tgt, src], [vm, None], [(0, 1)], [synthetic.expmap(synthetic.C1B_PERTURBATION)],
+    [(k["target_points"], k["target_covs"]), (k["source_points"], k["source_covs"])], 0.5, [0], iters=200)
+
+# ---- C3 ----
+rng = np.random.default_rng(8191)
+walls, stations = synthetic.make_street(64, spacing=6.0, seed=43)
+host, clouds, maps = [], [], []
+t0 = time.time()
+for i, T in enumerate(stations):
+    p, c, _ = synthetic.make_submap(20000 + 80 * i, seed=1000 + i, walls=walls, sensor_pose=T)
+    host.append((p, c))
+    clouds.append(gpa.PointCloudGPU(p, c))
+    m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+    m.insert(clouds[-1])
+    maps.append(m)
+pairs = [(i, j) for i in range(64) for j in range(i + 1, min(i + 5, 64))]
+pairs = (pairs + [(j, i) for i, j in pairs])[:256]
+deltas = [np.linalg.inv(stations[i]) @ stations[j] @ synthetic.expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs]
+run(f"C3 256-factor submap graph, 64 submaps x ~22k pts, 1.0 m (setup {time.time()-t0:.1f}s)", clouds, maps, pairs, deltas, host, 1.0, list(range(0, 256, 16)))
+
+# ---- C4 shard (one GPU of eight): 512 factors x 32768 points ----
+t0 = time.time()
+base_host, base_clouds = [], []
+for i in range(64):
+    p, c, _ = synthetic.make_submap(32768, seed=2000 + i, walls=walls, sensor_pose=stations[i])
+    base_host.append((p, c))
+host4, clouds4, maps4 = [], [], []
+g = torch.Generator(device="cuda").manual_seed(44)
+for i in range(512):
+    p, c = base_host[i % 64]
+    if i < 64:
+        ph = p
+    else:  # distinct memory and slightly different geometry per replica (deterministic jitter), so that nothing is shared in cache
+        ph = (p.astype(np.float64) + np.random.default_rng(3000 + i).normal(0, 0.01, p.shape)).astype(np.float32)
+    host4.append((ph, c))
+    clouds4.append(gpa.PointCloudGPU(ph, c))
+    m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+    m.insert(clouds4[-1])
+    maps4.append(m)
+pairs4 = [(i, (i // 64) * 64 + (i % 64 + 1) % 64) for i in range(512)]
+deltas4 = [np.linalg.inv(stations[i % 64]) @ stations[j % 64] @ synthetic.expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs4]
+run(f"C4 shard: 512 factors x 32768 pts (1/8 of the 4096-factor config), 1.0 m (setup {time.time()-t0:.1f}s)", clouds4, maps4, pairs4, deltas4, host4, 1.0, list(range(0, 512, 64)))
