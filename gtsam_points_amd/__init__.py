@@ -18,13 +18,17 @@ from .factors import (  # noqa: F401
     create_nonlinear_factor_set_gpu,
     pose_inverse,
 )
+from .features import IntegratedGICPFactorGPU, KdTreeGPU, estimate_covariances_gpu  # noqa: F401
 from .types import GaussianVoxelMapGPU, PointCloudGPU, overlap_gpu  # noqa: F401
 
 __all__ = [
     "GPError",
     "GaussianVoxelMapGPU",
     "HessianFactor",
+    "IntegratedGICPFactorGPU",
     "IntegratedVGICPFactorGPU",
+    "KdTreeGPU",
+    "estimate_covariances_gpu",
     "LinearizationHook",
     "LinearizedSystem6",
     "NonlinearFactorGPU",

@@ -125,6 +125,14 @@ _SIGNATURES = {
     "gp_vgicp_batch_sync": (C.c_int, [C.c_void_p]),
     "gp_vgicp_batch_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_point_grid_create": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_point_grid_destroy": (C.c_int, [C.c_void_p]),
+    "gp_knn_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_estimate_covariances": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "gp_gicp_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_gicp_factor_destroy": (C.c_int, [C.c_void_p]),
+    "gp_gicp_factor_linearize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(Linearized6)]),
+    "gp_gicp_factor_compute_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gp_debug_set_variant": (C.c_int, [C.c_int]),
     "gp_debug_set_trace_buffer": (C.c_int, [C.c_void_p]),
     "gp_debug_stream_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -1,0 +1,644 @@
+// gp_knn.hip -- exact k-nearest-neighbour search on a cell-sorted point grid, covariance estimation, and a GICP
+// linearisation that uses it (BASELINE.json configs[4]).
+//
+// Replaces (reference, CPU only -- there is no GPU counterpart upstream):
+//   ann/small_kdtree.hpp:124-186,437-474 + ann/knn_result.hpp:89-109   exact k-NN (kd-tree)      -> uniform-grid shell search
+//   features/covariance_estimation.cpp:18-77                          estimate_covariances      -> gp_estimate_covariances
+//   factors/impl/integrated_gicp_factor_impl.hpp:132-296              GICP correspondences+H/b  -> gp_gicp_factor_*
+//
+// Exactness: a query visits the cells of growing cubes around its own cell and stops after radius r once it holds k
+// neighbours whose k-th squared distance is <= d_safe(r)^2, where d_safe(r) = r*h + (distance from the query to the
+// nearest face of its own cell) is a lower bound on the distance to every unvisited point.  Distances are computed in
+// f64 on the f32 inputs (as the reference does on PointCloudCPU's doubles), so the neighbour SET equals the kd-tree's
+// except for exact ties at the k-th distance (where the reference's own result depends on traversal order).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "gp_host.hpp"
+#include "gp_vgicp_tile.hpp"
+
+namespace gp {
+
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+__host__ __device__ __forceinline__ unsigned long long pack_cell(int x, int y, int z) {
+  return ((unsigned long long)(unsigned)(x + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(y + (1 << 20)) << 21) | (unsigned long long)(unsigned)(z + (1 << 20));
+}
+
+__host__ __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+struct GridView {
+  const unsigned long long* keys;  // [slots] packed cell coordinate or kEmptyKey
+  const int* start;                // [slots + 1] first sorted point of the cell stored at this slot
+  const float4* sorted;            // [n] (x, y, z, original index as int bits), cell-sorted
+  uint32_t mask;
+  int n;
+  double inv_h, h;
+  int lo[3], hi[3];  // bounding box of the occupied cells: bounds the cube radius of any query
+};
+
+__device__ __forceinline__ int grid_find(const GridView& g, unsigned long long key) {
+  uint32_t s = hash_key(key) & g.mask;
+  for (;;) {
+    const unsigned long long k = g.keys[s];
+    if (k == key) return (int)s;
+    if (k == kEmptyKey) return -1;
+    s = (s + 1) & g.mask;
+  }
+}
+
+// ---- grid build -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) grid_insert_kernel(const float* __restrict__ points, int n, double inv_h, unsigned long long* __restrict__ keys,
+                                                          int* __restrict__ counts, int* __restrict__ point_slot, uint32_t mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int cx = fast_floor((double)points[3 * (size_t)i] * inv_h), cy = fast_floor((double)points[3 * (size_t)i + 1] * inv_h),
+            cz = fast_floor((double)points[3 * (size_t)i + 2] * inv_h);
+  const unsigned long long key = pack_cell(cx, cy, cz);
+  uint32_t s = hash_key(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&keys[s], kEmptyKey, key);
+    if (old == kEmptyKey || old == key) break;
+    s = (s + 1) & mask;
+  }
+  point_slot[i] = (int)s;
+  atomicAdd(&counts[s], 1);
+}
+
+// exclusive scan of counts[0..m) -> start[0..m], three small kernels (block sums, scan of block sums, add)
+constexpr int kScanBlock = 1024;
+__global__ void __launch_bounds__(kScanBlock) scan_block_kernel(const int* __restrict__ in, int* __restrict__ out, int* __restrict__ block_sums, int m) {
+  __shared__ int lds[kScanBlock];
+  const int i = blockIdx.x * kScanBlock + threadIdx.x;
+  const int v = i < m ? in[i] : 0;
+  lds[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < kScanBlock; off <<= 1) {
+    const int t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
+    __syncthreads();
+    lds[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (i < m) out[i] = lds[threadIdx.x] - v;  // exclusive
+  if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = lds[threadIdx.x];
+}
+__global__ void __launch_bounds__(kScanBlock) scan_sums_kernel(int* __restrict__ block_sums, int nb, int* __restrict__ total) {
+  __shared__ int lds[kScanBlock];
+  int carry = 0;
+  for (int base = 0; base < nb; base += kScanBlock) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? block_sums[i] : 0;
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+      const int t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
+      __syncthreads();
+      lds[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) block_sums[i] = carry + lds[threadIdx.x] - v;
+    const int last = lds[kScanBlock - 1];
+    __syncthreads();
+    carry += last;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(kScanBlock) scan_add_kernel(int* __restrict__ out, const int* __restrict__ block_sums, int m, const int* __restrict__ total) {
+  const int i = blockIdx.x * kScanBlock + threadIdx.x;
+  if (i < m) out[i] += block_sums[blockIdx.x];
+  if (i == 0) out[m] = *total;
+}
+
+__global__ void __launch_bounds__(256) grid_scatter_kernel(const float* __restrict__ points, int n, const int* __restrict__ point_slot, const int* __restrict__ start,
+                                                           int* __restrict__ cursor, float4* __restrict__ sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int s = point_slot[i];
+  const int pos = start[s] + atomicAdd(&cursor[s], 1);
+  sorted[pos] = make_float4(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2], __int_as_float(i));
+}
+
+// ---- exact k-NN -------------------------------------------------------------------------------------------------
+template <int KMAX>
+struct TopK {
+  double d[KMAX];
+  int idx[KMAX];
+  int k, found;
+  __device__ void init(int k_, double max_sq_dist) {
+    k = k_;
+    found = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+      d[j] = max_sq_dist;
+      idx[j] = -1;
+    }
+  }
+  __device__ double worst() const { return d[k - 1]; }
+  // KnnResult::push (ann/knn_result.hpp:89-109): strict '<', earlier-visited ties win
+  __device__ void push(int index, double dist) {
+    if (!(dist < d[k - 1])) return;
+    bool placed = false;
+#pragma unroll
+    for (int j = KMAX - 1; j >= 0; j--) {
+      if (j < k && !placed) {
+        if (j > 0 && dist < d[j - 1]) {
+          d[j] = d[j - 1];
+          idx[j] = idx[j - 1];
+        } else {
+          d[j] = dist;
+          idx[j] = index;
+          placed = true;
+        }
+      }
+    }
+    found = found + 1 < k ? found + 1 : k;
+  }
+};
+
+template <int KMAX>
+__device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
+  const int cx = fast_floor(qx * g.inv_h), cy = fast_floor(qy * g.inv_h), cz = fast_floor(qz * g.inv_h);
+  // distance from the query to the nearest face of its own cell
+  const double fx = qx * g.inv_h - (double)cx, fy = qy * g.inv_h - (double)cy, fz = qz * g.inv_h - (double)cz;
+  const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * g.h;
+  // cube radius after which every occupied cell has been visited from this query
+  const int rmax = max(max(max(abs(cx - g.lo[0]), abs(cx - g.hi[0])), max(abs(cy - g.lo[1]), abs(cy - g.hi[1]))), max(abs(cz - g.lo[2]), abs(cz - g.hi[2])));
+  for (int r = 0; r <= rmax; r++) {
+    for (int dz = -r; dz <= r; dz++)
+      for (int dy = -r; dy <= r; dy++) {
+        const bool shell_yz = (dz == -r || dz == r || dy == -r || dy == r);
+        const int step = (shell_yz || r == 0) ? 1 : 2 * r;  // interior rows: only dx = -r and dx = +r belong to the shell
+        for (int dx = -r; dx <= r; dx += step) {
+          const int s = grid_find(g, pack_cell(cx + dx, cy + dy, cz + dz));
+          if (s < 0) continue;
+          const int b = g.start[s], e = g.start[s + 1];
+          for (int p = b; p < e; p++) {
+            const float4 v = g.sorted[p];
+            const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
+            top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
+          }
+        }
+      }
+    const double safe = (double)r * g.h + face;
+    if (top.worst() <= safe * safe) return;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
+  }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(128) knn_kernel(GridView g, const float* __restrict__ queries, int nq, int k, double max_sq_dist, int* __restrict__ indices,
+                                                  double* __restrict__ sq_dists, int* __restrict__ num_found) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= nq) return;
+  TopK<KMAX> top;
+  top.init(k, max_sq_dist);
+  knn_query<KMAX>(g, (double)queries[3 * (size_t)i], (double)queries[3 * (size_t)i + 1], (double)queries[3 * (size_t)i + 2], top);
+#pragma unroll
+  for (int j = 0; j < KMAX; j++)
+    if (j < k) {
+      indices[(size_t)i * k + j] = j < top.found ? top.idx[j] : -1;
+      if (sq_dists) sq_dists[(size_t)i * k + j] = top.d[j];
+    }
+  if (num_found) num_found[i] = top.found;
+}
+
+// ---- Eigen 3.4.0 SelfAdjointEigenSolver<Matrix3d>::computeDirect, restated (see oracle/vgicp_oracle.c) -------------
+__device__ __forceinline__ void eig3_roots(const double* m /*col-major sym*/, double* roots) {
+  const double s_inv3 = 1.0 / 3.0, s_sqrt3 = 1.7320508075688772;
+  const double c0 = m[0] * m[4] * m[8] + 2.0 * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+  const double c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+  const double c2 = m[0] + m[4] + m[8];
+  const double c2_over_3 = c2 * s_inv3;
+  double a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+  a_over_3 = a_over_3 < 0.0 ? 0.0 : a_over_3;
+  const double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+  double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  q = q < 0.0 ? 0.0 : q;
+  const double rho = sqrt(a_over_3);
+  const double theta = atan2(sqrt(q), half_b) * s_inv3;
+  const double cos_theta = cos(theta), sin_theta = sin(theta);
+  roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 + 2.0 * rho * cos_theta;
+}
+
+__device__ __forceinline__ void eig3_extract_kernel(const double* mat, double* res, double* representative) {
+  int i0 = 0;
+  double best = fabs(mat[0]);
+  if (fabs(mat[4]) > best) {
+    best = fabs(mat[4]);
+    i0 = 1;
+  }
+  if (fabs(mat[8]) > best) i0 = 2;
+  for (int r = 0; r < 3; r++) representative[r] = mat[i0 * 3 + r];
+  const int i1 = (i0 + 1) % 3, i2 = (i0 + 2) % 3;
+  const double* a = representative;
+  const double* b1 = mat + 3 * i1;
+  const double* b2 = mat + 3 * i2;
+  const double c0[3] = {a[1] * b1[2] - a[2] * b1[1], a[2] * b1[0] - a[0] * b1[2], a[0] * b1[1] - a[1] * b1[0]};
+  const double c1[3] = {a[1] * b2[2] - a[2] * b2[1], a[2] * b2[0] - a[0] * b2[2], a[0] * b2[1] - a[1] * b2[0]};
+  const double n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2], n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+  if (n0 > n1) {
+    const double s = 1.0 / sqrt(n0);
+    for (int r = 0; r < 3; r++) res[r] = c0[r] * s;
+  } else {
+    const double s = 1.0 / sqrt(n1);
+    for (int r = 0; r < 3; r++) res[r] = c1[r] * s;
+  }
+}
+
+__device__ __forceinline__ void eig3_direct(const double* mat /*col-major, lower triangle referenced*/, double* evals, double* evecs) {
+  const double eps = 2.220446049250313e-16;
+  const double shift = (mat[0] + mat[4] + mat[8]) / 3.0;
+  double scaled[9] = {mat[0] - shift, mat[1], mat[2], mat[1], mat[4] - shift, mat[5], mat[2], mat[5], mat[8] - shift};
+  double scale = 0.0;
+  for (int i = 0; i < 9; i++) scale = fmax(scale, fabs(scaled[i]));
+  if (scale > 0.0)
+    for (int i = 0; i < 9; i++) scaled[i] /= scale;
+  eig3_roots(scaled, evals);
+  if ((evals[2] - evals[0]) <= eps) {
+    for (int i = 0; i < 9; i++) evecs[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    double tmp[9];
+    for (int i = 0; i < 9; i++) tmp[i] = scaled[i];
+    double d0 = evals[2] - evals[1];
+    const double d1 = evals[1] - evals[0];
+    int k = 0, l = 2;
+    if (d0 > d1) {
+      k = 2;
+      l = 0;
+      d0 = d1;
+    }
+    tmp[0] -= evals[k];
+    tmp[4] -= evals[k];
+    tmp[8] -= evals[k];
+    eig3_extract_kernel(tmp, evecs + 3 * k, evecs + 3 * l);
+    if (d0 <= 2.0 * eps * d1) {
+      double* ck = evecs + 3 * k;
+      double* cl = evecs + 3 * l;
+      const double dot = ck[0] * cl[0] + ck[1] * cl[1] + ck[2] * cl[2];
+      for (int r = 0; r < 3; r++) cl[r] -= dot * cl[r];
+      const double nn = sqrt(cl[0] * cl[0] + cl[1] * cl[1] + cl[2] * cl[2]);
+      for (int r = 0; r < 3; r++) cl[r] /= nn;
+    } else {
+      double dummy[3];
+      for (int i = 0; i < 9; i++) tmp[i] = scaled[i];
+      tmp[0] -= evals[l];
+      tmp[4] -= evals[l];
+      tmp[8] -= evals[l];
+      eig3_extract_kernel(tmp, evecs + 3 * l, dummy);
+    }
+    const double* c2 = evecs + 6;
+    const double* c0 = evecs;
+    const double c1[3] = {c2[1] * c0[2] - c2[2] * c0[1], c2[2] * c0[0] - c2[0] * c0[2], c2[0] * c0[1] - c2[1] * c0[0]};
+    const double nn = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+    for (int r = 0; r < 3; r++) evecs[3 + r] = c1[r] / nn;
+  }
+  for (int i = 0; i < 3; i++) evals[i] = evals[i] * scale + shift;
+}
+
+__device__ __forceinline__ void inverse3_general(const double* a /*col-major*/, double* inv) {
+  auto A = [&](int r, int c) { return a[c * 3 + r]; };
+  const double c00 = A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1), c10 = A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2), c20 = A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0);
+  const double invdet = 1.0 / (A(0, 0) * c00 + A(0, 1) * c10 + A(0, 2) * c20);
+  inv[0] = c00 * invdet;
+  inv[1] = c10 * invdet;
+  inv[2] = c20 * invdet;
+  inv[3] = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) * invdet;
+  inv[4] = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) * invdet;
+  inv[5] = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) * invdet;
+  inv[6] = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) * invdet;
+  inv[7] = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) * invdet;
+  inv[8] = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) * invdet;
+}
+
+// estimate_covariances (features/covariance_estimation.cpp:18-77): k-NN (query included) -> sample covariance ->
+// V diag(1e-3, 1, 1) V^-1.  Fewer than k neighbours -> identity (:27-31).
+template <int KMAX>
+__global__ void __launch_bounds__(128) covariance_kernel(GridView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
+                                                         int* __restrict__ num_short) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  const double qx = (double)points[3 * (size_t)i], qy = (double)points[3 * (size_t)i + 1], qz = (double)points[3 * (size_t)i + 2];
+  TopK<KMAX> top;
+  top.init(k, 1.7976931348623157e308);
+  knn_query<KMAX>(g, qx, qy, qz, top);
+  float* out = covs + 9 * (size_t)i;
+  if (top.found < k) {
+    atomicAdd(num_short, 1);
+    for (int j = 0; j < 9; j++) out[j] = (j % 4 == 0) ? 1.0f : 0.0f;
+    return;
+  }
+  double sp[3] = {0, 0, 0}, spp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < KMAX; j++)
+    if (j < k) {
+      const size_t nb = (size_t)top.idx[j];
+      const double p[3] = {(double)points[3 * nb], (double)points[3 * nb + 1], (double)points[3 * nb + 2]};
+      for (int r = 0; r < 3; r++) sp[r] += p[r];
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) spp[c * 3 + r] += p[r] * p[c];
+    }
+  double cov[9];
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) cov[c * 3 + r] = (spp[c * 3 + r] - (sp[r] / (double)k) * sp[c]) / (double)k;  // :43
+  double evals[3], V[9], Vinv[9];
+  eig3_direct(cov, evals, V);
+  inverse3_general(V, Vinv);
+  const double lam[3] = {1e-3, 1.0, 1.0};
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) {
+      double s = 0.0;
+      for (int kk = 0; kk < 3; kk++) s += V[kk * 3 + r] * lam[kk] * Vinv[c * 3 + kk];
+      out[c * 3 + r] = (float)s;
+    }
+}
+
+// ---- GICP: 1-NN correspondence within max distance + the same H/b algebra as VGICP ------------------------------------
+struct GicpDesc {
+  const float* points;
+  const float* covs;
+  const float* target_points;
+  const float* target_covs;
+  GridView grid;
+  int n;
+  double max_sq_dist;
+};
+
+template <int MODE>  // MODE_LIN or MODE_ERR
+__global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double* __restrict__ pose_lin, const double* __restrict__ pose_eval,
+                                                        int tile_points, double* __restrict__ partials) {
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  const Pose Tl = load_pose(pose_lin);
+  const Pose Te = MODE == MODE_ERR ? load_pose(pose_eval) : Tl;
+  double acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = 0.0;
+  const int begin = blockIdx.x * tile_points;
+  const int end = min(begin + tile_points, f.n);
+  for (int i = begin + threadIdx.x; i < end; i += 256) {
+    const double px = (double)f.points[3 * (size_t)i], py = (double)f.points[3 * (size_t)i + 1], pz = (double)f.points[3 * (size_t)i + 2];
+    const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
+    const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
+    const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
+    // correspondence: nearest target point with sq_dist < max (integrated_gicp_factor_impl.hpp:166-170)
+    TopK<1> top;
+    top.init(1, f.max_sq_dist);
+    knn_query<1>(f.grid, lx, ly, lz, top);
+    if (top.found == 0) continue;
+    const size_t j = (size_t)top.idx[0];
+    const float* cp = f.covs + 9 * (size_t)i;
+    const float* cq = f.target_covs + 9 * j;
+    const float cA[6] = {cp[0], cp[3], cp[6], cp[4], cp[7], cp[8]};
+    // reuse the VGICP per-point algebra: the "voxel" is the matched target point (centre 0, mean_local = mu_B)
+    const double mux = (double)f.target_points[3 * j], muy = (double)f.target_points[3 * j + 1], muz = (double)f.target_points[3 * j + 2];
+    const v2d c01 = {(double)cq[0], (double)cq[3]}, c23 = {(double)cq[6], (double)cq[4]}, c45 = {(double)cq[7], (double)cq[8]};
+    accumulate_terms_mu<MODE, double>(Tl, Te, (float)px, (float)py, (float)pz, cA, mux, muy, muz, c01, c23, c45, acc);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double lds[4][ACC_STRIDE];
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+  } else {
+    const double s = butterfly_reduce32(acc, lane);
+    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double s = 0.0;
+    if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    partials[(size_t)blockIdx.x * ACC_STRIDE + threadIdx.x] = s;
+  }
+}
+
+}  // namespace gp
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+struct gp_point_grid {
+  gp::DeviceArray keys, start, sorted;
+  uint32_t mask = 0;
+  int n = 0;
+  double h = 0.0;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  hipStream_t stream = nullptr;
+  gp::GridView view() const {
+    gp::GridView g;
+    g.keys = keys.as<unsigned long long>();
+    g.start = start.as<int>();
+    g.sorted = sorted.as<float4>();
+    g.mask = mask;
+    g.n = n;
+    g.h = h;
+    g.inv_h = 1.0 / h;
+    for (int a = 0; a < 3; a++) {
+      g.lo[a] = lo[a];
+      g.hi[a] = hi[a];
+    }
+    return g;
+  }
+};
+
+struct gp_gicp_factor {
+  gp_point_grid* grid = nullptr;
+  gp::GicpDesc desc{};
+  hipStream_t stream = nullptr;
+  int tile_points = 1024;
+  int num_tiles = 0;
+  gp::DeviceArray partials, d_poses, d_out;
+  gp::PinnedArray h_out;
+  void* h_out_dev = nullptr;
+};
+
+extern "C" {
+
+int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_stream_t stream, gp_point_grid_t** out) {
+  if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
+  auto* g = new gp_point_grid;
+  hipStream_t s = (hipStream_t)stream;
+  g->n = n;
+  g->h = cell_size;
+  g->stream = s;
+  uint32_t slots = 1024;
+  while (slots < 2u * (uint32_t)std::max(n, 1)) slots <<= 1;  // at most n distinct cells -> load factor <= 0.5
+  g->mask = slots - 1;
+  gp::DeviceArray counts, point_slot, block_sums, total, cursor;
+  const int nb = (int)((slots + gp::kScanBlock - 1) / gp::kScanBlock);
+  int rc = GP_OK;
+  if ((rc = g->keys.alloc(sizeof(unsigned long long) * slots)) || (rc = g->start.alloc(sizeof(int) * ((size_t)slots + 1))) ||
+      (rc = g->sorted.alloc(sizeof(float4) * (size_t)std::max(n, 1))) || (rc = counts.alloc(sizeof(int) * slots)) || (rc = cursor.alloc(sizeof(int) * slots)) ||
+      (rc = point_slot.alloc(sizeof(int) * (size_t)std::max(n, 1))) || (rc = block_sums.alloc(sizeof(int) * (size_t)nb)) || (rc = total.alloc(sizeof(int)))) {
+    delete g;
+    return rc;
+  }
+  GP_HIP(hipMemsetAsync(g->keys.ptr, 0xff, sizeof(unsigned long long) * slots, s));
+  GP_HIP(hipMemsetAsync(counts.ptr, 0, sizeof(int) * slots, s));
+  GP_HIP(hipMemsetAsync(cursor.ptr, 0, sizeof(int) * slots, s));
+  if (n > 0) {
+    hipLaunchKernelGGL(gp::grid_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, 1.0 / cell_size, g->keys.as<unsigned long long>(), counts.as<int>(),
+                       point_slot.as<int>(), g->mask);
+  }
+  hipLaunchKernelGGL(gp::scan_block_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, counts.as<int>(), g->start.as<int>(), block_sums.as<int>(), (int)slots);
+  hipLaunchKernelGGL(gp::scan_sums_kernel, dim3(1), dim3(gp::kScanBlock), 0, s, block_sums.as<int>(), nb, total.as<int>());
+  hipLaunchKernelGGL(gp::scan_add_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, g->start.as<int>(), block_sums.as<int>(), (int)slots, total.as<int>());
+  if (n > 0) {
+    hipLaunchKernelGGL(gp::grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, point_slot.as<int>(), g->start.as<int>(), cursor.as<int>(),
+                       g->sorted.as<float4>());
+  }
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipStreamSynchronize(s));
+  if (n > 0) {  // bounding box of the occupied cells (bounds every query's cube radius)
+    std::vector<unsigned long long> h_keys(slots);
+    GP_HIP(hipMemcpy(h_keys.data(), g->keys.ptr, sizeof(unsigned long long) * slots, hipMemcpyDeviceToHost));
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+    for (auto k : h_keys) {
+      if (k == gp::kEmptyKey) continue;
+      const int c[3] = {(int)((k >> 42) & 0x1fffff) - (1 << 20), (int)((k >> 21) & 0x1fffff) - (1 << 20), (int)(k & 0x1fffff) - (1 << 20)};
+      for (int a = 0; a < 3; a++) {
+        lo[a] = std::min(lo[a], c[a]);
+        hi[a] = std::max(hi[a], c[a]);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      g->lo[a] = lo[a];
+      g->hi[a] = hi[a];
+    }
+  }
+  *out = g;
+  return GP_OK;
+}
+
+int gp_point_grid_destroy(gp_point_grid_t* g) {
+  delete g;
+  return GP_OK;
+}
+
+int gp_knn_search(const gp_point_grid_t* g, const float* queries_dev, int nq, int k, double max_sq_dist, int* indices_dev, double* sq_dists_dev, int* num_found_dev,
+                  gp_stream_t stream) {
+  if (!g || !queries_dev || nq < 0 || k <= 0 || k > 32 || !indices_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_knn_search: bad arguments (1 <= k <= 32)");
+  if (nq == 0) return GP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gp::GridView v = g->view();
+  const dim3 grid((nq + 127) / 128), block(128);
+  if (k == 1)
+    hipLaunchKernelGGL(gp::knn_kernel<1>, grid, block, 0, s, v, queries_dev, nq, k, max_sq_dist, indices_dev, sq_dists_dev, num_found_dev);
+  else if (k <= 10)
+    hipLaunchKernelGGL(gp::knn_kernel<10>, grid, block, 0, s, v, queries_dev, nq, k, max_sq_dist, indices_dev, sq_dists_dev, num_found_dev);
+  else
+    hipLaunchKernelGGL(gp::knn_kernel<32>, grid, block, 0, s, v, queries_dev, nq, k, max_sq_dist, indices_dev, sq_dists_dev, num_found_dev);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
+int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_size, float* covs_dev, int* num_short, gp_stream_t stream) {
+  if (!points_dev || n < 0 || k <= 0 || k > 32 || !covs_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_estimate_covariances: bad arguments (1 <= k <= 32)");
+  if (num_short) *num_short = 0;
+  if (n == 0) return GP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gp_point_grid_t* g = nullptr;
+  GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.5, stream, &g));
+  gp::DeviceArray d_short;
+  int rc = d_short.alloc(sizeof(int));
+  if (rc == GP_OK) {
+    (void)hipMemsetAsync(d_short.ptr, 0, sizeof(int), s);
+    gp::GridView v = g->view();
+    const dim3 grid((n + 127) / 128), block(128);
+    if (k <= 10)
+      hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, n, k, covs_dev, d_short.as<int>());
+    else
+      hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, n, k, covs_dev, d_short.as<int>());
+    int h_short = 0;
+    hipError_t e = hipMemcpyAsync(&h_short, d_short.ptr, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = gp::hip_fail(e, "covariance_kernel", __FILE__, __LINE__);
+    if (num_short) *num_short = h_short;
+    if (h_short > 0) fprintf(stderr, "warning: fewer than k neighbors found for %d points\n", h_short);  // covariance_estimation.cpp:28
+  }
+  gp_point_grid_destroy(g);
+  return rc;
+}
+
+// ---- GICP factor ----------------------------------------------------------------------------------------------------
+
+int gp_gicp_factor_create(const float* target_points_dev, const float* target_covs_dev, int n_target, const float* points_dev, const float* covs_dev, int n,
+                          double max_correspondence_distance_sq, gp_stream_t stream, gp_gicp_factor_t** out) {
+  if (!target_points_dev || !target_covs_dev || !points_dev || !covs_dev || n < 0 || n_target < 0 || !(max_correspondence_distance_sq > 0.0) || !out)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_create: bad arguments");
+  auto* f = new gp_gicp_factor;
+  f->stream = (hipStream_t)stream;
+  // cell size = the correspondence radius: a 1-NN within max distance needs the 27 cells around the query at most
+  int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq), stream, &f->grid);
+  if (rc != GP_OK) {
+    delete f;
+    return rc;
+  }
+  f->desc.points = points_dev;
+  f->desc.covs = covs_dev;
+  f->desc.target_points = target_points_dev;
+  f->desc.target_covs = target_covs_dev;
+  f->desc.grid = f->grid->view();  // the max-distance bound terminates the search early (worst() starts at max_sq_dist)
+  f->desc.n = n;
+  f->desc.max_sq_dist = max_correspondence_distance_sq;
+  f->num_tiles = (n + f->tile_points - 1) / f->tile_points;
+  if ((rc = f->partials.alloc(sizeof(double) * gp::ACC_STRIDE * (size_t)std::max(f->num_tiles, 1))) || (rc = f->d_poses.alloc(sizeof(double) * 32)) ||
+      (rc = f->d_out.alloc(sizeof(gp_linearized6))) || (rc = f->h_out.ensure(sizeof(gp_linearized6)))) {
+    gp_point_grid_destroy(f->grid);
+    delete f;
+    return rc;
+  }
+  GP_HIP(hipHostGetDevicePointer(&f->h_out_dev, f->h_out.ptr, 0));
+  *out = f;
+  return GP_OK;
+}
+
+int gp_gicp_factor_destroy(gp_gicp_factor_t* f) {
+  if (!f) return GP_OK;
+  (void)hipStreamSynchronize(f->stream);
+  gp_point_grid_destroy(f->grid);
+  delete f;
+  return GP_OK;
+}
+
+int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host) {
+  if (!f || !pose || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_linearize: null");
+  GP_HIP(hipMemcpyAsync(f->d_poses.ptr, pose, sizeof(double) * 16, hipMemcpyHostToDevice, f->stream));
+  if (f->num_tiles > 0)
+    hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(), f->d_poses.as<double>(),
+                       f->tile_points, f->partials.as<double>());
+  GP_TRY(gp::launch_finalize_single(f->stream, f->d_poses.as<double>(), pose, f->partials.as<double>(), f->num_tiles, reinterpret_cast<gp_linearized6*>(f->h_out_dev)));
+  GP_HIP(hipStreamSynchronize(f->stream));
+  memcpy(out_host, f->h_out.ptr, sizeof(gp_linearized6));
+  return GP_OK;
+}
+
+int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host) {
+  if (!f || !pose_lin || !pose_eval || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_compute_error: null");
+  double both[32];
+  memcpy(both, pose_lin, sizeof(double) * 16);
+  memcpy(both + 16, pose_eval, sizeof(double) * 16);
+  GP_HIP(hipMemcpy(f->d_poses.ptr, both, sizeof(both), hipMemcpyHostToDevice));
+  if (f->num_tiles > 0)
+    hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_ERR>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(), f->d_poses.as<double>() + 16,
+                       f->tile_points, f->partials.as<double>());
+  GP_TRY(gp::launch_finalize_error_single(f->stream, f->partials.as<double>(), f->num_tiles, reinterpret_cast<double*>(f->h_out_dev)));
+  GP_HIP(hipStreamSynchronize(f->stream));
+  memcpy(out_host, f->h_out.ptr, sizeof(double));
+  return GP_OK;
+}
+
+}  // extern "C"

@@ -19,53 +19,11 @@
 #include <cstring>
 
 #include "gp_host.hpp"
-
-namespace gp {
-
-constexpr int kBlockThreads = 256;
-constexpr int kPointsPerThread = 4;
-constexpr int kTilePoints = kBlockThreads * kPointsPerThread;  // 1024 source points per workgroup
-constexpr int kNumXCD = 8;
-
-struct FactorDesc {
-  const float* points;   // [n][3]
-  const float* covs;     // [n][9]
-  const float* normals;  // [n][3] or null
-  VoxelMapView map;
-  int n;
-  int surface_validation;
-  int tile_begin;
-  int tile_count;
-};
-
-
-// a single-factor launch carries its poses AND its factor descriptor in the kernel arguments: no H2D copy and no
-// dependent descriptor loads on the latency path (2.8 us per workgroup in the timeline traces)
-struct InlinePoses {
-  double lin[16];
-  double eval[16];
-  FactorDesc factor;
-  int use;
-  int tile_points;
-};
-
-struct TileDesc {
-  int factor;
-  int begin;  // first point
-  int count;  // <= kTilePoints
-};
-
-__device__ __forceinline__ int xcd_swizzle(int b, int num_tiles) {
-  // workgroup b -> tile index; tiles [x*per, (x+1)*per) go to XCD x (dispatcher places workgroup b on XCD b % 8)
-  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
-  return (b % kNumXCD) * per + b / kNumXCD;
-}
-
-enum : int { MODE_LIN = 0, MODE_ERR = 1, MODE_LIN_GENERAL = 2 };
-
-}  // namespace gp
 #include "gp_vgicp_tile.hpp"
+
 namespace gp {
+
+
 
 template <int MODE>
 struct ModeTraits {
@@ -396,9 +354,9 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
 }
 
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
-                                                                             double* __restrict__ out) {
+                                                                             double* __restrict__ out, int single_tile_count = -1) {
   const int fi = blockIdx.x;
-  const int tile_begin = factors[fi].tile_begin, tile_count = factors[fi].tile_count;
+  const int tile_begin = single_tile_count >= 0 ? 0 : factors[fi].tile_begin, tile_count = single_tile_count >= 0 ? single_tile_count : factors[fi].tile_count;
   __shared__ double lds[kBlockThreads / 64];
   double s = 0.0;
   for (int t = threadIdx.x; t < tile_count; t += kBlockThreads) s += partials[(size_t)(tile_begin + t) * ACC_STRIDE + ACC_ERR];
@@ -450,6 +408,23 @@ __global__ void __launch_bounds__(256) stream_ldsdma_kernel(const char* __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const float v = reinterpret_cast<float*>(wbase)[lane * 3] + reinterpret_cast<float*>(wbase)[2048 + lane];
   if (v == 123.456f) sink[0] = v;
+}
+
+int launch_finalize_single(hipStream_t stream, const double* pose_dev, const double* pose_host, const double* partials, int num_tiles, gp_linearized6* out_dev) {
+  InlinePoses inl{};
+  memcpy(inl.lin, pose_host, sizeof(double) * 16);
+  inl.factor.tile_begin = 0;
+  inl.factor.tile_count = num_tiles;
+  inl.use = 1;
+  hipLaunchKernelGGL(vgicp_finalize_kernel<false>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_kernel", __FILE__, __LINE__);
+}
+
+int launch_finalize_error_single(hipStream_t stream, const double* partials, int num_tiles, double* out_dev) {
+  hipLaunchKernelGGL(vgicp_finalize_error_kernel, dim3(1), dim3(kBlockThreads), 0, stream, (const FactorDesc*)nullptr, partials, out_dev, num_tiles);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_error_kernel", __FILE__, __LINE__);
 }
 
 }  // namespace gp
@@ -718,7 +693,7 @@ int launch_error(gp_vgicp_batch* b, const PoseSource& ps, double* out_dev) {
   GP_TRY(partials_ptr(b, &partials));
   GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
   hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3((int)b->factors.size()), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
-                     partials, out_dev);
+                     partials, out_dev, -1);
   GP_HIP(hipGetLastError());
   return GP_OK;
 }

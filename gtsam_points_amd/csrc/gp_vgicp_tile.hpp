@@ -15,7 +15,7 @@
 
 #include <type_traits>
 
-#include "gp_device.hpp"
+#include "gp_vgicp_shared.hpp"
 
 namespace gp {
 
@@ -800,9 +800,10 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel4(const FactorDesc* __re
 // =====================================================================================================================
 #define GP_LDS __attribute__((address_space(3)))
 
+// per-correspondence algebra given the target mean mu_B in f64 (VGICP: voxel centre + offset; GICP: matched target point)
 template <int MODE, typename acc_t>
-__device__ __forceinline__ void accumulate_terms(const Pose& Tl, const Pose& Te, double leaf, float pxf, float pyf, float pzf, const float* cA, int cx, int cy, int cz,
-                                                 const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45, acc_t* acc) {
+__device__ __forceinline__ void accumulate_terms_mu(const Pose& Tl, const Pose& Te, float pxf, float pyf, float pzf, const float* cA, double mux, double muy, double muz,
+                                                    const v2d& c01, const v2d& c23, const v2d& c45, acc_t* acc) {
   const double px = (double)pxf, py = (double)pyf, pz = (double)pzf;
   double m[6];
   {
@@ -828,9 +829,7 @@ __device__ __forceinline__ void accumulate_terms(const Pose& Tl, const Pose& Te,
   const double qx = Te.r00 * px + Te.r01 * py + Te.r02 * pz + Te.tx;
   const double qy = Te.r10 * px + Te.r11 * py + Te.r12 * pz + Te.ty;
   const double qz = Te.r20 * px + Te.r21 * py + Te.r22 * pz + Te.tz;
-  const double rxd = (((double)cx + 0.5) * leaf - qx) + (double)head.x;
-  const double ryd = (((double)cy + 0.5) * leaf - qy) + (double)head.y;
-  const double rzd = (((double)cz + 0.5) * leaf - qz) + (double)head.z;
+  const double rxd = mux - qx, ryd = muy - qy, rzd = muz - qz;
   const acc_t M0 = (acc_t)m[0], M1 = (acc_t)m[1], M2 = (acc_t)m[2], M3 = (acc_t)m[3], M4 = (acc_t)m[4], M5 = (acc_t)m[5];
   const acc_t RX = (acc_t)rxd, RY = (acc_t)ryd, RZ = (acc_t)rzd, QX = (acc_t)qx, QY = (acc_t)qy, QZ = (acc_t)qz;
   const acc_t mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
@@ -870,8 +869,17 @@ __device__ __forceinline__ void accumulate_terms(const Pose& Tl, const Pose& Te,
   }
 }
 
+
+template <int MODE, typename acc_t>
+__device__ __forceinline__ void accumulate_terms(const Pose& Tl, const Pose& Te, double leaf, float pxf, float pyf, float pzf, const float* cA, int cx, int cy, int cz,
+                                                 const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45, acc_t* acc) {
+  // mu_B = voxel centre + f32 offset; (centre - q) is formed first so that the large coordinates cancel in f64
+  accumulate_terms_mu<MODE, acc_t>(Tl, Te, pxf, pyf, pzf, cA, ((double)cx + 0.5) * leaf + (double)head.x, ((double)cy + 0.5) * leaf + (double)head.y,
+                                   ((double)cz + 0.5) * leaf + (double)head.z, c01, c23, c45, acc);
+}
+
 // optional per-workgroup phase timestamps (s_memtime) for timeline analysis: [num_tiles][8] uint64, enabled by the host
-__device__ unsigned long long* g_trace = nullptr;
+static __device__ unsigned long long* g_trace = nullptr;
 #define GP_TRACE(slot)                                                                   \
   do {                                                                                   \
     if (trace && threadIdx.x == 0) trace[(size_t)tile_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \

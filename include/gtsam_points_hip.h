@@ -227,6 +227,29 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* batch, const double* poses_li
  * between two hipEvents and returns the average milliseconds per pass, and separately the two kernels' times */
 int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* batch, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel);
 
+/* ---- exact k-NN, covariance estimation, GICP (BASELINE configs[4]; CPU-only upstream) ----
+ * KdTree::knn_search (ann/small_kdtree.hpp:437-474, KnnResult ann/knn_result.hpp:36-117), estimate_covariances
+ * (features/covariance_estimation.cpp:18-77), IntegratedGICPFactor (factors/impl/integrated_gicp_factor_impl.hpp:132-296) */
+
+typedef struct gp_point_grid gp_point_grid_t; /* cell-sorted copy of a cloud: the GPU stand-in for the reference's KdTree */
+int gp_point_grid_create(const float* points_dev, int num_points, double cell_size, gp_stream_t stream, gp_point_grid_t** out);
+int gp_point_grid_destroy(gp_point_grid_t* grid);
+/* exact k nearest neighbours (1 <= k <= 32) of each query within max_sq_dist (strict '<', like KnnResult::push).
+ * indices_dev int[nq][k] (-1 padded), sq_dists_dev double[nq][k] (may be NULL), num_found_dev int[nq] (may be NULL). Asynchronous. */
+int gp_knn_search(const gp_point_grid_t* grid, const float* queries_dev, int num_queries, int k, double max_sq_dist, int* indices_dev, double* sq_dists_dev,
+                  int* num_found_dev, gp_stream_t stream);
+/* estimate_covariances(points, n, k): k-NN incl. the query -> sample covariance -> V diag(1e-3,1,1) V^-1; fewer than k -> identity.
+ * covs_dev float[n][9] column-major; cell_size <= 0 picks 0.5 m; *num_short = points with < k neighbours. Synchronous. */
+int gp_estimate_covariances(const float* points_dev, int num_points, int k, double cell_size, float* covs_dev, int* num_short, gp_stream_t stream);
+
+typedef struct gp_gicp_factor gp_gicp_factor_t;
+/* IntegratedGICPFactor(target, source) with its target 1-NN structure; max_correspondence_distance_sq defaults to 1.0 upstream (:30) */
+int gp_gicp_factor_create(const float* target_points_dev, const float* target_covs_dev, int num_target, const float* points_dev, const float* covs_dev, int num_points,
+                          double max_correspondence_distance_sq, gp_stream_t stream, gp_gicp_factor_t** out);
+int gp_gicp_factor_destroy(gp_gicp_factor_t* f);
+int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host);           /* update_correspondences + evaluate */
+int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host);
+
 /* tuning hook (not part of the reference API): selects the tile-kernel variant, see gp_vgicp.hip */
 int gp_debug_set_variant(int variant);
 /* timeline hook: per-workgroup phase timestamps of the LDS-DMA tile kernel into dev_buffer ([num_tiles][8] uint64) */
