@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(128) knn_kernel(GridView g, const float* __res
   if (num_found) num_found[i] = top.found;
 }
 
-// ---- Eigen 3.4.0 SelfAdjointEigenSolver<Matrix3d>::computeDirect, restated (see oracle/vgicp_oracle.c) -------------
+// ---- Eigen 3.4.0 SelfAdjointEigenSolver<Matrix3d>::computeDirect, restated from the published closed-form algorithm -----
 __device__ __forceinline__ void eig3_roots(const double* m /*col-major sym*/, double* roots) {
   const double s_inv3 = 1.0 / 3.0, s_sqrt3 = 1.7320508075688772;
   const double c0 = m[0] * m[4] * m[8] + 2.0 * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
