@@ -163,6 +163,42 @@ struct TopK {
   }
 };
 
+// LiDAR density varies by three orders of magnitude between the near and the far field, so one cell size cannot be right
+// everywhere: the structure keeps up to kMaxLevels grids (cell size x4 per level) and every query runs the same exact
+// search on the finest level whose 3x3x3 neighbourhood already holds enough points.  Exactness does not depend on the choice.
+constexpr int kMaxLevels = 3;
+struct MultiGridView {
+  GridView lv[kMaxLevels];
+  int num_levels;
+};
+
+template <int KMAX>
+__device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top);
+
+__device__ __forceinline__ int count27(const GridView& g, double qx, double qy, double qz) {
+  const int cx = fast_floor(qx * g.inv_h), cy = fast_floor(qy * g.inv_h), cz = fast_floor(qz * g.inv_h);
+  int c = 0;
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int s = grid_find(g, pack_cell(cx + dx, cy + dy, cz + dz));
+        if (s >= 0) c += g.start[s + 1] - g.start[s];
+      }
+  return c;
+}
+
+template <int KMAX>
+__device__ __forceinline__ void knn_query_multi(const MultiGridView& mg, double qx, double qy, double qz, int want, TopK<KMAX>& top) {
+  int level = mg.num_levels - 1;
+  for (int l = 0; l + 1 < mg.num_levels; l++) {
+    if (count27(mg.lv[l], qx, qy, qz) >= want) {
+      level = l;
+      break;
+    }
+  }
+  knn_query<KMAX>(mg.lv[level], qx, qy, qz, top);
+}
+
 template <int KMAX>
 __device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
   const int cx = fast_floor(qx * g.inv_h), cy = fast_floor(qy * g.inv_h), cz = fast_floor(qz * g.inv_h);
@@ -189,17 +225,18 @@ __device__ __forceinline__ void knn_query(const GridView& g, double qx, double q
       }
     const double safe = (double)r * g.h + face;
     if (top.worst() <= safe * safe) return;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
+    if (top.found >= g.n) return;            // the whole cloud has been seen (clouds smaller than k)
   }
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(128) knn_kernel(GridView g, const float* __restrict__ queries, int nq, int k, double max_sq_dist, int* __restrict__ indices,
+__global__ void __launch_bounds__(128) knn_kernel(MultiGridView g, const float* __restrict__ queries, int nq, int k, double max_sq_dist, int* __restrict__ indices,
                                                   double* __restrict__ sq_dists, int* __restrict__ num_found) {
   const int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= nq) return;
   TopK<KMAX> top;
   top.init(k, max_sq_dist);
-  knn_query<KMAX>(g, (double)queries[3 * (size_t)i], (double)queries[3 * (size_t)i + 1], (double)queries[3 * (size_t)i + 2], top);
+  knn_query_multi<KMAX>(g, (double)queries[3 * (size_t)i], (double)queries[3 * (size_t)i + 1], (double)queries[3 * (size_t)i + 2], 2 * k, top);
 #pragma unroll
   for (int j = 0; j < KMAX; j++)
     if (j < k) {
@@ -322,14 +359,14 @@ __device__ __forceinline__ void inverse3_general(const double* a /*col-major*/, 
 // estimate_covariances (features/covariance_estimation.cpp:18-77): k-NN (query included) -> sample covariance ->
 // V diag(1e-3, 1, 1) V^-1.  Fewer than k neighbours -> identity (:27-31).
 template <int KMAX>
-__global__ void __launch_bounds__(128) covariance_kernel(GridView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
+__global__ void __launch_bounds__(128) covariance_kernel(MultiGridView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
                                                          int* __restrict__ num_short) {
   const int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= n) return;
   const double qx = (double)points[3 * (size_t)i], qy = (double)points[3 * (size_t)i + 1], qz = (double)points[3 * (size_t)i + 2];
   TopK<KMAX> top;
   top.init(k, 1.7976931348623157e308);
-  knn_query<KMAX>(g, qx, qy, qz, top);
+  knn_query_multi<KMAX>(g, qx, qy, qz, 2 * k, top);
   float* out = covs + 9 * (size_t)i;
   if (top.found < k) {
     atomicAdd(num_short, 1);
@@ -367,7 +404,7 @@ struct GicpDesc {
   const float* covs;
   const float* target_points;
   const float* target_covs;
-  GridView grid;
+  MultiGridView grid;
   int n;
   double max_sq_dist;
 };
@@ -391,7 +428,7 @@ __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double
     // correspondence: nearest target point with sq_dist < max (integrated_gicp_factor_impl.hpp:166-170)
     TopK<1> top;
     top.init(1, f.max_sq_dist);
-    knn_query<1>(f.grid, lx, ly, lz, top);
+    knn_query_multi<1>(f.grid, lx, ly, lz, 1, top);
     if (top.found == 0) continue;
     const size_t j = (size_t)top.idx[0];
     const float* cp = f.covs + 9 * (size_t)i;
@@ -430,13 +467,12 @@ __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 
-struct gp_point_grid {
+struct gp_grid_level {
   gp::DeviceArray keys, start, sorted;
   uint32_t mask = 0;
   int n = 0;
   double h = 0.0;
   int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  hipStream_t stream = nullptr;
   gp::GridView view() const {
     gp::GridView g;
     g.keys = keys.as<unsigned long long>();
@@ -454,6 +490,17 @@ struct gp_point_grid {
   }
 };
 
+struct gp_point_grid {
+  std::vector<std::unique_ptr<gp_grid_level>> levels;
+  hipStream_t stream = nullptr;
+  gp::MultiGridView view() const {
+    gp::MultiGridView v{};
+    v.num_levels = (int)levels.size();
+    for (int l = 0; l < v.num_levels; l++) v.lv[l] = levels[l]->view();
+    return v;
+  }
+};
+
 struct gp_gicp_factor {
   gp_point_grid* grid = nullptr;
   gp::GicpDesc desc{};
@@ -467,13 +514,10 @@ struct gp_gicp_factor {
 
 extern "C" {
 
-int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_stream_t stream, gp_point_grid_t** out) {
-  if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
-  auto* g = new gp_point_grid;
-  hipStream_t s = (hipStream_t)stream;
+static int build_level(const float* points_dev, int n, double cell_size, hipStream_t s, gp_grid_level** out) {
+  auto* g = new gp_grid_level;
   g->n = n;
   g->h = cell_size;
-  g->stream = s;
   uint32_t slots = 1024;
   while (slots < 2u * (uint32_t)std::max(n, 1)) slots <<= 1;  // at most n distinct cells -> load factor <= 0.5
   g->mask = slots - 1;
@@ -523,6 +567,30 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   return GP_OK;
 }
 
+}  // extern "C" (re-opened below)
+
+extern "C" {
+
+// levels: cell_size, 4 cell_size, 16 cell_size (coarser levels only when the cloud is large enough to need them)
+int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_stream_t stream, gp_point_grid_t** out) {
+  if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
+  auto* g = new gp_point_grid;
+  g->stream = (hipStream_t)stream;
+  const int num_levels = n > 4096 ? gp::kMaxLevels : 1;
+  double h = cell_size;
+  for (int l = 0; l < num_levels; l++, h *= 4.0) {
+    gp_grid_level* lv = nullptr;
+    const int rc = build_level(points_dev, n, h, g->stream, &lv);
+    if (rc != GP_OK) {
+      delete g;
+      return rc;
+    }
+    g->levels.emplace_back(lv);
+  }
+  *out = g;
+  return GP_OK;
+}
+
 int gp_point_grid_destroy(gp_point_grid_t* g) {
   delete g;
   return GP_OK;
@@ -533,7 +601,7 @@ int gp_knn_search(const gp_point_grid_t* g, const float* queries_dev, int nq, in
   if (!g || !queries_dev || nq < 0 || k <= 0 || k > 32 || !indices_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_knn_search: bad arguments (1 <= k <= 32)");
   if (nq == 0) return GP_OK;
   hipStream_t s = (hipStream_t)stream;
-  gp::GridView v = g->view();
+  const gp::MultiGridView v = g->view();
   const dim3 grid((nq + 127) / 128), block(128);
   if (k == 1)
     hipLaunchKernelGGL(gp::knn_kernel<1>, grid, block, 0, s, v, queries_dev, nq, k, max_sq_dist, indices_dev, sq_dists_dev, num_found_dev);
@@ -551,12 +619,12 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   if (n == 0) return GP_OK;
   hipStream_t s = (hipStream_t)stream;
   gp_point_grid_t* g = nullptr;
-  GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.5, stream, &g));
+  GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.125, stream, &g));
   gp::DeviceArray d_short;
   int rc = d_short.alloc(sizeof(int));
   if (rc == GP_OK) {
     (void)hipMemsetAsync(d_short.ptr, 0, sizeof(int), s);
-    gp::GridView v = g->view();
+    const gp::MultiGridView v = g->view();
     const dim3 grid((n + 127) / 128), block(128);
     if (k <= 10)
       hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, n, k, covs_dev, d_short.as<int>());
@@ -581,8 +649,8 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
     return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_create: bad arguments");
   auto* f = new gp_gicp_factor;
   f->stream = (hipStream_t)stream;
-  // cell size = the correspondence radius: a 1-NN within max distance needs the 27 cells around the query at most
-  int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq), stream, &f->grid);
+  // finest cell = 1/8 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
+  int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 8.0, stream, &f->grid);
   if (rc != GP_OK) {
     delete f;
     return rc;

@@ -16,7 +16,7 @@ from .types import GaussianVoxelMapGPU, PointCloudGPU, _pose16
 class KdTreeGPU:
     """Exact nearest-neighbour search structure over a PointCloudGPU (KdTree::knn_search semantics)."""
 
-    def __init__(self, frame: PointCloudGPU, cell_size=0.5, stream=None):
+    def __init__(self, frame: PointCloudGPU, cell_size=0.125, stream=None):
         self._lib = _capi.load()
         self.frame = frame
         GaussianVoxelMapGPU._sync_torch(frame)
@@ -47,7 +47,7 @@ class KdTreeGPU:
         return idx.cpu().numpy(), d.cpu().numpy(), nf.cpu().numpy()
 
 
-def estimate_covariances_gpu(frame: PointCloudGPU, k_neighbors=10, cell_size=0.5, stream=None):
+def estimate_covariances_gpu(frame: PointCloudGPU, k_neighbors=10, cell_size=0.0, stream=None):
     """estimate_covariances(points, n, k): fills frame.covs_gpu (float [N][9]); returns the number of points with < k neighbours."""
     import torch
 

@@ -21,6 +21,7 @@ import oracle  # noqa: E402
 from gtsam_points_amd import _capi, synthetic  # noqa: E402
 
 lib = gpa.load()
+ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else {"C1", "C3", "C4", "C5"}
 BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
 
 
@@ -72,50 +73,93 @@ def run(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iter
 
 
 # ---- C1 ----
-k = np.load(os.path.join(ROOT, "tests/golden/kitti00_dec8.npz"))
-tgt = gpa.PointCloudGPU(k["target_points"], k["target_covs"])
-src = gpa.PointCloudGPU(k["source_points"], k["source_covs"])
-vm = gpa.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
-vm.insert(tgt)
-run("C1 kitti00 (every 8th point), 0.5 m, single linearise", [tgt, src], [vm, None], [(0, 1)], [synthetic.expmap(synthetic.C1B_PERTURBATION)],
-    [(k["target_points"], k["target_covs"]), (k["source_points"], k["source_covs"])], 0.5, [0], iters=200)
+if "C1" in ONLY:
+    k = np.load(os.path.join(ROOT, "tests/golden/kitti00_dec8.npz"))
+    tgt = gpa.PointCloudGPU(k["target_points"], k["target_covs"])
+    src = gpa.PointCloudGPU(k["source_points"], k["source_covs"])
+    vm = gpa.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+    vm.insert(tgt)
+    run("C1 kitti00 (every 8th point), 0.5 m, single linearise", [tgt, src], [vm, None], [(0, 1)], [synthetic.expmap(synthetic.C1B_PERTURBATION)],
+        [(k["target_points"], k["target_covs"]), (k["source_points"], k["source_covs"])], 0.5, [0], iters=200)
 
 # ---- C3 ----
-rng = np.random.default_rng(8191)
-walls, stations = synthetic.make_street(64, spacing=6.0, seed=43)
-host, clouds, maps = [], [], []
-t0 = time.time()
-for i, T in enumerate(stations):
-    p, c, _ = synthetic.make_submap(20000 + 80 * i, seed=1000 + i, walls=walls, sensor_pose=T)
-    host.append((p, c))
-    clouds.append(gpa.PointCloudGPU(p, c))
-    m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
-    m.insert(clouds[-1])
-    maps.append(m)
-pairs = [(i, j) for i in range(64) for j in range(i + 1, min(i + 5, 64))]
-pairs = (pairs + [(j, i) for i, j in pairs])[:256]
-deltas = [np.linalg.inv(stations[i]) @ stations[j] @ synthetic.expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs]
-run(f"C3 256-factor submap graph, 64 submaps x ~22k pts, 1.0 m (setup {time.time()-t0:.1f}s)", clouds, maps, pairs, deltas, host, 1.0, list(range(0, 256, 16)))
+if "C3" in ONLY or "C4" in ONLY:
+    rng = np.random.default_rng(8191)
+    walls, stations = synthetic.make_street(64, spacing=6.0, seed=43)
+    host, clouds, maps = [], [], []
+    t0 = time.time()
+    for i, T in enumerate(stations):
+        p, c, _ = synthetic.make_submap(20000 + 80 * i, seed=1000 + i, walls=walls, sensor_pose=T)
+        host.append((p, c))
+        clouds.append(gpa.PointCloudGPU(p, c))
+        m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(clouds[-1])
+        maps.append(m)
+    pairs = [(i, j) for i in range(64) for j in range(i + 1, min(i + 5, 64))]
+    pairs = (pairs + [(j, i) for i, j in pairs])[:256]
+    deltas = [np.linalg.inv(stations[i]) @ stations[j] @ synthetic.expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs]
+    run(f"C3 256-factor submap graph, 64 submaps x ~22k pts, 1.0 m (setup {time.time()-t0:.1f}s)", clouds, maps, pairs, deltas, host, 1.0, list(range(0, 256, 16)))
 
 # ---- C4 shard (one GPU of eight): 512 factors x 32768 points ----
-t0 = time.time()
-base_host, base_clouds = [], []
-for i in range(64):
-    p, c, _ = synthetic.make_submap(32768, seed=2000 + i, walls=walls, sensor_pose=stations[i])
-    base_host.append((p, c))
-host4, clouds4, maps4 = [], [], []
-g = torch.Generator(device="cuda").manual_seed(44)
-for i in range(512):
-    p, c = base_host[i % 64]
-    if i < 64:
-        ph = p
-    else:  # distinct memory and slightly different geometry per replica (deterministic jitter), so that nothing is shared in cache
-        ph = (p.astype(np.float64) + np.random.default_rng(3000 + i).normal(0, 0.01, p.shape)).astype(np.float32)
-    host4.append((ph, c))
-    clouds4.append(gpa.PointCloudGPU(ph, c))
-    m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
-    m.insert(clouds4[-1])
-    maps4.append(m)
-pairs4 = [(i, (i // 64) * 64 + (i % 64 + 1) % 64) for i in range(512)]
-deltas4 = [np.linalg.inv(stations[i % 64]) @ stations[j % 64] @ synthetic.expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs4]
-run(f"C4 shard: 512 factors x 32768 pts (1/8 of the 4096-factor config), 1.0 m (setup {time.time()-t0:.1f}s)", clouds4, maps4, pairs4, deltas4, host4, 1.0, list(range(0, 512, 64)))
+if "C4" in ONLY:
+    t0 = time.time()
+    base_host, base_clouds = [], []
+    for i in range(64):
+        p, c, _ = synthetic.make_submap(32768, seed=2000 + i, walls=walls, sensor_pose=stations[i])
+        base_host.append((p, c))
+    host4, clouds4, maps4 = [], [], []
+    g = torch.Generator(device="cuda").manual_seed(44)
+    for i in range(512):
+        p, c = base_host[i % 64]
+        if i < 64:
+            ph = p
+        else:  # distinct memory and slightly different geometry per replica (deterministic jitter), so that nothing is shared in cache
+            ph = (p.astype(np.float64) + np.random.default_rng(3000 + i).normal(0, 0.01, p.shape)).astype(np.float32)
+        host4.append((ph, c))
+        clouds4.append(gpa.PointCloudGPU(ph, c))
+        m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(clouds4[-1])
+        maps4.append(m)
+    pairs4 = [(i, (i // 64) * 64 + (i % 64 + 1) % 64) for i in range(512)]
+    deltas4 = [np.linalg.inv(stations[i % 64]) @ stations[j % 64] @ synthetic.expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs4]
+    run(f"C4 shard: 512 factors x 32768 pts (1/8 of the 4096-factor config), 1.0 m (setup {time.time()-t0:.1f}s)", clouds4, maps4, pairs4, deltas4, host4, 1.0, list(range(0, 512, 64)))
+
+# ---- C5: k-NN covariance estimation + GICP linearise, 1 M points ----
+if "C5" in ONLY:
+    d = synthetic.make_c2_workload(1_000_000, 1_000_000, seed=42)
+    tgt5 = gpa.PointCloudGPU(d["target_points"])
+    src5 = gpa.PointCloudGPU(d["source_points"])
+    torch.cuda.synchronize()
+    t_cov = []
+    for fr in (tgt5, src5, tgt5, src5):
+        t = time.perf_counter()
+        short = gpa.estimate_covariances_gpu(fr, 10)
+        t_cov.append(time.perf_counter() - t)
+    t_cov_gpu = min(t_cov[2:])
+    t = time.perf_counter()
+    oc_src, _ = oracle.estimate_covariances(d["source_points"], 10, oracle.max_threads())
+    t_cov_cpu = time.perf_counter() - t
+    got = src5.covs_gpu.cpu().numpy().reshape(-1, 3, 3).transpose(0, 2, 1).astype(np.float64)
+    rel = np.linalg.norm((got - oc_src).reshape(len(got), -1), axis=1) / np.linalg.norm(oc_src.reshape(len(got), -1), axis=1)
+    fg = gpa.IntegratedGICPFactorGPU(0, 1, tgt5, src5)
+    delta5 = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    L = fg.linearize_delta(delta5)
+    ts = []
+    for _ in range(10):
+        t = time.perf_counter()
+        L = fg.linearize_delta(delta5)
+        ts.append(time.perf_counter() - t)
+    tc = tgt5.covs_gpu.cpu().numpy().reshape(-1, 3, 3).transpose(0, 2, 1)
+    sc = src5.covs_gpu.cpu().numpy().reshape(-1, 3, 3).transpose(0, 2, 1)
+    fo = oracle.OracleGICPFactor(d["target_points"], tc, d["source_points"], sc, oracle.max_threads())
+    t = time.perf_counter()
+    Lo = fo.linearize(delta5)
+    t_gicp_cpu = time.perf_counter() - t
+    worst = max(float(np.linalg.norm(getattr(L, b) - getattr(Lo, b)) / np.linalg.norm(getattr(Lo, b))) for b in BLOCKS)
+    print(json.dumps(dict(
+        config="C5 kNN covariance estimation (k=10) + IntegratedGICPFactor linearise, 1M pts vs 1M pts", points=1_000_000,
+        cov_estimation_ms=round(t_cov_gpu * 1e3, 3), cov_points_per_s=round(1e6 / t_cov_gpu, 1), cov_cpu_oracle_ms=round(t_cov_cpu * 1e3, 1),
+        cov_rel_err_median=float(np.median(rel)), cov_frac_within_1e5=float((rel < 1e-5).mean()), cov_num_short=short,
+        gicp_linearize_ms=round(float(np.median(ts)) * 1e3, 4), gicp_corr_per_s=round(1e6 / float(np.median(ts)), 1), gicp_cpu_oracle_ms=round(t_gicp_cpu * 1e3, 1),
+        gicp_parity_max_rel_err=worst, gicp_inliers_equal=bool(L.num_inliers == Lo.num_inliers), gicp_inlier_fraction=round(L.num_inliers / 1e6, 4), cpu_threads=oracle.max_threads(),
+    )), flush=True)
