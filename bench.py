@@ -70,17 +70,22 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device(f"cuda:{local_rank}")
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node; lets a 1-GPU box rehearse N > 1
+    torch.cuda.set_device(dev_index)
+    device = torch.device(f"cuda:{dev_index}")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("GP_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; "gloo" only for the 1-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import gtsam_points_amd as gpa
     from gtsam_points_amd import _capi, synthetic
 
     lib = gpa.load()
-    _capi.check(lib.gp_set_device(local_rank), "gp_set_device")
+    _capi.check(lib.gp_set_device(dev_index), "gp_set_device")
 
     # ---- workload, resident in HBM before timing ----
     t_gen = time.time()
