@@ -39,7 +39,7 @@ struct VoxelMapView {
   const gp_voxel_bucket* pkeys;
   const VoxelRecord* pfat;
   uint32_t pmask;
-  uint32_t pad_;
+  uint32_t pwide;  // 1: key and record share one 128-B line (record at 128*s, key at 128*s + 64); 0: separate arrays
   // reference-visible table (reference hash + max_bucket_scan_count probe rule) and compact records
   const gp_voxel_bucket* buckets;
   const VoxelRecord* records;

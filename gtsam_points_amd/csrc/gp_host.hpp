@@ -119,6 +119,7 @@ struct gp_voxelmap {
   gp::DeviceArray voxel_coords; // int[num_voxels][3] voxel coordinate of each voxel index
   gp::DeviceArray pkeys, pfat;  // private slot table of the VGICP kernels (gp::VoxelMapView)
   uint32_t pmask = 0;
+  uint32_t pwide = 0;
 
   // offloaded copies (OffloadableGPU)
   bool offloaded = false;

@@ -79,6 +79,9 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel2(const FactorDesc* __re
   const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
   const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
   if (tile_idx >= num_tiles) return;
+  if (inl.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    for (int k = 0; k < inl.stagger; k++) __builtin_amdgcn_s_sleep(1);  // ~64 cycles each
+  }
   TileDesc tile;
   if (inl.use) {
     tile.factor = 0;
@@ -1055,6 +1058,305 @@ __global__ void __launch_bounds__(256) vgicp_tile_kernel5(const FactorDesc* __re
     ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = s;
   }
   GP_TRACE(6);
+}
+
+
+// =====================================================================================================================
+// vgicp_tile_kernel6 -- occupancy-first variant: one point per lane per step, NO register accumulators.
+// The 29 per-point terms (f32 outer products on f64-accurate M, r, q) are added straight into a per-thread column of
+// an LDS accumulator image [32][256] floats with ds_add_f32 (no return value, conflict-free: consecutive lanes ->
+// consecutive banks).  That frees the 58 VGPRs of the f64 accumulators (and the butterfly), so 5-6 waves per SIMD stay
+// resident and plain thread-level parallelism hides the two dependent round trips (source point, slot table).
+// =====================================================================================================================
+template <int MODE, int STEPS>
+__global__ void __launch_bounds__(256) vgicp_tile_kernel6(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                          const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                          double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  __shared__ float lacc[32][256];  // 32 KB
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
+  if (tile_idx >= num_tiles) return;
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const GP_GLOBAL char* pkeys = (const GP_GLOBAL char*)f.map.pkeys;
+  const GP_GLOBAL char* pfat = (const GP_GLOBAL char*)f.map.pfat;
+  const int kshift = f.map.pwide ? 7 : 4, rshift = f.map.pwide ? 7 : 6;
+  const uint32_t pmask = f.map.pmask;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NACC; k++) lacc[k][tid] = 0.0f;  // own column only: no barrier needed before the adds
+
+  for (int step = 0; step < STEPS; step++) {
+    const int local = step * 256 + tid;
+    if (local >= tile.count) break;
+    const size_t i = (size_t)tile.begin + local;
+    const GP_GLOBAL float* pp = points + 3 * i;
+    const GP_GLOBAL float* cp = covs + 9 * i;
+    const float px = __builtin_nontemporal_load(pp), py = __builtin_nontemporal_load(pp + 1), pz = __builtin_nontemporal_load(pp + 2);
+    const float cA[6] = {__builtin_nontemporal_load(cp),     __builtin_nontemporal_load(cp + 3), __builtin_nontemporal_load(cp + 6),
+                         __builtin_nontemporal_load(cp + 4), __builtin_nontemporal_load(cp + 7), __builtin_nontemporal_load(cp + 8)};
+    const double dx = (double)px, dy = (double)py, dz = (double)pz;
+    const double lx = Tl.r00 * dx + Tl.r01 * dy + Tl.r02 * dz + Tl.tx;
+    const double ly = Tl.r10 * dx + Tl.r11 * dy + Tl.r12 * dz + Tl.ty;
+    const double lz = Tl.r20 * dx + Tl.r21 * dy + Tl.r22 * dz + Tl.tz;
+    if (f.surface_validation && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * i)) continue;
+    const int cx = fast_floor(lx * f.map.inv_leaf), cy = fast_floor(ly * f.map.inv_leaf), cz = fast_floor(lz * f.map.inv_leaf);
+    uint32_t s = coord_hash32(cx, cy, cz) & pmask;
+    v4i key = *(const GP_GLOBAL v4i*)(pkeys + ((size_t)s << kshift));
+    const GP_GLOBAL char* rec = pfat + ((size_t)s << rshift);
+    v4f head = *(const GP_GLOBAL v4f*)rec;
+    v2d c01 = *(const GP_GLOBAL v2d*)(rec + 16), c23 = *(const GP_GLOBAL v2d*)(rec + 32), c45 = *(const GP_GLOBAL v2d*)(rec + 48);
+    bool hit = false, moved = false;
+    while (key.w >= 0) {
+      if (key.x == cx && key.y == cy && key.z == cz) {
+        hit = true;
+        break;
+      }
+      s = (s + 1) & pmask;
+      key = *(const GP_GLOBAL v4i*)(pkeys + ((size_t)s << kshift));
+      moved = true;
+    }
+    if (!hit) continue;
+    if (moved) {
+      rec = pfat + ((size_t)s << rshift);
+      head = *(const GP_GLOBAL v4f*)rec;
+      c01 = *(const GP_GLOBAL v2d*)(rec + 16);
+      c23 = *(const GP_GLOBAL v2d*)(rec + 32);
+      c45 = *(const GP_GLOBAL v2d*)(rec + 48);
+    }
+    float t[32];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) t[k] = 0.0f;
+    accumulate_terms<MODE, float>(Tl, Te, f.map.leaf, px, py, pz, cA, cx, cy, cz, head, c01, c23, c45, t);
+#pragma unroll
+    for (int k = 0; k < NACC; k++) lacc[k][tid] += t[k];  // own column: plain read-modify-write
+  }
+  __syncthreads();
+  // column sums: 8 lanes per component, 32 values each, then a 3-step shuffle
+  const int comp = tid >> 3, part = tid & 7;
+  double sum = 0.0;
+  if (comp < NACC) {
+#pragma unroll 8
+    for (int j = 0; j < 32; j++) sum += (double)lacc[comp][part * 32 + j];
+  }
+  sum += __shfl_xor(sum, 1, 64);
+  sum += __shfl_xor(sum, 2, 64);
+  sum += __shfl_xor(sum, 4, 64);
+  if (part == 0) ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + comp] = comp < NACC ? sum : 0.0;
+}
+
+
+// =====================================================================================================================
+// vgicp_tile_kernel7 -- rolling LDS-DMA source pipeline, one 64-point chunk per wave step.
+//
+// Measured background (scripts/stream_bench.py, scripts/alu_rate.py): reading the source (48 B/point) and gathering the
+// L2-resident voxel records take 8 us + 3.6 us for 1 M points and ADD UP in every register-staged variant, as does the
+// ~8-10 us of f64 arithmetic: a wave that is hashing or multiplying has no source bytes in flight, and with 16 waves per
+// CU the HBM pipe only stays full while every one of them is waiting on it.  Here the source of chunk j+2 is requested
+// (LDS-DMA: no VGPRs while in flight) before the gather and the arithmetic of chunk j are done, so a wave always has two
+// chunks (6 KB) in flight -- ~100 KB per CU -- whatever else it is doing.  LDS: 3 stages x 3 KB per wave = 36 KB per
+// workgroup, 4 workgroups per CU.  vmcnt retires in order; the issue order gather(j) -> DMA(j+2) makes "vmcnt <= 4" mean
+// "gather(j) has landed" for the compiler's own wait and "chunk j+1 has landed" at the top of the next step.
+// =====================================================================================================================
+constexpr int kChunkPoints = 64;
+constexpr int kChunkBytes = kChunkPoints * 48;  // [64][3] floats, then [64][9] floats
+constexpr int kChunkDmaOps = 3;                 // 3 x 64 lanes x 16 B: pieces 0..47 are the points, 48..191 the covariances
+
+// request one 64-point chunk (768 B of points + 2304 B of covariances) into an LDS stage: three full-wave 16-B DMA
+// instructions, no masked lanes and no branches, so the in-order vmcnt arithmetic around them stays static
+__device__ __forceinline__ void chunk_dma(const GP_GLOBAL float* points, const GP_GLOBAL float* covs, size_t first_point, char* stage, int lane) {
+  const GP_GLOBAL char* gp = (const GP_GLOBAL char*)(points + 3 * first_point);
+  const GP_GLOBAL char* gc = (const GP_GLOBAL char*)(covs + 9 * first_point);
+  const GP_GLOBAL char* a0 = lane < 48 ? gp + lane * 16 : gc + (lane - 48) * 16;
+  __builtin_amdgcn_global_load_lds((const GP_GLOBAL void*)a0, (GP_LDS void*)stage, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const GP_GLOBAL void*)(gc + (lane + 16) * 16), (GP_LDS void*)(stage + 1024), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const GP_GLOBAL void*)(gc + (lane + 80) * 16), (GP_LDS void*)(stage + 2048), 16, 0, 0);
+}
+
+// voxel gather with hand-placed waits: the five 16-B loads (key, then the 64-B record) are issued from inline asm so that the
+// compiler does not track them; gather_wait() ties the destination registers to the s_waitcnt so no use can be scheduled early
+__device__ __forceinline__ void gather_issue(const GP_GLOBAL v4i* kp, const GP_GLOBAL char* rec, v4i& key, v4f& head, v2d& c01, v2d& c23, v2d& c45) {
+  asm volatile(
+    "global_load_dwordx4 %0, %5, off\n\t"
+    "global_load_dwordx4 %1, %6, off\n\t"
+    "global_load_dwordx4 %2, %6, off offset:16\n\t"
+    "global_load_dwordx4 %3, %6, off offset:32\n\t"
+    "global_load_dwordx4 %4, %6, off offset:48"
+    : "=&v"(key), "=&v"(head), "=&v"(c01), "=&v"(c23), "=&v"(c45)
+    : "v"(kp), "v"(rec)
+    : "memory");
+}
+__device__ __forceinline__ void gather_wait(v4i& key, v4f& head, v2d& c01, v2d& c23, v2d& c45) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(key), "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
+}
+
+template <int MODE, bool OUTER_F32, int PPT>
+__global__ void __launch_bounds__(256, 4) vgicp_tile_kernel7(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                          const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                          double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  constexpr int STAGES = 3;
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGES * kChunkBytes];  // 36 KB
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  if (tile_idx >= num_tiles) return;
+  unsigned long long* trace = g_trace;
+  GP_TRACE(0);
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const size_t first = (size_t)tile.begin + (size_t)wave * (PPT * kChunkPoints);  // the wave's first point
+  int wcount = __builtin_amdgcn_readfirstlane(tile.count) - wave * (PPT * kChunkPoints);
+  wcount = wcount < 0 ? 0 : (wcount > PPT * kChunkPoints ? PPT * kChunkPoints : wcount);
+  // the DMA ring needs 16-B aligned rows; anything else (a partial wave, an odd base pointer) reads its points directly
+  const bool ring = wcount == PPT * kChunkPoints && (((uintptr_t)f.points | (uintptr_t)f.covs) & 15) == 0;
+  char* wbase = smem + wave * (STAGES * kChunkBytes);
+
+  if (ring) {
+    chunk_dma(points, covs, first, wbase, lane);
+    if (PPT > 1) chunk_dma(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
+  }
+
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+  const GP_GLOBAL v4i* pkeys = (const GP_GLOBAL v4i*)f.map.pkeys;
+  const GP_GLOBAL char* pfat = (const GP_GLOBAL char*)f.map.pfat;
+  const uint32_t pmask = f.map.pmask;
+
+  using acc_t = typename std::conditional<OUTER_F32, float, double>::type;
+  acc_t acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = (acc_t)0;
+
+  // one chunk: hash, gather (home slot speculatively, then the rare probe), [next DMA], algebra
+  auto step = [&](auto ring_tag, int j, bool active, float px, float py, float pz, const float* cA) {
+    constexpr bool RING = decltype(ring_tag)::value;
+    const double dx = (double)px, dy = (double)py, dz = (double)pz;
+    const double lx = Tl.r00 * dx + Tl.r01 * dy + Tl.r02 * dz + Tl.tx;
+    const double ly = Tl.r10 * dx + Tl.r11 * dy + Tl.r12 * dz + Tl.ty;
+    const double lz = Tl.r20 * dx + Tl.r21 * dy + Tl.r22 * dz + Tl.tz;
+    const int cx = fast_floor(lx * f.map.inv_leaf), cy = fast_floor(ly * f.map.inv_leaf), cz = fast_floor(lz * f.map.inv_leaf);
+    bool live = active;
+    if (f.surface_validation && live && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + (size_t)j * kChunkPoints + lane))) live = false;
+    uint32_t s = coord_hash32(cx, cy, cz) & pmask;
+    // home slot: key + record requested together with hand-placed waits (the compiler's own vmcnt bookkeeping would fold the
+    // younger DMA requests into the wait for these loads)
+    v4i key;
+    v4f head;
+    v2d c01, c23, c45;
+    gather_issue(pkeys + s, pfat + 64 * (size_t)s, key, head, c01, c23, c45);
+    gather_wait(key, head, c01, c23, c45);
+    if (j == 0) GP_TRACE(2);
+    if (j == 1) GP_TRACE(4);
+    bool hit = false, moved = false;
+    if (live) {
+      while (key.w >= 0) {
+        if (key.x == cx && key.y == cy && key.z == cz) {
+          hit = true;
+          break;
+        }
+        s = (s + 1) & pmask;
+        key = pkeys[s];
+        moved = true;
+      }
+      if (hit && moved) {
+        gather_issue(pkeys + s, pfat + 64 * (size_t)s, key, head, c01, c23, c45);
+        gather_wait(key, head, c01, c23, c45);
+      }
+    }
+    if constexpr (RING) {
+      // the probe is settled (its waits are behind us): request chunk j+2 -- its stage held chunk j-1, consumed a step ago --
+      // so that it travels while this chunk's algebra runs; it is older than gather(j+1), hence landed before step j+2
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < PPT) chunk_dma(points, covs, first + (size_t)(j + 2) * kChunkPoints, wbase + ((j + 2) % STAGES) * kChunkBytes, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (hit) accumulate_terms<MODE, acc_t>(Tl, Te, f.map.leaf, px, py, pz, cA, cx, cy, cz, head, c01, c23, c45, acc);
+  };
+
+  if (ring) {
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      // only chunk j+1's request may be younger than chunk j (normally already satisfied: step j-1 waited for its gather,
+      // which is younger than chunk j -- but a step whose lanes were all rejected waits for nothing)
+      if (j + 1 < PPT) {
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (j == 0) GP_TRACE(1);
+      if (j == 1) GP_TRACE(3);
+      if (j == 2) GP_TRACE(5);
+      const float* lp = reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes);
+      const float* lc = lp + kChunkPoints * 3;
+      const float px = lp[3 * lane], py = lp[3 * lane + 1], pz = lp[3 * lane + 2];
+      const float cA[6] = {lc[9 * lane], lc[9 * lane + 3], lc[9 * lane + 6], lc[9 * lane + 4], lc[9 * lane + 7], lc[9 * lane + 8]};
+      step(std::true_type{}, j, true, px, py, pz, cA);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    for (int j = 0; j < PPT; j++) {
+      const int nj = wcount - j * kChunkPoints;  // wave-uniform
+      if (nj <= 0) break;
+      const bool active = lane < nj;
+      const size_t i = first + (size_t)j * kChunkPoints + (active ? lane : 0);
+      const GP_GLOBAL float* pp = points + 3 * i;
+      const GP_GLOBAL float* cp = covs + 9 * i;
+      const float cA[6] = {cp[0], cp[3], cp[6], cp[4], cp[7], cp[8]};
+      step(std::false_type{}, j, active, pp[0], pp[1], pp[2], cA);
+    }
+  }
+
+  GP_TRACE(6);
+  // ---- reduction: butterfly within the wave, then across the 4 waves through LDS (the ring is drained) ----
+  double accd[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) accd[k] = (double)acc[k];
+  __syncthreads();
+  double(*lds)[ACC_STRIDE] = reinterpret_cast<double(*)[ACC_STRIDE]>(smem);
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = accd[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+  } else {
+    const double sum = butterfly_reduce32(accd, lane);
+    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double sum = 0.0;
+    if (threadIdx.x < NACC) sum = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = sum;
+  }
+  GP_TRACE(7);
 }
 
 }  // namespace gp

@@ -128,19 +128,22 @@ __global__ void __launch_bounds__(256) finalize_kernel(int num_voxels, double le
 
 // private slot table: claim a slot per voxel (cheap hash, unbounded linear probing), then store key + record at the slot
 __global__ void __launch_bounds__(256) private_claim_kernel(int num_voxels, const int* __restrict__ voxel_coords, const VoxelRecord* __restrict__ records,
-                                                            gp_voxel_bucket* __restrict__ pkeys, VoxelRecord* __restrict__ pfat, uint32_t pmask) {
+                                                            char* __restrict__ pkeys_raw, int kshift, char* __restrict__ pfat_raw, int rshift,
+                                                            uint32_t pmask) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= num_voxels) return;
   const int cx = voxel_coords[3 * (size_t)v], cy = voxel_coords[3 * (size_t)v + 1], cz = voxel_coords[3 * (size_t)v + 2];
   uint32_t s = coord_hash32(cx, cy, cz) & pmask;
   for (;;) {
-    if (atomicCAS(&pkeys[s].voxel_index, -1, v) == -1) break;  // voxel coordinates are distinct: no equality case
+    gp_voxel_bucket* key = (gp_voxel_bucket*)(pkeys_raw + ((size_t)s << kshift));
+    if (atomicCAS(&key->voxel_index, -1, v) == -1) break;  // voxel coordinates are distinct: no equality case
     s = (s + 1) & pmask;
   }
-  pkeys[s].coord[0] = cx;
-  pkeys[s].coord[1] = cy;
-  pkeys[s].coord[2] = cz;
-  pfat[s] = records[v];
+  gp_voxel_bucket* key = (gp_voxel_bucket*)(pkeys_raw + ((size_t)s << kshift));
+  key->coord[0] = cx;
+  key->coord[1] = cy;
+  key->coord[2] = cz;
+  *(VoxelRecord*)(pfat_raw + ((size_t)s << rshift)) = records[v];
 }
 
 // lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
@@ -169,10 +172,10 @@ __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ p
 
 gp::VoxelMapView gp_voxelmap::view() const {
   gp::VoxelMapView v;
-  v.pkeys = pkeys.as<gp_voxel_bucket>();
+  v.pkeys = pwide ? (const gp_voxel_bucket*)(pfat.as<char>() + 64) : pkeys.as<gp_voxel_bucket>();
   v.pfat = pfat.as<gp::VoxelRecord>();
   v.pmask = pmask;
-  v.pad_ = 0;
+  v.pwide = pwide;
   v.buckets = buckets.as<gp_voxel_bucket>();
   v.records = records.as<gp::VoxelRecord>();
   v.num_buckets = (uint32_t)info.num_buckets;
@@ -216,13 +219,21 @@ static int build_private_table(gp_voxelmap* m, hipStream_t s) {
   uint32_t slots = 1024;
   while (slots < 2u * (uint32_t)std::max(V, 1)) slots <<= 1;
   m->pmask = slots - 1;
-  GP_TRY(m->pkeys.alloc(sizeof(gp_voxel_bucket) * (size_t)slots));
-  GP_TRY(m->pfat.alloc(sizeof(gp::VoxelRecord) * (size_t)slots));
-  GP_HIP(hipMemsetAsync(m->pkeys.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)slots, s));
-  GP_HIP(hipMemsetAsync(m->pfat.ptr, 0, sizeof(gp::VoxelRecord) * (size_t)slots, s));
+  const char* wide_env = getenv("GP_PRIVATE_WIDE");  // experiment switch: one 128-B line per slot
+  m->pwide = (wide_env && wide_env[0] == '1') ? 1u : 0u;
+  if (m->pwide) {
+    GP_TRY(m->pfat.alloc(128 * (size_t)slots));
+    GP_HIP(hipMemsetAsync(m->pfat.ptr, 0xff, 128 * (size_t)slots, s));  // keys = -1; records of empty slots are never read as hits
+  } else {
+    GP_TRY(m->pkeys.alloc(sizeof(gp_voxel_bucket) * (size_t)slots));
+    GP_TRY(m->pfat.alloc(sizeof(gp::VoxelRecord) * (size_t)slots));
+    GP_HIP(hipMemsetAsync(m->pkeys.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)slots, s));
+    GP_HIP(hipMemsetAsync(m->pfat.ptr, 0, sizeof(gp::VoxelRecord) * (size_t)slots, s));
+  }
   if (V > 0) {
+    char* kbase = m->pwide ? m->pfat.as<char>() + 64 : m->pkeys.as<char>();
     hipLaunchKernelGGL(gp::private_claim_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), m->records.as<gp::VoxelRecord>(),
-                       m->pkeys.as<gp_voxel_bucket>(), m->pfat.as<gp::VoxelRecord>(), m->pmask);
+                       kbase, m->pwide ? 7 : 4, m->pfat.as<char>(), m->pwide ? 7 : 6, m->pmask);
     GP_HIP(hipGetLastError());
   }
   return GP_OK;

@@ -252,6 +252,7 @@ int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16],
 
 /* tuning hook (not part of the reference API): selects the tile-kernel variant, see gp_vgicp.hip */
 int gp_debug_set_variant(int variant);
+int gp_debug_set_stagger(int sleeps); /* experiment: phase-offset half of the workgroups */
 /* timeline hook: per-workgroup phase timestamps of the LDS-DMA tile kernel into dev_buffer ([num_tiles][8] uint64) */
 int gp_debug_set_trace_buffer(void* dev_buffer);
 /* profiling hook: streams 48*n bytes with the tile kernel's access pattern (calibrates rocprofv3 FETCH_SIZE) */

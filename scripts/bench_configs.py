@@ -21,6 +21,8 @@ import oracle  # noqa: E402
 from gtsam_points_amd import _capi, synthetic  # noqa: E402
 
 lib = gpa.load()
+if os.environ.get("GP_VARIANT"):  # tuning: pick a tile-kernel variant (gp_debug_set_variant)
+    _capi.check(lib.gp_debug_set_variant(int(os.environ["GP_VARIANT"])), "variant")
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else {"C1", "C3", "C4", "C5"}
 BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
 
@@ -44,6 +46,18 @@ def run(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iter
     _capi.check(lib.gp_vgicp_batch_time_linearize(batch, poses.ctypes.data, iters, C.byref(a), C.byref(b), C.byref(c)), "time")
     npts = int(lib.gp_vgicp_batch_total_points(batch))
     alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+    if os.environ.get("GP_TRACE_TILES"):  # tuning: per-workgroup s_memtime phases of the rolling-DMA kernel (variants >= 28)
+        trace = torch.zeros((65536, 8), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        _capi.check(lib.gp_debug_set_trace_buffer(C.c_void_p(trace.data_ptr())), "trace")
+        lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data)
+        torch.cuda.synchronize()
+        lib.gp_debug_set_trace_buffer(None)
+        t = trace.cpu().numpy().astype(np.float64)
+        t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]
+        dur = np.diff(t, axis=1)
+        print("traced", len(t), "lifetime median ticks", np.median(t[:, 7] - t[:, 0]), "phases median", [int(np.median(dur[:, k])) for k in range(7)],
+              "p90", [int(np.percentile(dur[:, k], 90)) for k in range(7)], flush=True)
     worst, t_cpu = 0.0, 0.0
     omaps = {}
     for k in oracle_sample:

@@ -40,12 +40,14 @@ t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 rel = (t - t0) / 100.0  # s_memtime ticks at 100 MHz -> microseconds
 names = ["start", "dma_issued", "src_in_lds", "table_issued", "table_arrived", "math_done", "end"]
+if variant >= 28:
+    names = ["start", "chunk0_landed", "gather0_landed", "step0_done", "gather1_landed", "step1_done", "steps_done", "end"]
 print("workgroups traced:", len(t))
 for k, n in enumerate(names):
     c = rel[:, k]
     print(f"{n:14s} min {c.min():7.2f}  p10 {np.percentile(c,10):7.2f}  median {np.median(c):7.2f}  p90 {np.percentile(c,90):7.2f}  max {c.max():7.2f} us")
-dur = np.diff(rel[:, :7], axis=1)
-for k in range(6):
+dur = np.diff(rel[:, :len(names)], axis=1)
+for k in range(len(names) - 1):
     print(f"phase {names[k]:>13s} -> {names[k+1]:13s}: median {np.median(dur[:,k]):6.2f}  p90 {np.percentile(dur[:,k],90):6.2f} us")
 starts = np.sort(rel[:, 0])
 print("block start times: first 5", starts[:5], " #started after 3us:", (starts > 3).sum())
