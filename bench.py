@@ -12,7 +12,7 @@ Inputs (source cloud, voxel map) are resident in HBM before the timed region.  v
 Weak scaling: per-GPU work is fixed as N grows.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (vgicp_tile_kernel<false>): algorithmic bytes (SURVEY.md 8(d):
+  roofline     -- dominant kernel (vgicp_pipeline_kernel): algorithmic bytes (SURVEY.md 8(d):
                   48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration measured with HIP events on the
                   stream it is launched on; peak 8 TB/s HBM3E.
   cpu_baseline -- the CPU oracle (restated reference CPU path, OpenMP guided schedule) timed on this box's cores on the
@@ -156,7 +156,7 @@ def main():
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_tile_kernel2<MODE_LIN, f64, 2 points/lane>",
+        kernel="vgicp_pipeline_kernel<MODE_LIN, f64, 4 chunks/wave>",
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",

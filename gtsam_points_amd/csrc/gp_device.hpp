@@ -32,14 +32,14 @@ struct __attribute__((aligned(64))) VoxelRecord {
 static_assert(sizeof(VoxelRecord) == 64, "VoxelRecord must be 64 B");
 
 struct VoxelMapView {
-  // private lookup structure of the VGICP kernels (built from the voxel list after insert / assign / reload):
-  //   pkeys[s] = {coord, voxel_index or -1}, pfat[s] = the voxel's 64-B record stored AT ITS SLOT, so the key and the
-  //   record of the home slot are requested together (no bucket -> record dependency), cheap 32-bit hash, power-of-two table
-  //   at load factor <= 0.5, unbounded linear probing (every voxel is always found).
-  const gp_voxel_bucket* pkeys;
-  const VoxelRecord* pfat;
-  uint32_t pmask;
-  uint32_t pwide;  // 1: key and record share one 128-B line (record at 128*s, key at 128*s + 64); 0: separate arrays
+  // line table, private to the VGICP pipeline kernel (built from the voxel list after insert / assign / reload):
+  // 64-B lines of 4 keys {coord, voxel_index or -1}, filled front to back, cheap 32-bit hash, power-of-two line count with
+  // at most one key per 8 slots on average.  A lookup reads the whole home line in one round trip: match -> index into
+  // `records`; a free slot in the line -> the voxel does not exist; only a full line without a match (P ~ 2e-3) sends the
+  // lookup on to the next line.
+  const gp_voxel_bucket* plines;
+  uint32_t plmask;  // number of lines - 1
+  uint32_t pad_;
   // reference-visible table (reference hash + max_bucket_scan_count probe rule) and compact records
   const gp_voxel_bucket* buckets;
   const VoxelRecord* records;

@@ -117,9 +117,8 @@ struct gp_voxelmap {
   gp::DeviceArray voxel_covs;   // float[num_voxels][9]
   gp::DeviceArray voxel_intensities;  // float[num_voxels]
   gp::DeviceArray voxel_coords; // int[num_voxels][3] voxel coordinate of each voxel index
-  gp::DeviceArray pkeys, pfat;  // private slot table of the VGICP kernels (gp::VoxelMapView)
-  uint32_t pmask = 0;
-  uint32_t pwide = 0;
+  gp::DeviceArray plines;  // line table of the VGICP pipeline kernel (gp::VoxelMapView::plines)
+  uint32_t plmask = 0;
 
   // offloaded copies (OffloadableGPU)
   bool offloaded = false;

@@ -30,7 +30,6 @@ struct InlinePoses {
   FactorDesc factor;
   int use;
   int tile_points;
-  int stagger;  // experiment: workgroups with odd (blockIdx/8) sleep this many x64 cycles before starting
 };
 
 struct TileDesc {

@@ -126,24 +126,24 @@ __global__ void __launch_bounds__(256) finalize_kernel(int num_voxels, double le
   c[8] = (float)rec.cov[5];
 }
 
-// private slot table: claim a slot per voxel (cheap hash, unbounded linear probing), then store key + record at the slot
-__global__ void __launch_bounds__(256) private_claim_kernel(int num_voxels, const int* __restrict__ voxel_coords, const VoxelRecord* __restrict__ records,
-                                                            char* __restrict__ pkeys_raw, int kshift, char* __restrict__ pfat_raw, int rshift,
-                                                            uint32_t pmask) {
+// line table: claim the first free key slot of the home line (front to back), else walk to the next line
+__global__ void __launch_bounds__(256) line_claim_kernel(int num_voxels, const int* __restrict__ voxel_coords, gp_voxel_bucket* __restrict__ lines, uint32_t lmask) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= num_voxels) return;
   const int cx = voxel_coords[3 * (size_t)v], cy = voxel_coords[3 * (size_t)v + 1], cz = voxel_coords[3 * (size_t)v + 2];
-  uint32_t s = coord_hash32(cx, cy, cz) & pmask;
+  uint32_t l = coord_hash32(cx, cy, cz) & lmask;
   for (;;) {
-    gp_voxel_bucket* key = (gp_voxel_bucket*)(pkeys_raw + ((size_t)s << kshift));
-    if (atomicCAS(&key->voxel_index, -1, v) == -1) break;  // voxel coordinates are distinct: no equality case
-    s = (s + 1) & pmask;
+    gp_voxel_bucket* line = lines + 4 * (size_t)l;
+    for (int t = 0; t < 4; t++) {
+      if (atomicCAS(&line[t].voxel_index, -1, v) == -1) {
+        line[t].coord[0] = cx;
+        line[t].coord[1] = cy;
+        line[t].coord[2] = cz;
+        return;
+      }
+    }
+    l = (l + 1) & lmask;
   }
-  gp_voxel_bucket* key = (gp_voxel_bucket*)(pkeys_raw + ((size_t)s << kshift));
-  key->coord[0] = cx;
-  key->coord[1] = cy;
-  key->coord[2] = cz;
-  *(VoxelRecord*)(pfat_raw + ((size_t)s << rshift)) = records[v];
 }
 
 // lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
@@ -172,10 +172,9 @@ __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ p
 
 gp::VoxelMapView gp_voxelmap::view() const {
   gp::VoxelMapView v;
-  v.pkeys = pwide ? (const gp_voxel_bucket*)(pfat.as<char>() + 64) : pkeys.as<gp_voxel_bucket>();
-  v.pfat = pfat.as<gp::VoxelRecord>();
-  v.pmask = pmask;
-  v.pwide = pwide;
+  v.plines = plines.as<gp_voxel_bucket>();
+  v.plmask = plmask;
+  v.pad_ = 0;
   v.buckets = buckets.as<gp_voxel_bucket>();
   v.records = records.as<gp::VoxelRecord>();
   v.num_buckets = (uint32_t)info.num_buckets;
@@ -213,27 +212,16 @@ int alloc_voxel_arrays(gp_voxelmap* m, int V) {
 
 }  // namespace
 
-// (re)build the kernels' private slot table from the voxel list; called at the end of insert / assign / reload
+// (re)build the pipeline kernel's line table from the voxel list; called at the end of insert / assign / reload
 static int build_private_table(gp_voxelmap* m, hipStream_t s) {
   const int V = m->info.num_voxels;
-  uint32_t slots = 1024;
-  while (slots < 2u * (uint32_t)std::max(V, 1)) slots <<= 1;
-  m->pmask = slots - 1;
-  const char* wide_env = getenv("GP_PRIVATE_WIDE");  // experiment switch: one 128-B line per slot
-  m->pwide = (wide_env && wide_env[0] == '1') ? 1u : 0u;
-  if (m->pwide) {
-    GP_TRY(m->pfat.alloc(128 * (size_t)slots));
-    GP_HIP(hipMemsetAsync(m->pfat.ptr, 0xff, 128 * (size_t)slots, s));  // keys = -1; records of empty slots are never read as hits
-  } else {
-    GP_TRY(m->pkeys.alloc(sizeof(gp_voxel_bucket) * (size_t)slots));
-    GP_TRY(m->pfat.alloc(sizeof(gp::VoxelRecord) * (size_t)slots));
-    GP_HIP(hipMemsetAsync(m->pkeys.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)slots, s));
-    GP_HIP(hipMemsetAsync(m->pfat.ptr, 0, sizeof(gp::VoxelRecord) * (size_t)slots, s));
-  }
+  uint32_t lines = 256;
+  while (lines < 2u * (uint32_t)std::max(V, 1)) lines <<= 1;  // 4 key slots per line: load factor <= 1/8
+  m->plmask = lines - 1;
+  GP_TRY(m->plines.alloc(64 * (size_t)lines));
+  GP_HIP(hipMemsetAsync(m->plines.ptr, 0xff, 64 * (size_t)lines, s));
   if (V > 0) {
-    char* kbase = m->pwide ? m->pfat.as<char>() + 64 : m->pkeys.as<char>();
-    hipLaunchKernelGGL(gp::private_claim_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), m->records.as<gp::VoxelRecord>(),
-                       kbase, m->pwide ? 7 : 4, m->pfat.as<char>(), m->pwide ? 7 : 6, m->pmask);
+    hipLaunchKernelGGL(gp::line_claim_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), m->plines.as<gp_voxel_bucket>(), m->plmask);
     GP_HIP(hipGetLastError());
   }
   return GP_OK;
@@ -552,9 +540,9 @@ int gp_voxelmap_load(const char* path, gp_stream_t stream, gp_voxelmap_t** out) 
 
 size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
   if (!map) return 0;
-  // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records and coordinates this implementation adds
+  // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records, coordinates and line table this implementation adds
   return (size_t)map->info.num_voxels * (sizeof(int) + sizeof(float) * 3 + sizeof(float) * 9 + sizeof(gp::VoxelRecord) + sizeof(int) * 3) +
-         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + ((size_t)map->pmask + 1) * (sizeof(gp_voxel_bucket) + sizeof(gp::VoxelRecord));
+         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + ((size_t)map->plmask + 1) * 4 * sizeof(gp_voxel_bucket);
 }
 
 int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map) { return map && map->loaded() ? 1 : 0; }
@@ -592,8 +580,7 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   m->voxel_covs.release();
   m->voxel_intensities.release();
   m->voxel_coords.release();
-  m->pkeys.release();
-  m->pfat.release();
+  m->plines.release();
   m->offloaded = true;
   return GP_OK;
 }

@@ -250,14 +250,15 @@ int gp_gicp_factor_destroy(gp_gicp_factor_t* f);
 int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host);           /* update_correspondences + evaluate */
 int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host);
 
-/* tuning hook (not part of the reference API): selects the tile-kernel variant, see gp_vgicp.hip */
+/* tuning hook (not part of the reference API): tile-kernel variant.  0 = reference-shaped kernel, 1 = pipeline kernel in f64
+ * (default), 2 = pipeline kernel with f32 outer products; see gp_vgicp.hip */
 int gp_debug_set_variant(int variant);
-int gp_debug_set_stagger(int sleeps); /* experiment: phase-offset half of the workgroups */
-/* timeline hook: per-workgroup phase timestamps of the LDS-DMA tile kernel into dev_buffer ([num_tiles][8] uint64) */
+/* timeline hook: per-workgroup phase timestamps (s_memtime) of the pipeline kernel into dev_buffer ([num_tiles][8] uint64) */
 int gp_debug_set_trace_buffer(void* dev_buffer);
-/* profiling hook: streams 48*n bytes with the tile kernel's access pattern (calibrates rocprofv3 FETCH_SIZE) */
-/* profiling hook: time to just read the 48*n source bytes (mode 0 strided dwords, 1 coalesced float4, 2 LDS-DMA) */
+/* measurement hook (gp_microbench.hip): mode 0-2 time to just read the 48*n source bytes (strided dwords / float4 / LDS-DMA),
+ * 3-12 source + voxel-gather access patterns, 100-115 VALU issue rates; see scripts/stream_bench.py, scripts/alu_rate.py */
 int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n, int mode, int iters, float* ms);
+/* profiling hook: streams 48*n bytes with strided dword loads (calibrates the rocprofv3 FETCH_SIZE scale) */
 int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
 
 #ifdef __cplusplus

@@ -46,7 +46,7 @@ def run(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iter
     _capi.check(lib.gp_vgicp_batch_time_linearize(batch, poses.ctypes.data, iters, C.byref(a), C.byref(b), C.byref(c)), "time")
     npts = int(lib.gp_vgicp_batch_total_points(batch))
     alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
-    if os.environ.get("GP_TRACE_TILES"):  # tuning: per-workgroup s_memtime phases of the rolling-DMA kernel (variants >= 28)
+    if os.environ.get("GP_TRACE_TILES"):  # tuning: per-workgroup s_memtime phases of the rolling-DMA kernel (variants 1, 2)
         trace = torch.zeros((65536, 8), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         _capi.check(lib.gp_debug_set_trace_buffer(C.c_void_p(trace.data_ptr())), "trace")

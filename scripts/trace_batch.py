@@ -1,12 +1,12 @@
 """Timeline of the rolling-DMA tile kernel in the BATCHED regime (F factors over the same 1 M-point pair -> F x 977 tiles,
-several residency rounds): per-workgroup s_memtime stamps -> phase durations in ticks.  python scripts/trace_batch.py 29 4"""
+several residency rounds): per-workgroup s_memtime stamps -> phase durations in ticks.  python scripts/trace_batch.py 1 4"""
 import ctypes as C, os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gtsam_points_amd as gpa
 from gtsam_points_amd import _capi, synthetic
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 29
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 lib = gpa.load()
 d = synthetic.make_c2_workload()

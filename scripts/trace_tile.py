@@ -1,4 +1,5 @@
-"""Timeline of the LDS-DMA tile kernel: per-workgroup s_memtime stamps -> phase durations (tuning tool)."""
+"""Timeline of the pipeline tile kernel: per-workgroup s_memtime stamps -> phase durations (tuning tool).
+Only the per-workgroup DIFFERENCES are meaningful (every XCD has its own counter)."""
 import ctypes as C
 import os
 import sys
@@ -10,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gtsam_points_amd as gpa
 from gtsam_points_amd import _capi, synthetic
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lib = gpa.load()
 d = synthetic.make_c2_workload()
 delta = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
@@ -38,10 +39,8 @@ lib.gp_debug_set_trace_buffer(None)
 t = trace.cpu().numpy().astype(np.float64)
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
-rel = (t - t0) / 100.0  # s_memtime ticks at 100 MHz -> microseconds
-names = ["start", "dma_issued", "src_in_lds", "table_issued", "table_arrived", "math_done", "end"]
-if variant >= 28:
-    names = ["start", "chunk0_landed", "gather0_landed", "step0_done", "gather1_landed", "step1_done", "steps_done", "end"]
+rel = (t - t0) / 2100.0  # s_memtime counts shader clocks (~2.1 GHz under this load); counters of different XCDs are not synchronised
+names = ["start", "chunk0_landed", "keys0_landed", "step0_done", "keys1_landed", "step1_done", "steps_done", "end"]
 print("workgroups traced:", len(t))
 for k, n in enumerate(names):
     c = rel[:, k]

@@ -16,7 +16,7 @@ import oracle  # noqa: E402
 from gtsam_points_amd import _capi, synthetic  # noqa: E402
 
 lib = gpa.load()
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5".split(","))]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2".split(","))]
 BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
 
 
