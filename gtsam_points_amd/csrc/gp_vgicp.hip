@@ -16,6 +16,7 @@
 //   The workgroup -> tile map is XCD-aware: workgroup b runs on XCD b % 8, so XCD x is handed the x-th contiguous
 //   eighth of the tile list and the voxel tables of "its" factors stay in that XCD's 4 MiB L2.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "gp_host.hpp"
@@ -238,25 +239,25 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
   const int comp = threadIdx.x % STRIDE, slice = threadIdx.x / STRIDE;
   if (slice < kSlices) {
-    // fixed summation order (deterministic); 8 independent loads in flight per lane instead of a serial load->add chain
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    // fixed summation order (deterministic).  All of a lane's rows are requested in ONE batch of up to 32 independent loads
+    // (the rows were written by workgroups on other XCDs, so every load is an L2 miss: round trips, not bytes, set the time)
     const double* base = partials + (size_t)tile_begin * STRIDE + comp;
-    int t = slice;
-    for (; t + 7 * kSlices < tile_count; t += 8 * kSlices) {
-      const double v0 = base[(size_t)(t) * STRIDE], v1 = base[(size_t)(t + kSlices) * STRIDE], v2 = base[(size_t)(t + 2 * kSlices) * STRIDE],
-                   v3 = base[(size_t)(t + 3 * kSlices) * STRIDE], v4 = base[(size_t)(t + 4 * kSlices) * STRIDE], v5 = base[(size_t)(t + 5 * kSlices) * STRIDE],
-                   v6 = base[(size_t)(t + 6 * kSlices) * STRIDE], v7 = base[(size_t)(t + 7 * kSlices) * STRIDE];
-      s0 += v0;
-      s1 += v1;
-      s2 += v2;
-      s3 += v3;
-      s4 += v4;
-      s5 += v5;
-      s6 += v6;
-      s7 += v7;
+    double total = 0.0;
+    for (int t0 = slice; t0 < tile_count; t0 += 32 * kSlices) {
+      double v[32];
+#pragma unroll
+      for (int k = 0; k < 32; k++) {
+        const int t = t0 + k * kSlices;
+        v[k] = t < tile_count ? base[(size_t)t * STRIDE] : 0.0;
+      }
+#pragma unroll
+      for (int w = 16; w > 0; w >>= 1) {
+#pragma unroll
+        for (int k = 0; k < w; k++) v[k] += v[k + w];
+      }
+      total += v[0];
     }
-    for (; t < tile_count; t += kSlices) s0 += base[(size_t)t * STRIDE];
-    lds[slice][comp] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    lds[slice][comp] = total;
   }
   __syncthreads();
   if (threadIdx.x < STRIDE) {

@@ -11,7 +11,7 @@ import gtsam_points_amd as gpa
 from gtsam_points_amd import _capi
 
 lib = gpa.load()
-for n in [1048576]:
+for n in [1048576, 8388608]:
     p = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     c = torch.zeros((n, 9), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
