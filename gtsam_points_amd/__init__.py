@@ -19,7 +19,7 @@ from .factors import (  # noqa: F401
     pose_inverse,
 )
 from .features import IntegratedGICPFactorGPU, KdTreeGPU, estimate_covariances_gpu  # noqa: F401
-from .types import GaussianVoxelMapGPU, PointCloudGPU, overlap_gpu  # noqa: F401
+from .types import GaussianVoxelMapGPU, PointCloudGPU, merge_frames_gpu, overlap_gpu  # noqa: F401
 
 __all__ = [
     "GPError",
@@ -38,5 +38,6 @@ __all__ = [
     "TempBufferManager",
     "create_nonlinear_factor_set_gpu",
     "overlap_gpu",
+    "merge_frames_gpu",
     "load",
 ]

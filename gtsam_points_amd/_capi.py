@@ -65,6 +65,7 @@ _SIGNATURES = {
     "gp_free": (C.c_int, [C.c_void_p]),
     "gp_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gp_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gp_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gp_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "gp_host_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "gp_host_free": (C.c_int, [C.c_void_p]),
@@ -98,6 +99,15 @@ _SIGNATURES = {
     "gp_voxelmap_reload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_voxelmap_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     "gp_voxelmap_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]),
+    "gp_voxelmap_overlap_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "gp_voxelmap_overlap_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    # callers either side of the path: merge_frames_gpu, PointCloudGPU upload
+    "gp_transform_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_merge_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_double,
+                                  C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_cloud_upload_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gp_cloud_upload_mat3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     # factor
     "gp_vgicp_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_vgicp_factor_destroy": (C.c_int, [C.c_void_p]),

@@ -2,6 +2,8 @@
 #pragma once
 #include <gtsam_points_hip.h>
 
+#include <array>
+
 #include <cstdlib>
 #include <iostream>
 #include <memory>
@@ -142,6 +144,84 @@ inline double overlap_gpu(const GaussianVoxelMap::ConstPtr& target_, const Point
   int hits = 0;
   check_error << gp_voxelmap_overlap(target->handle(), source->points_gpu, static_cast<int>(source->size()), delta, &hits, nullptr);
   return source->size() ? static_cast<double>(hits) / source->size() : 0.0;
+}
+
+// overlap_gpu(targets, source, Ts_target_source): fraction of source points in a voxel of ANY target (:265-335);
+// deltas = column-major 4x4 doubles, one per target
+inline double overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& targets_, const PointCloud::ConstPtr& source, const std::vector<std::array<double, 16>>& deltas) {
+  if (!source->points_gpu) {
+    std::cerr << "error: GPU source points have not been allocated!!" << std::endl;  // :270-273
+    abort();
+  }
+  std::vector<const gp_voxelmap_t*> handles(targets_.size());
+  for (size_t i = 0; i < targets_.size(); i++) {
+    auto t = std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(targets_[i]);
+    if (!t) std::cerr << "error: Failed to cast target voxelmap to GaussianVoxelMapGPU!!" << std::endl;  // :278-280 (no abort upstream)
+    handles[i] = t ? t->handle() : nullptr;
+  }
+  int hits = 0;
+  check_error << gp_voxelmap_overlap_multi(handles.data(), deltas.empty() ? nullptr : deltas[0].data(), static_cast<int>(handles.size()), source->points_gpu,
+                                           static_cast<int>(source->size()), &hits, nullptr);
+  return source->size() ? static_cast<double>(hits) / source->size() : 0.0;
+}
+
+// overlap_gpu(targets, sources, Ts_target_source) -> one rate per pair (:337-404), ONE launch for all pairs
+inline std::vector<double> overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& targets_, const std::vector<PointCloud::ConstPtr>& sources,
+                                       const std::vector<std::array<double, 16>>& deltas) {
+  if (targets_.size() != sources.size()) {
+    std::cerr << "error: The number of target voxelmaps and source point clouds must be the same!!" << std::endl;  // :342-345
+    abort();
+  }
+  const size_t P = sources.size();
+  std::vector<const gp_voxelmap_t*> handles(P);
+  std::vector<const float*> pts(P);
+  std::vector<int> ns(P), hits(P, 0);
+  for (size_t i = 0; i < P; i++) {
+    auto t = std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(targets_[i]);
+    if (!t) std::cerr << "error: Failed to cast target voxelmap to GaussianVoxelMapGPU!!" << std::endl;
+    handles[i] = t ? t->handle() : nullptr;
+    pts[i] = sources[i]->points_gpu;
+    ns[i] = static_cast<int>(sources[i]->size());
+  }
+  if (P) check_error << gp_voxelmap_overlap_batch(handles.data(), pts.data(), ns.data(), deltas[0].data(), static_cast<int>(P), hits.data(), nullptr);
+  std::vector<double> rates(P);
+  for (size_t i = 0; i < P; i++) rates[i] = ns[i] ? static_cast<double>(hits[i]) / ns[i] : 0.0;
+  return rates;
+}
+
+// merge_frames_gpu(poses, frames, downsample_resolution) (:65-152): the merged cloud is the voxel arrays of the down-sampling
+// map, copied device to device into a new PointCloudGPU (the reference downloads them and uploads them again)
+inline PointCloud::Ptr merge_frames_gpu(const std::vector<std::array<double, 16>>& poses, const std::vector<PointCloud::ConstPtr>& frames, double downsample_resolution,
+                                        ihipStream_t* stream = nullptr) {
+  const size_t F = frames.size();
+  std::vector<const float*> pts(F), covs(F), ints(F);
+  std::vector<int> ns(F);
+  for (size_t i = 0; i < F; i++) {
+    pts[i] = frames[i]->points_gpu;
+    covs[i] = frames[i]->covs_gpu;
+    ints[i] = frames[i]->intensities_gpu;
+    ns[i] = static_cast<int>(frames[i]->size());
+  }
+  gp_voxelmap_t* map = nullptr;
+  check_error << gp_merge_frames(poses[0].data(), pts.data(), covs.data(), ints.data(), ns.data(), static_cast<int>(F), downsample_resolution, 1e-3, stream, &map);
+  auto merged = std::make_shared<PointCloudGPU>();
+  if (!map) return merged;
+  gp_voxelmap_info info;
+  gp_voxelmap_views views;
+  check_error << gp_voxelmap_info_get(map, &info);
+  check_error << gp_voxelmap_views_get(map, &views);
+  const size_t V = static_cast<size_t>(info.num_voxels);
+  void *p = nullptr, *c = nullptr, *it = nullptr;
+  check_error << gp_malloc(&p, 12 * V);
+  check_error << gp_malloc(&c, 36 * V);
+  check_error << gp_malloc(&it, 4 * V);
+  check_error << gp_memcpy_d2d(p, views.voxel_means, 12 * V, stream);
+  check_error << gp_memcpy_d2d(c, views.voxel_covs, 36 * V, stream);
+  check_error << gp_memcpy_d2d(it, views.voxel_intensities, 4 * V, stream);
+  check_error << gp_stream_synchronize(stream);
+  merged->adopt(static_cast<float*>(p), static_cast<float*>(c), static_cast<float*>(it), V);
+  check_error << gp_voxelmap_destroy(map);
+  return merged;
 }
 
 }  // namespace gtsam_points

@@ -25,7 +25,9 @@ struct PointCloud {
   float* intensities_gpu = nullptr;  // float[N]
 };
 
-// owning variant: host double/float D in {3,4} -> float3 / 3x3 float staging -> device (add_*_gpu, point_cloud_gpu.cu:110-201)
+// owning variant: the host arrays go up as they lie in memory (Eigen::Matrix<T, D, 1> / <T, D, D>, D in {3,4}) and a pack
+// kernel writes the float3 / 3x3 float device layout (gp_cloud_upload_*; add_*_gpu, point_cloud_gpu.cu:110-201 converts
+// element by element on the host)
 struct PointCloudGPU : public PointCloud {
   using Ptr = std::shared_ptr<PointCloudGPU>;
   ~PointCloudGPU() override {
@@ -38,41 +40,52 @@ struct PointCloudGPU : public PointCloud {
   template <typename T, int D>
   void add_points_gpu(const T* points, int n) {
     num_points = n;
-    upload3<T, D>(points, n, &points_gpu);
+    upload_packed<T, D>(points, n, 3, &points_gpu);
   }
   template <typename T, int D>
-  void add_normals_gpu(const T* normals, int n) { upload3<T, D>(normals, n, &normals_gpu); }
+  void add_normals_gpu(const T* normals, int n) { upload_packed<T, D>(normals, n, 3, &normals_gpu); }
   // covs: n matrices of D x D (column-major), D in {3,4}
   template <typename T, int D>
-  void add_covs_gpu(const T* covs, int n) {
-    std::vector<float> staging(9 * (size_t)n);
-    for (int i = 0; i < n; i++)
-      for (int c = 0; c < 3; c++)
-        for (int r = 0; r < 3; r++) staging[9 * (size_t)i + c * 3 + r] = static_cast<float>(covs[(size_t)i * D * D + c * D + r]);
-    upload(staging, &covs_gpu);
-  }
+  void add_covs_gpu(const T* covs, int n) { upload_packed<T, D>(covs, n, 9, &covs_gpu); }
   template <typename T>
   void add_intensities_gpu(const T* intensities, int n) {
     std::vector<float> staging(intensities, intensities + n);
-    upload(staging, &intensities_gpu);
+    replace(&intensities_gpu, sizeof(float) * staging.size());
+    check_error << gp_memcpy_h2d(intensities_gpu, staging.data(), sizeof(float) * staging.size(), nullptr);
+    check_error << gp_stream_synchronize(nullptr);  // stream sync per attribute, as the reference does
+  }
+  // adopt device arrays that are already in the reference layout (merge_frames_gpu hands its result over this way)
+  void adopt(float* points, float* covs, float* intensities, size_t n) {
+    replace(&points_gpu, 0);
+    replace(&covs_gpu, 0);
+    replace(&intensities_gpu, 0);
+    points_gpu = points;
+    covs_gpu = covs;
+    intensities_gpu = intensities;
+    num_points = n;
   }
 
 private:
-  template <typename T, int D>
-  void upload3(const T* src, int n, float** dst) {
-    std::vector<float> staging(3 * (size_t)n);
-    for (int i = 0; i < n; i++)
-      for (int k = 0; k < 3; k++) staging[3 * (size_t)i + k] = static_cast<float>(src[(size_t)i * D + k]);
-    upload(staging, dst);
-  }
-  void upload(const std::vector<float>& staging, float** dst) {
+  static_assert(sizeof(float) == 4, "device layout is IEEE binary32");
+  void replace(float** dst, size_t bytes) {
     check_error << gp_free(*dst);
     *dst = nullptr;
-    void* p = nullptr;
-    check_error << gp_malloc(&p, sizeof(float) * staging.size());
-    check_error << gp_memcpy_h2d(p, staging.data(), sizeof(float) * staging.size(), nullptr);
-    check_error << gp_stream_synchronize(nullptr);  // stream sync per attribute, as the reference does
-    *dst = static_cast<float*>(p);
+    if (bytes) {
+      void* p = nullptr;
+      check_error << gp_malloc(&p, bytes);
+      *dst = static_cast<float*>(p);
+    }
+  }
+  template <typename T, int D>
+  void upload_packed(const T* src, int n, int width, float** dst) {
+    static_assert(D == 3 || D == 4, "D in {3,4}");
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "float or double");
+    replace(dst, sizeof(float) * width * (size_t)n);
+    if (width == 9) {
+      check_error << gp_cloud_upload_mat3(src, sizeof(T) == 8, D, n, *dst, nullptr);
+    } else {
+      check_error << gp_cloud_upload_vec3(src, sizeof(T) == 8, D, n, *dst, nullptr);
+    }
   }
 };
 

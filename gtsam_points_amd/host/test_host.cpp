@@ -2,7 +2,9 @@
 // Mirrors the shape of src/test/test_matching_cost_factors.cpp: frames -> voxel maps -> IntegratedVGICPFactorGPU through a
 // StreamTempBufferRoundRobin -> LinearizationHook-driven Levenberg-Marquardt -> pose error gate.
 #include <cmath>
+#include <array>
 #include <cstdio>
+#include <cstring>
 #include <random>
 
 #include "nonlinear_factor_set_gpu.hpp"
@@ -97,6 +99,33 @@ int main() {
   auto loaded = GaussianVoxelMapGPU::load("/tmp/gp_host_voxels.bin");
   CHECK(loaded && loaded->voxelmap_info.num_voxels == voxels->voxelmap_info.num_voxels);
   CHECK(std::fabs(overlap_gpu(loaded, source, T_true.matrix().data()) - overlap_gpu(voxels, source, T_true.matrix().data())) < 1e-3);
+
+  // overload set of overlap_gpu + merge_frames_gpu (the callers that decide which submap pairs get factors)
+  {
+    std::array<double, 16> I16, T16;
+    std::memcpy(I16.data(), gtsam::Pose3().matrix().data(), sizeof(double) * 16);
+    std::memcpy(T16.data(), T_true.matrix().data(), sizeof(double) * 16);
+    const std::vector<GaussianVoxelMap::ConstPtr> two{voxels, loaded};
+    const double u = overlap_gpu(two, source, std::vector<std::array<double, 16>>{T16, T16});
+    CHECK(std::fabs(u - overlap_gpu(voxels, source, T16.data())) < 1e-12);  // the same map twice: union == single
+    const auto rates = overlap_gpu(two, std::vector<PointCloud::ConstPtr>{target, source}, std::vector<std::array<double, 16>>{I16, T16});
+    CHECK(rates.size() == 2 && rates[0] == self_overlap && std::fabs(rates[1] - u) < 1e-12);
+    // double 4-vector / 4x4 inputs go through the same pack kernels
+    std::vector<double> p4(4 * (size_t)N), c4(16 * (size_t)N, 0.0);
+    for (int i = 0; i < N; i++) {
+      for (int k = 0; k < 3; k++) p4[4 * (size_t)i + k] = sp[3 * (size_t)i + k];
+      p4[4 * (size_t)i + 3] = 1.0;
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) c4[16 * (size_t)i + 4 * c + r] = sc[9 * (size_t)i + 3 * c + r];
+    }
+    auto source4 = std::make_shared<PointCloudGPU>();
+    source4->add_points_gpu<double, 4>(p4.data(), N);
+    source4->add_covs_gpu<double, 4>(c4.data(), N);
+    CHECK(overlap_gpu(voxels, source4, T16.data()) == overlap_gpu(voxels, source, T16.data()));
+    auto merged = merge_frames_gpu({I16, T16}, std::vector<PointCloud::ConstPtr>{target, source4}, 0.25);
+    CHECK(merged->size() > 1000 && merged->size() < (size_t)(2 * N) && merged->points_gpu && merged->covs_gpu);
+    CHECK(overlap_gpu(voxels, merged, I16.data()) > 0.9);  // both frames land on the target's surfaces
+  }
 
   // factor through the round-robin pool + the linearisation hook, as the applications do
   LinearizationHook::register_hook([] { return create_nonlinear_factor_set_gpu(); });

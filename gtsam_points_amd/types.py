@@ -2,7 +2,8 @@
 
   PointCloudGPU        <- types/point_cloud_gpu.hpp  (device attribute arrays, float3 / 3x3 float layout)
   GaussianVoxelMapGPU  <- types/gaussian_voxelmap_gpu.hpp:38-114
-  overlap_gpu          <- types/gaussian_voxelmap_gpu_funcs.cu:192-236
+  overlap_gpu          <- types/gaussian_voxelmap_gpu_funcs.cu:192-406 (single, multi-target union, pairwise batch)
+  merge_frames_gpu     <- types/gaussian_voxelmap_gpu_funcs.cu:65-152
 
 torch is used only as the device allocator / stream provider (plumbing).
 """
@@ -55,30 +56,72 @@ class PointCloudGPU:
             t = torch.from_numpy(a).to(self.device)
         return t
 
+    def _pack_upload(self, a, matrix):
+        """Raw host array of D-vectors / DxD matrices (D in {3,4}, float32 or float64, in the memory layout the
+        reference's Eigen arrays have) -> float[N][3] / float[N][9] on the device; the conversion runs on the GPU
+        (gp_cloud_upload_vec3 / _mat3) instead of element-wise on the host (types/point_cloud_gpu.cu:26-62,110-201)."""
+        import torch
+
+        a = np.asarray(a)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        if matrix:
+            if a.ndim != 3 or a.shape[1] != a.shape[2] or a.shape[1] not in (3, 4):
+                raise ValueError("covariances must be (N,3,3) or (N,4,4)")
+            a = np.ascontiguousarray(a.transpose(0, 2, 1))  # Eigen is column-major
+        else:
+            if a.ndim != 2 or a.shape[1] not in (3, 4):
+                raise ValueError("expected (N,3) or (N,4)")
+            a = np.ascontiguousarray(a)
+        n, dim = a.shape[0], a.shape[1]
+        out = torch.empty((n, 9 if matrix else 3), dtype=torch.float32, device=self.device)
+        fn = self._lib().gp_cloud_upload_mat3 if matrix else self._lib().gp_cloud_upload_vec3
+        torch.cuda.current_stream(self.device).synchronize()
+        _capi.check(fn(a.ctypes.data, int(a.dtype == np.float64), dim, n, C.c_void_p(out.data_ptr()), None), "gp_cloud_upload")
+        return out
+
+    @staticmethod
+    def _lib():
+        return _capi.load()
+
+    @staticmethod
+    def _is_tensor(a):
+        import torch
+
+        return isinstance(a, torch.Tensor)  # (numpy >= 2 arrays also carry a .device attribute)
+
     def add_points(self, points):  # add_points_gpu, types/point_cloud_gpu.cu:110-140 (D in {3,4})
-        p = np.asarray(points) if not hasattr(points, "device") else points
-        if hasattr(p, "shape") and p.shape[-1] == 4:
-            p = p[:, :3]
-        self.points_gpu = self._upload(p, 3)
+        if self._is_tensor(points):
+            self.points_gpu = self._upload(points[:, :3], 3)
+        else:
+            self.points_gpu = self._pack_upload(points, matrix=False)
         self.num_points = int(self.points_gpu.shape[0])
 
-    def add_covs(self, covs):  # add_covs_gpu: (N,3,3) or (N,4,4) or (N,9)
-        c = covs
-        if not hasattr(c, "device"):
-            c = np.asarray(c)
-            if c.ndim == 3 and c.shape[1] == 4:
-                c = c[:, :3, :3]
-            if c.ndim == 3:
-                c = c.transpose(0, 2, 1)  # column-major storage
-            c = c.reshape(len(c), 9)
-        self.covs_gpu = self._upload(c, 9)
+    def add_covs(self, covs):  # add_covs_gpu: (N,3,3) or (N,4,4); (N,9) = already column-major rows
+        if self._is_tensor(covs):
+            self.covs_gpu = self._upload(covs, 9)
+            return
+        c = np.asarray(covs)
+        self.covs_gpu = self._upload(c, 9) if c.ndim == 2 else self._pack_upload(c, matrix=True)
 
     def add_normals(self, normals):
-        n = normals if hasattr(normals, "device") else np.asarray(normals)[:, :3]
-        self.normals_gpu = self._upload(n, 3)
+        if self._is_tensor(normals):
+            self.normals_gpu = self._upload(normals[:, :3], 3)
+        else:
+            self.normals_gpu = self._pack_upload(normals, matrix=False)
+
+    @staticmethod
+    def from_device(points_gpu, covs_gpu=None, intensities_gpu=None):
+        """Adopt float32 device tensors that are already in the reference layout."""
+        pc = PointCloudGPU(device=str(points_gpu.device))
+        pc.points_gpu = points_gpu
+        pc.covs_gpu = covs_gpu
+        pc.intensities_gpu = intensities_gpu
+        pc.num_points = int(points_gpu.shape[0])
+        return pc
 
     def add_intensities(self, intensities):
-        self.intensities_gpu = self._upload(np.asarray(intensities).reshape(-1, 1) if not hasattr(intensities, "device") else intensities, 1)
+        self.intensities_gpu = self._upload(intensities if self._is_tensor(intensities) else np.asarray(intensities).reshape(-1, 1), 1)
 
     def size(self):
         return self.num_points
@@ -204,7 +247,90 @@ class GaussianVoxelMapGPU:
         return out.cpu().numpy()
 
 
-def overlap_gpu(target: GaussianVoxelMapGPU, source: PointCloudGPU, delta=np.eye(4)):
+def _poses_flat(poses):
+    return np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T.reshape(16) for T in poses]))
+
+
+def overlap_gpu(target, source, delta=None):
+    """The reference's overlap_gpu overload set (types/gaussian_voxelmap.hpp:72-140):
+      overlap_gpu(target, source, T_target_source)                      -> fraction of source points in a target voxel
+      overlap_gpu([targets], source, [Ts_target_source])                -> fraction in a voxel of ANY target
+      overlap_gpu([targets], [sources], [Ts_target_source])             -> list of per-pair fractions (one launch)
+    """
+    if isinstance(target, (list, tuple)):
+        targets = list(target)
+        lib = _capi.load()
+        handles = (C.c_void_p * len(targets))(*[t._h.value for t in targets])
+        if isinstance(source, (list, tuple)):
+            sources = list(source)
+            if len(sources) != len(targets):
+                raise _capi.GPError("error: The number of target voxelmaps and source point clouds must be the same!!")  # :342-345
+            if not sources:
+                return []
+            for src in sources:
+                if src.points_gpu is None:
+                    raise _capi.GPError("error: GPU source points have not been allocated!!")
+                GaussianVoxelMapGPU._sync_torch(src)
+            deltas = _poses_flat(delta)
+            pts = (C.c_void_p * len(sources))(*[src.points_gpu.data_ptr() for src in sources])
+            ns = (C.c_int * len(sources))(*[src.size() for src in sources])
+            hits = (C.c_int * len(sources))()
+            _capi.check(lib.gp_voxelmap_overlap_batch(handles, pts, ns, deltas.ctypes.data, len(sources), hits, targets[0].stream), "gp_voxelmap_overlap_batch")
+            return [hits[i] / float(sources[i].size()) if sources[i].size() else 0.0 for i in range(len(sources))]
+        if source.points_gpu is None:
+            raise _capi.GPError("error: GPU source points have not been allocated!!")
+        GaussianVoxelMapGPU._sync_torch(source)
+        deltas = _poses_flat(delta) if targets else np.zeros((0, 16))
+        hits = C.c_int(0)
+        _capi.check(
+            lib.gp_voxelmap_overlap_multi(handles, deltas.ctypes.data, len(targets), source.ptr(source.points_gpu), source.size(), C.byref(hits),
+                                          targets[0].stream if targets else None),
+            "gp_voxelmap_overlap_multi",
+        )
+        return hits.value / float(source.size()) if source.size() else 0.0
+    return _overlap_single(target, source, np.eye(4) if delta is None else delta)
+
+
+def merge_frames_gpu(poses, frames, downsample_resolution, stream=None, target_points_drop_rate=1e-3):
+    """merge_frames_gpu(poses, frames, downsample_resolution) (types/gaussian_voxelmap_gpu_funcs.cu:65-152): every frame is
+    transformed by its pose, all points go through a Gaussian voxel map at the down-sampling resolution, and the voxel
+    means / mean covariances / max intensities become the merged PointCloudGPU (device to device)."""
+    import torch
+
+    frames = list(frames)
+    if len(frames) != len(poses) or not frames:
+        raise ValueError("merge_frames_gpu: one pose per frame, at least one frame")
+    for f in frames:
+        if f.points_gpu is None or f.covs_gpu is None:
+            raise _capi.GPError("error: GPU points/covs not allocated!!")
+        GaussianVoxelMapGPU._sync_torch(f)
+    lib = _capi.load()
+    F = len(frames)
+    pts = (C.c_void_p * F)(*[f.points_gpu.data_ptr() for f in frames])
+    covs = (C.c_void_p * F)(*[f.covs_gpu.data_ptr() for f in frames])
+    ints = (C.c_void_p * F)(*[(f.intensities_gpu.data_ptr() if f.intensities_gpu is not None else None) for f in frames])
+    ns = (C.c_int * F)(*[f.size() for f in frames])
+    flat = _poses_flat(poses)
+    h = C.c_void_p()
+    _capi.check(lib.gp_merge_frames(flat.ctypes.data, pts, covs, ints, ns, F, float(downsample_resolution), float(target_points_drop_rate), stream, C.byref(h)),
+                "gp_merge_frames")
+    vm = GaussianVoxelMapGPU(downsample_resolution, _handle=h, stream=stream)
+    V = vm.voxelmap_info.num_voxels
+    views = vm.views()
+    dev = frames[0].device
+    out_p = torch.empty((V, 3), dtype=torch.float32, device=dev)
+    out_c = torch.empty((V, 9), dtype=torch.float32, device=dev)
+    out_i = torch.empty((V, 1), dtype=torch.float32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    _capi.check(lib.gp_memcpy_d2d(C.c_void_p(out_p.data_ptr()), views.voxel_means, 12 * V, stream), "gp_memcpy_d2d")
+    _capi.check(lib.gp_memcpy_d2d(C.c_void_p(out_c.data_ptr()), views.voxel_covs, 36 * V, stream), "gp_memcpy_d2d")
+    _capi.check(lib.gp_memcpy_d2d(C.c_void_p(out_i.data_ptr()), views.voxel_intensities, 4 * V, stream), "gp_memcpy_d2d")
+    _capi.check(lib.gp_stream_synchronize(stream), "gp_stream_synchronize")
+    return PointCloudGPU.from_device(out_p, out_c, out_i)
+
+
+def _overlap_single(target: GaussianVoxelMapGPU, source: PointCloudGPU, delta=np.eye(4)):
+
     """overlap_gpu(target, source, delta): fraction of source points that fall in a target voxel
     (types/gaussian_voxelmap_gpu_funcs.cu:192-236)."""
     if source.points_gpu is None:

@@ -57,6 +57,7 @@ int gp_malloc(void** ptr, size_t bytes);                        /* cuda/cuda_mal
 int gp_free(void* ptr);
 int gp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, gp_stream_t stream); /* async; caller syncs */
 int gp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, gp_stream_t stream); /* async; caller syncs */
+int gp_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, gp_stream_t stream);  /* async; caller syncs */
 int gp_memset(void* dst_dev, int value, size_t bytes, gp_stream_t stream);
 int gp_host_malloc(void** ptr, size_t bytes);                   /* pinned staging, cuda/cuda_buffer.cu */
 int gp_host_free(void* ptr);
@@ -142,6 +143,33 @@ int gp_voxelmap_lookup(const gp_voxelmap_t* map, const float* points_dev, const 
 /* overlap_gpu(target, source, delta): number of source points that hit a voxel,
  * types/gaussian_voxelmap_gpu_funcs.cu:192-236.  Synchronous. */
 int gp_voxelmap_overlap(const gp_voxelmap_t* map, const float* points_dev, int num_points, const double delta[16], int* num_hits, gp_stream_t stream);
+/* overlap_gpu(targets, source, Ts_target_source): number of source points that fall in a voxel of ANY target
+ * (deltas = [num_targets][16] column-major doubles), types/gaussian_voxelmap_gpu_funcs.cu:265-335.  Synchronous. */
+int gp_voxelmap_overlap_multi(const gp_voxelmap_t* const* targets, const double* deltas, int num_targets, const float* points_dev, int num_points, int* num_hits,
+                              gp_stream_t stream);
+/* overlap_gpu(targets, sources, Ts_target_source) -> one count per (target[i], source[i]) pair, one launch for all pairs,
+ * types/gaussian_voxelmap_gpu_funcs.cu:337-404.  Synchronous. */
+int gp_voxelmap_overlap_batch(const gp_voxelmap_t* const* targets, const float* const* points_dev, const int* num_points, const double* deltas, int num_pairs,
+                              int* num_hits, gp_stream_t stream);
+
+/* ---- merge_frames_gpu : types/gaussian_voxelmap_gpu_funcs.cu:65-152 ----
+ * gp_transform_frames: out[begin_i + j] = pose_i * frame_i[j] for all frames in one launch (transform_means_kernel /
+ * transform_covs_kernel, :42-62; f64 arithmetic on the f32 inputs).  out_covs_dev / out_intensities_dev may be NULL;
+ * a NULL intensities entry yields zeros (:103-107).  Synchronous.
+ * gp_merge_frames: the transform followed by the Gaussian voxel-map build at downsample_resolution (:122-123, the
+ * reference hard-codes init_num_buckets = total points, scan count 10, drop rate 1e-3); the merged cloud is the returned
+ * map's voxel_means / voxel_covs / voxel_intensities views (caller owns the map). */
+int gp_transform_frames(const double* poses, const float* const* points_dev, const float* const* covs_dev, const float* const* intensities_dev, const int* num_points,
+                        int num_frames, float* out_points_dev, float* out_covs_dev, float* out_intensities_dev, gp_stream_t stream);
+int gp_merge_frames(const double* poses, const float* const* points_dev, const float* const* covs_dev, const float* const* intensities_dev, const int* num_points,
+                    int num_frames, double downsample_resolution, double target_points_drop_rate, gp_stream_t stream, gp_voxelmap_t** out_map);
+
+/* ---- PointCloudGPU::add_points_gpu / add_normals_gpu / add_covs_gpu : types/point_cloud_gpu.cu:26-62,110-201 ----
+ * src_host: num_points vectors (vec3) or column-major matrices (mat3) of dimension src_dim in {3,4}, double or float,
+ * exactly as the reference's Eigen::Matrix<T, D, 1> / <T, D, D> arrays lie in memory; dst_dev: float[N][3] / float[N][9].
+ * The conversion runs on the device (the reference converts element-wise on the host).  Synchronous. */
+int gp_cloud_upload_vec3(const void* src_host, int src_is_double, int src_dim, int num_points, float* dst_dev, gp_stream_t stream);
+int gp_cloud_upload_mat3(const void* src_host, int src_is_double, int src_dim, int num_points, float* dst_dev, gp_stream_t stream);
 
 /* ---- LinearizedSystem6 : cuda/kernels/linearized_system.cuh:10-71 ----
  * Same fields, double precision, no Eigen alignment padding; num_inliers is carried as a double so

@@ -14,4 +14,5 @@ from .capi import (  # noqa: F401
     estimate_covariances,
     expmap,
     max_threads,
+    merge_frames,
 )

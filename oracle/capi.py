@@ -213,6 +213,26 @@ class OracleVoxelMap:
         return float(_lib().orc_voxelmap_overlap(self._h, _fp(p), len(p), _dp(d)))
 
 
+def merge_frames(poses, frames, downsample_resolution):
+    """CPU statement of merge_frames_gpu (types/gaussian_voxelmap_gpu_funcs.cu:65-152): every frame (points (N,3) f32,
+    covs (N,3,3) f32, optional intensities) is transformed by its pose -- p' = R p + t (:42-50), C' = R C R^T (:52-62),
+    results stored as f32 like the reference's device arrays (f64 arithmetic here, so that the only rounding is the
+    final store) -- then all points go through a Gaussian voxel map at the down-sampling resolution (:122-123) whose voxel
+    means / mean covariances / max intensities are the merged cloud (:125-149).
+    Returns (coords (V,3) int, means (V,3) f64, covs (V,3,3) f64, intensities (V,))."""
+    pts, covs, ints = [], [], []
+    for T, (p, c, it) in zip(poses, frames):
+        T = np.asarray(T, dtype=np.float64)
+        R, t = T[:3, :3], T[:3, 3]
+        pts.append((np.asarray(p, dtype=np.float64) @ R.T + t).astype(np.float32))
+        covs.append(np.einsum("ij,njk,lk->nil", R, np.asarray(c, dtype=np.float64), R).astype(np.float32))
+        ints.append(np.zeros(len(p), dtype=np.float32) if it is None else np.asarray(it, dtype=np.float32))  # :103-107
+    m = OracleVoxelMap(downsample_resolution)
+    m.insert(np.concatenate(pts), np.concatenate(covs), np.concatenate(ints))
+    coords, _, means, mcovs, intens = m.export()
+    return coords, means, mcovs, intens
+
+
 class OracleVGICPFactor:
     """IntegratedVGICPFactor (CPU) restatement; delta = T_target^-1 T_source is passed directly."""
 
