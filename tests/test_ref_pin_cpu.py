@@ -55,3 +55,56 @@ def test_reference_code_threads_and_synthetic(kitti00):
     assert om.num_voxels == rm.num_voxels
     delta = d["T_true"] @ expmap([0.002, -0.001, 0.0015, 0.02, -0.01, 0.015])
     assert_linearized_close(fo.linearize(delta), fr.linearize(delta), 1e-11, "synthetic, 4 threads")
+
+
+# ---- config 5: kd-tree k-NN, covariance estimation, GICP (the reference's ann/kdtree.cpp + small_kdtree.hpp + knn_result.hpp,
+# features/covariance_estimation.cpp, factors/impl/integrated_gicp_factor_impl.hpp compiled where they lie) ----
+
+
+def test_knn_equals_reference_kdtree(kitti00):
+    """exact k-NN: same neighbour sets and squared distances as the reference's KdTree (test_kdtree.cpp:139-140 uses 1e-6);
+    equal-distance neighbours may be listed in a different order, so indices are compared as sets per distance"""
+    pts = kitti00["target_points"]
+    q = np.concatenate([pts[::37], kitti00["source_points"][::53] + np.float32(0.01)])
+    oi, od = oracle.OracleKdTree(pts).knn(q, 10)
+    ri, rd, found = refcapi.RefKdTree(pts).knn(q, 10)
+    assert (found == 10).all()
+    assert np.abs(od - rd).max() <= 1e-12
+    same = (oi == ri).all(axis=1)
+    for row in np.nonzero(~same)[0]:  # rows that differ may only differ by ties
+        assert sorted(oi[row].tolist()) == sorted(ri[row].tolist()) or np.unique(od[row]).size < 10
+    assert same.mean() > 0.99
+    # bounded search (the GICP correspondence rule: max_correspondence_distance_sq)
+    oi1, od1 = oracle.OracleKdTree(pts).knn(q, 1, max_sq_dist=0.01)
+    ri1, rd1, f1 = refcapi.RefKdTree(pts).knn(q, 1, max_sq_dist=0.01)
+    hit = f1 == 1
+    assert ((oi1[:, 0] >= 0) == hit).all()
+    np.testing.assert_array_equal(oi1[hit, 0], ri1[hit, 0])
+
+
+def test_covariances_equal_reference_code(kitti00):
+    """estimate_covariances(k=10): the oracle (restating Eigen's closed-form computeDirect) against the reference's own
+    covariance_estimation.cpp running on an independent Jacobi eigen-solver: identical up to the solvers' accuracy, except
+    where the two smallest eigenvalues (nearly) coincide and the regularised normal direction is arbitrary"""
+    pts = kitti00["target_points"][:6000]
+    oc, short = oracle.estimate_covariances(pts, 10, 1)
+    rc = refcapi.ref_estimate_covariances(pts, 10, 1)
+    assert short == 0
+    err = np.linalg.norm((oc - rc).reshape(len(pts), 9), axis=1) / np.linalg.norm(rc.reshape(len(pts), 9), axis=1)
+    assert np.median(err) < 1e-9
+    assert (err < 1e-5).mean() > 0.995, (err < 1e-5).mean()
+    # multi-threaded build + search gives the same answer (schedule(guided, 8), covariance_estimation.cpp:58-62)
+    np.testing.assert_array_equal(refcapi.ref_estimate_covariances(pts, 10, 4), rc)
+
+
+def test_gicp_oracle_equals_reference_code(kitti00):
+    d = kitti00
+    for xi, thr in [(np.zeros(6), 1), ([0.01, -0.02, 0.015, 0.10, -0.05, 0.03], 1), ([0.05, 0.04, -0.06, -0.5, 0.3, 0.2], 4)]:
+        delta = expmap(xi)
+        fo = oracle.OracleGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], thr)
+        fr = refcapi.RefGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], thr)
+        assert_linearized_close(fo.linearize(delta), fr.linearize(delta), 1e-11, f"gicp xi {xi}")
+    # a tighter correspondence gate (strict '<' against max_correspondence_distance_sq, integrated_gicp_factor_impl.hpp:168-169)
+    fo = oracle.OracleGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], 1, 0.04)
+    fr = refcapi.RefGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], 1, 0.04)
+    assert_linearized_close(fo.linearize(expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])), fr.linearize(expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])), 1e-11, "gicp gate")
