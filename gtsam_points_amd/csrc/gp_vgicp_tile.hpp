@@ -362,28 +362,54 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline_kernel(const FactorDesc
   }
 
   GP_TRACE(6);
-  // ---- reduction: butterfly within the wave, then across the 4 waves through LDS (the ring is drained) ----
-  double accd[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) accd[k] = (double)acc[k];
-  __syncthreads();
-  double(*lds)[ACC_STRIDE] = reinterpret_cast<double(*)[ACC_STRIDE]>(smem);
+  // ---- reduction.  The wave's ring (3 x 3 KB, drained) becomes a transposition buffer: 16 components x 64 lanes of f64
+  // at a row stride of 68 doubles (conflicts <= 2-way) are written lane-major and read back so that every lane sums 16
+  // values of one component, the 4 lanes of a quad are combined with two DPP swaps, and lane 4c holds component c.
+  // Two passes (components 0-15, 16-31) ~ 300 issue cycles per wave instead of ~1000 for a 64-lane f64 butterfly.
+  // The 4-wave sum goes through the last 256 B of each wave's own region; one 32-double partial per tile. ----
+  constexpr int kRowStride = 68;
+  static_assert(16 * kRowStride * 8 + 32 * 8 <= STAGES * kChunkBytes, "transposition buffer + wave sums must fit the wave's ring");
+  double* wtrans = reinterpret_cast<double*>(wbase);
+  double* wsums = reinterpret_cast<double*>(wbase + STAGES * kChunkBytes - 32 * 8);
   if constexpr (MODE == MODE_ERR) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      double v = accd[k];
+      double v = (double)acc[k];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) lds[wave][k] = v;
+      if (lane == 0) wsums[k] = v;
     }
   } else {
-    const double sum = butterfly_reduce32(accd, lane);
-    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = sum;
+    const int comp = lane >> 2, part = lane & 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) wtrans[k * kRowStride + lane] = (double)acc[pass * 16 + k];
+      // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait between the writes and the reads
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        s0 += wtrans[comp * kRowStride + 4 * i + part];
+        s1 += wtrans[comp * kRowStride + 4 * (i + 1) + part];
+        s2 += wtrans[comp * kRowStride + 4 * (i + 2) + part];
+        s3 += wtrans[comp * kRowStride + 4 * (i + 3) + part];
+      }
+      double v = (s0 + s1) + (s2 + s3);
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      if (part == 0) wsums[pass * 16 + comp] = v;
+    }
   }
   __syncthreads();
   if (threadIdx.x < ACC_STRIDE) {
     double sum = 0.0;
-    if (threadIdx.x < NACC) sum = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    if (threadIdx.x < NACC) {
+      const double* w0 = reinterpret_cast<const double*>(smem + 1 * STAGES * kChunkBytes - 32 * 8);
+      const double* w1 = reinterpret_cast<const double*>(smem + 2 * STAGES * kChunkBytes - 32 * 8);
+      const double* w2 = reinterpret_cast<const double*>(smem + 3 * STAGES * kChunkBytes - 32 * 8);
+      const double* w3 = reinterpret_cast<const double*>(smem + 4 * STAGES * kChunkBytes - 32 * 8);
+      sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
+    }
     ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = sum;
   }
   GP_TRACE(7);

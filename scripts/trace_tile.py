@@ -48,5 +48,13 @@ for k, n in enumerate(names):
 dur = np.diff(rel[:, :len(names)], axis=1)
 for k in range(len(names) - 1):
     print(f"phase {names[k]:>13s} -> {names[k+1]:13s}: median {np.median(dur[:,k]):6.2f}  p90 {np.percentile(dur[:,k],90):6.2f} us")
-starts = np.sort(rel[:, 0])
-print("block start times: first 5", starts[:5], " #started after 3us:", (starts > 3).sum())
+# dispatch skew per clock domain: s_memtime counters are not synchronised across the chip, so workgroups are clustered by
+# their start stamp (gaps > 50 us separate domains) and skew / lifetime are taken inside each cluster
+raw = trace.cpu().numpy().astype(np.float64)
+raw = raw[raw[:, 0] > 0]
+raw = raw[np.argsort(raw[:, 0])]
+cuts = np.nonzero(np.diff(raw[:, 0]) > 50 * 2100)[0] + 1
+for k, r in enumerate(np.split(raw, cuts)):
+    s0 = r[:, 0].min()
+    print(f"clock domain {k}: {len(r):4d} workgroups, start skew {(r[:,0].max()-s0)/2100:5.2f} us, last end {(r[:,7].max()-s0)/2100:5.2f} us, "
+          f"median lifetime {np.median(r[:,7]-r[:,0])/2100:5.2f} us")
