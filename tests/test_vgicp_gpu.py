@@ -95,6 +95,30 @@ def test_ragged_sizes(gpu, kitti00, n):
         assert_linearized_close(L, Lo, PARITY_TOL, f"n={n}")
 
 
+def test_unaligned_source_views(gpu, kitti00):
+    """device arrays that start 12 / 36 bytes into an allocation (a sub-cloud view): the pipeline kernel's 16-B DMA ring
+    does not apply and the per-lane load path must give the same answer"""
+    import torch
+
+    n = 4200  # several full tiles + a partial one
+    d = dict(kitti00)
+    d["source_points"] = kitti00["source_points"][1 : n + 1]
+    d["source_covs"] = kitti00["source_covs"][1 : n + 1]
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    _, _, vm = _build(gpu, d, 0.5)
+    whole = gpu.PointCloudGPU(kitti00["source_points"][: n + 1], kitti00["source_covs"][: n + 1])
+    view = gpu.PointCloudGPU.from_device(whole.points_gpu[1:], whole.covs_gpu[1:])
+    assert view.points_gpu.data_ptr() % 16 != 0 and view.points_gpu.is_contiguous()
+    L = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, view), delta)
+    _, fo = _oracle(d, 0.5, 1)
+    assert_linearized_close(L, fo.linearize(delta), PARITY_TOL, "unaligned view")
+    aligned = gpu.PointCloudGPU(d["source_points"], d["source_covs"])
+    La = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, aligned), delta)
+    assert L.num_inliers == La.num_inliers
+    assert_linearized_close(L, La, 1e-13, "unaligned vs aligned path")  # two instantiations of the same algebra: last-bit differences only
+    del torch
+
+
 def test_factor_set_batch_equals_per_factor_and_oracle(gpu, kitti07):
     """NonlinearFactorSetGPU fast path (one batched launch) == per-factor sync path == oracle; error() after linearize()"""
     poses = kitti07["poses"]
