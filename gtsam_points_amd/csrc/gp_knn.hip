@@ -57,11 +57,28 @@ __device__ __forceinline__ int grid_find(const GridView& g, unsigned long long k
 
 // ---- grid build -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) grid_insert_kernel(const float* __restrict__ points, int n, double inv_h, unsigned long long* __restrict__ keys,
-                                                          int* __restrict__ counts, int* __restrict__ point_slot, uint32_t mask) {
+                                                          int* __restrict__ counts, int* __restrict__ point_slot, uint32_t mask, int* __restrict__ bbox) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const int j = i < n ? i : n - 1;  // the tail lanes repeat the last point so that the wave-wide min/max below needs no masking
+  const int cx = fast_floor((double)points[3 * (size_t)j] * inv_h), cy = fast_floor((double)points[3 * (size_t)j + 1] * inv_h),
+            cz = fast_floor((double)points[3 * (size_t)j + 2] * inv_h);
+  // bounding box of the occupied cells (bounds every query's cube radius): wave min/max, then 6 atomics per wave
+  int lo[3] = {cx, cy, cz}, hi[3] = {cx, cy, cz};
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(bbox + a, lo[a]);
+      atomicMax(bbox + 3 + a, hi[a]);
+    }
+  }
   if (i >= n) return;
-  const int cx = fast_floor((double)points[3 * (size_t)i] * inv_h), cy = fast_floor((double)points[3 * (size_t)i + 1] * inv_h),
-            cz = fast_floor((double)points[3 * (size_t)i + 2] * inv_h);
   const unsigned long long key = pack_cell(cx, cy, cz);
   uint32_t s = hash_key(key) & mask;
   for (;;) {
@@ -361,9 +378,13 @@ __device__ __forceinline__ void inverse3_general(const double* a /*col-major*/, 
 template <int KMAX>
 __global__ void __launch_bounds__(128) covariance_kernel(MultiGridView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
                                                          int* __restrict__ num_short) {
-  const int i = blockIdx.x * 128 + threadIdx.x;
-  if (i >= n) return;
-  const double qx = (double)points[3 * (size_t)i], qy = (double)points[3 * (size_t)i + 1], qz = (double)points[3 * (size_t)i + 2];
+  const int t = blockIdx.x * 128 + threadIdx.x;
+  if (t >= n) return;
+  // queries are taken in the finest grid's cell-sorted order: the lanes of a wave then sit in the same or adjacent cells,
+  // walk the same shells and read the same cell ranges (coherent loads, little divergence); results go to the original index
+  const float4 self = g.lv[0].sorted[t];
+  const int i = __float_as_int(self.w);
+  const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
   TopK<KMAX> top;
   top.init(k, 1.7976931348623157e308);
   knn_query_multi<KMAX>(g, qx, qy, qz, 2 * k, top);
@@ -468,16 +489,17 @@ __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double
 // ---------------------------------------------------------------------------------------------------------------
 
 struct gp_grid_level {
-  gp::DeviceArray keys, start, sorted;
+  gp::DeviceArray arena;  // one allocation: keys | start | sorted (device allocations cost far more than the build kernels)
+  void *keys_p = nullptr, *start_p = nullptr, *sorted_p = nullptr;
   uint32_t mask = 0;
   int n = 0;
   double h = 0.0;
   int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   gp::GridView view() const {
     gp::GridView g;
-    g.keys = keys.as<unsigned long long>();
-    g.start = start.as<int>();
-    g.sorted = sorted.as<float4>();
+    g.keys = static_cast<const unsigned long long*>(keys_p);
+    g.start = static_cast<const int*>(start_p);
+    g.sorted = static_cast<const float4*>(sorted_p);
     g.mask = mask;
     g.n = n;
     g.h = h;
@@ -514,53 +536,73 @@ struct gp_gicp_factor {
 
 extern "C" {
 
-static int build_level(const float* points_dev, int n, double cell_size, hipStream_t s, gp_grid_level** out) {
+static inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+static uint32_t level_slots(int n) {
+  uint32_t slots = 1024;
+  while (slots < 2u * (uint32_t)std::max(n, 1)) slots <<= 1;  // at most n distinct cells -> load factor <= 0.5
+  return slots;
+}
+
+// scratch of one level build (counts | cursor | point_slot | block_sums | total | bbox), reused by every level of a grid
+static size_t level_scratch_bytes(int n) {
+  const uint32_t slots = level_slots(n);
+  const size_t nb = (slots + gp::kScanBlock - 1) / gp::kScanBlock;
+  return 2 * align256(sizeof(int) * slots) + align256(sizeof(int) * (size_t)std::max(n, 1)) + align256(sizeof(int) * nb) + 2 * align256(64);
+}
+
+static int build_level(const float* points_dev, int n, double cell_size, hipStream_t s, char* scratch, gp_grid_level** out) {
   auto* g = new gp_grid_level;
   g->n = n;
   g->h = cell_size;
-  uint32_t slots = 1024;
-  while (slots < 2u * (uint32_t)std::max(n, 1)) slots <<= 1;  // at most n distinct cells -> load factor <= 0.5
+  const uint32_t slots = level_slots(n);
   g->mask = slots - 1;
-  gp::DeviceArray counts, point_slot, block_sums, total, cursor;
   const int nb = (int)((slots + gp::kScanBlock - 1) / gp::kScanBlock);
-  int rc = GP_OK;
-  if ((rc = g->keys.alloc(sizeof(unsigned long long) * slots)) || (rc = g->start.alloc(sizeof(int) * ((size_t)slots + 1))) ||
-      (rc = g->sorted.alloc(sizeof(float4) * (size_t)std::max(n, 1))) || (rc = counts.alloc(sizeof(int) * slots)) || (rc = cursor.alloc(sizeof(int) * slots)) ||
-      (rc = point_slot.alloc(sizeof(int) * (size_t)std::max(n, 1))) || (rc = block_sums.alloc(sizeof(int) * (size_t)nb)) || (rc = total.alloc(sizeof(int)))) {
+  const size_t keys_b = align256(sizeof(unsigned long long) * slots), start_b = align256(sizeof(int) * ((size_t)slots + 1)),
+               sorted_b = align256(sizeof(float4) * (size_t)std::max(n, 1));
+  const int rc = g->arena.alloc(keys_b + start_b + sorted_b);
+  if (rc != GP_OK) {
     delete g;
     return rc;
   }
-  GP_HIP(hipMemsetAsync(g->keys.ptr, 0xff, sizeof(unsigned long long) * slots, s));
-  GP_HIP(hipMemsetAsync(counts.ptr, 0, sizeof(int) * slots, s));
-  GP_HIP(hipMemsetAsync(cursor.ptr, 0, sizeof(int) * slots, s));
+  g->keys_p = g->arena.as<char>();
+  g->start_p = g->arena.as<char>() + keys_b;
+  g->sorted_p = g->arena.as<char>() + keys_b + start_b;
+  unsigned long long* keys = static_cast<unsigned long long*>(g->keys_p);
+  int* start = static_cast<int*>(g->start_p);
+  float4* sorted = static_cast<float4*>(g->sorted_p);
+  char* cur = scratch;
+  int* counts = reinterpret_cast<int*>(cur);
+  cur += align256(sizeof(int) * slots);
+  int* cursor = reinterpret_cast<int*>(cur);
+  cur += align256(sizeof(int) * slots);
+  int* point_slot = reinterpret_cast<int*>(cur);
+  cur += align256(sizeof(int) * (size_t)std::max(n, 1));
+  int* block_sums = reinterpret_cast<int*>(cur);
+  cur += align256(sizeof(int) * (size_t)nb);
+  int* total = reinterpret_cast<int*>(cur);
+  cur += align256(64);
+  int* bbox = reinterpret_cast<int*>(cur);
+  GP_HIP(hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * slots, s));
+  GP_HIP(hipMemsetAsync(counts, 0, 2 * align256(sizeof(int) * slots), s));  // counts and cursor are adjacent
+  int h_bbox[6] = {1 << 30, 1 << 30, 1 << 30, -(1 << 30), -(1 << 30), -(1 << 30)};
+  GP_HIP(hipMemcpyAsync(bbox, h_bbox, sizeof(h_bbox), hipMemcpyHostToDevice, s));
   if (n > 0) {
-    hipLaunchKernelGGL(gp::grid_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, 1.0 / cell_size, g->keys.as<unsigned long long>(), counts.as<int>(),
-                       point_slot.as<int>(), g->mask);
+    hipLaunchKernelGGL(gp::grid_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, 1.0 / cell_size, keys, counts, point_slot, g->mask, bbox);
   }
-  hipLaunchKernelGGL(gp::scan_block_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, counts.as<int>(), g->start.as<int>(), block_sums.as<int>(), (int)slots);
-  hipLaunchKernelGGL(gp::scan_sums_kernel, dim3(1), dim3(gp::kScanBlock), 0, s, block_sums.as<int>(), nb, total.as<int>());
-  hipLaunchKernelGGL(gp::scan_add_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, g->start.as<int>(), block_sums.as<int>(), (int)slots, total.as<int>());
+  hipLaunchKernelGGL(gp::scan_block_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, counts, start, block_sums, (int)slots);
+  hipLaunchKernelGGL(gp::scan_sums_kernel, dim3(1), dim3(gp::kScanBlock), 0, s, block_sums, nb, total);
+  hipLaunchKernelGGL(gp::scan_add_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, start, block_sums, (int)slots, total);
   if (n > 0) {
-    hipLaunchKernelGGL(gp::grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, point_slot.as<int>(), g->start.as<int>(), cursor.as<int>(),
-                       g->sorted.as<float4>());
+    hipLaunchKernelGGL(gp::grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, point_slot, start, cursor, sorted);
   }
   GP_HIP(hipGetLastError());
-  GP_HIP(hipStreamSynchronize(s));
-  if (n > 0) {  // bounding box of the occupied cells (bounds every query's cube radius)
-    std::vector<unsigned long long> h_keys(slots);
-    GP_HIP(hipMemcpy(h_keys.data(), g->keys.ptr, sizeof(unsigned long long) * slots, hipMemcpyDeviceToHost));
-    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
-    for (auto k : h_keys) {
-      if (k == gp::kEmptyKey) continue;
-      const int c[3] = {(int)((k >> 42) & 0x1fffff) - (1 << 20), (int)((k >> 21) & 0x1fffff) - (1 << 20), (int)(k & 0x1fffff) - (1 << 20)};
-      for (int a = 0; a < 3; a++) {
-        lo[a] = std::min(lo[a], c[a]);
-        hi[a] = std::max(hi[a], c[a]);
-      }
-    }
+  GP_HIP(hipMemcpyAsync(h_bbox, bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));  // h_bbox is read below; the scratch is reused by the next level
+  if (n > 0) {
     for (int a = 0; a < 3; a++) {
-      g->lo[a] = lo[a];
-      g->hi[a] = hi[a];
+      g->lo[a] = h_bbox[a];
+      g->hi[a] = h_bbox[3 + a];
     }
   }
   *out = g;
@@ -577,10 +619,18 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
   const int num_levels = n > 4096 ? gp::kMaxLevels : 1;
+  gp::DeviceArray scratch;
+  {
+    const int rc = scratch.alloc(level_scratch_bytes(n));
+    if (rc != GP_OK) {
+      delete g;
+      return rc;
+    }
+  }
   double h = cell_size;
   for (int l = 0; l < num_levels; l++, h *= 4.0) {
     gp_grid_level* lv = nullptr;
-    const int rc = build_level(points_dev, n, h, g->stream, &lv);
+    const int rc = build_level(points_dev, n, h, g->stream, scratch.as<char>(), &lv);
     if (rc != GP_OK) {
       delete g;
       return rc;
