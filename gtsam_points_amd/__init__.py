@@ -19,6 +19,7 @@ from .factors import (  # noqa: F401
     pose_inverse,
 )
 from .features import IntegratedGICPFactorGPU, KdTreeGPU, estimate_covariances_gpu  # noqa: F401
+from .solver import DenseLinearSystemGPU, linearize_on_device  # noqa: F401
 from .types import GaussianVoxelMapGPU, PointCloudGPU, merge_frames_gpu, overlap_gpu  # noqa: F401
 
 __all__ = [
@@ -39,5 +40,7 @@ __all__ = [
     "create_nonlinear_factor_set_gpu",
     "overlap_gpu",
     "merge_frames_gpu",
+    "DenseLinearSystemGPU",
+    "linearize_on_device",
     "load",
 ]

@@ -106,6 +106,13 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_merge_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_double,
                                   C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
+    # dense normal equations on the device
+    "gp_dense_system_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_dense_system_destroy": (C.c_int, [C.c_void_p]),
+    "gp_dense_system_size": (C.c_int, [C.c_void_p]),
+    "gp_dense_system_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "gp_dense_system_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_dense_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_cloud_upload_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gp_cloud_upload_mat3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     # factor

@@ -1,0 +1,366 @@
+// gp_solver.hip -- the step after the path: the damped normal equations of a pose graph
+// of VGICP factors are assembled and solved on the device, so that the H/b records never have to leave HBM between two
+// Levenberg-Marquardt iterations.
+//
+// Replaces (reference, host side, on top of GTSAM / Eigen):
+//   optimizers/linear_system_builder.cpp:39-48    DenseLinearSystemBuilder: A = sum of Hessian blocks scattered by key,
+//                                                  b = sum of the factors' g, c = sum of the constant terms
+//   optimizers/levenberg_marquardt_ext.cpp:146-161 buildDampedSystem: A + lambda I, or A + lambda clamp(diag A) with diagonalDamping
+//   optimizers/linear_solver.hpp:18-22             DenseLinearSolver::solve(A, b): A x = b
+//
+// Shape: variables are 6-dof poses in `num_slots` slots (a factor key that has no slot -- a fixed pose -- drops out of the
+// system, exactly as a constant drops out of a GaussianFactorGraph).  Assembly is a GATHER: the host turns the factor key
+// list into one contribution list per destination 6x6 block, so every block is summed in a fixed order (deterministic, no
+// atomics).  The solve is a dense blocked Cholesky (LL^T, 6x6 blocks = one pose) in f64 held in HBM: per block column one
+// small kernel for the diagonal block, one for the panel below it, one grid-wide rank-6 update of the trailing matrix; then
+// forward / backward substitution in one workgroup.  Dense O(n^3): meant for the hundreds of poses of a submap graph, not
+// tuned (the block-sparse factorisation is the obvious next step).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "gp_host.hpp"
+
+namespace gp {
+
+// which 6x6 of a record a contribution takes: H_target, H_source, H_target_source (as is: row = target, col = source) or
+// its transpose (row = source, col = target)
+enum : int { TAKE_HT = 0, TAKE_HS = 1, TAKE_HTS = 2, TAKE_HTS_T = 3 };
+
+struct BlockDest {
+  int row, col;      // block coordinates (row >= col: lower triangle)
+  int begin, count;  // range in the contribution list
+};
+
+struct Contribution {
+  int factor;
+  int take;
+};
+
+constexpr int REC_HT = 2, REC_HS = 38, REC_HTS = 74, REC_BT = 110, REC_BS = 116;  // offsets (doubles) inside gp_linearized6
+
+// A (n x n, column-major, lower triangle + diagonal) and, for diagonal destinations, b: one 64-thread workgroup per block
+__global__ void __launch_bounds__(64) assemble_kernel(const BlockDest* __restrict__ dests, const Contribution* __restrict__ contribs, const double* __restrict__ records,
+                                                      int n, double* __restrict__ A, double* __restrict__ b) {
+  const BlockDest d = dests[blockIdx.x];
+  const int t = threadIdx.x;
+  if (t < 36) {
+    const int r = t % 6, c = t / 6;
+    double s = 0.0;
+    for (int k = 0; k < d.count; k++) {
+      const Contribution q = contribs[d.begin + k];
+      const double* rec = records + 122 * (size_t)q.factor;
+      double v;
+      if (q.take == TAKE_HT) {
+        v = rec[REC_HT + c * 6 + r];
+      } else if (q.take == TAKE_HS) {
+        v = rec[REC_HS + c * 6 + r];
+      } else if (q.take == TAKE_HTS) {
+        v = rec[REC_HTS + c * 6 + r];
+      } else {
+        v = rec[REC_HTS + r * 6 + c];
+      }
+      s += v;
+    }
+    A[(size_t)(6 * d.col + c) * n + 6 * d.row + r] = s;
+  } else if (t < 42 && d.row == d.col) {
+    // b = sum of g = -b_target / -b_source (HessianFactor(.., -b_t, .., -b_s, ..), integrated_matching_cost_factor.cpp:49)
+    const int r = t - 36;
+    double s = 0.0;
+    for (int k = 0; k < d.count; k++) {
+      const Contribution q = contribs[d.begin + k];
+      const double* rec = records + 122 * (size_t)q.factor;
+      s -= q.take == TAKE_HT ? rec[REC_BT + r] : rec[REC_BS + r];
+    }
+    b[6 * d.row + r] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) sum_errors_kernel(const double* __restrict__ records, int num_factors, double* __restrict__ c_out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int f = threadIdx.x; f < num_factors; f += 256) s += records[122 * (size_t)f + 1];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *c_out = part[0];
+}
+
+// buildDampedSystem: diag += lambda (identity damping) or lambda * clamp(diag, min, max) (diagonalDamping), + optional prior
+__global__ void __launch_bounds__(256) damp_kernel(double* __restrict__ A, int n, double lambda, int diagonal, double min_diag, double max_diag,
+                                                   const double* __restrict__ prior_diag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double d = A[(size_t)i * n + i];
+  double add = diagonal ? lambda * fmin(fmax(d, min_diag), max_diag) : lambda;
+  if (prior_diag) add += prior_diag[i];
+  A[(size_t)i * n + i] = d + add;
+}
+
+// ---- blocked Cholesky, block size 6 -------------------------------------------------------------------------------
+// L_kk in place of A_kk (lower triangle; the strict upper part of the block is left untouched and never read)
+__global__ void __launch_bounds__(64) chol_diag_kernel(double* __restrict__ A, int n, int k, int* __restrict__ status) {
+  __shared__ double a[6][6];
+  const int t = threadIdx.x;
+  double* base = A + (size_t)(6 * k) * n + 6 * k;
+  if (t < 36) a[t % 6][t / 6] = base[(size_t)(t / 6) * n + t % 6];
+  __syncthreads();
+  if (t == 0) {
+    for (int j = 0; j < 6; j++) {
+      double d = a[j][j];
+      for (int p = 0; p < j; p++) d -= a[j][p] * a[j][p];
+      if (!(d > 0.0)) {
+        atomicExch(status, k + 1);  // not positive definite at this pose block (IndeterminantLinearSystemException upstream)
+        d = 1.0;
+      }
+      const double l = sqrt(d);
+      a[j][j] = l;
+      for (int i = j + 1; i < 6; i++) {
+        double s = a[i][j];
+        for (int p = 0; p < j; p++) s -= a[i][p] * a[j][p];
+        a[i][j] = s / l;
+      }
+    }
+  }
+  __syncthreads();
+  if (t < 36 && t % 6 >= t / 6) base[(size_t)(t / 6) * n + t % 6] = a[t % 6][t / 6];
+}
+
+// L_ik = A_ik L_kk^-T for every block row i > k: one 64-thread workgroup per block, one thread per row of the block
+__global__ void __launch_bounds__(64) chol_panel_kernel(double* __restrict__ A, int n, int k) {
+  __shared__ double l[6][6];
+  const int t = threadIdx.x;
+  const double* diag = A + (size_t)(6 * k) * n + 6 * k;
+  if (t < 36) l[t % 6][t / 6] = diag[(size_t)(t / 6) * n + t % 6];
+  __syncthreads();
+  const int i = k + 1 + blockIdx.x;
+  if (t < 6) {
+    double* row = A + (size_t)(6 * k) * n + 6 * i + t;  // element (6i + t, 6k + c) at row[c * n]
+    double x[6];
+    for (int c = 0; c < 6; c++) {
+      double s = row[(size_t)c * n];
+      for (int p = 0; p < c; p++) s -= x[p] * l[c][p];
+      x[c] = s / l[c][c];
+    }
+    for (int c = 0; c < 6; c++) row[(size_t)c * n] = x[c];
+  }
+}
+
+// trailing update A_ij -= L_ik L_jk^T for k < j <= i: the lower triangle of the (P-k-1)^2 blocks, 36 threads per block
+__global__ void __launch_bounds__(64) chol_update_kernel(double* __restrict__ A, int n, int k, int m /* = P - k - 1 */) {
+  // blockIdx.x enumerates the lower triangle of an m x m block grid row by row
+  const int q = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= q) bi++;
+  while (bi * (bi + 1) / 2 > q) bi--;
+  const int bj = q - bi * (bi + 1) / 2;
+  const int i = k + 1 + bi, j = k + 1 + bj;
+  const int t = threadIdx.x;
+  if (t >= 36) return;
+  const int r = t % 6, c = t / 6;
+  const double* li = A + (size_t)(6 * k) * n + 6 * i + r;  // L(6i + r, 6k + p) at li[p * n]
+  const double* lj = A + (size_t)(6 * k) * n + 6 * j + c;
+  double s = 0.0;
+#pragma unroll
+  for (int p = 0; p < 6; p++) s += li[(size_t)p * n] * lj[(size_t)p * n];
+  A[(size_t)(6 * j + c) * n + 6 * i + r] -= s;
+}
+
+// forward then backward substitution in one workgroup: x <- L^-T L^-1 b   (n <= 6 * kMaxSlots)
+constexpr int kSolveThreads = 384;  // 6 rows x 64 lanes
+__global__ void __launch_bounds__(kSolveThreads) chol_solve_kernel(const double* __restrict__ A, int n, int P, const double* __restrict__ b, double* __restrict__ x) {
+  extern __shared__ double y[];  // n doubles
+  __shared__ double rhs[6];
+  const int t = threadIdx.x, row = t / 64, lane = t % 64;
+  for (int i = t; i < n; i += kSolveThreads) y[i] = b[i];
+  __syncthreads();
+  for (int k = 0; k < P; k++) {  // L y = b
+    double s = 0.0;
+    for (int c = lane; c < 6 * k; c += 64) s += A[(size_t)c * n + 6 * k + row] * y[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) rhs[row] = y[6 * k + row] - s;
+    __syncthreads();
+    if (t == 0) {
+      const double* d = A + (size_t)(6 * k) * n + 6 * k;
+      double v[6];
+      for (int r = 0; r < 6; r++) {
+        double q = rhs[r];
+        for (int p = 0; p < r; p++) q -= d[(size_t)p * n + r] * v[p];
+        v[r] = q / d[(size_t)r * n + r];
+      }
+      for (int r = 0; r < 6; r++) y[6 * k + r] = v[r];
+    }
+    __syncthreads();
+  }
+  for (int k = P - 1; k >= 0; k--) {  // L^T x = y
+    double s = 0.0;
+    for (int c = 6 * (k + 1) + lane; c < n; c += 64) s += A[(size_t)(6 * k + row) * n + c] * y[c];  // L(c, 6k+row), contiguous in c
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) rhs[row] = y[6 * k + row] - s;
+    __syncthreads();
+    if (t == 0) {
+      const double* d = A + (size_t)(6 * k) * n + 6 * k;
+      double v[6];
+      for (int r = 5; r >= 0; r--) {
+        double q = rhs[r];
+        for (int p = r + 1; p < 6; p++) q -= d[(size_t)r * n + p] * v[p];  // L(p, r)
+        v[r] = q / d[(size_t)r * n + r];
+      }
+      for (int r = 0; r < 6; r++) y[6 * k + r] = v[r];
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += kSolveThreads) x[i] = y[i];
+}
+
+}  // namespace gp
+
+constexpr int kMaxSlots = 2048;  // 12288 unknowns: 96 KB of LDS for the substitution vector, 1.2 GB for the dense matrix
+
+struct gp_dense_system {
+  int num_slots = 0, num_factors = 0, n = 0;
+  hipStream_t stream = nullptr;
+  std::vector<gp::BlockDest> dests;
+  std::vector<gp::Contribution> contribs;
+  gp::DeviceArray d_dests, d_contribs, A, b, c, x, status, prior;
+  bool built = false;
+};
+
+extern "C" {
+
+int gp_dense_system_create(int num_slots, const int* factor_slots, int num_factors, gp_stream_t stream, gp_dense_system_t** out) {
+  if (!out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_create: null out");
+  *out = nullptr;
+  if (num_slots <= 0 || num_slots > kMaxSlots || num_factors < 0 || (num_factors > 0 && !factor_slots))
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_create: 1 <= num_slots <= 2048, factor_slots = [num_factors][2] (target, source; < 0 = fixed)");
+  // destination block -> ordered contribution list (factor order = summation order)
+  std::map<std::pair<int, int>, std::vector<gp::Contribution>> lists;
+  for (int f = 0; f < num_factors; f++) {
+    const int st = factor_slots[2 * f], ss = factor_slots[2 * f + 1];
+    if (st >= num_slots || ss >= num_slots) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_create: slot index out of range");
+    if (st >= 0 && st == ss) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_create: a factor needs two different poses");
+    if (st >= 0) lists[{st, st}].push_back({f, gp::TAKE_HT});
+    if (ss >= 0) lists[{ss, ss}].push_back({f, gp::TAKE_HS});
+    if (st >= 0 && ss >= 0) {
+      if (st > ss) {
+        lists[{st, ss}].push_back({f, gp::TAKE_HTS});    // row = target, col = source
+      } else {
+        lists[{ss, st}].push_back({f, gp::TAKE_HTS_T});  // row = source, col = target
+      }
+    }
+  }
+  auto* s = new gp_dense_system;
+  s->num_slots = num_slots;
+  s->num_factors = num_factors;
+  s->n = 6 * num_slots;
+  s->stream = (hipStream_t)stream;
+  for (int p = 0; p < num_slots; p++) lists[{p, p}];  // every diagonal block exists (an unconstrained pose gives a singular system, reported by solve)
+  for (auto& kv : lists) {
+    gp::BlockDest d;
+    d.row = kv.first.first;
+    d.col = kv.first.second;
+    d.begin = (int)s->contribs.size();
+    d.count = (int)kv.second.size();
+    s->contribs.insert(s->contribs.end(), kv.second.begin(), kv.second.end());
+    s->dests.push_back(d);
+  }
+  const size_t n = (size_t)s->n;
+  int rc = GP_OK;
+  if ((rc = s->d_dests.alloc(sizeof(gp::BlockDest) * s->dests.size())) || (rc = s->d_contribs.alloc(sizeof(gp::Contribution) * std::max<size_t>(s->contribs.size(), 1))) ||
+      (rc = s->A.alloc(sizeof(double) * n * n)) || (rc = s->b.alloc(sizeof(double) * n)) || (rc = s->x.alloc(sizeof(double) * n)) || (rc = s->c.alloc(sizeof(double))) ||
+      (rc = s->status.alloc(sizeof(int))) || (rc = s->prior.alloc(sizeof(double) * n))) {
+    delete s;
+    return rc;
+  }
+  hipError_t e = hipMemcpy(s->d_dests.ptr, s->dests.data(), sizeof(gp::BlockDest) * s->dests.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !s->contribs.empty())
+    e = hipMemcpy(s->d_contribs.ptr, s->contribs.data(), sizeof(gp::Contribution) * s->contribs.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete s;
+    return gp::hip_fail(e, "gp_dense_system_create", __FILE__, __LINE__);
+  }
+  *out = s;
+  return GP_OK;
+}
+
+int gp_dense_system_destroy(gp_dense_system_t* s) {
+  if (!s) return GP_OK;
+  (void)hipStreamSynchronize(s->stream);
+  delete s;
+  return GP_OK;
+}
+
+int gp_dense_system_size(const gp_dense_system_t* s) { return s ? s->n : 0; }
+
+int gp_dense_system_build(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                          const double* prior_diag_host) {
+  if (!s || (!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_build: bad arguments");
+  const size_t n = (size_t)s->n;
+  GP_HIP(hipMemsetAsync(s->A.ptr, 0, sizeof(double) * n * n, s->stream));
+  GP_HIP(hipMemsetAsync(s->b.ptr, 0, sizeof(double) * n, s->stream));
+  hipLaunchKernelGGL(gp::assemble_kernel, dim3((unsigned)s->dests.size()), dim3(64), 0, s->stream, s->d_dests.as<gp::BlockDest>(), s->d_contribs.as<gp::Contribution>(),
+                     reinterpret_cast<const double*>(records_dev), s->n, s->A.as<double>(), s->b.as<double>());
+  hipLaunchKernelGGL(gp::sum_errors_kernel, dim3(1), dim3(256), 0, s->stream, reinterpret_cast<const double*>(records_dev), s->num_factors, s->c.as<double>());
+  const double* prior = nullptr;
+  if (prior_diag_host) {
+    GP_HIP(hipMemcpyAsync(s->prior.ptr, prior_diag_host, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+    prior = s->prior.as<double>();
+  }
+  if (lambda > 0.0 || prior) {
+    hipLaunchKernelGGL(gp::damp_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->A.as<double>(), s->n, lambda, diagonal_damping, min_diagonal, max_diagonal,
+                       prior);
+  }
+  GP_HIP(hipGetLastError());
+  if (prior_diag_host) GP_HIP(hipStreamSynchronize(s->stream));  // the caller's pageable array may go away
+  s->built = true;
+  return GP_OK;
+}
+
+int gp_dense_system_download(const gp_dense_system_t* s, double* A_host, double* b_host, double* c_host) {
+  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_download: build the system first");
+  const size_t n = (size_t)s->n;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (A_host) {
+    GP_HIP(hipMemcpy(A_host, s->A.ptr, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < n; c++)  // selfadjointView: mirror the lower triangle (linear_system_builder.cpp:42)
+      for (size_t r = c + 1; r < n; r++) A_host[r * n + c] = A_host[c * n + r];
+  }
+  if (b_host) GP_HIP(hipMemcpy(b_host, s->b.ptr, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (c_host) GP_HIP(hipMemcpy(c_host, s->c.ptr, sizeof(double), hipMemcpyDeviceToHost));
+  return GP_OK;
+}
+
+// DenseLinearSolver::solve(A, b): A x = b by LL^T.  A is overwritten by its factor (build again before the next solve).
+int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_out) {
+  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_solve: build the system first");
+  const int P = s->num_slots, n = s->n;
+  double* A = s->A.as<double>();
+  GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
+  for (int k = 0; k < P; k++) {
+    hipLaunchKernelGGL(gp::chol_diag_kernel, dim3(1), dim3(64), 0, s->stream, A, n, k, s->status.as<int>());
+    const int m = P - k - 1;
+    if (m > 0) {
+      hipLaunchKernelGGL(gp::chol_panel_kernel, dim3(m), dim3(64), 0, s->stream, A, n, k);
+      hipLaunchKernelGGL(gp::chol_update_kernel, dim3((unsigned)((size_t)m * (m + 1) / 2)), dim3(64), 0, s->stream, A, n, k, m);
+    }
+  }
+  GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gp::chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)n)));
+  hipLaunchKernelGGL(gp::chol_solve_kernel, dim3(1), dim3(gp::kSolveThreads), sizeof(double) * (size_t)n, s->stream, A, n, P, s->b.as<double>(), s->x.as<double>());
+  GP_HIP(hipGetLastError());
+  s->built = false;
+  int h_status = 0;
+  GP_HIP(hipMemcpyAsync(&h_status, s->status.ptr, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  if (x_dev_out) GP_HIP(hipMemcpyAsync(x_dev_out, s->x.ptr, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s->stream));
+  if (x_host) GP_HIP(hipMemcpyAsync(x_host, s->x.ptr, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (h_status != 0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_dense_system_solve: the system is not positive definite (indeterminate linear system)");
+  return GP_OK;
+}
+
+}  // extern "C"

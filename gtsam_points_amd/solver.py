@@ -1,0 +1,91 @@
+"""The step after the path: the damped normal equations of a graph of VGICP factors, assembled and solved on the device.
+
+  DenseLinearSystemGPU  <- DenseLinearSystemBuilder (optimizers/linear_system_builder.cpp:39-48)
+                           + buildDampedSystem       (optimizers/levenberg_marquardt_ext.cpp:146-161)
+                           + DenseLinearSolver::solve (optimizers/linear_solver.hpp:18-22)
+  linearize_on_device   -- one batched linearise whose records stay in HBM (what the solver consumes)
+
+Poses that are variables get a slot (0..num_slots-1); a factor key without a slot (a fixed pose) drops out of the system.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+def linearize_on_device(factors, values, device="cuda:0", stream=None):
+    """Batched linearise of IntegratedVGICPFactorGPU objects; returns a [F, 122] float64 CUDA tensor of gp_linearized6
+    records (nothing is copied to the host)."""
+    import torch
+
+    lib = _capi.load()
+    F = len(factors)
+    poses = np.zeros((F, 16))
+    for i, f in enumerate(factors):
+        f.set_linearization_point(values, poses[i])
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch = C.c_void_p()
+    _capi.check(lib.gp_vgicp_batch_create(arr, F, stream, C.byref(batch)), "gp_vgicp_batch_create")
+    out = torch.zeros((F, _capi.LINEARIZED6_DOUBLES), dtype=torch.float64, device=device)
+    torch.cuda.current_stream(out.device).synchronize()
+    try:
+        _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses.ctypes.data, C.c_void_p(out.data_ptr())), "gp_vgicp_batch_issue_linearize")
+        _capi.check(lib.gp_vgicp_batch_sync(batch), "gp_vgicp_batch_sync")
+    finally:
+        lib.gp_vgicp_batch_destroy(batch)
+    return out
+
+
+class DenseLinearSystemGPU:
+    """A x = b over 6-dof pose slots, built from stacked device-resident gp_linearized6 records.
+
+    factor_slots: [(target_slot, source_slot)] per factor; a negative slot = that pose is not a variable."""
+
+    def __init__(self, num_slots, factor_slots, stream=None):
+        self._lib = _capi.load()
+        self.num_slots = int(num_slots)
+        self.factor_slots = np.ascontiguousarray(np.asarray(factor_slots, dtype=np.int32).reshape(-1, 2))
+        self.stream = stream
+        h = C.c_void_p()
+        _capi.check(self._lib.gp_dense_system_create(self.num_slots, self.factor_slots.ctypes.data, len(self.factor_slots), stream, C.byref(h)), "gp_dense_system_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.gp_dense_system_destroy(h)
+            self._h = None
+
+    @property
+    def size(self):
+        return 6 * self.num_slots
+
+    def build(self, records_dev, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, prior_diag=None):
+        """records_dev: [F, 122] float64 CUDA tensor.  lam / diagonal_damping: buildDampedSystem; prior_diag: optional
+        extra diagonal (length 6 * num_slots)."""
+        if tuple(records_dev.shape) != (len(self.factor_slots), _capi.LINEARIZED6_DOUBLES) or not records_dev.is_contiguous():
+            raise ValueError("records_dev must be a contiguous [num_factors, 122] float64 device tensor")
+        prior = None
+        if prior_diag is not None:
+            prior = np.ascontiguousarray(prior_diag, dtype=np.float64)
+            if prior.shape != (self.size,):
+                raise ValueError("prior_diag must have 6 * num_slots entries")
+        _capi.check(
+            self._lib.gp_dense_system_build(self._h, C.c_void_p(records_dev.data_ptr()), float(lam), int(bool(diagonal_damping)), float(min_diagonal), float(max_diagonal),
+                                            prior.ctypes.data if prior is not None else None),
+            "gp_dense_system_build",
+        )
+        return self
+
+    def download(self):
+        n = self.size
+        A, b, c = np.zeros((n, n)), np.zeros(n), np.zeros(1)
+        _capi.check(self._lib.gp_dense_system_download(self._h, A.ctypes.data, b.ctypes.data, c.ctypes.data), "gp_dense_system_download")
+        return A.T.copy(), b, float(c[0])  # column-major -> numpy (symmetric anyway)
+
+    def solve(self):
+        """x with A x = b (consumes the built system); raises GPError when A is not positive definite."""
+        x = np.zeros(self.size)
+        _capi.check(self._lib.gp_dense_system_solve(self._h, x.ctypes.data, None), "gp_dense_system_solve")
+        return x

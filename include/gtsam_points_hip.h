@@ -38,6 +38,7 @@ extern "C" {
 #define GP_ERROR_HIP 2
 #define GP_ERROR_NOT_LOADED 3 /* voxel map / cloud offloaded from the GPU */
 #define GP_ERROR_IO 4
+#define GP_ERROR_INDETERMINATE 5 /* normal equations not positive definite (IndeterminantLinearSystemException upstream) */
 
 typedef void* gp_stream_t; /* hipStream_t */
 
@@ -277,6 +278,26 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
 int gp_gicp_factor_destroy(gp_gicp_factor_t* f);
 int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host);           /* update_correspondences + evaluate */
 int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host);
+
+/* ---- the step after the path: damped normal equations assembled and solved on the device ----
+ * DenseLinearSystemBuilder (optimizers/linear_system_builder.cpp:39-48): A = sum of the Hessian blocks scattered by key,
+ *   b = sum of g (= -b_target / -b_source, integrated_matching_cost_factor.cpp:49), c = sum of the errors;
+ * buildDampedSystem (optimizers/levenberg_marquardt_ext.cpp:146-161): A + lambda I, or A + lambda clamp(diag A, min, max);
+ * DenseLinearSolver::solve(A, b) (optimizers/linear_solver.hpp:18-22): A x = b, here by a blocked LL^T in f64.
+ * Variables are 6-dof poses in num_slots slots; factor_slots = [num_factors][2] = (target slot, source slot), a negative
+ * slot = a pose that is not a variable (fixed / unary factor).  records_dev = the stacked [num_factors] gp_linearized6
+ * records exactly as gp_vgicp_batch_issue_linearize (or the multi-GPU all-reduce) leaves them in HBM. */
+typedef struct gp_dense_system gp_dense_system_t;
+int gp_dense_system_create(int num_slots, const int* factor_slots, int num_factors, gp_stream_t stream, gp_dense_system_t** out);
+int gp_dense_system_destroy(gp_dense_system_t* sys);
+int gp_dense_system_size(const gp_dense_system_t* sys); /* 6 * num_slots */
+/* prior_diag_host: optional [6 * num_slots] extra diagonal (prior factors), may be NULL */
+int gp_dense_system_build(gp_dense_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                          const double* prior_diag_host);
+/* A as a full symmetric column-major [n][n], b [n], c; any pointer may be NULL.  Synchronous. */
+int gp_dense_system_download(const gp_dense_system_t* sys, double* A_host, double* b_host, double* c_host);
+/* x (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
+int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev);
 
 /* tuning hook (not part of the reference API): tile-kernel variant.  0 = reference-shaped kernel, 1 = pipeline kernel in f64
  * (default), 2 = pipeline kernel with f32 outer products; see gp_vgicp.hip */

@@ -1,0 +1,142 @@
+"""GPU tests of the device-side normal equations: DenseLinearSystemBuilder + buildDampedSystem +
+DenseLinearSolver::solve restated with numpy on the host as the checker (the reference's own solve is GTSAM / Eigen, absent)."""
+import numpy as np
+import pytest
+
+from helpers import expmap, pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(gpu, kitti07, res=1.0):
+    n = 5
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(n)]
+    maps = []
+    for c in clouds:
+        vm = gpu.GaussianVoxelMapGPU(res, target_points_drop_rate=0.0)
+        vm.insert(c)
+        maps.append(vm)
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n) if j - i <= 2]  # 7 binary factors
+    factors = [gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
+    rng = np.random.default_rng(8191)
+    values = {i: np.asarray(kitti07["poses"][i], dtype=np.float64) @ expmap(rng.uniform(-0.02, 0.02, 6)) for i in range(n)}
+    return clouds, maps, pairs, factors, values
+
+
+def _host_system(records, slots, n_slots):
+    """DenseLinearSystemBuilder (linear_system_builder.cpp:39-48) on the host: scatter the Hessian blocks by key"""
+    A, b, c = np.zeros((6 * n_slots, 6 * n_slots)), np.zeros(6 * n_slots), 0.0
+    for rec, (st, ss) in zip(records, slots):
+        Ht, Hs, Hts = rec[2:38].reshape(6, 6).T, rec[38:74].reshape(6, 6).T, rec[74:110].reshape(6, 6).T
+        bt, bs = rec[110:116], rec[116:122]
+        c += rec[1]
+        if st >= 0:
+            A[6 * st : 6 * st + 6, 6 * st : 6 * st + 6] += Ht
+            b[6 * st : 6 * st + 6] -= bt
+        if ss >= 0:
+            A[6 * ss : 6 * ss + 6, 6 * ss : 6 * ss + 6] += Hs
+            b[6 * ss : 6 * ss + 6] -= bs
+        if st >= 0 and ss >= 0:
+            A[6 * st : 6 * st + 6, 6 * ss : 6 * ss + 6] += Hts
+            A[6 * ss : 6 * ss + 6, 6 * st : 6 * st + 6] += Hts.T
+    return A, b, c
+
+
+def test_build_damp_solve_match_host(gpu, kitti07):
+    _, _, pairs, factors, values = _graph(gpu, kitti07)
+    rec_dev = gpu.linearize_on_device(factors, values)
+    rec = rec_dev.cpu().numpy()
+    # pose 0 fixed (no slot), poses 1..4 -> slots 0..3
+    slots = [(i - 1, j - 1) for i, j in pairs]
+    sys = gpu.DenseLinearSystemGPU(4, slots)
+    A, b, c = sys.build(rec_dev).download()
+    Ah, bh, ch = _host_system(rec, slots, 4)
+    assert np.abs(A - Ah).max() <= 1e-12 * np.abs(Ah).max() and np.abs(b - bh).max() <= 1e-12 * np.abs(bh).max() and abs(c - ch) <= 1e-12 * abs(ch)
+    assert np.array_equal(A, A.T)
+    for lam, diag in [(0.0, False), (1e-3, False), (10.0, True)]:
+        sys.build(rec_dev, lam=lam, diagonal_damping=diag)
+        Ad = sys.download()[0]
+        want = Ah + (lam * np.diag(np.clip(np.diag(Ah), 1e-6, 1e32)) if diag else lam * np.eye(24))
+        assert np.abs(Ad - want).max() <= 1e-12 * np.abs(want).max()
+        x = sys.solve()
+        xh = np.linalg.solve(want, bh)
+        assert np.linalg.norm(x - xh) <= 1e-9 * np.linalg.norm(xh), (lam, diag)
+    # deterministic: same records -> bit-identical solution
+    x1 = sys.build(rec_dev, lam=1e-3).solve()
+    x2 = sys.build(rec_dev, lam=1e-3).solve()
+    assert np.array_equal(x1, x2)
+    # all five poses free and no prior: the gauge freedom makes the system singular -> reported, not swallowed
+    free = gpu.DenseLinearSystemGPU(5, pairs)
+    with pytest.raises(gpu.GPError):
+        free.build(rec_dev).solve()
+    # ... a prior on pose 0 fixes it
+    prior = np.zeros(30)
+    prior[:6] = 1e6
+    x = free.build(rec_dev, prior_diag=prior).solve()
+    Af, bf, _ = _host_system(rec, pairs, 5)
+    xf = np.linalg.solve(Af + np.diag(prior), bf)
+    assert np.linalg.norm(x - xf) <= 1e-8 * np.linalg.norm(xf)
+
+
+def test_larger_random_spd_system(gpu):
+    """the blocked Cholesky on a synthetic 60-pose chain-with-loops graph (records made on the host, uploaded)"""
+    import torch
+
+    rng = np.random.default_rng(3)
+    P, pairs = 60, []
+    for i in range(P):
+        for d in (1, 2, 7):
+            if i + d < P:
+                pairs.append((i, i + d))
+    rec = np.zeros((len(pairs), 122))
+    for k in range(len(pairs)):
+        J = rng.normal(size=(40, 12))
+        H = J.T @ J  # PSD 12x12: [[Ht, Hts], [Hts^T, Hs]]
+        rec[k, 0], rec[k, 1] = 40, rng.uniform(1, 2)
+        rec[k, 2:38], rec[k, 38:74], rec[k, 74:110] = H[:6, :6].T.reshape(36), H[6:, 6:].T.reshape(36), H[:6, 6:].T.reshape(36)
+        rec[k, 110:122] = rng.normal(size=12)
+    rec_dev = torch.from_numpy(rec).cuda()
+    sys = gpu.DenseLinearSystemGPU(P, pairs)
+    x = sys.build(rec_dev, lam=1e-2).solve()
+    Ah, bh, _ = _host_system(rec, pairs, P)
+    xh = np.linalg.solve(Ah + 1e-2 * np.eye(6 * P), bh)
+    assert np.linalg.norm(x - xh) <= 1e-9 * np.linalg.norm(xh)
+
+
+def test_lm_with_device_solve_reaches_the_alignment_gate(gpu, kitti07):
+    """the reference's alignment gate (test_matching_cost_factors.cpp:227: < 0.015 rad / 0.15 m) with every linear algebra
+    step of the LM loop on the GPU: batched linearise -> records in HBM -> device assembly + damping + Cholesky"""
+    clouds, maps, pairs, factors, values0 = _graph(gpu, kitti07)
+    slots = [(i - 1, j - 1) for i, j in pairs]
+    sys = gpu.DenseLinearSystemGPU(4, slots)
+    fset = gpu.NonlinearFactorSetGPU()
+    for f in factors:
+        fset.add(f)
+    values, lam = dict(values0), 1e-5
+    fset.linearize(values)
+    err = sum(f.error(values) for f in factors)
+    for _ in range(30):
+        rec_dev = gpu.linearize_on_device(factors, values)
+        improved = False
+        for _try in range(12):
+            dx = sys.build(rec_dev, lam=lam, diagonal_damping=True).solve()
+            new_values = dict(values)
+            for k in range(1, 5):
+                new_values[k] = values[k] @ expmap(dx[6 * (k - 1) : 6 * k])
+            fset.linearize(values)  # error() evaluates with the correspondences frozen at the linearisation point
+            fset.error(new_values)
+            new_err = sum(f.error(new_values) for f in factors)
+            if new_err < err:
+                improved, lam = True, max(lam / 10.0, 1e-12)
+                break
+            lam *= 10.0
+        if not improved:
+            break
+        rel = (err - new_err) / max(err, 1e-300)
+        values, err = new_values, new_err
+        if rel < 1e-4:
+            break
+    gt = [np.asarray(T, dtype=np.float64) for T in kitti07["poses"]]
+    for k in range(1, 5):
+        ang, trans = pose_error(np.linalg.inv(values[0]) @ values[k], np.linalg.inv(gt[0]) @ gt[k])
+        assert ang < 0.015 and trans < 0.15, (k, ang, trans)
