@@ -6,6 +6,8 @@ OUT=gpurun_out/pmc_tile_v$V.txt; : > $OUT
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
+  case "$line" in \#*) continue;; esac
+  if [ -n "${PMC_QUICK:-}" ]; then case "$line" in SQ_WAVES*|SQ_INSTS_VALU*|TCC_HIT*) ;; *) continue;; esac; fi
   i=$((i+1)); D=gpurun_out/pmc_tile_tmp_$i; rm -rf $D
   timeout 300 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $D -o p -- python scripts/profile_tile.py $V 10 > $D.log 2>&1
   f=$(find $D -name "*counter_collection.csv" | head -1)
