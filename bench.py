@@ -113,8 +113,12 @@ def main():
 
     if world == 1:
         # the product's synchronous entry point: pose in host memory -> records in host memory
+        linearize = lib.gp_vgicp_batch_linearize  # bound once: the step is ~40 us, attribute lookups and .ctypes views are not free
+        pose_ptr, out_ptr = C.c_void_p(pose.ctypes.data), C.c_void_p(out_np.ctypes.data)
+
         def step():
-            _capi.check(lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out_np.ctypes.data), "gp_vgicp_batch_linearize")
+            if linearize(batch, pose_ptr, out_ptr) != 0:
+                _capi.check(1, "gp_vgicp_batch_linearize")
 
     else:
         from gtsam_points_amd.distributed import ShardedLinearizer
