@@ -434,8 +434,11 @@ namespace {
 //   0  reference-shaped kernel (reference bucket table, one point per lane per stride, all modes) -- also the cross-check
 //   1  pipeline kernel, f64 throughout (default)
 //   2  pipeline kernel, f32 outer products / accumulators on f64-accurate M, r, q (parity ~1e-8; ~5 % faster)
+//   3  deep pipeline kernel (lookup of the next chunks overlapped with the algebra), f64, 6 chunks per wave
+//   4  deep pipeline kernel, f32 outer products
 int g_variant = 1;
-constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
+constexpr int kPipelineChunks = 4;      // 64-point chunks per wave: 1024-point tiles
+constexpr int kDeepPipelineChunks = 6;  // 1536-point tiles: 651 workgroups for 1 M points on the 768 slots of 3 workgroups per CU
 
 // where a launch takes its poses from
 struct PoseSource {
@@ -450,7 +453,7 @@ int build_table(gp_vgicp_batch* b) {
   std::vector<gp::TileDesc> tiles;
   b->total_points = 0;
   b->variant = g_variant;
-  b->tile_points = gp::kBlockThreads * kPipelineChunks;
+  b->tile_points = gp::kBlockThreads * (g_variant >= 3 ? kDeepPipelineChunks : kPipelineChunks);
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -530,6 +533,14 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
         break;
       case 2:
         hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
+                           ps.inl, partials);
+        break;
+      case 3:
+        hipLaunchKernelGGL((gp::vgicp_deep_pipeline_kernel<MODE, false, kDeepPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
+                           ps.inl, partials);
+        break;
+      case 4:
+        hipLaunchKernelGGL((gp::vgicp_deep_pipeline_kernel<MODE, true, kDeepPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
                            ps.inl, partials);
         break;
       default:
@@ -620,7 +631,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 2) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..2");
+  if (variant < 0 || variant > 4) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..4");
   g_variant = variant;
   return GP_OK;
 }

@@ -415,4 +415,248 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline_kernel(const FactorDesc
   GP_TRACE(7);
 }
 
+
+// =====================================================================================================================
+// vgicp_deep_pipeline_kernel -- the pipeline kernel with the voxel lookup taken out of the critical path as well.
+//
+// In vgicp_pipeline_kernel a wave still waits twice per step (keys, then record) and, because the four waves of a SIMD start
+// together and do the same work, they wait together: ~1.2 us of every ~3 us step has the SIMD idle.  Here every wave keeps
+// three chunks in different stages at once, so its own algebra covers its own latencies:
+//     iteration j:  wait (keys of chunk j+1, record of chunk j; the youngest DMA keeps flying)
+//                   match keys(j+1) -> request record(j+1)
+//                   point(j+2) from LDS -> transform, floor, hash -> request keys(j+2)
+//                   point + covariance (j) from LDS -> [request source chunk j+4 into the stage just read]
+//                   algebra(j) with record(j)
+// Cost: two records' worth of VGPRs in flight (3 waves per SIMD instead of 4) and a 4-stage ring (12 KB per wave, 48 KB per
+// workgroup, 3 workgroups per CU).  All VMEM traffic of the ring path, the DMA included, is issued from inline asm: the
+// compiler then tracks none of it and inserts no vmcnt waits of its own; every wait below is explicit and static.
+// =====================================================================================================================
+__device__ __forceinline__ void chunk_dma_asm(const GP_GLOBAL float* points, const GP_GLOBAL float* covs, size_t first_point, char* stage, int lane) {
+  const GP_GLOBAL char* gp = (const GP_GLOBAL char*)(points + 3 * first_point);
+  const GP_GLOBAL char* gc = (const GP_GLOBAL char*)(covs + 9 * first_point);
+  const GP_GLOBAL char* a0 = lane < 48 ? gp + lane * 16 : gc + (lane - 48) * 16;
+  const GP_GLOBAL char* a1 = gc + (lane + 16) * 16;
+  const GP_GLOBAL char* a2 = gc + (lane + 80) * 16;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(GP_LDS char*)stage);
+  asm volatile(
+    "s_mov_b32 m0, %3\n\t"
+    "s_nop 0\n\t"
+    "global_load_lds_dwordx4 %0, off\n\t"
+    "s_add_i32 m0, %3, 0x400\n\t"
+    "s_nop 0\n\t"
+    "global_load_lds_dwordx4 %1, off\n\t"
+    "s_add_i32 m0, %3, 0x800\n\t"
+    "s_nop 0\n\t"
+    "global_load_lds_dwordx4 %2, off"
+    :
+    : "v"(a0), "v"(a1), "v"(a2), "s"(lds0)
+    : "memory", "m0");
+}
+
+template <int MODE, bool OUTER_F32, int PPT>
+__global__ void __launch_bounds__(256, 3) vgicp_deep_pipeline_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                                  const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                                  double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "tuned kernel covers the rigid linearise and the error evaluation");
+  static_assert(PPT >= 4, "the prologue fills four ring stages");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  constexpr int STAGES = 4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGES * kChunkBytes];  // 48 KB
+  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  if (tile_idx >= num_tiles) return;
+  unsigned long long* trace = g_trace;
+  GP_TRACE(0);
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+  } else {
+    tile = tiles[tile_idx];
+  }
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const GP_GLOBAL float* points = as_global(f.points);
+  const GP_GLOBAL float* covs = as_global(f.covs);
+  const size_t first = (size_t)tile.begin + (size_t)wave * (PPT * kChunkPoints);
+  int wcount = __builtin_amdgcn_readfirstlane(tile.count) - wave * (PPT * kChunkPoints);
+  wcount = wcount < 0 ? 0 : (wcount > PPT * kChunkPoints ? PPT * kChunkPoints : wcount);
+  const bool ring = wcount == PPT * kChunkPoints && (((uintptr_t)f.points | (uintptr_t)f.covs) & 15) == 0;
+  char* wbase = smem + wave * (STAGES * kChunkBytes);
+  const GP_GLOBAL char* lines = (const GP_GLOBAL char*)f.map.plines;
+  const GP_GLOBAL char* records = (const GP_GLOBAL char*)f.map.records;
+
+  if (ring) {
+    chunk_dma_asm(points, covs, first, wbase, lane);
+    chunk_dma_asm(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
+  }
+  const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
+
+  using acc_t = typename std::conditional<OUTER_F32, float, double>::type;
+  acc_t acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = (acc_t)0;
+
+  // stage S1: this lane's point of chunk c -> voxel coordinate -> request the 4 keys of its home line
+  auto hash_and_request_keys = [&](int c, int& cx, int& cy, int& cz, bool& live, v4i& k0, v4i& k1, v4i& k2, v4i& k3) {
+    const float* lp = reinterpret_cast<const float*>(wbase + (c % STAGES) * kChunkBytes);
+    const double dx = (double)lp[3 * lane], dy = (double)lp[3 * lane + 1], dz = (double)lp[3 * lane + 2];
+    const double lx = Tl.r00 * dx + Tl.r01 * dy + Tl.r02 * dz + Tl.tx;
+    const double ly = Tl.r10 * dx + Tl.r11 * dy + Tl.r12 * dz + Tl.ty;
+    const double lz = Tl.r20 * dx + Tl.r21 * dy + Tl.r22 * dz + Tl.tz;
+    cx = fast_floor(lx * f.map.inv_leaf);
+    cy = fast_floor(ly * f.map.inv_leaf);
+    cz = fast_floor(lz * f.map.inv_leaf);
+    live = true;
+    if (f.surface_validation && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + (size_t)c * kChunkPoints + lane))) live = false;
+    const uint32_t l = coord_hash32(cx, cy, cz) & f.map.plmask;
+    line_issue(lines + 64 * (size_t)l, k0, k1, k2, k3);
+  };
+  // stage S2: keys -> voxel index (the rare full line without a match walks on, synchronously) -> request the record
+  auto match_and_request_record = [&](int cx, int cy, int cz, bool live, const v4i& k0, const v4i& k1, const v4i& k2, const v4i& k3, bool& hit, v4f& head, v2d& c01,
+                                      v2d& c23, v2d& c45) {
+    int idx = line_match(k0, k1, k2, k3, cx, cy, cz);
+    if (live && idx < 0 && k3.w >= 0) {
+      uint32_t l = coord_hash32(cx, cy, cz) & f.map.plmask;
+      for (;;) {
+        l = (l + 1) & f.map.plmask;
+        const GP_GLOBAL v4i* q = (const GP_GLOBAL v4i*)(lines + 64 * (size_t)l);
+        const v4i a = q[0], b = q[1], c = q[2], d = q[3];
+        idx = line_match(a, b, c, d, cx, cy, cz);
+        if (idx >= 0 || d.w < 0) break;
+      }
+    }
+    hit = live && idx >= 0;
+    record_issue(hit ? records + 64 * (size_t)idx : lines, head, c01, c23, c45);
+  };
+
+  if (ring) {
+    // rotating state (indices are compile-time after unrolling): coordinates / liveness of chunks j, j+1, j+2; two records
+    int cxs[3], cys[3], czs[3];
+    bool lives[3], hits[2];
+    v4i k0, k1, k2, k3;
+    v4f head[2];
+    v2d c01[2], c23[2], c45[2];
+    // ---- prologue: leaves {record(0), keys(1), DMA(3)} in flight, in that issue order.  (Threading the source requests
+    // one by one between the hops -- chunk 0 alone first -- lands chunk 0 sooner, 2.2 instead of 3.4 us, but the hops then
+    // queue behind everybody's chunk-1 burst: measured no better.) ----
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // chunk 0
+    GP_TRACE(1);
+    hash_and_request_keys(0, cxs[0], cys[0], czs[0], lives[0], k0, k1, k2, k3);
+    chunk_dma_asm(points, covs, first + 2 * kChunkPoints, wbase + 2 * kChunkBytes, lane);
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3) : : "memory");  // chunk 1 and keys(0)
+    match_and_request_record(cxs[0], cys[0], czs[0], lives[0], k0, k1, k2, k3, hits[0], head[0], c01[0], c23[0], c45[0]);
+    hash_and_request_keys(1, cxs[1], cys[1], czs[1], lives[1], k0, k1, k2, k3);
+    chunk_dma_asm(points, covs, first + 3 * kChunkPoints, wbase + 3 * kChunkBytes, lane);
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      const int cur = j & 1, nxt = cur ^ 1;
+      // record(j) and keys(j+1) have landed when only the youngest DMA request (3 instructions, if one was issued) is left
+      if (j == 0 || j + 3 < PPT) {
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3), "+v"(head[cur]), "+v"(c01[cur]), "+v"(c23[cur]), "+v"(c45[cur]) : : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3), "+v"(head[cur]), "+v"(c01[cur]), "+v"(c23[cur]), "+v"(c45[cur]) : : "memory");
+      }
+      if (j == 0) GP_TRACE(2);
+      if (j == 1) GP_TRACE(3);
+      if (j == 2) GP_TRACE(4);
+      if (j == 3) GP_TRACE(5);
+      if (j + 1 < PPT)
+        match_and_request_record(cxs[(j + 1) % 3], cys[(j + 1) % 3], czs[(j + 1) % 3], lives[(j + 1) % 3], k0, k1, k2, k3, hits[nxt], head[nxt], c01[nxt], c23[nxt],
+                                 c45[nxt]);
+      if (j + 2 < PPT) hash_and_request_keys(j + 2, cxs[(j + 2) % 3], cys[(j + 2) % 3], czs[(j + 2) % 3], lives[(j + 2) % 3], k0, k1, k2, k3);
+      const float* lp = reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes);
+      const float* lc = lp + kChunkPoints * 3;
+      const float px = lp[3 * lane], py = lp[3 * lane + 1], pz = lp[3 * lane + 2];
+      const float cA[6] = {lc[9 * lane], lc[9 * lane + 3], lc[9 * lane + 6], lc[9 * lane + 4], lc[9 * lane + 7], lc[9 * lane + 8]};
+      if (j + 4 < PPT) {
+        // the stage just read is free: the LDS reads above must have returned before the DMA may overwrite it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        chunk_dma_asm(points, covs, first + (size_t)(j + 4) * kChunkPoints, wbase + (j % STAGES) * kChunkBytes, lane);
+      }
+      if (hits[cur])
+        accumulate_terms<MODE, acc_t>(Tl, Te, f.map.leaf, px, py, pz, cA, cxs[j % 3], cys[j % 3], czs[j % 3], head[cur], c01[cur], c23[cur], c45[cur], acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP_TRACE(6);
+  } else {
+    for (int j = 0; j < PPT; j++) {
+      const int nj = wcount - j * kChunkPoints;  // wave-uniform
+      if (nj <= 0) break;
+      const bool active = lane < nj;
+      const size_t i = first + (size_t)j * kChunkPoints + (active ? lane : 0);
+      const GP_GLOBAL float* pp = points + 3 * i;
+      const GP_GLOBAL float* cp = covs + 9 * i;
+      const float px = pp[0], py = pp[1], pz = pp[2];
+      const float cA[6] = {cp[0], cp[3], cp[6], cp[4], cp[7], cp[8]};
+      const double dx = (double)px, dy = (double)py, dz = (double)pz;
+      const double lx = Tl.r00 * dx + Tl.r01 * dy + Tl.r02 * dz + Tl.tx;
+      const double ly = Tl.r10 * dx + Tl.r11 * dy + Tl.r12 * dz + Tl.ty;
+      const double lz = Tl.r20 * dx + Tl.r21 * dy + Tl.r22 * dz + Tl.tz;
+      const int cx = fast_floor(lx * f.map.inv_leaf), cy = fast_floor(ly * f.map.inv_leaf), cz = fast_floor(lz * f.map.inv_leaf);
+      bool live = active;
+      if (f.surface_validation && live && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * i)) live = false;
+      const uint32_t l = coord_hash32(cx, cy, cz) & f.map.plmask;
+      v4i k0, k1, k2, k3;
+      line_issue(lines + 64 * (size_t)l, k0, k1, k2, k3);
+      line_wait(k0, k1, k2, k3);
+      bool hit;
+      v4f head;
+      v2d c01, c23, c45;
+      match_and_request_record(cx, cy, cz, live, k0, k1, k2, k3, hit, head, c01, c23, c45);
+      record_wait<0>(head, c01, c23, c45);
+      if (hit) accumulate_terms<MODE, acc_t>(Tl, Te, f.map.leaf, px, py, pz, cA, cx, cy, cz, head, c01, c23, c45, acc);
+    }
+  }
+
+  // ---- reduction: as in vgicp_pipeline_kernel (transposition through the wave's own drained ring) ----
+  constexpr int kRowStride = 68;
+  double* wtrans = reinterpret_cast<double*>(wbase);
+  double* wsums = reinterpret_cast<double*>(wbase + STAGES * kChunkBytes - 32 * 8);
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = (double)acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) wsums[k] = v;
+    }
+  } else {
+    const int comp = lane >> 2, part = lane & 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) wtrans[k * kRowStride + lane] = (double)acc[pass * 16 + k];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        s0 += wtrans[comp * kRowStride + 4 * i + part];
+        s1 += wtrans[comp * kRowStride + 4 * (i + 1) + part];
+        s2 += wtrans[comp * kRowStride + 4 * (i + 2) + part];
+        s3 += wtrans[comp * kRowStride + 4 * (i + 3) + part];
+      }
+      double v = (s0 + s1) + (s2 + s3);
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      if (part == 0) wsums[pass * 16 + comp] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double sum = 0.0;
+    if (threadIdx.x < NACC) {
+      const double* w0 = reinterpret_cast<const double*>(smem + 1 * STAGES * kChunkBytes - 32 * 8);
+      const double* w1 = reinterpret_cast<const double*>(smem + 2 * STAGES * kChunkBytes - 32 * 8);
+      const double* w2 = reinterpret_cast<const double*>(smem + 3 * STAGES * kChunkBytes - 32 * 8);
+      const double* w3 = reinterpret_cast<const double*>(smem + 4 * STAGES * kChunkBytes - 32 * 8);
+      sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
+    }
+    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = sum;
+  }
+  GP_TRACE(7);
+}
+
 }  // namespace gp

@@ -41,6 +41,8 @@ t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 rel = (t - t0) / 2100.0  # s_memtime counts shader clocks (~2.1 GHz under this load); counters of different XCDs are not synchronised
 names = ["start", "chunk0_landed", "keys0_landed", "step0_done", "keys1_landed", "step1_done", "steps_done", "end"]
+if variant >= 3:
+    names = ["start", "chunk0_landed", "iter0_top", "iter1_top", "iter2_top", "iter3_top", "loop_done", "end"]
 print("workgroups traced:", len(t))
 for k, n in enumerate(names):
     c = rel[:, k]

@@ -73,6 +73,29 @@ def test_rigid_and_general_pose_paths(gpu, kitti00):
         assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), PARITY_TOL, name)
 
 
+@pytest.mark.parametrize("variant,tol", [(0, PARITY_TOL), (1, PARITY_TOL), (2, 1e-6), (3, PARITY_TOL), (4, 1e-6)])
+def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
+    """gp_debug_set_variant: 0 reference-shaped kernel, 1 pipeline kernel (default), 2 pipeline + f32 outer products,
+    3 / 4 deep pipeline (lookup overlapped with the algebra) in f64 / f32 outer products -- linearise and error evaluation,
+    full tiles, a partial tile and the per-lane fallback all go through the selected kernel"""
+    lib = gpu.load()
+    try:
+        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
+        _, src, vm = _build(gpu, kitti00, 0.5)
+        f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+        _, fo = _oracle(kitti00, 0.5)
+        delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+        assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), tol, f"variant {variant}")
+        de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
+        err = C.c_double()
+        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+        fo.linearize(delta)
+        eo = fo.error(de)
+        assert abs(err.value - eo) <= tol * abs(eo)
+    finally:
+        lib.gp_debug_set_variant(1)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1023, 1024, 1025, 4097])
 def test_ragged_sizes(gpu, kitti00, n):
     """empty, single-point, wave/tile boundary sizes"""
