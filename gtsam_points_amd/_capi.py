@@ -119,6 +119,7 @@ _SIGNATURES = {
     "gp_vgicp_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_vgicp_factor_destroy": (C.c_int, [C.c_void_p]),
     "gp_vgicp_factor_set_surface_validation": (C.c_int, [C.c_void_p, C.c_int]),
+    "gp_vgicp_factor_set_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_factor_set_inlier_update_thresh": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "gp_vgicp_factor_num_points": (C.c_int, [C.c_void_p]),
     "gp_vgicp_factor_stream": (C.c_void_p, [C.c_void_p]),

@@ -122,6 +122,7 @@ struct gp_voxelmap {
 
   // offloaded copies (OffloadableGPU)
   bool offloaded = false;
+  uint64_t generation = 0;  // bumped whenever the device arrays are (re)allocated: factor tables built from view() go stale
   std::vector<char> h_buckets, h_records, h_num_points, h_means, h_covs, h_intensities, h_coords;
 
   bool loaded() const { return buckets.ptr != nullptr && !offloaded; }

@@ -404,6 +404,7 @@ struct gp_vgicp_factor {
   const float* normals = nullptr;
   int n = 0;
   bool surface_validation = false;
+  uint64_t generation = 0;  // bumped when the source pointers or flags change (tables that hold this factor go stale)
   double inlier_thresh_trans = 1e-6, inlier_thresh_angle = 1e-6;  // integrated_vgicp_derivatives.cu:26-27 (kept for API parity)
   hipStream_t stream = nullptr;
   bool owns_stream = false;
@@ -426,6 +427,7 @@ struct gp_vgicp_batch {
   gp::PinnedArray h_out;  // results land here straight from the finalize kernel (host-mapped, no D2H copy op)
   void* h_out_dev = nullptr;
   bool table_dirty = true;
+  std::vector<uint64_t> seen;  // per factor: its generation + its target map's generation when the table was built
 };
 
 namespace {
@@ -481,8 +483,19 @@ int build_table(gp_vgicp_batch* b) {
   // the table upload is synchronous (pageable source); it happens once per factor-set change, not per linearise
   if (F) GP_HIP(hipMemcpy(b->d_factors.ptr, descs.data(), sizeof(gp::FactorDesc) * (size_t)F, hipMemcpyHostToDevice));
   if (b->num_tiles) GP_HIP(hipMemcpy(b->d_tiles.ptr, tiles.data(), sizeof(gp::TileDesc) * (size_t)b->num_tiles, hipMemcpyHostToDevice));
+  b->seen.resize((size_t)F);
+  for (int i = 0; i < F; i++) b->seen[i] = b->factors[i]->generation + b->factors[i]->target->generation;
   b->table_dirty = false;
   return GP_OK;
+}
+
+// the factor table caches device pointers: rebuild it when the variant changed, a flag or source pointer of a factor changed,
+// or a target map was re-inserted / offloaded / reloaded since (OffloadableGPU protocol)
+bool table_is_stale(const gp_vgicp_batch* b) {
+  if (b->table_dirty || b->variant != g_variant || b->seen.size() != b->factors.size()) return true;
+  for (size_t i = 0; i < b->factors.size(); i++)
+    if (b->seen[i] != b->factors[i]->generation + b->factors[i]->target->generation) return true;
+  return false;
 }
 
 int partials_ptr(gp_vgicp_batch* b, double** out) {
@@ -615,7 +628,7 @@ int ensure_self_batch(gp_vgicp_factor* f) {
     b->temp_buffer = f->temp_buffer;
     f->self_batch = b;
   }
-  if (f->self_batch->table_dirty || f->self_batch->variant != g_variant) GP_TRY(build_table(f->self_batch));
+  if (table_is_stale(f->self_batch)) GP_TRY(build_table(f->self_batch));
   return GP_OK;
 }
 
@@ -696,7 +709,18 @@ int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable) {
   if (!f) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "null factor");
   if (enable && !f->normals) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "surface validation needs source normals (integrated_vgicp_factor_gpu.hpp:84-86)");
   f->surface_validation = enable != 0;
-  if (f->self_batch) f->self_batch->table_dirty = true;
+  f->generation++;
+  return GP_OK;
+}
+
+// the source cloud was offloaded and reloaded (PointCloudGPU::reload_gpu re-allocates): hand the factor the new arrays
+int gp_vgicp_factor_set_source(gp_vgicp_factor_t* f, const float* points_dev, const float* covs_dev, const float* normals_dev) {
+  if (!f || !points_dev || !covs_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_set_source: null factor / points / covs");
+  if (f->surface_validation && !normals_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_set_source: surface validation is on but no normals given");
+  f->points = points_dev;
+  f->covs = covs_dev;
+  f->normals = normals_dev;
+  f->generation++;
   return GP_OK;
 }
 
@@ -805,7 +829,7 @@ int64_t gp_vgicp_batch_algorithmic_bytes(const gp_vgicp_batch_t* batch) {
 
 int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_dev) {
   if (!b || !poses_host || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_linearize: null");
-  if (b->table_dirty || b->variant != g_variant) GP_TRY(build_table(b));
+  if (table_is_stale(b)) GP_TRY(build_table(b));
   if (b->factors.empty()) return GP_OK;
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
@@ -814,7 +838,7 @@ int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* b, const double* poses_host
 
 int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_host, const double* poses_eval_host, double* out_dev) {
   if (!b || !poses_lin_host || !poses_eval_host || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_compute_error: null");
-  if (b->table_dirty || b->variant != g_variant) GP_TRY(build_table(b));
+  if (table_is_stale(b)) GP_TRY(build_table(b));
   if (b->factors.empty()) return GP_OK;
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_lin_host, poses_eval_host, &ps));
@@ -850,7 +874,7 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
 
 int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel) {
   if (!b || !poses_host || iters <= 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_time_linearize: bad arguments");
-  if (b->table_dirty || b->variant != g_variant) GP_TRY(build_table(b));
+  if (table_is_stale(b)) GP_TRY(build_table(b));
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
   gp::DeviceArray d_out;

@@ -263,6 +263,7 @@ int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float*
   hipStream_t s = m->stream;
   const double inv_leaf = 1.0 / m->resolution;
   m->offloaded = false;
+  m->generation++;
 
   // ---- create_bucket_table (:253-307): double the table until the drop rate is met ----
   gp::DeviceArray rep, counters;
@@ -438,6 +439,7 @@ int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, co
   m->info.num_voxels = num_voxels;
   m->info.num_buckets = (int)nb;
   m->offloaded = false;
+  m->generation++;
   hipStream_t s = m->stream;
   GP_TRY(m->buckets.alloc(sizeof(gp_voxel_bucket) * (size_t)nb));
   GP_TRY(alloc_voxel_arrays(m, num_voxels));
@@ -582,6 +584,7 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   m->voxel_coords.release();
   m->plines.release();
   m->offloaded = true;
+  m->generation++;
   return GP_OK;
 }
 
@@ -600,6 +603,7 @@ int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream) {
   GP_TRY(build_private_table(m, s));
   GP_HIP(hipStreamSynchronize(s));
   m->offloaded = false;
+  m->generation++;
   return GP_OK;
 }
 

@@ -214,6 +214,8 @@ class IntegratedVGICPFactorGPU(NonlinearFactorGPU):
             "gp_vgicp_factor_create",
         )
         self._h = h
+        self._enable_offloading = False
+        self._source_generation = source.generation
         self.linearized = False
         self.linearization_point = np.eye(4)
         self.evaluation_result = None
@@ -250,7 +252,25 @@ class IntegratedVGICPFactorGPU(NonlinearFactorGPU):
         _capi.check(self._lib.gp_vgicp_factor_set_inlier_update_thresh(self._h, float(trans), float(angle)), "set_inlier_update_thresh")
 
     def set_enable_offloading(self, enable):
+        """integrated_vgicp_factor_gpu.cpp:102-104: when set, target and source are touch()ed (= reloaded if an application
+        offloaded them) before every linearisation"""
         self._enable_offloading = bool(enable)
+
+    def touch_points(self):
+        """IntegratedVGICPDerivatives::touch_points (integrated_vgicp_derivatives.cu:63-78)"""
+        if self._enable_offloading:
+            self.target.touch(self.target.stream)
+            self.source.touch()
+        if self.source.generation != self._source_generation:
+            if self.source.points_gpu is None or self.source.covs_gpu is None:
+                raise _capi.GPError("error: GPU source points have not been allocated!!")
+            GaussianVoxelMapGPU._sync_torch(self.source)
+            _capi.check(
+                self._lib.gp_vgicp_factor_set_source(self._h, self.source.ptr(self.source.points_gpu), self.source.ptr(self.source.covs_gpu),
+                                                     self.source.ptr(self.source.normals_gpu)),
+                "gp_vgicp_factor_set_source",
+            )
+            self._source_generation = self.source.generation
 
     def num_inliers(self):
         return self._num_inliers
@@ -300,6 +320,7 @@ class IntegratedVGICPFactorGPU(NonlinearFactorGPU):
             self.linearization_result = None
         else:
             print("warning: performing linearization in sync mode seriously affects the processing speed!!", file=sys.stderr)
+            self.touch_points()
             rec = _capi.Linearized6()
             _capi.check(self._lib.gp_vgicp_factor_linearize(self._h, _pose16(self.linearization_point), C.byref(rec)), "gp_vgicp_factor_linearize")
             l = LinearizedSystem6(rec)
@@ -322,6 +343,7 @@ class IntegratedVGICPFactorGPU(NonlinearFactorGPU):
         return int(self._lib.gp_vgicp_evaluation_output_size())
 
     def set_linearization_point(self, values, lin_input_cpu):
+        self.touch_points()  # reset_inliers -> touch_points upstream (integrated_vgicp_derivatives_inliers.cu:47)
         lin_input_cpu[:] = np.ascontiguousarray(self.calc_delta(values).T).reshape(16)
 
     def set_evaluation_point(self, values, eval_input_cpu):

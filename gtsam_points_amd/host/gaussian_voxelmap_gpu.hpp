@@ -30,7 +30,7 @@ public:
   virtual void save_compact(const std::string& path) const = 0;
 };
 
-class GaussianVoxelMapGPU : public GaussianVoxelMap {
+class GaussianVoxelMapGPU : public GaussianVoxelMap, public OffloadableGPU {
 public:
   using Ptr = std::shared_ptr<GaussianVoxelMapGPU>;
   using ConstPtr = std::shared_ptr<const GaussianVoxelMapGPU>;
@@ -65,14 +65,15 @@ public:
     return map;
   }
 
-  size_t memory_usage_gpu() const { return gp_voxelmap_memory_usage_gpu(h); }
-  bool loaded_on_gpu() const { return gp_voxelmap_loaded_on_gpu(h) != 0; }
-  bool offload_gpu(ihipStream_t* s = nullptr) {
+  size_t memory_usage_gpu() const override { return gp_voxelmap_memory_usage_gpu(h); }
+  bool loaded_on_gpu() const override { return gp_voxelmap_loaded_on_gpu(h) != 0; }
+  bool offload_gpu(ihipStream_t* s = nullptr) override {
     const bool ok = gp_voxelmap_offload(h, s) == GP_OK;
     refresh();
     return ok;
   }
-  bool reload_gpu(ihipStream_t* s = nullptr) {
+  bool reload_gpu(ihipStream_t* s = nullptr) override {
+    if (loaded_on_gpu()) return false;  // gaussian_voxelmap_gpu.cu:509-511
     const bool ok = gp_voxelmap_reload(h, s) == GP_OK;
     refresh();
     return ok;

@@ -89,6 +89,7 @@ public:
       linearization_result.reset();
     } else {
       std::cerr << "warning: performing linearization in sync mode seriously affects the processing speed!!" << std::endl;
+      touch_points();
       check_error << gp_vgicp_factor_linearize(h, linearization_point.matrix().data(), &l);
       num_inliers_ = static_cast<int>(l.num_inliers);
     }
@@ -110,7 +111,23 @@ public:
   size_t evaluation_input_size() const override { return gp_vgicp_evaluation_input_size(); }
   size_t evaluation_output_size() const override { return gp_vgicp_evaluation_output_size(); }
 
+  // IntegratedVGICPDerivatives::touch_points (integrated_vgicp_derivatives.cu:63-78): with offloading enabled both operands are
+  // brought back to the GPU; a source cloud whose device arrays moved hands its new pointers to the factor handle
+  void touch_points() const {
+    if (enable_offloading) {
+      const_cast<GaussianVoxelMapGPU*>(target.get())->touch(nullptr);
+      if (auto src = dynamic_cast<const PointCloudGPU*>(source.get())) const_cast<PointCloudGPU*>(src)->touch(nullptr);
+    }
+    if (auto src = dynamic_cast<const PointCloudGPU*>(source.get())) {
+      if (src->generation != source_generation) {
+        check_error << gp_vgicp_factor_set_source(h, source->points_gpu, source->covs_gpu, source->normals_gpu);
+        source_generation = src->generation;
+      }
+    }
+  }
+
   void set_linearization_point(const gtsam::Values& values, void* lin_input_cpu) override {  // memcpy: no alignment assumed (:219-220)
+    touch_points();  // reset_inliers -> touch_points upstream (integrated_vgicp_derivatives_inliers.cu:47)
     const gtsam::Pose3 d = calc_delta(values);
     std::memcpy(lin_input_cpu, d.matrix().data(), sizeof(double) * 16);
   }
@@ -164,6 +181,7 @@ private:
     }
     check_error << gp_vgicp_factor_create(target->handle(), source->points_gpu, source->covs_gpu, source->normals_gpu, static_cast<int>(source->size()), stream,
                                           temp_buffer ? temp_buffer->handle() : nullptr, &h);
+    if (auto src = dynamic_cast<const PointCloudGPU*>(source.get())) source_generation = src->generation;
   }
 
   bool is_binary;
@@ -173,6 +191,7 @@ private:
   std::shared_ptr<TempBufferManager> temp_buffer;
   gp_vgicp_factor_t* h = nullptr;
   bool enable_offloading = false;
+  mutable std::uint64_t source_generation = 0;
   mutable bool linearized = false;
   mutable gtsam::Pose3 linearization_point;
   mutable int num_inliers_ = 0;

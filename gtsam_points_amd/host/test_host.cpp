@@ -127,6 +127,15 @@ int main() {
     CHECK(overlap_gpu(voxels, merged, I16.data()) > 0.9);  // both frames land on the target's surfaces
   }
 
+  // OffloadableGPU round trip on a cloud (the factor-level protocol is exercised further down)
+  {
+    const double before = overlap_gpu(voxels, source, T_true.matrix().data());
+    CHECK(source->loaded_on_gpu() && source->memory_usage_gpu() == (size_t)48 * N);
+    CHECK(source->offload_gpu() && !source->offload_gpu() && !source->loaded_on_gpu() && source->points_gpu == nullptr);
+    CHECK(source->touch() && source->loaded_on_gpu() && !source->reload_gpu());
+    CHECK(overlap_gpu(voxels, source, T_true.matrix().data()) == before);
+  }
+
   // factor through the round-robin pool + the linearisation hook, as the applications do
   LinearizationHook::register_hook([] { return create_nonlinear_factor_set_gpu(); });
   StreamTempBufferRoundRobin roundrobin(4);
@@ -185,6 +194,21 @@ int main() {
   // offload / reload
   CHECK(voxels->offload_gpu() && !voxels->loaded_on_gpu() && voxels->buckets == nullptr);
   CHECK(voxels->reload_gpu() && voxels->loaded_on_gpu());
+  // the factor-level protocol: both operands offloaded by the application, the factor brings them back and gets the same answer
+  {
+    hook.linearize(values);
+    auto ref_lin = std::dynamic_pointer_cast<gtsam::HessianFactor>(factor_b->linearize(values));
+    (void)factor->linearize(values);
+    factor->set_enable_offloading(true);
+    factor_b->set_enable_offloading(true);
+    CHECK(voxels->offload_gpu() && source->offload_gpu());
+    hook.linearize(values);
+    auto again = std::dynamic_pointer_cast<gtsam::HessianFactor>(factor_b->linearize(values));
+    (void)factor->linearize(values);
+    CHECK(voxels->loaded_on_gpu() && source->loaded_on_gpu());
+    for (int k = 0; k < 36; k++) CHECK(again->G11[k] == ref_lin->G11[k] && again->G22[k] == ref_lin->G22[k] && again->G12[k] == ref_lin->G12[k]);
+    CHECK(again->f == ref_lin->f);
+  }
   roundrobin.sync_all();
   std::printf("HOST_TEST_OK\n");
   return 0;

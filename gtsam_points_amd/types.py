@@ -23,20 +23,48 @@ def _pose16(T):
     return (C.c_double * 16)(*flat.tolist())
 
 
-class PointCloudGPU:
+class OffloadableGPU:
+    """types/offloadable.hpp:17-63, offloadable.cpp: a global access counter, `touch()` = remember the access and make sure
+    the data is on the GPU.  Applications sort their frames by last_accessed_time() to decide what to offload."""
+
+    _access_counter = 0
+
+    def __init__(self):
+        self._last_access = OffloadableGPU._access_counter
+
+    @staticmethod
+    def current_access_time():
+        return OffloadableGPU._access_counter
+
+    def last_accessed_time(self):
+        return self._last_access
+
+    def touch(self, stream=None):
+        self._last_access = OffloadableGPU._access_counter
+        OffloadableGPU._access_counter += 1
+        return self.reload_gpu(stream)
+
+
+class PointCloudGPU(OffloadableGPU):
     """Device attribute arrays in the reference layout (types/point_cloud.hpp:114-118):
     points_gpu float[N][3], covs_gpu float[N][9] (3x3 column-major, symmetric), normals_gpu float[N][3],
-    intensities_gpu float[N]."""
+    intensities_gpu float[N].  Like the reference class (a PointCloudCPU with device mirrors) it keeps the host arrays it was
+    given, so that offload_gpu() / reload_gpu() (types/point_cloud_gpu.cu:304-370) can drop and restore the device side."""
+
+    _ATTRS = ("points", "covs", "normals", "intensities")
 
     def __init__(self, points=None, covs=None, normals=None, intensities=None, device="cuda:0"):
         import torch
 
+        OffloadableGPU.__init__(self)
         self.device = torch.device(device)
         self.points_gpu = None
         self.covs_gpu = None
         self.normals_gpu = None
         self.intensities_gpu = None
         self.num_points = 0
+        self._host = {}       # attribute -> the host array as given (None for device-only attributes)
+        self.generation = 0   # bumped whenever the device arrays are re-allocated (factors re-read the pointers)
         if points is not None:
             self.add_points(points)
         if covs is not None:
@@ -95,7 +123,9 @@ class PointCloudGPU:
             self.points_gpu = self._upload(points[:, :3], 3)
         else:
             self.points_gpu = self._pack_upload(points, matrix=False)
+            self._host["points"] = np.asarray(points)
         self.num_points = int(self.points_gpu.shape[0])
+        self.generation += 1
 
     def add_covs(self, covs):  # add_covs_gpu: (N,3,3) or (N,4,4); (N,9) = already column-major rows
         if self._is_tensor(covs):
@@ -103,12 +133,16 @@ class PointCloudGPU:
             return
         c = np.asarray(covs)
         self.covs_gpu = self._upload(c, 9) if c.ndim == 2 else self._pack_upload(c, matrix=True)
+        self._host["covs"] = c
+        self.generation += 1
 
     def add_normals(self, normals):
         if self._is_tensor(normals):
             self.normals_gpu = self._upload(normals[:, :3], 3)
         else:
             self.normals_gpu = self._pack_upload(normals, matrix=False)
+            self._host["normals"] = np.asarray(normals)
+        self.generation += 1
 
     @staticmethod
     def from_device(points_gpu, covs_gpu=None, intensities_gpu=None):
@@ -118,10 +152,56 @@ class PointCloudGPU:
         pc.covs_gpu = covs_gpu
         pc.intensities_gpu = intensities_gpu
         pc.num_points = int(points_gpu.shape[0])
+        pc.generation += 1
         return pc
 
     def add_intensities(self, intensities):
         self.intensities_gpu = self._upload(intensities if self._is_tensor(intensities) else np.asarray(intensities).reshape(-1, 1), 1)
+        if not self._is_tensor(intensities):
+            self._host["intensities"] = np.asarray(intensities)
+        self.generation += 1
+
+    # ---- OffloadableGPU (types/point_cloud_gpu.cu:281-370) ----
+    def loaded_on_gpu(self):
+        return any(getattr(self, a + "_gpu") is not None for a in self._ATTRS)
+
+    def memory_usage_gpu(self):
+        width = {"points": 12, "covs": 36, "normals": 12, "intensities": 4}
+        return sum(width[a] * self.num_points for a in self._ATTRS if getattr(self, a + "_gpu") is not None)
+
+    def download(self, attr):
+        """download_points_gpu / _covs_gpu / _normals_gpu / _intensities_gpu (:221-279): the float device array, on the host"""
+        t = getattr(self, attr + "_gpu")
+        if t is None:
+            raise _capi.GPError(f"error: frame does not have {attr} on GPU!!")
+        a = t.cpu().numpy()
+        return a.reshape(-1, 3, 3).transpose(0, 2, 1).copy() if attr == "covs" else (a.reshape(-1) if attr == "intensities" else a)
+
+    def offload_gpu(self, stream=None):
+        """frees the device arrays (:304-336); returns False when there was nothing to offload.  An attribute that only ever
+        existed on the device (from_device) is downloaded first so that reload_gpu() can restore it."""
+        if not self.loaded_on_gpu():
+            return False
+        for a in self._ATTRS:
+            if getattr(self, a + "_gpu") is not None:
+                if self._host.get(a) is None:
+                    self._host[a] = self.download(a)
+                setattr(self, a + "_gpu", None)
+        self.generation += 1
+        return True
+
+    def reload_gpu(self, stream=None):
+        """re-uploads every attribute that has a host copy (:338-370); returns False when the cloud is already on the GPU"""
+        if self.loaded_on_gpu():
+            return False
+        host, self._host = self._host, {}
+        adders = {"points": self.add_points, "covs": self.add_covs, "normals": self.add_normals, "intensities": self.add_intensities}
+        reloaded = False
+        for a in self._ATTRS:
+            if host.get(a) is not None:
+                adders[a](host[a])
+                reloaded = True
+        return reloaded
 
     def size(self):
         return self.num_points
@@ -131,11 +211,12 @@ class PointCloudGPU:
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-class GaussianVoxelMapGPU:
+class GaussianVoxelMapGPU(OffloadableGPU):
     """GaussianVoxelMapGPU(resolution, init_num_buckets=8192*2, max_bucket_scan_count=10,
     target_points_drop_rate=1e-3, stream=0), types/gaussian_voxelmap_gpu.hpp:51-56."""
 
     def __init__(self, resolution, init_num_buckets=8192 * 2, max_bucket_scan_count=10, target_points_drop_rate=1e-3, stream=None, _handle=None):
+        OffloadableGPU.__init__(self)
         self._lib = _capi.load()
         self.stream = stream
         if _handle is not None:

@@ -212,6 +212,9 @@ typedef struct gp_vgicp_factor gp_vgicp_factor_t;
 int gp_vgicp_factor_create(const gp_voxelmap_t* target, const float* points_dev, const float* covs_dev, const float* normals_dev, int num_points, gp_stream_t stream, gp_temp_buffer_t* temp_buffer, gp_vgicp_factor_t** out);
 int gp_vgicp_factor_destroy(gp_vgicp_factor_t* f);
 int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable); /* set_enable_surface_validation */
+/* the source cloud's device arrays moved (PointCloudGPU::offload_gpu + reload_gpu, types/point_cloud_gpu.cu:304-370):
+ * hand the factor the new pointers; every batch holding the factor rebuilds its table on the next issue */
+int gp_vgicp_factor_set_source(gp_vgicp_factor_t* f, const float* points_dev, const float* covs_dev, const float* normals_dev);
 int gp_vgicp_factor_set_inlier_update_thresh(gp_vgicp_factor_t* f, double trans, double angle); /* kept for API parity; every linearise rescans all points */
 int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f);
 gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f);

@@ -142,6 +142,43 @@ def test_unaligned_source_views(gpu, kitti00):
     del torch
 
 
+def test_offloading_protocol(gpu, kitti00):
+    """OffloadableGPU (types/offloadable.hpp, point_cloud_gpu.cu:281-370, gaussian_voxelmap_gpu.cu:474-535,
+    integrated_vgicp_derivatives.cu:63-78): an application may offload a factor's source cloud and target map between
+    optimisations; with set_enable_offloading(true) the factor touch()es both back in before linearising, and the result is
+    the one from before the round trip.  Without it, an offloaded map is an error, never a read of freed memory."""
+    _, src, vm = _build(gpu, kitti00, 0.5)
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    values = {0: np.eye(4), 1: delta}
+    fset = gpu.NonlinearFactorSetGPU()
+    fset.add(f)
+    fset.linearize(values)
+    before = f.linearize(values)
+    bytes_src, bytes_map = src.memory_usage_gpu(), vm.memory_usage_gpu()
+    assert src.loaded_on_gpu() and vm.loaded_on_gpu() and bytes_src == 48 * src.size() and bytes_map > 0
+    assert src.offload_gpu() and not src.offload_gpu()  # second call: nothing left to offload (:305-307)
+    assert vm.offload_gpu() and not vm.loaded_on_gpu() and not src.loaded_on_gpu() and src.memory_usage_gpu() == 0
+    with pytest.raises(gpu.GPError):
+        fset.linearize(values)  # offloading not enabled on the factor: reported, not dereferenced
+    f.set_enable_offloading(True)
+    t0 = gpu.types.OffloadableGPU.current_access_time()
+    fset.linearize(values)
+    after = f.linearize(values)
+    assert src.loaded_on_gpu() and vm.loaded_on_gpu() and src.memory_usage_gpu() == bytes_src
+    assert gpu.types.OffloadableGPU.current_access_time() == t0 + 2 and src.last_accessed_time() == t0 + 1 and vm.last_accessed_time() == t0
+    for (_, a), (_, b) in zip(sorted(before.G.items()), sorted(after.G.items())):
+        assert np.array_equal(a, b)
+    assert all(np.array_equal(a, b) for a, b in zip(before.g, after.g)) and before.f == after.f
+    assert not src.reload_gpu() and not vm.reload_gpu()  # already on the GPU (:339-341, gaussian_voxelmap_gpu.cu:509-511)
+    np.testing.assert_array_equal(src.download("points"), kitti00["source_points"])
+    np.testing.assert_array_equal(src.download("covs"), kitti00["source_covs"])
+    # a device-only cloud (adopted arrays) survives the round trip too
+    dev_only = gpu.PointCloudGPU.from_device(src.points_gpu.clone(), src.covs_gpu.clone())
+    assert dev_only.offload_gpu() and dev_only.reload_gpu()
+    np.testing.assert_array_equal(dev_only.download("points"), kitti00["source_points"])
+
+
 def test_factor_set_batch_equals_per_factor_and_oracle(gpu, kitti07):
     """NonlinearFactorSetGPU fast path (one batched launch) == per-factor sync path == oracle; error() after linearize()"""
     poses = kitti07["poses"]
