@@ -142,6 +142,54 @@ def test_unaligned_source_views(gpu, kitti00):
     del torch
 
 
+def _coord_hash32(x, y, z):
+    """gp_device.hpp coord_hash32, restated to construct colliding voxels"""
+    m = 0xFFFFFFFF
+    h = ((x & m) * 73856093 ^ (y & m) * 19349669 ^ (z & m) * 83492791) & m
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & m
+    h ^= h >> 12
+    h = (h * 0x297A2D39) & m
+    h ^= h >> 15
+    return h
+
+
+def test_line_table_overflow_walks_on(gpu):
+    """the pipeline kernel's line table holds 4 keys per home line; seven voxels built to share one home line force the
+    walk-on path (full line, no match -> next line) for hits, and a probe of the same full line for a voxel that does not
+    exist must end as a miss.  Checked against the oracle, which uses an exact hash map."""
+    rng = np.random.default_rng(21)
+    lines = 256  # >= 2 * num_voxels for the 8 voxels below
+    cands = [(x, y, z) for x in range(-12, 12) for y in range(-12, 12) for z in range(-3, 3)]
+    by_line = {}
+    for c in cands:
+        by_line.setdefault(_coord_hash32(*c) & (lines - 1), []).append(c)
+    group = max(by_line.values(), key=len)
+    assert len(group) >= 9
+    present, absent = group[:7], group[7:9]
+    res = 0.5
+    tgt_pts, src_pts = [], []
+    for c in present + [(50, 50, 50)]:  # the 8th voxel lives elsewhere
+        tgt_pts.append((np.array(c) + rng.uniform(0.2, 0.8, (40, 3))) * res)
+    for c in present + absent:
+        src_pts.append((np.array(c) + rng.uniform(0.05, 0.95, (96, 3))) * res)
+    tgt_pts, src_pts = np.concatenate(tgt_pts).astype(np.float32), np.concatenate(src_pts).astype(np.float32)
+
+    def covs(n):
+        a = rng.normal(size=(n, 3, 3))
+        return (a @ a.transpose(0, 2, 1) * 0.01 + 1e-3 * np.eye(3)).astype(np.float32)
+
+    d = dict(target_points=tgt_pts, target_covs=covs(len(tgt_pts)), source_points=src_pts, source_covs=covs(len(src_pts)))
+    _, src, vm = _build(gpu, d, res)
+    assert vm.voxelmap_info.num_voxels == 8
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    _, fo = _oracle(d, res, 1)
+    Lo = fo.linearize(np.eye(4))
+    L = _sync_linearize(gpu, f, np.eye(4))
+    assert Lo.num_inliers == 7 * 96 and L.num_inliers == Lo.num_inliers  # every present voxel found, the absent ones missed
+    assert_linearized_close(L, Lo, PARITY_TOL, "colliding voxels")
+
+
 def test_offloading_protocol(gpu, kitti00):
     """OffloadableGPU (types/offloadable.hpp, point_cloud_gpu.cu:281-370, gaussian_voxelmap_gpu.cu:474-535,
     integrated_vgicp_derivatives.cu:63-78): an application may offload a factor's source cloud and target map between
