@@ -49,10 +49,48 @@ struct DeviceArray {
     return GP_OK;
   }
   int ensure(size_t n) { return (n <= bytes && ptr) ? GP_OK : alloc(n + n / 5); }
+  // stream-ordered allocation from the device's default memory pool (cudaMallocAsync upstream, cuda/cuda_malloc_async.hpp):
+  // for short-lived scratch -- a pooled block is reused by the next call instead of going through hipMalloc / hipFree, which
+  // cost more than the kernels they serve.  The block may only be used by work ordered after this call on `stream`.
+  int alloc_async(size_t n, hipStream_t stream) {
+    release();
+    if (n == 0) n = 16;
+    keep_pool_memory();
+    hipError_t e = hipMallocAsync(&ptr, n, stream);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return hip_fail(e, "hipMallocAsync", __FILE__, __LINE__);
+    }
+    bytes = n;
+    pooled = true;
+    pool_stream = stream;
+    return GP_OK;
+  }
   void release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr) {
+      if (pooled) {
+        (void)hipFreeAsync(ptr, pool_stream);
+      } else {
+        (void)hipFree(ptr);
+      }
+    }
     ptr = nullptr;
     bytes = 0;
+    pooled = false;
+  }
+  bool pooled = false;
+  hipStream_t pool_stream = nullptr;
+  // the default pool hands memory back to the driver at every synchronisation unless told to keep it
+  static void keep_pool_memory() {
+    static thread_local int configured_device = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev == configured_device) return;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+      uint64_t threshold = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+    }
+    configured_device = dev;
   }
   template <typename T>
   T* as() const {

@@ -12,6 +12,8 @@
 // f64 on the f32 inputs (as the reference does on PointCloudCPU's doubles), so the neighbour SET equals the kd-tree's
 // except for exact ties at the k-th distance (where the reference's own result depends on traversal order).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -62,7 +64,8 @@ __global__ void __launch_bounds__(256) grid_insert_kernel(const float* __restric
   const int j = i < n ? i : n - 1;  // the tail lanes repeat the last point so that the wave-wide min/max below needs no masking
   const int cx = fast_floor((double)points[3 * (size_t)j] * inv_h), cy = fast_floor((double)points[3 * (size_t)j + 1] * inv_h),
             cz = fast_floor((double)points[3 * (size_t)j + 2] * inv_h);
-  // bounding box of the occupied cells (bounds every query's cube radius): wave min/max, then 6 atomics per wave
+  // bounding box of the occupied cells (bounds every query's cube radius): wave min/max, one row per workgroup, reduced by
+  // bbox_reduce_kernel (atomics on six shared words serialise ~100 k operations per level: measured 1 ms)
   int lo[3] = {cx, cy, cz}, hi[3] = {cx, cy, cz};
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
@@ -71,12 +74,19 @@ __global__ void __launch_bounds__(256) grid_insert_kernel(const float* __restric
       lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
       hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
     }
+  __shared__ int wave_box[4][6];
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      atomicMin(bbox + a, lo[a]);
-      atomicMax(bbox + 3 + a, hi[a]);
+      wave_box[threadIdx.x >> 6][a] = lo[a];
+      wave_box[threadIdx.x >> 6][3 + a] = hi[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int v = wave_box[0][threadIdx.x];
+    for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? min(v, wave_box[w][threadIdx.x]) : max(v, wave_box[w][threadIdx.x]);
+    bbox[6 * (size_t)blockIdx.x + threadIdx.x] = v;
   }
   if (i >= n) return;
   const unsigned long long key = pack_cell(cx, cy, cz);
@@ -88,6 +98,28 @@ __global__ void __launch_bounds__(256) grid_insert_kernel(const float* __restric
   }
   point_slot[i] = (int)s;
   atomicAdd(&counts[s], 1);
+}
+
+// per-workgroup boxes [nb][6] -> one box
+__global__ void __launch_bounds__(256) bbox_reduce_kernel(const int* __restrict__ block_boxes, int nb, int* __restrict__ bbox) {
+  __shared__ int part[256][6];
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int b = threadIdx.x; b < nb; b += 256)
+    for (int a = 0; a < 3; a++) {
+      lo[a] = min(lo[a], block_boxes[6 * (size_t)b + a]);
+      hi[a] = max(hi[a], block_boxes[6 * (size_t)b + 3 + a]);
+    }
+  for (int a = 0; a < 3; a++) {
+    part[threadIdx.x][a] = lo[a];
+    part[threadIdx.x][3 + a] = hi[a];
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+      for (int a = 0; a < 6; a++) part[threadIdx.x][a] = a < 3 ? min(part[threadIdx.x][a], part[threadIdx.x + w][a]) : max(part[threadIdx.x][a], part[threadIdx.x + w][a]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) bbox[threadIdx.x] = part[0][threadIdx.x];
 }
 
 // exclusive scan of counts[0..m) -> start[0..m], three small kernels (block sums, scan of block sums, add)
@@ -548,10 +580,11 @@ static uint32_t level_slots(int n) {
 static size_t level_scratch_bytes(int n) {
   const uint32_t slots = level_slots(n);
   const size_t nb = (slots + gp::kScanBlock - 1) / gp::kScanBlock;
-  return 2 * align256(sizeof(int) * slots) + align256(sizeof(int) * (size_t)std::max(n, 1)) + align256(sizeof(int) * nb) + 2 * align256(64);
+  return 2 * align256(sizeof(int) * slots) + align256(sizeof(int) * (size_t)std::max(n, 1)) + align256(sizeof(int) * nb) + align256(64) +
+         align256(sizeof(int) * 6 * (((size_t)std::max(n, 1) + 255) / 256));
 }
 
-static int build_level(const float* points_dev, int n, double cell_size, hipStream_t s, char* scratch, gp_grid_level** out) {
+static int build_level(const float* points_dev, int n, double cell_size, hipStream_t s, char* scratch, int* bbox, gp_grid_level** out) {
   auto* g = new gp_grid_level;
   g->n = n;
   g->h = cell_size;
@@ -560,7 +593,7 @@ static int build_level(const float* points_dev, int n, double cell_size, hipStre
   const int nb = (int)((slots + gp::kScanBlock - 1) / gp::kScanBlock);
   const size_t keys_b = align256(sizeof(unsigned long long) * slots), start_b = align256(sizeof(int) * ((size_t)slots + 1)),
                sorted_b = align256(sizeof(float4) * (size_t)std::max(n, 1));
-  const int rc = g->arena.alloc(keys_b + start_b + sorted_b);
+  const int rc = g->arena.alloc_async(keys_b + start_b + sorted_b, s);
   if (rc != GP_OK) {
     delete g;
     return rc;
@@ -582,13 +615,13 @@ static int build_level(const float* points_dev, int n, double cell_size, hipStre
   cur += align256(sizeof(int) * (size_t)nb);
   int* total = reinterpret_cast<int*>(cur);
   cur += align256(64);
-  int* bbox = reinterpret_cast<int*>(cur);
+  int* block_boxes = reinterpret_cast<int*>(cur);
   GP_HIP(hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * slots, s));
   GP_HIP(hipMemsetAsync(counts, 0, 2 * align256(sizeof(int) * slots), s));  // counts and cursor are adjacent
-  int h_bbox[6] = {1 << 30, 1 << 30, 1 << 30, -(1 << 30), -(1 << 30), -(1 << 30)};
-  GP_HIP(hipMemcpyAsync(bbox, h_bbox, sizeof(h_bbox), hipMemcpyHostToDevice, s));
   if (n > 0) {
-    hipLaunchKernelGGL(gp::grid_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, 1.0 / cell_size, keys, counts, point_slot, g->mask, bbox);
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(gp::grid_insert_kernel, dim3(blocks), dim3(256), 0, s, points_dev, n, 1.0 / cell_size, keys, counts, point_slot, g->mask, block_boxes);
+    hipLaunchKernelGGL(gp::bbox_reduce_kernel, dim3(1), dim3(256), 0, s, block_boxes, blocks, bbox);
   }
   hipLaunchKernelGGL(gp::scan_block_kernel, dim3(nb), dim3(gp::kScanBlock), 0, s, counts, start, block_sums, (int)slots);
   hipLaunchKernelGGL(gp::scan_sums_kernel, dim3(1), dim3(gp::kScanBlock), 0, s, block_sums, nb, total);
@@ -597,14 +630,7 @@ static int build_level(const float* points_dev, int n, double cell_size, hipStre
     hipLaunchKernelGGL(gp::grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, point_slot, start, cursor, sorted);
   }
   GP_HIP(hipGetLastError());
-  GP_HIP(hipMemcpyAsync(h_bbox, bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, s));
-  GP_HIP(hipStreamSynchronize(s));  // h_bbox is read below; the scratch is reused by the next level
-  if (n > 0) {
-    for (int a = 0; a < 3; a++) {
-      g->lo[a] = h_bbox[a];
-      g->hi[a] = h_bbox[3 + a];
-    }
-  }
+  // no synchronisation here: the next level reuses the scratch in stream order; the caller fetches all bounding boxes at once
   *out = g;
   return GP_OK;
 }
@@ -621,7 +647,16 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   const int num_levels = n > 4096 ? gp::kMaxLevels : 1;
   gp::DeviceArray scratch;
   {
-    const int rc = scratch.alloc(level_scratch_bytes(n));
+    const int rc = scratch.alloc_async(level_scratch_bytes(n), g->stream);
+    if (rc != GP_OK) {
+      delete g;
+      return rc;
+    }
+  }
+  gp::DeviceArray d_bbox;
+  int h_bbox[6 * gp::kMaxLevels];
+  {
+    const int rc = d_bbox.alloc_async(sizeof(int) * 6 * gp::kMaxLevels, g->stream);
     if (rc != GP_OK) {
       delete g;
       return rc;
@@ -630,18 +665,37 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   double h = cell_size;
   for (int l = 0; l < num_levels; l++, h *= 4.0) {
     gp_grid_level* lv = nullptr;
-    const int rc = build_level(points_dev, n, h, g->stream, scratch.as<char>(), &lv);
+    const int rc = build_level(points_dev, n, h, g->stream, scratch.as<char>(), d_bbox.as<int>() + 6 * l, &lv);
     if (rc != GP_OK) {
       delete g;
       return rc;
     }
     g->levels.emplace_back(lv);
   }
+  // one copy + one synchronisation for the whole structure (the scratch and d_bbox go back to the pool on return)
+  hipError_t e = hipMemcpyAsync(h_bbox, d_bbox.ptr, sizeof(int) * 6 * (size_t)num_levels, hipMemcpyDeviceToHost, g->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+  if (e != hipSuccess) {
+    delete g;
+    return gp::hip_fail(e, "gp_point_grid_create", __FILE__, __LINE__);
+  }
+  if (n > 0) {
+    const int* hb = h_bbox;
+    for (int l = 0; l < num_levels; l++)
+      for (int a = 0; a < 3; a++) {
+        g->levels[l]->lo[a] = hb[6 * l + a];
+        g->levels[l]->hi[a] = hb[6 * l + 3 + a];
+      }
+  }
   *out = g;
   return GP_OK;
 }
 
 int gp_point_grid_destroy(gp_point_grid_t* g) {
+  if (!g) return GP_OK;
+  // the arenas come from the stream-ordered pool and are returned to it in the order of the creation stream: searches issued
+  // on other streams must have finished first (hipFree used to imply this)
+  (void)hipDeviceSynchronize();
   delete g;
   return GP_OK;
 }
@@ -671,7 +725,7 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   gp_point_grid_t* g = nullptr;
   GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.125, stream, &g));
   gp::DeviceArray d_short;
-  int rc = d_short.alloc(sizeof(int));
+  int rc = d_short.alloc_async(sizeof(int), s);
   if (rc == GP_OK) {
     (void)hipMemsetAsync(d_short.ptr, 0, sizeof(int), s);
     const gp::MultiGridView v = g->view();
