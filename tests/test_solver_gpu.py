@@ -103,6 +103,37 @@ def test_larger_random_spd_system(gpu):
     assert np.linalg.norm(x - xh) <= 1e-9 * np.linalg.norm(xh)
 
 
+def test_unary_only_and_single_pose_systems(gpu):
+    """factors whose target is fixed contribute H_source / b_source only (the unary HessianFactor of
+    integrated_vgicp_factor_gpu.cpp:210-213); a one-pose system is a single 6x6 solve"""
+    import torch
+
+    rng = np.random.default_rng(9)
+    rec = np.zeros((5, 122))
+    for k in range(5):
+        J = rng.normal(size=(30, 12))
+        H = J.T @ J
+        rec[k, 0], rec[k, 1] = 30, 1.0 + k
+        rec[k, 2:38], rec[k, 38:74], rec[k, 74:110] = H[:6, :6].T.reshape(36), H[6:, 6:].T.reshape(36), H[:6, 6:].T.reshape(36)
+        rec[k, 110:122] = rng.normal(size=12)
+    rec_dev = torch.from_numpy(rec).cuda()
+    slots = [(-1, 0), (-1, 1), (-1, 2), (-1, 0), (-1, 2)]
+    A, b, c = gpu.DenseLinearSystemGPU(3, slots).build(rec_dev).download()
+    Ah, bh, ch = _host_system(rec, slots, 3)
+    assert np.allclose(A, Ah, rtol=1e-13, atol=0) and np.allclose(b, bh, rtol=1e-13) and abs(c - ch) < 1e-12
+    assert np.abs(A[:6, 6:]).max() == 0.0  # no coupling between poses
+    x = gpu.DenseLinearSystemGPU(3, slots).build(rec_dev).solve()
+    assert np.linalg.norm(x - np.linalg.solve(Ah, bh)) <= 1e-10 * np.linalg.norm(x)
+    one = gpu.DenseLinearSystemGPU(1, [(-1, 0)])
+    x1 = one.build(rec_dev[:1].contiguous()).solve()
+    A1, b1, _ = _host_system(rec[:1], [(-1, 0)], 1)
+    assert np.linalg.norm(x1 - np.linalg.solve(A1, b1)) <= 1e-11 * np.linalg.norm(x1)
+    with pytest.raises(gpu.GPError):
+        gpu.DenseLinearSystemGPU(2, [(0, 0)])  # a factor needs two different poses
+    with pytest.raises(gpu.GPError):
+        gpu.DenseLinearSystemGPU(2, [(0, 2)])  # slot out of range
+
+
 def test_lm_with_device_solve_reaches_the_alignment_gate(gpu, kitti07):
     """the reference's alignment gate (test_matching_cost_factors.cpp:227: < 0.015 rad / 0.15 m) with every linear algebra
     step of the LM loop on the GPU: batched linearise -> records in HBM -> device assembly + damping + Cholesky"""
