@@ -438,19 +438,24 @@ __device__ __forceinline__ void chunk_dma_asm(const GP_GLOBAL float* points, con
   const GP_GLOBAL char* a1 = gc + (lane + 16) * 16;
   const GP_GLOBAL char* a2 = gc + (lane + 80) * 16;
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(GP_LDS char*)stage);
+  uint32_t saved_m0;
+  // M0 carries the LDS base of an LDS-DMA instruction; it is a reserved register for the compiler, so it is saved and restored
+  // around the three requests instead of being declared clobbered
   asm volatile(
-    "s_mov_b32 m0, %3\n\t"
-    "s_nop 0\n\t"
-    "global_load_lds_dwordx4 %0, off\n\t"
-    "s_add_i32 m0, %3, 0x400\n\t"
+    "s_mov_b32 %0, m0\n\t"
+    "s_mov_b32 m0, %4\n\t"
     "s_nop 0\n\t"
     "global_load_lds_dwordx4 %1, off\n\t"
-    "s_add_i32 m0, %3, 0x800\n\t"
+    "s_add_i32 m0, %4, 0x400\n\t"
     "s_nop 0\n\t"
-    "global_load_lds_dwordx4 %2, off"
-    :
+    "global_load_lds_dwordx4 %2, off\n\t"
+    "s_add_i32 m0, %4, 0x800\n\t"
+    "s_nop 0\n\t"
+    "global_load_lds_dwordx4 %3, off\n\t"
+    "s_mov_b32 m0, %0"
+    : "=&s"(saved_m0)
     : "v"(a0), "v"(a1), "v"(a2), "s"(lds0)
-    : "memory", "m0");
+    : "memory");
 }
 
 template <int MODE, bool OUTER_F32, int PPT>
