@@ -723,7 +723,7 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   if (n == 0) return GP_OK;
   hipStream_t s = (hipStream_t)stream;
   gp_point_grid_t* g = nullptr;
-  GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.125, stream, &g));
+  GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, stream, &g));
   gp::DeviceArray d_short;
   int rc = d_short.alloc_async(sizeof(int), s);
   if (rc == GP_OK) {
@@ -753,8 +753,8 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
     return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_create: bad arguments");
   auto* f = new gp_gicp_factor;
   f->stream = (hipStream_t)stream;
-  // finest cell = 1/8 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
-  int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 8.0, stream, &f->grid);
+  // finest cell = 1/4 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
+  int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 4.0, stream, &f->grid);
   if (rc != GP_OK) {
     delete f;
     return rc;

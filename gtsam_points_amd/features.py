@@ -16,7 +16,7 @@ from .types import GaussianVoxelMapGPU, PointCloudGPU, _pose16
 class KdTreeGPU:
     """Exact nearest-neighbour search structure over a PointCloudGPU (KdTree::knn_search semantics)."""
 
-    def __init__(self, frame: PointCloudGPU, cell_size=0.125, stream=None):
+    def __init__(self, frame: PointCloudGPU, cell_size=0.25, stream=None):
         self._lib = _capi.load()
         self.frame = frame
         GaussianVoxelMapGPU._sync_torch(frame)
