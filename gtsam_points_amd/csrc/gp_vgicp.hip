@@ -270,7 +270,10 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   (void)NACC;
   const int t = threadIdx.x;
   const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
-  double* dst = reinterpret_cast<double*>(out + fi);  // may be only 8-byte aligned (integrated_vgicp_factor_gpu.cpp:219-220)
+  // the record is assembled in LDS and leaves in one coalesced sweep of 8-byte stores at the end: when `out` is host-mapped
+  // memory, ~130 scattered stores would each be their own PCIe write
+  __shared__ double dst[122];
+  double* out_rec = reinterpret_cast<double*>(out + fi);  // may be only 8-byte aligned (integrated_vgicp_factor_gpu.cpp:219-220)
   constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
   const Pose T = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);
   if (t < 36) {
@@ -352,6 +355,8 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
     }
     if (t < 6) dst[OFF_BS + t] = sum[ACCG_BS + t];
   }
+  __syncthreads();
+  if (t < 122) out_rec[t] = dst[t];
 }
 
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
