@@ -12,7 +12,7 @@
 // system, exactly as a constant drops out of a GaussianFactorGraph).  Assembly is a GATHER: the host turns the factor key
 // list into one contribution list per destination 6x6 block, so every block is summed in a fixed order (deterministic, no
 // atomics).  The solve is a dense blocked Cholesky (LL^T, 6x6 blocks = one pose) in f64 held in HBM: per block column one
-// small kernel for the diagonal block, one for the panel below it, one grid-wide rank-6 update of the trailing matrix; then
+// kernel for the diagonal block and the panel below it, one grid-wide rank-6 update of the trailing matrix; then
 // forward / backward substitution in one workgroup.  Dense O(n^3): meant for the hundreds of poses of a submap graph, not
 // tuned (the block-sparse factorisation is the obvious next step).
 #include <algorithm>
@@ -102,42 +102,45 @@ __global__ void __launch_bounds__(256) damp_kernel(double* __restrict__ A, int n
 }
 
 // ---- blocked Cholesky, block size 6 -------------------------------------------------------------------------------
-// L_kk in place of A_kk (lower triangle; the strict upper part of the block is left untouched and never read)
-__global__ void __launch_bounds__(64) chol_diag_kernel(double* __restrict__ A, int n, int k, int* __restrict__ status) {
-  __shared__ double a[6][6];
-  const int t = threadIdx.x;
-  double* base = A + (size_t)(6 * k) * n + 6 * k;
-  if (t < 36) a[t % 6][t / 6] = base[(size_t)(t / 6) * n + t % 6];
-  __syncthreads();
-  if (t == 0) {
-    for (int j = 0; j < 6; j++) {
-      double d = a[j][j];
-      for (int p = 0; p < j; p++) d -= a[j][p] * a[j][p];
-      if (!(d > 0.0)) {
-        atomicExch(status, k + 1);  // not positive definite at this pose block (IndeterminantLinearSystemException upstream)
-        d = 1.0;
-      }
-      const double l = sqrt(d);
-      a[j][j] = l;
-      for (int i = j + 1; i < 6; i++) {
-        double s = a[i][j];
-        for (int p = 0; p < j; p++) s -= a[i][p] * a[j][p];
-        a[i][j] = s / l;
-      }
+// One launch per block column k does both the diagonal block and the panel below it: workgroup 0 factors A_kk into Ldiag[k];
+// workgroup i - k (block row i > k) factors A_kk once more for itself (6x6: ~100 flops, cheaper than a kernel boundary) and
+// turns A_ik into L_ik = A_ik L_kk^-T in place.  A_kk itself is left untouched, so the redundant factorisations all read the
+// same data; the substitution kernel takes the diagonal blocks from Ldiag.
+__device__ __forceinline__ bool chol6(double (*a)[6]) {  // in place, lower triangle; false when a pivot is not positive
+  bool ok = true;
+  for (int j = 0; j < 6; j++) {
+    double d = a[j][j];
+    for (int p = 0; p < j; p++) d -= a[j][p] * a[j][p];
+    if (!(d > 0.0)) {
+      ok = false;
+      d = 1.0;
+    }
+    const double l = sqrt(d);
+    a[j][j] = l;
+    for (int i = j + 1; i < 6; i++) {
+      double s = a[i][j];
+      for (int p = 0; p < j; p++) s -= a[i][p] * a[j][p];
+      a[i][j] = s / l;
     }
   }
-  __syncthreads();
-  if (t < 36 && t % 6 >= t / 6) base[(size_t)(t / 6) * n + t % 6] = a[t % 6][t / 6];
+  return ok;
 }
 
-// L_ik = A_ik L_kk^-T for every block row i > k: one 64-thread workgroup per block, one thread per row of the block
-__global__ void __launch_bounds__(64) chol_panel_kernel(double* __restrict__ A, int n, int k) {
+__global__ void __launch_bounds__(64) chol_panel_kernel(double* __restrict__ A, int n, int k, double* __restrict__ Ldiag, int* __restrict__ status) {
   __shared__ double l[6][6];
   const int t = threadIdx.x;
   const double* diag = A + (size_t)(6 * k) * n + 6 * k;
   if (t < 36) l[t % 6][t / 6] = diag[(size_t)(t / 6) * n + t % 6];
   __syncthreads();
-  const int i = k + 1 + blockIdx.x;
+  if (t == 0) {
+    if (!chol6(l) && blockIdx.x == 0) atomicExch(status, k + 1);  // not positive definite at this pose block
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (t < 36) Ldiag[36 * (size_t)k + t] = (t % 6 >= t / 6) ? l[t % 6][t / 6] : 0.0;  // column-major 6x6, lower triangle
+    return;
+  }
+  const int i = k + blockIdx.x;
   if (t < 6) {
     double* row = A + (size_t)(6 * k) * n + 6 * i + t;  // element (6i + t, 6k + c) at row[c * n]
     double x[6];
@@ -150,29 +153,44 @@ __global__ void __launch_bounds__(64) chol_panel_kernel(double* __restrict__ A, 
   }
 }
 
-// trailing update A_ij -= L_ik L_jk^T for k < j <= i: the lower triangle of the (P-k-1)^2 blocks, 36 threads per block
-__global__ void __launch_bounds__(64) chol_update_kernel(double* __restrict__ A, int n, int k, int m /* = P - k - 1 */) {
-  // blockIdx.x enumerates the lower triangle of an m x m block grid row by row
+// trailing update A_ij -= L_ik L_jk^T for k < j <= i.  One 256-thread workgroup per 8x8 tile of pose blocks (48 x 48 entries) of the
+// lower triangle: the two 48 x 6 panels go through LDS once and every thread produces 9 entries.
+// TB = pose blocks per tile edge: 8 for a large trailing matrix, 1 (one 6x6 block per 64-thread workgroup) when it is small and
+// parallelism matters more than panel reuse
+template <int TB>
+__global__ void __launch_bounds__(TB == 1 ? 64 : 256) chol_update_kernel(double* __restrict__ A, int n, int k, int m /* = P - k - 1 */) {
+  constexpr int E = 6 * TB;
+  __shared__ double Li[E][7], Lj[E][7];  // padded rows: conflict-free column access
+  // blockIdx.x enumerates the lower triangle of the tile grid row by row
   const int q = blockIdx.x;
-  int bi = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-  while ((bi + 1) * (bi + 2) / 2 <= q) bi++;
-  while (bi * (bi + 1) / 2 > q) bi--;
-  const int bj = q - bi * (bi + 1) / 2;
-  const int i = k + 1 + bi, j = k + 1 + bj;
-  const int t = threadIdx.x;
-  if (t >= 36) return;
-  const int r = t % 6, c = t / 6;
-  const double* li = A + (size_t)(6 * k) * n + 6 * i + r;  // L(6i + r, 6k + p) at li[p * n]
-  const double* lj = A + (size_t)(6 * k) * n + 6 * j + c;
-  double s = 0.0;
+  int ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
+  while (ti * (ti + 1) / 2 > q) ti--;
+  const int tj = q - ti * (ti + 1) / 2;
+  const int row0 = 6 * (k + 1) + E * ti, col0 = 6 * (k + 1) + E * tj;  // first matrix row / column of the tile
+  const int rows = min(E, n - row0), cols = min(E, n - col0);
+  const double* panel = A + (size_t)(6 * k) * n;  // L(r, 6k + p) at panel[p * n + r]
+  for (int e = threadIdx.x; e < E * 6; e += (int)blockDim.x) {
+    const int r = e % E, p = e / E;
+    Li[r][p] = r < rows ? panel[(size_t)p * n + row0 + r] : 0.0;
+    Lj[r][p] = r < cols ? panel[(size_t)p * n + col0 + r] : 0.0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E * E; e += (int)blockDim.x) {
+    const int r = e % E, c = e / E;
+    if (r >= rows || c >= cols) continue;
+    if (ti == tj && (row0 + r) / 6 < (col0 + c) / 6) continue;  // strictly upper pose blocks of a diagonal tile are never read
+    double s = 0.0;
 #pragma unroll
-  for (int p = 0; p < 6; p++) s += li[(size_t)p * n] * lj[(size_t)p * n];
-  A[(size_t)(6 * j + c) * n + 6 * i + r] -= s;
+    for (int p = 0; p < 6; p++) s += Li[r][p] * Lj[c][p];
+    A[(size_t)(col0 + c) * n + row0 + r] -= s;
+  }
 }
 
 // forward then backward substitution in one workgroup: x <- L^-T L^-1 b   (n <= 6 * kMaxSlots)
 constexpr int kSolveThreads = 384;  // 6 rows x 64 lanes
-__global__ void __launch_bounds__(kSolveThreads) chol_solve_kernel(const double* __restrict__ A, int n, int P, const double* __restrict__ b, double* __restrict__ x) {
+__global__ void __launch_bounds__(kSolveThreads) chol_solve_kernel(const double* __restrict__ A, const double* __restrict__ Ldiag, int n, int P,
+                                                                   const double* __restrict__ b, double* __restrict__ x) {
   extern __shared__ double y[];  // n doubles
   __shared__ double rhs[6];
   const int t = threadIdx.x, row = t / 64, lane = t % 64;
@@ -186,12 +204,12 @@ __global__ void __launch_bounds__(kSolveThreads) chol_solve_kernel(const double*
     if (lane == 0) rhs[row] = y[6 * k + row] - s;
     __syncthreads();
     if (t == 0) {
-      const double* d = A + (size_t)(6 * k) * n + 6 * k;
+      const double* d = Ldiag + 36 * (size_t)k;  // L_kk(r, p) at d[p * 6 + r]
       double v[6];
       for (int r = 0; r < 6; r++) {
         double q = rhs[r];
-        for (int p = 0; p < r; p++) q -= d[(size_t)p * n + r] * v[p];
-        v[r] = q / d[(size_t)r * n + r];
+        for (int p = 0; p < r; p++) q -= d[p * 6 + r] * v[p];
+        v[r] = q / d[r * 6 + r];
       }
       for (int r = 0; r < 6; r++) y[6 * k + r] = v[r];
     }
@@ -205,12 +223,12 @@ __global__ void __launch_bounds__(kSolveThreads) chol_solve_kernel(const double*
     if (lane == 0) rhs[row] = y[6 * k + row] - s;
     __syncthreads();
     if (t == 0) {
-      const double* d = A + (size_t)(6 * k) * n + 6 * k;
+      const double* d = Ldiag + 36 * (size_t)k;
       double v[6];
       for (int r = 5; r >= 0; r--) {
         double q = rhs[r];
-        for (int p = r + 1; p < 6; p++) q -= d[(size_t)r * n + p] * v[p];  // L(p, r)
-        v[r] = q / d[(size_t)r * n + r];
+        for (int p = r + 1; p < 6; p++) q -= d[r * 6 + p] * v[p];  // L_kk(p, r)
+        v[r] = q / d[r * 6 + r];
       }
       for (int r = 0; r < 6; r++) y[6 * k + r] = v[r];
     }
@@ -228,7 +246,7 @@ struct gp_dense_system {
   hipStream_t stream = nullptr;
   std::vector<gp::BlockDest> dests;
   std::vector<gp::Contribution> contribs;
-  gp::DeviceArray d_dests, d_contribs, A, b, c, x, status, prior;
+  gp::DeviceArray d_dests, d_contribs, A, b, c, x, status, prior, Ldiag;
   bool built = false;
 };
 
@@ -274,7 +292,7 @@ int gp_dense_system_create(int num_slots, const int* factor_slots, int num_facto
   int rc = GP_OK;
   if ((rc = s->d_dests.alloc(sizeof(gp::BlockDest) * s->dests.size())) || (rc = s->d_contribs.alloc(sizeof(gp::Contribution) * std::max<size_t>(s->contribs.size(), 1))) ||
       (rc = s->A.alloc(sizeof(double) * n * n)) || (rc = s->b.alloc(sizeof(double) * n)) || (rc = s->x.alloc(sizeof(double) * n)) || (rc = s->c.alloc(sizeof(double))) ||
-      (rc = s->status.alloc(sizeof(int))) || (rc = s->prior.alloc(sizeof(double) * n))) {
+      (rc = s->status.alloc(sizeof(int))) || (rc = s->prior.alloc(sizeof(double) * n)) || (rc = s->Ldiag.alloc(sizeof(double) * 36 * (size_t)num_slots))) {
     delete s;
     return rc;
   }
@@ -343,15 +361,18 @@ int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_ou
   double* A = s->A.as<double>();
   GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
   for (int k = 0; k < P; k++) {
-    hipLaunchKernelGGL(gp::chol_diag_kernel, dim3(1), dim3(64), 0, s->stream, A, n, k, s->status.as<int>());
     const int m = P - k - 1;
-    if (m > 0) {
-      hipLaunchKernelGGL(gp::chol_panel_kernel, dim3(m), dim3(64), 0, s->stream, A, n, k);
-      hipLaunchKernelGGL(gp::chol_update_kernel, dim3((unsigned)((size_t)m * (m + 1) / 2)), dim3(64), 0, s->stream, A, n, k, m);
+    hipLaunchKernelGGL(gp::chol_panel_kernel, dim3(m + 1), dim3(64), 0, s->stream, A, n, k, s->Ldiag.as<double>(), s->status.as<int>());
+    if (m >= 128) {
+      const int tiles = (m + 7) / 8;
+      hipLaunchKernelGGL(gp::chol_update_kernel<8>, dim3((unsigned)((size_t)tiles * (tiles + 1) / 2)), dim3(256), 0, s->stream, A, n, k, m);
+    } else if (m > 0) {
+      hipLaunchKernelGGL(gp::chol_update_kernel<1>, dim3((unsigned)((size_t)m * (m + 1) / 2)), dim3(64), 0, s->stream, A, n, k, m);
     }
   }
   GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gp::chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)n)));
-  hipLaunchKernelGGL(gp::chol_solve_kernel, dim3(1), dim3(gp::kSolveThreads), sizeof(double) * (size_t)n, s->stream, A, n, P, s->b.as<double>(), s->x.as<double>());
+  hipLaunchKernelGGL(gp::chol_solve_kernel, dim3(1), dim3(gp::kSolveThreads), sizeof(double) * (size_t)n, s->stream, A, s->Ldiag.as<double>(), n, P, s->b.as<double>(),
+                     s->x.as<double>());
   GP_HIP(hipGetLastError());
   s->built = false;
   int h_status = 0;
