@@ -43,6 +43,7 @@ struct VoxelMapView {
   // reference-visible table (reference hash + max_bucket_scan_count probe rule) and compact records
   const gp_voxel_bucket* buckets;
   const VoxelRecord* records;
+  const int* voxel_coords;  // [num_voxels][3] integer voxel coordinates (the source-frame pre-pass rebuilds the f64 mean from them)
   uint32_t num_buckets;
   uint32_t bucket_mask;  // num_buckets - 1 when num_buckets is a power of two, else 0
   int max_scan;

@@ -269,6 +269,43 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   __syncthreads();
   (void)NACC;
   const int t = threadIdx.x;
+  if constexpr (!GENERAL) {
+    if (inl.src_frame) {
+      // the tile kernel summed in the source frame of the linearisation pose (gp_vgicp_tile.hpp, source-frame formulation):
+      // rotate every 3x3 block B' -> R B' R^T and every 3-vector v' -> R v' before the target-side system is expanded
+      __shared__ double rot[33];
+      const Pose Tr = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);
+      const double R[3][3] = {{Tr.r00, Tr.r01, Tr.r02}, {Tr.r10, Tr.r11, Tr.r12}, {Tr.r20, Tr.r21, Tr.r22}};
+      const int sym3r[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+      if (t < 27) {
+        const int which = t / 9, rr = (t % 9) / 3, cc = t % 3;
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) {
+            const double e = which == 0 ? sum[ACC_M + sym3r[a][b]] : (which == 1 ? sum[ACC_K + a * 3 + b] : sum[ACC_TL + sym3r[a][b]]);
+            v += R[rr][a] * e * R[cc][b];
+          }
+        rot[t] = v;
+      } else if (t < 33) {
+        const int base = t < 30 ? ACC_QXMR : ACC_MR, rr = (t - 27) % 3;
+        rot[t] = R[rr][0] * sum[base] + R[rr][1] * sum[base + 1] + R[rr][2] * sum[base + 2];
+      }
+      __syncthreads();
+      if (t < 27) {
+        const int which = t / 9, rr = (t % 9) / 3, cc = t % 3;
+        if (which == 1) {
+          sum[ACC_K + rr * 3 + cc] = rot[t];
+        } else if (rr <= cc) {
+          sum[(which == 0 ? ACC_M : ACC_TL) + sym3r[rr][cc]] = rot[t];
+        }
+      } else if (t < 33) {
+        sum[(t < 30 ? ACC_QXMR : ACC_MR) + (t - 27) % 3] = rot[t];
+      }
+      __syncthreads();
+    }
+  }
   const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
   // the record is assembled in LDS and leaves in one coalesced sweep of 8-byte stores at the end: when `out` is host-mapped
   // memory, ~130 scattered stores would each be their own PCIe write
@@ -427,6 +464,8 @@ struct gp_vgicp_batch {
   int tile_points = 0;
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
+  gp::DeviceArray d_posed, d_vtiles;  // source-frame variants: per-factor posed voxel records and the pre-pass tile table
+  int num_vtiles = 0;
   std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
   gp::PinnedArray h_out;  // results land here straight from the finalize kernel (host-mapped, no D2H copy op)
@@ -443,6 +482,8 @@ namespace {
 //   2  pipeline kernel, f32 outer products / accumulators on f64-accurate M, r, q (parity ~1e-8; ~5 % faster)
 //   3  deep pipeline kernel (lookup of the next chunks overlapped with the algebra), f64, 6 chunks per wave
 //   4  deep pipeline kernel, f32 outer products
+//   5  pipeline kernel in the source-frame formulation (per-voxel pre-pass + 6 adds instead of 45 FMAs per point), f64
+//   6  the same with f32 outer products
 int g_variant = 1;
 constexpr int kPipelineChunks = 4;      // 64-point chunks per wave: 1024-point tiles
 constexpr int kDeepPipelineChunks = 6;  // 1536-point tiles: 651 workgroups for 1 M points on the 768 slots of 3 workgroups per CU
@@ -460,7 +501,7 @@ int build_table(gp_vgicp_batch* b) {
   std::vector<gp::TileDesc> tiles;
   b->total_points = 0;
   b->variant = g_variant;
-  b->tile_points = gp::kBlockThreads * (g_variant >= 3 ? kDeepPipelineChunks : kPipelineChunks);
+  b->tile_points = gp::kBlockThreads * ((g_variant == 3 || g_variant == 4) ? kDeepPipelineChunks : kPipelineChunks);
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -471,12 +512,31 @@ int build_table(gp_vgicp_batch* b) {
     d.map = f->target->view();
     d.n = f->n;
     d.surface_validation = (f->surface_validation && f->normals) ? 1 : 0;
+    d.posed = nullptr;
     d.tile_begin = (int)tiles.size();
     for (int p = 0; p < f->n; p += b->tile_points) tiles.push_back(gp::TileDesc{i, p, std::min(b->tile_points, f->n - p)});
     d.tile_count = (int)tiles.size() - d.tile_begin;
     b->total_points += f->n;
   }
   b->num_tiles = (int)tiles.size();
+  b->num_vtiles = 0;
+  if (g_variant == 5 || g_variant == 6) {
+    // per-factor slices of the posed-record buffer (a map shared by several factors is posed once per factor: different poses)
+    std::vector<gp::TileDesc> vtiles;
+    size_t total_voxels = 0;
+    for (int i = 0; i < F; i++) total_voxels += (size_t)std::max(descs[i].map.num_voxels, 0);
+    GP_TRY(b->d_posed.ensure(sizeof(double) * gp::kPosedDoubles * std::max<size_t>(total_voxels, 1)));
+    size_t off = 0;
+    for (int i = 0; i < F; i++) {
+      const int V = std::max(descs[i].map.num_voxels, 0);
+      descs[i].posed = b->d_posed.as<double>() + gp::kPosedDoubles * off;
+      for (int v = 0; v < V; v += 256) vtiles.push_back(gp::TileDesc{i, v, std::min(256, V - v)});
+      off += (size_t)V;
+    }
+    b->num_vtiles = (int)vtiles.size();
+    GP_TRY(b->d_vtiles.ensure(sizeof(gp::TileDesc) * std::max<size_t>(vtiles.size(), 1)));
+    if (!vtiles.empty()) GP_HIP(hipMemcpy(b->d_vtiles.ptr, vtiles.data(), sizeof(gp::TileDesc) * vtiles.size(), hipMemcpyHostToDevice));
+  }
   b->h_descs = descs;
   GP_TRY(b->d_factors.ensure(sizeof(gp::FactorDesc) * (size_t)std::max(F, 1)));
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
@@ -553,6 +613,18 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
         hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
                            ps.inl, partials);
         break;
+      case 5:
+      case 6:
+        // pre-pass: this pass's voxel statistics in the source frame of every factor's linearisation pose
+        if (b->num_vtiles > 0)
+          hipLaunchKernelGGL(gp::pose_records_kernel<0>, dim3(b->num_vtiles), dim3(256), 0, b->stream, fd, b->d_vtiles.as<gp::TileDesc>(), ps.d_lin, ps.inl);
+        if (b->variant == 5)
+          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks, true>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
+                             ps.inl, partials);
+        else
+          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks, true>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
+                             ps.inl, partials);
+        break;
       case 3:
         hipLaunchKernelGGL((gp::vgicp_deep_pipeline_kernel<MODE, false, kDeepPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
                            ps.inl, partials);
@@ -586,8 +658,10 @@ int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* ou
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
   if (rigid) {
-    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
-    return launch_finalize<false>(b, ps, partials, out_dev);
+    PoseSource rs = ps;
+    rs.inl.src_frame = (b->variant == 5 || b->variant == 6) ? 1 : 0;  // sums arrive in the source frame: the finalize kernel rotates them
+    GP_TRY(launch_tiles<gp::MODE_LIN>(b, rs, partials));
+    return launch_finalize<false>(b, rs, partials, out_dev);
   }
   GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
   return launch_finalize<true>(b, ps, partials, out_dev);
@@ -649,7 +723,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 4) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..4");
+  if (variant < 0 || variant > 6) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..6");
   g_variant = variant;
   return GP_OK;
 }

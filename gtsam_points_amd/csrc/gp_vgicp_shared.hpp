@@ -14,6 +14,7 @@ struct FactorDesc {
   const float* points;   // [n][3]
   const float* covs;     // [n][9]
   const float* normals;  // [n][3] or null
+  double* posed;         // [map.num_voxels][10] this factor's voxel statistics in the SOURCE frame of its linearisation pose (or null)
   VoxelMapView map;
   int n;
   int surface_validation;
@@ -30,6 +31,7 @@ struct InlinePoses {
   FactorDesc factor;
   int use;
   int tile_points;
+  int src_frame;  // the partial sums are in the source frame: the finalize kernel rotates them back
 };
 
 struct TileDesc {

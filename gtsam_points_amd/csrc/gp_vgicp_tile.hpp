@@ -234,7 +234,181 @@ __device__ __forceinline__ int line_match(const v4i& k0, const v4i& k1, const v4
   return idx;
 }
 
-template <int MODE, bool OUTER_F32, int PPT>
+// ---- source-frame formulation ------------------------------------------------------------------------------------------
+// The fused covariance C_B + R C_A R^T costs 45 f64 FMAs per POINT in the target frame.  Rotated into the source frame it is
+// R^T C_B R + C_A: the rotated term depends on the voxel and the pose only, so a pre-pass computes it once per VOXEL
+// (pose_records_kernel: mu' = R^T (mu_B - t), C' = R^T C_B R, 10 doubles per voxel), and a point pays 6 additions.  With
+// r' = mu' - p and q' = p + R^T t every sum of the target-side system is the rotation of the same sum formed from the primed
+// quantities (M = R M' R^T, K = R K' R^T, -S K = R (-S' K') R^T, q x Mr = R (q' x M'r'), Mr = R M'r'; r^T M r and the count are
+// invariant), which the finalize kernel applies once per factor.  ~140 instead of ~200 f64-rate instructions per point.
+constexpr int kPosedDoubles = 10;  // mu'(3), C'(xx xy xz yy yz zz), pad: 80 B = five 16-B loads
+
+struct SrcFrame {
+  double rtx, rty, rtz;                                  // R_l^T t_l                       (MODE_LIN: q' = p + R^T t)
+  double d00, d01, d02, d10, d11, d12, d20, d21, d22;    // D = R_l^T R_e                   (MODE_ERR: r' = mu' - (D p + d))
+  double dx, dy, dz;                                     // d = R_l^T (t_e - t_l)
+};
+
+__device__ __forceinline__ SrcFrame make_src_frame(const Pose& Tl, const Pose& Te) {
+  SrcFrame s;
+  s.rtx = Tl.r00 * Tl.tx + Tl.r10 * Tl.ty + Tl.r20 * Tl.tz;
+  s.rty = Tl.r01 * Tl.tx + Tl.r11 * Tl.ty + Tl.r21 * Tl.tz;
+  s.rtz = Tl.r02 * Tl.tx + Tl.r12 * Tl.ty + Tl.r22 * Tl.tz;
+  s.d00 = Tl.r00 * Te.r00 + Tl.r10 * Te.r10 + Tl.r20 * Te.r20;
+  s.d01 = Tl.r00 * Te.r01 + Tl.r10 * Te.r11 + Tl.r20 * Te.r21;
+  s.d02 = Tl.r00 * Te.r02 + Tl.r10 * Te.r12 + Tl.r20 * Te.r22;
+  s.d10 = Tl.r01 * Te.r00 + Tl.r11 * Te.r10 + Tl.r21 * Te.r20;
+  s.d11 = Tl.r01 * Te.r01 + Tl.r11 * Te.r11 + Tl.r21 * Te.r21;
+  s.d12 = Tl.r01 * Te.r02 + Tl.r11 * Te.r12 + Tl.r21 * Te.r22;
+  s.d20 = Tl.r02 * Te.r00 + Tl.r12 * Te.r10 + Tl.r22 * Te.r20;
+  s.d21 = Tl.r02 * Te.r01 + Tl.r12 * Te.r11 + Tl.r22 * Te.r21;
+  s.d22 = Tl.r02 * Te.r02 + Tl.r12 * Te.r12 + Tl.r22 * Te.r22;
+  const double ex = Te.tx - Tl.tx, ey = Te.ty - Tl.ty, ez = Te.tz - Tl.tz;
+  s.dx = Tl.r00 * ex + Tl.r10 * ey + Tl.r20 * ez;
+  s.dy = Tl.r01 * ex + Tl.r11 * ey + Tl.r21 * ez;
+  s.dz = Tl.r02 * ex + Tl.r12 * ey + Tl.r22 * ez;
+  return s;
+}
+
+// per-correspondence algebra in the source frame; rec = {mu'x mu'y | mu'z C'xx | C'xy C'xz | C'yy C'yz | C'zz pad}
+template <int MODE, typename acc_t>
+__device__ __forceinline__ void accumulate_terms_src(const SrcFrame& sf, float pxf, float pyf, float pzf, const float* cA, const v2d& r0, const v2d& r1, const v2d& r2,
+                                                     const v2d& r3, const v2d& r4, acc_t* acc) {
+  const double px = (double)pxf, py = (double)pyf, pz = (double)pzf;
+  double m[6];
+  {
+    const double s00 = r1.y + (double)cA[0], s01 = r2.x + (double)cA[1], s02 = r2.y + (double)cA[2];
+    const double s11 = r3.x + (double)cA[3], s12 = r3.y + (double)cA[4], s22 = r4.x + (double)cA[5];
+    const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
+    const double invdet = fast_rcp(s00 * i00 + s01 * i01 + s02 * i02);
+    m[0] = i00 * invdet;
+    m[1] = i01 * invdet;
+    m[2] = i02 * invdet;
+    m[3] = (s00 * s22 - s02 * s02) * invdet;
+    m[4] = (s01 * s02 - s00 * s12) * invdet;
+    m[5] = (s00 * s11 - s01 * s01) * invdet;
+  }
+  double rxd, ryd, rzd, qx, qy, qz;
+  if constexpr (MODE == MODE_ERR) {
+    rxd = r0.x - (sf.d00 * px + sf.d01 * py + sf.d02 * pz + sf.dx);
+    ryd = r0.y - (sf.d10 * px + sf.d11 * py + sf.d12 * pz + sf.dy);
+    rzd = r1.x - (sf.d20 * px + sf.d21 * py + sf.d22 * pz + sf.dz);
+    qx = qy = qz = 0.0;
+  } else {
+    rxd = r0.x - px;
+    ryd = r0.y - py;
+    rzd = r1.x - pz;
+    qx = px + sf.rtx;
+    qy = py + sf.rty;
+    qz = pz + sf.rtz;
+  }
+  const acc_t M0 = (acc_t)m[0], M1 = (acc_t)m[1], M2 = (acc_t)m[2], M3 = (acc_t)m[3], M4 = (acc_t)m[4], M5 = (acc_t)m[5];
+  const acc_t RX = (acc_t)rxd, RY = (acc_t)ryd, RZ = (acc_t)rzd, QX = (acc_t)qx, QY = (acc_t)qy, QZ = (acc_t)qz;
+  const acc_t mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+  acc[ACC_COUNT] += (acc_t)1;
+  acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+  if constexpr (MODE == MODE_LIN) {
+    acc[ACC_M + 0] += M0;
+    acc[ACC_M + 1] += M1;
+    acc[ACC_M + 2] += M2;
+    acc[ACC_M + 3] += M3;
+    acc[ACC_M + 4] += M4;
+    acc[ACC_M + 5] += M5;
+    const acc_t k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
+    const acc_t k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
+    const acc_t k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+    acc[ACC_K + 0] += k00;
+    acc[ACC_K + 1] += k01;
+    acc[ACC_K + 2] += k02;
+    acc[ACC_K + 3] += k10;
+    acc[ACC_K + 4] += k11;
+    acc[ACC_K + 5] += k12;
+    acc[ACC_K + 6] += k20;
+    acc[ACC_K + 7] += k21;
+    acc[ACC_K + 8] += k22;
+    acc[ACC_TL + 0] += QZ * k10 - QY * k20;
+    acc[ACC_TL + 1] += QZ * k11 - QY * k21;
+    acc[ACC_TL + 2] += QZ * k12 - QY * k22;
+    acc[ACC_TL + 3] += QX * k21 - QZ * k01;
+    acc[ACC_TL + 4] += QX * k22 - QZ * k02;
+    acc[ACC_TL + 5] += QY * k02 - QX * k12;
+    acc[ACC_QXMR + 0] += QY * mrz - QZ * mry;
+    acc[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
+    acc[ACC_QXMR + 2] += QX * mry - QY * mrx;
+    acc[ACC_MR + 0] += mrx;
+    acc[ACC_MR + 1] += mry;
+    acc[ACC_MR + 2] += mrz;
+  }
+}
+
+// the pre-pass: one thread per (factor, voxel); tiles[] = {factor, first voxel, count} in chunks of 256 voxels
+template <int UNUSED = 0>  // a template only so that the header can be included by several translation units
+__global__ void __launch_bounds__(256) pose_records_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ vtiles, const double* __restrict__ poses_lin,
+                                                           const InlinePoses inl) {
+  TileDesc tile;
+  if (inl.use) {
+    tile.factor = 0;
+    tile.begin = blockIdx.x * 256;
+    tile.count = min(256, inl.factor.map.num_voxels - tile.begin);
+  } else {
+    tile = vtiles[blockIdx.x];
+  }
+  if ((int)threadIdx.x >= tile.count) return;
+  const FactorDesc f = inl.use ? inl.factor : factors[tile.factor];
+  const Pose T = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const int v = tile.begin + threadIdx.x;
+  const VoxelRecord rec = f.map.records[v];
+  const int* c = f.map.voxel_coords + 3 * (size_t)v;
+  const double mx = ((double)c[0] + 0.5) * f.map.leaf + (double)rec.mean_local[0] - T.tx;
+  const double my = ((double)c[1] + 0.5) * f.map.leaf + (double)rec.mean_local[1] - T.ty;
+  const double mz = ((double)c[2] + 0.5) * f.map.leaf + (double)rec.mean_local[2] - T.tz;
+  double* out = f.posed + kPosedDoubles * (size_t)v;
+  out[0] = T.r00 * mx + T.r10 * my + T.r20 * mz;
+  out[1] = T.r01 * mx + T.r11 * my + T.r21 * mz;
+  out[2] = T.r02 * mx + T.r12 * my + T.r22 * mz;
+  // C' = R^T C R with C symmetric (xx xy xz yy yz zz)
+  const double c00 = rec.cov[0], c01 = rec.cov[1], c02 = rec.cov[2], c11 = rec.cov[3], c12 = rec.cov[4], c22 = rec.cov[5];
+  const double R[3][3] = {{T.r00, T.r01, T.r02}, {T.r10, T.r11, T.r12}, {T.r20, T.r21, T.r22}};
+  double CR[3][3];  // C R
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    CR[0][j] = c00 * R[0][j] + c01 * R[1][j] + c02 * R[2][j];
+    CR[1][j] = c01 * R[0][j] + c11 * R[1][j] + c12 * R[2][j];
+    CR[2][j] = c02 * R[0][j] + c12 * R[1][j] + c22 * R[2][j];
+  }
+  auto rtcr = [&](int i, int j) { return R[0][i] * CR[0][j] + R[1][i] * CR[1][j] + R[2][i] * CR[2][j]; };
+  out[3] = rtcr(0, 0);
+  out[4] = rtcr(0, 1);
+  out[5] = rtcr(0, 2);
+  out[6] = rtcr(1, 1);
+  out[7] = rtcr(1, 2);
+  out[8] = rtcr(2, 2);
+  out[9] = 0.0;
+}
+
+// hop 2 of the source-frame kernel: the 80-B posed record
+__device__ __forceinline__ void posed_issue(const GP_GLOBAL char* rec, v2d& r0, v2d& r1, v2d& r2, v2d& r3, v2d& r4) {
+  asm volatile(
+    "global_load_dwordx4 %0, %5, off\n\t"
+    "global_load_dwordx4 %1, %5, off offset:16\n\t"
+    "global_load_dwordx4 %2, %5, off offset:32\n\t"
+    "global_load_dwordx4 %3, %5, off offset:48\n\t"
+    "global_load_dwordx4 %4, %5, off offset:64"
+    : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+    : "v"(rec)
+    : "memory");
+}
+template <int WAIT_YOUNGER>
+__device__ __forceinline__ void posed_wait(v2d& r0, v2d& r1, v2d& r2, v2d& r3, v2d& r4) {
+  if constexpr (WAIT_YOUNGER == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : : "memory");
+  } else {
+    static_assert(WAIT_YOUNGER == 3, "one chunk request = 3 DMA instructions");
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : : "memory");
+  }
+}
+
+template <int MODE, bool OUTER_F32, int PPT, bool SRC = false>
 __global__ void __launch_bounds__(256, 4) vgicp_pipeline_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                              const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                              double* __restrict__ partials) {
@@ -275,6 +449,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline_kernel(const FactorDesc
   const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
   const Pose Te = MODE == MODE_ERR ? (inl.use ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
 
+  const SrcFrame sf = make_src_frame(Tl, Te);  // only the SRC instantiation uses it
   using acc_t = typename std::conditional<OUTER_F32, float, double>::type;
   acc_t acc[32];
 #pragma unroll
@@ -312,20 +487,37 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline_kernel(const FactorDesc
       }
     }
     hit = live && idx >= 0;
-    // hop 2: the record (lanes without a voxel read the line table again: any valid address)
-    const GP_GLOBAL char* rec = hit ? (const GP_GLOBAL char*)f.map.records + 64 * (size_t)idx : lines;
-    record_issue(rec, head, c01, c23, c45);
-    if constexpr (RING) {
-      if (j + 2 < PPT) {
-        chunk_dma(points, covs, first + (size_t)(j + 2) * kChunkPoints, wbase + ((j + 2) % STAGES) * kChunkBytes, lane);
-        record_wait<3>(head, c01, c23, c45);
+    if constexpr (SRC) {
+      // hop 2: the voxel's statistics in the source frame of this factor's linearisation pose (80 B, pose_records_kernel)
+      v2d p0, p1, p2, p3, p4;
+      posed_issue(hit ? (const GP_GLOBAL char*)f.posed + 8 * kPosedDoubles * (size_t)idx : lines, p0, p1, p2, p3, p4);
+      if constexpr (RING) {
+        if (j + 2 < PPT) {
+          chunk_dma(points, covs, first + (size_t)(j + 2) * kChunkPoints, wbase + ((j + 2) % STAGES) * kChunkBytes, lane);
+          posed_wait<3>(p0, p1, p2, p3, p4);
+        } else {
+          posed_wait<0>(p0, p1, p2, p3, p4);
+        }
+      } else {
+        posed_wait<0>(p0, p1, p2, p3, p4);
+      }
+      if (hit) accumulate_terms_src<MODE, acc_t>(sf, px, py, pz, cA, p0, p1, p2, p3, p4, acc);
+    } else {
+      // hop 2: the record (lanes without a voxel read the line table again: any valid address)
+      const GP_GLOBAL char* rec = hit ? (const GP_GLOBAL char*)f.map.records + 64 * (size_t)idx : lines;
+      record_issue(rec, head, c01, c23, c45);
+      if constexpr (RING) {
+        if (j + 2 < PPT) {
+          chunk_dma(points, covs, first + (size_t)(j + 2) * kChunkPoints, wbase + ((j + 2) % STAGES) * kChunkBytes, lane);
+          record_wait<3>(head, c01, c23, c45);
+        } else {
+          record_wait<0>(head, c01, c23, c45);
+        }
       } else {
         record_wait<0>(head, c01, c23, c45);
       }
-    } else {
-      record_wait<0>(head, c01, c23, c45);
+      if (hit) accumulate_terms<MODE, acc_t>(Tl, Te, f.map.leaf, px, py, pz, cA, cx, cy, cz, head, c01, c23, c45, acc);
     }
-    if (hit) accumulate_terms<MODE, acc_t>(Tl, Te, f.map.leaf, px, py, pz, cA, cx, cy, cz, head, c01, c23, c45, acc);
   };
 
   if (ring) {

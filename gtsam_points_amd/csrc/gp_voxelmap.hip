@@ -177,6 +177,7 @@ gp::VoxelMapView gp_voxelmap::view() const {
   v.pad_ = 0;
   v.buckets = buckets.as<gp_voxel_bucket>();
   v.records = records.as<gp::VoxelRecord>();
+  v.voxel_coords = voxel_coords.as<int>();
   v.num_buckets = (uint32_t)info.num_buckets;
   v.bucket_mask = (info.num_buckets > 0 && (info.num_buckets & (info.num_buckets - 1)) == 0) ? (uint32_t)(info.num_buckets - 1) : 0u;
   v.max_scan = info.max_bucket_scan_count;

@@ -303,7 +303,8 @@ int gp_dense_system_download(const gp_dense_system_t* sys, double* A_host, doubl
 int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev);
 
 /* tuning hook (not part of the reference API): tile-kernel variant.  0 = reference-shaped kernel, 1 = pipeline kernel in f64
- * (default), 2 = pipeline kernel with f32 outer products; see gp_vgicp.hip */
+ * (default), 2 = pipeline kernel with f32 outer products, 3/4 = deep pipeline (f64 / f32 outer), 5/6 = source-frame formulation
+ * (f64 / f32 outer); see gp_vgicp.hip and DESIGN.md section 8 */
 int gp_debug_set_variant(int variant);
 /* timeline hook: per-workgroup phase timestamps (s_memtime) of the pipeline kernel into dev_buffer ([num_tiles][8] uint64) */
 int gp_debug_set_trace_buffer(void* dev_buffer);

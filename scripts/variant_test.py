@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gtsam_points_amd as gpa
 from gtsam_points_amd import _capi, synthetic
 lib = gpa.load()
-variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4]
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6]
 d = synthetic.make_c2_workload()
 delta = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
 tgt = gpa.PointCloudGPU(d["target_points"], d["target_covs"]); src = gpa.PointCloudGPU(d["source_points"], d["source_covs"])

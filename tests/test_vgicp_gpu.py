@@ -73,10 +73,11 @@ def test_rigid_and_general_pose_paths(gpu, kitti00):
         assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), PARITY_TOL, name)
 
 
-@pytest.mark.parametrize("variant,tol", [(0, PARITY_TOL), (1, PARITY_TOL), (2, 1e-6), (3, PARITY_TOL), (4, 1e-6)])
+@pytest.mark.parametrize("variant,tol", [(0, PARITY_TOL), (1, PARITY_TOL), (2, 1e-6), (3, PARITY_TOL), (4, 1e-6), (5, PARITY_TOL), (6, 1e-6)])
 def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
     """gp_debug_set_variant: 0 reference-shaped kernel, 1 pipeline kernel (default), 2 pipeline + f32 outer products,
-    3 / 4 deep pipeline (lookup overlapped with the algebra) in f64 / f32 outer products -- linearise and error evaluation,
+    3 / 4 deep pipeline (lookup overlapped with the algebra) in f64 / f32 outer products, 5 / 6 source-frame formulation
+    (per-voxel pre-pass, sums rotated back by the finalize kernel) in f64 / f32 outer products -- linearise and error evaluation,
     full tiles, a partial tile and the per-lane fallback all go through the selected kernel"""
     lib = gpu.load()
     try:
