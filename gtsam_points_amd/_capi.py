@@ -95,6 +95,7 @@ _SIGNATURES = {
     "gp_voxelmap_load": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_voxelmap_memory_usage_gpu": (C.c_size_t, [C.c_void_p]),
     "gp_voxelmap_loaded_on_gpu": (C.c_int, [C.c_void_p]),
+    "gp_voxelmap_has_block_grid": (C.c_int, [C.c_void_p]),
     "gp_voxelmap_offload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_voxelmap_reload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_voxelmap_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
@@ -152,6 +153,7 @@ _SIGNATURES = {
     "gp_gicp_factor_linearize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(Linearized6)]),
     "gp_gicp_factor_compute_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gp_debug_set_variant": (C.c_int, [C.c_int]),
+    "gp_debug_set_stagger": (C.c_int, [C.c_int]),
     "gp_debug_set_trace_buffer": (C.c_int, [C.c_void_p]),
     "gp_debug_stream_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gp_debug_calibration_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -49,6 +49,12 @@ struct DeviceArray {
     return GP_OK;
   }
   int ensure(size_t n) { return (n <= bytes && ptr) ? GP_OK : alloc(n + n / 5); }
+  void swap(DeviceArray& o) {
+    std::swap(ptr, o.ptr);
+    std::swap(bytes, o.bytes);
+    std::swap(pooled, o.pooled);
+    std::swap(pool_stream, o.pool_stream);
+  }
   // stream-ordered allocation from the device's default memory pool (cudaMallocAsync upstream, cuda/cuda_malloc_async.hpp):
   // for short-lived scratch -- a pooled block is reused by the next call instead of going through hipMalloc / hipFree, which
   // cost more than the kernels they serve.  The block may only be used by work ordered after this call on `stream`.
@@ -157,11 +163,14 @@ struct gp_voxelmap {
   gp::DeviceArray voxel_coords; // int[num_voxels][3] voxel coordinate of each voxel index
   gp::DeviceArray plines;  // line table of the VGICP pipeline kernel (gp::VoxelMapView::plines)
   uint32_t plmask = 0;
+  gp::DeviceArray gblocks;  // occupancy-block grid (gp::GridBlock[gdim0 * gdim1 * gdim2]); empty when the box is too large
+  int glo[3] = {0, 0, 0}, gdim[3] = {0, 0, 0};
+  bool has_grid = false;
 
   // offloaded copies (OffloadableGPU)
   bool offloaded = false;
   uint64_t generation = 0;  // bumped whenever the device arrays are (re)allocated: factor tables built from view() go stale
-  std::vector<char> h_buckets, h_records, h_num_points, h_means, h_covs, h_intensities, h_coords;
+  std::vector<char> h_buckets, h_records, h_num_points, h_means, h_covs, h_intensities, h_coords, h_gblocks;
 
   bool loaded() const { return buckets.ptr != nullptr && !offloaded; }
   gp::VoxelMapView view() const;

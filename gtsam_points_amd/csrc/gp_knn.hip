@@ -462,15 +462,17 @@ struct GicpDesc {
   double max_sq_dist;
 };
 
-template <int MODE>  // MODE_LIN or MODE_ERR
+template <int MODE>  // MODE_LIN (rigid pose: 29 sums + adjoint finalize), MODE_ERR, MODE_LIN_GENERAL (any 3x3 block: 92 explicit sums)
 __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double* __restrict__ pose_lin, const double* __restrict__ pose_eval,
                                                         int tile_points, double* __restrict__ partials) {
-  constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
+  constexpr int NACC = MODE == MODE_ERR ? 2 : (MODE == MODE_LIN ? ACC_SIZE : ACCG_SIZE);
+  constexpr int STRIDE = MODE == MODE_LIN_GENERAL ? ACCG_STRIDE : ACC_STRIDE;
+  constexpr int NREG = MODE == MODE_LIN_GENERAL ? ACCG_SIZE : 32;
   const Pose Tl = load_pose(pose_lin);
   const Pose Te = MODE == MODE_ERR ? load_pose(pose_eval) : Tl;
-  double acc[32];
+  double acc[NREG];
 #pragma unroll
-  for (int k = 0; k < 32; k++) acc[k] = 0.0;
+  for (int k = 0; k < NREG; k++) acc[k] = 0.0;
   const int begin = blockIdx.x * tile_points;
   const int end = min(begin + tile_points, f.n);
   for (int i = begin + threadIdx.x; i < end; i += 256) {
@@ -486,31 +488,41 @@ __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double
     const size_t j = (size_t)top.idx[0];
     const float* cp = f.covs + 9 * (size_t)i;
     const float* cq = f.target_covs + 9 * j;
-    const float cA[6] = {cp[0], cp[3], cp[6], cp[4], cp[7], cp[8]};
-    // reuse the VGICP per-point algebra: the "voxel" is the matched target point (centre 0, mean_local = mu_B)
+    // reuse the VGICP per-point algebra: the "voxel" is the matched target point (mu_B, C_B)
     const double mux = (double)f.target_points[3 * j], muy = (double)f.target_points[3 * j + 1], muz = (double)f.target_points[3 * j + 2];
-    const v2d c01 = {(double)cq[0], (double)cq[3]}, c23 = {(double)cq[6], (double)cq[4]}, c45 = {(double)cq[7], (double)cq[8]};
-    accumulate_terms_mu<MODE, double>(Tl, Te, (float)px, (float)py, (float)pz, cA, mux, muy, muz, c01, c23, c45, acc);
+    // symmetric parts of both column-major 3x3 covariances (exactly the inputs when they are symmetric)
+    const double cb[6] = {(double)cq[0], 0.5 * ((double)cq[3] + (double)cq[1]), 0.5 * ((double)cq[6] + (double)cq[2]),
+                          (double)cq[4], 0.5 * ((double)cq[7] + (double)cq[5]), (double)cq[8]};
+    if constexpr (MODE == MODE_LIN_GENERAL) {
+      const double ca[6] = {(double)cp[0], 0.5 * ((double)cp[3] + (double)cp[1]), 0.5 * ((double)cp[6] + (double)cp[2]),
+                            (double)cp[4], 0.5 * ((double)cp[7] + (double)cp[5]), (double)cp[8]};
+      double m[6];
+      fused_mahalanobis(Tl, ca, cb, m);
+      accumulate_sums<MODE_LIN_GENERAL>(Tl, m, px, py, pz, lx, ly, lz, mux - lx, muy - ly, muz - lz, acc);
+    } else {
+      const v2d c01 = {cb[0], cb[1]}, c23 = {cb[2], cb[3]}, c45 = {cb[4], cb[5]};
+      accumulate_terms_mu<MODE, double>(Tl, Te, (float)px, (float)py, (float)pz, cp, mux, muy, muz, c01, c23, c45, acc);
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ double lds[4][ACC_STRIDE];
-  if constexpr (MODE == MODE_ERR) {
+  __shared__ double lds[4][STRIDE];
+  if constexpr (MODE == MODE_LIN) {
+    const double s = butterfly_reduce32(acc, lane);
+    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
+  } else {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NACC; k++) {
       double v = acc[k];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
       if (lane == 0) lds[wave][k] = v;
     }
-  } else {
-    const double s = butterfly_reduce32(acc, lane);
-    if ((lane & 1) == 0) lds[wave][butterfly_component(lane)] = s;
   }
   __syncthreads();
-  if (threadIdx.x < ACC_STRIDE) {
+  if (threadIdx.x < STRIDE) {
     double s = 0.0;
     if (threadIdx.x < NACC) s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
-    partials[(size_t)blockIdx.x * ACC_STRIDE + threadIdx.x] = s;
+    partials[(size_t)blockIdx.x * STRIDE + threadIdx.x] = s;
   }
 }
 
@@ -767,7 +779,7 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
   f->desc.n = n;
   f->desc.max_sq_dist = max_correspondence_distance_sq;
   f->num_tiles = (n + f->tile_points - 1) / f->tile_points;
-  if ((rc = f->partials.alloc(sizeof(double) * gp::ACC_STRIDE * (size_t)std::max(f->num_tiles, 1))) || (rc = f->d_poses.alloc(sizeof(double) * 32)) ||
+  if ((rc = f->partials.alloc(sizeof(double) * gp::ACCG_STRIDE * (size_t)std::max(f->num_tiles, 1))) || (rc = f->d_poses.alloc(sizeof(double) * 32)) ||
       (rc = f->d_out.alloc(sizeof(gp_linearized6))) || (rc = f->h_out.ensure(sizeof(gp_linearized6)))) {
     gp_point_grid_destroy(f->grid);
     delete f;
@@ -789,10 +801,20 @@ int gp_gicp_factor_destroy(gp_gicp_factor_t* f) {
 int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host) {
   if (!f || !pose || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_linearize: null");
   GP_HIP(hipMemcpyAsync(f->d_poses.ptr, pose, sizeof(double) * 16, hipMemcpyHostToDevice, f->stream));
-  if (f->num_tiles > 0)
-    hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(), f->d_poses.as<double>(),
-                       f->tile_points, f->partials.as<double>());
-  GP_TRY(gp::launch_finalize_single(f->stream, f->d_poses.as<double>(), pose, f->partials.as<double>(), f->num_tiles, reinterpret_cast<gp_linearized6*>(f->h_out_dev)));
+  // the 29-sum kernel + adjoint finalize is exact only for an orthonormal 3x3 block; any other pose (e.g. built from 6-digit
+  // quaternions, src/test/test_matching_cost_factors.cpp:50-55) takes the 92-sum path with the explicit J_s, like the VGICP factor
+  const bool rigid = gp::pose_is_rigid(pose);
+  if (f->num_tiles > 0) {
+    if (rigid)
+      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(), f->d_poses.as<double>(),
+                         f->tile_points, f->partials.as<double>());
+    else
+      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN_GENERAL>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(),
+                         f->d_poses.as<double>(), f->tile_points, f->partials.as<double>());
+    GP_HIP(hipGetLastError());
+  }
+  GP_TRY(gp::launch_finalize_single(f->stream, f->d_poses.as<double>(), pose, f->partials.as<double>(), f->num_tiles, reinterpret_cast<gp_linearized6*>(f->h_out_dev),
+                                    !rigid));
   GP_HIP(hipStreamSynchronize(f->stream));
   memcpy(out_host, f->h_out.ptr, sizeof(gp_linearized6));
   return GP_OK;

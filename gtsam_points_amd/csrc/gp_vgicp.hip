@@ -54,7 +54,9 @@ __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose
   const double cb[6] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y};
 
   const float* __restrict__ cp = f.covs + 9 * (size_t)i;
-  const double ca[6] = {(double)cp[0], (double)cp[3], (double)cp[6], (double)cp[4], (double)cp[7], (double)cp[8]};
+  // symmetric part of the column-major 3x3 (exactly the input when it is symmetric)
+  const double ca[6] = {(double)cp[0], 0.5 * ((double)cp[3] + (double)cp[1]), 0.5 * ((double)cp[6] + (double)cp[2]),
+                        (double)cp[4], 0.5 * ((double)cp[7] + (double)cp[5]), (double)cp[8]};
 
   double m[6];
   fused_mahalanobis(Tl, ca, cb, m);
@@ -75,97 +77,7 @@ __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose
   const double rx = (ox - qx) + (double)head.x;
   const double ry = (oy - qy) + (double)head.y;
   const double rz = (oz - qz) + (double)head.z;
-  const double mrx = m[0] * rx + m[1] * ry + m[2] * rz;
-  const double mry = m[1] * rx + m[3] * ry + m[4] * rz;
-  const double mrz = m[2] * rx + m[4] * ry + m[5] * rz;
-  acc[ACC_COUNT] += 1.0;
-  acc[ACC_ERR] += rx * mrx + ry * mry + rz * mrz;
-  if constexpr (MODE != MODE_ERR) {
-    for (int k = 0; k < 6; k++) acc[ACC_M + k] += m[k];
-    // K = M S, S = [q]x ; K[:,0] = M[:,1] qz - M[:,2] qy ; K[:,1] = M[:,2] qx - M[:,0] qz ; K[:,2] = M[:,0] qy - M[:,1] qx
-    const double k00 = m[1] * qz - m[2] * qy, k01 = m[2] * qx - m[0] * qz, k02 = m[0] * qy - m[1] * qx;
-    const double k10 = m[3] * qz - m[4] * qy, k11 = m[4] * qx - m[1] * qz, k12 = m[1] * qy - m[3] * qx;
-    const double k20 = m[4] * qz - m[5] * qy, k21 = m[5] * qx - m[2] * qz, k22 = m[2] * qy - m[4] * qx;
-    acc[ACC_K + 0] += k00;
-    acc[ACC_K + 1] += k01;
-    acc[ACC_K + 2] += k02;
-    acc[ACC_K + 3] += k10;
-    acc[ACC_K + 4] += k11;
-    acc[ACC_K + 5] += k12;
-    acc[ACC_K + 6] += k20;
-    acc[ACC_K + 7] += k21;
-    acc[ACC_K + 8] += k22;
-    // TL = -S K (= S^T M S), rows of -S: [0, qz, -qy], [-qz, 0, qx], [qy, -qx, 0]; upper triangle
-    acc[ACC_TL + 0] += qz * k10 - qy * k20;
-    acc[ACC_TL + 1] += qz * k11 - qy * k21;
-    acc[ACC_TL + 2] += qz * k12 - qy * k22;
-    acc[ACC_TL + 3] += qx * k21 - qz * k01;
-    acc[ACC_TL + 4] += qx * k22 - qz * k02;
-    acc[ACC_TL + 5] += qy * k02 - qx * k12;
-    // b_t = [q x (M r); M r]
-    acc[ACC_QXMR + 0] += qy * mrz - qz * mry;
-    acc[ACC_QXMR + 1] += qz * mrx - qx * mrz;
-    acc[ACC_QXMR + 2] += qx * mry - qy * mrx;
-    acc[ACC_MR + 0] += mrx;
-    acc[ACC_MR + 1] += mry;
-    acc[ACC_MR + 2] += mrz;
-
-    if constexpr (MODE == MODE_LIN_GENERAL) {
-      // explicit source side, vgicp_derivatives.cuh:57-70: J_s = [R [p]x, -R] = [G, -R]
-      const double Mf[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
-      const double Rf[3][3] = {{Tl.r00, Tl.r01, Tl.r02}, {Tl.r10, Tl.r11, Tl.r12}, {Tl.r20, Tl.r21, Tl.r22}};
-      const double Kf[3][3] = {{k00, k01, k02}, {k10, k11, k12}, {k20, k21, k22}};
-      double G[3][3], Js[3][6], JtM[6][3], JsM[6][3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        G[r][0] = Rf[r][1] * pz - Rf[r][2] * py;
-        G[r][1] = Rf[r][2] * px - Rf[r][0] * pz;
-        G[r][2] = Rf[r][0] * py - Rf[r][1] * px;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          Js[r][c] = G[r][c];
-          Js[r][3 + c] = -Rf[r][c];
-        }
-      }
-      // JtM = J_t^T M = [S M; M] = [-K^T; M] ;  JsM = J_s^T M
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          JtM[r][c] = -Kf[c][r];
-          JtM[3 + r][c] = Mf[r][c];
-        }
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) JsM[r][c] = Js[0][r] * Mf[0][c] + Js[1][r] * Mf[1][c] + Js[2][r] * Mf[2][c];
-      // H_s = JsM J_s : TL (0..2 x 0..2, upper), BL (3..5 x 0..2), BR (3..5 x 3..5, upper)
-      int idx = ACCG_HS_TL;
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = r; c < 3; c++) acc[idx++] += JsM[r][0] * Js[0][c] + JsM[r][1] * Js[1][c] + JsM[r][2] * Js[2][c];
-      idx = ACCG_HS_BL;
-#pragma unroll
-      for (int r = 3; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[idx++] += JsM[r][0] * Js[0][c] + JsM[r][1] * Js[1][c] + JsM[r][2] * Js[2][c];
-      idx = ACCG_HS_BR;
-#pragma unroll
-      for (int r = 3; r < 6; r++)
-#pragma unroll
-        for (int c = r; c < 6; c++) acc[idx++] += JsM[r][0] * Js[0][c] + JsM[r][1] * Js[1][c] + JsM[r][2] * Js[2][c];
-      // H_ts = JtM J_s (6x6, row-major)
-      idx = ACCG_HTS;
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc[idx++] += JtM[r][0] * Js[0][c] + JtM[r][1] * Js[1][c] + JtM[r][2] * Js[2][c];
-      // b_s = JsM r
-#pragma unroll
-      for (int r = 0; r < 6; r++) acc[ACCG_BS + r] += JsM[r][0] * rx + JsM[r][1] * ry + JsM[r][2] * rz;
-    }
-  }
+  accumulate_sums<MODE>(Tl, m, px, py, pz, qx, qy, qz, rx, ry, rz, acc);
 }
 
 // main kernel: one workgroup per tile; writes partials[tile][kStride]
@@ -269,43 +181,6 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   __syncthreads();
   (void)NACC;
   const int t = threadIdx.x;
-  if constexpr (!GENERAL) {
-    if (inl.src_frame) {
-      // the tile kernel summed in the source frame of the linearisation pose (gp_vgicp_tile.hpp, source-frame formulation):
-      // rotate every 3x3 block B' -> R B' R^T and every 3-vector v' -> R v' before the target-side system is expanded
-      __shared__ double rot[33];
-      const Pose Tr = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);
-      const double R[3][3] = {{Tr.r00, Tr.r01, Tr.r02}, {Tr.r10, Tr.r11, Tr.r12}, {Tr.r20, Tr.r21, Tr.r22}};
-      const int sym3r[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-      if (t < 27) {
-        const int which = t / 9, rr = (t % 9) / 3, cc = t % 3;
-        double v = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int b = 0; b < 3; b++) {
-            const double e = which == 0 ? sum[ACC_M + sym3r[a][b]] : (which == 1 ? sum[ACC_K + a * 3 + b] : sum[ACC_TL + sym3r[a][b]]);
-            v += R[rr][a] * e * R[cc][b];
-          }
-        rot[t] = v;
-      } else if (t < 33) {
-        const int base = t < 30 ? ACC_QXMR : ACC_MR, rr = (t - 27) % 3;
-        rot[t] = R[rr][0] * sum[base] + R[rr][1] * sum[base + 1] + R[rr][2] * sum[base + 2];
-      }
-      __syncthreads();
-      if (t < 27) {
-        const int which = t / 9, rr = (t % 9) / 3, cc = t % 3;
-        if (which == 1) {
-          sum[ACC_K + rr * 3 + cc] = rot[t];
-        } else if (rr <= cc) {
-          sum[(which == 0 ? ACC_M : ACC_TL) + sym3r[rr][cc]] = rot[t];
-        }
-      } else if (t < 33) {
-        sum[(t < 30 ? ACC_QXMR : ACC_MR) + (t - 27) % 3] = rot[t];
-      }
-      __syncthreads();
-    }
-  }
   const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
   // the record is assembled in LDS and leaves in one coalesced sweep of 8-byte stores at the end: when `out` is host-mapped
   // memory, ~130 scattered stores would each be their own PCIe write
@@ -414,13 +289,17 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(con
   }
 }
 
-int launch_finalize_single(hipStream_t stream, const double* pose_dev, const double* pose_host, const double* partials, int num_tiles, gp_linearized6* out_dev) {
+int launch_finalize_single(hipStream_t stream, const double* pose_dev, const double* pose_host, const double* partials, int num_tiles, gp_linearized6* out_dev,
+                           bool general) {
   InlinePoses inl{};
   memcpy(inl.lin, pose_host, sizeof(double) * 16);
   inl.factor.tile_begin = 0;
   inl.factor.tile_count = num_tiles;
   inl.use = 1;
-  hipLaunchKernelGGL(vgicp_finalize_kernel<false>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev);
+  if (general)
+    hipLaunchKernelGGL(vgicp_finalize_kernel<true>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev);
+  else
+    hipLaunchKernelGGL(vgicp_finalize_kernel<false>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_kernel", __FILE__, __LINE__);
 }
@@ -464,10 +343,10 @@ struct gp_vgicp_batch {
   int tile_points = 0;
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
-  gp::DeviceArray d_posed, d_vtiles;  // source-frame variants: per-factor posed voxel records and the pre-pass tile table
-  int num_vtiles = 0;
+  bool use_grid = false;  // every factor's map carries an occupancy-block grid (else the hashed line table is used)
   std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
+  hipEvent_t h2d_done = nullptr;  // recorded behind every H2D copy of h_poses; the next staging waits on it
   gp::PinnedArray h_out;  // results land here straight from the finalize kernel (host-mapped, no D2H copy op)
   void* h_out_dev = nullptr;
   bool table_dirty = true;
@@ -478,15 +357,17 @@ namespace {
 
 // Kernel variant (gp_debug_set_variant):
 //   0  reference-shaped kernel (reference bucket table, one point per lane per stride, all modes) -- also the cross-check
-//   1  pipeline kernel, f64 throughout (default)
-//   2  pipeline kernel, f32 outer products / accumulators on f64-accurate M, r, q (parity ~1e-8; ~5 % faster)
-//   3  deep pipeline kernel (lookup of the next chunks overlapped with the algebra), f64, 6 chunks per wave
-//   4  deep pipeline kernel, f32 outer products
-//   5  pipeline kernel in the source-frame formulation (per-voxel pre-pass + 6 adds instead of 45 FMAs per point), f64
-//   6  the same with f32 outer products
-int g_variant = 1;
-constexpr int kPipelineChunks = 4;      // 64-point chunks per wave: 1024-point tiles
-constexpr int kDeepPipelineChunks = 6;  // 1536-point tiles: 651 workgroups for 1 M points on the 768 slots of 3 workgroups per CU
+//   1  pipeline kernel, f64 throughout, hashed line table          (the round-1 default)
+//   2  pipeline kernel, f32 outer products / accumulators on f64-accurate M, r, q, hashed line table
+//   3  pipeline kernel, f64 throughout, occupancy-block grid
+//   4  pipeline kernel, f32 outer products, occupancy-block grid    (default)
+// Variants 3 / 4 fall back to 1 / 2 for a batch in which some map has no grid (bounding box beyond the block budget).
+// Measured and removed in round 2: the deep pipeline (lookups of the next chunks overlapped with the
+// algebra) and the source-frame formulation (per-voxel pre-pass).
+int g_variant = 4;
+int g_stagger = 0;
+bool g_trace_on = false;
+constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
 
 // where a launch takes its poses from
 struct PoseSource {
@@ -501,7 +382,8 @@ int build_table(gp_vgicp_batch* b) {
   std::vector<gp::TileDesc> tiles;
   b->total_points = 0;
   b->variant = g_variant;
-  b->tile_points = gp::kBlockThreads * ((g_variant == 3 || g_variant == 4) ? kDeepPipelineChunks : kPipelineChunks);
+  b->tile_points = gp::kBlockThreads * kPipelineChunks;
+  b->use_grid = true;
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -512,31 +394,13 @@ int build_table(gp_vgicp_batch* b) {
     d.map = f->target->view();
     d.n = f->n;
     d.surface_validation = (f->surface_validation && f->normals) ? 1 : 0;
-    d.posed = nullptr;
+    if (!d.map.gblocks) b->use_grid = false;
     d.tile_begin = (int)tiles.size();
     for (int p = 0; p < f->n; p += b->tile_points) tiles.push_back(gp::TileDesc{i, p, std::min(b->tile_points, f->n - p)});
     d.tile_count = (int)tiles.size() - d.tile_begin;
     b->total_points += f->n;
   }
   b->num_tiles = (int)tiles.size();
-  b->num_vtiles = 0;
-  if (g_variant == 5 || g_variant == 6) {
-    // per-factor slices of the posed-record buffer (a map shared by several factors is posed once per factor: different poses)
-    std::vector<gp::TileDesc> vtiles;
-    size_t total_voxels = 0;
-    for (int i = 0; i < F; i++) total_voxels += (size_t)std::max(descs[i].map.num_voxels, 0);
-    GP_TRY(b->d_posed.ensure(sizeof(double) * gp::kPosedDoubles * std::max<size_t>(total_voxels, 1)));
-    size_t off = 0;
-    for (int i = 0; i < F; i++) {
-      const int V = std::max(descs[i].map.num_voxels, 0);
-      descs[i].posed = b->d_posed.as<double>() + gp::kPosedDoubles * off;
-      for (int v = 0; v < V; v += 256) vtiles.push_back(gp::TileDesc{i, v, std::min(256, V - v)});
-      off += (size_t)V;
-    }
-    b->num_vtiles = (int)vtiles.size();
-    GP_TRY(b->d_vtiles.ensure(sizeof(gp::TileDesc) * std::max<size_t>(vtiles.size(), 1)));
-    if (!vtiles.empty()) GP_HIP(hipMemcpy(b->d_vtiles.ptr, vtiles.data(), sizeof(gp::TileDesc) * vtiles.size(), hipMemcpyHostToDevice));
-  }
   b->h_descs = descs;
   GP_TRY(b->d_factors.ensure(sizeof(gp::FactorDesc) * (size_t)std::max(F, 1)));
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
@@ -579,64 +443,45 @@ inline int grid_tiles(int num_tiles) {
   return per * gp::kNumXCD;
 }
 
-// is the 3x3 block of every pose orthonormal to 1e-9?  (GTSAM Pose3 values are; poses parsed from 6-digit text are not)
+// is the 3x3 block of every pose orthonormal to 1e-9?  (gp::pose_is_rigid, gp_vgicp_shared.hpp)
 bool poses_are_rigid(const double* poses_host, size_t F) {
   if (!poses_host) return false;
-  for (size_t i = 0; i < F; i++) {
-    const double* m = poses_host + 16 * i;
-    for (int a = 0; a < 3; a++)
-      for (int c = a; c < 3; c++) {
-        const double d = m[4 * a] * m[4 * c] + m[4 * a + 1] * m[4 * c + 1] + m[4 * a + 2] * m[4 * c + 2] - (a == c ? 1.0 : 0.0);
-        if (!(d < 1e-9 && d > -1e-9)) return false;
-      }
-    const double det = m[0] * (m[5] * m[10] - m[9] * m[6]) - m[4] * (m[1] * m[10] - m[9] * m[2]) + m[8] * (m[1] * m[6] - m[5] * m[2]);
-    if (!(det > 0.0)) return false;
-  }
+  for (size_t i = 0; i < F; i++)
+    if (!gp::pose_is_rigid(poses_host + 16 * i)) return false;
   return true;
 }
 
 template <int MODE>
 int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   if (b->num_tiles <= 0) return GP_OK;
-  const dim3 grid(grid_tiles(b->num_tiles)), block(gp::kBlockThreads);
+  const dim3 grid_dim(grid_tiles(b->num_tiles)), block(gp::kBlockThreads);
   const gp::FactorDesc* fd = b->d_factors.as<gp::FactorDesc>();
   const gp::TileDesc* td = b->d_tiles.as<gp::TileDesc>();
+  gp::InlinePoses inl = ps.inl;
+  inl.stagger = g_stagger;
   if constexpr (MODE == gp::MODE_LIN_GENERAL) {
     // the general (non-orthonormal pose) path always uses the reference-shaped kernel
-    hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials);
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
   } else {
-    switch (b->variant) {
-      case 0:
-        hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, ps.inl, partials);
-        break;
-      case 2:
-        hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
-                           ps.inl, partials);
-        break;
-      case 5:
-      case 6:
-        // pre-pass: this pass's voxel statistics in the source frame of every factor's linearisation pose
-        if (b->num_vtiles > 0)
-          hipLaunchKernelGGL(gp::pose_records_kernel<0>, dim3(b->num_vtiles), dim3(256), 0, b->stream, fd, b->d_vtiles.as<gp::TileDesc>(), ps.d_lin, ps.inl);
-        if (b->variant == 5)
-          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks, true>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
-                             ps.inl, partials);
-        else
-          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks, true>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
-                             ps.inl, partials);
-        break;
-      case 3:
-        hipLaunchKernelGGL((gp::vgicp_deep_pipeline_kernel<MODE, false, kDeepPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
-                           ps.inl, partials);
-        break;
-      case 4:
-        hipLaunchKernelGGL((gp::vgicp_deep_pipeline_kernel<MODE, true, kDeepPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
-                           ps.inl, partials);
-        break;
-      default:
-        hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks>), grid, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval,
-                           ps.inl, partials);
-        break;
+    const bool grid = (b->variant == 3 || b->variant == 4) && b->use_grid;
+    const bool f32 = b->variant == 2 || b->variant == 4;
+    if (b->variant == 0) {
+      hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
+    } else if (grid && f32 && g_trace_on && MODE == gp::MODE_LIN) {  // timeline build of the default kernel (gp_debug_set_trace_buffer)
+      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, kPipelineChunks, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
+                         ps.d_eval, inl, partials);
+    } else if (grid && f32) {
+      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
+                         partials);
+    } else if (grid) {
+      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
+                         partials);
+    } else if (f32) {
+      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks, false>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
+                         partials);
+    } else {
+      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks, false>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
+                         partials);
     }
   }
   GP_HIP(hipGetLastError());
@@ -658,10 +503,8 @@ int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* ou
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
   if (rigid) {
-    PoseSource rs = ps;
-    rs.inl.src_frame = (b->variant == 5 || b->variant == 6) ? 1 : 0;  // sums arrive in the source frame: the finalize kernel rotates them
-    GP_TRY(launch_tiles<gp::MODE_LIN>(b, rs, partials));
-    return launch_finalize<false>(b, rs, partials, out_dev);
+    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+    return launch_finalize<false>(b, ps, partials, out_dev);
   }
   GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
   return launch_finalize<true>(b, ps, partials, out_dev);
@@ -689,10 +532,18 @@ int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSo
     ps->inl.use = 1;
     return GP_OK;
   }
+  // the previous pass's H2D copy may still be reading the pinned staging buffer (the issue_* entry points are asynchronous):
+  // wait for it before the buffer is overwritten
+  if (b->h2d_done) {
+    GP_HIP(hipEventSynchronize(b->h2d_done));
+  } else {
+    GP_HIP(hipEventCreateWithFlags(&b->h2d_done, hipEventDisableTiming));
+  }
   double* h = b->h_poses.as<double>();
   memcpy(h, lin, sizeof(double) * 16 * F);
   if (eval) memcpy(h + 16 * F, eval, sizeof(double) * 16 * F);
   GP_HIP(hipMemcpyAsync(b->d_poses.ptr, h, sizeof(double) * 16 * F * (eval ? 2 : 1), hipMemcpyHostToDevice, b->stream));
+  GP_HIP(hipEventRecord(b->h2d_done, b->stream));
   ps->d_lin = b->d_poses.as<double>();
   ps->d_eval = eval ? b->d_poses.as<double>() + 16 * F : nullptr;
   ps->inl.use = 0;
@@ -719,12 +570,19 @@ extern "C" {
 int gp_debug_set_trace_buffer(void* dev_buffer) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buffer);
   GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gp::g_trace), &p, sizeof(p)));
+  g_trace_on = p != nullptr;
   return GP_OK;
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 6) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..6");
+  if (variant < 0 || variant > 4) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..4");
   g_variant = variant;
+  return GP_OK;
+}
+
+int gp_debug_set_stagger(int units) {
+  if (units < 0 || units > 64) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_stagger: 0..64 (x 512 clocks)");
+  g_stagger = units;
   return GP_OK;
 }
 
@@ -890,7 +748,12 @@ int gp_vgicp_batch_create(gp_vgicp_factor_t* const* factors, int num_factors, gp
 
 int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch) {
   if (!batch) return GP_OK;
-  (void)hipStreamSynchronize(batch->stream);
+  // the staging buffers are about to be freed: the last H2D copy must have finished.  The stream itself is the caller's and may
+  // already be gone (the reference's clone() drops it, integrated_vgicp_factor_gpu.cpp:122-134), so it is not synchronised here.
+  if (batch->h2d_done) {
+    (void)hipEventSynchronize(batch->h2d_done);
+    (void)hipEventDestroy(batch->h2d_done);
+  }
   delete batch;
   return GP_OK;
 }

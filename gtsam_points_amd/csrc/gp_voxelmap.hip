@@ -18,6 +18,7 @@
 #include <sstream>
 
 #include "gp_host.hpp"
+#include "gp_scan.hpp"
 
 namespace gp {
 
@@ -85,10 +86,10 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const float* __restrict
   unsafeAtomicAdd(s + 1, py - oy);
   unsafeAtomicAdd(s + 2, pz - oz);
   unsafeAtomicAdd(s + 3, (double)c[0]);  // xx
-  unsafeAtomicAdd(s + 4, (double)c[3]);  // xy  (column-major (0,1))
-  unsafeAtomicAdd(s + 5, (double)c[6]);  // xz
-  unsafeAtomicAdd(s + 6, (double)c[4]);  // yy
-  unsafeAtomicAdd(s + 7, (double)c[7]);  // yz
+  unsafeAtomicAdd(s + 4, 0.5 * ((double)c[3] + (double)c[1]));  // xy: symmetric part of the column-major 3x3 (the input itself when symmetric)
+  unsafeAtomicAdd(s + 5, 0.5 * ((double)c[6] + (double)c[2]));  // xz
+  unsafeAtomicAdd(s + 6, (double)c[4]);                         // yy
+  unsafeAtomicAdd(s + 7, 0.5 * ((double)c[7] + (double)c[5]));  // yz
   unsafeAtomicAdd(s + 8, (double)c[8]);  // zz
   atomicAdd(counts + v, 1);
   if (intensities) atomicMax(intensity_bits + v, __float_as_uint(intensities[i]));  // max intensity (:138-139)
@@ -146,6 +147,75 @@ __global__ void __launch_bounds__(256) line_claim_kernel(int num_voxels, const i
   }
 }
 
+
+// ---- occupancy-block grid (gp_device.hpp: GridBlock) ----------------------------------------------------------------
+struct GridGeom {
+  int lo[3];   // block coordinate of the low corner
+  int dim[3];  // blocks per axis
+};
+
+__host__ __device__ __forceinline__ long long grid_block_index(const GridGeom& g, int cx, int cy, int cz) {
+  const int bx = (cx >> 2) - g.lo[0], by = (cy >> 2) - g.lo[1], bz = (cz >> 2) - g.lo[2];
+  return ((long long)bz * g.dim[1] + by) * g.dim[0] + bx;
+}
+__host__ __device__ __forceinline__ int grid_bit(int cx, int cy, int cz) { return ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3); }
+
+// bounding box of the voxel coordinates in block units: bbox[0..2] = min, bbox[3..5] = max (wave reduce + one atomic per wave)
+__global__ void __launch_bounds__(256) coords_bbox_kernel(int num_voxels, const int* __restrict__ voxel_coords, int* __restrict__ bbox) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int u = v < num_voxels ? v : num_voxels - 1;
+  int lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) lo[a] = hi[a] = voxel_coords[3 * (size_t)u + a] >> 2;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(bbox + a, lo[a]);
+      atomicMax(bbox + 3 + a, hi[a]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) grid_mark_kernel(int num_voxels, const int* __restrict__ voxel_coords, GridGeom g, GridBlock* __restrict__ blocks) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_voxels) return;
+  const int cx = voxel_coords[3 * (size_t)v], cy = voxel_coords[3 * (size_t)v + 1], cz = voxel_coords[3 * (size_t)v + 2];
+  atomicOr(&blocks[grid_block_index(g, cx, cy, cz)].bits, 1ull << grid_bit(cx, cy, cz));
+}
+
+__global__ void __launch_bounds__(256) grid_count_kernel(long long num_blocks, GridBlock* __restrict__ blocks) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < num_blocks) blocks[b].base = __popcll(blocks[b].bits);
+}
+
+// new index of every voxel = base of its block + number of occupied bits below its own; coordinates move to the new order
+__global__ void __launch_bounds__(256) grid_renumber_kernel(int num_voxels, const int* __restrict__ coords_old, GridGeom g, const GridBlock* __restrict__ blocks,
+                                                            int* __restrict__ perm, int* __restrict__ coords_new) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_voxels) return;
+  const int cx = coords_old[3 * (size_t)v], cy = coords_old[3 * (size_t)v + 1], cz = coords_old[3 * (size_t)v + 2];
+  const GridBlock blk = blocks[grid_block_index(g, cx, cy, cz)];
+  const int nv = blk.base + __popcll(blk.bits & ((1ull << grid_bit(cx, cy, cz)) - 1ull));
+  perm[v] = nv;
+  coords_new[3 * (size_t)nv] = cx;
+  coords_new[3 * (size_t)nv + 1] = cy;
+  coords_new[3 * (size_t)nv + 2] = cz;
+}
+
+__global__ void __launch_bounds__(256) buckets_renumber_kernel(uint32_t num_buckets, gp_voxel_bucket* __restrict__ buckets, const int* __restrict__ perm) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= num_buckets) return;
+  const int v = buckets[b].voxel_index;
+  if (v >= 0) buckets[b].voxel_index = perm[v];
+}
+
 // lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
 __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ points, const float* __restrict__ normals, int n, VoxelMapView map,
                                                      const double* __restrict__ pose, int* __restrict__ out, int* __restrict__ hit_count) {
@@ -172,6 +242,11 @@ __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ p
 
 gp::VoxelMapView gp_voxelmap::view() const {
   gp::VoxelMapView v;
+  v.gblocks = has_grid ? gblocks.as<gp::GridBlock>() : nullptr;
+  for (int a = 0; a < 3; a++) {
+    v.glo[a] = glo[a];
+    v.gdim[a] = gdim[a];
+  }
   v.plines = plines.as<gp_voxel_bucket>();
   v.plmask = plmask;
   v.pad_ = 0;
@@ -226,6 +301,103 @@ static int build_private_table(gp_voxelmap* m, hipStream_t s) {
     GP_HIP(hipGetLastError());
   }
   return GP_OK;
+}
+
+
+constexpr long long kMaxGridBlocks = 1ll << 24;  // 16 B each: at most 256 MB per map; a larger box keeps the line table only
+
+// geometry of the block grid from the block-unit bounding box; false when the box exceeds the budget
+static bool grid_geometry(const int bbox[6], gp::GridGeom* g, long long* num_blocks) {
+  double nb = 1.0;
+  for (int a = 0; a < 3; a++) {
+    g->lo[a] = bbox[a];
+    const long long d = (long long)bbox[3 + a] - (long long)bbox[a] + 1;
+    if (d <= 0 || d > (1ll << 30)) return false;
+    g->dim[a] = (int)d;
+    nb *= (double)d;
+  }
+  if (nb > (double)kMaxGridBlocks) return false;
+  *num_blocks = (long long)g->dim[0] * g->dim[1] * g->dim[2];
+  return true;
+}
+
+// device build of the occupancy-block grid: bounding box -> occupancy bits -> prefix sums -> voxels renumbered in
+// (block, bit) order.  On return voxel_coords and the reference bucket table carry the NEW numbering (nothing else has been
+// computed per voxel yet).  Synchronises the stream.
+static int build_grid_device(gp_voxelmap* m, hipStream_t s) {
+  m->has_grid = false;
+  m->gblocks.release();
+  const int V = m->info.num_voxels;
+  if (V <= 0) return GP_OK;
+  gp::DeviceArray d_bbox;
+  GP_TRY(d_bbox.alloc(sizeof(int) * 6));
+  int h_bbox[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  GP_HIP(hipMemcpyAsync(d_bbox.ptr, h_bbox, sizeof(h_bbox), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gp::coords_bbox_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), d_bbox.as<int>());
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipMemcpyAsync(h_bbox, d_bbox.ptr, sizeof(h_bbox), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  gp::GridGeom g;
+  long long nb = 0;
+  if (!grid_geometry(h_bbox, &g, &nb)) return GP_OK;
+  GP_TRY(m->gblocks.alloc(sizeof(gp::GridBlock) * (size_t)nb));
+  GP_HIP(hipMemsetAsync(m->gblocks.ptr, 0, sizeof(gp::GridBlock) * (size_t)nb, s));
+  gp::GridBlock* blocks = m->gblocks.as<gp::GridBlock>();
+  hipLaunchKernelGGL(gp::grid_mark_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), g, blocks);
+  GP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(gp::grid_count_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, nb, blocks);
+  GP_HIP(hipGetLastError());
+  gp::DeviceArray scratch, perm, coords_new;
+  GP_TRY(scratch.alloc(sizeof(int) * (size_t)(nb / gp::kScanThreads + 4)));
+  GP_TRY(perm.alloc(sizeof(int) * (size_t)V));
+  GP_TRY(coords_new.alloc(sizeof(int) * 3 * (size_t)V));
+  int* base0 = &blocks[0].base;
+  GP_TRY(gp::exclusive_scan_strided(base0, 4, base0, 4, nb, scratch.as<int>(), s));
+  hipLaunchKernelGGL(gp::grid_renumber_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), g, (const gp::GridBlock*)blocks, perm.as<int>(),
+                     coords_new.as<int>());
+  GP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(gp::buckets_renumber_kernel, dim3(grid_for((size_t)m->info.num_buckets)), dim3(kBlock), 0, s, (uint32_t)m->info.num_buckets,
+                     m->buckets.as<gp_voxel_bucket>(), (const int*)perm.as<int>());
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipStreamSynchronize(s));  // perm / scratch die with this scope
+  m->voxel_coords.swap(coords_new);
+  for (int a = 0; a < 3; a++) {
+    m->glo[a] = g.lo[a];
+    m->gdim[a] = g.dim[a];
+  }
+  m->has_grid = true;
+  return GP_OK;
+}
+
+// host build of the same structure (load / assign path): returns the permutation old index -> new index
+static bool build_grid_host(int V, const int* coords, gp::GridGeom* g, std::vector<gp::GridBlock>* blocks, std::vector<int>* perm) {
+  if (V <= 0) return false;
+  int bbox[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int v = 0; v < V; v++)
+    for (int a = 0; a < 3; a++) {
+      bbox[a] = std::min(bbox[a], coords[3 * (size_t)v + a] >> 2);
+      bbox[3 + a] = std::max(bbox[3 + a], coords[3 * (size_t)v + a] >> 2);
+    }
+  long long nb = 0;
+  if (!grid_geometry(bbox, g, &nb)) return false;
+  blocks->assign((size_t)nb, gp::GridBlock{0ull, 0, 0});
+  for (int v = 0; v < V; v++) {
+    const int* c = coords + 3 * (size_t)v;
+    (*blocks)[(size_t)gp::grid_block_index(*g, c[0], c[1], c[2])].bits |= 1ull << gp::grid_bit(c[0], c[1], c[2]);
+  }
+  int run = 0;
+  for (auto& b : *blocks) {
+    b.base = run;
+    run += __builtin_popcountll(b.bits);
+  }
+  if (run != V) return false;  // duplicate coordinates in the input: no canonical numbering
+  perm->resize((size_t)V);
+  for (int v = 0; v < V; v++) {
+    const int* c = coords + 3 * (size_t)v;
+    const gp::GridBlock& b = (*blocks)[(size_t)gp::grid_block_index(*g, c[0], c[1], c[2])];
+    (*perm)[(size_t)v] = b.base + __builtin_popcountll(b.bits & ((1ull << gp::grid_bit(c[0], c[1], c[2])) - 1ull));
+  }
+  return true;
 }
 
 static inline gp_voxelmap* ext(gp_voxelmap* m) { return m; }
@@ -302,6 +474,8 @@ int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float*
   GP_HIP(hipStreamSynchronize(s));
   const int V = h_counters[0];
   m->info.num_voxels = V;
+  // occupancy-block grid + canonical voxel numbering (block order); the bucket table and voxel_coords follow it
+  GP_TRY(build_grid_device(m, s));
 
   // ---- accumulate + finalize (:218-250) ----
   GP_TRY(alloc_voxel_arrays(m, V));
@@ -394,6 +568,32 @@ int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, co
   if (num_voxels > 0 && (!coords || !num_points || !means || !covs6)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_assign: null arrays");
   auto* m = ext(map);
   const size_t V = (size_t)num_voxels;
+  // occupancy-block grid + canonical (block-order) numbering: the input arrays are permuted before anything is derived from them
+  gp::GridGeom geom{};
+  std::vector<gp::GridBlock> h_blocks;
+  std::vector<int> perm, p_coords, p_np;
+  std::vector<float> p_means, p_covs6, p_int;
+  const bool grid = build_grid_host(num_voxels, coords, &geom, &h_blocks, &perm);
+  if (grid) {
+    p_coords.resize(3 * V);
+    p_np.resize(V);
+    p_means.resize(3 * V);
+    p_covs6.resize(6 * V);
+    if (intensities) p_int.resize(V);
+    for (size_t v = 0; v < V; v++) {
+      const size_t nv = (size_t)perm[v];
+      memcpy(p_coords.data() + 3 * nv, coords + 3 * v, sizeof(int) * 3);
+      p_np[nv] = num_points[v];
+      memcpy(p_means.data() + 3 * nv, means + 3 * v, sizeof(float) * 3);
+      memcpy(p_covs6.data() + 6 * nv, covs6 + 6 * v, sizeof(float) * 6);
+      if (intensities) p_int[nv] = intensities[v];
+    }
+    coords = p_coords.data();
+    num_points = p_np.data();
+    means = p_means.data();
+    covs6 = p_covs6.data();
+    if (intensities) intensities = p_int.data();
+  }
   std::vector<gp_voxel_bucket> h_buckets;
   const int max_scan = m->info.max_bucket_scan_count;
   auto assign_buckets = [&](int64_t nb) {
@@ -457,6 +657,17 @@ int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, co
     GP_HIP(hipMemcpyAsync(m->voxel_covs.ptr, h_covs.data(), sizeof(float) * 9 * V, hipMemcpyHostToDevice, s));
     GP_HIP(hipMemcpyAsync(m->voxel_intensities.ptr, h_int.data(), sizeof(float) * V, hipMemcpyHostToDevice, s));
     GP_HIP(hipMemcpyAsync(m->voxel_coords.ptr, coords, sizeof(int) * 3 * V, hipMemcpyHostToDevice, s));
+  }
+  m->has_grid = false;
+  m->gblocks.release();
+  if (grid) {
+    GP_TRY(m->gblocks.alloc(sizeof(gp::GridBlock) * h_blocks.size()));
+    GP_HIP(hipMemcpyAsync(m->gblocks.ptr, h_blocks.data(), sizeof(gp::GridBlock) * h_blocks.size(), hipMemcpyHostToDevice, s));
+    for (int a = 0; a < 3; a++) {
+      m->glo[a] = geom.lo[a];
+      m->gdim[a] = geom.dim[a];
+    }
+    m->has_grid = true;
   }
   GP_HIP(hipStreamSynchronize(s));  // the staging vectors die with this scope
   GP_TRY(build_private_table(m, s));
@@ -549,10 +760,12 @@ size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
   if (!map) return 0;
   // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records, coordinates and line table this implementation adds
   return (size_t)map->info.num_voxels * (sizeof(int) + sizeof(float) * 3 + sizeof(float) * 9 + sizeof(gp::VoxelRecord) + sizeof(int) * 3) +
-         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + ((size_t)map->plmask + 1) * 4 * sizeof(gp_voxel_bucket);
+         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + ((size_t)map->plmask + 1) * 4 * sizeof(gp_voxel_bucket) +
+         (map->has_grid ? (size_t)map->gdim[0] * map->gdim[1] * map->gdim[2] * sizeof(gp::GridBlock) : 0);
 }
 
 int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map) { return map && map->loaded() ? 1 : 0; }
+int gp_voxelmap_has_block_grid(const gp_voxelmap_t* map) { return map && map->has_grid ? 1 : 0; }
 
 static int to_host(std::vector<char>& dst, const gp::DeviceArray& src, size_t bytes, hipStream_t s) {
   dst.resize(bytes);
@@ -579,6 +792,8 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   GP_TRY(to_host(m->h_covs, m->voxel_covs, sizeof(float) * 9 * V, s));
   GP_TRY(to_host(m->h_intensities, m->voxel_intensities, sizeof(float) * V, s));
   GP_TRY(to_host(m->h_coords, m->voxel_coords, sizeof(int) * 3 * V, s));
+  const size_t G = m->has_grid ? (size_t)m->gdim[0] * m->gdim[1] * m->gdim[2] : 0;
+  GP_TRY(to_host(m->h_gblocks, m->gblocks, sizeof(gp::GridBlock) * G, s));
   GP_HIP(hipStreamSynchronize(s));
   m->buckets.release();
   m->records.release();
@@ -588,6 +803,7 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   m->voxel_intensities.release();
   m->voxel_coords.release();
   m->plines.release();
+  m->gblocks.release();
   m->offloaded = true;
   m->generation++;
   return GP_OK;
@@ -605,6 +821,7 @@ int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream) {
   GP_TRY(to_device(m->voxel_covs, m->h_covs, s));
   GP_TRY(to_device(m->voxel_intensities, m->h_intensities, s));
   GP_TRY(to_device(m->voxel_coords, m->h_coords, s));
+  if (m->has_grid) GP_TRY(to_device(m->gblocks, m->h_gblocks, s));
   GP_TRY(build_private_table(m, s));
   GP_HIP(hipStreamSynchronize(s));
   m->offloaded = false;

@@ -18,8 +18,13 @@
  *     Eigen::Isometry3f the reference uploads (integrated_vgicp_factor_gpu.cpp:136-164).
  *     Double is required for <=1e-5 parity with the CPU IntegratedVGICPFactor.
  *   - Source clouds are caller-owned device arrays in the reference's GPU layout
- *     (types/point_cloud.hpp:114-118): points float[N][3], covs float[N][9] (3x3,
- *     symmetric), normals float[N][3] (optional).  The library never frees them.
+ *     (types/point_cloud.hpp:114-118): points float[N][3], covs float[N][9] (column-major
+ *     3x3), normals float[N][3] (optional).  The library never frees them.
+ *   - Covariances: all nine entries are read.  A symmetric matrix (what estimate_covariances
+ *     produces after the cast to float) is used as it is; of a non-symmetric one the kernels use
+ *     the symmetric part (a_ij + a_ji) / 2, formed in double -- the part the reference CPU
+ *     factor's full 3x3 algebra sees to first order in the asymmetry (the HessianFactor keeps
+ *     only the upper triangle of H, integrated_matching_cost_factor.cpp:49).
  *   - gp_stream_t is a hipStream_t (the reference's CUstream_st*).  NULL = default stream.
  *   - Handles are thread-compatible (external synchronisation per handle).
  */
@@ -136,6 +141,9 @@ int gp_voxelmap_load(const char* path, gp_stream_t stream, gp_voxelmap_t** out);
 /* OffloadableGPU: memory_usage_gpu / loaded_on_gpu / offload_gpu / reload_gpu, gaussian_voxelmap_gpu.cu:469-535 */
 size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map);
 int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map);
+/* 1 when the map carries the occupancy-block grid the default VGICP kernel looks voxels up in (bounding box <= 2^24 blocks of
+ * 4x4x4 voxels), 0 when only the hashed tables exist (the kernels then use those) */
+int gp_voxelmap_has_block_grid(const gp_voxelmap_t* map);
 int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream);
 int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream);
 /* correspondence lookup of delta * p for every source point -> voxel index or -1
@@ -302,11 +310,16 @@ int gp_dense_system_download(const gp_dense_system_t* sys, double* A_host, doubl
 /* x (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
 int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev);
 
-/* tuning hook (not part of the reference API): tile-kernel variant.  0 = reference-shaped kernel, 1 = pipeline kernel in f64
- * (default), 2 = pipeline kernel with f32 outer products, 3/4 = deep pipeline (f64 / f32 outer), 5/6 = source-frame formulation
- * (f64 / f32 outer); see gp_vgicp.hip and DESIGN.md section 8 */
+/* kernel selection (not part of the reference API): 0 = reference-shaped kernel (reference bucket table, 92 explicit sums: also
+ * the path of non-orthonormal poses and the in-library cross-check), 1 / 2 = pipeline kernel over the hashed line table in f64 /
+ * with f32 outer products, 3 / 4 = pipeline kernel over the occupancy-block grid in f64 / with f32 outer products.  Default 4:
+ * M = (C_B + R C_A R^T)^-1, the transform and the residual are f64 in every variant; "f32 outer products" computes what follows
+ * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md section 8 */
 int gp_debug_set_variant(int variant);
-/* timeline hook: per-workgroup phase timestamps (s_memtime) of the pipeline kernel into dev_buffer ([num_tiles][8] uint64) */
+/* tuning knob: the odd wave slots of every SIMD start `units` x 512 clocks late (0 = off, default) */
+int gp_debug_set_stagger(int units);
+/* timeline hook: per-workgroup phase timestamps (s_memtime) of the default pipeline kernel into dev_buffer ([num_tiles][16] uint64:
+ * slots 0-7 phases, 8 HW_ID, 9 XCC_ID); NULL disables */
 int gp_debug_set_trace_buffer(void* dev_buffer);
 /* measurement hook (gp_microbench.hip): mode 0-2 time to just read the 48*n source bytes (strided dwords / float4 / LDS-DMA),
  * 3-12 source + voxel-gather access patterns, 100-115 VALU issue rates; see scripts/stream_bench.py, scripts/alu_rate.py */

@@ -1,0 +1,153 @@
+"""Round-2 tuning sweep of the tile kernel on the GPU box (one JSON object per line on stdout):
+  * kernel variants 1-4 (hashed line table / occupancy-block grid x f64 / f32 outer products) on the C2 workload:
+    tile-kernel time (HIP events, best of 3 x 50 launches), whole device pass, synchronous call, parity vs the oracle
+  * the phase-stagger knob on the f32 variants
+  * per-workgroup timeline of the default kernel incl. the hardware placement (HW_ID) of every workgroup
+  * the real kernel on an 8 M-point source (working set > the 256 MiB Infinity Cache)
+Usage: python scripts/r02_sweep.py [variants] [staggers] [--big]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import gtsam_points_amd as gpa  # noqa: E402
+import oracle  # noqa: E402
+from gtsam_points_amd import _capi, synthetic  # noqa: E402
+
+lib = gpa.load()
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+variants = [int(v) for v in (args[0] if len(args) > 0 else "1,2,3,4").split(",")]
+staggers = [int(v) for v in (args[1] if len(args) > 1 else "0,1,2,3,4,6").split(",")]
+BIG = "--big" in sys.argv
+BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
+
+
+def make_batch(f):
+    arr = (C.c_void_p * 1)(f._h.value)
+    batch, s = C.c_void_p(), C.c_void_p()
+    lib.gp_stream_create(C.byref(s))
+    _capi.check(lib.gp_vgicp_batch_create(arr, 1, s, C.byref(batch)), "batch")
+    return batch, s
+
+
+def time_batch(batch, pose, iters=50, reps=3):
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    best = (1e9, 0, 0)
+    for _ in range(reps):
+        _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pose.ctypes.data, iters, C.byref(a), C.byref(b), C.byref(c)), "time")
+        best = min(best, (b.value, a.value, c.value))
+    return best
+
+
+def run_case(name, d, res, delta, Lo, iters=50):
+    tgt = gpa.PointCloudGPU(d["target_points"], d["target_covs"])
+    src = gpa.PointCloudGPU(d["source_points"], d["source_covs"])
+    vm = gpa.GaussianVoxelMapGPU(res, target_points_drop_rate=0.0)
+    t0 = time.perf_counter()
+    vm.insert(tgt)
+    t_map = time.perf_counter() - t0
+    f = gpa.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
+    out = np.zeros((1, 122))
+    for v in variants:
+        for st in (staggers if v in (2, 4) else [0]):
+            _capi.check(lib.gp_debug_set_variant(v), "variant")
+            _capi.check(lib.gp_debug_set_stagger(st), "stagger")
+            batch, s = make_batch(f)
+            _capi.check(lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data), "lin")
+            L = gpa.LinearizedSystem6.from_doubles(out[0])
+            errs = {k: float(np.linalg.norm(getattr(L, k) - getattr(Lo, k)) / np.linalg.norm(getattr(Lo, k))) for k in BLOCKS} if Lo is not None else {}
+            best = time_batch(batch, pose, iters)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
+            wall = (time.perf_counter() - t0) / 200 * 1e3
+            alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+            print(json.dumps(dict(case=name, variant=v, stagger=st, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5), fin_ms=round(best[2], 5), sync_call_ms=round(wall, 5),
+                                  frac=round(alg / (best[0] * 1e-3) / 8e12, 4), alg_bytes=alg, max_rel_err=max(errs.values()) if errs else None,
+                                  inliers_ok=(L.num_inliers == Lo.num_inliers) if Lo is not None else None, has_grid=int(lib.gp_voxelmap_has_block_grid(vm._h)),
+                                  voxels=vm.voxelmap_info.num_voxels, map_build_ms=round(t_map * 1e3, 3))), flush=True)
+            lib.gp_vgicp_batch_destroy(batch)
+            lib.gp_stream_destroy(s)
+    lib.gp_debug_set_stagger(0)
+    lib.gp_debug_set_variant(4)
+    return f, vm, src, tgt
+
+
+def trace_case(f, delta, stagger, label):
+    lib.gp_debug_set_variant(4)
+    lib.gp_debug_set_stagger(stagger)
+    batch, s = make_batch(f)
+    pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
+    out = np.zeros((1, 122))
+    for _ in range(5):
+        lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
+    trace = torch.zeros((2048, 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    _capi.check(lib.gp_debug_set_trace_buffer(C.c_void_p(trace.data_ptr())), "trace")
+    lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
+    torch.cuda.synchronize()
+    lib.gp_debug_set_trace_buffer(None)
+    raw = trace.cpu().numpy()
+    raw = raw[raw[:, 0] > 0]
+    t = raw[:, :8].astype(np.float64)
+    hw = raw[:, 8]
+    xcc = raw[:, 9] & 0xF
+    wave_slot, simd, cu, sh, se = hw & 0xF, (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+    names = ["start", "chunk0", "look0", "step0_done", "look1", "step1_done", "steps_done", "end"]
+    dur = np.diff(t, axis=1) / 2100.0
+    # per clock domain (XCC): lifetimes and end skew
+    doms = []
+    for x in sorted(set(xcc.tolist())):
+        r = t[xcc == x]
+        s0 = r[:, 0].min()
+        doms.append(dict(xcc=int(x), wgs=int(len(r)), start_skew_us=round(float((r[:, 0].max() - s0) / 2100), 2), last_end_us=round(float((r[:, 7].max() - s0) / 2100), 2),
+                         median_life_us=round(float(np.median(r[:, 7] - r[:, 0]) / 2100), 2)))
+    # placement: workgroups per (xcc, se, sh, cu), and which tile indices share a CU
+    keys = xcc * 4096 + se * 512 + sh * 256 + cu
+    uniq, counts = np.unique(keys, return_counts=True)
+    tile_ids = np.nonzero(trace.cpu().numpy()[:, 0] > 0)[0]
+    same_cu = {}
+    for k_, tid in zip(keys.tolist(), tile_ids.tolist()):
+        same_cu.setdefault(k_, []).append(tid)
+    example = [v for v in same_cu.values()][:4]
+    print(json.dumps(dict(trace=label, stagger=stagger, wgs=int(len(t)), phases=names,
+                          phase_median_us=[round(float(np.median(dur[:, k])), 3) for k in range(7)], phase_p90_us=[round(float(np.percentile(dur[:, k], 90)), 3) for k in range(7)],
+                          domains=doms, cus_used=int(len(uniq)), wgs_per_cu_hist=np.bincount(counts).tolist(), wave_slot_hist=np.bincount(wave_slot.astype(np.int64), minlength=16).tolist(),
+                          simd_hist=np.bincount(simd.astype(np.int64), minlength=4).tolist(), tiles_sharing_a_cu_examples=example)), flush=True)
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+    lib.gp_debug_set_stagger(0)
+
+
+d = synthetic.make_c2_workload()
+delta = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+om = oracle.OracleVoxelMap(0.5)
+om.insert(d["target_points"], d["target_covs"])
+Lo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], oracle.max_threads()).linearize(delta)
+f, vm, src, tgt = run_case("c2_1M", d, 0.5, delta, Lo)
+trace_case(f, delta, 0, "c2_1M default")
+for st in [s for s in staggers if s > 0][:2]:
+    trace_case(f, delta, st, "c2_1M staggered")
+
+k = np.load(os.path.join(ROOT, "tests/golden/kitti00_dec8.npz"))
+dk = {n: k[n] for n in k.files}
+dlt = synthetic.expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+omk = oracle.OracleVoxelMap(0.5)
+omk.insert(dk["target_points"], dk["target_covs"])
+Lok = oracle.OracleVGICPFactor(omk, dk["source_points"], dk["source_covs"], 4).linearize(dlt)
+staggers = [0]
+run_case("kitti00_dec8", dk, 0.5, dlt, Lok, iters=200)
+
+if BIG:
+    # the real kernel on a working set beyond the 256 MiB Infinity Cache: 8 M source points (384 MB) vs the same 2 M-point map
+    big = synthetic.make_c2_workload(8_000_000, 2_000_000, seed=42)
+    variants = [4, 3]
+    run_case("c2_8M_source", big, 0.5, big["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015]), None, iters=20)

@@ -1,7 +1,9 @@
 """GPU parity tests of the VGICP hot path: HIP (through the C-ABI) vs the CPU oracle on the same seeded inputs.
 
-Tolerance: the north-star gate is <= 1e-5 relative on H and b; the HIP path computes in f64 and stores only the voxel
-mean offset in f32, so these tests hold it to 1e-7 (PARITY_TOL) -- two orders tighter than required."""
+Tolerance: the north-star gate is <= 1e-5 relative on H and b.  The default kernel (variant 4) computes the transform, the
+fused covariance, its inverse and the residual in f64 and the outer products that follow in f32: measured <= 1e-7, held
+here to PARITY_TOL = 1e-6 -- ten times tighter than required.  The all-f64 variants (0, 1, 3) are held to F64_TOL = 1e-7
+(the only f32 quantity left is the stored voxel mean offset)."""
 import ctypes as C
 
 import numpy as np
@@ -11,7 +13,8 @@ import oracle
 from helpers import BLOCKS, assert_linearized_close, expmap, lm_optimize, pose_error, rel_err
 
 pytestmark = pytest.mark.gpu
-PARITY_TOL = 1e-7
+PARITY_TOL = 1e-6
+F64_TOL = 1e-7
 
 
 def _build(gpu, d, res, drop_rate=0.0, **kw):
@@ -73,12 +76,15 @@ def test_rigid_and_general_pose_paths(gpu, kitti00):
         assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), PARITY_TOL, name)
 
 
-@pytest.mark.parametrize("variant,tol", [(0, PARITY_TOL), (1, PARITY_TOL), (2, 1e-6), (3, PARITY_TOL), (4, 1e-6), (5, PARITY_TOL), (6, 1e-6)])
+DEFAULT_VARIANT = 4
+MIXED_TOL = 1e-6  # variants with f32 outer products (2, 4): measured <= 1e-7, gate 1e-5
+
+
+@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (1, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (4, MIXED_TOL)])
 def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
-    """gp_debug_set_variant: 0 reference-shaped kernel, 1 pipeline kernel (default), 2 pipeline + f32 outer products,
-    3 / 4 deep pipeline (lookup overlapped with the algebra) in f64 / f32 outer products, 5 / 6 source-frame formulation
-    (per-voxel pre-pass, sums rotated back by the finalize kernel) in f64 / f32 outer products -- linearise and error evaluation,
-    full tiles, a partial tile and the per-lane fallback all go through the selected kernel"""
+    """gp_debug_set_variant: 0 reference-shaped kernel, 1 / 2 pipeline kernel over the hashed line table (f64 / f32 outer products),
+    3 / 4 pipeline kernel over the occupancy-block grid (f64 / f32 outer products; 4 is the default) -- linearise and error
+    evaluation, full tiles, a partial tile and the per-lane fallback all go through the selected kernel"""
     lib = gpu.load()
     try:
         gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
@@ -94,7 +100,7 @@ def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
         eo = fo.error(de)
         assert abs(err.value - eo) <= tol * abs(eo)
     finally:
-        lib.gp_debug_set_variant(1)
+        lib.gp_debug_set_variant(DEFAULT_VARIANT)
 
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1023, 1024, 1025, 4097])
@@ -139,7 +145,7 @@ def test_unaligned_source_views(gpu, kitti00):
     aligned = gpu.PointCloudGPU(d["source_points"], d["source_covs"])
     La = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, aligned), delta)
     assert L.num_inliers == La.num_inliers
-    assert_linearized_close(L, La, 1e-13, "unaligned vs aligned path")  # two instantiations of the same algebra: last-bit differences only
+    assert_linearized_close(L, La, 1e-7, "unaligned vs aligned path")  # two instantiations of the same algebra: last-bit (f32) differences only
     del torch
 
 
@@ -155,8 +161,11 @@ def _coord_hash32(x, y, z):
     return h
 
 
-def test_line_table_overflow_walks_on(gpu):
-    """the pipeline kernel's line table holds 4 keys per home line; seven voxels built to share one home line force the
+@pytest.mark.parametrize("variant", [1, 2, 4])
+def test_line_table_overflow_walks_on(gpu, variant):
+    """(variants 1 / 2: the hashed line table, the fallback of maps too large for the block grid; variant 4: the same voxels
+    through the occupancy-block grid, where nothing collides)
+    the pipeline kernel's line table holds 4 keys per home line; seven voxels built to share one home line force the
     walk-on path (full line, no match -> next line) for hits, and a probe of the same full line for a voxel that does not
     exist must end as a miss.  Checked against the oracle, which uses an exact hash map."""
     rng = np.random.default_rng(21)
@@ -181,14 +190,37 @@ def test_line_table_overflow_walks_on(gpu):
         return (a @ a.transpose(0, 2, 1) * 0.01 + 1e-3 * np.eye(3)).astype(np.float32)
 
     d = dict(target_points=tgt_pts, target_covs=covs(len(tgt_pts)), source_points=src_pts, source_covs=covs(len(src_pts)))
-    _, src, vm = _build(gpu, d, res)
-    assert vm.voxelmap_info.num_voxels == 8
+    lib = gpu.load()
+    try:
+        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
+        _, src, vm = _build(gpu, d, res)
+        assert vm.voxelmap_info.num_voxels == 8
+        f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+        _, fo = _oracle(d, res, 1)
+        Lo = fo.linearize(np.eye(4))
+        L = _sync_linearize(gpu, f, np.eye(4))
+        assert Lo.num_inliers == 7 * 96 and L.num_inliers == Lo.num_inliers  # every present voxel found, the absent ones missed
+        assert_linearized_close(L, Lo, PARITY_TOL, "colliding voxels")
+    finally:
+        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+
+
+def test_block_grid_fallback_for_huge_boxes(gpu, kitti00):
+    """a map whose bounding box needs more than 2^24 occupancy blocks (here: the scan plus one point 20 km away at 0.25 m voxels)
+    carries no block grid; the default variant then runs over the hashed line table and must give the same answer"""
+    d = dict(kitti00)
+    far = np.array([[20000.0, -15000.0, 3000.0]], np.float32)
+    d["target_points"] = np.concatenate([kitti00["target_points"], far])
+    d["target_covs"] = np.concatenate([kitti00["target_covs"], kitti00["target_covs"][:1]])
+    _, src, vm = _build(gpu, d, 0.25)
+    assert vm._lib.gp_voxelmap_has_block_grid(vm._h) == 0
     f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
-    _, fo = _oracle(d, res, 1)
-    Lo = fo.linearize(np.eye(4))
-    L = _sync_linearize(gpu, f, np.eye(4))
-    assert Lo.num_inliers == 7 * 96 and L.num_inliers == Lo.num_inliers  # every present voxel found, the absent ones missed
-    assert_linearized_close(L, Lo, PARITY_TOL, "colliding voxels")
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    _, fo = _oracle(d, 0.25)
+    assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), PARITY_TOL, "no block grid")
+    # the same scan without the far point has a grid: same correspondences except none for the far voxel
+    _, src2, vm2 = _build(gpu, kitti00, 0.25)
+    assert vm.voxelmap_info.num_voxels == vm2.voxelmap_info.num_voxels + 1 and vm2._lib.gp_voxelmap_has_block_grid(vm2._h) == 1
 
 
 def test_offloading_protocol(gpu, kitti00):
@@ -382,7 +414,7 @@ def test_linearity_and_determinism_at_1m(gpu):
         s = gpu.PointCloudGPU(d["source_points"][sl], d["source_covs"][sl])
         halves.append((_sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, s), delta), s))
     for k in BLOCKS:
-        assert rel_err(getattr(halves[0][0], k) + getattr(halves[1][0], k), getattr(L, k)) < 1e-12
+        assert rel_err(getattr(halves[0][0], k) + getattr(halves[1][0], k), getattr(L, k)) < 1e-7  # f32 per-lane sums of <= 4 points regroup
     assert halves[0][0].num_inliers + halves[1][0].num_inliers == L.num_inliers
     assert rel_err(L.H_source, L.H_source.T) < 1e-12 and np.linalg.eigvalsh(L.H_source).min() > 0
     vo, fo = _oracle(d, 0.5, oracle.max_threads())
