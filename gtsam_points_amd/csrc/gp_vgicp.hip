@@ -552,10 +552,17 @@ int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSo
 
 int ensure_self_batch(gp_vgicp_factor* f) {
   if (!f->self_batch) {
-    gp_vgicp_batch_t* b = nullptr;
-    gp_vgicp_factor_t* one = f;
-    GP_TRY(gp_vgicp_batch_create(&one, 1, f->stream, &b));
+    // a batch of one on the factor's own stream whose partials live in the factor's TempBufferManager arena
+    // (set before the table is built, so that no second partials array is allocated)
+    auto* b = new gp_vgicp_batch;
+    b->factors.push_back(f);
+    b->stream = f->stream;
     b->temp_buffer = f->temp_buffer;
+    const int rc = build_table(b);
+    if (rc != GP_OK) {
+      delete b;
+      return rc;
+    }
     f->self_batch = b;
   }
   if (table_is_stale(f->self_batch)) GP_TRY(build_table(f->self_batch));
