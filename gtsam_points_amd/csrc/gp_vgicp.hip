@@ -344,6 +344,7 @@ struct gp_vgicp_batch {
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
   bool use_grid = false;  // every factor's map carries an occupancy-block grid (else the hashed line table is used)
+  int ppt = 4;            // 64-point chunks per wave of the pipeline kernel (tile = 256 x ppt points)
   std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
   hipEvent_t h2d_done = nullptr;  // recorded behind every H2D copy of h_poses; the next staging waits on it
@@ -364,9 +365,29 @@ namespace {
 // Variants 3 / 4 fall back to 1 / 2 for a batch in which some map has no grid (bounding box beyond the block budget).
 // Measured and removed in round 2: the deep pipeline (lookups of the next chunks overlapped with the
 // algebra) and the source-frame formulation (per-voxel pre-pass).
+//      Variant 4 starts lean (the prologue requests chunk 0 only; chunk 1 follows the first lookup) and picks the tile size from
+//      the batch: the largest of 1024 / 512 / 256 points that still gives >= 768 tiles (3/4 of the 1024 resident workgroups),
+//      so that a 15 k-point scan is not left to 15 workgroups.
+//   5  as 4 without the lean start, always 1024-point tiles (the first round-2 kernel; A/B)
+//   6 / 7  as 4 with 512- / 256-point tiles forced (A/B)
 int g_variant = 4;
 int g_stagger = 0;
 bool g_trace_on = false;
+struct VariantDesc {
+  bool f32, grid, lean;
+  int ppt;  // 64-point chunks per wave (0 = chosen per batch)
+};
+VariantDesc variant_desc(int v) {
+  switch (v) {
+    case 1: return {false, false, false, 4};
+    case 2: return {true, false, false, 4};
+    case 3: return {false, true, false, 4};
+    case 5: return {true, true, false, 4};
+    case 6: return {true, true, true, 2};
+    case 7: return {true, true, true, 1};
+    default: return {true, true, true, 0};
+  }
+}
 constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
 
 // where a launch takes its poses from
@@ -382,7 +403,25 @@ int build_table(gp_vgicp_batch* b) {
   std::vector<gp::TileDesc> tiles;
   b->total_points = 0;
   b->variant = g_variant;
-  b->tile_points = gp::kBlockThreads * kPipelineChunks;
+  {
+    int ppt = b->variant >= 1 ? variant_desc(b->variant).ppt : kPipelineChunks;
+    bool all_grid = true;
+    for (const auto* f : b->factors) all_grid = all_grid && f->target->has_grid;
+    if (!all_grid) ppt = kPipelineChunks;  // the hashed-line-table kernel exists for 1024-point tiles only
+    if (ppt == 0) {  // per batch: the largest tile that still fills 3/4 of the chip's resident workgroups
+      ppt = 1;
+      for (int cand : {4, 2}) {
+        int64_t tiles = 0;
+        for (const auto* f : b->factors) tiles += (f->n + 256 * cand - 1) / (256 * cand);
+        if (tiles >= 768) {
+          ppt = cand;
+          break;
+        }
+      }
+    }
+    b->ppt = ppt;
+    b->tile_points = 64 * 4 * ppt;
+  }
   b->use_grid = true;
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
@@ -463,26 +502,31 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
     // the general (non-orthonormal pose) path always uses the reference-shaped kernel
     hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
   } else {
-    const bool grid = (b->variant == 3 || b->variant == 4) && b->use_grid;
-    const bool f32 = b->variant == 2 || b->variant == 4;
+    const VariantDesc vd = variant_desc(b->variant);
+    const bool grid = vd.grid && b->use_grid;
+#define GP_LAUNCH_PIPE(F32, PPT, GRID, TRACE, LEAN)                                                                                                         \
+  hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, F32, PPT, GRID, TRACE, LEAN>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, \
+                     partials)
     if (b->variant == 0) {
       hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
-    } else if (grid && f32 && g_trace_on && MODE == gp::MODE_LIN) {  // timeline build of the default kernel (gp_debug_set_trace_buffer)
-      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, kPipelineChunks, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
+    } else if (!grid) {  // hashed line table (variants 1 / 2, or a map without a block grid): 1024-point tiles
+      if (vd.f32) GP_LAUNCH_PIPE(true, 4, false, false, false);
+      else GP_LAUNCH_PIPE(false, 4, false, false, false);
+    } else if (!vd.f32) {
+      GP_LAUNCH_PIPE(false, 4, true, false, false);
+    } else if (!vd.lean) {
+      GP_LAUNCH_PIPE(true, 4, true, false, false);
+    } else if (b->ppt == 1) {
+      GP_LAUNCH_PIPE(true, 1, true, false, true);
+    } else if (b->ppt == 2) {
+      GP_LAUNCH_PIPE(true, 2, true, false, true);
+    } else if (g_trace_on && MODE == gp::MODE_LIN) {  // timeline build of the default kernel (gp_debug_set_trace_buffer)
+      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 4, true, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
                          ps.d_eval, inl, partials);
-    } else if (grid && f32) {
-      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
-                         partials);
-    } else if (grid) {
-      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
-                         partials);
-    } else if (f32) {
-      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, true, kPipelineChunks, false>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
-                         partials);
     } else {
-      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, false, kPipelineChunks, false>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl,
-                         partials);
+      GP_LAUNCH_PIPE(true, 4, true, false, true);
     }
+#undef GP_LAUNCH_PIPE
   }
   GP_HIP(hipGetLastError());
   return GP_OK;
@@ -582,7 +626,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 4) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..4");
+  if (variant < 0 || variant > 7) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..7");
   g_variant = variant;
   return GP_OK;
 }

@@ -270,7 +270,15 @@ __device__ __forceinline__ int line_match(const v4i& k0, const v4i& k1, const v4
 __device__ __forceinline__ void grid_issue(const GP_GLOBAL char* entry, v4i& blk) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(blk) : "v"(entry) : "memory");
 }
-__device__ __forceinline__ void grid_wait(v4i& blk) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk) : : "memory"); }
+template <int WAIT_YOUNGER = 0>
+__device__ __forceinline__ void grid_wait(v4i& blk) {
+  if constexpr (WAIT_YOUNGER == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk) : : "memory");
+  } else {
+    static_assert(WAIT_YOUNGER == 3, "one chunk request = 3 DMA instructions");
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(blk) : : "memory");
+  }
+}
 
 // HW_ID register fields (s_getreg_b32): wave slot within the SIMD, and the whole word / the XCC id for the timeline traces
 #define GP_GETREG_WAVE_SLOT ((3 << 11) | (0 << 6) | 4)  // HW_REG_HW_ID[3:0]
@@ -279,7 +287,9 @@ __device__ __forceinline__ void grid_wait(v4i& blk) { asm volatile("s_waitcnt vm
 
 // Waves per SIMD: 4 with f32 accumulators (<= 128 VGPRs), 3 with f64 accumulators (<= 168 VGPRs).  The kernel must not spill:
 // scratch traffic counts in vmcnt and would break the hand-placed waits (tests/test_build_cpu.py checks the resource usage).
-template <int MODE, bool OUTER_F32, int PPT, bool GRID, bool TRACE = false>
+// LEAN: the prologue requests only chunk 0 (everybody's first burst is half as large, so it lands sooner); chunk 1 is requested
+// right behind the first lookup's hop 1.
+template <int MODE, bool OUTER_F32, int PPT, bool GRID, bool TRACE = false, bool LEAN = false>
 __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) vgicp_pipeline_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                              const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                              double* __restrict__ partials) {
@@ -320,7 +330,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
 
   if (ring) {
     chunk_dma(points, covs, first, wbase, lane);
-    if (PPT > 1) chunk_dma(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
+    if (PPT > 1 && !LEAN) chunk_dma(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
   }
 
   const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
@@ -378,7 +388,12 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
       const unsigned lin = inbox ? ((unsigned)bz * (unsigned)f.map.gdim[1] + (unsigned)by) * (unsigned)f.map.gdim[0] + (unsigned)bx : 0u;  // < 2^24 blocks
       v4i blk;
       grid_issue(gblocks + 16 * (size_t)lin, blk);
-      grid_wait(blk);
+      if (RING && LEAN && PPT > 1 && j == 0) {
+        chunk_dma(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
+        grid_wait<3>(blk);
+      } else {
+        grid_wait<0>(blk);
+      }
       if (j == 0) GP_TRACE(2);
       if (j == 1) GP_TRACE(4);
       const unsigned long long bits = ((unsigned long long)(unsigned)blk.y << 32) | (unsigned long long)(unsigned)blk.x;
@@ -440,7 +455,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
     for (int j = 0; j < PPT; j++) {
       // only chunk j+1's request may be younger than chunk j (normally already satisfied: step j-1 waited for its gather,
       // which is younger than chunk j -- but a step whose lanes were all rejected waits for nothing)
-      if (j + 1 < PPT) {
+      if (j + 1 < PPT && !(LEAN && j == 0)) {
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -483,6 +498,27 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
       if (lane == 0) wsums[k] = v;
     }
+  } else if constexpr (OUTER_F32) {
+    // f32 accumulators (each holds <= PPT points): ONE pass of 32 components x 64 lanes of f32 at a row stride of 66 floats
+    // (conflict-free both ways), every lane sums 32 values of one component in f64, lane pairs meet with one DPP swap: half the
+    // LDS bytes of the f64 transposition
+    constexpr int kRowStrideF = 66;
+    static_assert(32 * kRowStrideF * 4 + 32 * 8 <= STAGES * kChunkBytes, "f32 transposition buffer + wave sums must fit the wave's ring");
+    float* wtf = reinterpret_cast<float*>(wbase);
+#pragma unroll
+    for (int k = 0; k < 32; k++) wtf[k * kRowStrideF + lane] = acc[k];
+    const int comp = lane >> 1, part = lane & 1;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      s0 += (double)wtf[comp * kRowStrideF + 2 * i + part];
+      s1 += (double)wtf[comp * kRowStrideF + 2 * (i + 1) + part];
+      s2 += (double)wtf[comp * kRowStrideF + 2 * (i + 2) + part];
+      s3 += (double)wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+    }
+    double v = (s0 + s1) + (s2 + s3);
+    v += __shfl_xor(v, 1, 64);
+    if (part == 0) wsums[comp] = v;
   } else {
     const int comp = lane >> 2, part = lane & 3;
 #pragma unroll

@@ -213,3 +213,64 @@ def make_c2_workload(num_source=1_000_000, num_target=2_000_000, seed=42, num_st
     T_true = expmap(C1B_PERTURBATION)
     sp, sc, sn = make_merged_cloud(num_source, walls, poses[::2], T_true, seed + 2)
     return dict(target_points=tp, target_covs=tc, source_points=sp, source_covs=sc, source_normals=sn, T_true=T_true)
+
+
+def make_c3_graph(num_submaps=64, num_factors=256, seed=43):
+    """BASELINE.json configs[2]: a 256-factor submap graph.  64 synthetic submaps (~20-25 k points, scan order shuffled like the
+    kitti_07_dump submaps) along a street, 6 m apart; factors (target i, source j) for j = i+1..i+4 and their reverses, cut to
+    `num_factors`; poses = ground truth o Expmap(U(-0.02, 0.02)^6) (rng 8191, like the reference tests).
+    Returns dict(clouds=[(points, covs)], pairs=[(i, j)], deltas=[4x4], stations=[4x4])."""
+    rng = np.random.default_rng(8191)
+    walls, stations = make_street(num_submaps, spacing=6.0, seed=seed)
+    clouds = []
+    for i, T in enumerate(stations):
+        p, c, _ = make_submap(20000 + 80 * i, seed=1000 + i, walls=walls, sensor_pose=T)
+        clouds.append((p, c))
+    pairs = [(i, j) for i in range(num_submaps) for j in range(i + 1, min(i + 5, num_submaps))]
+    pairs = (pairs + [(j, i) for i, j in pairs])[:num_factors]
+    deltas = [np.linalg.inv(stations[i]) @ stations[j] @ expmap(rng.uniform(-0.02, 0.02, 6)) for i, j in pairs]
+    return dict(clouds=clouds, pairs=pairs, deltas=deltas, stations=stations, walls=walls)
+
+
+C4_SUBMAPS, C4_POINTS, C4_OUT = 512, 32768, 8
+
+
+def c4_factor_pairs(num_submaps=C4_SUBMAPS, out_degree=C4_OUT, base=64):
+    """BASELINE.json configs[3]: 4096 pairwise factors = 8 outgoing factors per source submap.  Factor (target t, source s) for
+    t = s + k, k = 1..8 (s - k where s + k would leave the street of `base` stations the submap belongs to, see
+    make_c4_submaps), listed source-major so that a contiguous slice of the list is the shard of a contiguous range of source
+    submaps."""
+    pairs = []
+    for s in range(num_submaps):
+        for k in range(1, out_degree + 1):
+            t = s + k if (s % base) + k < base else s - k
+            pairs.append((t, s))
+    return pairs
+
+
+def make_c4_submaps(indices, base=64, seed=44):
+    """The C4 submaps with the given indices (any subset of 0..511): 32768 points each, 1.0 m voxels downstream.
+    Casting 512 scans on the host takes minutes, so the 512 submaps are 8 generations of `base` cast scans along a street
+    (stations 6 m apart); generation g > 0 re-uses the geometry of generation 0 with an independent 1 cm jitter per point and
+    is shifted 10 km along y, so that all 512 clouds and maps are distinct memory with distinct contents and no two
+    generations overlap.  Deterministic in (index, seed).  Returns {index: (points, covs, station pose 4x4)}."""
+    walls, stations = make_street(base, spacing=6.0, seed=seed - 1)
+    cache, out = {}, {}
+    for idx in indices:
+        g, b = divmod(int(idx), base)
+        if b not in cache:
+            p, c, _ = make_submap(C4_POINTS, seed=2000 + b, walls=walls, sensor_pose=stations[b])
+            cache[b] = (p, c)
+        p, c = cache[b]
+        if g > 0:
+            p = (p.astype(np.float64) + np.random.default_rng(3000 + int(idx)).normal(0, 0.01, p.shape)).astype(np.float32)
+        T = stations[b].copy()
+        T[1, 3] += 10000.0 * g  # the station pose of this generation (points are in the sensor frame: unaffected)
+        out[int(idx)] = (p, c, T)
+    return out
+
+
+def c4_delta(submaps, t, s, rng_seed=8191):
+    """relative pose of factor (target t, source s): ground truth o a small deterministic perturbation"""
+    rng = np.random.default_rng(rng_seed + 4096 * t + s)
+    return np.linalg.inv(submaps[t][2]) @ submaps[s][2] @ expmap(rng.uniform(-0.02, 0.02, 6))

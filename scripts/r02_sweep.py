@@ -57,7 +57,7 @@ def run_case(name, d, res, delta, Lo, iters=50):
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
     out = np.zeros((1, 122))
     for v in variants:
-        for st in (staggers if v in (2, 4) else [0]):
+        for st in (staggers if v in (2, 4, 5) else [0]):
             _capi.check(lib.gp_debug_set_variant(v), "variant")
             _capi.check(lib.gp_debug_set_stagger(st), "stagger")
             batch, s = make_batch(f)

@@ -1,0 +1,35 @@
+"""Build-time invariants of the HIP library that a GPU-less host can check.
+
+The pipeline tile kernel places its s_waitcnt vmcnt(N) by hand around in-flight LDS-DMA requests.  Scratch (spill) traffic
+counts in vmcnt too, so a spilling build would silently break that arithmetic: the build keeps the compiler's
+kernel-resource-usage remarks (gtsam_points_amd/csrc/Makefile -> gp_vgicp.resources.txt) and this test holds every
+instantiation of the kernel to zero scratch, zero spills and the occupancy its __launch_bounds__ asks for."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RES = os.path.join(ROOT, "gtsam_points_amd", "csrc", "gp_vgicp.resources.txt")
+
+
+def _kernels():
+    txt = open(RES).read()
+    out = {}
+    for block in txt.split("remark: Function Name: ")[1:]:
+        name = block.split()[0]
+        get = lambda key: int(re.search(re.escape(key) + r":\s+(\d+)", block).group(1))
+        out[name] = dict(vgprs=get("VGPRs"), scratch=get("ScratchSize [bytes/lane]"), sspill=get("SGPRs Spill"), vspill=get("VGPRs Spill"),
+                         occupancy=get("Occupancy [waves/SIMD]"), lds=get("LDS Size [bytes/block]"))
+    return out
+
+
+def test_pipeline_kernels_do_not_spill():
+    assert os.path.exists(RES), "build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')"
+    ks = {k: v for k, v in _kernels().items() if "vgicp_pipeline_kernel" in k}
+    assert len(ks) >= 10  # MODE_LIN / MODE_ERR x precision x lookup structure x tile size
+    for name, r in ks.items():
+        assert r["scratch"] == 0 and r["vspill"] == 0, (name, r)
+        assert r["lds"] == 36864, (name, r)  # 4 waves x 3 stages x 3 KB
+        mode_lin = "ILi0E" in name
+        f32_outer = "ILi0ELb1E" in name or "ILi1ELb1E" in name
+        want = 4 if (f32_outer or not mode_lin) else 3  # __launch_bounds__(256, ...) in gp_vgicp_tile.hpp
+        assert r["occupancy"] >= want, (name, r)

@@ -108,3 +108,31 @@ def test_gicp_oracle_equals_reference_code(kitti00):
     fo = oracle.OracleGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], 1, 0.04)
     fr = refcapi.RefGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], 1, 0.04)
     assert_linearized_close(fo.linearize(expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])), fr.linearize(expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])), 1e-11, "gicp gate")
+
+
+def test_oracle_equals_reference_code_on_unsymmetric_covariances(kitti00):
+    """covariances whose lower triangle is 1-2 ulp off the upper one (what a float cast of V diag V^-1 can produce): the
+    reference's full-3x3 algebra (integrated_vgicp_factor_impl.hpp:138-140, general inverse; the voxel covariance is the mean of
+    the full matrices, gaussian_voxelmap_cpu.cpp:39-47) and the oracle's restatement of it agree -- this is what
+    tests/test_configs_gpu.py::test_unsymmetrised_covariances checks the HIP path against"""
+    rng = np.random.default_rng(5)
+
+    def perturb(c):
+        c = c.copy()
+        pick = np.arange(len(c)) % 3 == 0
+        for (a, b) in [(1, 0), (2, 0), (2, 1)]:
+            steps = rng.integers(1, 3, size=pick.sum()) * rng.choice([-1, 1], size=pick.sum())
+            c[pick, a, b] = (c[pick, a, b].view(np.int32) + steps.astype(np.int32)).view(np.float32)
+        return c
+
+    d = dict(kitti00)
+    d["target_covs"], d["source_covs"] = perturb(kitti00["target_covs"]), perturb(kitti00["source_covs"])
+    assert (d["source_covs"] != d["source_covs"].transpose(0, 2, 1)).any()
+    (om, fo), (rm, fr) = _both(d, 0.5)
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    Lo, Lr = fo.linearize(delta), fr.linearize(delta)
+    assert_linearized_close(Lo, Lr, 1e-12, "unsymmetric covariances")
+    assert rel_err(Lr.H_source, Lr.H_source.T) > 1e-13  # the reference's H really is not symmetric here
+    fgo = oracle.OracleGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], 1)
+    fgr = refcapi.RefGICPFactor(d["target_points"], d["target_covs"], d["source_points"], d["source_covs"], 1)
+    assert_linearized_close(fgo.linearize(delta), fgr.linearize(delta), 1e-11, "gicp, unsymmetric covariances")
