@@ -119,6 +119,22 @@ _SIGNATURES = {
     # factor
     "gp_vgicp_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_vgicp_factor_destroy": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_factor_device": (C.c_int, [C.c_void_p]),
+    # sharded batches (single process, several devices)
+    "gp_shard_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gp_shard_plan_num_shards": (C.c_int, [C.c_void_p]),
+    "gp_shard_plan_range": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gp_shard_plan_destroy": (C.c_int, [C.c_void_p]),
+    "gp_voxelmap_clone_to_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_vgicp_multi_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gp_vgicp_multi_batch_destroy": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_multi_batch_size": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_multi_batch_num_shards": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_multi_batch_uses_rccl": (C.c_int, [C.c_void_p]),
+    "gp_vgicp_multi_batch_shard_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "gp_vgicp_multi_batch_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_multi_batch_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_multi_batch_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gp_vgicp_factor_set_surface_validation": (C.c_int, [C.c_void_p, C.c_int]),
     "gp_vgicp_factor_set_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_factor_set_inlier_update_thresh": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),

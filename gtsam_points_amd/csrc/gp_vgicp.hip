@@ -324,6 +324,7 @@ struct gp_vgicp_factor {
   const float* covs = nullptr;
   const float* normals = nullptr;
   int n = 0;
+  int device = 0;  // the device the source arrays live on (hipPointerGetAttributes at creation)
   bool surface_validation = false;
   uint64_t generation = 0;  // bumped when the source pointers or flags change (tables that hold this factor go stale)
   double inlier_thresh_trans = 1e-6, inlier_thresh_angle = 1e-6;  // integrated_vgicp_derivatives.cu:26-27 (kept for API parity)
@@ -656,6 +657,13 @@ int gp_vgicp_factor_create(const gp_voxelmap_t* target, const float* points_dev,
   f->covs = covs_dev;
   f->normals = normals_dev;
   f->n = num_points;
+  {
+    hipPointerAttribute_t attr{};
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    f->device = (hipPointerGetAttributes(&attr, points_dev) == hipSuccess) ? attr.device : cur;
+    (void)hipGetLastError();  // a pointer the runtime does not know leaves a sticky error behind
+  }
   if (stream) {
     f->stream = (hipStream_t)stream;
   } else {
@@ -720,6 +728,7 @@ int gp_vgicp_factor_set_inlier_update_thresh(gp_vgicp_factor_t* f, double trans,
 }
 
 int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f) { return f ? f->n : 0; }
+int gp_vgicp_factor_device(const gp_vgicp_factor_t* f) { return f ? f->device : 0; }
 gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f) { return f ? (gp_stream_t)f->stream : nullptr; }
 
 int gp_vgicp_factor_issue_linearize(gp_vgicp_factor_t* f, const double* pose_host, const double* pose_dev, gp_linearized6* out_dev) {

@@ -756,6 +756,64 @@ int gp_voxelmap_load(const char* path, gp_stream_t stream, gp_voxelmap_t** out) 
   return GP_OK;
 }
 
+// replica of a map on another device (multi-GPU sharding: a target map referenced from several shards).  Arrays travel
+// device-to-device with hipMemcpyPeerAsync; the clone owns its memory and carries the same voxel numbering.
+int gp_voxelmap_clone_to_device(const gp_voxelmap_t* map, int device, gp_stream_t stream_on_device, gp_voxelmap_t** out) {
+  if (!map || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_clone_to_device: null");
+  if (!map->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "gp_voxelmap_clone_to_device: voxel map is not on the GPU");
+  int src_device = 0, saved = 0;
+  GP_HIP(hipGetDevice(&saved));
+  {
+    hipPointerAttribute_t attr{};
+    src_device = (hipPointerGetAttributes(&attr, map->buckets.ptr) == hipSuccess) ? attr.device : saved;
+    (void)hipGetLastError();
+  }
+  GP_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream_on_device;
+  auto* m = new gp_voxelmap;
+  m->resolution = map->resolution;
+  m->init_num_buckets = map->init_num_buckets;
+  m->target_points_drop_rate = map->target_points_drop_rate;
+  m->stream = s;
+  m->info = map->info;
+  m->plmask = map->plmask;
+  m->has_grid = map->has_grid;
+  for (int a = 0; a < 3; a++) {
+    m->glo[a] = map->glo[a];
+    m->gdim[a] = map->gdim[a];
+  }
+  int rc = GP_OK;
+  auto copy = [&](gp::DeviceArray& dst, const gp::DeviceArray& src, size_t bytes) {
+    if (rc != GP_OK) return;
+    if ((rc = dst.alloc(bytes)) != GP_OK) return;
+    if (bytes == 0) return;
+    const hipError_t e = hipMemcpyPeerAsync(dst.ptr, device, src.ptr, src_device, bytes, s);
+    if (e != hipSuccess) rc = gp::hip_fail(e, "hipMemcpyPeerAsync", __FILE__, __LINE__);
+  };
+  const size_t V = (size_t)map->info.num_voxels, B = (size_t)map->info.num_buckets;
+  copy(m->buckets, map->buckets, sizeof(gp_voxel_bucket) * B);
+  copy(m->records, map->records, sizeof(gp::VoxelRecord) * V);
+  copy(m->num_points, map->num_points, sizeof(int) * V);
+  copy(m->voxel_means, map->voxel_means, sizeof(float) * 3 * V);
+  copy(m->voxel_covs, map->voxel_covs, sizeof(float) * 9 * V);
+  copy(m->voxel_intensities, map->voxel_intensities, sizeof(float) * V);
+  copy(m->voxel_coords, map->voxel_coords, sizeof(int) * 3 * V);
+  copy(m->plines, map->plines, 64 * ((size_t)map->plmask + 1));
+  if (map->has_grid) copy(m->gblocks, map->gblocks, sizeof(gp::GridBlock) * (size_t)map->gdim[0] * map->gdim[1] * map->gdim[2]);
+  if (rc == GP_OK) {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = gp::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+  }
+  (void)hipSetDevice(saved);
+  if (rc != GP_OK) {
+    delete m;
+    return rc;
+  }
+  m->generation = 1;
+  *out = m;
+  return GP_OK;
+}
+
 size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
   if (!map) return 0;
   // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records, coordinates and line table this implementation adds

@@ -15,26 +15,100 @@ RECORD_DOUBLES = 122  # gp_linearized6
 
 
 def partition_factors(weights, world_size):
-    """Contiguous partition of the factor list into `world_size` ranges balanced by sum(weights) (= source points per
-    factor).  Contiguity keeps factors that share a source cloud / target map on one rank when the list is ordered by
-    submap.  Returns [(begin, end)] per rank; ranges may be empty when there are fewer factors than ranks."""
-    w = np.asarray(weights, dtype=np.float64)
-    n = len(w)
+    """Contiguous partition of the factor list into `world_size` ranges minimising the largest sum(weights) (= source points
+    per shard) -- gp_shard_plan_create of the C-ABI, the same plan the single-process multi-GPU batch uses.  Contiguity keeps
+    factors that share a source cloud / target map on one rank when the list is ordered by submap.
+    Returns [(begin, end)] per rank; ranges may be empty when there are fewer factors than ranks.  Pure host code (no GPU)."""
+    import ctypes as C
+
+    from . import _capi
+
     if world_size <= 0:
         raise ValueError("world_size must be positive")
-    cum = np.concatenate([[0.0], np.cumsum(w)])
-    total = cum[-1]
-    bounds = [0]
-    for r in range(1, world_size):
-        target = total * r / world_size
-        # first index whose prefix reaches the target, but never before the previous bound
-        i = int(np.searchsorted(cum, target, side="left"))
-        if i > 0 and i <= n and abs(cum[i - 1] - target) <= abs(cum[min(i, n)] - target):
-            i -= 1  # the boundary nearest to the ideal split
-        i = min(max(i, bounds[-1]), n)
-        bounds.append(i)
-    bounds.append(n)
-    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+    lib = _capi.load()
+    w = np.ascontiguousarray(weights, dtype=np.int64)
+    plan = C.c_void_p()
+    _capi.check(lib.gp_shard_plan_create(C.c_void_p(w.ctypes.data) if len(w) else None, len(w), int(world_size), C.byref(plan)), "gp_shard_plan_create")
+    out = []
+    for r in range(world_size):
+        b, e = C.c_int(), C.c_int()
+        _capi.check(lib.gp_shard_plan_range(plan, r, C.byref(b), C.byref(e)), "gp_shard_plan_range")
+        out.append((b.value, e.value))
+    lib.gp_shard_plan_destroy(plan)
+    return out
+
+
+class MultiDeviceBatch:
+    """gp_vgicp_multi_batch_*: a factor list sharded over the GPUs of one node from ONE process (the form a C++ optimizer
+    process uses; `ShardedLinearizer` below is the one-process-per-GPU form bench.py is launched in).
+      factors        IntegratedVGICPFactorGPU objects, each created from arrays / a map on the device of its shard
+      shard_of       None = one shard per device; or a list of shard indices (several shards may share a device)
+      use_rccl       -1 auto, 0 never (host gather), 1 required"""
+
+    def __init__(self, factors, shard_of=None, num_shards=0, use_rccl=-1):
+        import ctypes as C
+
+        from . import _capi
+
+        self._lib = _capi.load()
+        self._factors = list(factors)  # keep them alive
+        F = len(self._factors)
+        arr = (C.c_void_p * max(F, 1))(*[f._h.value for f in self._factors])
+        so = None
+        if shard_of is not None:
+            so = np.ascontiguousarray(shard_of, dtype=np.int32)
+            assert len(so) == F
+        self._h = C.c_void_p()
+        _capi.check(self._lib.gp_vgicp_multi_batch_create(arr, F, C.c_void_p(so.ctypes.data) if so is not None else None, int(num_shards), int(use_rccl), C.byref(self._h)),
+                    "gp_vgicp_multi_batch_create")
+        self.size = F
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.gp_vgicp_multi_batch_destroy(self._h)
+            self._h = None
+
+    @property
+    def num_shards(self):
+        return int(self._lib.gp_vgicp_multi_batch_num_shards(self._h))
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.gp_vgicp_multi_batch_uses_rccl(self._h))
+
+    def shard_info(self, shard):
+        import ctypes as C
+
+        from . import _capi
+
+        d, n, p = C.c_int(), C.c_int(), C.c_int64()
+        _capi.check(self._lib.gp_vgicp_multi_batch_shard_info(self._h, shard, C.byref(d), C.byref(n), C.byref(p)), "gp_vgicp_multi_batch_shard_info")
+        return dict(device=d.value, num_factors=n.value, num_points=p.value)
+
+    def linearize(self, deltas):
+        """deltas: F 4x4 poses (T_target^-1 T_source) -> [F x 122] f64 records (gp_linearized6 layout)"""
+        from . import _capi
+
+        poses = np.stack([np.ascontiguousarray(np.asarray(d, dtype=np.float64).T).reshape(16) for d in deltas]).copy() if self.size else np.zeros((0, 16))
+        out = np.zeros((self.size, RECORD_DOUBLES))
+        _capi.check(self._lib.gp_vgicp_multi_batch_linearize(self._h, poses.ctypes.data, out.ctypes.data), "gp_vgicp_multi_batch_linearize")
+        return out
+
+    def compute_error(self, deltas_lin, deltas_eval):
+        from . import _capi
+
+        pl = np.stack([np.ascontiguousarray(np.asarray(d, dtype=np.float64).T).reshape(16) for d in deltas_lin]).copy()
+        pe = np.stack([np.ascontiguousarray(np.asarray(d, dtype=np.float64).T).reshape(16) for d in deltas_eval]).copy()
+        out = np.zeros(self.size)
+        _capi.check(self._lib.gp_vgicp_multi_batch_compute_error(self._h, pl.ctypes.data, pe.ctypes.data, out.ctypes.data), "gp_vgicp_multi_batch_compute_error")
+        return out
+
+    def last_timing(self):
+        import ctypes as C
+
+        a, b = C.c_float(), C.c_float()
+        self._lib.gp_vgicp_multi_batch_last_timing(self._h, C.byref(a), C.byref(b))
+        return dict(ms_compute=a.value, ms_exchange=b.value)
 
 
 class ShardedLinearizer:
@@ -44,17 +118,20 @@ class ShardedLinearizer:
                                        stacked buffer (on GPUs: gp_vgicp_batch_issue_linearize with out_dev = view pointer)
     """
 
-    def __init__(self, total_factors, slot_range, device, issue, group=None):
+    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None):
+        """stream: the torch.cuda.Stream the `issue` callback launches its kernels on (a torch.cuda.ExternalStream around the
+        batch's hipStream_t when the batch owns its stream).  The zeroing of the stack, the kernels and the all-reduce are then
+        all ordered on that one stream; None = torch's current stream (CPU / gloo, or a batch created on torch's stream)."""
         import torch
 
         self.total = int(total_factors)
         self.begin, self.end = int(slot_range[0]), int(slot_range[1])
         self.issue = issue
         self.group = group
+        self.stream = stream
         self.stacked = torch.zeros((self.total, RECORD_DOUBLES), dtype=torch.float64, device=device)
 
-    def linearize(self, poses_local):
-        """Returns the stacked [F_total x 122] tensor holding every rank's records (device-resident)."""
+    def _run(self, poses_local):
         import torch.distributed as dist
 
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -65,3 +142,12 @@ class ShardedLinearizer:
         if world > 1:
             dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked
+
+    def linearize(self, poses_local):
+        """Returns the stacked [F_total x 122] tensor holding every rank's records (device-resident)."""
+        if self.stream is None:
+            return self._run(poses_local)
+        import torch
+
+        with torch.cuda.stream(self.stream):  # zero_ / all_reduce follow the stream the kernels are issued on
+            return self._run(poses_local)

@@ -225,6 +225,7 @@ int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable); /*
 int gp_vgicp_factor_set_source(gp_vgicp_factor_t* f, const float* points_dev, const float* covs_dev, const float* normals_dev);
 int gp_vgicp_factor_set_inlier_update_thresh(gp_vgicp_factor_t* f, double trans, double angle); /* kept for API parity; every linearise rescans all points */
 int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f);
+int gp_vgicp_factor_device(const gp_vgicp_factor_t* f); /* the device the source arrays live on */
 gp_stream_t gp_vgicp_factor_stream(const gp_vgicp_factor_t* f);
 /* sizes the factor reports through NonlinearFactorGPU (integrated_vgicp_factor_gpu.cpp:136-150):
  * 128 (pose, double[16]) / 976 (gp_linearized6) / 128 / 8 (double error) */
@@ -266,6 +267,44 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* batch, const double* poses_li
 /* timing hook for bench.py: re-runs only the device work (pose upload excluded) `iters` times on the batch stream
  * between two hipEvents and returns the average milliseconds per pass, and separately the two kernels' times */
 int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* batch, const double* poses_host, int iters, float* ms_total, float* ms_main_kernel, float* ms_finalize_kernel);
+
+/* ---- many-factor batches sharded over the GPUs of one node, driven from ONE process ----
+ * The reference has no multi-GPU code; this is the sharded form of NonlinearFactorSetGPU::linearize
+ * (cuda/nonlinear_factor_set_gpu.cpp:64-139) that BASELINE.json's north_star asks for: the factor list is partitioned into
+ * shards, every shard runs the batched kernels on its own device and stream, every shard writes its records into its rows of a
+ * zeroed [F x 122] f64 stack, ONE ncclAllReduce(sum) per device over that stack (RCCL over xGMI; each row has one writer, so the
+ * sum is exact), one D2H from the first shard's device.  RCCL is dlopen()ed only when a multi-batch spans several devices. */
+
+/* contiguous partition of a factor list into num_shards ranges minimising the largest sum of weights (weights = source points of
+ * each factor; list the factors source-submap-major so that a shard holds whole submaps).  Pure host code: needs no GPU. */
+typedef struct gp_shard_plan gp_shard_plan_t;
+int gp_shard_plan_create(const int64_t* weights, int num_factors, int num_shards, gp_shard_plan_t** out);
+int gp_shard_plan_num_shards(const gp_shard_plan_t* plan);
+int gp_shard_plan_range(const gp_shard_plan_t* plan, int shard, int* begin, int* end); /* factors [begin, end) */
+int gp_shard_plan_destroy(gp_shard_plan_t* plan);
+
+/* a voxel map replicated onto another device (maps are immutable after insert(): a shard that references a target map of a
+ * neighbouring shard gets its own copy; arrays travel device-to-device).  The clone is independent of the original. */
+int gp_voxelmap_clone_to_device(const gp_voxelmap_t* map, int device, gp_stream_t stream_on_device, gp_voxelmap_t** out);
+
+typedef struct gp_vgicp_multi_batch gp_vgicp_multi_batch_t;
+/* factors[i] must have been created from arrays / a map resident on the device of its shard.
+ * shard_of_factor == NULL: one shard per device the factors live on (num_shards ignored).  Otherwise shard_of_factor[i] in
+ * [0, num_shards): several shards may share a device (the single-GPU rehearsal of an N-GPU plan).
+ * use_rccl: -1 = RCCL all-reduce when the shards sit on distinct devices and librccl.so loads, else every shard copies its own rows
+ * to the host; 0 = never; 1 = required (error otherwise; one shard on one device is a valid 1-rank communicator). */
+int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_factors, const int* shard_of_factor, int num_shards, int use_rccl,
+                                gp_vgicp_multi_batch_t** out);
+int gp_vgicp_multi_batch_destroy(gp_vgicp_multi_batch_t* mb);
+int gp_vgicp_multi_batch_size(const gp_vgicp_multi_batch_t* mb);
+int gp_vgicp_multi_batch_num_shards(const gp_vgicp_multi_batch_t* mb);
+int gp_vgicp_multi_batch_uses_rccl(const gp_vgicp_multi_batch_t* mb);
+int gp_vgicp_multi_batch_shard_info(const gp_vgicp_multi_batch_t* mb, int shard, int* device, int* num_factors, int64_t* num_points);
+/* synchronous; poses_host = double[F][16] and out_host = gp_linearized6[F] in the order of `factors` */
+int gp_vgicp_multi_batch_linearize(gp_vgicp_multi_batch_t* mb, const double* poses_host, gp_linearized6* out_host);
+int gp_vgicp_multi_batch_compute_error(gp_vgicp_multi_batch_t* mb, const double* poses_lin_host, const double* poses_eval_host, double* out_host);
+/* HIP-event times of the last pass: the slowest shard's kernels, and what followed them (all-reduce + D2H, or the host gather) */
+int gp_vgicp_multi_batch_last_timing(const gp_vgicp_multi_batch_t* mb, float* ms_compute, float* ms_exchange);
 
 /* ---- exact k-NN, covariance estimation, GICP (BASELINE configs[4]; CPU-only upstream) ----
  * KdTree::knn_search (ann/small_kdtree.hpp:437-474, KnnResult ann/knn_result.hpp:36-117), estimate_covariances

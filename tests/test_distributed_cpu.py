@@ -75,3 +75,26 @@ def test_sharded_linearize_gloo_world2():
     ref = _records_for(PAIRS, list(range(len(PAIRS))))
     for r in range(world):
         assert np.array_equal(ret[r], ref), f"rank {r}: stacked records differ from the single-process result"
+
+
+def test_shard_plan_is_optimal_and_leaves_no_shard_empty():
+    """gp_shard_plan_create (pure host code of the C-ABI): contiguous, complete, minimises the largest shard (checked against
+    brute force over all boundary placements on small lists), and never leaves a shard empty while another holds two factors"""
+    import itertools
+
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        n = int(rng.integers(1, 10))
+        k = int(rng.integers(1, 6))
+        w = rng.integers(1, 100, size=n).tolist()
+        parts = partition_factors(w, k)
+        assert parts[0][0] == 0 and parts[-1][1] == n and all(parts[i][1] == parts[i + 1][0] for i in range(k - 1))
+        worst = max(sum(w[b:e]) for b, e in parts)
+        best = min(max(sum(w[a:b]) for a, b in zip((0,) + cut, cut + (n,))) for cut in itertools.combinations_with_replacement(range(n + 1), k - 1))
+        assert worst == best, (w, k, parts)
+        empty = sum(1 for b, e in parts if b == e)
+        assert empty == max(0, k - n), (w, k, parts)
+    # the C4 shape: 4096 equal factors over 8 shards -> 512 each; over 3 shards the largest holds ceil(4096 / 3) = 1366
+    assert [e - b for b, e in partition_factors([32768] * 4096, 8)] == [512] * 8
+    three = [e - b for b, e in partition_factors([32768] * 4096, 3)]
+    assert max(three) == 1366 and sum(three) == 4096 and min(three) >= 1364

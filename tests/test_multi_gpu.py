@@ -1,0 +1,136 @@
+"""GPU tests of the single-process sharded batch (gp_vgicp_multi_batch_*, gp_multi.hip).  A 1-GPU box rehearses an N-GPU plan
+with N shards on one device (host gather); the RCCL path is exercised as a 1-rank communicator.  On a multi-GPU node the
+same tests additionally spread the shards over the devices (one shard per device, ncclAllReduce over xGMI)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import expmap
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(gpu, kitti07, device="cuda:0"):
+    poses = kitti07["poses"]
+    rng = np.random.default_rng(8191)
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"], device=device) for i in range(5)]
+    maps = []
+    for c in clouds:
+        vm = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        vm.insert(c)
+        maps.append(vm)
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4), (0, 3), (1, 4), (0, 4)]
+    factors = [gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
+    values = {k: poses[k] @ expmap(rng.uniform(-0.05, 0.05, 6)) for k in range(5)}
+    deltas = [np.linalg.inv(values[i]) @ values[j] for i, j in pairs]
+    deltas2 = [d @ expmap(rng.uniform(-0.01, 0.01, 6)) for d in deltas]
+    return clouds, maps, factors, deltas, deltas2
+
+
+def _plain_batch(gpu, factors, deltas, deltas2):
+    lib = gpu.load()
+    F = len(factors)
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch, s = C.c_void_p(), C.c_void_p()
+    lib.gp_stream_create(C.byref(s))
+    gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+    poses = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas]).copy()
+    poses2 = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas2]).copy()
+    out, err = np.zeros((F, 122)), np.zeros(F)
+    gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data), "linearize")
+    gpu._capi.check(lib.gp_vgicp_batch_compute_error(batch, poses.ctypes.data, poses2.ctypes.data, err.ctypes.data), "error")
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+    return out, err
+
+
+def test_sharded_batch_equals_plain_batch(gpu, kitti07):
+    """1, 2, 4 shards on one device (contiguous plan from gp_shard_plan) and a round-robin (non-contiguous) assignment: the records
+    and the error evaluations are bit-identical to the plain single batch (same kernels, per-factor fixed summation order)"""
+    from gtsam_points_amd.distributed import MultiDeviceBatch, partition_factors
+
+    _, _, factors, deltas, deltas2 = _graph(gpu, kitti07)
+    ref, ref_err = _plain_batch(gpu, factors, deltas, deltas2)
+    assert ref[:, 0].min() > 1000  # every factor has inliers
+    for shards in [1, 2, 4]:
+        parts = partition_factors([int(gpu.load().gp_vgicp_factor_num_points(f._h)) for f in factors], shards)
+        shard_of = np.zeros(len(factors), np.int32)
+        for k, (b, e) in enumerate(parts):
+            shard_of[b:e] = k
+        mb = MultiDeviceBatch(factors, shard_of=shard_of, num_shards=shards, use_rccl=0)
+        assert mb.num_shards == shards and not mb.uses_rccl
+        assert sum(mb.shard_info(k)["num_factors"] for k in range(shards)) == len(factors)
+        out = mb.linearize(deltas)
+        assert np.array_equal(out, ref), shards
+        assert np.array_equal(mb.compute_error(deltas, deltas2), ref_err)
+        t = mb.last_timing()
+        assert t["ms_compute"] > 0
+    rr = MultiDeviceBatch(factors, shard_of=np.arange(len(factors)) % 3, num_shards=3, use_rccl=0)
+    assert np.array_equal(rr.linearize(deltas), ref) and np.array_equal(rr.compute_error(deltas, deltas2), ref_err)
+
+
+def test_rccl_allreduce_path(gpu, kitti07):
+    """the ncclAllReduce exchange over the zeroed [F x 122] stack: one shard per visible device (a single GPU is a valid 1-rank
+    communicator).  With several devices the factor list is split with gp_shard_plan, clouds and maps are replicated onto the
+    shard's device (gp_voxelmap_clone_to_device) and the records must again equal the single-device batch bit for bit."""
+    import torch
+
+    from gtsam_points_amd.distributed import MultiDeviceBatch, partition_factors
+
+    clouds, maps, factors, deltas, deltas2 = _graph(gpu, kitti07)
+    ref, ref_err = _plain_batch(gpu, factors, deltas, deltas2)
+    one = MultiDeviceBatch(factors, use_rccl=1)
+    assert one.num_shards == 1 and one.uses_rccl
+    assert np.array_equal(one.linearize(deltas), ref) and np.array_equal(one.compute_error(deltas, deltas2), ref_err)
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        return
+    lib = gpu.load()
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4), (0, 3), (1, 4), (0, 4)]
+    parts = partition_factors([int(lib.gp_vgicp_factor_num_points(f._h)) for f in factors], ndev)
+    sharded, keep = [], []
+    for dev, (b, e) in enumerate(parts):
+        torch.cuda.set_device(dev)
+        gpu._capi.check(lib.gp_set_device(dev), "gp_set_device")
+        local_clouds, local_maps = {}, {}
+        for (i, j) in pairs[b:e]:
+            if j not in local_clouds:
+                local_clouds[j] = gpu.PointCloudGPU(kitti07[f"points_{j}"], kitti07[f"covs_{j}"], device=f"cuda:{dev}")
+            if i not in local_maps:
+                h = C.c_void_p()
+                gpu._capi.check(lib.gp_voxelmap_clone_to_device(maps[i]._h, dev, None, C.byref(h)), "clone")
+                local_maps[i] = gpu.GaussianVoxelMapGPU(1.0, _handle=h)
+            sharded.append(gpu.IntegratedVGICPFactorGPU(i, j, local_maps[i], local_clouds[j]))
+        keep.append((local_clouds, local_maps))
+    torch.cuda.set_device(0)
+    lib.gp_set_device(0)
+    multi = MultiDeviceBatch(sharded, use_rccl=1)
+    assert multi.num_shards == len({p for p in range(ndev) if parts[p][1] > parts[p][0]}) and multi.uses_rccl
+    assert np.array_equal(multi.linearize(deltas), ref) and np.array_equal(multi.compute_error(deltas, deltas2), ref_err)
+
+
+def test_voxelmap_clone(gpu, kitti00):
+    """gp_voxelmap_clone_to_device: an independent replica (here onto the same device) gives the same linearisation bit for bit"""
+    lib = gpu.load()
+    tgt = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"])
+    src = gpu.PointCloudGPU(kitti00["source_points"], kitti00["source_covs"])
+    vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+    vm.insert(tgt)
+    h = C.c_void_p()
+    gpu._capi.check(lib.gp_voxelmap_clone_to_device(vm._h, 0, None, C.byref(h)), "clone")
+    clone = gpu.GaussianVoxelMapGPU(0.5, _handle=h)
+    assert clone.voxelmap_info.num_voxels == vm.voxelmap_info.num_voxels and lib.gp_voxelmap_has_block_grid(clone._h) == 1
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    recs = []
+    for m in (vm, clone):
+        f = gpu.IntegratedVGICPFactorGPU(0, 1, m, src)
+        rec = gpu._capi.Linearized6()
+        gpu._capi.check(lib.gp_vgicp_factor_linearize(f._h, gpu.types._pose16(delta), C.byref(rec)), "linearize")
+        recs.append(bytes(rec))
+    assert recs[0] == recs[1]
+    del vm  # the clone owns its memory
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, clone, src)
+    rec = gpu._capi.Linearized6()
+    gpu._capi.check(lib.gp_vgicp_factor_linearize(f._h, gpu.types._pose16(delta), C.byref(rec)), "linearize")
+    assert bytes(rec) == recs[0]
