@@ -15,8 +15,13 @@ Extra objects on the JSON line:
   roofline     -- dominant kernel (vgicp_pipeline_kernel): algorithmic bytes (SURVEY.md 8(d):
                   48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration measured with HIP events on the
                   stream it is launched on; peak 8 TB/s HBM3E.
-  cpu_baseline -- the CPU oracle (restated reference CPU path, OpenMP guided schedule) timed on this box's cores on the
-                  same workload (kind "port"), rank 0 / N=1 only.
+  cpu_baseline -- the reference's own CPU factor (oracle/_ref/libref.so, kind "reference"; the C restatement, kind "port", when
+                  that library is absent) timed on this box's cores on the same workload, rank 0 / N=1 only.
+  c4           -- BASELINE configs[3] next to the headline: the 4096-factor graph (512 submaps x 32768 points, 8 factors per
+                  source submap, 1.0 m voxels) partitioned over the N ranks by source submap with the target maps a shard
+                  references replicated onto it (gtsam_points_amd.synthetic.c4_factor_pairs / make_c4_submaps, plan from
+                  gp_shard_plan_create); one step = every rank's batched linearise into its rows of the zeroed [4096 x 122] f64
+                  stack + ONE all-reduce (RCCL) + D2H.  Strong scaling: total work is fixed as N grows.  --no-c4 skips it.
 """
 import argparse
 import ctypes as C
@@ -46,6 +51,103 @@ def _load_traffic():
         return None
 
 
+def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, stream):
+    """BASELINE configs[3]: 4096 pairwise factors sharded over the ranks (see the module docstring).  Returns the `c4` object
+    (rank 0) or None."""
+    from gtsam_points_amd.distributed import RECORD_DOUBLES, ShardedLinearizer, partition_factors
+
+    t_setup = time.time()
+    pairs = synthetic.c4_factor_pairs()
+    F = len(pairs)
+    begin, end = partition_factors([synthetic.C4_POINTS] * F, world)[rank]
+    mine = pairs[begin:end]
+    need = sorted({i for p in mine for i in p})
+    sub = synthetic.make_c4_submaps(need)
+    clouds, maps = {}, {}
+    for i in need:
+        clouds[i] = gpa.PointCloudGPU(sub[i][0], sub[i][1], device=device)
+    for t in sorted({t for t, _ in mine}):
+        m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(clouds[t])
+        maps[t] = m
+    sptr = C.c_void_p(stream.cuda_stream)
+    factors = [gpa.IntegratedVGICPFactorGPU(t, s, maps[t], clouds[s], stream=sptr) for t, s in mine]
+    n_local = len(factors)
+    arr = (C.c_void_p * max(n_local, 1))(*[f._h.value for f in factors])
+    batch = C.c_void_p()
+    _capi.check(lib.gp_vgicp_batch_create(arr, n_local, sptr, C.byref(batch)), "gp_vgicp_batch_create")
+    deltas = [synthetic.c4_delta(sub, t, s) for t, s in mine]
+    poses = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas]).copy() if n_local else np.zeros((0, 16))
+    t_setup = time.time() - t_setup
+
+    def issue(poses_local, view):
+        _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses_local.ctypes.data, C.c_void_p(view.data_ptr())), "gp_vgicp_batch_issue_linearize")
+
+    sharded = ShardedLinearizer(F, (begin, end), device, issue)
+    host_out = torch.zeros((F, RECORD_DOUBLES), dtype=torch.float64).pin_memory()
+
+    def step():
+        stacked = sharded.linearize(poses)
+        host_out.copy_(stacked, non_blocking=True)
+        stream.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(3):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.c4_steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the exchange alone: all-reduce of the stacked records (+ zeroing), HIP events on the stream it is issued on
+    ar_ms = 0.0
+    if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record(stream)
+        for _ in range(10):
+            sharded.stacked.zero_()
+            dist.all_reduce(sharded.stacked, op=dist.ReduceOp.SUM)
+        e1.record(stream)
+        e1.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 10
+    ms_total, ms_main, ms_fin = C.c_float(), C.c_float(), C.c_float()
+    alg = 0
+    if n_local:
+        _capi.check(lib.gp_vgicp_batch_time_linearize(batch, poses.ctypes.data, 10, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
+        alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+    stats = torch.tensor([elapsed, ms_main.value, float(alg), float(n_local)], dtype=torch.float64, device=device)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    else:
+        mx, sm = stats, stats
+    elapsed_max, tile_ms_max, alg_sum = float(mx[0]), float(mx[1]), float(sm[2])
+    inliers = float(host_out[:, 0].sum())
+    lib.gp_vgicp_batch_destroy(batch)
+    if rank != 0:
+        return None
+    points = F * synthetic.C4_POINTS
+    ms = elapsed_max / args.c4_steps * 1e3
+    return dict(
+        workload="BASELINE configs[3]: 4096 pairwise VGICP factors (512 submaps x 32768 pts, 1.0 m voxels), sharded by source submap over the ranks",
+        factors=F, points_per_linearize=points, n_gpus=world, scaling="strong", steps=args.c4_steps,
+        ms_per_linearize=round(ms, 4), value=round(points / (ms * 1e-3), 1), unit="point-correspondences/s",
+        allreduce_ms=round(ar_ms, 4), stack_bytes=F * RECORD_DOUBLES * 8,
+        tile_kernel_ms_slowest_rank=round(tile_ms_max, 5), algorithmic_bytes_total=int(alg_sum),
+        roofline_frac_per_gpu=round(alg_sum / world / (tile_ms_max * 1e-3) / 8e12, 4) if tile_ms_max > 0 else None,
+        factors_rank0=n_local, inlier_fraction=round(inliers / points, 4), setup_s=round(t_setup, 1),
+        step="per rank: zero [4096 x 122] f64 stack -> batched tile + finalize kernels into own rows -> ONE all-reduce (RCCL) -> D2H -> sync",
+    )
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +159,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--kernel-iters", type=int, default=50)
+    ap.add_argument("--no-c4", action="store_true", help="skip the sharded 4096-factor configuration (BASELINE configs[3])")
+    ap.add_argument("--c4-steps", type=int, default=30)
     args = ap.parse_args()
 
     import torch
@@ -160,7 +264,7 @@ def main():
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_pipeline_kernel<MODE_LIN, f64, 4 chunks/wave>",
+        kernel="vgicp_pipeline_kernel<MODE_LIN, f32 outer products, 4 chunks/wave, block grid, lean start>",
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",
@@ -176,6 +280,9 @@ def main():
         _capi.check(lib.gp_debug_calibration_stream(src.ptr(src.points_gpu), src.ptr(src.covs_gpu), args.source_points, 5, C.c_void_p(stream.cuda_stream)), "calibration")
 
     rec = gpa.LinearizedSystem6.from_doubles(host_out[rank].numpy())
+    c4 = None
+    if not args.no_c4:
+        c4 = run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, stream)
     result = None
     if rank == 0:
         cpu_baseline = None
@@ -237,6 +344,7 @@ def main():
             scaling="weak",
             vs_baseline=None,
             dtype="f64",
+            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel variant 4)",
             data="synthetic",
             config=dict(
                 workload="BASELINE configs[1]: single VGICP factor per GPU, 1M synthetic source pts vs 2M-pt GaussianVoxelMap @0.5 m",
@@ -252,6 +360,7 @@ def main():
             roofline=roofline,
             cpu_baseline=cpu_baseline,
             parity_vs_oracle=parity,
+            c4=c4,
             setup=dict(generate_s=round(t_gen, 2), voxelmap_build_s=round(t_map, 4)),
         )
         print(json.dumps(result), flush=True)
