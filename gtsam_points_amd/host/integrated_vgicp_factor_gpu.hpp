@@ -1,7 +1,12 @@
-// integrated_vgicp_factor_gpu.hpp -- IntegratedVGICPFactorGPU (factors/integrated_vgicp_factor_gpu.{hpp,cpp}) over the C-ABI.
+// integrated_vgicp_factor_gpu.hpp -- IntegratedVGICPFactorGPU (factors/integrated_vgicp_factor_gpu.{hpp,cpp}) over the C-ABI,
+// a subclass of the reference's own NonlinearFactorGPU (factors/nonlinear_factor_gpu.hpp:49-121).
 // Same constructors, setters, caching protocol (store_linearized / linearize / error) and abort()-on-precondition behaviour.
 #pragma once
-#include <gtsam_points_hip.h>
+#include <gtsam/geometry/Pose3.h>
+#include <gtsam/linear/HessianFactor.h>
+#include <gtsam/nonlinear/Values.h>
+#include <gtsam_points/factors/nonlinear_factor_gpu.hpp>
+#include <gtsam_points/util/gtsam_migration.hpp>
 
 #include <cstdlib>
 #include <cstring>
@@ -11,7 +16,6 @@
 
 #include "check_error.hpp"
 #include "gaussian_voxelmap_gpu.hpp"
-#include "nonlinear_factor_gpu.hpp"
 #include "stream_temp_buffer_roundrobin.hpp"
 
 namespace gtsam_points {
@@ -24,13 +28,13 @@ public:
 
   /// binary factor (integrated_vgicp_factor_gpu.hpp:54-60)
   IntegratedVGICPFactorGPU(gtsam::Key target_key, gtsam::Key source_key, const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source,
-                           ihipStream_t* stream = nullptr, std::shared_ptr<TempBufferManager> temp_buffer = nullptr)
+                           CUstream_st* stream = nullptr, std::shared_ptr<TempBufferManager> temp_buffer = nullptr)
   : NonlinearFactorGPU(gtsam::KeyVector{target_key, source_key}), is_binary(true), target(std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(target)), source(source), temp_buffer(temp_buffer) {
     init(stream);
   }
   /// unary factor with a fixed target pose (:71-77)
   IntegratedVGICPFactorGPU(const gtsam::Pose3& fixed_target_pose, gtsam::Key source_key, const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source,
-                           ihipStream_t* stream = nullptr, std::shared_ptr<TempBufferManager> temp_buffer = nullptr)
+                           CUstream_st* stream = nullptr, std::shared_ptr<TempBufferManager> temp_buffer = nullptr)
   : NonlinearFactorGPU(gtsam::KeyVector{source_key}), is_binary(false), fixed_target_pose(fixed_target_pose), target(std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(target)), source(source), temp_buffer(temp_buffer) {
     init(stream);
   }
@@ -56,8 +60,9 @@ public:
   int num_inliers() const { return num_inliers_; }
   double inlier_fraction() const { return num_inliers_ / static_cast<double>(source->size()); }
   GaussianVoxelMapGPU::ConstPtr get_target() const { return target; }
-  gtsam::Pose3 get_fixed_target_pose() const { return fixed_target_pose; }
+  Eigen::Isometry3f get_fixed_target_pose() const { return Eigen::Isometry3d(fixed_target_pose.matrix()).cast<float>(); }  // integrated_vgicp_factor_gpu.hpp:106
   gp_vgicp_factor_t* handle() const { return h; }
+  int device() const { return gp_vgicp_factor_device(h); }  // the GPU the operands live on (multi-GPU sharding)
 
   gtsam::NonlinearFactor::shared_ptr clone() const override {  // drops stream/buffer like the reference (:122-134)
     if (is_binary) return gtsam::make_shared<IntegratedVGICPFactorGPU>(keys()[0], keys()[1], target, source, nullptr, nullptr);
@@ -74,9 +79,9 @@ public:
     }
     std::cerr << "warning: computing error in sync mode seriously affects the processing speed!!" << std::endl;
     if (!linearized) linearize(values);
-    const gtsam::Pose3 evaluation_point = calc_delta(values);
+    const Eigen::Matrix4d lin = linearization_point.matrix(), eval = calc_delta(values).matrix();
     double err = 0.0;
-    check_error << gp_vgicp_factor_compute_error(h, linearization_point.matrix().data(), evaluation_point.matrix().data(), &err);
+    check_error << gp_vgicp_factor_compute_error(h, lin.data(), eval.data(), &err);
     return err;
   }
 
@@ -90,7 +95,8 @@ public:
     } else {
       std::cerr << "warning: performing linearization in sync mode seriously affects the processing speed!!" << std::endl;
       touch_points();
-      check_error << gp_vgicp_factor_linearize(h, linearization_point.matrix().data(), &l);
+      const Eigen::Matrix4d lin = linearization_point.matrix();
+      check_error << gp_vgicp_factor_linearize(h, lin.data(), &l);
       num_inliers_ = static_cast<int>(l.num_inliers);
     }
     gtsam::Matrix6 Ht, Hs, Hts;
@@ -116,11 +122,11 @@ public:
   void touch_points() const {
     if (enable_offloading) {
       const_cast<GaussianVoxelMapGPU*>(target.get())->touch(nullptr);
-      if (auto src = dynamic_cast<const PointCloudGPU*>(source.get())) const_cast<PointCloudGPU*>(src)->touch(nullptr);
+      if (auto src = dynamic_cast<const OffloadableGPU*>(source.get())) const_cast<OffloadableGPU*>(src)->touch(nullptr);
     }
     if (auto src = dynamic_cast<const PointCloudGPU*>(source.get())) {
       if (src->generation != source_generation) {
-        check_error << gp_vgicp_factor_set_source(h, source->points_gpu, source->covs_gpu, source->normals_gpu);
+        check_error << gp_vgicp_factor_set_source(h, as_floats(source->points_gpu), as_floats(source->covs_gpu), as_floats(source->normals_gpu));
         source_generation = src->generation;
       }
     }
@@ -128,12 +134,12 @@ public:
 
   void set_linearization_point(const gtsam::Values& values, void* lin_input_cpu) override {  // memcpy: no alignment assumed (:219-220)
     touch_points();  // reset_inliers -> touch_points upstream (integrated_vgicp_derivatives_inliers.cu:47)
-    const gtsam::Pose3 d = calc_delta(values);
-    std::memcpy(lin_input_cpu, d.matrix().data(), sizeof(double) * 16);
+    const Eigen::Matrix4d d = calc_delta(values).matrix();
+    std::memcpy(lin_input_cpu, d.data(), sizeof(double) * 16);
   }
   void set_evaluation_point(const gtsam::Values& values, void* eval_input_cpu) override {
-    const gtsam::Pose3 d = calc_delta(values);
-    std::memcpy(eval_input_cpu, d.matrix().data(), sizeof(double) * 16);
+    const Eigen::Matrix4d d = calc_delta(values).matrix();
+    std::memcpy(eval_input_cpu, d.data(), sizeof(double) * 16);
   }
   void issue_linearize(const void* lin_input_cpu, const void* lin_input_gpu, void* lin_output_gpu) override {
     double pose[16];
@@ -166,7 +172,7 @@ public:
   }
 
 private:
-  void init(ihipStream_t* stream) {
+  void init(CUstream_st* stream) {
     if (!source->points_gpu) {
       std::cerr << "error: GPU source points have not been allocated!!" << std::endl;  // :33-36
       abort();
@@ -179,7 +185,7 @@ private:
       std::cerr << "error: GPU target voxels have not been created!!" << std::endl;  // :43-46
       abort();
     }
-    check_error << gp_vgicp_factor_create(target->handle(), source->points_gpu, source->covs_gpu, source->normals_gpu, static_cast<int>(source->size()), stream,
+    check_error << gp_vgicp_factor_create(target->handle(), as_floats(source->points_gpu), as_floats(source->covs_gpu), as_floats(source->normals_gpu), static_cast<int>(source->size()), gp_stream(stream),
                                           temp_buffer ? temp_buffer->handle() : nullptr, &h);
     if (auto src = dynamic_cast<const PointCloudGPU*>(source.get())) source_generation = src->generation;
   }

@@ -1,9 +1,15 @@
-// nonlinear_factor_set_gpu.hpp -- NonlinearFactorSet / LinearizationHook / NonlinearFactorSetGPU
-// (optimizers/linearization_hook.{hpp,cpp}, cuda/nonlinear_factor_set_gpu.{hpp,cpp}) over the C-ABI.
-// An all-VGICP set issues ONE batched launch per linearize()/error(); any other NonlinearFactorGPU goes through the
-// reference's staging-buffer protocol with the same byte cursors.
+// nonlinear_factor_set_gpu.hpp -- NonlinearFactorSetGPU (cuda/nonlinear_factor_set_gpu.{hpp,cpp}) over the C-ABI, a subclass of the
+// reference's own NonlinearFactorSet (optimizers/linearization_hook.hpp:11-29); LinearizationHook itself is the reference's
+// (optimizers/linearization_hook.cpp, compiled where it lies).
+//   * an all-VGICP set on one device issues ONE batched launch per linearize() / error();
+//   * an all-VGICP set whose factors live on several devices is sharded by device (gp_vgicp_multi_batch_*: per-device batched
+//     launches + one RCCL all-reduce of the stacked records) -- the reference has no counterpart;
+//   * any other NonlinearFactorGPU goes through the reference's staging-buffer protocol with the same byte cursors (:64-218).
 #pragma once
-#include <gtsam_points_hip.h>
+#include <gtsam/nonlinear/NonlinearFactorGraph.h>
+#include <gtsam/nonlinear/Values.h>
+#include <gtsam_points/factors/nonlinear_factor_gpu.hpp>
+#include <gtsam_points/optimizers/linearization_hook.hpp>
 
 #include <cstring>
 #include <functional>
@@ -14,21 +20,6 @@
 #include "integrated_vgicp_factor_gpu.hpp"
 
 namespace gtsam_points {
-
-class NonlinearFactorSet {  // linearization_hook.hpp:11-29
-public:
-  virtual ~NonlinearFactorSet() {}
-  virtual int size() const = 0;
-  virtual void clear() = 0;
-  virtual void clear_counts() = 0;
-  virtual int linearization_count() const = 0;
-  virtual int evaluation_count() const = 0;
-  virtual bool add(gtsam::NonlinearFactor::shared_ptr factor) = 0;
-  virtual void add(const gtsam::NonlinearFactorGraph& factors) = 0;
-  virtual void linearize(const gtsam::Values& values) = 0;
-  virtual void error(const gtsam::Values& values) = 0;
-  virtual std::vector<gtsam::GaussianFactor::shared_ptr> calc_linear_factors(const gtsam::Values& linearization_point) = 0;
-};
 
 class NonlinearFactorSetGPU : public NonlinearFactorSet {
 public:
@@ -52,7 +43,7 @@ public:
   int evaluation_count() const override { return num_evaluations; }
 
   bool add(gtsam::NonlinearFactor::shared_ptr factor) override {  // keeps only NonlinearFactorGPU instances (:48-56)
-    auto gpu_factor = gtsam_points::dynamic_pointer_cast<NonlinearFactorGPU>(factor);
+    auto gpu_factor = gtsam_points::dynamic_pointer_cast<NonlinearFactorGPU>(factor);  // nonlinear_factor_set_gpu.cpp:48-56
     if (!gpu_factor) return false;
     factors.push_back(gpu_factor);
     drop_batch();
@@ -78,7 +69,11 @@ public:
       cur += f->linearization_input_size();
     }
     if (ensure_batch()) {  // fast path: every factor is an IntegratedVGICPFactorGPU (input = 128-B pose, output = 976-B record)
-      check_error << gp_vgicp_batch_linearize(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<gp_linearized6*>(lin_out_cpu.data()));
+      if (multi) {
+        check_error << gp_vgicp_multi_batch_linearize(multi, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<gp_linearized6*>(lin_out_cpu.data()));
+      } else {
+        check_error << gp_vgicp_batch_linearize(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<gp_linearized6*>(lin_out_cpu.data()));
+      }
     } else {
       resize(&d_lin_in, &d_lin_in_size, in_size);
       resize(&d_lin_out, &d_lin_out_size, out_size);
@@ -117,8 +112,13 @@ public:
       cur += f->evaluation_input_size();
     }
     if (ensure_batch()) {
-      check_error << gp_vgicp_batch_compute_error(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<const double*>(eval_in_cpu.data()),
-                                                  reinterpret_cast<double*>(eval_out_cpu.data()));
+      if (multi) {
+        check_error << gp_vgicp_multi_batch_compute_error(multi, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<const double*>(eval_in_cpu.data()),
+                                                          reinterpret_cast<double*>(eval_out_cpu.data()));
+      } else {
+        check_error << gp_vgicp_batch_compute_error(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<const double*>(eval_in_cpu.data()),
+                                                    reinterpret_cast<double*>(eval_out_cpu.data()));
+      }
     } else {
       resize(&d_eval_in, &d_eval_in_size, in_size);
       resize(&d_eval_out, &d_eval_out_size, out_size);
@@ -151,21 +151,32 @@ public:
 
 private:
   bool ensure_batch() {
-    if (batch) return true;
+    if (batch || multi) return true;
     if (batch_checked) return false;
     batch_checked = true;
     std::vector<gp_vgicp_factor_t*> handles;
+    bool one_device = true;
     for (const auto& f : factors) {
-      auto v = std::dynamic_pointer_cast<IntegratedVGICPFactorGPU>(f);
+      auto v = gtsam_points::dynamic_pointer_cast<IntegratedVGICPFactorGPU>(f);
       if (!v) return false;
       handles.push_back(v->handle());
+      one_device = one_device && gp_vgicp_factor_device(v->handle()) == gp_vgicp_factor_device(handles[0]);
     }
-    check_error << gp_vgicp_batch_create(handles.data(), static_cast<int>(handles.size()), stream, &batch);
-    return batch != nullptr;
+    if (one_device && forced_shards.empty()) {
+      check_error << gp_vgicp_batch_create(handles.data(), static_cast<int>(handles.size()), stream, &batch);
+      return batch != nullptr;
+    }
+    // factors on several devices (or an explicit shard assignment: the single-GPU rehearsal of a multi-GPU plan):
+    // one shard per device, RCCL all-reduce of the stacked records when the shards sit on distinct devices
+    check_error << gp_vgicp_multi_batch_create(handles.data(), static_cast<int>(handles.size()), forced_shards.empty() ? nullptr : forced_shards.data(), forced_num_shards, -1,
+                                               &multi);
+    return multi != nullptr;
   }
   void drop_batch() {
     if (batch) check_error << gp_vgicp_batch_destroy(batch);
+    if (multi) check_error << gp_vgicp_multi_batch_destroy(multi);
     batch = nullptr;
+    multi = nullptr;
     batch_checked = false;
   }
   void resize(void** buf, size_t* cap, size_t size) {  // grow-only DeviceBuffer::resize (:20-28)
@@ -182,46 +193,22 @@ private:
   void *d_lin_in = nullptr, *d_lin_out = nullptr, *d_eval_in = nullptr, *d_eval_out = nullptr;
   size_t d_lin_in_size = 0, d_lin_out_size = 0, d_eval_in_size = 0, d_eval_out_size = 0;
   gp_vgicp_batch_t* batch = nullptr;
+  gp_vgicp_multi_batch_t* multi = nullptr;
   bool batch_checked = false;
-};
+  std::vector<int> forced_shards;
+  int forced_num_shards = 0;
 
-inline std::shared_ptr<NonlinearFactorSet> create_nonlinear_factor_set_gpu() { return std::make_shared<NonlinearFactorSetGPU>(); }  // nonlinear_factor_set_gpu_create.hpp:10
-
-class LinearizationHook {  // linearization_hook.hpp:31-57, .cpp:10-90
 public:
-  LinearizationHook() {
-    for (const auto& ctor : hook_constructors()) hooks.push_back(ctor());
+  /// rehearsal / tuning: assign the factors (in add() order) to `num_shards` shards explicitly; shards may share a device
+  void set_shard_assignment(const std::vector<int>& shard_of_factor, int num_shards) {
+    forced_shards = shard_of_factor;
+    forced_num_shards = num_shards;
+    drop_batch();
   }
-  explicit LinearizationHook(const gtsam::NonlinearFactorGraph& factors) : LinearizationHook() { add(factors); }
-  int size() const { int n = 0; for (auto& h : hooks) n += h->size(); return n; }
-  void clear() { for (auto& h : hooks) h->clear(); }
-  void clear_counts() { for (auto& h : hooks) h->clear_counts(); }
-  int linearization_count() const { int n = 0; for (auto& h : hooks) n += h->linearization_count(); return n; }
-  int evaluation_count() const { int n = 0; for (auto& h : hooks) n += h->evaluation_count(); return n; }
-  bool add(gtsam::NonlinearFactor::shared_ptr factor) {
-    bool inserted = false;
-    for (auto& h : hooks) inserted |= h->add(factor);
-    return inserted;
-  }
-  void add(const gtsam::NonlinearFactorGraph& factors) { for (auto& h : hooks) h->add(factors); }
-  void linearize(const gtsam::Values& values) { for (auto& h : hooks) h->linearize(values); }
-  void error(const gtsam::Values& values) { for (auto& h : hooks) h->error(values); }
-  std::vector<gtsam::GaussianFactor::shared_ptr> calc_linear_factors(const gtsam::Values& p) {
-    std::vector<gtsam::GaussianFactor::shared_ptr> out;
-    for (auto& h : hooks) {
-      auto l = h->calc_linear_factors(p);
-      out.insert(out.end(), l.begin(), l.end());
-    }
-    return out;
-  }
-  static void register_hook(const std::function<std::shared_ptr<NonlinearFactorSet>()>& hook) { hook_constructors().push_back(hook); }
-
-private:
-  static std::vector<std::function<std::shared_ptr<NonlinearFactorSet>()>>& hook_constructors() {
-    static std::vector<std::function<std::shared_ptr<NonlinearFactorSet>()>> ctors;
-    return ctors;
-  }
-  std::vector<std::shared_ptr<NonlinearFactorSet>> hooks;
+  int num_shards() const { return multi ? gp_vgicp_multi_batch_num_shards(multi) : (batch ? 1 : 0); }
+  bool uses_rccl() const { return multi && gp_vgicp_multi_batch_uses_rccl(multi) != 0; }
 };
+
+std::shared_ptr<NonlinearFactorSet> create_nonlinear_factor_set_gpu();  // cuda/nonlinear_factor_set_gpu_create.hpp:10; defined in gtsam_points_hip_host.cpp
 
 }  // namespace gtsam_points

@@ -1,21 +1,17 @@
 // stream_temp_buffer_roundrobin.hpp -- TempBufferManager / StreamTempBufferRoundRobin
-// (cuda/stream_temp_buffer_roundrobin.hpp:19-65) over the C-ABI.  The stream type is the opaque ihipStream_t*.
+// (cuda/stream_temp_buffer_roundrobin.hpp:19-65, cuda/stream_roundrobin.hpp) over the C-ABI.
 #pragma once
-#include <gtsam_points_hip.h>
-
 #include <memory>
 #include <utility>
 
 #include "check_error.hpp"
-
-struct ihipStream_t;
 
 namespace gtsam_points {
 
 class TempBufferManager {
 public:
   using Ptr = std::shared_ptr<TempBufferManager>;
-  explicit TempBufferManager(size_t init_buffer_size = 0) : owned(true) { check_error << gp_temp_buffer_create(init_buffer_size, &h); }
+  TempBufferManager(size_t init_buffer_size = 0) : owned(true) { check_error << gp_temp_buffer_create(init_buffer_size, &h); }
   TempBufferManager(gp_temp_buffer_t* borrowed, bool) : h(borrowed), owned(false) {}
   ~TempBufferManager() {
     if (owned) check_error << gp_temp_buffer_destroy(h);
@@ -44,11 +40,11 @@ public:
   StreamTempBufferRoundRobin(const StreamTempBufferRoundRobin&) = delete;
   StreamTempBufferRoundRobin& operator=(const StreamTempBufferRoundRobin&) = delete;
 
-  std::pair<ihipStream_t*, TempBufferManager::Ptr> get_stream_buffer() {
+  std::pair<CUstream_st*, TempBufferManager::Ptr> get_stream_buffer() {
     gp_stream_t s = nullptr;
     gp_temp_buffer_t* b = nullptr;
     check_error << gp_stream_pool_get(h, &s, &b);
-    return {static_cast<ihipStream_t*>(s), std::make_shared<TempBufferManager>(b, false)};
+    return {reinterpret_cast<CUstream_st*>(s), std::make_shared<TempBufferManager>(b, false)};
   }
   void sync_all() { check_error << gp_stream_pool_sync_all(h); }
   void clear() { check_error << gp_stream_pool_clear(h); }

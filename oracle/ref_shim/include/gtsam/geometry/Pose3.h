@@ -34,6 +34,17 @@ public:
     m.block<3, 1>(0, 3) = t_;
     return m;
   }
+  // Pose3::Expmap, xi = [omega, v] (Rodrigues + the SE(3) left Jacobian of omega applied to v)
+  static Pose3 Expmap(const Eigen::Matrix<double, 6, 1>& xi) {
+    const Eigen::Vector3d w(xi[0], xi[1], xi[2]), v(xi[3], xi[4], xi[5]);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    const Eigen::Matrix3d W = SO3::Hat(w), W2 = W * W;
+    const double A = th > 1e-10 ? std::sin(th) / th : 1.0, B = th > 1e-10 ? (1.0 - std::cos(th)) / th2 : 0.5, C = th > 1e-10 ? (th - std::sin(th)) / (th2 * th) : 1.0 / 6.0;
+    const Eigen::Matrix3d R = Eigen::Matrix3d::Identity() + W * A + W2 * B;
+    const Eigen::Matrix3d V = Eigen::Matrix3d::Identity() + W * B + W2 * C;
+    return Pose3(R, V * v);
+  }
+  Pose3 retract(const Eigen::Matrix<double, 6, 1>& xi) const { return (*this) * Expmap(xi); }
   const Eigen::Matrix3d& rotationMatrix() const { return R_; }
   const Eigen::Vector3d& translation() const { return t_; }
 

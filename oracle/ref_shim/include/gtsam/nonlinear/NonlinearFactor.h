@@ -15,6 +15,9 @@ public:
   template <typename T>
   const T& at(Key k) const { return poses_.at(k); }
   void insert(Key k, const Pose3& p) { poses_[k] = p; }
+  void update(Key k, const Pose3& p) { poses_[k] = p; }
+  bool exists(Key k) const { return poses_.count(k) > 0; }
+  size_t size() const { return poses_.size(); }
 private:
   std::map<Key, Pose3> poses_;
 };

@@ -1,0 +1,320 @@
+// test_host.cpp -- end-to-end driver of the C++ mirror, compiled AGAINST THE REFERENCE'S OWN HEADERS (see the Makefile) and run on
+// the GPU box by tests/test_host_gpu.py.  Mirrors the shape of src/test/test_matching_cost_factors.cpp and test_voxelmap.cpp:
+// frames -> voxel maps -> IntegratedVGICPFactorGPU through a StreamTempBufferRoundRobin -> the reference's LinearizationHook ->
+// Levenberg-Marquardt -> pose error gate; plus the overlap_gpu overload set, merge_frames_gpu, offloading, the generic
+// NonlinearFactorGPU protocol and the sharded (multi-device) factor set.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "nonlinear_factor_set_gpu.hpp"
+
+using namespace gtsam_points;
+using Vec3f = Eigen::Vector3f;
+using Mat3f = Eigen::Matrix3f;
+
+static void make_room(int n, unsigned seed, const gtsam::Pose3& frame_from_world, std::vector<Vec3f>& pts, std::vector<Mat3f>& covs) {
+  // three orthogonal walls of a room corner; covariance I - 0.999 n n^T from the surface normal
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<double> u(0.0, 1.0);
+  std::normal_distribution<double> noise(0.0, 0.01);
+  const Eigen::Matrix4d F = frame_from_world.matrix();
+  pts.resize((size_t)n);
+  covs.resize((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const int wall = i % 3;
+    double p[3] = {0, 0, 0}, nrm[3] = {0, 0, 0};
+    const double a = 1.0 + 9.0 * u(rng), b = 1.0 + 9.0 * u(rng);
+    if (wall == 0) { p[0] = a; p[1] = b; p[2] = noise(rng); nrm[2] = 1; }
+    if (wall == 1) { p[0] = a; p[2] = 0.3 * b; p[1] = 10.5 + noise(rng); nrm[1] = 1; }
+    if (wall == 2) { p[1] = a; p[2] = 0.3 * b; p[0] = 10.5 + noise(rng); nrm[0] = 1; }
+    double nf[3];
+    for (int r = 0; r < 3; r++) {
+      pts[(size_t)i][r] = (float)(F(r, 0) * p[0] + F(r, 1) * p[1] + F(r, 2) * p[2] + F(r, 3));
+      nf[r] = F(r, 0) * nrm[0] + F(r, 1) * nrm[1] + F(r, 2) * nrm[2];
+    }
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) covs[(size_t)i](r, c) = (float)((r == c ? 1.0 : 0.0) - 0.999 * nf[r] * nf[c]);
+  }
+}
+
+static bool solve6(gtsam::Matrix6 A, gtsam::Vector6 b, gtsam::Vector6& x) {  // Gaussian elimination with partial pivoting
+  const int n = 6;
+  for (int k = 0; k < n; k++) {
+    int piv = k;
+    for (int r = k + 1; r < n; r++)
+      if (std::fabs(A(r, k)) > std::fabs(A(piv, k))) piv = r;
+    if (std::fabs(A(piv, k)) < 1e-12) return false;
+    if (piv != k) {
+      for (int c = 0; c < n; c++) std::swap(A(k, c), A(piv, c));
+      std::swap(b[k], b[piv]);
+    }
+    for (int r = k + 1; r < n; r++) {
+      const double f = A(r, k) / A(k, k);
+      for (int c = k; c < n; c++) A(r, c) -= f * A(k, c);
+      b[r] -= f * b[k];
+    }
+  }
+  for (int r = n - 1; r >= 0; r--) {
+    double s = b[r];
+    for (int c = r + 1; c < n; c++) s -= A(r, c) * x[c];
+    x[r] = s / A(r, r);
+  }
+  return true;
+}
+
+static gtsam::Vector6 xi6(double a, double b, double c, double d, double e, double f) {
+  gtsam::Vector6 v;
+  v[0] = a; v[1] = b; v[2] = c; v[3] = d; v[4] = e; v[5] = f;
+  return v;
+}
+
+#define CHECK(cond)                                                    \
+  do {                                                                 \
+    if (!(cond)) {                                                     \
+      std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #cond, __LINE__); \
+      return 1;                                                        \
+    }                                                                  \
+  } while (0)
+
+// a third-party NonlinearFactorGPU (wraps the VGICP factor so that the set cannot take its batched fast path): must keep working
+// through the reference's staging-buffer protocol (cuda/nonlinear_factor_set_gpu.cpp:64-139)
+class WrappedFactor : public NonlinearFactorGPU {
+public:
+  explicit WrappedFactor(const std::shared_ptr<IntegratedVGICPFactorGPU>& inner) : NonlinearFactorGPU(inner->keys()), inner(inner) {}
+  size_t dim() const override { return 6; }
+  double error(const gtsam::Values& v) const override { return inner->error(v); }
+  gtsam::GaussianFactor::shared_ptr linearize(const gtsam::Values& v) const override { return inner->linearize(v); }
+  size_t linearization_input_size() const override { return inner->linearization_input_size(); }
+  size_t linearization_output_size() const override { return inner->linearization_output_size(); }
+  size_t evaluation_input_size() const override { return inner->evaluation_input_size(); }
+  size_t evaluation_output_size() const override { return inner->evaluation_output_size(); }
+  void set_linearization_point(const gtsam::Values& v, void* b) override { inner->set_linearization_point(v, b); }
+  void issue_linearize(const void* a, const void* b, void* c) override { inner->issue_linearize(a, b, c); }
+  void store_linearized(const void* b) override { inner->store_linearized(b); }
+  void set_evaluation_point(const gtsam::Values& v, void* b) override { inner->set_evaluation_point(v, b); }
+  void issue_compute_error(const void* a, const void* b, const void* c, const void* d, void* e) override { inner->issue_compute_error(a, b, c, d, e); }
+  void store_computed_error(const void* b) override { inner->store_computed_error(b); }
+  void sync() override { inner->sync(); }
+  std::shared_ptr<IntegratedVGICPFactorGPU> inner;
+};
+
+int main() {
+  int ndev = 0;
+  CHECK(gp_device_count(&ndev) == GP_OK && ndev > 0);
+  const int N = 30000;
+  const gtsam::Pose3 world;  // identity: target frame == world
+  const gtsam::Pose3 T_true = gtsam::Pose3::Expmap(xi6(0.02, -0.03, 0.05, 0.15, -0.1, 0.05));  // source sensor pose in the target frame
+  const Eigen::Isometry3d I_iso = Eigen::Isometry3d::Identity(), T_iso(T_true.matrix());
+  std::vector<Vec3f> tp, sp;
+  std::vector<Mat3f> tc, sc;
+  make_room(N, 1, world, tp, tc);
+  make_room(N, 2, T_true.inverse(), sp, sc);  // source points expressed in the source frame
+
+  auto target = std::make_shared<PointCloudGPU>();
+  target->add_points_gpu(tp);
+  target->add_covs_gpu(tc);
+  auto source = std::make_shared<PointCloudGPU>();
+  source->add_points_gpu(sp);
+  source->add_covs_gpu(sc);
+  CHECK(target->has_points_gpu() && target->check_covs_gpu());  // the reference's own PointCloud members (types/point_cloud.cpp)
+
+  auto voxels = std::make_shared<GaussianVoxelMapGPU>(0.5f);
+  voxels->insert(*target);
+  CHECK(voxels->voxelmap_info.num_voxels > 100 && voxels->buckets != nullptr && voxels->loaded_on_gpu());
+  const auto means = download_voxel_means(*voxels);
+  const auto buckets = download_buckets(*voxels);
+  CHECK((int)means.size() == voxels->voxelmap_info.num_voxels && (int)buckets.size() == voxels->voxelmap_info.num_buckets);
+  int used = 0;
+  for (const auto& b : buckets) used += b.second >= 0;
+  CHECK(used == voxels->voxelmap_info.num_voxels);  // test_voxelmap.cpp:352-380
+  const double self_overlap = overlap_gpu(voxels, target, I_iso);
+  CHECK(self_overlap > 0.99);  // test_voxelmap.cpp:226
+
+  // save / load round trip
+  voxels->save_compact("/tmp/gp_host_voxels.bin");
+  auto loaded = GaussianVoxelMapGPU::load("/tmp/gp_host_voxels.bin");
+  CHECK(loaded && loaded->voxelmap_info.num_voxels == voxels->voxelmap_info.num_voxels);
+  CHECK(std::fabs(overlap_gpu(loaded, source, T_iso) - overlap_gpu(voxels, source, T_iso)) < 1e-3);
+
+  // the overload set of overlap_gpu (types/gaussian_voxelmap.hpp:72-165) + merge_frames_gpu
+  {
+    const std::vector<GaussianVoxelMap::ConstPtr> two{voxels, loaded};
+    const double single = overlap_gpu(voxels, source, T_iso);
+    const double u = overlap_gpu(two, source, std::vector<Eigen::Isometry3d>{T_iso, T_iso});
+    CHECK(std::fabs(u - single) < 1e-12);  // the same map twice: union == single
+    const auto rates = overlap_gpu(two, std::vector<PointCloud::ConstPtr>{target, source}, std::vector<Eigen::Isometry3d>{I_iso, T_iso});
+    CHECK(rates.size() == 2 && rates[0] == self_overlap && std::fabs(rates[1] - u) < 1e-12);
+    // templated forwarding overloads of the reference header (vector of derived pointers)
+    const std::vector<GaussianVoxelMapGPU::ConstPtr> two_gpu{voxels, loaded};
+    CHECK(overlap_gpu(two_gpu, source, std::vector<Eigen::Isometry3d>{T_iso, T_iso}) == u);
+    // pose resident in device memory as an Eigen::Isometry3f (:72-76)
+    const Eigen::Isometry3f Tf = T_iso.cast<float>();
+    void* d_pose = nullptr;
+    CHECK(gp_malloc(&d_pose, sizeof(float) * 16) == GP_OK && gp_memcpy_h2d(d_pose, Tf.data(), sizeof(float) * 16, nullptr) == GP_OK && gp_stream_synchronize(nullptr) == GP_OK);
+    const double from_dev = overlap_gpu(voxels, source, static_cast<const Eigen::Isometry3f*>(d_pose));
+    CHECK(std::fabs(from_dev - single) < 1e-3);  // the float pose moves a handful of points across voxel faces
+    gp_free(d_pose);
+    // a point cloud as the target (:93-97)
+    CHECK(overlap_gpu(std::static_pointer_cast<const PointCloud>(target), std::static_pointer_cast<const PointCloud>(source), T_iso) > 0.9);
+    // double 4-vector / 4x4 inputs go through the same pack kernels
+    std::vector<Eigen::Vector4d> p4((size_t)N);
+    std::vector<Eigen::Matrix4d> c4((size_t)N, Eigen::Matrix4d::Zero());
+    for (int i = 0; i < N; i++) {
+      for (int k = 0; k < 3; k++) p4[(size_t)i][k] = sp[(size_t)i][k];
+      p4[(size_t)i][3] = 1.0;
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) c4[(size_t)i](r, c) = sc[(size_t)i](r, c);
+    }
+    auto source4 = std::make_shared<PointCloudGPU>();
+    source4->add_points_gpu(p4);
+    source4->add_covs_gpu(c4);
+    CHECK(overlap_gpu(voxels, source4, T_iso) == single);
+    const auto back = download_points_gpu(*source4);
+    CHECK(back.size() == (size_t)N && back[7][1] == sp[7][1]);
+    auto merged = merge_frames_gpu({I_iso, T_iso}, std::vector<PointCloud::ConstPtr>{target, source4}, 0.25);
+    CHECK(merged->size() > 1000 && merged->size() < (size_t)(2 * N) && merged->points_gpu && merged->covs_gpu);
+    CHECK(overlap_gpu(voxels, merged, I_iso) > 0.9);  // both frames land on the target's surfaces
+  }
+
+  // OffloadableGPU round trip on a cloud (the reference's own touch() / access counter, types/offloadable.cpp)
+  {
+    const double before = overlap_gpu(voxels, source, T_iso);
+    const auto t0 = OffloadableGPU::current_access_time();
+    CHECK(source->loaded_on_gpu() && source->memory_usage_gpu() == (size_t)48 * N);
+    CHECK(source->offload_gpu() && !source->offload_gpu() && !source->loaded_on_gpu() && source->points_gpu == nullptr);
+    CHECK(source->touch() && source->loaded_on_gpu() && !source->reload_gpu());
+    CHECK(OffloadableGPU::current_access_time() == t0 + 1 && source->last_accessed_time() == t0);
+    CHECK(overlap_gpu(voxels, source, T_iso) == before);
+  }
+
+  // factor through the round-robin pool + the REFERENCE's linearisation hook, as the applications do
+  LinearizationHook::register_hook([] { return create_nonlinear_factor_set_gpu(); });
+  StreamTempBufferRoundRobin roundrobin(4);
+  auto sb = roundrobin.get_stream_buffer();
+  gtsam::NonlinearFactorGraph graph;
+  auto factor = graph.emplace_shared<IntegratedVGICPFactorGPU>(world, 1, voxels, source, sb.first, sb.second);  // unary: fixed target
+  auto sb2 = roundrobin.get_stream_buffer();
+  auto factor_b = graph.emplace_shared<IntegratedVGICPFactorGPU>(0, 1, voxels, source, sb2.first, sb2.second);  // binary
+  LinearizationHook hook(graph);
+  CHECK(hook.size() == 2);
+  CHECK((factor->get_fixed_target_pose().matrix() - Eigen::Matrix4f::Identity()).norm() == 0.0f && factor_b->get_target() == voxels);
+
+  gtsam::Values values;
+  values.insert(0, world);
+  values.insert(1, T_true * gtsam::Pose3::Expmap(xi6(0.03, -0.02, 0.04, 0.1, 0.08, -0.05)));
+  double lambda = 1e-5, err = 0.0;
+  for (int iter = 0; iter < 30; iter++) {
+    hook.linearize(values);
+    auto hf = std::dynamic_pointer_cast<gtsam::HessianFactor>(factor->linearize(values));
+    auto hb = std::dynamic_pointer_cast<gtsam::HessianFactor>(factor_b->linearize(values));
+    CHECK(hf && hb && hb->binary);
+    // the binary factor's source block equals the unary factor's (same delta): batch consistency
+    for (int k = 0; k < 36; k++) CHECK(std::fabs(hb->G22.data()[k] - hf->G22.data()[k]) <= 1e-9 * (1.0 + std::fabs(hf->G22.data()[k])));
+    err = hf->f;
+    bool improved = false;
+    for (int t = 0; t < 10 && !improved; t++) {
+      gtsam::Matrix6 A = hf->G22;
+      for (int d = 0; d < 6; d++) A(d, d) *= (1.0 + lambda);
+      gtsam::Vector6 dx = gtsam::Vector6::Zero();
+      CHECK(solve6(A, hf->g2, dx));
+      gtsam::Values trial = values;
+      trial.update(1, values.at<gtsam::Pose3>(1).retract(dx));
+      hook.error(trial);
+      const double new_err = factor->error(trial);
+      (void)factor_b->error(trial);
+      if (new_err < err) {
+        values = trial;
+        lambda = std::max(lambda / 10.0, 1e-12);
+        improved = true;
+        if ((err - new_err) / err < 1e-6) iter = 1000;
+      } else {
+        lambda *= 10.0;
+      }
+    }
+    if (!improved) break;
+  }
+  const Eigen::Matrix4d d = (T_true.inverse() * values.at<gtsam::Pose3>(1)).matrix();
+  const double trace = d(0, 0) + d(1, 1) + d(2, 2);
+  const double ang = std::acos(std::min(1.0, std::max(-1.0, (trace - 1.0) / 2.0)));
+  const double trans = std::sqrt(d(0, 3) * d(0, 3) + d(1, 3) * d(1, 3) + d(2, 3) * d(2, 3));
+  std::printf("rot err %.5f rad, trans err %.5f m, inliers %d / %d, gpu linearizations %d, evaluations %d\n", ang, trans, factor->num_inliers(), N, hook.linearization_count(),
+              hook.evaluation_count());
+  CHECK(ang < 0.015 && trans < 0.15);  // the reference's gate (test_matching_cost_factors.cpp:227-228)
+  CHECK(factor->inlier_fraction() > 0.8 && hook.linearization_count() > 0 && hook.evaluation_count() > 0);
+  auto cl = factor->clone();
+  CHECK(cl->keys().size() == 1 && cl->dim() == 6);
+  // offload / reload
+  CHECK(voxels->offload_gpu() && !voxels->loaded_on_gpu() && voxels->buckets == nullptr);
+  CHECK(voxels->reload_gpu() && voxels->loaded_on_gpu());
+  // the factor-level protocol: both operands offloaded by the application, the factor brings them back and gets the same answer
+  std::shared_ptr<gtsam::HessianFactor> ref_lin;
+  {
+    hook.linearize(values);
+    ref_lin = std::dynamic_pointer_cast<gtsam::HessianFactor>(factor_b->linearize(values));
+    (void)factor->linearize(values);
+    factor->set_enable_offloading(true);
+    factor_b->set_enable_offloading(true);
+    CHECK(voxels->offload_gpu() && source->offload_gpu());
+    hook.linearize(values);
+    auto again = std::dynamic_pointer_cast<gtsam::HessianFactor>(factor_b->linearize(values));
+    (void)factor->linearize(values);
+    CHECK(voxels->loaded_on_gpu() && source->loaded_on_gpu());
+    for (int k = 0; k < 36; k++)
+      CHECK(again->G11.data()[k] == ref_lin->G11.data()[k] && again->G22.data()[k] == ref_lin->G22.data()[k] && again->G12.data()[k] == ref_lin->G12.data()[k]);
+    CHECK(again->f == ref_lin->f);
+  }
+  // a third-party NonlinearFactorGPU goes through the generic staging-buffer path of the set and gives the same record
+  {
+    auto inner = std::make_shared<IntegratedVGICPFactorGPU>(0, 1, voxels, source);
+    auto set = create_nonlinear_factor_set_gpu();
+    CHECK(set->add(std::make_shared<WrappedFactor>(inner)) && set->size() == 1);
+    auto lin = set->calc_linear_factors(values);
+    auto h = std::dynamic_pointer_cast<gtsam::HessianFactor>(lin[0]);
+    CHECK(h && h->f == ref_lin->f);
+    for (int k = 0; k < 36; k++) CHECK(h->G22.data()[k] == ref_lin->G22.data()[k]);
+  }
+  // the sharded set: four factors in two shards (on one GPU: two shards on the same device with the host gather; on a multi-GPU
+  // node the same call spreads shards over devices and all-reduces the stacked records with RCCL) == the single batch
+  {
+    std::vector<std::shared_ptr<IntegratedVGICPFactorGPU>> fs;
+    NonlinearFactorSetGPU single, sharded;
+    for (int k = 0; k < 4; k++) {
+      fs.push_back(std::make_shared<IntegratedVGICPFactorGPU>(0, 1, k % 2 ? loaded : voxels, source));
+      single.add(fs.back());
+    }
+    auto a = single.calc_linear_factors(values);
+    CHECK(single.num_shards() == 1);
+    std::vector<std::shared_ptr<gtsam::HessianFactor>> ref;
+    for (auto& g : a) ref.push_back(std::dynamic_pointer_cast<gtsam::HessianFactor>(g));
+    for (auto& f : fs) sharded.add(f);
+    sharded.set_shard_assignment({0, 1, 0, 1}, 2);
+    auto b = sharded.calc_linear_factors(values);
+    CHECK(sharded.num_shards() == 2 && !sharded.uses_rccl());
+    for (int k = 0; k < 4; k++) {
+      auto hb2 = std::dynamic_pointer_cast<gtsam::HessianFactor>(b[(size_t)k]);
+      CHECK(hb2 && hb2->f == ref[(size_t)k]->f);
+      for (int e = 0; e < 36; e++) CHECK(hb2->G12.data()[e] == ref[(size_t)k]->G12.data()[e]);
+    }
+    sharded.error(values);
+    for (auto& f : fs) CHECK(f->error(values) > 0.0);
+    // the partitioner of the C-ABI: 10 equal factors over 4 shards
+    int64_t w[10];
+    for (auto& x : w) x = 32768;
+    gp_shard_plan_t* plan = nullptr;
+    CHECK(gp_shard_plan_create(w, 10, 4, &plan) == GP_OK && gp_shard_plan_num_shards(plan) == 4);
+    int covered = 0, worst = 0;
+    for (int s = 0; s < 4; s++) {
+      int b0 = 0, e0 = 0;
+      CHECK(gp_shard_plan_range(plan, s, &b0, &e0) == GP_OK && b0 == covered && e0 > b0);
+      covered = e0;
+      worst = std::max(worst, e0 - b0);
+    }
+    CHECK(covered == 10 && worst == 3);
+    gp_shard_plan_destroy(plan);
+  }
+  roundrobin.sync_all();
+  std::printf("HOST_TEST_OK\n");
+  return 0;
+}

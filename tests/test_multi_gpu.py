@@ -52,7 +52,7 @@ def test_sharded_batch_equals_plain_batch(gpu, kitti07):
 
     _, _, factors, deltas, deltas2 = _graph(gpu, kitti07)
     ref, ref_err = _plain_batch(gpu, factors, deltas, deltas2)
-    assert ref[:, 0].min() > 1000  # every factor has inliers
+    assert ref[:, 0].min() > 100  # every factor has inliers
     for shards in [1, 2, 4]:
         parts = partition_factors([int(gpu.load().gp_vgicp_factor_num_points(f._h)) for f in factors], shards)
         shard_of = np.zeros(len(factors), np.int32)
