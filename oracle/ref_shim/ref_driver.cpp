@@ -71,6 +71,45 @@ void ref_voxelmap_insert(void* h, const float* points, const float* covs, int n)
 }
 int ref_voxelmap_num_voxels(void* h) { return (int)(*static_cast<std::shared_ptr<gtsam_points::GaussianVoxelMapCPU>*>(h))->num_voxels(); }
 
+// ---- on-disk format interop (src/test/test_voxelmap.cpp:301-432): the reference's own save_compact / load ----
+void ref_voxelmap_save_compact(void* h, const char* path) { (*static_cast<std::shared_ptr<gtsam_points::GaussianVoxelMapCPU>*>(h))->save_compact(path); }
+void* ref_voxelmap_load(const char* path) {
+  auto m = gtsam_points::GaussianVoxelMapCPU::load(path);
+  return m ? new std::shared_ptr<gtsam_points::GaussianVoxelMapCPU>(m) : nullptr;
+}
+double ref_voxelmap_resolution(void* h) { return (*static_cast<std::shared_ptr<gtsam_points::GaussianVoxelMapCPU>*>(h))->voxel_resolution(); }
+// voxel statistics in the map's own order: coords int[V][3] (voxel_coord of the mean), num_points int[V], means double[V][3],
+// covs double[V][9] column-major, intensities double[V]
+void ref_voxelmap_export(void* h, int* coords, int* num_points, double* means, double* covs, double* intensities) {
+  auto& m = *static_cast<std::shared_ptr<gtsam_points::GaussianVoxelMapCPU>*>(h);
+  const int V = (int)m->num_voxels();
+  for (int v = 0; v < V; v++) {
+    const auto& vox = m->lookup_voxel(v);
+    const Eigen::Vector3i c = m->voxel_coord(vox.mean);
+    for (int k = 0; k < 3; k++) {
+      coords[3 * v + k] = c[k];
+      means[3 * v + k] = vox.mean[k];
+    }
+    num_points[v] = (int)vox.num_points;
+    for (int cc = 0; cc < 3; cc++)
+      for (int r = 0; r < 3; r++) covs[9 * v + cc * 3 + r] = vox.cov(r, cc);
+    intensities[v] = vox.intensity;
+  }
+}
+// overlap(target, source, T) (src/gtsam_points/types/gaussian_voxelmap_cpu_funcs.cpp:126-143): the loop of that function over the
+// reference's own voxel_coord / lookup_voxel_index (the file itself also holds merge_frames and needs PointCloudCPU's samplers)
+double ref_voxelmap_overlap(void* h, const float* points, int n, const double* delta) {
+  auto& m = *static_cast<std::shared_ptr<gtsam_points::GaussianVoxelMapCPU>*>(h);
+  Eigen::Matrix4d T;
+  std::memcpy(T.data(), delta, sizeof(double) * 16);
+  int num_overlap = 0;
+  for (int i = 0; i < n; i++) {
+    const Eigen::Vector4d pt = T * Eigen::Vector4d(points[3 * i], points[3 * i + 1], points[3 * i + 2], 1.0);
+    if (m->lookup_voxel_index(m->voxel_coord(pt)) >= 0) num_overlap++;
+  }
+  return n ? static_cast<double>(num_overlap) / n : 0.0;
+}
+
 void* ref_vgicp_create(void* map, const float* points, const float* covs, int n, int num_threads) {
   auto* f = new RefFactor;
   f->source = std::make_shared<OwnedCloud>(points, covs, n);

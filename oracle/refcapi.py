@@ -34,6 +34,14 @@ def _lib():
         lib.ref_voxelmap_insert.argtypes = [vp, fp, fp, C.c_int]
         lib.ref_voxelmap_num_voxels.argtypes = [vp]
         lib.ref_voxelmap_num_voxels.restype = C.c_int
+        lib.ref_voxelmap_save_compact.argtypes = [vp, C.c_char_p]
+        lib.ref_voxelmap_load.restype = vp
+        lib.ref_voxelmap_load.argtypes = [C.c_char_p]
+        lib.ref_voxelmap_resolution.restype = C.c_double
+        lib.ref_voxelmap_resolution.argtypes = [vp]
+        lib.ref_voxelmap_export.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_voxelmap_overlap.restype = C.c_double
+        lib.ref_voxelmap_overlap.argtypes = [vp, fp, C.c_int, dp]
         lib.ref_vgicp_create.restype = vp
         lib.ref_vgicp_create.argtypes = [vp, fp, fp, C.c_int, C.c_int]
         lib.ref_vgicp_destroy.argtypes = [vp]
@@ -72,6 +80,34 @@ class RefVoxelMap:
     @property
     def num_voxels(self):
         return int(_lib().ref_voxelmap_num_voxels(self._h))
+
+    # ---- the reference's own on-disk format (GaussianVoxelMapCPU::save_compact / load) and overlap() ----
+    def save_compact(self, path):
+        _lib().ref_voxelmap_save_compact(self._h, str(path).encode())
+
+    @staticmethod
+    def load(path):
+        h = _lib().ref_voxelmap_load(str(path).encode())
+        if not h:
+            return None
+        m = RefVoxelMap.__new__(RefVoxelMap)
+        m._h = h
+        return m
+
+    def voxel_resolution(self):
+        return float(_lib().ref_voxelmap_resolution(self._h))
+
+    def export(self):
+        V = self.num_voxels
+        coords, npts = np.zeros((V, 3), np.int32), np.zeros(V, np.int32)
+        means, covs, ints = np.zeros((V, 3)), np.zeros((V, 9)), np.zeros(V)
+        _lib().ref_voxelmap_export(self._h, coords.ctypes.data, npts.ctypes.data, means.ctypes.data, covs.ctypes.data, ints.ctypes.data)
+        return coords, npts, means, covs.reshape(V, 3, 3).transpose(0, 2, 1).copy(), ints
+
+    def overlap(self, points, delta=np.eye(4)):
+        p = _f32(points, 3)
+        d = np.ascontiguousarray(np.asarray(delta, dtype=np.float64).T).reshape(16).copy()
+        return float(_lib().ref_voxelmap_overlap(self._h, _fp(p), len(p), d.ctypes.data_as(C.POINTER(C.c_double))))
 
 
 class RefVGICPFactor:

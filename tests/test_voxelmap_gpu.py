@@ -165,3 +165,66 @@ def test_table_growth_drop_rate_and_empty(gpu, kitti00):
     assert gpu.overlap_gpu(vme, cloud) == 0.0
     with pytest.raises(gpu.GPError):
         vme.insert(gpu.PointCloudGPU(p))  # no covs: the reference abort()s (gaussian_voxelmap_gpu.cu:212-215)
+
+
+def test_file_interop_with_the_reference_cpu_map(gpu, kitti00, tmp_path):
+    """src/test/test_voxelmap.cpp:301-432 across implementations: a file written by gp_voxelmap_save_compact is loaded by the
+    REFERENCE's own GaussianVoxelMapCPU::load (oracle/_ref/libref.so, compiled from gaussian_voxelmap_cpu.cpp where it lies) and a
+    file written by the reference's GaussianVoxelMapCPU::save_compact is loaded by gp_voxelmap_load; voxel sets identical,
+    means / covs within 1e-3 (the on-disk record is float), overlap within 1e-3 -- the reference's own gates (:326-408, :418-431)"""
+    from oracle import refcapi
+
+    if not refcapi.available():
+        pytest.skip("oracle/_ref/libref.so not built (needs /root/reference at build time)")
+    intens = np.linalg.norm(kitti00["target_points"], axis=1).astype(np.float32)
+    cloud, vm, _ = _maps(gpu, kitti00["target_points"], kitti00["target_covs"], 0.5, intensities=intens)
+    ref = refcapi.RefVoxelMap(0.5)
+    ref.insert(kitti00["target_points"], kitti00["target_covs"])
+    src = kitti00["source_points"]
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    src_gpu = gpu.PointCloudGPU(src)
+
+    def compare(gpu_map, ref_map, tol):
+        coords, npts, means, covs = gpu_map.download_f64()
+        rc, rn, rmean, rcov, _ = ref_map.export()
+        assert len(coords) == len(rc) == vm.voxelmap_info.num_voxels
+        order = {tuple(c): i for i, c in enumerate(rc.tolist())}
+        idx = np.array([order[tuple(c)] for c in coords.tolist()])  # KeyError = a voxel the other side does not have
+        assert len(set(idx.tolist())) == len(rc)
+        np.testing.assert_array_equal(npts, rn[idx])
+        assert np.abs(means - rmean[idx]).max() < tol and np.abs(covs - rcov[idx]).max() < tol
+        for T in (np.eye(4), delta):
+            assert abs(gpu.overlap_gpu(gpu_map, src_gpu, T) - ref_map.overlap(src, T)) < 1e-3
+
+    compare(vm, ref, 1e-6)  # before any file: same statistics (f64 vs f64)
+    # GPU -> file -> reference CPU map
+    p1 = str(tmp_path / "from_gpu.bin")
+    vm.save_compact(p1)
+    ref_loaded = refcapi.RefVoxelMap.load(p1)
+    assert ref_loaded is not None and ref_loaded.num_voxels == vm.voxelmap_info.num_voxels and abs(ref_loaded.voxel_resolution() - 0.5) < 1e-12
+    compare(vm, ref_loaded, 1e-3)
+    _, _, _, _, ri = ref_loaded.export()
+    dl = vm.download()
+    coords = vm.download_f64()[0]
+    order = {tuple(c): i for i, c in enumerate(ref_loaded.export()[0].tolist())}
+    idx = np.array([order[tuple(c)] for c in coords.tolist()])
+    assert np.abs(dl["intensities"] - ri[idx]).max() < 1e-3  # the max-intensity field survives too
+    # reference CPU map -> file -> GPU
+    p2 = str(tmp_path / "from_ref.bin")
+    ref.save_compact(p2)
+    gpu_loaded = gpu.GaussianVoxelMapGPU.load(p2)
+    assert gpu_loaded.voxelmap_info.num_voxels == ref.num_voxels and abs(gpu_loaded.voxel_resolution() - 0.5) < 1e-12
+    compare(gpu_loaded, ref, 1e-3)
+    # and a VGICP factor on the map loaded from the reference's file agrees with the factor on the GPU-built map to the file's precision
+    import ctypes as C
+
+    srcc = gpu.PointCloudGPU(kitti00["source_points"], kitti00["source_covs"])
+    recs = []
+    for m in (vm, gpu_loaded):
+        f = gpu.IntegratedVGICPFactorGPU(0, 1, m, srcc)
+        rec = gpu._capi.Linearized6()
+        gpu._capi.check(f._lib.gp_vgicp_factor_linearize(f._h, gpu.types._pose16(delta), C.byref(rec)), "linearize")
+        recs.append(gpu.LinearizedSystem6(rec))
+    assert recs[0].num_inliers == recs[1].num_inliers
+    assert np.linalg.norm(recs[0].H_source - recs[1].H_source) / np.linalg.norm(recs[0].H_source) < 1e-3
+    del cloud
