@@ -17,6 +17,7 @@
 #include <limits>
 #include <sstream>
 
+#include "gp_binning.hpp"
 #include "gp_host.hpp"
 #include "gp_scan.hpp"
 
@@ -148,17 +149,7 @@ __global__ void __launch_bounds__(256) line_claim_kernel(int num_voxels, const i
 }
 
 
-// ---- occupancy-block grid (gp_device.hpp: GridBlock) ----------------------------------------------------------------
-struct GridGeom {
-  int lo[3];   // block coordinate of the low corner
-  int dim[3];  // blocks per axis
-};
-
-__host__ __device__ __forceinline__ long long grid_block_index(const GridGeom& g, int cx, int cy, int cz) {
-  const int bx = (cx >> 2) - g.lo[0], by = (cy >> 2) - g.lo[1], bz = (cz >> 2) - g.lo[2];
-  return ((long long)bz * g.dim[1] + by) * g.dim[0] + bx;
-}
-__host__ __device__ __forceinline__ int grid_bit(int cx, int cy, int cz) { return ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3); }
+// ---- occupancy-block grid (gp_device.hpp: GridBlock; geometry helpers in gp_binning.hpp) ----
 
 // bounding box of the voxel coordinates in block units: bbox[0..2] = min, bbox[3..5] = max (wave reduce + one atomic per wave)
 __global__ void __launch_bounds__(256) coords_bbox_kernel(int num_voxels, const int* __restrict__ voxel_coords, int* __restrict__ bbox) {
@@ -214,6 +205,101 @@ __global__ void __launch_bounds__(256) buckets_renumber_kernel(uint32_t num_buck
   if (b >= num_buckets) return;
   const int v = buckets[b].voxel_index;
   if (v >= 0) buckets[b].voxel_index = perm[v];
+}
+
+// ---- binned build (gp_binning.hpp): per-voxel statistics as an ORDERED segmented sum ----------------------------------------
+// One wave per voxel.  The voxel's points come in ascending index order (stable sort); every chunk of 64 is reduced with a fixed
+// butterfly and the chunk sums are added in order: the statistics are bit-identical from run to run (no atomics).
+// sums relative to the voxel centre in f64, like accumulate_kernel; outputs as finalize_kernel.
+__global__ void __launch_bounds__(256) segmented_stats_kernel(const float* __restrict__ points, const float* __restrict__ covs, const float* __restrict__ intensities,
+                                                              int num_voxels, const int* __restrict__ cell_start, const int* __restrict__ order, double inv_leaf, double leaf,
+                                                              VoxelRecord* __restrict__ records, int* __restrict__ num_points, float* __restrict__ voxel_means,
+                                                              float* __restrict__ voxel_covs, float* __restrict__ voxel_intensities, int* __restrict__ voxel_coords) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= num_voxels) return;
+  const int b = cell_start[v], e = cell_start[v + 1];
+  const size_t i0 = (size_t)order[b];
+  const int cx = fast_floor((double)points[3 * i0] * inv_leaf), cy = fast_floor((double)points[3 * i0 + 1] * inv_leaf), cz = fast_floor((double)points[3 * i0 + 2] * inv_leaf);
+  const double ox = ((double)cx + 0.5) * leaf, oy = ((double)cy + 0.5) * leaf, oz = ((double)cz + 0.5) * leaf;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float imax = 0.0f;  // max intensity (:138-139): intensities are non-negative upstream (atomicMax on the float bits), 0 when absent
+  for (int chunk = b; chunk < e; chunk += 64) {
+    const int j = chunk + lane;
+    double val[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float it = 0.0f;
+    if (j < e) {
+      const size_t i = (size_t)order[j];
+      const float* c = covs + 9 * i;
+      val[0] = (double)points[3 * i] - ox;
+      val[1] = (double)points[3 * i + 1] - oy;
+      val[2] = (double)points[3 * i + 2] - oz;
+      val[3] = (double)c[0];
+      val[4] = 0.5 * ((double)c[3] + (double)c[1]);  // symmetric part of the column-major 3x3 (the input itself when symmetric)
+      val[5] = 0.5 * ((double)c[6] + (double)c[2]);
+      val[6] = (double)c[4];
+      val[7] = 0.5 * ((double)c[7] + (double)c[5]);
+      val[8] = (double)c[8];
+      if (intensities) it = intensities[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      double x = val[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      acc[k] += x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) it = fmaxf(it, __shfl_xor(it, off, 64));
+    imax = fmaxf(imax, it);
+  }
+  if (lane != 0) return;
+  const int n = e - b;
+  const double inv_n = 1.0 / (double)n;
+  VoxelRecord rec;
+  const double lx = acc[0] * inv_n, ly = acc[1] * inv_n, lz = acc[2] * inv_n;
+  rec.mean_local[0] = (float)lx;
+  rec.mean_local[1] = (float)ly;
+  rec.mean_local[2] = (float)lz;
+  rec.num_points = n;
+  for (int k = 0; k < 6; k++) rec.cov[k] = acc[3 + k] / (double)n;
+  records[v] = rec;
+  num_points[v] = n;
+  voxel_means[3 * (size_t)v] = (float)(ox + lx);
+  voxel_means[3 * (size_t)v + 1] = (float)(oy + ly);
+  voxel_means[3 * (size_t)v + 2] = (float)(oz + lz);
+  float* c = voxel_covs + 9 * (size_t)v;
+  c[0] = (float)rec.cov[0];
+  c[1] = c[3] = (float)rec.cov[1];
+  c[2] = c[6] = (float)rec.cov[2];
+  c[4] = (float)rec.cov[3];
+  c[5] = c[7] = (float)rec.cov[4];
+  c[8] = (float)rec.cov[5];
+  voxel_intensities[v] = imax;
+  voxel_coords[3 * (size_t)v] = cx;
+  voxel_coords[3 * (size_t)v + 1] = cy;
+  voxel_coords[3 * (size_t)v + 2] = cz;
+}
+
+// reference-visible bucket table from the list of DISTINCT voxels: claim the first free bucket of the probe chain
+// (reference hash + max_bucket_scan_count rule, so lookup_voxel finds it); failed[0] += points of a voxel whose chain is full
+__global__ void __launch_bounds__(256) insert_voxels_kernel(int num_voxels, const int* __restrict__ voxel_coords, const int* __restrict__ num_points,
+                                                            gp_voxel_bucket* __restrict__ buckets, uint32_t num_buckets, uint32_t mask, int max_scan,
+                                                            int* __restrict__ failed) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_voxels) return;
+  const int cx = voxel_coords[3 * (size_t)v], cy = voxel_coords[3 * (size_t)v + 1], cz = voxel_coords[3 * (size_t)v + 2];
+  const uint64_t hash = coord_hash(cx, cy, cz);
+  for (int j = 0; j < max_scan; j++) {
+    gp_voxel_bucket* b = buckets + bucket_index(hash, j, num_buckets, mask);
+    if (atomicCAS(&b->voxel_index, -1, v) == -1) {
+      b->coord[0] = cx;
+      b->coord[1] = cy;
+      b->coord[2] = cz;
+      return;
+    }
+  }
+  atomicAdd(failed, num_points[v]);
 }
 
 // lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
@@ -304,7 +390,7 @@ static int build_private_table(gp_voxelmap* m, hipStream_t s) {
 }
 
 
-constexpr long long kMaxGridBlocks = 1ll << 24;  // 16 B each: at most 256 MB per map; a larger box keeps the line table only
+using gp::kMaxGridBlocks;  // gp_binning.hpp: at most 2^24 blocks (256 MB) per map; a larger box keeps the hashed tables only
 
 // geometry of the block grid from the block-unit bounding box; false when the box exceeds the budget
 static bool grid_geometry(const int bbox[6], gp::GridGeom* g, long long* num_blocks) {
@@ -400,6 +486,8 @@ static bool build_grid_host(int V, const int* coords, gp::GridGeom* g, std::vect
   return true;
 }
 
+static bool g_force_hashed_build = false;  // gp_debug_set_map_build: A/B and tests of the fallback path
+
 static inline gp_voxelmap* ext(gp_voxelmap* m) { return m; }
 static inline const gp_voxelmap* ext(const gp_voxelmap* m) { return m; }
 
@@ -428,6 +516,52 @@ int gp_voxelmap_destroy(gp_voxelmap_t* map) {
   return GP_OK;
 }
 
+// the binned build (default): gp_binning.hpp gives the occupancy-block grid, the voxel numbering (block order) and the points
+// sorted by voxel (stable); the statistics are an ordered segmented sum, the reference-visible bucket table is filled from the
+// list of distinct voxels.  Deterministic: two builds of the same cloud give bit-identical maps.
+static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* points_dev, const float* covs_dev, const float* intensities_dev, hipStream_t s) {
+  const int V = bins.num_cells;
+  m->info.num_voxels = V;
+  GP_TRY(alloc_voxel_arrays(m, V));
+  GP_TRY(m->voxel_coords.alloc(sizeof(int) * 3 * (size_t)std::max(V, 1)));
+  hipLaunchKernelGGL(gp::segmented_stats_kernel, dim3((V + 3) / 4), dim3(256), 0, s, points_dev, covs_dev, intensities_dev, V, (const int*)bins.cell_start.as<int>(),
+                     (const int*)bins.order.as<int>(), 1.0 / m->resolution, m->resolution, m->records.as<gp::VoxelRecord>(), m->num_points.as<int>(), m->voxel_means.as<float>(),
+                     m->voxel_covs.as<float>(), m->voxel_intensities.as<float>(), m->voxel_coords.as<int>());
+  GP_HIP(hipGetLastError());
+  // occupancy-block grid: taken over from the bins
+  m->gblocks.swap(bins.blocks);
+  for (int a = 0; a < 3; a++) {
+    m->glo[a] = bins.geom.lo[a];
+    m->gdim[a] = bins.geom.dim[a];
+  }
+  m->has_grid = true;
+  // reference-visible bucket table (create_bucket_table, :253-307): the reference doubles the table until the fraction of points
+  // whose probe chain is exhausted is <= target_points_drop_rate and then drops those points; here the table is doubled along the
+  // same sequence until every voxel is placed, so no point is ever dropped (the CPU map, the parity target, drops none either)
+  gp::DeviceArray failed;
+  GP_TRY(failed.alloc_async(sizeof(int) * 4, s));
+  int64_t num_buckets = m->init_num_buckets;
+  while (num_buckets < (int64_t)V + V / 2) num_buckets *= 2;  // the sequence is entered where the voxels fit at a load factor <= 2/3
+  for (;; num_buckets *= 2) {
+    if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
+    GP_TRY(m->buckets.ensure(sizeof(gp_voxel_bucket) * (size_t)num_buckets));
+    GP_HIP(hipMemsetAsync(m->buckets.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
+    GP_HIP(hipMemsetAsync(failed.ptr, 0, sizeof(int), s));
+    const uint32_t mask = ((num_buckets & (num_buckets - 1)) == 0) ? (uint32_t)(num_buckets - 1) : 0u;
+    hipLaunchKernelGGL(gp::insert_voxels_kernel, dim3(grid_for((size_t)V)), dim3(kBlock), 0, s, V, (const int*)m->voxel_coords.as<int>(), (const int*)m->num_points.as<int>(),
+                       m->buckets.as<gp_voxel_bucket>(), (uint32_t)num_buckets, mask, m->info.max_bucket_scan_count, failed.as<int>());
+    GP_HIP(hipGetLastError());
+    int h_failed = 0;
+    GP_HIP(hipMemcpyAsync(&h_failed, failed.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    if (h_failed == 0) break;
+  }
+  m->info.num_buckets = (int)num_buckets;
+  GP_TRY(build_private_table(m, s));
+  GP_HIP(hipStreamSynchronize(s));  // :250
+  return GP_OK;
+}
+
 int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float* covs_dev, const float* intensities_dev, int n) {
   if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: null map");
   if (!points_dev || !covs_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "error: GPU points/covs not allocated!!");  // gaussian_voxelmap_gpu.cu:212-215
@@ -437,6 +571,14 @@ int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float*
   const double inv_leaf = 1.0 / m->resolution;
   m->offloaded = false;
   m->generation++;
+  if (n > 0 && !g_force_hashed_build) {
+    gp::PointBins bins;
+    bool too_large = false;
+    GP_TRY(gp::bin_points(points_dev, n, inv_leaf, s, &bins, &too_large));
+    if (!too_large && bins.num_cells > 0) return insert_binned(m, bins, points_dev, covs_dev, intensities_dev, s);
+  }
+  // ---- hashed build: an empty cloud, or a cloud whose bounding box is too large for the block grid.  The reference's own
+  // scheme: claim buckets with atomicCAS, allocate voxel ids, accumulate with atomics (not bit-reproducible) ----
 
   // ---- create_bucket_table (:253-307): double the table until the drop rate is met ----
   gp::DeviceArray rep, counters;
@@ -824,6 +966,10 @@ size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
 
 int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map) { return map && map->loaded() ? 1 : 0; }
 int gp_voxelmap_has_block_grid(const gp_voxelmap_t* map) { return map && map->has_grid ? 1 : 0; }
+int gp_debug_set_map_build(int hashed) {
+  g_force_hashed_build = hashed != 0;
+  return GP_OK;
+}
 
 static int to_host(std::vector<char>& dst, const gp::DeviceArray& src, size_t bytes, hipStream_t s) {
   dst.resize(bytes);

@@ -355,6 +355,9 @@ int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev)
  * M = (C_B + R C_A R^T)^-1, the transform and the residual are f64 in every variant; "f32 outer products" computes what follows
  * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md section 8 */
 int gp_debug_set_variant(int variant);
+/* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
+ * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
+int gp_debug_set_map_build(int hashed);
 /* tuning knob: the odd wave slots of every SIMD start `units` x 512 clocks late (0 = off, default) */
 int gp_debug_set_stagger(int units);
 /* timeline hook: per-workgroup phase timestamps (s_memtime) of the default pipeline kernel into dev_buffer ([num_tiles][16] uint64:

@@ -228,3 +228,60 @@ def test_file_interop_with_the_reference_cpu_map(gpu, kitti00, tmp_path):
     assert recs[0].num_inliers == recs[1].num_inliers
     assert np.linalg.norm(recs[0].H_source - recs[1].H_source) / np.linalg.norm(recs[0].H_source) < 1e-3
     del cloud
+
+
+def test_binned_build_is_bit_reproducible_and_matches_the_hashed_build(gpu, kitti00):
+    """the default (binned) build sorts the points by voxel with a stable radix sort and sums every voxel in ascending point order:
+    two builds of the same cloud are bit-identical (records, reference-visible arrays, voxel numbering).  The reference-shaped
+    hashed build (atomicCAS claims + atomic f64 sums; also the fallback for huge bounding boxes) gives the same voxel set and the
+    same statistics up to the summation order."""
+    lib = gpu.load()
+    intens = np.abs(kitti00["target_points"][:, 0]).astype(np.float32)
+    cloud = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"], intensities=intens)
+
+    def build():
+        vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+        vm.insert(cloud)
+        return vm
+
+    a, b = build(), build()
+    ca, na, ma, va = a.download_f64()
+    cb, nb, mb, vb = b.download_f64()
+    assert np.array_equal(ca, cb) and np.array_equal(na, nb) and np.array_equal(ma, mb) and np.array_equal(va, vb)
+    da, db = a.download(), b.download()
+    for k in ["num_points", "means", "covs", "intensities"]:
+        assert np.array_equal(da[k], db[k]), k
+    assert lib.gp_voxelmap_has_block_grid(a._h) == 1
+    try:
+        gpu._capi.check(lib.gp_debug_set_map_build(1), "map build")
+        h = build()
+    finally:
+        lib.gp_debug_set_map_build(0)
+    ch, nh, mh, vh = h.download_f64()
+    assert len(ch) == len(ca)
+    order = {tuple(c): i for i, c in enumerate(ch.tolist())}
+    idx = np.array([order[tuple(c)] for c in ca.tolist()])
+    assert np.array_equal(na, nh[idx]) and np.abs(ma - mh[idx]).max() < 1e-7 and np.abs(va - vh[idx]).max() < 1e-13
+    assert np.array_equal(da["intensities"], h.download()["intensities"][idx])
+
+
+def test_non_finite_points_are_skipped(gpu, kitti00):
+    """LiDAR clouds contain NaN / inf returns: they belong to no voxel (the reference floors them into undefined coordinates)"""
+    p = kitti00["target_points"].copy()
+    c = kitti00["target_covs"]
+    bad = [5, 100, 4096, len(p) - 1]
+    p[bad[0]] = np.nan
+    p[bad[1], 1] = np.inf
+    p[bad[2], 2] = -np.inf
+    p[bad[3], 0] = np.nan
+    keep = np.ones(len(p), bool)
+    keep[bad] = False
+    _, vm, _ = _maps(gpu, p, c, 0.5)
+    _, _, om = _maps(gpu, p[keep], c[keep], 0.5)
+    assert vm.voxelmap_info.num_voxels == om.num_voxels
+    coords, num_points, means, covs = vm.download_f64()
+    oc, on, omean, ocov, _ = om.export()
+    order = {tuple(x): i for i, x in enumerate(oc.tolist())}
+    idx = np.array([order[tuple(x)] for x in coords.tolist()])
+    np.testing.assert_array_equal(num_points, on[idx])
+    assert np.abs(covs - ocov[idx]).max() < 1e-13 and num_points.sum() == keep.sum()
