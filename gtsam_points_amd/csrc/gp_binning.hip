@@ -76,52 +76,50 @@ __global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __rest
   if (threadIdx.x < 6) bbox[threadIdx.x] = part[0][threadIdx.x];
 }
 
-// occupancy bits.  Most points fall into a cell whose bit is already set: a plain load filters them out before the atomic
-// (a stale read only costs a redundant atomicOr)
-__global__ void __launch_bounds__(256) bins_mark_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, GridBlock* __restrict__ blocks) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)n) return;
-  int cx, cy, cz;
-  if (!point_cell(points, i, inv_cell, cx, cy, cz)) return;
-  unsigned long long* w = &blocks[grid_block_index(g, cx, cy, cz)].bits;
-  const unsigned long long bit = 1ull << grid_bit(cx, cy, cz);
-  if (!(*reinterpret_cast<volatile unsigned long long*>(w) & bit)) atomicOr(w, bit);
-}
-
-__global__ void __launch_bounds__(256) bins_count_kernel(long long num_blocks, GridBlock* __restrict__ blocks) {
-  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (b < num_blocks) blocks[b].base = __popcll(blocks[b].bits);
-}
-
-__global__ void __launch_bounds__(256) bins_ordinal_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, const GridBlock* __restrict__ blocks,
-                                                           unsigned* __restrict__ keys) {
+// sort key of a point: (block index, bit inside the block) -- the order the cells are numbered in.  < 2^24 * 64 = 2^30
+__global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)n) return;
   int cx, cy, cz;
   unsigned key = kInvalidKey;
-  if (point_cell(points, i, inv_cell, cx, cy, cz)) {
-    const GridBlock blk = blocks[grid_block_index(g, cx, cy, cz)];
-    key = (unsigned)(blk.base + __popcll(blk.bits & ((1ull << grid_bit(cx, cy, cz)) - 1ull)));
-  }
+  if (point_cell(points, i, inv_cell, cx, cy, cz)) key = (unsigned)(grid_block_index(g, cx, cy, cz) * 64 + grid_bit(cx, cy, cz));
   keys[i] = key;
 }
 
-// sorted keys -> first position of every cell; every cell holds at least one point, so every entry is written exactly once
-__global__ void __launch_bounds__(256) bins_starts_kernel(const unsigned* __restrict__ sorted_keys, int n, int num_cells, int* __restrict__ cell_start,
-                                                          int* __restrict__ num_binned) {
+// sorted keys -> 1 at the first point of every cell (0 elsewhere and on the skipped points behind the cells)
+__global__ void __launch_bounds__(256) bins_flag_kernel(const unsigned* __restrict__ sorted_keys, int n, int* __restrict__ flags) {
   const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= (size_t)n) return;
   const unsigned k = sorted_keys[j];
-  const unsigned prev = j > 0 ? sorted_keys[j - 1] : 0xffffffffu;
-  if (k != prev) {
-    if (k == kInvalidKey) {
+  flags[j] = (k != kInvalidKey && (j == 0 || sorted_keys[j - 1] != k)) ? 1 : 0;
+}
+
+// ordinal of every sorted point's cell (exclusive scan of the flags, + its own flag, - 1); at the first point of a cell: the cell's
+// start, its occupancy bit, and -- at the first cell of a block -- the block's base.  total[0] = number of cells.
+__global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __restrict__ sorted_keys, const int* __restrict__ flags, const int* __restrict__ scanned, int n,
+                                                          const int* __restrict__ total, GridBlock* __restrict__ blocks, int* __restrict__ cell_start,
+                                                          unsigned* __restrict__ cell_of, int* __restrict__ num_binned) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= (size_t)n) return;
+  const unsigned k = sorted_keys[j];
+  const int num_cells = *total;
+  if (k == kInvalidKey) {
+    cell_of[j] = kInvalidKey;
+    if (j == 0 || sorted_keys[j - 1] != kInvalidKey) {
       cell_start[num_cells] = (int)j;
       *num_binned = (int)j;
-    } else {
-      cell_start[k] = (int)j;
     }
+    return;
   }
-  if (j == (size_t)n - 1 && k != kInvalidKey) {
+  const int ord = scanned[j] + flags[j] - 1;
+  cell_of[j] = (unsigned)ord;
+  if (flags[j]) {
+    cell_start[ord] = (int)j;
+    GridBlock* blk = blocks + (k >> 6);
+    atomicOr(&blk->bits, 1ull << (k & 63u));  // one atomic per CELL (not per point); the bits of a block come from <= 64 cells
+    if (j == 0 || (sorted_keys[j - 1] >> 6) != (k >> 6)) blk->base = ord;
+  }
+  if (j == (size_t)n - 1) {
     cell_start[num_cells] = n;
     *num_binned = n;
   }
@@ -135,7 +133,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   bins->num_binned = 0;
   bins->num_blocks = 0;
   if (n <= 0) {
-    GP_TRY(bins->cell_start.alloc(sizeof(int)));
+    GP_TRY(bins->cell_start.alloc_pooled(sizeof(int), s));
     GP_HIP(hipMemsetAsync(bins->cell_start.ptr, 0, sizeof(int), s));
     return GP_OK;
   }
@@ -151,7 +149,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_HIP(hipMemcpyAsync(h_bbox, d_small.ptr, sizeof(h_bbox), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));
   if (h_bbox[0] > h_bbox[3]) {  // no finite point at all
-    GP_TRY(bins->cell_start.alloc(sizeof(int)));
+    GP_TRY(bins->cell_start.alloc_pooled(sizeof(int), s));
     GP_HIP(hipMemsetAsync(bins->cell_start.ptr, 0, sizeof(int), s));
     return GP_OK;
   }
@@ -167,47 +165,45 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
     return GP_OK;
   }
   bins->num_blocks = (long long)bins->geom.dim[0] * bins->geom.dim[1] * bins->geom.dim[2];
-  // ---- occupancy bits, bases ----
-  GP_TRY(bins->blocks.alloc(sizeof(GridBlock) * (size_t)bins->num_blocks));
+  // ---- keys = (block, bit), stable sort, cells = runs of equal keys ----
+  DeviceArray keys_b, vals_b, sort_scratch, flags, scanned, scan_scratch;
+  GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_HIP(hipMemsetAsync(bins->blocks.ptr, 0, sizeof(GridBlock) * (size_t)bins->num_blocks, s));
-  GridBlock* blocks = bins->blocks.as<GridBlock>();
-  hipLaunchKernelGGL(bins_mark_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, blocks);
-  hipLaunchKernelGGL(bins_count_kernel, dim3((unsigned)((bins->num_blocks + 255) / 256)), dim3(256), 0, s, bins->num_blocks, blocks);
-  GP_HIP(hipGetLastError());
-  DeviceArray scan_scratch;
-  GP_TRY(scan_scratch.alloc_async(sizeof(int) * (size_t)(bins->num_blocks / kScanThreads + 8), s));
-  int* base0 = &blocks[0].base;
-  GP_TRY(exclusive_scan_strided(base0, 4, base0, 4, bins->num_blocks, scan_scratch.as<int>(), s));
-  // total = the scan's grand total (kept behind the block sums, exclusive_scan_strided: scratch[nb])
-  const int scan_blocks = (int)((bins->num_blocks + kScanThreads - 1) / kScanThreads);
-  int h_cells = 0;
-  GP_HIP(hipMemcpyAsync(&h_cells, scan_scratch.as<int>() + scan_blocks, sizeof(int), hipMemcpyDeviceToHost, s));
-  // ---- ordinals + stable sort ----
-  DeviceArray keys_b, vals_b, sort_scratch;
-  GP_TRY(bins->cell_of.alloc(sizeof(unsigned) * (size_t)n));
-  GP_TRY(bins->order.alloc(sizeof(int) * (size_t)n));
-  GP_TRY(keys_b.alloc_async(sizeof(unsigned) * (size_t)n, s));
-  GP_TRY(vals_b.alloc_async(sizeof(int) * (size_t)n, s));
+  GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
+  GP_TRY(bins->order.alloc_pooled(sizeof(int) * (size_t)n, s));
+  GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
+  GP_TRY(vals_b.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(sort_scratch.alloc_async(sizeof(int) * radix_sort_scratch_ints(n), s));
-  hipLaunchKernelGGL(bins_ordinal_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, (const GridBlock*)blocks, bins->cell_of.as<unsigned>());
+  GP_TRY(flags.alloc_async(sizeof(int) * (size_t)n, s));
+  GP_TRY(scanned.alloc_async(sizeof(int) * (size_t)n, s));
+  GP_TRY(scan_scratch.alloc_async(sizeof(int) * ((size_t)n / kScanThreads + 8), s));
+  hipLaunchKernelGGL(bins_key_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>());
   GP_HIP(hipGetLastError());
-  GP_HIP(hipStreamSynchronize(s));  // the cell count decides the number of radix passes
-  bins->num_cells = h_cells;
-  // sort over the bits of num_cells: the invalid key (0x7fffffff) of skipped points must sort last, so they are re-keyed to
-  // num_cells by sorting over enough bits to hold it... simpler: 31 bits are only needed when points were skipped; the common
-  // case sorts ceil(log2(num_cells + 1)) bits and treats a key >= num_cells as "skipped" afterwards
-  int bits = 1;
-  while ((1ll << bits) <= (long long)h_cells) bits++;
+  int bits = 6;
+  while ((1ll << bits) < bins->num_blocks * 64) bits++;
+  // skipped points carry kInvalidKey = 0x7fffffff: every pass sees all-ones digits, so they land behind every cell
   bool in_b = false;
-  // skipped points carry kInvalidKey whose low `bits` bits are all ones = 2^bits - 1 >= num_cells: they land behind every cell
-  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, bits, true, sort_scratch.as<int>(), s, &in_b));
+  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, std::min(bits + 1, 31), true,
+                          sort_scratch.as<int>(), s, &in_b));
   if (in_b) {
-    GP_HIP(hipMemcpyAsync(bins->cell_of.ptr, keys_b.ptr, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    GP_HIP(hipMemcpyAsync(bins->order.ptr, vals_b.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    bins->cell_of.swap(keys_b);
+    bins->order.swap(vals_b);
   }
-  GP_TRY(bins->cell_start.alloc(sizeof(int) * ((size_t)h_cells + 1)));
-  hipLaunchKernelGGL(bins_starts_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, h_cells, bins->cell_start.as<int>(), d_small.as<int>() + 8);
+  // keys_b is free now: it receives the sorted keys' cell ordinals while cell_of still holds the sorted keys
+  hipLaunchKernelGGL(bins_flag_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, flags.as<int>());
   GP_HIP(hipGetLastError());
+  GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, n, scan_scratch.as<int>(), s));
+  const int scan_blocks = (int)(((long long)n + kScanThreads - 1) / kScanThreads);
+  const int* d_total = scan_scratch.as<int>() + scan_blocks;  // the scan's grand total = number of cells
+  int h_cells = 0;
+  GP_HIP(hipMemcpyAsync(&h_cells, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));  // the cell count sizes cell_start
+  bins->num_cells = h_cells;
+  GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)h_cells + 1), s));
+  hipLaunchKernelGGL(bins_finish_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), (const int*)flags.as<int>(),
+                     (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), d_small.as<int>() + 8);
+  GP_HIP(hipGetLastError());
+  bins->cell_of.swap(keys_b);  // cell_of = ordinals of the sorted points
   int h_binned = 0;
   GP_HIP(hipMemcpyAsync(&h_binned, d_small.as<int>() + 8, sizeof(int), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));

@@ -72,6 +72,15 @@ struct DeviceArray {
     pool_stream = stream;
     return GP_OK;
   }
+  // library-owned arrays that outlive the call (voxel maps, bins): pooled like the reference's cudaMallocAsync'ed members, but
+  // returned to the pool on the NULL stream -- the creating stream is the caller's and may be gone by then; owners synchronise
+  // the device before they let go of such arrays (gp_voxelmap_destroy)
+  int alloc_pooled(size_t n, hipStream_t stream) {
+    const int rc = alloc_async(n, stream);
+    pool_stream = nullptr;
+    return rc;
+  }
+  int ensure_pooled(size_t n, hipStream_t stream) { return (n <= bytes && ptr) ? GP_OK : alloc_pooled(n + n / 5, stream); }
   void release() {
     if (ptr) {
       if (pooled) {

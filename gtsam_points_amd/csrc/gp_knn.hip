@@ -17,6 +17,7 @@
 #include <cstring>
 #include <vector>
 
+#include "gp_binning.hpp"
 #include "gp_host.hpp"
 #include "gp_vgicp_tile.hpp"
 
@@ -278,14 +279,146 @@ __device__ __forceinline__ void knn_query(const GridView& g, double qx, double q
   }
 }
 
+// ---- search over the binned structure (gp_binning.hpp): occupancy-block grid over the cells + cell-sorted points -------------------
+// A query walks the cube shells around its cell like knn_query above, but reads ONE 16-B block entry per 4 x 4 x 4 cells instead of
+// probing a hash table per cell, visits only occupied cells (bit scan), and filters candidates with an f32 distance before the f64
+// distance that decides (the reference compares doubles): the shell loop of a typical query touches <= 8 block entries.
+struct BinGridView {
+  const GridBlock* blocks;
+  const int* cell_start;  // [num_cells + 1]
+  const float4* sorted;   // [n] (x, y, z, original index as int bits), cell-major, ascending index inside a cell
+  GridGeom geom;
+  double inv_h, h;
+  int n;  // binned (finite) points
+};
+
+// 4-bit mask of the cells x = 4 * b + {0, 1, 2, 3} inside [c - r, c + r]
+__device__ __forceinline__ unsigned axis_mask(int b, int c, int r) {
+  int lo = c - r - 4 * b, hi = c + r - 4 * b;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > 3 ? 3 : hi;
+  return lo > hi ? 0u : (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+}
+// 64-bit cell mask of a block from its per-axis 4-bit masks (bit = z * 16 + y * 4 + x)
+__device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my, unsigned mz) {
+  const unsigned long long X = (unsigned long long)mx * 0x1111111111111111ull;
+  const unsigned long long Y = (unsigned long long)(((my * 0x249u) & 0x1111u) * 0xFu) * 0x0001000100010001ull;
+  const unsigned long long z1 = (unsigned long long)mz;
+  const unsigned long long Z = ((z1 | (z1 << 15) | (z1 << 30) | (z1 << 45)) & 0x0001000100010001ull) * 0xFFFFull;
+  return X & Y & Z;
+}
+
 template <int KMAX>
-__global__ void __launch_bounds__(128) knn_kernel(MultiGridView g, const float* __restrict__ queries, int nq, int k, double max_sq_dist, int* __restrict__ indices,
+__device__ __forceinline__ void knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
+  const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
+  if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return;  // non-finite query: no neighbours
+  const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
+  const double fx = ux - (double)c[0], fy = uy - (double)c[1], fz = uz - (double)c[2];
+  const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * g.h;
+  int lo[3], hi[3], r0 = 0, rmax = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = g.geom.lo[a] * 4;
+    hi[a] = (g.geom.lo[a] + g.geom.dim[a]) * 4 - 1;
+    r0 = max(r0, max(lo[a] - c[a], c[a] - hi[a]));              // first shell that reaches the box
+    rmax = max(rmax, max(abs(c[a] - lo[a]), abs(c[a] - hi[a])));  // shell that covers it
+  }
+  const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+  // |f32 difference - exact difference| <= margin per axis (rounding of q to float + the subtraction), generously
+  const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;
+  auto loosened = [&](double worst) {
+    const float w = (float)worst;  // +inf while fewer than k neighbours are held and no distance bound was given
+    return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
+  };
+  float accept = loosened(top.worst());
+  for (int r = r0; r <= rmax; r++) {
+    int b0[3], b1[3];
+    bool any = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int x0 = max(c[a] - r, lo[a]), x1 = min(c[a] + r, hi[a]);
+      any = any && x0 <= x1;
+      b0[a] = x0 >> 2;
+      b1[a] = x1 >> 2;
+    }
+    if (any) {
+      for (int bz = b0[2]; bz <= b1[2]; bz++) {
+        const unsigned mz = axis_mask(bz, c[2], r), mz1 = r > 0 ? axis_mask(bz, c[2], r - 1) : 0u;
+        for (int by = b0[1]; by <= b1[1]; by++) {
+          const unsigned my = axis_mask(by, c[1], r), my1 = r > 0 ? axis_mask(by, c[1], r - 1) : 0u;
+          for (int bx = b0[0]; bx <= b1[0]; bx++) {
+            const unsigned mx = axis_mask(bx, c[0], r), mx1 = r > 0 ? axis_mask(bx, c[0], r - 1) : 0u;
+            if (mx1 == 0xFu && my1 == 0xFu && mz1 == 0xFu) continue;  // the whole block lies inside the previous cube
+            const size_t bi = ((size_t)(bz - g.geom.lo[2]) * (size_t)g.geom.dim[1] + (size_t)(by - g.geom.lo[1])) * (size_t)g.geom.dim[0] + (size_t)(bx - g.geom.lo[0]);
+            const int4 raw = *reinterpret_cast<const int4*>(g.blocks + bi);
+            const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
+            unsigned long long m = bits & cube_mask(mx, my, mz) & ~cube_mask(mx1, my1, mz1);  // occupied cells of this shell
+            while (m) {
+              const int bit = __ffsll((long long)m) - 1;
+              m &= m - 1ull;
+              const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
+              const int pb = g.cell_start[ord], pe = g.cell_start[ord + 1];
+              for (int p = pb; p < pe; p++) {
+                const float4 v = g.sorted[p];
+                const float dxf = v.x - qxf, dyf = v.y - qyf, dzf = v.z - qzf;
+                if (dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
+                  const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
+                  top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
+                  accept = loosened(top.worst());
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    const double safe = (double)r * g.h + face;
+    if (top.worst() <= safe * safe) return;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
+    if (top.found >= g.n) return;            // the whole cloud has been seen (clouds smaller than k)
+  }
+}
+
+// what a search runs on: the binned structure, or -- for clouds whose bounding box is too large for it -- the hashed multi-level grid
+struct SearchView {
+  int binned;
+  BinGridView bins;
+  MultiGridView hashed;
+};
+
+template <int KMAX>
+__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX>& top) {
+  if (g.binned) {
+    knn_query_bins<KMAX>(g.bins, qx, qy, qz, top);
+  } else {
+    knn_query_multi<KMAX>(g.hashed, qx, qy, qz, want, top);
+  }
+}
+
+// non-finite points have no neighbours: identity covariance, counted as "short" (covariance_estimation.cpp:27-31)
+__global__ void __launch_bounds__(256) nonfinite_identity_kernel(const float* __restrict__ points, int n, float* __restrict__ covs, int* __restrict__ num_short) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = points[3 * (size_t)i], y = points[3 * (size_t)i + 1], z = points[3 * (size_t)i + 2];
+  if (fabsf(x) < 3.0e38f && fabsf(y) < 3.0e38f && fabsf(z) < 3.0e38f) return;
+  for (int j = 0; j < 9; j++) covs[9 * (size_t)i + j] = (j % 4 == 0) ? 1.0f : 0.0f;
+  atomicAdd(num_short, 1);
+}
+
+__global__ void __launch_bounds__(256) gather_sorted_kernel(const float* __restrict__ points, const int* __restrict__ order, int n, float4* __restrict__ sorted) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const size_t i = (size_t)order[j];
+  sorted[j] = make_float4(points[3 * i], points[3 * i + 1], points[3 * i + 2], __int_as_float((int)i));
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(128) knn_kernel(SearchView g, const float* __restrict__ queries, int nq, int k, double max_sq_dist, int* __restrict__ indices,
                                                   double* __restrict__ sq_dists, int* __restrict__ num_found) {
   const int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= nq) return;
   TopK<KMAX> top;
   top.init(k, max_sq_dist);
-  knn_query_multi<KMAX>(g, (double)queries[3 * (size_t)i], (double)queries[3 * (size_t)i + 1], (double)queries[3 * (size_t)i + 2], 2 * k, top);
+  knn_query_any<KMAX>(g, (double)queries[3 * (size_t)i], (double)queries[3 * (size_t)i + 1], (double)queries[3 * (size_t)i + 2], 2 * k, top);
 #pragma unroll
   for (int j = 0; j < KMAX; j++)
     if (j < k) {
@@ -408,18 +541,18 @@ __device__ __forceinline__ void inverse3_general(const double* a /*col-major*/, 
 // estimate_covariances (features/covariance_estimation.cpp:18-77): k-NN (query included) -> sample covariance ->
 // V diag(1e-3, 1, 1) V^-1.  Fewer than k neighbours -> identity (:27-31).
 template <int KMAX>
-__global__ void __launch_bounds__(128) covariance_kernel(MultiGridView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
+__global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
                                                          int* __restrict__ num_short) {
   const int t = blockIdx.x * 128 + threadIdx.x;
   if (t >= n) return;
   // queries are taken in the finest grid's cell-sorted order: the lanes of a wave then sit in the same or adjacent cells,
   // walk the same shells and read the same cell ranges (coherent loads, little divergence); results go to the original index
-  const float4 self = g.lv[0].sorted[t];
+  const float4 self = g.binned ? g.bins.sorted[t] : g.hashed.lv[0].sorted[t];
   const int i = __float_as_int(self.w);
   const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
   TopK<KMAX> top;
   top.init(k, 1.7976931348623157e308);
-  knn_query_multi<KMAX>(g, qx, qy, qz, 2 * k, top);
+  knn_query_any<KMAX>(g, qx, qy, qz, 2 * k, top);
   float* out = covs + 9 * (size_t)i;
   if (top.found < k) {
     atomicAdd(num_short, 1);
@@ -457,7 +590,7 @@ struct GicpDesc {
   const float* covs;
   const float* target_points;
   const float* target_covs;
-  MultiGridView grid;
+  SearchView grid;
   int n;
   double max_sq_dist;
 };
@@ -483,7 +616,7 @@ __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double
     // correspondence: nearest target point with sq_dist < max (integrated_gicp_factor_impl.hpp:166-170)
     TopK<1> top;
     top.init(1, f.max_sq_dist);
-    knn_query_multi<1>(f.grid, lx, ly, lz, 1, top);
+    knn_query_any<1>(f.grid, lx, ly, lz, 1, top);
     if (top.found == 0) continue;
     const size_t j = (size_t)top.idx[0];
     const float* cp = f.covs + 9 * (size_t)i;
@@ -557,15 +690,34 @@ struct gp_grid_level {
 };
 
 struct gp_point_grid {
+  // default: the binned structure (gp_binning.hpp) + the cell-sorted copy of the points
+  bool binned = false;
+  gp::PointBins bins;
+  gp::DeviceArray sorted;  // float4[num_binned]
+  double h = 0.0;
+  // fallback for clouds whose bounding box is too large for the block grid: hashed multi-level grid
   std::vector<std::unique_ptr<gp_grid_level>> levels;
   hipStream_t stream = nullptr;
-  gp::MultiGridView view() const {
-    gp::MultiGridView v{};
-    v.num_levels = (int)levels.size();
-    for (int l = 0; l < v.num_levels; l++) v.lv[l] = levels[l]->view();
+  gp::SearchView view() const {
+    gp::SearchView v{};
+    v.binned = binned ? 1 : 0;
+    if (binned) {
+      v.bins.blocks = bins.blocks.as<gp::GridBlock>();
+      v.bins.cell_start = bins.cell_start.as<int>();
+      v.bins.sorted = sorted.as<float4>();
+      v.bins.geom = bins.geom;
+      v.bins.inv_h = 1.0 / h;
+      v.bins.h = h;
+      v.bins.n = bins.num_binned;
+    } else {
+      v.hashed.num_levels = (int)levels.size();
+      for (int l = 0; l < v.hashed.num_levels; l++) v.hashed.lv[l] = levels[l]->view();
+    }
     return v;
   }
 };
+
+static bool g_force_hashed_grid = false;  // gp_debug_set_knn_structure: A/B and tests of the fallback
 
 struct gp_gicp_factor {
   gp_point_grid* grid = nullptr;
@@ -656,6 +808,31 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
+  if (n > 0 && !g_force_hashed_grid) {
+    bool too_large = false;
+    int rc = gp::bin_points(points_dev, n, 1.0 / cell_size, g->stream, &g->bins, &too_large);
+    if (rc == GP_OK && !too_large && g->bins.num_cells > 0) {
+      rc = g->sorted.alloc_pooled(sizeof(float4) * (size_t)std::max(g->bins.num_binned, 1), g->stream);
+      if (rc == GP_OK) {
+        hipLaunchKernelGGL(gp::gather_sorted_kernel, dim3((g->bins.num_binned + 255) / 256), dim3(256), 0, g->stream, points_dev, (const int*)g->bins.order.as<int>(),
+                           g->bins.num_binned, g->sorted.as<float4>());
+        const hipError_t e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
+      }
+      if (rc == GP_OK) {
+        g->binned = true;
+        g->h = cell_size;
+        g->bins.order.release();    // only the sorted copy is searched
+        g->bins.cell_of.release();
+        *out = g;
+        return GP_OK;
+      }
+    }
+    if (rc != GP_OK) {
+      delete g;
+      return rc;
+    }
+  }
   const int num_levels = n > 4096 ? gp::kMaxLevels : 1;
   gp::DeviceArray scratch;
   {
@@ -703,6 +880,11 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   return GP_OK;
 }
 
+int gp_debug_set_knn_structure(int hashed) {
+  g_force_hashed_grid = hashed != 0;
+  return GP_OK;
+}
+
 int gp_point_grid_destroy(gp_point_grid_t* g) {
   if (!g) return GP_OK;
   // the arenas come from the stream-ordered pool and are returned to it in the order of the creation stream: searches issued
@@ -717,7 +899,7 @@ int gp_knn_search(const gp_point_grid_t* g, const float* queries_dev, int nq, in
   if (!g || !queries_dev || nq < 0 || k <= 0 || k > 32 || !indices_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_knn_search: bad arguments (1 <= k <= 32)");
   if (nq == 0) return GP_OK;
   hipStream_t s = (hipStream_t)stream;
-  const gp::MultiGridView v = g->view();
+  const gp::SearchView v = g->view();
   const dim3 grid((nq + 127) / 128), block(128);
   if (k == 1)
     hipLaunchKernelGGL(gp::knn_kernel<1>, grid, block, 0, s, v, queries_dev, nq, k, max_sq_dist, indices_dev, sq_dists_dev, num_found_dev);
@@ -740,12 +922,16 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   int rc = d_short.alloc_async(sizeof(int), s);
   if (rc == GP_OK) {
     (void)hipMemsetAsync(d_short.ptr, 0, sizeof(int), s);
-    const gp::MultiGridView v = g->view();
-    const dim3 grid((n + 127) / 128), block(128);
-    if (k <= 10)
-      hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, n, k, covs_dev, d_short.as<int>());
-    else
-      hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, n, k, covs_dev, d_short.as<int>());
+    const gp::SearchView v = g->view();
+    const int nq = g->binned ? g->bins.num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
+    if (nq < n) hipLaunchKernelGGL(gp::nonfinite_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, covs_dev, d_short.as<int>());
+    const dim3 grid((nq + 127) / 128), block(128);
+    if (nq > 0) {
+      if (k <= 10)
+        hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>());
+      else
+        hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>());
+    }
     int h_short = 0;
     hipError_t e = hipMemcpyAsync(&h_short, d_short.ptr, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -364,11 +364,12 @@ struct VoxelDataRecord {
 static_assert(sizeof(VoxelDataRecord) == 56, "GaussianVoxelData must be 56 B");
 
 int alloc_voxel_arrays(gp_voxelmap* m, int V) {
-  GP_TRY(m->records.alloc(sizeof(gp::VoxelRecord) * (size_t)V));
-  GP_TRY(m->num_points.alloc(sizeof(int) * (size_t)V));
-  GP_TRY(m->voxel_means.alloc(sizeof(float) * 3 * (size_t)V));
-  GP_TRY(m->voxel_covs.alloc(sizeof(float) * 9 * (size_t)V));
-  GP_TRY(m->voxel_intensities.alloc(sizeof(float) * (size_t)V));
+  hipStream_t s = m->stream;
+  GP_TRY(m->records.alloc_pooled(sizeof(gp::VoxelRecord) * (size_t)V, s));
+  GP_TRY(m->num_points.alloc_pooled(sizeof(int) * (size_t)V, s));
+  GP_TRY(m->voxel_means.alloc_pooled(sizeof(float) * 3 * (size_t)V, s));
+  GP_TRY(m->voxel_covs.alloc_pooled(sizeof(float) * 9 * (size_t)V, s));
+  GP_TRY(m->voxel_intensities.alloc_pooled(sizeof(float) * (size_t)V, s));
   return GP_OK;
 }
 
@@ -380,7 +381,7 @@ static int build_private_table(gp_voxelmap* m, hipStream_t s) {
   uint32_t lines = 256;
   while (lines < 2u * (uint32_t)std::max(V, 1)) lines <<= 1;  // 4 key slots per line: load factor <= 1/8
   m->plmask = lines - 1;
-  GP_TRY(m->plines.alloc(64 * (size_t)lines));
+  GP_TRY(m->plines.alloc_pooled(64 * (size_t)lines, s));
   GP_HIP(hipMemsetAsync(m->plines.ptr, 0xff, 64 * (size_t)lines, s));
   if (V > 0) {
     hipLaunchKernelGGL(gp::line_claim_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), m->plines.as<gp_voxel_bucket>(), m->plmask);
@@ -512,6 +513,9 @@ int gp_voxelmap_create(double resolution, int init_num_buckets, int max_bucket_s
 }
 
 int gp_voxelmap_destroy(gp_voxelmap_t* map) {
+  if (!map) return GP_OK;
+  // the arrays go back to the device's memory pool: nothing may still be reading them (what hipFree would have waited for)
+  (void)hipDeviceSynchronize();
   delete ext(map);
   return GP_OK;
 }
@@ -523,7 +527,7 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   const int V = bins.num_cells;
   m->info.num_voxels = V;
   GP_TRY(alloc_voxel_arrays(m, V));
-  GP_TRY(m->voxel_coords.alloc(sizeof(int) * 3 * (size_t)std::max(V, 1)));
+  GP_TRY(m->voxel_coords.alloc_pooled(sizeof(int) * 3 * (size_t)std::max(V, 1), s));
   hipLaunchKernelGGL(gp::segmented_stats_kernel, dim3((V + 3) / 4), dim3(256), 0, s, points_dev, covs_dev, intensities_dev, V, (const int*)bins.cell_start.as<int>(),
                      (const int*)bins.order.as<int>(), 1.0 / m->resolution, m->resolution, m->records.as<gp::VoxelRecord>(), m->num_points.as<int>(), m->voxel_means.as<float>(),
                      m->voxel_covs.as<float>(), m->voxel_intensities.as<float>(), m->voxel_coords.as<int>());
@@ -544,7 +548,7 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   while (num_buckets < (int64_t)V + V / 2) num_buckets *= 2;  // the sequence is entered where the voxels fit at a load factor <= 2/3
   for (;; num_buckets *= 2) {
     if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
-    GP_TRY(m->buckets.ensure(sizeof(gp_voxel_bucket) * (size_t)num_buckets));
+    GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
     GP_HIP(hipMemsetAsync(m->buckets.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
     GP_HIP(hipMemsetAsync(failed.ptr, 0, sizeof(int), s));
     const uint32_t mask = ((num_buckets & (num_buckets - 1)) == 0) ? (uint32_t)(num_buckets - 1) : 0u;

@@ -75,3 +75,43 @@ def test_gicp_linearize_matches_oracle(gpu, kitti00, xi):
     assert abs(e - eo) < PARITY_TOL * eo
     hf = f.linearize({0: np.eye(4), 1: delta})
     assert np.array_equal(hf.G[(1, 1)], L.H_source) and hf.keys == [0, 1]
+
+
+def test_binned_and_hashed_structures_agree(gpu, kitti00):
+    """the default search structure (occupancy-block grid over the cells + cell-sorted points) and the hashed multi-level grid (the
+    fallback of clouds whose bounding box is too large for the block grid) return the same neighbours; a cloud with non-finite points
+    and one with a far outlier (bounding box beyond the block budget -> fallback) still give exact answers"""
+    lib = gpu.load()
+    p = kitti00["target_points"]
+    q = kitti00["source_points"][:4000]
+    res = []
+    try:
+        for hashed in (0, 1):
+            gpu._capi.check(lib.gp_debug_set_knn_structure(hashed), "structure")
+            tree = gpu.KdTreeGPU(gpu.PointCloudGPU(p), cell_size=0.5)
+            res.append(tree.knn_search(q, 10))
+            res.append(tree.knn_search(q, 1, max_sq_dist=0.04))
+    finally:
+        lib.gp_debug_set_knn_structure(0)
+    assert np.abs(res[0][1] - res[2][1]).max() == 0.0 and (res[0][0] == res[2][0]).mean() > 0.999
+    np.testing.assert_array_equal(res[1][2], res[3][2])
+    assert np.array_equal(res[1][1][res[1][2] == 1], res[3][1][res[3][2] == 1])
+    # non-finite points are left out of the structure; queries that are not finite find nothing
+    p2 = p.copy()
+    p2[[3, 77, 5000]] = [np.nan, np.inf, -np.inf]
+    keep = np.isfinite(p2).all(1)
+    q2 = q.copy()
+    q2[5] = np.nan
+    idx, d, nf = gpu.KdTreeGPU(gpu.PointCloudGPU(p2), cell_size=0.5).knn_search(q2, 5)
+    oidx, od = oracle.OracleKdTree(p2[keep]).knn(np.delete(q2, 5, 0), 5, num_threads=4)
+    assert nf[5] == 0 and (np.delete(nf, 5) == 5).all()
+    assert np.abs(np.delete(d, 5, 0) - od).max() < 1e-9
+    # covariance estimation on the same cloud: identity + counted as short for the three non-finite points
+    fr = gpu.PointCloudGPU(p2)
+    assert gpu.estimate_covariances_gpu(fr, 10) == 3
+    np.testing.assert_array_equal(fr.download("covs")[77], np.eye(3, dtype=np.float32))
+    # a far outlier: 40 km away at 0.1 m cells the bounding box needs > 2^24 blocks -> hashed fallback, still exact
+    p3 = np.concatenate([p, np.array([[40000.0, -30000.0, 5000.0]], np.float32)])
+    idx3, d3, nf3 = gpu.KdTreeGPU(gpu.PointCloudGPU(p3), cell_size=0.1).knn_search(q[:500], 10)
+    oidx3, od3 = oracle.OracleKdTree(p3).knn(q[:500], 10, num_threads=4)
+    assert np.abs(d3 - od3).max() < 1e-9
