@@ -29,6 +29,16 @@ __host__ __device__ __forceinline__ unsigned long long pack_cell(int x, int y, i
   return ((unsigned long long)(unsigned)(x + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(y + (1 << 20)) << 21) | (unsigned long long)(unsigned)(z + (1 << 20));
 }
 
+// cell coordinate of the hashed grid: 21-bit fields.  Coordinates beyond +-2^20 cells are clamped to the border cells and a
+// non-finite coordinate goes to cell 0: such points sit in a cell that is never FARTHER from a query than their true cell, so the
+// shell search still meets them in time (distances always come from the real coordinates; NaN / inf distances are never selected)
+__host__ __device__ __forceinline__ int hashed_cell(double u) {
+  if (!(fabs(u) < 1.0e9)) return 0;
+  const int c = fast_floor(u);
+  const int lim = (1 << 20) - 3;
+  return c < -lim ? -lim : (c > lim ? lim : c);
+}
+
 __host__ __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdull;
@@ -63,8 +73,8 @@ __global__ void __launch_bounds__(256) grid_insert_kernel(const float* __restric
                                                           int* __restrict__ counts, int* __restrict__ point_slot, uint32_t mask, int* __restrict__ bbox) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int j = i < n ? i : n - 1;  // the tail lanes repeat the last point so that the wave-wide min/max below needs no masking
-  const int cx = fast_floor((double)points[3 * (size_t)j] * inv_h), cy = fast_floor((double)points[3 * (size_t)j + 1] * inv_h),
-            cz = fast_floor((double)points[3 * (size_t)j + 2] * inv_h);
+  const int cx = hashed_cell((double)points[3 * (size_t)j] * inv_h), cy = hashed_cell((double)points[3 * (size_t)j + 1] * inv_h),
+            cz = hashed_cell((double)points[3 * (size_t)j + 2] * inv_h);
   // bounding box of the occupied cells (bounds every query's cube radius): wave min/max, one row per workgroup, reduced by
   // bbox_reduce_kernel (atomics on six shared words serialise ~100 k operations per level: measured 1 ms)
   int lo[3] = {cx, cy, cz}, hi[3] = {cx, cy, cz};
@@ -226,7 +236,7 @@ template <int KMAX>
 __device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top);
 
 __device__ __forceinline__ int count27(const GridView& g, double qx, double qy, double qz) {
-  const int cx = fast_floor(qx * g.inv_h), cy = fast_floor(qy * g.inv_h), cz = fast_floor(qz * g.inv_h);
+  const int cx = hashed_cell(qx * g.inv_h), cy = hashed_cell(qy * g.inv_h), cz = hashed_cell(qz * g.inv_h);
   int c = 0;
   for (int dz = -1; dz <= 1; dz++)
     for (int dy = -1; dy <= 1; dy++)
@@ -251,7 +261,8 @@ __device__ __forceinline__ void knn_query_multi(const MultiGridView& mg, double 
 
 template <int KMAX>
 __device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
-  const int cx = fast_floor(qx * g.inv_h), cy = fast_floor(qy * g.inv_h), cz = fast_floor(qz * g.inv_h);
+  if (!(fabs(qx) < 1.0e300 && fabs(qy) < 1.0e300 && fabs(qz) < 1.0e300)) return;  // non-finite query: no neighbours
+  const int cx = hashed_cell(qx * g.inv_h), cy = hashed_cell(qy * g.inv_h), cz = hashed_cell(qz * g.inv_h);
   // distance from the query to the nearest face of its own cell
   const double fx = qx * g.inv_h - (double)cx, fy = qy * g.inv_h - (double)cy, fz = qz * g.inv_h - (double)cz;
   const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * g.h;
@@ -302,7 +313,8 @@ __device__ __forceinline__ unsigned axis_mask(int b, int c, int r) {
 // 64-bit cell mask of a block from its per-axis 4-bit masks (bit = z * 16 + y * 4 + x)
 __device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my, unsigned mz) {
   const unsigned long long X = (unsigned long long)mx * 0x1111111111111111ull;
-  const unsigned long long Y = (unsigned long long)(((my * 0x249u) & 0x1111u) * 0xFu) * 0x0001000100010001ull;
+  const unsigned y4 = (my & 1u) | ((my & 2u) << 3) | ((my & 4u) << 6) | ((my & 8u) << 9);  // bit y -> bit 4 y
+  const unsigned long long Y = (unsigned long long)(y4 * 0xFu) * 0x0001000100010001ull;
   const unsigned long long z1 = (unsigned long long)mz;
   const unsigned long long Z = ((z1 | (z1 << 15) | (z1 << 30) | (z1 << 45)) & 0x0001000100010001ull) * 0xFFFFull;
   return X & Y & Z;
