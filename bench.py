@@ -277,7 +277,7 @@ def main():
     )
 
     if os.environ.get("GP_BENCH_CALIBRATE"):  # PMC passes only: known-byte-count stream for FETCH_SIZE calibration
-        _capi.check(lib.gp_debug_calibration_stream(src.ptr(src.points_gpu), src.ptr(src.covs_gpu), args.source_points, 5, C.c_void_p(stream.cuda_stream)), "calibration")
+        _capi.check(_capi.load_tune().gp_debug_calibration_stream(src.ptr(src.points_gpu), src.ptr(src.covs_gpu), args.source_points, 5, C.c_void_p(stream.cuda_stream)), "calibration")
 
     rec = gpa.LinearizedSystem6.from_doubles(host_out[rank].numpy())
     c4 = None

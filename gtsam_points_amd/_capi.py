@@ -173,8 +173,6 @@ _SIGNATURES = {
     "gp_debug_set_map_build": (C.c_int, [C.c_int]),
     "gp_debug_set_knn_structure": (C.c_int, [C.c_int]),
     "gp_debug_set_trace_buffer": (C.c_int, [C.c_void_p]),
-    "gp_debug_stream_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
-    "gp_debug_calibration_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
@@ -199,6 +197,30 @@ def load():
             fn.argtypes = argtypes
         _LIB = lib
     return _LIB
+
+
+_TUNE_SIGNATURES = {
+    "gp_debug_stream_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "gp_debug_calibration_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+}
+_TUNE = None
+
+
+def load_tune():
+    """libgtsam_points_hip_tune.so: measurement kernels only (include/gtsam_points_hip_tune.h); never needed by the product path"""
+    global _TUNE
+    if _TUNE is None:
+        load()
+        path = os.path.join(_HERE, "libgtsam_points_hip_tune.so")
+        if not os.path.exists(path):
+            raise GPError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _TUNE_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _TUNE = lib
+    return _TUNE
 
 
 def check(rc, what=""):

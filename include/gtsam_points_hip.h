@@ -366,12 +366,6 @@ int gp_debug_set_stagger(int units);
 /* timeline hook: per-workgroup phase timestamps (s_memtime) of the default pipeline kernel into dev_buffer ([num_tiles][16] uint64:
  * slots 0-7 phases, 8 HW_ID, 9 XCC_ID); NULL disables */
 int gp_debug_set_trace_buffer(void* dev_buffer);
-/* measurement hook (gp_microbench.hip): mode 0-2 time to just read the 48*n source bytes (strided dwords / float4 / LDS-DMA),
- * 3-12 source + voxel-gather access patterns, 100-115 VALU issue rates; see scripts/stream_bench.py, scripts/alu_rate.py */
-int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n, int mode, int iters, float* ms);
-/* profiling hook: streams 48*n bytes with strided dword loads (calibrates the rocprofv3 FETCH_SIZE scale) */
-int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,25 @@
+/*
+ * gtsam_points_hip_tune.h -- measurement entry points of libgtsam_points_hip_tune.so (gp_microbench.hip): micro-benchmarks of the
+ * access patterns and VALU instructions the tile kernel is made of, and the known-byte-count stream that calibrates the rocprofv3
+ * FETCH_SIZE counter.  Tuning / profiling tools only (scripts/stream_bench.py, scripts/alu_rate.py, bench.py under
+ * GP_BENCH_CALIBRATE): NOT part of the drop-in boundary and not linked into libgtsam_points_hip.so.
+ */
+#ifndef GTSAM_POINTS_HIP_TUNE_H
+#define GTSAM_POINTS_HIP_TUNE_H
+
+#include "gtsam_points_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* measurement hook (gp_microbench.hip): mode 0-2 time to just read the 48*n source bytes (strided dwords / float4 / LDS-DMA),
+ * 3-12 source + voxel-gather access patterns, 100-115 VALU issue rates; see scripts/stream_bench.py, scripts/alu_rate.py */
+int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n, int mode, int iters, float* ms);
+/* profiling hook: streams 48*n bytes with strided dword loads (calibrates the rocprofv3 FETCH_SIZE scale) */
+int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTSAM_POINTS_HIP_TUNE_H */

@@ -12,6 +12,6 @@ blocks = 256 * 8 * 4   # 8 waves per SIMD resident, 4 rounds
 for op, name in enumerate(names):
     ms = C.c_float(); best = 1e9
     for _ in range(3):
-        _capi.check(lib.gp_debug_stream_bench(C.c_void_p(p.data_ptr()), C.c_void_p(c.data_ptr()), blocks, 100 + op, 5, C.byref(ms)), "bench"); best = min(best, ms.value)
+        _capi.check(_capi.load_tune().gp_debug_stream_bench(C.c_void_p(p.data_ptr()), C.c_void_p(c.data_ptr()), blocks, 100 + op, 5, C.byref(ms)), "bench"); best = min(best, ms.value)
     wave_instr_per_simd = blocks * 4 * 64 * 64 / 1024
     print(f"{name:16s} {best*1e3:9.1f} us  {best*1e-3*2.4e9/wave_instr_per_simd:6.2f} cycles/wave-instr @2.4GHz", flush=True)

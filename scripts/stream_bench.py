@@ -21,7 +21,7 @@ for n in [1048576, 8388608]:
         ms = C.c_float()
         best = 1e9
         for _ in range(3):
-            _capi.check(lib.gp_debug_stream_bench(C.c_void_p(p.data_ptr()), C.c_void_p(c.data_ptr()), n, mode, 50, C.byref(ms)), "bench")
+            _capi.check(_capi.load_tune().gp_debug_stream_bench(C.c_void_p(p.data_ptr()), C.c_void_p(c.data_ptr()), n, mode, 50, C.byref(ms)), "bench")
             best = min(best, ms.value)
         row[name] = f"{best*1e3:8.2f} us = {48*n/best/1e6:7.1f} GB/s"
     print(n, flush=True)
