@@ -320,10 +320,12 @@ __device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my
   return X & Y & Z;
 }
 
+// max_shells: how many shells beyond the first one that reaches the box this call may walk before it gives up (returns false: the
+// caller retries on a coarser level); returns true when the search is complete (bound met, or every point seen)
 template <int KMAX>
-__device__ __forceinline__ void knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
+__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top, int max_shells) {
   const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
-  if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return;  // non-finite query: no neighbours
+  if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;  // non-finite query: no neighbours
   const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
   const double fx = ux - (double)c[0], fy = uy - (double)c[1], fz = uz - (double)c[2];
   const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * g.h;
@@ -343,7 +345,8 @@ __device__ __forceinline__ void knn_query_bins(const BinGridView& g, double qx, 
     return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
   };
   float accept = loosened(top.worst());
-  for (int r = r0; r <= rmax; r++) {
+  const int rlast = (max_shells < rmax - r0) ? r0 + max_shells : rmax;
+  for (int r = r0; r <= rlast; r++) {
     int b0[3], b1[3];
     bool any = true;
 #pragma unroll
@@ -354,11 +357,16 @@ __device__ __forceinline__ void knn_query_bins(const BinGridView& g, double qx, 
       b1[a] = x1 >> 2;
     }
     if (any) {
+      // only blocks that touch the shell are visited: a z-slab of blocks that lies inside the previous cube along z contributes
+      // its y-border rows, and such a row its two x-border blocks (surface, not volume, per shell)
       for (int bz = b0[2]; bz <= b1[2]; bz++) {
         const unsigned mz = axis_mask(bz, c[2], r), mz1 = r > 0 ? axis_mask(bz, c[2], r - 1) : 0u;
+        const bool zin = mz1 == 0xFu;
         for (int by = b0[1]; by <= b1[1]; by++) {
           const unsigned my = axis_mask(by, c[1], r), my1 = r > 0 ? axis_mask(by, c[1], r - 1) : 0u;
-          for (int bx = b0[0]; bx <= b1[0]; bx++) {
+          const bool yin = zin && my1 == 0xFu;
+          const int xstep = (yin && b1[0] > b0[0]) ? b1[0] - b0[0] : 1;  // interior row: first and last block only
+          for (int bx = b0[0]; bx <= b1[0]; bx += xstep) {
             const unsigned mx = axis_mask(bx, c[0], r), mx1 = r > 0 ? axis_mask(bx, c[0], r - 1) : 0u;
             if (mx1 == 0xFu && my1 == 0xFu && mz1 == 0xFu) continue;  // the whole block lies inside the previous cube
             const size_t bi = ((size_t)(bz - g.geom.lo[2]) * (size_t)g.geom.dim[1] + (size_t)(by - g.geom.lo[1])) * (size_t)g.geom.dim[0] + (size_t)(bx - g.geom.lo[0]);
@@ -385,22 +393,32 @@ __device__ __forceinline__ void knn_query_bins(const BinGridView& g, double qx, 
       }
     }
     const double safe = (double)r * g.h + face;
-    if (top.worst() <= safe * safe) return;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
-    if (top.found >= g.n) return;            // the whole cloud has been seen (clouds smaller than k)
+    if (top.worst() <= safe * safe) return true;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
+    if (top.found >= g.n) return true;            // the whole cloud has been seen (clouds smaller than k)
   }
+  return rlast >= rmax;  // the whole box was walked
 }
 
 // what a search runs on: the binned structure, or -- for clouds whose bounding box is too large for it -- the hashed multi-level grid
+// LiDAR density spans three orders of magnitude between the near and the far field, so the binned structure comes in up to three
+// levels (cell size x4 per level): a query first tries the finest level for the shells 0 and 1 (<= 8 block entries); when that does not
+// settle it (sparse neighbourhood) it starts over on the next coarser level; the coarsest level walks on until the bound is met.
+// Every level is searched exactly, so the choice of level affects speed only.
 struct SearchView {
-  int binned;
-  BinGridView bins;
+  int binned;      // number of binned levels (0: hashed fallback)
+  BinGridView bins[kMaxLevels];
   MultiGridView hashed;
 };
 
 template <int KMAX>
 __device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX>& top) {
   if (g.binned) {
-    knn_query_bins<KMAX>(g.bins, qx, qy, qz, top);
+    const int k = top.k;
+    const double bound = top.d[KMAX - 1 < k - 1 ? KMAX - 1 : k - 1];  // the caller's max_sq_dist (init() filled every slot with it)
+    for (int l = 0; l < g.binned; l++) {
+      if (l > 0) top.init(k, bound);
+      if (knn_query_bins<KMAX>(g.bins[l], qx, qy, qz, top, l + 1 < g.binned ? 1 : 0x3fffffff)) return;
+    }
   } else {
     knn_query_multi<KMAX>(g.hashed, qx, qy, qz, want, top);
   }
@@ -559,7 +577,7 @@ __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const flo
   if (t >= n) return;
   // queries are taken in the finest grid's cell-sorted order: the lanes of a wave then sit in the same or adjacent cells,
   // walk the same shells and read the same cell ranges (coherent loads, little divergence); results go to the original index
-  const float4 self = g.binned ? g.bins.sorted[t] : g.hashed.lv[0].sorted[t];
+  const float4 self = g.binned ? g.bins[0].sorted[t] : g.hashed.lv[0].sorted[t];
   const int i = __float_as_int(self.w);
   const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
   TopK<KMAX> top;
@@ -702,25 +720,32 @@ struct gp_grid_level {
 };
 
 struct gp_point_grid {
-  // default: the binned structure (gp_binning.hpp) + the cell-sorted copy of the points
+  // default: the binned structure (gp_binning.hpp) + the cell-sorted copy of the points, in up to kMaxLevels levels (cell x4 each)
+  struct BinLevel {
+    gp::PointBins bins;
+    gp::DeviceArray sorted;  // float4[num_binned]
+    double h = 0.0;
+  };
+  std::vector<std::unique_ptr<BinLevel>> bin_levels;
   bool binned = false;
-  gp::PointBins bins;
-  gp::DeviceArray sorted;  // float4[num_binned]
-  double h = 0.0;
+  int num_binned = 0;
   // fallback for clouds whose bounding box is too large for the block grid: hashed multi-level grid
   std::vector<std::unique_ptr<gp_grid_level>> levels;
   hipStream_t stream = nullptr;
   gp::SearchView view() const {
     gp::SearchView v{};
-    v.binned = binned ? 1 : 0;
+    v.binned = binned ? (int)bin_levels.size() : 0;
     if (binned) {
-      v.bins.blocks = bins.blocks.as<gp::GridBlock>();
-      v.bins.cell_start = bins.cell_start.as<int>();
-      v.bins.sorted = sorted.as<float4>();
-      v.bins.geom = bins.geom;
-      v.bins.inv_h = 1.0 / h;
-      v.bins.h = h;
-      v.bins.n = bins.num_binned;
+      for (size_t l = 0; l < bin_levels.size(); l++) {
+        const BinLevel& b = *bin_levels[l];
+        v.bins[l].blocks = b.bins.blocks.as<gp::GridBlock>();
+        v.bins[l].cell_start = b.bins.cell_start.as<int>();
+        v.bins[l].sorted = b.sorted.as<float4>();
+        v.bins[l].geom = b.bins.geom;
+        v.bins[l].inv_h = 1.0 / b.h;
+        v.bins[l].h = b.h;
+        v.bins[l].n = b.bins.num_binned;
+      }
     } else {
       v.hashed.num_levels = (int)levels.size();
       for (int l = 0; l < v.hashed.num_levels; l++) v.hashed.lv[l] = levels[l]->view();
@@ -730,6 +755,7 @@ struct gp_point_grid {
 };
 
 static bool g_force_hashed_grid = false;  // gp_debug_set_knn_structure: A/B and tests of the fallback
+static int g_knn_levels = gp::kMaxLevels;  // levels of the next binned grid (the GICP factor asks for one)
 
 struct gp_gicp_factor {
   gp_point_grid* grid = nullptr;
@@ -821,29 +847,42 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
   if (n > 0 && !g_force_hashed_grid) {
-    bool too_large = false;
-    int rc = gp::bin_points(points_dev, n, 1.0 / cell_size, g->stream, &g->bins, &too_large);
-    if (rc == GP_OK && !too_large && g->bins.num_cells > 0) {
-      rc = g->sorted.alloc_pooled(sizeof(float4) * (size_t)std::max(g->bins.num_binned, 1), g->stream);
-      if (rc == GP_OK) {
-        hipLaunchKernelGGL(gp::gather_sorted_kernel, dim3((g->bins.num_binned + 255) / 256), dim3(256), 0, g->stream, points_dev, (const int*)g->bins.order.as<int>(),
-                           g->bins.num_binned, g->sorted.as<float4>());
-        const hipError_t e = hipStreamSynchronize(g->stream);
-        if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
+    // binned levels h, 4h, 16h (one level for small clouds and for radius-bounded searches, which never leave the first shells)
+    const int want_levels = (n > 4096 && g_knn_levels > 1) ? std::min(g_knn_levels, gp::kMaxLevels) : 1;
+    int rc = GP_OK;
+    bool ok = true;
+    double h = cell_size;
+    for (int l = 0; l < want_levels && ok && rc == GP_OK; l++, h *= 4.0) {
+      auto lv = std::make_unique<gp_point_grid::BinLevel>();
+      bool too_large = false;
+      rc = gp::bin_points(points_dev, n, 1.0 / h, g->stream, &lv->bins, &too_large);
+      if (rc != GP_OK) break;
+      if (too_large || lv->bins.num_cells <= 0) {
+        ok = false;
+        break;
       }
-      if (rc == GP_OK) {
-        g->binned = true;
-        g->h = cell_size;
-        g->bins.order.release();    // only the sorted copy is searched
-        g->bins.cell_of.release();
-        *out = g;
-        return GP_OK;
-      }
+      rc = lv->sorted.alloc_pooled(sizeof(float4) * (size_t)std::max(lv->bins.num_binned, 1), g->stream);
+      if (rc != GP_OK) break;
+      hipLaunchKernelGGL(gp::gather_sorted_kernel, dim3((lv->bins.num_binned + 255) / 256), dim3(256), 0, g->stream, points_dev, (const int*)lv->bins.order.as<int>(),
+                         lv->bins.num_binned, lv->sorted.as<float4>());
+      const hipError_t e = hipStreamSynchronize(g->stream);
+      if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
+      lv->h = h;
+      lv->bins.order.release();  // only the sorted copy is searched
+      lv->bins.cell_of.release();
+      g->bin_levels.push_back(std::move(lv));
     }
     if (rc != GP_OK) {
       delete g;
       return rc;
     }
+    if (ok && !g->bin_levels.empty()) {
+      g->binned = true;
+      g->num_binned = g->bin_levels[0]->bins.num_binned;
+      *out = g;
+      return GP_OK;
+    }
+    g->bin_levels.clear();  // bounding box too large for the block grid: hashed fallback below
   }
   const int num_levels = n > 4096 ? gp::kMaxLevels : 1;
   gp::DeviceArray scratch;
@@ -935,7 +974,7 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   if (rc == GP_OK) {
     (void)hipMemsetAsync(d_short.ptr, 0, sizeof(int), s);
     const gp::SearchView v = g->view();
-    const int nq = g->binned ? g->bins.num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
+    const int nq = g->binned ? g->num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
     if (nq < n) hipLaunchKernelGGL(gp::nonfinite_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, covs_dev, d_short.as<int>());
     const dim3 grid((nq + 127) / 128), block(128);
     if (nq > 0) {
@@ -964,7 +1003,9 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
   auto* f = new gp_gicp_factor;
   f->stream = (hipStream_t)stream;
   // finest cell = 1/4 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
+  g_knn_levels = 1;  // the distance bound ends every search within 4 shells of the finest level
   int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 4.0, stream, &f->grid);
+  g_knn_levels = gp::kMaxLevels;
   if (rc != GP_OK) {
     delete f;
     return rc;
