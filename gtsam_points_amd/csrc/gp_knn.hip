@@ -570,25 +570,9 @@ __device__ __forceinline__ void inverse3_general(const double* a /*col-major*/, 
 
 // estimate_covariances (features/covariance_estimation.cpp:18-77): k-NN (query included) -> sample covariance ->
 // V diag(1e-3, 1, 1) V^-1.  Fewer than k neighbours -> identity (:27-31).
+// sample covariance of the k neighbours -> V diag(1e-3, 1, 1) V^-1 (features/covariance_estimation.cpp:33-53)
 template <int KMAX>
-__global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
-                                                         int* __restrict__ num_short) {
-  const int t = blockIdx.x * 128 + threadIdx.x;
-  if (t >= n) return;
-  // queries are taken in the finest grid's cell-sorted order: the lanes of a wave then sit in the same or adjacent cells,
-  // walk the same shells and read the same cell ranges (coherent loads, little divergence); results go to the original index
-  const float4 self = g.binned ? g.bins[0].sorted[t] : g.hashed.lv[0].sorted[t];
-  const int i = __float_as_int(self.w);
-  const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
-  TopK<KMAX> top;
-  top.init(k, 1.7976931348623157e308);
-  knn_query_any<KMAX>(g, qx, qy, qz, 2 * k, top);
-  float* out = covs + 9 * (size_t)i;
-  if (top.found < k) {
-    atomicAdd(num_short, 1);
-    for (int j = 0; j < 9; j++) out[j] = (j % 4 == 0) ? 1.0f : 0.0f;
-    return;
-  }
+__device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX>& top, const float* __restrict__ points, int k, float* __restrict__ out) {
   double sp[3] = {0, 0, 0}, spp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < KMAX; j++)
@@ -612,6 +596,124 @@ __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const flo
       for (int kk = 0; kk < 3; kk++) s += V[kk * 3 + r] * lam[kk] * Vinv[c * 3 + kk];
       out[c * 3 + r] = (float)s;
     }
+}
+
+// estimate_covariances, per-lane search (every query walks its own shells; see knn_query_bins / knn_query): the general path, and
+// the second pass of the tiled kernel below for the queries it left over (todo != nullptr: only positions with todo[t] != 0)
+template <int KMAX>
+__global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
+                                                         int* __restrict__ num_short, const unsigned char* __restrict__ todo) {
+  const int t = blockIdx.x * 128 + threadIdx.x;
+  if (t >= n) return;
+  if (todo && !todo[t]) return;
+  // queries are taken in the finest grid's cell-sorted order: the lanes of a wave then sit in the same or adjacent cells,
+  // walk the same shells and read the same cell ranges (coherent loads, little divergence); results go to the original index
+  const float4 self = g.binned ? g.bins[0].sorted[t] : g.hashed.lv[0].sorted[t];
+  const int i = __float_as_int(self.w);
+  const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
+  TopK<KMAX> top;
+  top.init(k, 1.7976931348623157e308);
+  knn_query_any<KMAX>(g, qx, qy, qz, 2 * k, top);
+  float* out = covs + 9 * (size_t)i;
+  if (top.found < k) {
+    atomicAdd(num_short, 1);
+    for (int j = 0; j < 9; j++) out[j] = (j % 4 == 0) ? 1.0f : 0.0f;
+    return;
+  }
+  covariance_from_neighbours<KMAX>(top, points, k, out);
+}
+
+// estimate_covariances, tiled: ONE WORKGROUP PER OCCUPIED BLOCK of the finest binned level.  The queries are the block's own points
+// (one contiguous range of the cell-sorted array); the candidates are all points of the 3 x 3 x 3 blocks around it (27 contiguous
+// ranges), staged through LDS in chunks and scanned by every query lane with broadcast reads: coalesced loads, no per-lane pointer
+// chasing, no divergence in the scan loop.  A query is settled when its k-th distance is no larger than its distance to the border of
+// that region (>= one block edge): every point outside is farther.  Anything else -- sparse neighbourhoods, blocks too dense for a
+// workgroup -- is flagged in `todo` and goes through the per-lane search above, so the result is exact either way.
+constexpr int kTileCand = 2048;        // candidates per LDS chunk (32 KB)
+constexpr int kTileMaxQueries = 1024;  // larger blocks (dense near field) are left to the per-lane search, which settles them in <= 2 shells
+constexpr long long kTileMaxPairs = 4ll << 20;
+template <int KMAX>
+__global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, const float* __restrict__ points, int k, float* __restrict__ covs,
+                                                               unsigned char* __restrict__ todo) {
+  __shared__ float4 cand[kTileCand];
+  __shared__ int rstart[27], rpref[28];
+  const long long b = blockIdx.x;
+  const GridBlock me = g.blocks[b];
+  if (me.bits == 0ull) return;
+  const int q0 = g.cell_start[me.base];
+  const int Q = g.cell_start[me.base + __popcll(me.bits)] - q0;
+  const int bx = (int)(b % g.geom.dim[0]), by = (int)((b / g.geom.dim[0]) % g.geom.dim[1]), bz = (int)(b / ((long long)g.geom.dim[0] * g.geom.dim[1]));
+  if (threadIdx.x < 27) {
+    const int nx = bx + (int)(threadIdx.x % 3) - 1, ny = by + (int)((threadIdx.x / 3) % 3) - 1, nz = bz + (int)(threadIdx.x / 9) - 1;
+    int start = 0, len = 0;
+    if (nx >= 0 && nx < g.geom.dim[0] && ny >= 0 && ny < g.geom.dim[1] && nz >= 0 && nz < g.geom.dim[2]) {
+      const GridBlock nb = g.blocks[((long long)nz * g.geom.dim[1] + ny) * g.geom.dim[0] + nx];
+      if (nb.bits) {
+        start = g.cell_start[nb.base];
+        len = g.cell_start[nb.base + __popcll(nb.bits)] - start;
+      }
+    }
+    rstart[threadIdx.x] = start;
+    rpref[threadIdx.x + 1] = len;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rpref[0] = 0;
+    for (int t = 0; t < 27; t++) rpref[t + 1] += rpref[t];
+  }
+  __syncthreads();
+  const int C = rpref[27];
+  if (Q > kTileMaxQueries || (long long)Q * C > kTileMaxPairs) {
+    for (int t = threadIdx.x; t < Q; t += 256) todo[q0 + t] = 1;
+    return;
+  }
+  // the region's faces (metres): blocks bx-1 .. bx+1 along every axis
+  const double edge = 4.0 * g.h;
+  const double rlo[3] = {(double)(g.geom.lo[0] + bx - 1) * edge, (double)(g.geom.lo[1] + by - 1) * edge, (double)(g.geom.lo[2] + bz - 1) * edge};
+  for (int pass = 0; pass * 256 < Q; pass++) {
+    const int qi = pass * 256 + (int)threadIdx.x;
+    const bool active = qi < Q;
+    const float4 self = g.sorted[q0 + (active ? qi : 0)];
+    const bool wave_active = pass * 256 + (int)(threadIdx.x & ~63u) < Q;  // wave-uniform: this wave holds at least one query
+    TopK<KMAX> top;
+    top.init(k, 1.7976931348623157e308);
+    float accept = __builtin_inff();
+    for (int c0 = 0; c0 < C; c0 += kTileCand) {
+      __syncthreads();  // the previous chunk has been consumed
+      const int cnt = min(kTileCand, C - c0);
+      for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int gi = c0 + i;
+        int r = 0;
+#pragma unroll
+        for (int t = 1; t < 27; t++) r += (rpref[t] <= gi) ? 1 : 0;  // range holding candidate gi (prefix sums are non-decreasing)
+        cand[i] = g.sorted[rstart[r] + (gi - rpref[r])];
+      }
+      __syncthreads();
+      if (wave_active) {
+        for (int j = 0; j < cnt; j++) {
+          const float4 v = cand[j];  // every lane reads the same address: broadcast
+          const float dxf = v.x - self.x, dyf = v.y - self.y, dzf = v.z - self.z;
+          if (active && dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
+            // queries and candidates are both floats here, so the f32 differences are exact up to one rounding of each product
+            const double ddx = (double)v.x - (double)self.x, ddy = (double)v.y - (double)self.y, ddz = (double)v.z - (double)self.z;
+            top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
+            accept = (float)top.worst() * 1.00001f;
+          }
+        }
+      }
+    }
+    if (active) {
+      const double q[3] = {(double)self.x, (double)self.y, (double)self.z};
+      double safe = 1.0e300;
+#pragma unroll
+      for (int a = 0; a < 3; a++) safe = fmin(safe, fmin(q[a] - rlo[a], rlo[a] + 3.0 * edge - q[a]));
+      if (top.found >= k && top.worst() <= safe * safe) {
+        covariance_from_neighbours<KMAX>(top, points, k, covs + 9 * (size_t)__float_as_int(self.w));
+      } else {
+        todo[q0 + qi] = 1;
+      }
+    }
+  }
 }
 
 // ---- GICP: 1-NN correspondence within max distance + the same H/b algebra as VGICP ------------------------------------
@@ -755,6 +857,7 @@ struct gp_point_grid {
 };
 
 static bool g_force_hashed_grid = false;  // gp_debug_set_knn_structure: A/B and tests of the fallback
+static bool g_knn_untiled = false;        // gp_debug_set_knn_structure(2): binned structure, per-lane search only (A/B)
 static int g_knn_levels = gp::kMaxLevels;  // levels of the next binned grid (the GICP factor asks for one)
 
 struct gp_gicp_factor {
@@ -931,8 +1034,9 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   return GP_OK;
 }
 
-int gp_debug_set_knn_structure(int hashed) {
-  g_force_hashed_grid = hashed != 0;
+int gp_debug_set_knn_structure(int mode) {
+  g_force_hashed_grid = mode == 1;
+  g_knn_untiled = mode == 2;
   return GP_OK;
 }
 
@@ -977,11 +1081,23 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
     const int nq = g->binned ? g->num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
     if (nq < n) hipLaunchKernelGGL(gp::nonfinite_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, covs_dev, d_short.as<int>());
     const dim3 grid((nq + 127) / 128), block(128);
-    if (nq > 0) {
+    gp::DeviceArray todo;
+    const unsigned char* d_todo = nullptr;
+    if (nq > 0 && g->binned && !g_knn_untiled && k <= 10) {
+      // tiled pass over the occupied blocks of the finest level; what it cannot settle is flagged for the per-lane pass
+      rc = todo.alloc_async((size_t)nq, s);
+      if (rc == GP_OK) {
+        (void)hipMemsetAsync(todo.ptr, 0, (size_t)nq, s);
+        hipLaunchKernelGGL(gp::covariance_tiled_kernel<10>, dim3((unsigned)g->bin_levels[0]->bins.num_blocks), dim3(256), 0, s, v.bins[0], points_dev, k, covs_dev,
+                           todo.as<unsigned char>());
+        d_todo = todo.as<unsigned char>();
+      }
+    }
+    if (nq > 0 && rc == GP_OK) {
       if (k <= 10)
-        hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>());
+        hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo);
       else
-        hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>());
+        hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo);
     }
     int h_short = 0;
     hipError_t e = hipMemcpyAsync(&h_short, d_short.ptr, sizeof(int), hipMemcpyDeviceToHost, s);

@@ -358,9 +358,9 @@ int gp_debug_set_variant(int variant);
 /* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
  * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
 int gp_debug_set_map_build(int hashed);
-/* A/B hook: 1 = k-NN / GICP search on the hashed multi-level grid (also the fallback of clouds whose bounding box is too large for
- * the block grid), 0 = binned structure (default) */
-int gp_debug_set_knn_structure(int hashed);
+/* A/B hook: 0 = binned structure, covariance estimation tiled per occupied block (default); 1 = hashed multi-level grid (also the
+ * fallback of clouds whose bounding box is too large for the block grid); 2 = binned structure, per-lane search only */
+int gp_debug_set_knn_structure(int mode);
 /* tuning knob: the odd wave slots of every SIMD start `units` x 512 clocks late (0 = off, default) */
 int gp_debug_set_stagger(int units);
 /* timeline hook: per-workgroup phase timestamps (s_memtime) of the default pipeline kernel into dev_buffer ([num_tiles][16] uint64:

@@ -106,6 +106,20 @@ def test_binned_and_hashed_structures_agree(gpu, kitti00):
     oidx, od = oracle.OracleKdTree(p2[keep]).knn(np.delete(q2, 5, 0), 5, num_threads=4)
     assert nf[5] == 0 and (np.delete(nf, 5) == 5).all()
     assert np.abs(np.delete(d, 5, 0) - od).max() < 1e-9
+    # covariance estimation: the tiled kernel (default), the per-lane search on the binned structure and on the hashed grid agree
+    # (same exact neighbour sets; ties may be ordered differently, which the sample covariance does not see)
+    covs = []
+    try:
+        for mode in (0, 2, 1):
+            gpu._capi.check(lib.gp_debug_set_knn_structure(mode), "structure")
+            fr0 = gpu.PointCloudGPU(p)
+            assert gpu.estimate_covariances_gpu(fr0, 10) == 0
+            covs.append(fr0.download("covs").astype(np.float64))
+    finally:
+        lib.gp_debug_set_knn_structure(0)
+    for other in covs[1:]:
+        rel = np.linalg.norm((covs[0] - other).reshape(len(p), -1), axis=1) / np.linalg.norm(other.reshape(len(p), -1), axis=1)
+        assert (rel < 1e-5).mean() > 0.999, (rel < 1e-5).mean()  # all but the neighbourhoods with exact distance ties at rank k
     # covariance estimation on the same cloud: identity + counted as short for the three non-finite points
     fr = gpu.PointCloudGPU(p2)
     assert gpu.estimate_covariances_gpu(fr, 10) == 3
