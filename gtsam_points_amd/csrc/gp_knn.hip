@@ -189,22 +189,26 @@ __global__ void __launch_bounds__(256) grid_scatter_kernel(const float* __restri
 // ---- exact k-NN -------------------------------------------------------------------------------------------------
 template <int KMAX>
 struct TopK {
+  // d / idx are only ever indexed with compile-time constants (unrolled loops + predicates): a run-time index such as d[k - 1]
+  // would send both arrays to scratch memory (160 B per lane for KMAX = 10) and turn every comparison into a memory access
   double d[KMAX];
   int idx[KMAX];
+  double bound;  // = d[k - 1]: the current k-th distance (or the caller's max_sq_dist while fewer than k are held)
   int k, found;
   __device__ void init(int k_, double max_sq_dist) {
     k = k_;
     found = 0;
+    bound = max_sq_dist;
 #pragma unroll
     for (int j = 0; j < KMAX; j++) {
       d[j] = max_sq_dist;
       idx[j] = -1;
     }
   }
-  __device__ double worst() const { return d[k - 1]; }
+  __device__ double worst() const { return bound; }
   // KnnResult::push (ann/knn_result.hpp:89-109): strict '<', earlier-visited ties win
   __device__ void push(int index, double dist) {
-    if (!(dist < d[k - 1])) return;
+    if (!(dist < bound)) return;
     bool placed = false;
 #pragma unroll
     for (int j = KMAX - 1; j >= 0; j--) {
@@ -219,6 +223,9 @@ struct TopK {
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < KMAX; j++)
+      if (j == k - 1) bound = d[j];
     found = found + 1 < k ? found + 1 : k;
   }
 };
@@ -414,7 +421,7 @@ template <int KMAX>
 __device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX>& top) {
   if (g.binned) {
     const int k = top.k;
-    const double bound = top.d[KMAX - 1 < k - 1 ? KMAX - 1 : k - 1];  // the caller's max_sq_dist (init() filled every slot with it)
+    const double bound = top.worst();  // the caller's max_sq_dist (nothing has been pushed yet)
     for (int l = 0; l < g.binned; l++) {
       if (l > 0) top.init(k, bound);
       if (knn_query_bins<KMAX>(g.bins[l], qx, qy, qz, top, l + 1 < g.binned ? 1 : 0x3fffffff)) return;
