@@ -638,11 +638,53 @@ __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const flo
 // workgroup -- is flagged in `todo` and goes through the per-lane search above, so the result is exact either way.
 constexpr int kTileCand = 2048;        // candidates per LDS chunk (32 KB)
 constexpr int kTileMaxQueries = 1024;  // larger blocks (dense near field) are left to the per-lane search, which settles them in <= 2 shells
-constexpr long long kTileMaxPairs = 4ll << 20;
+constexpr long long kTileMaxPairs = 8ll << 20;
+constexpr int kTileQueue = 32;         // per-lane queue of candidates that passed the f32 filter (2 B each)
+constexpr int kTileKeep = 12;          // f32 top list: k (<= 10) + 2 entries of slack for the exactness check
+
+// f32 top list of the tiled kernel: same insertion rule as TopK, floats, compile-time indices only
+struct TopF {
+  float d[kTileKeep];
+  int idx[kTileKeep];
+  __device__ void init() {
+#pragma unroll
+    for (int j = 0; j < kTileKeep; j++) {
+      d[j] = __builtin_inff();
+      idx[j] = -1;
+    }
+  }
+  __device__ float bound() const { return d[kTileKeep - 1]; }
+  __device__ void push(int index, float dist) {
+    if (!(dist < d[kTileKeep - 1])) return;
+    bool placed = false;
+#pragma unroll
+    for (int j = kTileKeep - 1; j >= 0; j--) {
+      if (!placed) {
+        if (j > 0 && dist < d[j - 1]) {
+          d[j] = d[j - 1];
+          idx[j] = idx[j - 1];
+        } else {
+          d[j] = dist;
+          idx[j] = index;
+          placed = true;
+        }
+      }
+    }
+  }
+};
+
+// The scan loop costs ~12 cycles per candidate for a whole wave (LDS broadcast read, f32 distance, compare, a 2-byte LDS append for
+// the lanes whose candidate passes).  What passes is pushed into the lane's f32 top list only when a queue is full or the chunk ends
+// -- then every lane is busy with its OWN candidates, instead of the whole wave executing an insertion whenever any one lane has a
+// hit (which is every iteration).  At the end the <= 12 kept candidates are re-scored in f64 (the reference compares doubles) and the
+// query is settled only if (i) the k-th exact distance is below the 12th f32 distance by more than f32 rounding -- so nothing that was
+// filtered out can belong to the k nearest -- and (ii) it is no larger than the distance to the region's border.
 template <int KMAX>
 __global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, const float* __restrict__ points, int k, float* __restrict__ covs,
                                                                unsigned char* __restrict__ todo) {
+  static_assert(KMAX + 2 <= kTileKeep, "two entries of slack");
   __shared__ float4 cand[kTileCand];
+  __shared__ unsigned short queue[kTileQueue][256];  // [slot][lane]: a lane's slots are 512 B apart -> the 64 lanes of a wave hit 32 banks twice
   __shared__ int rstart[27], rpref[28];
   const long long b = blockIdx.x;
   const GridBlock me = g.blocks[b];
@@ -682,9 +724,19 @@ __global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, co
     const bool active = qi < Q;
     const float4 self = g.sorted[q0 + (active ? qi : 0)];
     const bool wave_active = pass * 256 + (int)(threadIdx.x & ~63u) < Q;  // wave-uniform: this wave holds at least one query
-    TopK<KMAX> top;
-    top.init(k, 1.7976931348623157e308);
-    float accept = __builtin_inff();
+    TopF top;
+    top.init();
+    int queued = 0;
+    auto drain = [&]() {  // every lane inserts its own queued candidates (f32 distance recomputed from LDS)
+      for (int i = 0; __any(i < queued); i++) {
+        if (i < queued) {
+          const float4 v = cand[queue[i][threadIdx.x]];
+          const float dxf = v.x - self.x, dyf = v.y - self.y, dzf = v.z - self.z;
+          top.push(__float_as_int(v.w), dxf * dxf + dyf * dyf + dzf * dzf);
+        }
+      }
+      queued = 0;
+    };
     for (int c0 = 0; c0 < C; c0 += kTileCand) {
       __syncthreads();  // the previous chunk has been consumed
       const int cnt = min(kTileCand, C - c0);
@@ -697,25 +749,43 @@ __global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, co
       }
       __syncthreads();
       if (wave_active) {
+        float thr = top.bound();
         for (int j = 0; j < cnt; j++) {
           const float4 v = cand[j];  // every lane reads the same address: broadcast
           const float dxf = v.x - self.x, dyf = v.y - self.y, dzf = v.z - self.z;
-          if (active && dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
-            // queries and candidates are both floats here, so the f32 differences are exact up to one rounding of each product
-            const double ddx = (double)v.x - (double)self.x, ddy = (double)v.y - (double)self.y, ddz = (double)v.z - (double)self.z;
-            top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
-            accept = (float)top.worst() * 1.00001f;
+          if (active && dxf * dxf + dyf * dyf + dzf * dzf < thr) {
+            queue[queued][threadIdx.x] = (unsigned short)j;
+            queued++;
+          }
+          if (__any(queued == kTileQueue)) {
+            drain();
+            thr = top.bound();
           }
         }
+        drain();  // the chunk is about to be replaced
       }
     }
     if (active) {
+      // exact re-score of the kept candidates in f64, in f32 rank order
       const double q[3] = {(double)self.x, (double)self.y, (double)self.z};
+      TopK<KMAX> exact;
+      exact.init(k, 1.7976931348623157e308);
+#pragma unroll
+      for (int j = 0; j < kTileKeep; j++) {
+        if (top.idx[j] >= 0) {
+          const size_t nb = (size_t)top.idx[j];
+          const double ddx = (double)points[3 * nb] - q[0], ddy = (double)points[3 * nb + 1] - q[1], ddz = (double)points[3 * nb + 2] - q[2];
+          exact.push(top.idx[j], ddx * ddx + ddy * ddy + ddz * ddz);
+        }
+      }
       double safe = 1.0e300;
 #pragma unroll
       for (int a = 0; a < 3; a++) safe = fmin(safe, fmin(q[a] - rlo[a], rlo[a] + 3.0 * edge - q[a]));
-      if (top.found >= k && top.worst() <= safe * safe) {
-        covariance_from_neighbours<KMAX>(top, points, k, covs + 9 * (size_t)__float_as_int(self.w));
+      // (i) nothing outside the kept list can be among the k nearest: everything that was filtered out has an f32 distance >= the
+      // 12th kept one, i.e. a true distance >= bound * (1 - 1e-5); (ii) nothing outside the region can
+      const bool separated = exact.worst() <= (double)top.bound() * (1.0 - 1.0e-5);
+      if (exact.found >= k && separated && exact.worst() <= safe * safe) {
+        covariance_from_neighbours<KMAX>(exact, points, k, covs + 9 * (size_t)__float_as_int(self.w));
       } else {
         todo[q0 + qi] = 1;
       }
