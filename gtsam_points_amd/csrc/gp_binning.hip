@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) bins_flag_kernel(const unsigned* __restri
 // start, its occupancy bit, and -- at the first cell of a block -- the block's base.  total[0] = number of cells.
 __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __restrict__ sorted_keys, const int* __restrict__ flags, const int* __restrict__ scanned, int n,
                                                           const int* __restrict__ total, GridBlock* __restrict__ blocks, int* __restrict__ cell_start,
-                                                          unsigned* __restrict__ cell_of, int* __restrict__ num_binned) {
+                                                          unsigned* __restrict__ cell_of, int* __restrict__ cell_block, int* __restrict__ num_binned) {
   const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= (size_t)n) return;
   const unsigned k = sorted_keys[j];
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __rest
   cell_of[j] = (unsigned)ord;
   if (flags[j]) {
     cell_start[ord] = (int)j;
+    cell_block[ord] = (int)(k >> 6);
     GridBlock* blk = blocks + (k >> 6);
     atomicOr(&blk->bits, 1ull << (k & 63u));  // one atomic per CELL (not per point); the bits of a block come from <= 64 cells
     if (j == 0 || (sorted_keys[j - 1] >> 6) != (k >> 6)) blk->base = ord;
@@ -123,6 +124,17 @@ __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __rest
     cell_start[num_cells] = n;
     *num_binned = n;
   }
+}
+
+// occupied blocks as a compact ascending list: cell c opens a block when it is the block's first cell
+__global__ void __launch_bounds__(256) bins_block_flag_kernel(int num_cells, const int* __restrict__ cell_block, const GridBlock* __restrict__ blocks, int* __restrict__ flags) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < num_cells) flags[c] = blocks[cell_block[c]].base == c ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) bins_block_list_kernel(int num_cells, const int* __restrict__ cell_block, const int* __restrict__ flags, const int* __restrict__ scanned,
+                                                              int* __restrict__ occ_blocks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < num_cells && flags[c]) occ_blocks[scanned[c]] = cell_block[c];
 }
 
 }  // namespace
@@ -200,13 +212,29 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_HIP(hipStreamSynchronize(s));  // the cell count sizes cell_start
   bins->num_cells = h_cells;
   GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)h_cells + 1), s));
+  GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)std::max(h_cells, 1), s));
+  GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)std::max(h_cells, 1), s));  // at most one block per cell
   hipLaunchKernelGGL(bins_finish_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), (const int*)flags.as<int>(),
-                     (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), d_small.as<int>() + 8);
+                     (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(),
+                     d_small.as<int>() + 8);
   GP_HIP(hipGetLastError());
   bins->cell_of.swap(keys_b);  // cell_of = ordinals of the sorted points
+  // the compact list of occupied blocks (flags / scanned are re-used: num_cells <= n)
+  int h_occ = 0;
+  if (h_cells > 0) {
+    const int cw = (h_cells + 255) / 256;
+    hipLaunchKernelGGL(bins_block_flag_kernel, dim3(cw), dim3(256), 0, s, h_cells, (const int*)bins->cell_block.as<int>(), (const GridBlock*)bins->blocks.as<GridBlock>(), flags.as<int>());
+    GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, h_cells, scan_scratch.as<int>(), s));
+    hipLaunchKernelGGL(bins_block_list_kernel, dim3(cw), dim3(256), 0, s, h_cells, (const int*)bins->cell_block.as<int>(), (const int*)flags.as<int>(),
+                       (const int*)scanned.as<int>(), bins->occ_blocks.as<int>());
+    GP_HIP(hipGetLastError());
+    const int cell_scan_blocks = (h_cells + kScanThreads - 1) / kScanThreads;
+    GP_HIP(hipMemcpyAsync(&h_occ, scan_scratch.as<int>() + cell_scan_blocks, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
   int h_binned = 0;
   GP_HIP(hipMemcpyAsync(&h_binned, d_small.as<int>() + 8, sizeof(int), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));
+  bins->num_occ_blocks = h_occ;
   bins->num_binned = h_binned;
   return GP_OK;
 }

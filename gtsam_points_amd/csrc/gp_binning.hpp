@@ -43,6 +43,9 @@ struct PointBins {
   DeviceArray cell_start;  // int[num_cells + 1]
   DeviceArray order;       // int[n]: point indices, cell-major, ascending inside a cell; positions >= num_binned hold the skipped points
   DeviceArray cell_of;     // unsigned[n]: cell ordinal of order[j] (sorted keys); kept for the consumers' segmented passes
+  DeviceArray cell_block;  // int[num_cells]: block index of every cell
+  DeviceArray occ_blocks;  // int[num_occ_blocks]: indices of the occupied blocks, ascending (work list of block-tiled kernels)
+  int num_occ_blocks = 0;
 };
 
 // Bins points_dev[n] (float xyz, 12-B stride) by floor(p * inv_cell) in double -- the CPU map's rule (util/fast_floor.hpp:12-15).

@@ -680,13 +680,13 @@ struct TopF {
 // query is settled only if (i) the k-th exact distance is below the 12th f32 distance by more than f32 rounding -- so nothing that was
 // filtered out can belong to the k nearest -- and (ii) it is no larger than the distance to the region's border.
 template <int KMAX>
-__global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, const float* __restrict__ points, int k, float* __restrict__ covs,
-                                                               unsigned char* __restrict__ todo) {
+__global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, const int* __restrict__ occ_blocks, const float* __restrict__ points, int k,
+                                                               float* __restrict__ covs, unsigned char* __restrict__ todo) {
   static_assert(KMAX + 2 <= kTileKeep, "two entries of slack");
   __shared__ float4 cand[kTileCand];
   __shared__ unsigned short queue[kTileQueue][256];  // [slot][lane]: a lane's slots are 512 B apart -> the 64 lanes of a wave hit 32 banks twice
   __shared__ int rstart[27], rpref[28];
-  const long long b = blockIdx.x;
+  const long long b = occ_blocks[blockIdx.x];  // work list: the occupied blocks only (a LiDAR box is >99 % empty blocks)
   const GridBlock me = g.blocks[b];
   if (me.bits == 0ull) return;
   const int q0 = g.cell_start[me.base];
@@ -1050,6 +1050,7 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
       lv->h = h;
       lv->bins.order.release();  // only the sorted copy is searched
       lv->bins.cell_of.release();
+      lv->bins.cell_block.release();
       g->bin_levels.push_back(std::move(lv));
     }
     if (rc != GP_OK) {
@@ -1165,8 +1166,8 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
       rc = todo.alloc_async((size_t)nq, s);
       if (rc == GP_OK) {
         (void)hipMemsetAsync(todo.ptr, 0, (size_t)nq, s);
-        hipLaunchKernelGGL(gp::covariance_tiled_kernel<10>, dim3((unsigned)g->bin_levels[0]->bins.num_blocks), dim3(256), 0, s, v.bins[0], points_dev, k, covs_dev,
-                           todo.as<unsigned char>());
+        hipLaunchKernelGGL(gp::covariance_tiled_kernel<10>, dim3((unsigned)g->bin_levels[0]->bins.num_occ_blocks), dim3(256), 0, s, v.bins[0],
+                           (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), points_dev, k, covs_dev, todo.as<unsigned char>());
         d_todo = todo.as<unsigned char>();
       }
     }
