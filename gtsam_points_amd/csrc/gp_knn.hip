@@ -308,6 +308,7 @@ struct BinGridView {
   GridGeom geom;
   double inv_h, h;
   int n;  // binned (finite) points
+  unsigned long long* counters;  // measurement build only (gp_debug_knn_counters): {queries, f32 distances, f64 distances, block entries, cells}
 };
 
 // 4-bit mask of the cells x = 4 * b + {0, 1, 2, 3} inside [c - r, c + r]
@@ -352,6 +353,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
     return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
   };
   float accept = loosened(top.worst());
+  unsigned n_f32 = 0, n_f64 = 0, n_blk = 0, n_cell = 0;  // work counters: only read when g.counters is set (measurement runs)
   const int rlast = (max_shells < rmax - r0) ? r0 + max_shells : rmax;
   for (int r = r0; r <= rlast; r++) {
     int b0[3], b1[3];
@@ -378,6 +380,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
             if (mx1 == 0xFu && my1 == 0xFu && mz1 == 0xFu) continue;  // the whole block lies inside the previous cube
             const size_t bi = ((size_t)(bz - g.geom.lo[2]) * (size_t)g.geom.dim[1] + (size_t)(by - g.geom.lo[1])) * (size_t)g.geom.dim[0] + (size_t)(bx - g.geom.lo[0]);
             const int4 raw = *reinterpret_cast<const int4*>(g.blocks + bi);
+            n_blk++;
             const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
             unsigned long long m = bits & cube_mask(mx, my, mz) & ~cube_mask(mx1, my1, mz1);  // occupied cells of this shell
             while (m) {
@@ -385,10 +388,13 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
               m &= m - 1ull;
               const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
               const int pb = g.cell_start[ord], pe = g.cell_start[ord + 1];
+              n_cell++;
+              n_f32 += (unsigned)(pe - pb);
               for (int p = pb; p < pe; p++) {
                 const float4 v = g.sorted[p];
                 const float dxf = v.x - qxf, dyf = v.y - qyf, dzf = v.z - qzf;
                 if (dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
+                  n_f64++;
                   const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
                   top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
                   accept = loosened(top.worst());
@@ -400,10 +406,20 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
       }
     }
     const double safe = (double)r * g.h + face;
-    if (top.worst() <= safe * safe) return true;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
-    if (top.found >= g.n) return true;            // the whole cloud has been seen (clouds smaller than k)
+    const bool done = top.worst() <= safe * safe   // every unvisited point is farther than the current k-th (or than max_sq_dist)
+                      || top.found >= g.n;         // the whole cloud has been seen (clouds smaller than k)
+    if (done || r == rlast) {
+      if (g.counters) {
+        atomicAdd(g.counters + 0, 1ull);
+        atomicAdd(g.counters + 1, (unsigned long long)n_f32);
+        atomicAdd(g.counters + 2, (unsigned long long)n_f64);
+        atomicAdd(g.counters + 3, (unsigned long long)n_blk);
+        atomicAdd(g.counters + 4, (unsigned long long)n_cell);
+      }
+      return done || rlast >= rmax;
+    }
   }
-  return rlast >= rmax;  // the whole box was walked
+  return rlast >= rmax;  // (r0 > rlast: nothing to walk)
 }
 
 // what a search runs on: the binned structure, or -- for clouds whose bounding box is too large for it -- the hashed multi-level grid
@@ -636,7 +652,8 @@ __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const flo
 // chasing, no divergence in the scan loop.  A query is settled when its k-th distance is no larger than its distance to the border of
 // that region (>= one block edge): every point outside is farther.  Anything else -- sparse neighbourhoods, blocks too dense for a
 // workgroup -- is flagged in `todo` and goes through the per-lane search above, so the result is exact either way.
-constexpr int kTileCand = 2048;        // candidates per LDS chunk (32 KB)
+constexpr int kTileThreads = 64;       // ONE wave per workgroup: a block holds ~30-90 queries, so a second wave would mostly idle at the barriers
+constexpr int kTileCand = 1024;        // candidates per LDS chunk (16 KB)
 constexpr int kTileMaxQueries = 1024;  // larger blocks (dense near field) are left to the per-lane search, which settles them in <= 2 shells
 constexpr long long kTileMaxPairs = 8ll << 20;
 constexpr int kTileQueue = 32;         // per-lane queue of candidates that passed the f32 filter (2 B each)
@@ -680,20 +697,21 @@ struct TopF {
 // query is settled only if (i) the k-th exact distance is below the 12th f32 distance by more than f32 rounding -- so nothing that was
 // filtered out can belong to the k nearest -- and (ii) it is no larger than the distance to the region's border.
 template <int KMAX>
-__global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, const int* __restrict__ occ_blocks, const float* __restrict__ points, int k,
-                                                               float* __restrict__ covs, unsigned char* __restrict__ todo) {
+__global__ void __launch_bounds__(kTileThreads) covariance_tiled_kernel(BinGridView g, const int* __restrict__ occ_blocks, const float* __restrict__ points, int k,
+                                                                        float* __restrict__ covs, unsigned char* __restrict__ todo) {
   static_assert(KMAX + 2 <= kTileKeep, "two entries of slack");
   __shared__ float4 cand[kTileCand];
-  __shared__ unsigned short queue[kTileQueue][256];  // [slot][lane]: a lane's slots are 512 B apart -> the 64 lanes of a wave hit 32 banks twice
+  __shared__ unsigned short queue[kTileQueue][kTileThreads];
   __shared__ int rstart[27], rpref[28];
+  const int lane = threadIdx.x;
   const long long b = occ_blocks[blockIdx.x];  // work list: the occupied blocks only (a LiDAR box is >99 % empty blocks)
   const GridBlock me = g.blocks[b];
   if (me.bits == 0ull) return;
   const int q0 = g.cell_start[me.base];
   const int Q = g.cell_start[me.base + __popcll(me.bits)] - q0;
   const int bx = (int)(b % g.geom.dim[0]), by = (int)((b / g.geom.dim[0]) % g.geom.dim[1]), bz = (int)(b / ((long long)g.geom.dim[0] * g.geom.dim[1]));
-  if (threadIdx.x < 27) {
-    const int nx = bx + (int)(threadIdx.x % 3) - 1, ny = by + (int)((threadIdx.x / 3) % 3) - 1, nz = bz + (int)(threadIdx.x / 9) - 1;
+  if (lane < 27) {
+    const int nx = bx + (lane % 3) - 1, ny = by + ((lane / 3) % 3) - 1, nz = bz + (lane / 9) - 1;
     int start = 0, len = 0;
     if (nx >= 0 && nx < g.geom.dim[0] && ny >= 0 && ny < g.geom.dim[1] && nz >= 0 && nz < g.geom.dim[2]) {
       const GridBlock nb = g.blocks[((long long)nz * g.geom.dim[1] + ny) * g.geom.dim[0] + nx];
@@ -702,35 +720,34 @@ __global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, co
         len = g.cell_start[nb.base + __popcll(nb.bits)] - start;
       }
     }
-    rstart[threadIdx.x] = start;
-    rpref[threadIdx.x + 1] = len;
+    rstart[lane] = start;
+    rpref[lane + 1] = len;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     rpref[0] = 0;
     for (int t = 0; t < 27; t++) rpref[t + 1] += rpref[t];
   }
   __syncthreads();
   const int C = rpref[27];
   if (Q > kTileMaxQueries || (long long)Q * C > kTileMaxPairs) {
-    for (int t = threadIdx.x; t < Q; t += 256) todo[q0 + t] = 1;
+    for (int t = lane; t < Q; t += kTileThreads) todo[q0 + t] = 1;
     return;
   }
   // the region's faces (metres): blocks bx-1 .. bx+1 along every axis
   const double edge = 4.0 * g.h;
   const double rlo[3] = {(double)(g.geom.lo[0] + bx - 1) * edge, (double)(g.geom.lo[1] + by - 1) * edge, (double)(g.geom.lo[2] + bz - 1) * edge};
-  for (int pass = 0; pass * 256 < Q; pass++) {
-    const int qi = pass * 256 + (int)threadIdx.x;
+  for (int pass = 0; pass * kTileThreads < Q; pass++) {
+    const int qi = pass * kTileThreads + lane;
     const bool active = qi < Q;
     const float4 self = g.sorted[q0 + (active ? qi : 0)];
-    const bool wave_active = pass * 256 + (int)(threadIdx.x & ~63u) < Q;  // wave-uniform: this wave holds at least one query
     TopF top;
     top.init();
     int queued = 0;
     auto drain = [&]() {  // every lane inserts its own queued candidates (f32 distance recomputed from LDS)
       for (int i = 0; __any(i < queued); i++) {
         if (i < queued) {
-          const float4 v = cand[queue[i][threadIdx.x]];
+          const float4 v = cand[queue[i][lane]];
           const float dxf = v.x - self.x, dyf = v.y - self.y, dzf = v.z - self.z;
           top.push(__float_as_int(v.w), dxf * dxf + dyf * dyf + dzf * dzf);
         }
@@ -740,7 +757,7 @@ __global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, co
     for (int c0 = 0; c0 < C; c0 += kTileCand) {
       __syncthreads();  // the previous chunk has been consumed
       const int cnt = min(kTileCand, C - c0);
-      for (int i = threadIdx.x; i < cnt; i += 256) {
+      for (int i = lane; i < cnt; i += kTileThreads) {
         const int gi = c0 + i;
         int r = 0;
 #pragma unroll
@@ -748,22 +765,34 @@ __global__ void __launch_bounds__(256) covariance_tiled_kernel(BinGridView g, co
         cand[i] = g.sorted[rstart[r] + (gi - rpref[r])];
       }
       __syncthreads();
-      if (wave_active) {
-        float thr = top.bound();
-        for (int j = 0; j < cnt; j++) {
-          const float4 v = cand[j];  // every lane reads the same address: broadcast
-          const float dxf = v.x - self.x, dyf = v.y - self.y, dzf = v.z - self.z;
-          if (active && dxf * dxf + dyf * dyf + dzf * dzf < thr) {
-            queue[queued][threadIdx.x] = (unsigned short)j;
-            queued++;
-          }
-          if (__any(queued == kTileQueue)) {
-            drain();
-            thr = top.bound();
-          }
+      float thr = top.bound();
+      // four candidates per step: the four broadcast reads are in flight together, one queue-full test per step
+      const int cnt4 = cnt & ~3;
+      for (int j = 0; j < cnt4; j += 4) {
+        const float4 v0 = cand[j], v1 = cand[j + 1], v2 = cand[j + 2], v3 = cand[j + 3];
+        const float ax = v0.x - self.x, ay = v0.y - self.y, az = v0.z - self.z;
+        const float bx_ = v1.x - self.x, by_ = v1.y - self.y, bz_ = v1.z - self.z;
+        const float cx_ = v2.x - self.x, cy_ = v2.y - self.y, cz_ = v2.z - self.z;
+        const float dx_ = v3.x - self.x, dy_ = v3.y - self.y, dz_ = v3.z - self.z;
+        const float d0 = ax * ax + ay * ay + az * az, d1 = bx_ * bx_ + by_ * by_ + bz_ * bz_;
+        const float d2 = cx_ * cx_ + cy_ * cy_ + cz_ * cz_, d3 = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
+        if (active) {
+          if (d0 < thr) queue[queued++][lane] = (unsigned short)j;
+          if (d1 < thr) queue[queued++][lane] = (unsigned short)(j + 1);
+          if (d2 < thr) queue[queued++][lane] = (unsigned short)(j + 2);
+          if (d3 < thr) queue[queued++][lane] = (unsigned short)(j + 3);
         }
-        drain();  // the chunk is about to be replaced
+        if (__any(queued > kTileQueue - 4)) {
+          drain();
+          thr = top.bound();
+        }
       }
+      for (int j = cnt4; j < cnt; j++) {
+        const float4 v = cand[j];
+        const float dxf = v.x - self.x, dyf = v.y - self.y, dzf = v.z - self.z;
+        if (active && dxf * dxf + dyf * dyf + dzf * dzf < thr) queue[queued++][lane] = (unsigned short)j;
+      }
+      drain();  // the chunk is about to be replaced (at most kTileQueue - 4 + 3 entries are queued)
     }
     if (active) {
       // exact re-score of the kept candidates in f64, in f32 rank order
@@ -898,6 +927,8 @@ struct gp_grid_level {
   }
 };
 
+static unsigned long long* g_knn_counters = nullptr;  // device buffer of 8 counters, or null (gp_debug_knn_counters)
+
 struct gp_point_grid {
   // default: the binned structure (gp_binning.hpp) + the cell-sorted copy of the points, in up to kMaxLevels levels (cell x4 each)
   struct BinLevel {
@@ -924,6 +955,7 @@ struct gp_point_grid {
         v.bins[l].inv_h = 1.0 / b.h;
         v.bins[l].h = b.h;
         v.bins[l].n = b.bins.num_binned;
+        v.bins[l].counters = g_knn_counters;
       }
     } else {
       v.hashed.num_levels = (int)levels.size();
@@ -934,8 +966,8 @@ struct gp_point_grid {
 };
 
 static bool g_force_hashed_grid = false;  // gp_debug_set_knn_structure: A/B and tests of the fallback
-static bool g_knn_untiled = false;        // gp_debug_set_knn_structure(2): binned structure, per-lane search only (A/B)
-static int g_knn_levels = gp::kMaxLevels;  // levels of the next binned grid (the GICP factor asks for one)
+static bool g_knn_untiled = true;         // false (gp_debug_set_knn_structure(3)): covariance estimation tiled per occupied block (measured slower)
+static int g_knn_levels = 2;  // levels of the next binned grid: h and 4h (the GICP factor asks for one)
 
 struct gp_gicp_factor {
   gp_point_grid* grid = nullptr;
@@ -1112,9 +1144,27 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   return GP_OK;
 }
 
+// measurement hook: start (enable != 0: zero the counters and count from now on) / stop-and-read (enable == 0) the work counters of the
+// binned search: out[0..4] = {queries (counted once per level they walk), f32 distance evaluations, f64 distance evaluations, block entries
+// read, occupied cells visited}.  Structures created while counting carry the counter pointer.
+int gp_debug_knn_counters(int enable, unsigned long long* out) {
+  if (enable) {
+    if (!g_knn_counters) GP_HIP(hipMalloc(reinterpret_cast<void**>(&g_knn_counters), sizeof(unsigned long long) * 8));
+    GP_HIP(hipMemset(g_knn_counters, 0, sizeof(unsigned long long) * 8));
+    return GP_OK;
+  }
+  if (g_knn_counters) {
+    GP_HIP(hipDeviceSynchronize());
+    if (out) GP_HIP(hipMemcpy(out, g_knn_counters, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost));
+    (void)hipFree(g_knn_counters);
+    g_knn_counters = nullptr;
+  }
+  return GP_OK;
+}
+
 int gp_debug_set_knn_structure(int mode) {
   g_force_hashed_grid = mode == 1;
-  g_knn_untiled = mode == 2;
+  g_knn_untiled = mode != 3;
   return GP_OK;
 }
 
@@ -1166,9 +1216,17 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
       rc = todo.alloc_async((size_t)nq, s);
       if (rc == GP_OK) {
         (void)hipMemsetAsync(todo.ptr, 0, (size_t)nq, s);
-        hipLaunchKernelGGL(gp::covariance_tiled_kernel<10>, dim3((unsigned)g->bin_levels[0]->bins.num_occ_blocks), dim3(256), 0, s, v.bins[0],
+        hipLaunchKernelGGL(gp::covariance_tiled_kernel<10>, dim3((unsigned)g->bin_levels[0]->bins.num_occ_blocks), dim3(gp::kTileThreads), 0, s, v.bins[0],
                            (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), points_dev, k, covs_dev, todo.as<unsigned char>());
         d_todo = todo.as<unsigned char>();
+        if (getenv("GP_KNN_DEBUG")) {  // how much the tiled pass left over
+          std::vector<unsigned char> h((size_t)nq);
+          (void)hipMemcpyAsync(h.data(), todo.ptr, (size_t)nq, hipMemcpyDeviceToHost, s);
+          (void)hipStreamSynchronize(s);
+          long long left = 0;
+          for (unsigned char c : h) left += c;
+          fprintf(stderr, "gp_estimate_covariances: tiled pass over %d blocks settled %lld of %d queries\n", g->bin_levels[0]->bins.num_occ_blocks, (long long)nq - left, nq);
+        }
       }
     }
     if (nq > 0 && rc == GP_OK) {
@@ -1199,7 +1257,7 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
   // finest cell = 1/4 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
   g_knn_levels = 1;  // the distance bound ends every search within 4 shells of the finest level
   int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 4.0, stream, &f->grid);
-  g_knn_levels = gp::kMaxLevels;
+  g_knn_levels = 2;
   if (rc != GP_OK) {
     delete f;
     return rc;

@@ -358,9 +358,13 @@ int gp_debug_set_variant(int variant);
 /* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
  * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
 int gp_debug_set_map_build(int hashed);
-/* A/B hook: 0 = binned structure, covariance estimation tiled per occupied block (default); 1 = hashed multi-level grid (also the
- * fallback of clouds whose bounding box is too large for the block grid); 2 = binned structure, per-lane search only */
+/* A/B hook: 0 = binned structure, per-lane search (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding box
+ * is too large for the block grid); 3 = binned structure with covariance estimation tiled per occupied block (27-block neighbourhood
+ * staged through LDS; exact, measured 4x slower than the per-lane search: DESIGN.md section 4.8) */
 int gp_debug_set_knn_structure(int mode);
+/* measurement hook: enable != 0 zeroes and starts the work counters of the binned search; enable == 0 stops and reads them:
+ * out[0..4] = {queries, f32 distance evaluations, f64 distance evaluations, block entries read, occupied cells visited} */
+int gp_debug_knn_counters(int enable, unsigned long long* out);
 /* tuning knob: the odd wave slots of every SIMD start `units` x 512 clocks late (0 = off, default) */
 int gp_debug_set_stagger(int units);
 /* timeline hook: per-workgroup phase timestamps (s_memtime) of the default pipeline kernel into dev_buffer ([num_tiles][16] uint64:

@@ -15,6 +15,8 @@ import gtsam_points_amd as gpa  # noqa: E402
 from gtsam_points_amd import synthetic  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "map"
+if os.environ.get("GP_KNN_MODE"):
+    gpa.load().gp_debug_set_knn_structure(int(os.environ["GP_KNN_MODE"]))
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 d = synthetic.make_c2_workload(1_000_000, 2_000_000 if what == "map" else 1_000_000, seed=42)
 if what == "map":
