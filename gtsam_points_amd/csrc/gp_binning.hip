@@ -1,6 +1,10 @@
 // gp_binning.hip -- see gp_binning.hpp
 #include "gp_binning.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "gp_sort.hpp"
 
 namespace gp {
@@ -150,6 +154,9 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
     return GP_OK;
   }
   const int wgs = (n + 255) / 256;
+  const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   // ---- bounding box ----
   DeviceArray boxes, d_small;
   GP_TRY(boxes.alloc_async(sizeof(int) * 6 * (size_t)wgs, s));
@@ -160,6 +167,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   int h_bbox[6];
   GP_HIP(hipMemcpyAsync(h_bbox, d_small.ptr, sizeof(h_bbox), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));
+  const double t1 = now();
   if (h_bbox[0] > h_bbox[3]) {  // no finite point at all
     GP_TRY(bins->cell_start.alloc_pooled(sizeof(int), s));
     GP_HIP(hipMemsetAsync(bins->cell_start.ptr, 0, sizeof(int), s));
@@ -209,7 +217,9 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   const int* d_total = scan_scratch.as<int>() + scan_blocks;  // the scan's grand total = number of cells
   int h_cells = 0;
   GP_HIP(hipMemcpyAsync(&h_cells, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
+  const double t2 = now();
   GP_HIP(hipStreamSynchronize(s));  // the cell count sizes cell_start
+  const double t3 = now();
   bins->num_cells = h_cells;
   GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)h_cells + 1), s));
   GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)std::max(h_cells, 1), s));
@@ -236,6 +246,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_HIP(hipStreamSynchronize(s));
   bins->num_occ_blocks = h_occ;
   bins->num_binned = h_binned;
+  if (dbg) fprintf(stderr, "bin_points: bbox %.0f us, sort issue %.0f us, wait %.0f us, finish %.0f us\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
   return GP_OK;
 }
 

@@ -29,6 +29,58 @@ int hip_fail(hipError_t err, const char* expr, const char* file, int line);
     if (gp_rc__ != GP_OK) return gp_rc__; \
   } while (0)
 
+// Per-thread cache of stream-ordered blocks.  hipMallocAsync / hipFreeAsync cost 20-50 us apiece on this stack even when the pool
+// holds the memory, and the structure builds (bin_points, voxel-map insert, k-NN grid) take ~15 scratch arrays each: the allocator
+// calls were 1-2 ms of a 3 ms covariance estimation.  A released block is parked here, tagged with the stream in whose order it
+// was released (nullptr: the owner synchronised the device first, so any stream may take it), and handed to the next request of
+// the same device and stream whose size it fits (<= 2x).  Bounded: kMaxEntries blocks / kMaxBytes; beyond that blocks go back to
+// the pool.  gp_trim_device_cache() empties it.
+struct BlockCache {
+  struct Entry {
+    void* ptr;
+    size_t bytes;
+    hipStream_t stream;
+    int device;
+  };
+  static constexpr size_t kMaxEntries = 96;
+  static constexpr size_t kMaxBytes = size_t(4) << 30;
+  std::vector<Entry> entries;
+  size_t total = 0;
+  static BlockCache& get() {
+    static thread_local BlockCache c;
+    return c;
+  }
+  void* take(size_t n, hipStream_t stream, int device, size_t* got) {
+    int best = -1;
+    for (int i = 0; i < (int)entries.size(); i++) {
+      const Entry& e = entries[i];
+      if (e.device != device || (e.stream != nullptr && e.stream != stream) || e.bytes < n || e.bytes > 2 * n + 4096) continue;
+      if (best < 0 || e.bytes < entries[best].bytes) best = i;
+    }
+    if (best < 0) return nullptr;
+    void* p = entries[best].ptr;
+    *got = entries[best].bytes;
+    total -= entries[best].bytes;
+    entries[best] = entries.back();
+    entries.pop_back();
+    return p;
+  }
+  bool put(void* p, size_t bytes, hipStream_t stream, int device) {
+    if (entries.size() >= kMaxEntries || total + bytes > kMaxBytes) return false;
+    entries.push_back({p, bytes, stream, device});
+    total += bytes;
+    return true;
+  }
+  void trim() {
+    if (entries.empty()) return;
+    (void)hipDeviceSynchronize();  // the tagged streams may be gone by now: everything is returned on the NULL stream
+    for (const Entry& e : entries) (void)hipFreeAsync(e.ptr, nullptr);
+    entries.clear();
+    total = 0;
+  }
+  ~BlockCache() {}  // at thread exit the blocks stay with the pool's owner (the process is usually going down; the runtime may be gone)
+};
+
 // RAII device allocation used for library-owned arrays
 struct DeviceArray {
   void* ptr = nullptr;
@@ -54,6 +106,7 @@ struct DeviceArray {
     std::swap(bytes, o.bytes);
     std::swap(pooled, o.pooled);
     std::swap(pool_stream, o.pool_stream);
+    std::swap(device, o.device);
   }
   // stream-ordered allocation from the device's default memory pool (cudaMallocAsync upstream, cuda/cuda_malloc_async.hpp):
   // for short-lived scratch -- a pooled block is reused by the next call instead of going through hipMalloc / hipFree, which
@@ -62,12 +115,19 @@ struct DeviceArray {
     release();
     if (n == 0) n = 16;
     keep_pool_memory();
-    hipError_t e = hipMallocAsync(&ptr, n, stream);
-    if (e != hipSuccess) {
-      ptr = nullptr;
-      return hip_fail(e, "hipMallocAsync", __FILE__, __LINE__);
+    (void)hipGetDevice(&device);
+    size_t got = 0;
+    if (void* cached = BlockCache::get().take(n, stream, device, &got)) {
+      ptr = cached;
+      bytes = got;
+    } else {
+      hipError_t e = hipMallocAsync(&ptr, n, stream);
+      if (e != hipSuccess) {
+        ptr = nullptr;
+        return hip_fail(e, "hipMallocAsync", __FILE__, __LINE__);
+      }
+      bytes = n;
     }
-    bytes = n;
     pooled = true;
     pool_stream = stream;
     return GP_OK;
@@ -80,11 +140,16 @@ struct DeviceArray {
     pool_stream = nullptr;
     return rc;
   }
+  // for owners that know every use of the array was ordered on `stream`: return it to the pool in that stream's order
+  void release_on(hipStream_t stream) {
+    if (pooled) pool_stream = stream;
+    release();
+  }
   int ensure_pooled(size_t n, hipStream_t stream) { return (n <= bytes && ptr) ? GP_OK : alloc_pooled(n + n / 5, stream); }
   void release() {
     if (ptr) {
       if (pooled) {
-        (void)hipFreeAsync(ptr, pool_stream);
+        if (!BlockCache::get().put(ptr, bytes, pool_stream, device)) (void)hipFreeAsync(ptr, pool_stream);
       } else {
         (void)hipFree(ptr);
       }
@@ -95,6 +160,7 @@ struct DeviceArray {
   }
   bool pooled = false;
   hipStream_t pool_stream = nullptr;
+  int device = 0;
   // the default pool hands memory back to the driver at every synchronisation unless told to keep it
   static void keep_pool_memory() {
     static thread_local int configured_device = -1;

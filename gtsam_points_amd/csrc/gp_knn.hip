@@ -12,6 +12,7 @@
 // f64 on the f32 inputs (as the reference does on PointCloudCPU's doubles), so the neighbour SET equals the kd-tree's
 // except for exact ties at the k-th distance (where the reference's own result depends on traversal order).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -308,6 +309,8 @@ struct BinGridView {
   GridGeom geom;
   double inv_h, h;
   int n;  // binned (finite) points
+  const unsigned long long* super;  // [sdim[2]][sdim[1]][sdim[0]] occupancy masks of 4 x 4 x 4 blocks, relative block coordinate >> 2
+  int sdim[3];
   unsigned long long* counters;  // measurement build only (gp_debug_knn_counters): {queries, f32 distances, f64 distances, block entries, cells}
 };
 
@@ -354,6 +357,34 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
   };
   float accept = loosened(top.worst());
   unsigned n_f32 = 0, n_f64 = 0, n_blk = 0, n_cell = 0;  // work counters: only read when g.counters is set (measurement runs)
+  // candidates of one cell: the loads of four consecutive points are issued together (a lane's loads miss L1 more often than not, and
+  // one round trip per point was the whole cost of this search), the tests follow in point order
+  auto test_point = [&](const float4 v) {
+    const float dxf = v.x - qxf, dyf = v.y - qyf, dzf = v.z - qzf;
+    if (dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
+      n_f64++;
+      const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
+      top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
+      accept = loosened(top.worst());
+    }
+  };
+  auto scan_range = [&](int pb, int pe) {
+    int p = pb;
+    for (; p + 4 <= pe; p += 4) {
+      const float4 v0 = g.sorted[p], v1 = g.sorted[p + 1], v2 = g.sorted[p + 2], v3 = g.sorted[p + 3];
+      test_point(v0);
+      test_point(v1);
+      test_point(v2);
+      test_point(v3);
+    }
+    if (p < pe) {
+      const int last = pe - 1;
+      const float4 v0 = g.sorted[p], v1 = g.sorted[min(p + 1, last)], v2 = g.sorted[min(p + 2, last)];
+      test_point(v0);
+      if (p + 1 < pe) test_point(v1);
+      if (p + 2 < pe) test_point(v2);
+    }
+  };
   const int rlast = (max_shells < rmax - r0) ? r0 + max_shells : rmax;
   for (int r = r0; r <= rlast; r++) {
     int b0[3], b1[3];
@@ -390,16 +421,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
               const int pb = g.cell_start[ord], pe = g.cell_start[ord + 1];
               n_cell++;
               n_f32 += (unsigned)(pe - pb);
-              for (int p = pb; p < pe; p++) {
-                const float4 v = g.sorted[p];
-                const float dxf = v.x - qxf, dyf = v.y - qyf, dzf = v.z - qzf;
-                if (dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
-                  n_f64++;
-                  const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
-                  top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
-                  accept = loosened(top.worst());
-                }
-              }
+              scan_range(pb, pe);
             }
           }
         }
@@ -422,26 +444,246 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
   return rlast >= rmax;  // (r0 > rlast: nothing to walk)
 }
 
+// First stage of a 1-NN search (GICP correspondences): the 2 x 2 x 2 cells nearest to the query -- its own cell and, per axis, the
+// neighbour on the side the query leans to.  Every point within min over the axes of max(f, 1 - f) >= 1/2 cells (f = the query's
+// position inside its cell) is in there, and a matched point's neighbour is a few centimetres away, so this settles almost every query with 8 cells instead of the
+// 27 of shells 0 + 1.  The 8 block entries are requested together, then the 8 cell ranges, then the points four at a time: three
+// dependent round trips in front of the point scan instead of one per block, cell and point.  Returns true when the bound is met;
+// otherwise the caller walks the shells with the list as it stands (a point pushed twice cannot displace itself in a 1-NN list).
+template <int KMAX>
+__device__ __forceinline__ bool knn_query_octant(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
+  static_assert(KMAX == 1, "duplicates are harmless only in a 1-NN list");
+  const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
+  if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;  // non-finite query: no neighbours
+  const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
+  const double f[3] = {ux - (double)c[0], uy - (double)c[1], uz - (double)c[2]};
+  int o[3];
+  double reach = 1.0e300;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    o[a] = f[a] < 0.5 ? -1 : 1;
+    reach = fmin(reach, fmax(f[a], 1.0 - f[a]));  // distance (cells) to the nearer end of the two-cell span along this axis
+  }
+  const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+  const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;  // as in knn_query_bins
+  auto loosened = [&](double worst) {
+    const float w = (float)worst;
+    return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
+  };
+  float accept = loosened(top.worst());
+  unsigned n_f32 = 0, n_f64 = 0, n_cell = 0;
+  int4 e[8];
+  int bit[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int cx = c[0] + ((i & 1) ? o[0] : 0), cy = c[1] + ((i & 2) ? o[1] : 0), cz = c[2] + ((i & 4) ? o[2] : 0);
+    const int bx = (cx >> 2) - g.geom.lo[0], by = (cy >> 2) - g.geom.lo[1], bz = (cz >> 2) - g.geom.lo[2];
+    bit[i] = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+    const bool in = bx >= 0 && bx < g.geom.dim[0] && by >= 0 && by < g.geom.dim[1] && bz >= 0 && bz < g.geom.dim[2];
+    e[i] = in ? *reinterpret_cast<const int4*>(g.blocks + ((size_t)bz * (size_t)g.geom.dim[1] + (size_t)by) * (size_t)g.geom.dim[0] + (size_t)bx) : make_int4(0, 0, 0, 0);
+  }
+  int pb[8], pe[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned long long bits = ((unsigned long long)(unsigned)e[i].y << 32) | (unsigned long long)(unsigned)e[i].x;
+    const bool occ = (bits >> bit[i]) & 1ull;
+    const int ord = e[i].z + __popcll(bits & ((1ull << bit[i]) - 1ull));
+    pb[i] = occ ? g.cell_start[ord] : 0;
+    pe[i] = occ ? g.cell_start[ord + 1] : 0;
+  }
+  auto test_point = [&](const float4 v) {
+    const float dxf = v.x - qxf, dyf = v.y - qyf, dzf = v.z - qzf;
+    if (dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
+      n_f64++;
+      const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
+      top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
+      accept = loosened(top.worst());
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (pe[i] > pb[i]) {
+      n_cell++;
+      n_f32 += (unsigned)(pe[i] - pb[i]);
+      const int last = pe[i] - 1;
+      for (int p = pb[i]; p < pe[i]; p += 4) {
+        const float4 v0 = g.sorted[p], v1 = g.sorted[min(p + 1, last)], v2 = g.sorted[min(p + 2, last)], v3 = g.sorted[min(p + 3, last)];
+        test_point(v0);  // (the clamped repeats of the last point are harmless in a 1-NN list)
+        test_point(v1);
+        test_point(v2);
+        test_point(v3);
+      }
+    }
+  }
+  if (g.counters) {
+    atomicAdd(g.counters + 5, 1ull);
+    atomicAdd(g.counters + 1, (unsigned long long)n_f32);
+    atomicAdd(g.counters + 2, (unsigned long long)n_f64);
+    atomicAdd(g.counters + 3, 8ull);
+    atomicAdd(g.counters + 4, (unsigned long long)n_cell);
+  }
+  const double safe = reach * g.h;
+  return top.worst() <= safe * safe;
+}
+
+// The same exact search one and two levels up WITHOUT further sorted copies: the 4 x 4 x 4-cell blocks of the grid are the cells of a
+// grid with four times the cell size, and because the points are sorted by (block, cell) a block's points are ONE contiguous range
+// of the sorted array -- [cell_start[base], cell_start[base + popcount(bits)]).  Queries whose neighbourhood is too sparse for the
+// fine shells (far field of a LiDAR scan) walk cube shells of blocks here, surface only.  SUPER: the cells are 4 x 4 x 4 BLOCKS
+// (16 x the cell size) and an entry is the 64-bit occupancy mask of its blocks (BinGridView::super) -- isolated points walk hundreds
+// of shells' worth of empty space in a few dozen 8-byte loads this way.  Entries of an x-row are contiguous in memory and are
+// requested four at a time: one round trip per (mostly empty) entry was what these walks cost.
+// Returns true when the search is complete (bound met, every point seen, or the box exhausted), false after max_shells + 1 shells.
+template <int KMAX, bool SUPER>
+__device__ __forceinline__ bool knn_query_coarse(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top, int max_shells) {
+  const double unit = (SUPER ? 16.0 : 4.0) * g.h, inv_unit = (SUPER ? 0.0625 : 0.25) * g.inv_h;
+  // SUPER coordinates are relative to the grid's first block (the grid origin is not a multiple of four blocks)
+  const double ux = qx * inv_unit - (SUPER ? 0.25 * (double)g.geom.lo[0] : 0.0), uy = qy * inv_unit - (SUPER ? 0.25 * (double)g.geom.lo[1] : 0.0),
+               uz = qz * inv_unit - (SUPER ? 0.25 * (double)g.geom.lo[2] : 0.0);
+  if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;
+  const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
+  const double fx = ux - (double)c[0], fy = uy - (double)c[1], fz = uz - (double)c[2];
+  const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * unit;
+  int lo[3], hi[3], r0 = 0, rmax = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = SUPER ? 0 : g.geom.lo[a];
+    hi[a] = SUPER ? g.sdim[a] - 1 : g.geom.lo[a] + g.geom.dim[a] - 1;
+    r0 = max(r0, max(lo[a] - c[a], c[a] - hi[a]));
+    rmax = max(rmax, max(abs(c[a] - lo[a]), abs(c[a] - hi[a])));
+  }
+  const int dimx = SUPER ? g.sdim[0] : g.geom.dim[0], dimy = SUPER ? g.sdim[1] : g.geom.dim[1];
+  const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+  const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;  // as in knn_query_bins
+  auto loosened = [&](double worst) {
+    const float w = (float)worst;
+    return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
+  };
+  float accept = loosened(top.worst());
+  unsigned n_f32 = 0, n_f64 = 0, n_blk = 0;
+  auto test_point = [&](const float4 v) {
+    const float dxf = v.x - qxf, dyf = v.y - qyf, dzf = v.z - qzf;
+    if (dxf * dxf + dyf * dyf + dzf * dzf <= accept) {
+      n_f64++;
+      const double ddx = (double)v.x - qx, ddy = (double)v.y - qy, ddz = (double)v.z - qz;
+      top.push(__float_as_int(v.w), ddx * ddx + ddy * ddy + ddz * ddz);
+      accept = loosened(top.worst());
+    }
+  };
+  auto scan_block = [&](const int4 raw) {
+    const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
+    if (bits == 0ull) return;
+    const int pb = g.cell_start[raw.z], pe = g.cell_start[raw.z + __popcll(bits)];
+    n_f32 += (unsigned)(pe - pb);
+    int p = pb;
+    for (; p + 4 <= pe; p += 4) {  // four loads in flight (a block holds a few hundred points at most)
+      const float4 v0 = g.sorted[p], v1 = g.sorted[p + 1], v2 = g.sorted[p + 2], v3 = g.sorted[p + 3];
+      test_point(v0);
+      test_point(v1);
+      test_point(v2);
+      test_point(v3);
+    }
+    for (; p < pe; p++) test_point(g.sorted[p]);
+  };
+  auto scan_super = [&](unsigned long long m, int sx, int sy, int sz) {  // occupied blocks of superblock (sx, sy, sz)
+    while (m) {
+      const int bit = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const int bx = 4 * sx + (bit & 3), by = 4 * sy + ((bit >> 2) & 3), bz = 4 * sz + (bit >> 4);
+      // a block farther away than the current k-th neighbour holds nothing of interest
+      const double e = 4.0 * g.h;
+      const double x0 = (double)(g.geom.lo[0] + bx) * e, y0 = (double)(g.geom.lo[1] + by) * e, z0 = (double)(g.geom.lo[2] + bz) * e;
+      const double ddx = fmax(fmax(x0 - qx, qx - (x0 + e)), 0.0), ddy = fmax(fmax(y0 - qy, qy - (y0 + e)), 0.0), ddz = fmax(fmax(z0 - qz, qz - (z0 + e)), 0.0);
+      if (ddx * ddx + ddy * ddy + ddz * ddz > top.worst()) continue;
+      n_blk++;
+      scan_block(*reinterpret_cast<const int4*>(g.blocks + ((size_t)bz * (size_t)g.geom.dim[1] + (size_t)by) * (size_t)g.geom.dim[0] + (size_t)bx));
+    }
+  };
+  // entries xa .. xb (step `step`) of one x-row
+  auto visit_row = [&](int xa, int xb, int step, int y, int z) {
+    const size_t row0 = ((size_t)(z - lo[2]) * (size_t)dimy + (size_t)(y - lo[1])) * (size_t)dimx;
+    for (int x = xa; x <= xb; x += 4 * step) {
+      if constexpr (SUPER) {
+        unsigned long long e[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) e[i] = g.super[row0 + (size_t)(min(x + i * step, xb) - lo[0])];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (x + i * step <= xb) scan_super(e[i], x + i * step, y, z);
+      } else {
+        int4 e[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) e[i] = *reinterpret_cast<const int4*>(g.blocks + row0 + (size_t)(min(x + i * step, xb) - lo[0]));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (x + i * step <= xb) {
+            n_blk++;
+            scan_block(e[i]);
+          }
+      }
+    }
+  };
+  bool done = false;
+  const int rlast = (max_shells < rmax - r0) ? r0 + max_shells : rmax;
+  for (int r = r0; r <= rlast && !done; r++) {
+    const int z0 = max(c[2] - r, lo[2]), z1 = min(c[2] + r, hi[2]);
+    const int y0 = max(c[1] - r, lo[1]), y1 = min(c[1] + r, hi[1]);
+    const int x0 = max(c[0] - r, lo[0]), x1 = min(c[0] + r, hi[0]);
+    if (z0 <= z1 && y0 <= y1 && x0 <= x1) {
+      for (int z = z0; z <= z1; z++) {
+        const bool zface = z == c[2] - r || z == c[2] + r;
+        for (int y = y0; y <= y1; y++) {
+          if (zface || y == c[1] - r || y == c[1] + r || r == 0) {
+            visit_row(x0, x1, 1, y, z);
+          } else {  // interior row of the cube: only its two end entries belong to the shell
+            const int xa = c[0] - r >= lo[0] ? c[0] - r : c[0] + r, xb = c[0] + r <= hi[0] ? c[0] + r : c[0] - r;
+            if (xa >= lo[0] && xa <= hi[0] && xb >= xa) visit_row(xa, xb, xb > xa ? xb - xa : 1, y, z);
+          }
+        }
+      }
+    }
+    const double safe = (double)r * unit + face;
+    done = top.worst() <= safe * safe || top.found >= g.n;
+  }
+  if (g.counters) {
+    atomicAdd(g.counters + 0, 1ull);
+    atomicAdd(g.counters + 1, (unsigned long long)n_f32);
+    atomicAdd(g.counters + 2, (unsigned long long)n_f64);
+    atomicAdd(g.counters + 3, (unsigned long long)n_blk);
+  }
+  return done || rlast >= rmax;
+}
+
 // what a search runs on: the binned structure, or -- for clouds whose bounding box is too large for it -- the hashed multi-level grid
-// LiDAR density spans three orders of magnitude between the near and the far field, so the binned structure comes in up to three
-// levels (cell size x4 per level): a query first tries the finest level for the shells 0 and 1 (<= 8 block entries); when that does not
-// settle it (sparse neighbourhood) it starts over on the next coarser level; the coarsest level walks on until the bound is met.
-// Every level is searched exactly, so the choice of level affects speed only.
+// LiDAR density spans three orders of magnitude between the near and the far field: a query first tries the shells 0 and 1 of the
+// cells (<= 8 block entries); when that does not settle it (sparse neighbourhood) it starts over on the blocks taken as cells four
+// times the size, and then on the superblocks (knn_query_coarse), which it walks until the bound is met.  (More binned levels, cell size x4 each, can be stacked in
+// between -- gp_debug_set_knn_structure -- but building them costs more than they save.)  Every stage is an exact search, so the
+// staging affects speed only.
 struct SearchView {
   int binned;      // number of binned levels (0: hashed fallback)
   BinGridView bins[kMaxLevels];
   MultiGridView hashed;
 };
 
+// stage 0: cell shells 0 .. 4 (occupied cells only: work-efficient while the neighbourhood is a few cells wide); stage 1: superblock
+// shells -- blocks as cells, those beyond the current k-th distance skipped -- until the bound is met or the box is exhausted
 template <int KMAX>
-__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX>& top) {
+__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX>& top, bool skip_fine = false) {
   if (g.binned) {
     const int k = top.k;
     const double bound = top.worst();  // the caller's max_sq_dist (nothing has been pushed yet)
+    // (skip_fine: the row-tiled pass has scanned the shells 0 and 1 of the finest level, which therefore cannot settle the query; the
+    // walk still starts there -- the list is not carried over -- but goes on to shell 4 at once)
+    if constexpr (KMAX == 1) {
+      if (knn_query_octant<KMAX>(g.bins[0], qx, qy, qz, top)) return;
+    }
     for (int l = 0; l < g.binned; l++) {
       if (l > 0) top.init(k, bound);
-      if (knn_query_bins<KMAX>(g.bins[l], qx, qy, qz, top, l + 1 < g.binned ? 1 : 0x3fffffff)) return;
+      if (knn_query_bins<KMAX>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : 4)) return;
     }
+    top.init(k, bound);
+    knn_query_coarse<KMAX, true>(g.bins[g.binned - 1], qx, qy, qz, top, 0x3fffffff);
   } else {
     knn_query_multi<KMAX>(g.hashed, qx, qy, qz, want, top);
   }
@@ -455,6 +697,15 @@ __global__ void __launch_bounds__(256) nonfinite_identity_kernel(const float* __
   if (fabsf(x) < 3.0e38f && fabsf(y) < 3.0e38f && fabsf(z) < 3.0e38f) return;
   for (int j = 0; j < 9; j++) covs[9 * (size_t)i + j] = (j % 4 == 0) ? 1.0f : 0.0f;
   atomicAdd(num_short, 1);
+}
+
+// superblock occupancy: bit (bx & 3) + 4 (by & 3) + 16 (bz & 3) of entry (bx >> 2, by >> 2, bz >> 2), relative block coordinates
+__global__ void super_mark_kernel(const int* __restrict__ occ_blocks, int num, GridGeom geom, int sdim0, int sdim1, unsigned long long* __restrict__ super) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  const long long b = occ_blocks[i];
+  const int bx = (int)(b % geom.dim[0]), by = (int)((b / geom.dim[0]) % geom.dim[1]), bz = (int)(b / ((long long)geom.dim[0] * geom.dim[1]));
+  atomicOr(super + ((size_t)(bz >> 2) * sdim1 + (by >> 2)) * sdim0 + (bx >> 2), 1ull << ((bx & 3) | ((by & 3) << 2) | ((bz & 3) << 4)));
 }
 
 __global__ void __launch_bounds__(256) gather_sorted_kernel(const float* __restrict__ points, const int* __restrict__ order, int n, float4* __restrict__ sorted) {
@@ -622,13 +873,16 @@ __device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX>& top
 }
 
 // estimate_covariances, per-lane search (every query walks its own shells; see knn_query_bins / knn_query): the general path, and
-// the second pass of the tiled kernel below for the queries it left over (todo != nullptr: only positions with todo[t] != 0)
+// the second pass of the tiled kernel below for the queries it left over (todo_list != nullptr: the *todo_count positions listed)
 template <int KMAX>
 __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
-                                                         int* __restrict__ num_short, const unsigned char* __restrict__ todo) {
-  const int t = blockIdx.x * 128 + threadIdx.x;
+                                                         int* __restrict__ num_short, const int* __restrict__ todo_list, const int* __restrict__ todo_count) {
+  int t = blockIdx.x * 128 + threadIdx.x;
+  if (todo_list) {
+    if (t >= *todo_count) return;
+    t = todo_list[t];
+  }
   if (t >= n) return;
-  if (todo && !todo[t]) return;
   // queries are taken in the finest grid's cell-sorted order: the lanes of a wave then sit in the same or adjacent cells,
   // walk the same shells and read the same cell ranges (coherent loads, little divergence); results go to the original index
   const float4 self = g.binned ? g.bins[0].sorted[t] : g.hashed.lv[0].sorted[t];
@@ -636,7 +890,7 @@ __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const flo
   const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
   TopK<KMAX> top;
   top.init(k, 1.7976931348623157e308);
-  knn_query_any<KMAX>(g, qx, qy, qz, 2 * k, top);
+  knn_query_any<KMAX>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr);
   float* out = covs + 9 * (size_t)i;
   if (top.found < k) {
     atomicAdd(num_short, 1);
@@ -646,18 +900,22 @@ __global__ void __launch_bounds__(128) covariance_kernel(SearchView g, const flo
   covariance_from_neighbours<KMAX>(top, points, k, out);
 }
 
-// estimate_covariances, tiled: ONE WORKGROUP PER OCCUPIED BLOCK of the finest binned level.  The queries are the block's own points
-// (one contiguous range of the cell-sorted array); the candidates are all points of the 3 x 3 x 3 blocks around it (27 contiguous
-// ranges), staged through LDS in chunks and scanned by every query lane with broadcast reads: coalesced loads, no per-lane pointer
-// chasing, no divergence in the scan loop.  A query is settled when its k-th distance is no larger than its distance to the border of
-// that region (>= one block edge): every point outside is farther.  Anything else -- sparse neighbourhoods, blocks too dense for a
-// workgroup -- is flagged in `todo` and goes through the per-lane search above, so the result is exact either way.
-constexpr int kTileThreads = 64;       // ONE wave per workgroup: a block holds ~30-90 queries, so a second wave would mostly idle at the barriers
-constexpr int kTileCand = 1024;        // candidates per LDS chunk (16 KB)
-constexpr int kTileMaxQueries = 1024;  // larger blocks (dense near field) are left to the per-lane search, which settles them in <= 2 shells
-constexpr long long kTileMaxPairs = 8ll << 20;
-constexpr int kTileQueue = 32;         // per-lane queue of candidates that passed the f32 filter (2 B each)
-constexpr int kTileKeep = 12;          // f32 top list: k (<= 10) + 2 entries of slack for the exactness check
+// estimate_covariances, tiled: ONE WAVE PER OCCUPIED CELL ROW (the <= 4 x-adjacent cells of one (y, z) row of a block).  The queries
+// are the row's own points -- one contiguous range of the cell-sorted array, ~20-70 of them -- and the candidates are the points of the
+// cells x_min-1 .. x_max+1 of the 3 x 3 rows around it: 27 (block, row, x-mask) pieces, each again ONE contiguous range because
+// occupied cells of a row have consecutive ordinals.  The 27 lookups run on 27 lanes at once (one latency chain for the whole row
+// instead of one per lane and cell), the candidates are staged through LDS with coalesced loads and scanned by every query lane with
+// broadcast reads: no per-lane pointer chasing, no divergence in the scan loop, and only ~1.5x the candidates a single query needs
+// (the block-sized tiles tried first scanned 15-30x: DESIGN.md section 4.8).  A query is settled when its k-th distance is no
+// larger than its distance to the border of that region (>= one cell edge): every point outside is farther.  Anything else -- sparse
+// neighbourhoods, rows too dense for one wave -- is appended to `todo_list` and goes through the per-lane search, so the result is
+// exact either way.
+constexpr int kRowThreads = 64;       // one wave per workgroup: __syncthreads() is free and rows finish independently
+constexpr int kRowCand = 256;         // candidates per LDS chunk (4 KB)
+constexpr int kRowMaxCand = 8192;     // denser neighbourhoods (near field) are left to the per-lane search
+constexpr int kRowMaxQueries = 512;
+constexpr int kTileQueue = 32;        // per-lane queue of candidates that passed the f32 filter (2 B each)
+constexpr int kTileKeep = 12;         // f32 top list: k (<= 10) + 2 entries of slack for the exactness check
 
 // f32 top list of the tiled kernel: same insertion rule as TopK, floats, compile-time indices only
 struct TopF {
@@ -690,55 +948,91 @@ struct TopF {
   }
 };
 
-// The scan loop costs ~12 cycles per candidate for a whole wave (LDS broadcast read, f32 distance, compare, a 2-byte LDS append for
-// the lanes whose candidate passes).  What passes is pushed into the lane's f32 top list only when a queue is full or the chunk ends
-// -- then every lane is busy with its OWN candidates, instead of the whole wave executing an insertion whenever any one lane has a
-// hit (which is every iteration).  At the end the <= 12 kept candidates are re-scored in f64 (the reference compares doubles) and the
-// query is settled only if (i) the k-th exact distance is below the 12th f32 distance by more than f32 rounding -- so nothing that was
-// filtered out can belong to the k nearest -- and (ii) it is no larger than the distance to the region's border.
-template <int KMAX>
-__global__ void __launch_bounds__(kTileThreads) covariance_tiled_kernel(BinGridView g, const int* __restrict__ occ_blocks, const float* __restrict__ points, int k,
-                                                                        float* __restrict__ covs, unsigned char* __restrict__ todo) {
-  static_assert(KMAX + 2 <= kTileKeep, "two entries of slack");
-  __shared__ float4 cand[kTileCand];
-  __shared__ unsigned short queue[kTileQueue][kTileThreads];
+// appends the sorted positions of the lanes with `flag` to todo_list (one atomic per wave; the order of the list does not matter:
+// every leftover query writes its own output slot)
+__device__ __forceinline__ void todo_append(bool flag, int pos, int* __restrict__ todo_list, int* __restrict__ todo_count) {
+  const unsigned long long m = __ballot(flag);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(todo_count, __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1, 64);
+  if (flag) todo_list[base + __popcll(m & ((1ull << lane) - 1ull))] = pos;
+}
+
+// Scan kernel.  The scan loop is an LDS broadcast read, an f32 distance, a compare and a 2-byte LDS append for the lanes whose
+// candidate passes.  What passes is pushed into the lane's f32 top list only when a queue is full or the chunk ends -- then every lane
+// is busy with its OWN candidates, instead of the whole wave executing an insertion whenever any one lane has a hit.  The pieces are
+// scanned own row first, so the acceptance threshold is tight after the first few dozen candidates.  Per query the kernel leaves the
+// kTileKeep nearest candidates by f32 distance (original indices), the kTileKeep-th f32 distance and the query's distance to the
+// border of the scanned region; the exact decision is taken by covariance_settle_kernel below with all lanes busy (a row fills a
+// quarter of a wave on average, and the f64 work is the expensive part).
+struct RowScanOut {
+  int* kept;     // [kTileKeep][nq] original indices (-1: none), by sorted position
+  float* bound;  // [nq] kTileKeep-th f32 squared distance (inf: fewer candidates than that), < 0: row not scanned
+  float* safe;   // [nq] distance to the border of the scanned region, rounded down
+  int nq;
+};
+
+__global__ void __launch_bounds__(kRowThreads) covariance_rows_kernel(BinGridView g, const int* __restrict__ occ_blocks, RowScanOut out, int knock) {
+  __shared__ float4 cand[kRowCand];
+  __shared__ unsigned short queue[kTileQueue][kRowThreads];
   __shared__ int rstart[27], rpref[28];
   const int lane = threadIdx.x;
-  const long long b = occ_blocks[blockIdx.x];  // work list: the occupied blocks only (a LiDAR box is >99 % empty blocks)
+  const int row = blockIdx.x & 15;                  // y + 4 z inside the block
+  const long long b = occ_blocks[blockIdx.x >> 4];  // work list: the occupied blocks only (a LiDAR box is >99 % empty blocks)
   const GridBlock me = g.blocks[b];
-  if (me.bits == 0ull) return;
-  const int q0 = g.cell_start[me.base];
-  const int Q = g.cell_start[me.base + __popcll(me.bits)] - q0;
-  const int bx = (int)(b % g.geom.dim[0]), by = (int)((b / g.geom.dim[0]) % g.geom.dim[1]), bz = (int)(b / ((long long)g.geom.dim[0] * g.geom.dim[1]));
+  const unsigned rowbits = (unsigned)(me.bits >> (4 * row)) & 0xFu;
+  if (rowbits == 0u) return;
+  const int ord0 = me.base + __popcll(me.bits & ((1ull << (4 * row)) - 1ull));
+  const int q0 = g.cell_start[ord0];
+  const int Q = g.cell_start[ord0 + __popc(rowbits)] - q0;
+  const int dim0 = g.geom.dim[0], dim1 = g.geom.dim[1], dim2 = g.geom.dim[2];
+  const int bx = (int)(b % dim0), by = (int)((b / dim0) % dim1), bz = (int)(b / ((long long)dim0 * dim1));
+  // cell coordinates relative to the grid's first cell; the candidate region is x in [cx_lo, cx_hi], y in cy +- 1, z in cz +- 1
+  const int cy = 4 * by + (row & 3), cz = 4 * bz + (row >> 2);
+  const int cx_lo = 4 * bx + (__ffs((int)rowbits) - 1) - 1, cx_hi = 4 * bx + (31 - __clz((int)rowbits)) + 1;
+  int len = 0;
   if (lane < 27) {
-    const int nx = bx + (lane % 3) - 1, ny = by + ((lane / 3) % 3) - 1, nz = bz + (lane / 9) - 1;
-    int start = 0, len = 0;
-    if (nx >= 0 && nx < g.geom.dim[0] && ny >= 0 && ny < g.geom.dim[1] && nz >= 0 && nz < g.geom.dim[2]) {
-      const GridBlock nb = g.blocks[((long long)nz * g.geom.dim[1] + ny) * g.geom.dim[0] + nx];
-      if (nb.bits) {
-        start = g.cell_start[nb.base];
-        len = g.cell_start[nb.base + __popcll(nb.bits)] - start;
+    // piece order: own row first, then the rows sharing a face with it, then the diagonal ones; own block column first in each
+    const int t = lane / 3, u = lane % 3;
+    const int dy = (int)((0x22161u >> (2 * t)) & 3u) - 1;  // two bits per entry: t = 0..8 -> dy = 0,-1,1, 0,0, -1,1,-1,1
+    const int dz = (int)((0x28215u >> (2 * t)) & 3u) - 1;  //                                    dz = 0, 0,0,-1,1, -1,-1,1,1
+    const int nbx = bx + (u == 0 ? 0 : (u == 1 ? -1 : 1)), ny = cy + dy, nz = cz + dz;
+    int start = 0;
+    const int lo = max(cx_lo - 4 * nbx, 0), hi = min(cx_hi - 4 * nbx, 3);  // cells of block column nbx inside the x-range
+    if (lo <= hi && nbx >= 0 && nbx < dim0 && ny >= 0 && ny < 4 * dim1 && nz >= 0 && nz < 4 * dim2) {
+      const GridBlock nb = g.blocks[((long long)(nz >> 2) * dim1 + (ny >> 2)) * dim0 + nbx];
+      const int sh = 4 * ((ny & 3) + 4 * (nz & 3)) + lo;
+      const unsigned m = (unsigned)(nb.bits >> sh) & ((2u << (hi - lo)) - 1u);
+      if (m) {
+        const int o = nb.base + __popcll(nb.bits & ((1ull << sh) - 1ull));
+        start = g.cell_start[o];
+        len = g.cell_start[o + __popc(m)] - start;
       }
     }
     rstart[lane] = start;
-    rpref[lane + 1] = len;
   }
-  __syncthreads();
-  if (lane == 0) {
-    rpref[0] = 0;
-    for (int t = 0; t < 27; t++) rpref[t + 1] += rpref[t];
+  int incl = len;  // inclusive prefix of the 27 piece lengths across the lanes
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
   }
+  if (lane < 27) rpref[lane + 1] = incl;
+  if (lane == 0) rpref[0] = 0;
   __syncthreads();
   const int C = rpref[27];
-  if (Q > kTileMaxQueries || (long long)Q * C > kTileMaxPairs) {
-    for (int t = lane; t < Q; t += kTileThreads) todo[q0 + t] = 1;
+  if (knock == 1) return;
+  if (Q > kRowMaxQueries || C > kRowMaxCand) {
+    for (int t = lane; t < Q; t += kRowThreads) out.bound[q0 + t] = -1.0f;
     return;
   }
-  // the region's faces (metres): blocks bx-1 .. bx+1 along every axis
-  const double edge = 4.0 * g.h;
-  const double rlo[3] = {(double)(g.geom.lo[0] + bx - 1) * edge, (double)(g.geom.lo[1] + by - 1) * edge, (double)(g.geom.lo[2] + bz - 1) * edge};
-  for (int pass = 0; pass * kTileThreads < Q; pass++) {
-    const int qi = pass * kTileThreads + lane;
+  // the region's faces (metres)
+  const double rlo[3] = {(double)(4 * g.geom.lo[0] + cx_lo) * g.h, (double)(4 * g.geom.lo[1] + cy - 1) * g.h, (double)(4 * g.geom.lo[2] + cz - 1) * g.h};
+  const double rhi[3] = {(double)(4 * g.geom.lo[0] + cx_hi + 1) * g.h, (double)(4 * g.geom.lo[1] + cy + 2) * g.h, (double)(4 * g.geom.lo[2] + cz + 2) * g.h};
+  for (int pass = 0; pass * kRowThreads < Q; pass++) {
+    const int qi = pass * kRowThreads + lane;
     const bool active = qi < Q;
     const float4 self = g.sorted[q0 + (active ? qi : 0)];
     TopF top;
@@ -754,17 +1048,18 @@ __global__ void __launch_bounds__(kTileThreads) covariance_tiled_kernel(BinGridV
       }
       queued = 0;
     };
-    for (int c0 = 0; c0 < C; c0 += kTileCand) {
+    for (int c0 = 0; c0 < C; c0 += kRowCand) {
       __syncthreads();  // the previous chunk has been consumed
-      const int cnt = min(kTileCand, C - c0);
-      for (int i = lane; i < cnt; i += kTileThreads) {
+      const int cnt = min(kRowCand, C - c0);
+      for (int i = lane; i < cnt; i += kRowThreads) {
         const int gi = c0 + i;
         int r = 0;
 #pragma unroll
-        for (int t = 1; t < 27; t++) r += (rpref[t] <= gi) ? 1 : 0;  // range holding candidate gi (prefix sums are non-decreasing)
+        for (int t = 1; t < 27; t++) r += (rpref[t] <= gi) ? 1 : 0;  // piece holding candidate gi (prefix sums are non-decreasing)
         cand[i] = g.sorted[rstart[r] + (gi - rpref[r])];
       }
       __syncthreads();
+      if (knock == 2) continue;
       float thr = top.bound();
       // four candidates per step: the four broadcast reads are in flight together, one queue-full test per step
       const int cnt4 = cnt & ~3;
@@ -783,6 +1078,7 @@ __global__ void __launch_bounds__(kTileThreads) covariance_tiled_kernel(BinGridV
           if (d3 < thr) queue[queued++][lane] = (unsigned short)(j + 3);
         }
         if (__any(queued > kTileQueue - 4)) {
+          if (knock == 3) queued = 0;
           drain();
           thr = top.bound();
         }
@@ -795,31 +1091,59 @@ __global__ void __launch_bounds__(kTileThreads) covariance_tiled_kernel(BinGridV
       drain();  // the chunk is about to be replaced (at most kTileQueue - 4 + 3 entries are queued)
     }
     if (active) {
-      // exact re-score of the kept candidates in f64, in f32 rank order
+      const size_t pos = (size_t)q0 + qi;
+#pragma unroll
+      for (int j = 0; j < kTileKeep; j++) out.kept[(size_t)j * out.nq + pos] = top.idx[j];
+      out.bound[pos] = top.bound();
+      double safe = 1.0e300;
+      const double q[3] = {(double)self.x, (double)self.y, (double)self.z};
+#pragma unroll
+      for (int a = 0; a < 3; a++) safe = fmin(safe, fmin(q[a] - rlo[a], rhi[a] - q[a]));
+      out.safe[pos] = (float)fmax(safe, 0.0) * 0.999999f;
+    }
+  }
+}
+
+// Decision kernel, one query per lane in sorted order: exact re-score of the kept candidates in f64 (the reference compares doubles),
+// in f32 rank order.  A query is settled only if (i) the k-th exact distance is below the kTileKeep-th f32 distance by more than f32
+// rounding -- everything that was filtered out has an f32 distance >= that, i.e. a true distance >= bound * (1 - 1e-5), so it cannot
+// belong to the k nearest -- and (ii) it is no larger than the distance to the region's border, so nothing outside the region can
+// either.  The rest is listed for the per-lane search.
+template <int KMAX>
+__global__ void __launch_bounds__(128) covariance_settle_kernel(const float4* __restrict__ sorted, RowScanOut in, const float* __restrict__ points, int k,
+                                                                float* __restrict__ covs, int* __restrict__ todo_list, int* __restrict__ todo_count) {
+  static_assert(KMAX + 2 <= kTileKeep, "two entries of slack");
+  const int pos = blockIdx.x * 128 + threadIdx.x;
+  const bool active = pos < in.nq;
+  bool leftover = false;
+  if (active) {
+    const float bound = in.bound[pos];
+    leftover = true;
+    if (bound >= 0.0f) {
+      const float4 self = sorted[pos];
       const double q[3] = {(double)self.x, (double)self.y, (double)self.z};
       TopK<KMAX> exact;
       exact.init(k, 1.7976931348623157e308);
+      int idx[kTileKeep];
+#pragma unroll
+      for (int j = 0; j < kTileKeep; j++) idx[j] = in.kept[(size_t)j * in.nq + pos];
 #pragma unroll
       for (int j = 0; j < kTileKeep; j++) {
-        if (top.idx[j] >= 0) {
-          const size_t nb = (size_t)top.idx[j];
+        if (idx[j] >= 0) {
+          const size_t nb = (size_t)idx[j];
           const double ddx = (double)points[3 * nb] - q[0], ddy = (double)points[3 * nb + 1] - q[1], ddz = (double)points[3 * nb + 2] - q[2];
-          exact.push(top.idx[j], ddx * ddx + ddy * ddy + ddz * ddz);
+          exact.push(idx[j], ddx * ddx + ddy * ddy + ddz * ddz);
         }
       }
-      double safe = 1.0e300;
-#pragma unroll
-      for (int a = 0; a < 3; a++) safe = fmin(safe, fmin(q[a] - rlo[a], rlo[a] + 3.0 * edge - q[a]));
-      // (i) nothing outside the kept list can be among the k nearest: everything that was filtered out has an f32 distance >= the
-      // 12th kept one, i.e. a true distance >= bound * (1 - 1e-5); (ii) nothing outside the region can
-      const bool separated = exact.worst() <= (double)top.bound() * (1.0 - 1.0e-5);
+      const double safe = (double)in.safe[pos];
+      const bool separated = exact.worst() <= (double)bound * (1.0 - 1.0e-5);
       if (exact.found >= k && separated && exact.worst() <= safe * safe) {
         covariance_from_neighbours<KMAX>(exact, points, k, covs + 9 * (size_t)__float_as_int(self.w));
-      } else {
-        todo[q0 + qi] = 1;
+        leftover = false;
       }
     }
   }
+  todo_append(leftover, pos, todo_list, todo_count);
 }
 
 // ---- GICP: 1-NN correspondence within max distance + the same H/b algebra as VGICP ------------------------------------
@@ -934,6 +1258,8 @@ struct gp_point_grid {
   struct BinLevel {
     gp::PointBins bins;
     gp::DeviceArray sorted;  // float4[num_binned]
+    gp::DeviceArray super;   // unsigned long long[sdim product]
+    int sdim[3] = {0, 0, 0};
     double h = 0.0;
   };
   std::vector<std::unique_ptr<BinLevel>> bin_levels;
@@ -955,6 +1281,8 @@ struct gp_point_grid {
         v.bins[l].inv_h = 1.0 / b.h;
         v.bins[l].h = b.h;
         v.bins[l].n = b.bins.num_binned;
+        v.bins[l].super = b.super.as<unsigned long long>();
+        for (int a = 0; a < 3; a++) v.bins[l].sdim[a] = b.sdim[a];
         v.bins[l].counters = g_knn_counters;
       }
     } else {
@@ -966,8 +1294,8 @@ struct gp_point_grid {
 };
 
 static bool g_force_hashed_grid = false;  // gp_debug_set_knn_structure: A/B and tests of the fallback
-static bool g_knn_untiled = true;         // false (gp_debug_set_knn_structure(3)): covariance estimation tiled per occupied block (measured slower)
-static int g_knn_levels = 2;  // levels of the next binned grid: h and 4h (the GICP factor asks for one)
+static bool g_knn_untiled = true;         // false (gp_debug_set_knn_structure(3)): row-tiled covariance pass in front of the per-lane search (measured slower)
+static int g_knn_levels = 1;  // binned levels of the next grid (cell size x4 each); the blocks of the last one serve as the coarse level
 
 struct gp_gicp_factor {
   gp_point_grid* grid = nullptr;
@@ -1077,6 +1405,18 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
       if (rc != GP_OK) break;
       hipLaunchKernelGGL(gp::gather_sorted_kernel, dim3((lv->bins.num_binned + 255) / 256), dim3(256), 0, g->stream, points_dev, (const int*)lv->bins.order.as<int>(),
                          lv->bins.num_binned, lv->sorted.as<float4>());
+      // superblock occupancy (coarse stage of the search)
+      size_t sn = 1;
+      for (int a = 0; a < 3; a++) {
+        lv->sdim[a] = (lv->bins.geom.dim[a] + 3) / 4;
+        sn *= (size_t)lv->sdim[a];
+      }
+      rc = lv->super.alloc_pooled(sizeof(unsigned long long) * sn, g->stream);
+      if (rc != GP_OK) break;
+      (void)hipMemsetAsync(lv->super.ptr, 0, sizeof(unsigned long long) * sn, g->stream);
+      if (lv->bins.num_occ_blocks > 0)
+        hipLaunchKernelGGL(gp::super_mark_kernel, dim3((lv->bins.num_occ_blocks + 255) / 256), dim3(256), 0, g->stream, (const int*)lv->bins.occ_blocks.as<int>(),
+                           lv->bins.num_occ_blocks, lv->bins.geom, lv->sdim[0], lv->sdim[1], lv->super.as<unsigned long long>());
       const hipError_t e = hipStreamSynchronize(g->stream);
       if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
       lv->h = h;
@@ -1145,8 +1485,8 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 }
 
 // measurement hook: start (enable != 0: zero the counters and count from now on) / stop-and-read (enable == 0) the work counters of the
-// binned search: out[0..4] = {queries (counted once per level they walk), f32 distance evaluations, f64 distance evaluations, block entries
-// read, occupied cells visited}.  Structures created while counting carry the counter pointer.
+// binned search: out[0..5] = {shell walks (a query counts once per stage it walks), f32 distance evaluations, f64 distance evaluations,
+// block entries read, occupied cells visited, octant stages (1-NN)}.  Structures created while counting carry the counter pointer.
 int gp_debug_knn_counters(int enable, unsigned long long* out) {
   if (enable) {
     if (!g_knn_counters) GP_HIP(hipMalloc(reinterpret_cast<void**>(&g_knn_counters), sizeof(unsigned long long) * 8));
@@ -1155,7 +1495,7 @@ int gp_debug_knn_counters(int enable, unsigned long long* out) {
   }
   if (g_knn_counters) {
     GP_HIP(hipDeviceSynchronize());
-    if (out) GP_HIP(hipMemcpy(out, g_knn_counters, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost));
+    if (out) GP_HIP(hipMemcpy(out, g_knn_counters, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost));
     (void)hipFree(g_knn_counters);
     g_knn_counters = nullptr;
   }
@@ -1165,6 +1505,7 @@ int gp_debug_knn_counters(int enable, unsigned long long* out) {
 int gp_debug_set_knn_structure(int mode) {
   g_force_hashed_grid = mode == 1;
   g_knn_untiled = mode != 3;
+  g_knn_levels = mode == 4 ? 2 : 1;
   return GP_OK;
 }
 
@@ -1200,7 +1541,11 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   if (n == 0) return GP_OK;
   hipStream_t s = (hipStream_t)stream;
   gp_point_grid_t* g = nullptr;
+  const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, stream, &g));
+  const double t1 = now();
   gp::DeviceArray d_short;
   int rc = d_short.alloc_async(sizeof(int), s);
   if (rc == GP_OK) {
@@ -1209,31 +1554,34 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
     const int nq = g->binned ? g->num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
     if (nq < n) hipLaunchKernelGGL(gp::nonfinite_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, covs_dev, d_short.as<int>());
     const dim3 grid((nq + 127) / 128), block(128);
-    gp::DeviceArray todo;
-    const unsigned char* d_todo = nullptr;
+    gp::DeviceArray todo;  // [nq] positions + the count behind them
+    gp::DeviceArray scan_buf;  // RowScanOut: kept [kTileKeep][nq] | bound [nq] | safe [nq]
+    const int* d_todo = nullptr;
     if (nq > 0 && g->binned && !g_knn_untiled && k <= 10) {
-      // tiled pass over the occupied blocks of the finest level; what it cannot settle is flagged for the per-lane pass
-      rc = todo.alloc_async((size_t)nq, s);
+      // tiled pass over the occupied cell rows of the finest level; what it cannot settle is listed for the per-lane pass
+      rc = todo.alloc_async(sizeof(int) * ((size_t)nq + 1), s);
+      if (rc == GP_OK) rc = scan_buf.alloc_async(sizeof(int) * (size_t)(gp::kTileKeep + 2) * nq, s);
       if (rc == GP_OK) {
-        (void)hipMemsetAsync(todo.ptr, 0, (size_t)nq, s);
-        hipLaunchKernelGGL(gp::covariance_tiled_kernel<10>, dim3((unsigned)g->bin_levels[0]->bins.num_occ_blocks), dim3(gp::kTileThreads), 0, s, v.bins[0],
-                           (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), points_dev, k, covs_dev, todo.as<unsigned char>());
-        d_todo = todo.as<unsigned char>();
+        (void)hipMemsetAsync(todo.as<int>() + nq, 0, sizeof(int), s);
+        const gp::RowScanOut scan{scan_buf.as<int>(), reinterpret_cast<float*>(scan_buf.as<int>() + (size_t)gp::kTileKeep * nq),
+                                  reinterpret_cast<float*>(scan_buf.as<int>() + (size_t)(gp::kTileKeep + 1) * nq), nq};
+        hipLaunchKernelGGL(gp::covariance_rows_kernel, dim3(16u * (unsigned)g->bin_levels[0]->bins.num_occ_blocks), dim3(gp::kRowThreads), 0, s, v.bins[0],
+                           (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), scan, getenv("GP_KNN_KNOCK") ? atoi(getenv("GP_KNN_KNOCK")) : 0);
+        hipLaunchKernelGGL(gp::covariance_settle_kernel<10>, grid, block, 0, s, v.bins[0].sorted, scan, points_dev, k, covs_dev, todo.as<int>(), todo.as<int>() + nq);
+        d_todo = todo.as<int>();
         if (getenv("GP_KNN_DEBUG")) {  // how much the tiled pass left over
-          std::vector<unsigned char> h((size_t)nq);
-          (void)hipMemcpyAsync(h.data(), todo.ptr, (size_t)nq, hipMemcpyDeviceToHost, s);
+          int left = 0;
+          (void)hipMemcpyAsync(&left, todo.as<int>() + nq, sizeof(int), hipMemcpyDeviceToHost, s);
           (void)hipStreamSynchronize(s);
-          long long left = 0;
-          for (unsigned char c : h) left += c;
-          fprintf(stderr, "gp_estimate_covariances: tiled pass over %d blocks settled %lld of %d queries\n", g->bin_levels[0]->bins.num_occ_blocks, (long long)nq - left, nq);
+          fprintf(stderr, "gp_estimate_covariances: tiled pass over %d blocks settled %d of %d queries\n", g->bin_levels[0]->bins.num_occ_blocks, nq - left, nq);
         }
       }
     }
     if (nq > 0 && rc == GP_OK) {
       if (k <= 10)
-        hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo);
+        hipLaunchKernelGGL(gp::covariance_kernel<10>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
       else
-        hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo);
+        hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
     }
     int h_short = 0;
     hipError_t e = hipMemcpyAsync(&h_short, d_short.ptr, sizeof(int), hipMemcpyDeviceToHost, s);
@@ -1242,7 +1590,15 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
     if (num_short) *num_short = h_short;
     if (h_short > 0) fprintf(stderr, "warning: fewer than k neighbors found for %d points\n", h_short);  // covariance_estimation.cpp:28
   }
-  gp_point_grid_destroy(g);
+  const double t2 = now();
+  // the structure was built and searched on `s` only, and `s` has been synchronised: its arrays go back to the pool in stream order
+  // (gp_point_grid_destroy has to assume searches on other streams and synchronises the device: 1.4 ms in a process with many streams)
+  for (auto& lv : g->bin_levels) {
+    for (gp::DeviceArray* a : {&lv->bins.blocks, &lv->bins.cell_start, &lv->bins.order, &lv->bins.cell_of, &lv->bins.cell_block, &lv->bins.occ_blocks, &lv->sorted, &lv->super})
+      a->release_on(s);
+  }
+  delete g;
+  if (dbg) fprintf(stderr, "gp_estimate_covariances: structure %.0f us, search %.0f us, destroy %.0f us\n", t1 - t0, t2 - t1, now() - t2);
   return rc;
 }
 
@@ -1255,9 +1611,9 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
   auto* f = new gp_gicp_factor;
   f->stream = (hipStream_t)stream;
   // finest cell = 1/4 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
-  g_knn_levels = 1;  // the distance bound ends every search within 4 shells of the finest level
+  // cell = 1/4 of the correspondence radius: the fine shells 0 and 1 settle the well-matched points, and one block edge = the
+  // radius, so the block walk behind them ends at the first block shell at the latest
   int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 4.0, stream, &f->grid);
-  g_knn_levels = 2;
   if (rc != GP_OK) {
     delete f;
     return rc;

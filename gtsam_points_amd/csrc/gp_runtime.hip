@@ -70,6 +70,11 @@ int gp_device_synchronize(void) {
   return GP_OK;
 }
 
+int gp_trim_device_cache(void) {
+  gp::BlockCache::get().trim();
+  return GP_OK;
+}
+
 int gp_stream_create(gp_stream_t* stream) {
   hipStream_t s;
   GP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -78,6 +83,9 @@ int gp_stream_create(gp_stream_t* stream) {
 }
 
 int gp_stream_destroy(gp_stream_t stream) {
+  // blocks parked in a thread's BlockCache are tagged with the stream they were released on; a later stream may be given the same
+  // handle value, so the work of this one is finished before the handle can be recycled
+  GP_HIP(hipStreamSynchronize((hipStream_t)stream));
   GP_HIP(hipStreamDestroy((hipStream_t)stream));
   return GP_OK;
 }

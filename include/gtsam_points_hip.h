@@ -56,6 +56,9 @@ int gp_set_device(int device);
 int gp_get_device(int* device);
 int gp_device_name(int device, char* name, size_t name_len);    /* cuda_device_names() */
 int gp_device_synchronize(void);                                /* cuda/cuda_device_sync.cu */
+/* Scratch and structure arrays are stream-ordered pool blocks; released ones are parked in a bounded per-thread cache (<= 96 blocks,
+ * <= 4 GiB) and re-used by the next build on the same stream.  This returns the calling thread's parked blocks to the pool. */
+int gp_trim_device_cache(void);
 int gp_stream_create(gp_stream_t* stream);                      /* cuda/cuda_stream.cu (cudaStreamNonBlocking) */
 int gp_stream_destroy(gp_stream_t stream);
 int gp_stream_synchronize(gp_stream_t stream);
@@ -358,12 +361,14 @@ int gp_debug_set_variant(int variant);
 /* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
  * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
 int gp_debug_set_map_build(int hashed);
-/* A/B hook: 0 = binned structure, per-lane search (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding box
- * is too large for the block grid); 3 = binned structure with covariance estimation tiled per occupied block (27-block neighbourhood
- * staged through LDS; exact, measured 4x slower than the per-lane search: DESIGN.md section 4.8) */
+/* A/B hook: 0 = binned structure, per-lane search (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding
+ * box is too large for the block grid); 3 = as 0 with the row-tiled covariance pass (one wave per occupied cell row, candidates staged
+ * through LDS) in front of the per-lane search -- exact, measured slower; 4 = as 0 with a second binned level
+ * (cell size x4) between the cells and the superblocks */
 int gp_debug_set_knn_structure(int mode);
 /* measurement hook: enable != 0 zeroes and starts the work counters of the binned search; enable == 0 stops and reads them:
- * out[0..4] = {queries, f32 distance evaluations, f64 distance evaluations, block entries read, occupied cells visited} */
+ * out[0..5] = {shell walks (a query counts once per stage it walks), f32 distance evaluations, f64 distance evaluations, block entries
+ * read, occupied cells visited, octant stages (first stage of a 1-NN search)} */
 int gp_debug_knn_counters(int enable, unsigned long long* out);
 /* tuning knob: the odd wave slots of every SIMD start `units` x 512 clocks late (0 = off, default) */
 int gp_debug_set_stagger(int units);

@@ -106,11 +106,11 @@ def test_binned_and_hashed_structures_agree(gpu, kitti00):
     oidx, od = oracle.OracleKdTree(p2[keep]).knn(np.delete(q2, 5, 0), 5, num_threads=4)
     assert nf[5] == 0 and (np.delete(nf, 5) == 5).all()
     assert np.abs(np.delete(d, 5, 0) - od).max() < 1e-9
-    # covariance estimation: the per-lane search on the binned structure (default), the tiled kernel and the hashed grid agree
+    # covariance estimation: the per-lane search on the binned structure (default), the row-tiled pass, two binned levels and the hashed grid agree
     # (same exact neighbour sets; ties may be ordered differently, which the sample covariance does not see)
     covs = []
     try:
-        for mode in (0, 3, 1):
+        for mode in (0, 3, 4, 1):
             gpu._capi.check(lib.gp_debug_set_knn_structure(mode), "structure")
             fr0 = gpu.PointCloudGPU(p)
             assert gpu.estimate_covariances_gpu(fr0, 10) == 0
