@@ -1157,14 +1157,19 @@ struct GicpDesc {
   double max_sq_dist;
 };
 
+// the poses ride in the kernel arguments (no H2D copy in front of the launch)
+struct GicpPoses {
+  double lin[16], eval[16];
+};
+
 template <int MODE>  // MODE_LIN (rigid pose: 29 sums + adjoint finalize), MODE_ERR, MODE_LIN_GENERAL (any 3x3 block: 92 explicit sums)
-__global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const double* __restrict__ pose_lin, const double* __restrict__ pose_eval,
+__global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const GicpPoses poses,
                                                         int tile_points, double* __restrict__ partials) {
   constexpr int NACC = MODE == MODE_ERR ? 2 : (MODE == MODE_LIN ? ACC_SIZE : ACCG_SIZE);
   constexpr int STRIDE = MODE == MODE_LIN_GENERAL ? ACCG_STRIDE : ACC_STRIDE;
   constexpr int NREG = MODE == MODE_LIN_GENERAL ? ACCG_SIZE : 32;
-  const Pose Tl = load_pose(pose_lin);
-  const Pose Te = MODE == MODE_ERR ? load_pose(pose_eval) : Tl;
+  const Pose Tl = load_pose(poses.lin);
+  const Pose Te = MODE == MODE_ERR ? load_pose(poses.eval) : Tl;
   double acc[NREG];
 #pragma unroll
   for (int k = 0; k < NREG; k++) acc[k] = 0.0;
@@ -1306,6 +1311,9 @@ struct gp_gicp_factor {
   gp::DeviceArray partials, d_poses, d_out;
   gp::PinnedArray h_out;
   void* h_out_dev = nullptr;
+  gp::PinnedArray h_done;  // completion word of the synchronous calls (gp_vgicp_shared.hpp: DoneFlags)
+  void* h_done_dev = nullptr;
+  unsigned long long seq = 0;
 };
 
 extern "C" {
@@ -1633,6 +1641,13 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
     return rc;
   }
   GP_HIP(hipHostGetDevicePointer(&f->h_out_dev, f->h_out.ptr, 0));
+  if ((rc = f->h_done.ensure(sizeof(unsigned long long))) != GP_OK) {
+    gp_point_grid_destroy(f->grid);
+    delete f;
+    return rc;
+  }
+  memset(f->h_done.ptr, 0, f->h_done.bytes);
+  GP_HIP(hipHostGetDevicePointer(&f->h_done_dev, f->h_done.ptr, 0));
   *out = f;
   return GP_OK;
 }
@@ -1647,37 +1662,38 @@ int gp_gicp_factor_destroy(gp_gicp_factor_t* f) {
 
 int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host) {
   if (!f || !pose || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_linearize: null");
-  GP_HIP(hipMemcpyAsync(f->d_poses.ptr, pose, sizeof(double) * 16, hipMemcpyHostToDevice, f->stream));
+  gp::GicpPoses P;
+  memcpy(P.lin, pose, sizeof(double) * 16);
+  memcpy(P.eval, pose, sizeof(double) * 16);
   // the 29-sum kernel + adjoint finalize is exact only for an orthonormal 3x3 block; any other pose (e.g. built from 6-digit
   // quaternions, src/test/test_matching_cost_factors.cpp:50-55) takes the 92-sum path with the explicit J_s, like the VGICP factor
   const bool rigid = gp::pose_is_rigid(pose);
   if (f->num_tiles > 0) {
     if (rigid)
-      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(), f->d_poses.as<double>(),
-                         f->tile_points, f->partials.as<double>());
+      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>());
     else
-      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN_GENERAL>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(),
-                         f->d_poses.as<double>(), f->tile_points, f->partials.as<double>());
+      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN_GENERAL>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>());
     GP_HIP(hipGetLastError());
   }
-  GP_TRY(gp::launch_finalize_single(f->stream, f->d_poses.as<double>(), pose, f->partials.as<double>(), f->num_tiles, reinterpret_cast<gp_linearized6*>(f->h_out_dev),
-                                    !rigid));
-  GP_HIP(hipStreamSynchronize(f->stream));
+  const gp::DoneFlags done{static_cast<unsigned long long*>(f->h_done_dev), ++f->seq};
+  GP_TRY(gp::launch_finalize_single(f->stream, nullptr, pose, f->partials.as<double>(), f->num_tiles, reinterpret_cast<gp_linearized6*>(f->h_out_dev), !rigid, done));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(f->h_done.ptr), 1, done.seq, f->stream));
   memcpy(out_host, f->h_out.ptr, sizeof(gp_linearized6));
   return GP_OK;
 }
 
 int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host) {
   if (!f || !pose_lin || !pose_eval || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_compute_error: null");
-  double both[32];
-  memcpy(both, pose_lin, sizeof(double) * 16);
-  memcpy(both + 16, pose_eval, sizeof(double) * 16);
-  GP_HIP(hipMemcpy(f->d_poses.ptr, both, sizeof(both), hipMemcpyHostToDevice));
-  if (f->num_tiles > 0)
-    hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_ERR>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, f->d_poses.as<double>(), f->d_poses.as<double>() + 16,
-                       f->tile_points, f->partials.as<double>());
-  GP_TRY(gp::launch_finalize_error_single(f->stream, f->partials.as<double>(), f->num_tiles, reinterpret_cast<double*>(f->h_out_dev)));
-  GP_HIP(hipStreamSynchronize(f->stream));
+  gp::GicpPoses P;
+  memcpy(P.lin, pose_lin, sizeof(double) * 16);
+  memcpy(P.eval, pose_eval, sizeof(double) * 16);
+  if (f->num_tiles > 0) {
+    hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_ERR>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>());
+    GP_HIP(hipGetLastError());
+  }
+  const gp::DoneFlags done{static_cast<unsigned long long*>(f->h_done_dev), ++f->seq};
+  GP_TRY(gp::launch_finalize_error_single(f->stream, f->partials.as<double>(), f->num_tiles, reinterpret_cast<double*>(f->h_out_dev), done));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(f->h_done.ptr), 1, done.seq, f->stream));
   memcpy(out_host, f->h_out.ptr, sizeof(double));
   return GP_OK;
 }

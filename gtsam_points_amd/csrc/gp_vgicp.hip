@@ -16,6 +16,8 @@
 //   The workgroup -> tile map is XCD-aware: workgroup b runs on XCD b % 8, so XCD x is handed the x-th contiguous
 //   eighth of the tile list and the voxel tables of "its" factors stay in that XCD's 4 MiB L2.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -139,7 +141,7 @@ constexpr int kFinalizeThreads = 1024;
 template <bool GENERAL>
 __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
                                                                           const InlinePoses inl, const double* __restrict__ partials,
-                                                                          gp_linearized6* __restrict__ out) {
+                                                                          gp_linearized6* __restrict__ out, const DoneFlags done) {
   constexpr int STRIDE = GENERAL ? ACCG_STRIDE : ACC_STRIDE;
   constexpr int NACC = GENERAL ? ACCG_SIZE : ACC_SIZE;
   constexpr int kSlices = kFinalizeThreads / STRIDE;  // 1024 threads = 32 slices x 32 sums, or 10 x 96 (+ idle)
@@ -269,10 +271,11 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   }
   __syncthreads();
   if (t < 122) out_rec[t] = dst[t];
+  signal_done(done, fi, t < 122);
 }
 
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
-                                                                             double* __restrict__ out, int single_tile_count = -1) {
+                                                                             double* __restrict__ out, int single_tile_count, const DoneFlags done) {
   const int fi = blockIdx.x;
   const int tile_begin = single_tile_count >= 0 ? 0 : factors[fi].tile_begin, tile_count = single_tile_count >= 0 ? single_tile_count : factors[fi].tile_count;
   __shared__ double lds[kBlockThreads / 64];
@@ -287,25 +290,44 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(con
     for (int w = 0; w < kBlockThreads / 64; w++) a += lds[w];
     out[fi] = a;
   }
+  signal_done(done, fi, threadIdx.x == 0);
+}
+
+int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream) {
+  const volatile unsigned long long* fl = flags_host;
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t next = 0;
+  for (unsigned spins = 1;; spins++) {
+    while (next < count && fl[next] == seq) next++;
+    if (next == count) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return GP_OK;
+    }
+    __builtin_ia32_pause();
+    // large batches (and failed kernels, whose words never arrive) are left to the runtime after 100 us of spinning
+    if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+  }
+  GP_HIP(hipStreamSynchronize(stream));
+  return GP_OK;
 }
 
 int launch_finalize_single(hipStream_t stream, const double* pose_dev, const double* pose_host, const double* partials, int num_tiles, gp_linearized6* out_dev,
-                           bool general) {
+                           bool general, DoneFlags done) {
   InlinePoses inl{};
   memcpy(inl.lin, pose_host, sizeof(double) * 16);
   inl.factor.tile_begin = 0;
   inl.factor.tile_count = num_tiles;
   inl.use = 1;
   if (general)
-    hipLaunchKernelGGL(vgicp_finalize_kernel<true>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev);
+    hipLaunchKernelGGL(vgicp_finalize_kernel<true>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
   else
-    hipLaunchKernelGGL(vgicp_finalize_kernel<false>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev);
+    hipLaunchKernelGGL(vgicp_finalize_kernel<false>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_kernel", __FILE__, __LINE__);
 }
 
-int launch_finalize_error_single(hipStream_t stream, const double* partials, int num_tiles, double* out_dev) {
-  hipLaunchKernelGGL(vgicp_finalize_error_kernel, dim3(1), dim3(kBlockThreads), 0, stream, (const FactorDesc*)nullptr, partials, out_dev, num_tiles);
+int launch_finalize_error_single(hipStream_t stream, const double* partials, int num_tiles, double* out_dev, DoneFlags done) {
+  hipLaunchKernelGGL(vgicp_finalize_error_kernel, dim3(1), dim3(kBlockThreads), 0, stream, (const FactorDesc*)nullptr, partials, out_dev, num_tiles, done);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_error_kernel", __FILE__, __LINE__);
 }
@@ -351,6 +373,9 @@ struct gp_vgicp_batch {
   hipEvent_t h2d_done = nullptr;  // recorded behind every H2D copy of h_poses; the next staging waits on it
   gp::PinnedArray h_out;  // results land here straight from the finalize kernel (host-mapped, no D2H copy op)
   void* h_out_dev = nullptr;
+  gp::PinnedArray h_done;  // one completion word per factor, written by the finalize kernel behind its record (synchronous calls poll it)
+  void* h_done_dev = nullptr;
+  unsigned long long seq = 0;
   bool table_dirty = true;
   std::vector<uint64_t> seen;  // per factor: its generation + its target map's generation when the table was built
 };
@@ -448,6 +473,12 @@ int build_table(gp_vgicp_batch* b) {
   GP_TRY(b->h_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
   GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * (size_t)std::max(F, 1)));
   GP_HIP(hipHostGetDevicePointer(&b->h_out_dev, b->h_out.ptr, 0));
+  {
+    const size_t before = b->h_done.bytes;
+    GP_TRY(b->h_done.ensure(sizeof(unsigned long long) * (size_t)std::max(F, 1)));
+    if (b->h_done.bytes != before) memset(b->h_done.ptr, 0, b->h_done.bytes);
+    GP_HIP(hipHostGetDevicePointer(&b->h_done_dev, b->h_done.ptr, 0));
+  }
   if (!b->temp_buffer) GP_TRY(b->d_partials.ensure(sizeof(double) * gp::ACCG_STRIDE * (size_t)std::max(b->num_tiles, 1)));
   // the table upload is synchronous (pageable source); it happens once per factor-set change, not per linearise
   if (F) GP_HIP(hipMemcpy(b->d_factors.ptr, descs.data(), sizeof(gp::FactorDesc) * (size_t)F, hipMemcpyHostToDevice));
@@ -534,34 +565,34 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
 }
 
 template <bool GENERAL>
-int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev) {
+int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev, gp::DoneFlags done = {}) {
   hipLaunchKernelGGL(gp::vgicp_finalize_kernel<GENERAL>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream,
-                     b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev);
+                     b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev, done);
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
 
 // device work of one linearisation pass.  rigid == true: 29-sum kernel + adjoint expansion; false: 92-sum kernel
 // (exact for any 3x3 block, like the reference's explicit J_s).
-int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid) {
+int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid, gp::DoneFlags done = {}) {
   if (b->factors.empty()) return GP_OK;
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
   if (rigid) {
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
-    return launch_finalize<false>(b, ps, partials, out_dev);
+    return launch_finalize<false>(b, ps, partials, out_dev, done);
   }
   GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
-  return launch_finalize<true>(b, ps, partials, out_dev);
+  return launch_finalize<true>(b, ps, partials, out_dev, done);
 }
 
-int launch_error(gp_vgicp_batch* b, const PoseSource& ps, double* out_dev) {
+int launch_error(gp_vgicp_batch* b, const PoseSource& ps, double* out_dev, gp::DoneFlags done = {}) {
   if (b->factors.empty()) return GP_OK;
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
   GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
   hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3((int)b->factors.size()), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
-                     partials, out_dev, -1);
+                     partials, out_dev, -1, done);
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
@@ -858,8 +889,12 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
-  GP_TRY(gp_vgicp_batch_issue_linearize(b, poses_host, reinterpret_cast<gp_linearized6*>(b->h_out_dev)));
-  GP_HIP(hipStreamSynchronize(b->stream));
+  if (table_is_stale(b)) GP_TRY(build_table(b));
+  PoseSource ps;
+  GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
+  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), poses_are_rigid(poses_host, F), done));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream));
   memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
   return GP_OK;
 }
@@ -868,8 +903,12 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
   if (!b || !poses_lin_host || !poses_eval_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_compute_error: null");
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
-  GP_TRY(gp_vgicp_batch_issue_compute_error(b, poses_lin_host, poses_eval_host, reinterpret_cast<double*>(b->h_out_dev)));
-  GP_HIP(hipStreamSynchronize(b->stream));
+  if (table_is_stale(b)) GP_TRY(build_table(b));
+  PoseSource ps;
+  GP_TRY(stage_poses(b, poses_lin_host, poses_eval_host, &ps));
+  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+  GP_TRY(launch_error(b, ps, reinterpret_cast<double*>(b->h_out_dev), done));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream));
   memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
   return GP_OK;
 }
