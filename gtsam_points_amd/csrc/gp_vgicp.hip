@@ -151,6 +151,8 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   __shared__ double lds[kSlices][STRIDE];
   __shared__ double sum[STRIDE];
   __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
+  GP_FIN_TRACE(0);
+  if (done.trace && threadIdx.x == 0 && blockIdx.x == 0) done.trace[9] = __builtin_amdgcn_s_getreg(GP_GETREG_XCC_ID);
   const int comp = threadIdx.x % STRIDE, slice = threadIdx.x / STRIDE;
   if (slice < kSlices) {
     // fixed summation order (deterministic).  All of a lane's rows are requested in ONE batch of up to 32 independent loads
@@ -173,6 +175,7 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
     }
     lds[slice][comp] = total;
   }
+  GP_FIN_TRACE(1);
   __syncthreads();
   if (threadIdx.x < STRIDE) {
     double a = 0.0;
@@ -181,6 +184,7 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
     sum[threadIdx.x] = a;
   }
   __syncthreads();
+  GP_FIN_TRACE(2);
   (void)NACC;
   const int t = threadIdx.x;
   const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
@@ -270,8 +274,173 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
     if (t < 6) dst[OFF_BS + t] = sum[ACCG_BS + t];
   }
   __syncthreads();
+  GP_FIN_TRACE(3);
   if (t < 122) out_rec[t] = dst[t];
   signal_done(done, fi, t < 122);
+}
+
+// visibility of LDS writes between the lanes of ONE wave (its LDS operations execute in program order; this only keeps the compiler
+// from moving them and makes it wait for the writes): what __syncthreads() is for a workgroup, without the s_barrier
+#define GP_WAVE_SYNC()                                       \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+  } while (0)
+
+__device__ __forceinline__ double pick9(int i, double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7, double a8) {
+  double v = a0;
+  v = i == 1 ? a1 : v;
+  v = i == 2 ? a2 : v;
+  v = i == 3 ? a3 : v;
+  v = i == 4 ? a4 : v;
+  v = i == 5 ? a5 : v;
+  v = i == 6 ? a6 : v;
+  v = i == 7 ? a7 : v;
+  v = i == 8 ? a8 : v;
+  return v;
+}
+
+// finalize of the 29-sum (rigid pose) pass, round 2.  The timeline of the generic kernel above (scripts/trace_finalize.py) showed
+// 2.7 us for the partials (250 KB through ONE compute unit's L1: bandwidth, not latency), and then 2.1 + 2.4 us for what should be
+// nothing: sixteen waves meeting at four barriers, 6x6 tables indexed at run time (= scratch memory round trips) and a pose fetched
+// when it was needed.  Here all sixteen waves load and tree-add their rows, the two slices of a wave meet through one cross-lane
+// add, ONE barrier, and wave 0 alone does the rest out of LDS with wave-level synchronisation; the pose is requested first of all.
+__global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
+                                                                                const InlinePoses inl, const double* __restrict__ partials,
+                                                                                gp_linearized6* __restrict__ out, const DoneFlags done) {
+  static_assert(ACC_STRIDE == 32 && kFinalizeThreads == 1024, "lane = (slice parity, component); 16 waves x 2 slices");
+  const int fi = blockIdx.x;
+  const Pose T = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);  // in flight while the partials arrive
+  const int tile_begin = inl.use ? inl.factor.tile_begin : factors[fi].tile_begin;
+  const int tile_count = inl.use ? inl.factor.tile_count : factors[fi].tile_count;
+  __shared__ double wsum[16][32];
+  __shared__ double sum[32];
+  __shared__ double Rl[9], Xl[9];  // R and [t]x, row-major
+  __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
+  __shared__ double dst[122];
+  GP_FIN_TRACE(0);
+  if (done.trace && threadIdx.x == 0 && blockIdx.x == 0) done.trace[9] = __builtin_amdgcn_s_getreg(GP_GETREG_XCC_ID);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  {
+    // fixed summation order (deterministic).  All of a lane's rows are requested in ONE batch of up to 32 independent loads
+    const double* base = partials + (size_t)tile_begin * ACC_STRIDE + comp;
+    double total = 0.0;
+    for (int t0 = slice; t0 < tile_count; t0 += 32 * 32) {
+      double v[32];
+#pragma unroll
+      for (int k = 0; k < 32; k++) {
+        const int t = t0 + k * 32;
+        v[k] = t < tile_count ? base[(size_t)t * ACC_STRIDE] : 0.0;
+      }
+#pragma unroll
+      for (int w = 16; w > 0; w >>= 1) {
+#pragma unroll
+        for (int k = 0; k < w; k++) v[k] += v[k + w];
+      }
+      total += v[0];
+    }
+    total += __shfl_xor(total, 32, 64);  // the wave's two slices
+    if (lane < 32) wsum[wave][lane] = total;
+  }
+  GP_FIN_TRACE(1);
+  __syncthreads();
+  if (wave != 0) return;  // (a finished wave no longer takes part in barriers; none follow anyway)
+  if (lane < 32) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = wsum[k][lane];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) {
+#pragma unroll
+      for (int k = 0; k < w; k++) v[k] += v[k + w];
+    }
+    sum[lane] = v[0];
+  } else if (lane < 41) {
+    const int i = lane - 32;
+    Rl[i] = pick9(i, T.r00, T.r01, T.r02, T.r10, T.r11, T.r12, T.r20, T.r21, T.r22);
+    Xl[i] = pick9(i, 0.0, -T.tz, T.ty, T.tz, 0.0, -T.tx, -T.ty, T.tx, 0.0);
+  }
+  GP_WAVE_SYNC();
+  GP_FIN_TRACE(2);
+  const int t = lane;
+  const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
+  constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
+  auto sym3 = [](int a, int b) {  // packed index of a symmetric 3x3 (00 01 02 11 12 22)
+    const int i = a < b ? a : b, j = a < b ? b : a;
+    return (i * (5 - i)) / 2 + j;
+  };
+  if (t < 36) {
+    // H_t = [[TL, -K^T], [-K, M]]
+    double h;
+    if (r < 3 && c < 3) {
+      h = sum[ACC_TL + sym3(r, c)];
+    } else if (r >= 3 && c < 3) {
+      h = -sum[ACC_K + (r - 3) * 3 + c];
+    } else if (r < 3) {
+      h = -sum[ACC_K + (c - 3) * 3 + r];
+    } else {
+      h = sum[ACC_M + sym3(r - 3, c - 3)];
+    }
+    Ht[r][c] = h;
+    dst[OFF_HT + c * 6 + r] = h;
+    // Ad(delta) = [[R, 0], [[t]x R, R]]   ([omega, v] ordering, GTSAM Pose3::AdjointMap)
+    double a;
+    if (r < 3 && c < 3) {
+      a = Rl[r * 3 + c];
+    } else if (r < 3) {
+      a = 0.0;
+    } else if (c >= 3) {
+      a = Rl[(r - 3) * 3 + (c - 3)];
+    } else {
+      a = Xl[(r - 3) * 3] * Rl[c] + Xl[(r - 3) * 3 + 1] * Rl[3 + c] + Xl[(r - 3) * 3 + 2] * Rl[6 + c];
+    }
+    Ad[r][c] = a;
+  } else if (t < 42) {
+    const int k = t - 36;
+    const double b = k < 3 ? sum[ACC_QXMR + k] : sum[ACC_MR + k - 3];
+    bt[k] = b;
+    dst[OFF_BT + k] = b;
+  } else if (t == 42) {
+    dst[0] = sum[ACC_COUNT];
+    dst[1] = sum[ACC_ERR];
+  }
+  GP_WAVE_SYNC();
+  if (t < 36) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a += Ht[r][k] * Ad[k][c];
+    HtA[r][c] = a;
+    dst[OFF_HTS + c * 6 + r] = -a;  // H_ts = -H_t Ad
+  } else if (t < 42) {
+    const int k6 = t - 36;
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a += Ad[k][k6] * bt[k];
+    dst[OFF_BS + k6] = -a;  // b_s = -Ad^T b_t
+  }
+  GP_WAVE_SYNC();
+  if (t < 36) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a += Ad[k][r] * HtA[k][c];
+    dst[OFF_HS + c * 6 + r] = a;  // H_s = Ad^T H_t Ad
+  }
+  GP_WAVE_SYNC();
+  GP_FIN_TRACE(3);
+  // the record leaves in two coalesced sweeps of 8-byte stores (it may be only 8-byte aligned, integrated_vgicp_factor_gpu.cpp:219-220;
+  // when `out` is host-mapped memory, scattered stores would each be their own PCIe write)
+  double* out_rec = reinterpret_cast<double*>(out + fi);
+  out_rec[t] = dst[t];
+  if (t + 64 < 122) out_rec[t + 64] = dst[t + 64];
+  if (done.flags) {
+    GP_FIN_TRACE(4);
+    __threadfence_system();  // the record is visible to the host before the word that announces it (one wave: no barrier needed)
+    GP_FIN_TRACE(5);
+    if (t == 0) __hip_atomic_store(done.flags + fi, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    GP_FIN_TRACE(6);
+  }
 }
 
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
@@ -321,7 +490,7 @@ int launch_finalize_single(hipStream_t stream, const double* pose_dev, const dou
   if (general)
     hipLaunchKernelGGL(vgicp_finalize_kernel<true>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
   else
-    hipLaunchKernelGGL(vgicp_finalize_kernel<false>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
+    hipLaunchKernelGGL(vgicp_finalize_rigid_kernel, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_kernel", __FILE__, __LINE__);
 }
@@ -399,6 +568,7 @@ namespace {
 int g_variant = 4;
 int g_stagger = 0;
 bool g_trace_on = false;
+unsigned long long* g_trace_host = nullptr;  // host copy of the trace buffer pointer (finalize stamps go to row 2047)
 struct VariantDesc {
   bool f32, grid, lean;
   int ppt;  // 64-point chunks per wave (0 = chosen per batch)
@@ -566,8 +736,12 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
 
 template <bool GENERAL>
 int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev, gp::DoneFlags done = {}) {
-  hipLaunchKernelGGL(gp::vgicp_finalize_kernel<GENERAL>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream,
-                     b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev, done);
+  if constexpr (GENERAL)
+    hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
+                       ps.d_lin, ps.inl, partials, out_dev, done);
+  else
+    hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
+                       ps.d_lin, ps.inl, partials, out_dev, done);
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
@@ -654,6 +828,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buffer);
   GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gp::g_trace), &p, sizeof(p)));
   g_trace_on = p != nullptr;
+  g_trace_host = static_cast<unsigned long long*>(p);
   return GP_OK;
 }
 
@@ -892,7 +1067,7 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   if (table_is_stale(b)) GP_TRY(build_table(b));
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
-  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, g_trace_host ? g_trace_host + 2047 * 16 : nullptr};
   GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), poses_are_rigid(poses_host, F), done));
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream));
   memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);

@@ -158,13 +158,21 @@ __device__ __forceinline__ void accumulate_sums(const Pose& Tl, const double* m,
 struct DoneFlags {
   unsigned long long* flags = nullptr;
   unsigned long long seq = 0;
+  unsigned long long* trace = nullptr;  // timeline build (gp_debug_set_trace_buffer): 8 shader-clock stamps of the finalize kernel
 };
+#define GP_FIN_TRACE(k)                                                            \
+  do {                                                                             \
+    if (done.trace && threadIdx.x == 0 && blockIdx.x == 0) done.trace[k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 // every thread that has written part of the record calls this with wrote = true; all threads of the workgroup must call it
 __device__ __forceinline__ void signal_done(const DoneFlags& done, int slot, bool wrote) {
   if (!done.flags) return;
+  GP_FIN_TRACE(4);
   if (wrote) __threadfence_system();  // the record is visible to the host before ...
   __syncthreads();
+  GP_FIN_TRACE(5);
   if (threadIdx.x == 0) __hip_atomic_store(done.flags + slot, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... the word that announces it
+  GP_FIN_TRACE(6);
 }
 // host side: spin on the words (bounded), then fall back to the stream -- which also surfaces a failed kernel as an error
 int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream);
