@@ -9,6 +9,7 @@ rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > $O/device.txt; n
 timeout 1500 python -m pytest -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke exit $?" >> $O/smoke.txt; tail -2 $O/smoke.txt
 timeout 900 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log > $O/bench_n1.json; cut -c1-300 $O/bench_n1.json
+python scripts/trace_finalize.py 2>/dev/null | grep -E "^rep|^   " > $O/finalize_timeline.txt; tail -2 $O/finalize_timeline.txt
 # per-kernel times of the same command
 rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-c4 > $O/rocprof_bench.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv && head -6 $f | cut -c1-160
@@ -23,6 +24,23 @@ ff=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(f
 bash scripts/pmc_tile.sh 4 > /dev/null 2>&1; cp gpurun_out/pmc_tile_v4.txt $O/pmc_tile_sq.txt; head -12 $O/pmc_tile_sq.txt
 # the other BASELINE configurations
 timeout 1500 python scripts/bench_configs.py > $O/configs.jsonl 2> $O/configs.err; cut -c1-260 $O/configs.jsonl
+# L2 hit rate of the tile kernel on the C4 shard
+rm -rf /tmp/pc4 && timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d /tmp/pc4 -o p -- python scripts/bench_configs.py C4 > /tmp/pc4.log 2>&1
+f=$(find /tmp/pc4 -name "*counter_collection.csv" | head -1)
+[ -n "$f" ] && python - "$f" > $O/c4_tcc.txt <<'PY'
+import csv, sys
+from collections import defaultdict
+acc = defaultdict(list)
+for row in csv.DictReader(open(sys.argv[1])):
+    if "vgicp_pipeline_kernel" in row["Kernel_Name"]:
+        acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+m = {k: sum(v) / len(v) for k, v in acc.items()}
+for k, v in m.items():
+    print(f"{k:16s} mean/launch {v:14.1f}  (n={len(acc[k])})")
+if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+    print(f"TCC_HIT / (HIT + MISS) = {m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.3f}   (C4 shard: 512 factors x 32768 points, default tile kernel)")
+PY
+cat $O/c4_tcc.txt
 # tile-kernel variants, per-workgroup timeline, 8 M-point source
 timeout 900 python scripts/r02_sweep.py 1,2,3,4,5 0 --big > $O/sweep.jsonl 2> $O/sweep.err; cut -c1-200 $O/sweep.jsonl | tail -12
 # C5: work counters, kernel times, PMC of the two kernels
