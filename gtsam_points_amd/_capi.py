@@ -114,6 +114,14 @@ _SIGNATURES = {
     "gp_dense_system_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "gp_dense_system_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_dense_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_sparse_system_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_sparse_system_destroy": (C.c_int, [C.c_void_p]),
+    "gp_sparse_system_size": (C.c_int, [C.c_void_p]),
+    "gp_sparse_system_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gp_sparse_system_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "gp_sparse_system_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_sparse_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_sparse_symbolic": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gp_cloud_upload_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gp_cloud_upload_mat3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     # factor

@@ -1,0 +1,738 @@
+// gp_sparse.hip -- the step after the path, block-sparse: the damped normal equations of a pose
+// graph assembled as a block-sparse lower triangle (6x6 blocks = one pose) and solved by a sparse LL^T on the device.
+//
+// Replaces (reference, host side, on top of GTSAM / Eigen):
+//   include/gtsam_points/optimizers/linear_system_builder.hpp:41-72   SparseLinearSystemBuilder<BLOCK_SIZE>: lower-triangular
+//                                                                    block-sparse A in a given ordering, b, c
+//   src/gtsam_points/optimizers/levenberg_marquardt_ext.cpp:146-161    buildDampedSystem
+//   include/gtsam_points/optimizers/linear_solver.hpp:18-30            SparseLinearSolver::solve(A, b)   (called at levenberg_marquardt_ext.cpp:200-220)
+//
+// Host, once per graph (gp_sparse_system_create): elimination order (the slot order of the factor key list, or nested dissection
+// by BFS bisection of the pose graph), symbolic factorisation (elimination tree, block structure of L incl. fill), and for every
+// block of L the ordered list of block products that update it -- the numeric phase is then a pure GATHER: every block is
+// computed by one group of lanes in a fixed order, no atomics, bit-reproducible.
+//
+// Device, per solve: left-looking block Cholesky scheduled over the elimination tree.  The tree is cut into independent subtrees
+// (one workgroup each, columns in elimination order: a column only gathers from its descendants, which are in the same subtree)
+// and a top part of separator columns (one workgroup, after the subtrees).  A pose-graph chain ordered by nested dissection
+// is ~log2(P) separator columns on top of P / 8-column subtrees; in the natural order it is one path, i.e. one workgroup walking P
+// columns.  The forward substitution rides along (y_k is computed when column k is finished); the backward substitution runs
+// the same schedule in reverse.  Four launches per solve, whatever the graph.
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <numeric>
+#include <queue>
+#include <vector>
+
+#include "gp_host.hpp"
+
+namespace gp {
+
+// ---- symbolic phase (pure host code; also exported for the CPU tests) ------------------------------------------------------------
+
+struct SparseSymbolic {
+  int P = 0;
+  std::vector<int> perm, iperm;    // perm[k] = slot eliminated k-th; iperm[slot] = k
+  std::vector<int> parent;         // elimination tree (-1: root)
+  std::vector<int> colptr;         // [P + 1] block offsets; column k = its diagonal block followed by its sub-diagonal blocks
+  std::vector<int> rowidx;         // [nnzL] row (elimination index) of every block
+  std::vector<int> upd_ptr;        // [nnzL + 1] -> upd_a / upd_b: block (i, k) -= L[upd_a] * L[upd_b]^T, in ascending source column
+  std::vector<int> upd_a, upd_b;
+  std::vector<int> row_ptr;        // [P + 1] -> row_blk / row_col: the blocks L_kj (j < k) of row k and their columns, ascending j
+  std::vector<int> row_blk, row_col;
+  std::vector<int> work_ptr, work_cols;  // work lists: [num_subtrees] subtrees, then ONE list with the top columns (may be empty)
+  int num_subtrees = 0;
+  long long nnzA = 0;
+};
+
+// nested dissection by BFS bisection: order = nd(A) ++ nd(B) ++ separator
+static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vector<int>* order) {
+  const int P = (int)adj.size();
+  std::vector<int> label(P, 0), level(P, -1);  // label: id of the current piece a node belongs to
+  order->clear();
+  order->reserve(P);
+  int next_label = 1;
+  std::function<void(const std::vector<int>&)> rec = [&](const std::vector<int>& nodes) {
+    if (nodes.size() <= 8) {
+      for (int v : nodes) order->push_back(v);
+      return;
+    }
+    const int mine = next_label++;
+    for (int v : nodes) label[v] = mine;
+    // connected components of the piece
+    std::vector<std::vector<int>> comps;
+    for (int v : nodes) level[v] = -1;
+    for (int s : nodes) {
+      if (level[s] != -1) continue;
+      comps.emplace_back();
+      std::vector<int>& c = comps.back();
+      level[s] = 0;
+      c.push_back(s);
+      for (size_t h = 0; h < c.size(); h++)
+        for (int w : adj[c[h]])
+          if (label[w] == mine && level[w] == -1) {
+            level[w] = 0;
+            c.push_back(w);
+          }
+    }
+    if (comps.size() > 1) {
+      for (auto& c : comps) {
+        std::sort(c.begin(), c.end());
+        rec(c);
+      }
+      return;
+    }
+    // one component: BFS from a pseudo-peripheral node (two sweeps), cut at the thinnest level near the middle
+    auto bfs = [&](int s, std::vector<int>* seq) {
+      for (int v : nodes) level[v] = -1;
+      seq->clear();
+      level[s] = 0;
+      seq->push_back(s);
+      for (size_t h = 0; h < seq->size(); h++)
+        for (int w : adj[(*seq)[h]])
+          if (label[w] == mine && level[w] == -1) {
+            level[w] = level[(*seq)[h]] + 1;
+            seq->push_back(w);
+          }
+    };
+    std::vector<int> seq;
+    bfs(nodes[0], &seq);
+    bfs(seq.back(), &seq);
+    const int depth = level[seq.back()] + 1;
+    if (depth < 3) {  // (nearly) complete piece: no useful separator
+      for (int v : nodes) order->push_back(v);
+      return;
+    }
+    std::vector<int> width(depth, 0);
+    for (int v : nodes) width[level[v]]++;
+    std::vector<long long> below(depth + 1, 0);
+    for (int l = 0; l < depth; l++) below[l + 1] = below[l] + width[l];
+    int cut = -1;
+    double best = 1e300;
+    for (int l = 1; l + 1 < depth; l++) {
+      const double a = (double)below[l], b = (double)(below[depth] - below[l + 1]);
+      if (a < 0.25 * nodes.size() || b < 0.25 * nodes.size()) continue;  // balanced enough
+      const double score = width[l] + 0.01 * std::abs(a - b);
+      if (score < best) {
+        best = score;
+        cut = l;
+      }
+    }
+    if (cut < 0) cut = depth / 2;
+    std::vector<int> A, B, S;
+    for (int v : nodes) (level[v] < cut ? A : (level[v] > cut ? B : S)).push_back(v);
+    rec(A);
+    rec(B);
+    for (int v : S) order->push_back(v);
+  };
+  std::vector<int> all(P);
+  std::iota(all.begin(), all.end(), 0);
+  rec(all);
+}
+
+static int sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, SparseSymbolic* out) {
+  SparseSymbolic& S = *out;
+  const int P = num_slots;
+  S.P = P;
+  // pose graph
+  std::vector<std::vector<int>> adj((size_t)P);
+  for (int f = 0; f < num_factors; f++) {
+    const int a = factor_slots[2 * f], b = factor_slots[2 * f + 1];
+    if (a >= P || b >= P) return fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system: slot index out of range");
+    if (a >= 0 && a == b) return fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system: a factor needs two different poses");
+    if (a >= 0 && b >= 0) {
+      adj[a].push_back(b);
+      adj[b].push_back(a);
+    }
+  }
+  for (auto& v : adj) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  }
+  S.perm.resize(P);
+  if (ordering == 1) {
+    nested_dissection(adj, &S.perm);
+  } else {
+    std::iota(S.perm.begin(), S.perm.end(), 0);
+  }
+  S.iperm.assign(P, -1);
+  for (int k = 0; k < P; k++) S.iperm[S.perm[k]] = k;
+  // structure of A below the diagonal, per column, in elimination indices
+  std::vector<std::vector<int>> col((size_t)P);
+  S.nnzA = P;
+  for (int v = 0; v < P; v++)
+    for (int w : adj[v]) {
+      const int i = S.iperm[v], j = S.iperm[w];
+      if (i > j) {
+        col[j].push_back(i);
+        S.nnzA++;
+      }
+    }
+  // symbolic Cholesky: struct(L_j) = struct(A_j) U (struct(L_c) \ {j}) over the children c of j in the elimination tree
+  S.parent.assign(P, -1);
+  std::vector<std::vector<int>> children((size_t)P);
+  for (int j = 0; j < P; j++) {
+    std::vector<int>& s = col[j];
+    for (int c : children[j])
+      for (int r : col[c])
+        if (r != j) s.push_back(r);
+    std::sort(s.begin(), s.end());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    if (!s.empty()) {
+      S.parent[j] = s[0];
+      children[s[0]].push_back(j);
+    }
+  }
+  S.colptr.assign(P + 1, 0);
+  for (int j = 0; j < P; j++) S.colptr[j + 1] = S.colptr[j] + 1 + (int)col[j].size();
+  const int nnzL = S.colptr[P];
+  S.rowidx.resize(nnzL);
+  for (int j = 0; j < P; j++) {
+    S.rowidx[S.colptr[j]] = j;
+    for (size_t q = 0; q < col[j].size(); q++) S.rowidx[S.colptr[j] + 1 + q] = col[j][q];
+  }
+  auto find_block = [&](int i, int k) {  // block (i, k), i >= k, must exist
+    if (i == k) return S.colptr[k];
+    const auto it = std::lower_bound(col[k].begin(), col[k].end(), i);
+    return S.colptr[k] + 1 + (int)(it - col[k].begin());
+  };
+  // update lists (two passes: count, fill), source columns in ascending order; row lists for the substitutions
+  S.upd_ptr.assign(nnzL + 1, 0);
+  S.row_ptr.assign(P + 1, 0);
+  for (int j = 0; j < P; j++)
+    for (size_t q = 0; q < col[j].size(); q++) {
+      const int k = col[j][q];
+      S.row_ptr[k + 1]++;
+      for (size_t p = q; p < col[j].size(); p++) S.upd_ptr[find_block(col[j][p], k) + 1]++;
+    }
+  for (int d = 0; d < nnzL; d++) S.upd_ptr[d + 1] += S.upd_ptr[d];
+  for (int k = 0; k < P; k++) S.row_ptr[k + 1] += S.row_ptr[k];
+  S.upd_a.resize(S.upd_ptr[nnzL]);
+  S.upd_b.resize(S.upd_ptr[nnzL]);
+  S.row_blk.resize(S.row_ptr[P]);
+  S.row_col.resize(S.row_ptr[P]);
+  {
+    std::vector<int> ucur(S.upd_ptr.begin(), S.upd_ptr.end() - 1), rcur(S.row_ptr.begin(), S.row_ptr.end() - 1);
+    for (int j = 0; j < P; j++)
+      for (size_t q = 0; q < col[j].size(); q++) {
+        const int k = col[j][q], bkj = S.colptr[j] + 1 + (int)q;
+        S.row_blk[rcur[k]] = bkj;
+        S.row_col[rcur[k]++] = j;
+        for (size_t p = q; p < col[j].size(); p++) {
+          const int d = find_block(col[j][p], k);
+          S.upd_a[ucur[d]] = S.colptr[j] + 1 + (int)p;
+          S.upd_b[ucur[d]++] = bkj;
+        }
+      }
+  }
+  // schedule: cut the elimination forest into independent subtrees + the top
+  std::vector<long long> weight((size_t)P, 0);
+  for (int j = 0; j < P; j++) {
+    const long long nb = 1 + (long long)col[j].size();
+    weight[j] += nb * nb;  // ~ block products + solves of the column
+    if (S.parent[j] >= 0) weight[S.parent[j]] += weight[j];
+  }
+  std::vector<char> in_top((size_t)P, 0);
+  std::priority_queue<std::pair<long long, int>> heap;
+  for (int j = 0; j < P; j++)
+    if (S.parent[j] < 0) heap.push({weight[j], j});
+  // the heaviest subtree is split at its first branching column: the path from its root down to that column goes to the top, the
+  // branches become subtrees of their own.  A subtree that is one path down to a leaf cannot be split (nothing in it runs in parallel).
+  const size_t want = 256;
+  std::vector<int> roots;
+  while (!heap.empty() && heap.size() + roots.size() < want) {
+    const int r = heap.top().second;
+    heap.pop();
+    int b = r;
+    while (children[b].size() == 1) b = children[b][0];
+    if (children[b].empty()) {
+      roots.push_back(r);
+      continue;
+    }
+    for (int v = r;; v = children[v][0]) {
+      in_top[v] = 1;
+      if (v == b) break;
+    }
+    for (int c : children[b]) heap.push({weight[c], c});
+  }
+  std::vector<int> owner((size_t)P, -1);  // subtree id; -1: top
+  S.num_subtrees = 0;
+  while (!heap.empty()) {
+    roots.push_back(heap.top().second);
+    heap.pop();
+  }
+  std::sort(roots.begin(), roots.end());
+  for (int r : roots) owner[r] = S.num_subtrees++;
+  for (int j = P - 1; j >= 0; j--)
+    if (!in_top[j] && owner[j] < 0) owner[j] = owner[S.parent[j]];  // parent index > child index: the parent is done
+  S.work_ptr.assign(S.num_subtrees + 2, 0);
+  for (int j = 0; j < P; j++) S.work_ptr[(in_top[j] ? S.num_subtrees : owner[j]) + 1]++;
+  for (int w = 0; w <= S.num_subtrees; w++) S.work_ptr[w + 1] += S.work_ptr[w];
+  S.work_cols.resize(P);
+  {
+    std::vector<int> cur(S.work_ptr.begin(), S.work_ptr.end() - 1);
+    for (int j = 0; j < P; j++) S.work_cols[cur[in_top[j] ? S.num_subtrees : owner[j]]++] = j;  // ascending inside every list
+  }
+  return GP_OK;
+}
+
+// ---- numeric phase ----------------------------------------------------------------------------------------------------------------
+
+enum : int { STAKE_HT = 0, STAKE_HS = 1, STAKE_HTS = 2, STAKE_HTS_T = 3 };
+constexpr int SREC_HT = 2, SREC_HS = 38, SREC_HTS = 74, SREC_BT = 110, SREC_BS = 116;  // offsets (doubles) inside gp_linearized6
+
+struct SparseDest {
+  int block;         // destination block of L
+  int diag_col;      // >= 0: the block is the diagonal block of this column (b is assembled with it)
+  int begin, count;  // range in the contribution list
+};
+struct SparseContribution {
+  int factor, take;
+};
+
+// A's blocks into their places in L's storage (fill blocks stay zero) + b, one 64-lane workgroup per destination, factor order
+__global__ void __launch_bounds__(64) sparse_assemble_kernel(const SparseDest* __restrict__ dests, const SparseContribution* __restrict__ contribs,
+                                                             const double* __restrict__ records, double* __restrict__ L, double* __restrict__ b) {
+  const SparseDest d = dests[blockIdx.x];
+  const int t = threadIdx.x;
+  if (t < 36) {
+    const int r = t % 6, c = t / 6;
+    double s = 0.0;
+    for (int k = 0; k < d.count; k++) {
+      const SparseContribution q = contribs[d.begin + k];
+      const double* rec = records + 122 * (size_t)q.factor;
+      double v;
+      if (q.take == STAKE_HT) {
+        v = rec[SREC_HT + c * 6 + r];
+      } else if (q.take == STAKE_HS) {
+        v = rec[SREC_HS + c * 6 + r];
+      } else if (q.take == STAKE_HTS) {
+        v = rec[SREC_HTS + c * 6 + r];
+      } else {
+        v = rec[SREC_HTS + r * 6 + c];
+      }
+      s += v;
+    }
+    L[36 * (size_t)d.block + t] = s;
+  } else if (t < 42 && d.diag_col >= 0) {
+    const int r = t - 36;
+    double s = 0.0;
+    for (int k = 0; k < d.count; k++) {
+      const SparseContribution q = contribs[d.begin + k];
+      const double* rec = records + 122 * (size_t)q.factor;
+      s -= q.take == STAKE_HT ? rec[SREC_BT + r] : rec[SREC_BS + r];  // g = -b (integrated_matching_cost_factor.cpp:49)
+    }
+    b[6 * (size_t)d.diag_col + r] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) sparse_damp_kernel(double* __restrict__ L, const int* __restrict__ colptr, int n, double lambda, int diagonal, double min_diag,
+                                                          double max_diag, const double* __restrict__ prior_diag /*elimination order*/) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double* p = L + 36 * (size_t)colptr[i / 6] + 7 * (i % 6);
+  const double d = *p;
+  double add = diagonal ? lambda * fmin(fmax(d, min_diag), max_diag) : lambda;
+  if (prior_diag) add += prior_diag[i];
+  *p = d + add;
+}
+
+struct SparseView {
+  const int* colptr;
+  const int* rowidx;
+  const int* upd_ptr;
+  const int* upd_a;
+  const int* upd_b;
+  const int* row_ptr;
+  const int* row_blk;
+  const int* row_col;
+  const int* work_ptr;
+  const int* work_cols;
+  double* L;      // [nnzL][36], column-major 6x6 blocks
+  double* y;      // [6 P] forward-substituted right-hand side (in: b), elimination order
+  double* x;      // [6 P] solution, elimination order
+  int* status;    // != 0: a pivot was not positive
+};
+
+constexpr int kSparseThreads = 256;
+
+// visibility of LDS writes between the lanes of ONE wave (its LDS operations execute in program order; this keeps the compiler from
+// moving them and makes it wait for the writes): what __syncthreads() is for a workgroup, without the s_barrier
+#define GP_WAVE_SYNC_LDS()                                   \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+  } while (0)
+
+// left-looking block Cholesky of the columns of work list (first_list + blockIdx.x), in elimination order
+__global__ void __launch_bounds__(kSparseThreads) sparse_factor_kernel(SparseView S, int first_list) {
+  __shared__ double D[6][7];   // diagonal block (row stride 7: the column sweeps below are conflict-free), becomes L_kk
+  __shared__ double rhs[6];
+  __shared__ int bad;
+  const int list = first_list + blockIdx.x;
+  const int t = threadIdx.x;
+  if (t == 0) bad = 0;
+  for (int w = S.work_ptr[list]; w < S.work_ptr[list + 1]; w++) {
+    const int k = S.work_cols[w];
+    const int base = S.colptr[k], nb = S.colptr[k + 1] - base;
+    // 1. gather: every entry of every block of the column collects its updates (ascending source column)
+    for (int e = t; e < 36 * nb; e += kSparseThreads) {
+      const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
+      double acc = S.L[36 * (size_t)d + (e % 36)];
+      for (int u = S.upd_ptr[d]; u < S.upd_ptr[d + 1]; u++) {
+        const double* A = S.L + 36 * (size_t)S.upd_a[u];
+        const double* B = S.L + 36 * (size_t)S.upd_b[u];
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * B[c + 6 * q];
+      }
+      if (d == base) {
+        D[r][c] = acc;
+      } else {
+        S.L[36 * (size_t)d + (e % 36)] = acc;
+      }
+    }
+    // right-hand side of the forward substitution: b_k - sum_j L_kj y_j
+    if (t >= 64 && t < 70) {
+      const int r = t - 64;
+      double acc = S.y[6 * (size_t)k + r];
+      for (int u = S.row_ptr[k]; u < S.row_ptr[k + 1]; u++) {
+        const double* A = S.L + 36 * (size_t)S.row_blk[u];
+        const double* yj = S.y + 6 * (size_t)S.row_col[u];
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * yj[q];
+      }
+      rhs[r] = acc;
+    }
+    __syncthreads();
+    // 2. the diagonal block: 6x6 Cholesky by the first wave (lane = (row, column)), then y_k = L_kk^-1 rhs
+    if (t < 64) {
+      const int r = t % 6, c = t / 6;
+      for (int j = 0; j < 6; j++) {
+        double piv = D[j][j];
+        if (!(piv > 0.0)) {
+          if (t == 0) bad = 1;
+          piv = 1.0;
+        }
+        const double l = sqrt(piv);
+        GP_WAVE_SYNC_LDS();
+        if (t < 36 && c == j && r >= j) D[r][j] = r == j ? l : D[r][j] / l;
+        GP_WAVE_SYNC_LDS();
+        if (t < 36 && c > j && r >= c) D[r][c] -= D[r][j] * D[c][j];
+        GP_WAVE_SYNC_LDS();
+      }
+      if (t == 0) {
+        for (int i = 0; i < 6; i++) {
+          double s = rhs[i];
+          for (int q = 0; q < i; q++) s -= D[i][q] * rhs[q];
+          rhs[i] = s / D[i][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (t < 36) S.L[36 * (size_t)base + t] = (t % 6) >= (t / 6) ? D[t % 6][t / 6] : 0.0;
+    if (t >= 64 && t < 70) S.y[6 * (size_t)k + (t - 64)] = rhs[t - 64];
+    // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row): forward substitution along the row
+    for (int e = t; e < 6 * (nb - 1); e += kSparseThreads) {
+      double* Bk = S.L + 36 * (size_t)(base + 1 + e / 6);
+      const int r = e % 6;
+      double o[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = Bk[r + 6 * c];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+          if (q < c) s -= o[q] * D[c][q];
+        o[c] = s / D[c][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
+    }
+    __syncthreads();  // the next column of this list reads these blocks (same compute unit: global writes are visible after the barrier)
+  }
+  if (t == 0 && bad) atomicOr(S.status, 1);
+}
+
+// backward substitution x_k = L_kk^-T (y_k - sum_i L_ik^T x_i) over the columns of a work list in REVERSE elimination order
+__global__ void __launch_bounds__(64) sparse_backsolve_kernel(SparseView S, int first_list) {
+  __shared__ double part[6][6], v[6];
+  const int list = first_list + blockIdx.x;
+  const int t = threadIdx.x;
+  for (int w = S.work_ptr[list + 1] - 1; w >= S.work_ptr[list]; w--) {
+    const int k = S.work_cols[w];
+    const int base = S.colptr[k], nb = S.colptr[k + 1] - base;
+    if (t < 36) {
+      // lane (c, slice): component c of sum_i L_ik^T x_i over the blocks slice, slice + 6, ... (fixed order)
+      const int c = t % 6, slice = t / 6;
+      double acc = 0.0;
+      for (int p = 1 + slice; p < nb; p += 6) {
+        const double* A = S.L + 36 * (size_t)(base + p);
+        const double* xi = S.x + 6 * (size_t)S.rowidx[base + p];
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc += A[q + 6 * c] * xi[q];
+      }
+      part[slice][c] = acc;
+    }
+    __syncthreads();
+    if (t < 6) {
+      double s = S.y[6 * (size_t)k + t];
+      for (int sl = 0; sl < 6; sl++) s -= part[sl][t];
+      v[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+      const double* Dk = S.L + 36 * (size_t)base;
+      double xk[6];
+      for (int i = 5; i >= 0; i--) {
+        double s = v[i];
+        for (int q = i + 1; q < 6; q++) s -= Dk[q + 6 * i] * xk[q];  // (L^T)_{iq} = L_{qi}
+        xk[i] = s / Dk[i + 6 * i];
+      }
+      for (int i = 0; i < 6; i++) S.x[6 * (size_t)k + i] = xk[i];
+    }
+    __syncthreads();  // x_k is read by the next columns of this list (one wave per workgroup: the barrier is free)
+  }
+}
+
+__global__ void __launch_bounds__(256) sparse_unpermute_kernel(const double* __restrict__ x_elim, const int* __restrict__ perm, int P, double* __restrict__ x_slots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 6 * P) x_slots[6 * (size_t)perm[i / 6] + i % 6] = x_elim[i];
+}
+
+__global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __restrict__ records, int num_factors, double* __restrict__ c_out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int f = threadIdx.x; f < num_factors; f += 256) s += records[122 * (size_t)f + 1];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *c_out = part[0];
+}
+
+}  // namespace gp
+
+struct gp_sparse_system {
+  gp::SparseSymbolic sym;
+  int num_factors = 0, n = 0;
+  hipStream_t stream = nullptr;
+  std::vector<gp::SparseDest> dests;
+  std::vector<gp::SparseContribution> contribs;
+  gp::DeviceArray d_dests, d_contribs, d_int, L, y, x, x_slots, c, status, prior;
+  gp::SparseView view{};
+  const int* d_perm = nullptr;
+  bool built = false;
+};
+
+extern "C" {
+
+int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
+                       int* num_subtrees, int* top_columns) {
+  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 1)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_symbolic: bad arguments (ordering: 0 = natural, 1 = nested dissection)");
+  gp::SparseSymbolic S;
+  GP_TRY(gp::sparse_symbolic(num_slots, factor_slots, num_factors, ordering, &S));
+  if (perm_out) memcpy(perm_out, S.perm.data(), sizeof(int) * (size_t)num_slots);
+  if (parent_out) memcpy(parent_out, S.parent.data(), sizeof(int) * (size_t)num_slots);
+  if (nnz_a_blocks) *nnz_a_blocks = S.nnzA;
+  if (nnz_l_blocks) *nnz_l_blocks = S.colptr[num_slots];
+  if (num_subtrees) *num_subtrees = S.num_subtrees;
+  if (top_columns) *top_columns = S.work_ptr[S.num_subtrees + 1] - S.work_ptr[S.num_subtrees];
+  return GP_OK;
+}
+
+int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_factors, int ordering, gp_stream_t stream, gp_sparse_system_t** out) {
+  if (!out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: null out");
+  *out = nullptr;
+  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 1)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: factor_slots = [num_factors][2] (target, source; < 0 = fixed), ordering 0 | 1");
+  auto s = std::make_unique<gp_sparse_system>();
+  GP_TRY(gp::sparse_symbolic(num_slots, factor_slots, num_factors, ordering, &s->sym));
+  const gp::SparseSymbolic& S = s->sym;
+  const int P = num_slots, nnzL = S.colptr[P];
+  s->num_factors = num_factors;
+  s->n = 6 * P;
+  s->stream = (hipStream_t)stream;
+  // destination block -> ordered contribution list (factor order = summation order)
+  std::map<int, std::vector<gp::SparseContribution>> lists;
+  auto block_of = [&](int i, int k) {
+    if (i == k) return S.colptr[k];
+    const int* b = S.rowidx.data() + S.colptr[k] + 1;
+    const int* e = S.rowidx.data() + S.colptr[k + 1];
+    return (int)(std::lower_bound(b, e, i) - S.rowidx.data());
+  };
+  for (int k = 0; k < P; k++) lists[S.colptr[k]];  // every diagonal block exists
+  for (int f = 0; f < num_factors; f++) {
+    const int st = factor_slots[2 * f], ss = factor_slots[2 * f + 1];
+    const int it = st >= 0 ? S.iperm[st] : -1, is = ss >= 0 ? S.iperm[ss] : -1;
+    if (it >= 0) lists[S.colptr[it]].push_back({f, gp::STAKE_HT});
+    if (is >= 0) lists[S.colptr[is]].push_back({f, gp::STAKE_HS});
+    if (it >= 0 && is >= 0) {
+      if (it > is) {
+        lists[block_of(it, is)].push_back({f, gp::STAKE_HTS});    // row = target, col = source
+      } else {
+        lists[block_of(is, it)].push_back({f, gp::STAKE_HTS_T});  // row = source, col = target
+      }
+    }
+  }
+  std::vector<int> diag_of((size_t)nnzL, -1);
+  for (int k = 0; k < P; k++) diag_of[S.colptr[k]] = k;
+  for (auto& kv : lists) {
+    gp::SparseDest d;
+    d.block = kv.first;
+    d.diag_col = diag_of[kv.first];
+    d.begin = (int)s->contribs.size();
+    d.count = (int)kv.second.size();
+    s->contribs.insert(s->contribs.end(), kv.second.begin(), kv.second.end());
+    s->dests.push_back(d);
+  }
+  // one device arena for all index arrays
+  const std::vector<int>* arrs[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols, &S.perm};
+  size_t total = 0;
+  for (const auto* a : arrs) total += a->size() + 1;
+  std::vector<int> packed;
+  packed.reserve(total);
+  size_t offs[11];
+  for (int i = 0; i < 11; i++) {
+    offs[i] = packed.size();
+    packed.insert(packed.end(), arrs[i]->begin(), arrs[i]->end());
+    packed.push_back(0);
+  }
+  int rc = GP_OK;
+  if ((rc = s->d_int.alloc(sizeof(int) * packed.size())) || (rc = s->d_dests.alloc(sizeof(gp::SparseDest) * s->dests.size())) ||
+      (rc = s->d_contribs.alloc(sizeof(gp::SparseContribution) * std::max<size_t>(s->contribs.size(), 1))) || (rc = s->L.alloc(sizeof(double) * 36 * (size_t)nnzL)) ||
+      (rc = s->y.alloc(sizeof(double) * (size_t)s->n)) || (rc = s->x.alloc(sizeof(double) * (size_t)s->n)) || (rc = s->x_slots.alloc(sizeof(double) * (size_t)s->n)) ||
+      (rc = s->c.alloc(sizeof(double))) || (rc = s->status.alloc(sizeof(int))) || (rc = s->prior.alloc(sizeof(double) * (size_t)s->n)))
+    return rc;
+  GP_HIP(hipMemcpy(s->d_int.ptr, packed.data(), sizeof(int) * packed.size(), hipMemcpyHostToDevice));
+  GP_HIP(hipMemcpy(s->d_dests.ptr, s->dests.data(), sizeof(gp::SparseDest) * s->dests.size(), hipMemcpyHostToDevice));
+  if (!s->contribs.empty()) GP_HIP(hipMemcpy(s->d_contribs.ptr, s->contribs.data(), sizeof(gp::SparseContribution) * s->contribs.size(), hipMemcpyHostToDevice));
+  const int* base = s->d_int.as<int>();
+  s->view.colptr = base + offs[0];
+  s->view.rowidx = base + offs[1];
+  s->view.upd_ptr = base + offs[2];
+  s->view.upd_a = base + offs[3];
+  s->view.upd_b = base + offs[4];
+  s->view.row_ptr = base + offs[5];
+  s->view.row_blk = base + offs[6];
+  s->view.row_col = base + offs[7];
+  s->view.work_ptr = base + offs[8];
+  s->view.work_cols = base + offs[9];
+  s->d_perm = base + offs[10];
+  s->view.L = s->L.as<double>();
+  s->view.y = s->y.as<double>();
+  s->view.x = s->x.as<double>();
+  s->view.status = s->status.as<int>();
+  *out = s.release();
+  return GP_OK;
+}
+
+int gp_sparse_system_destroy(gp_sparse_system_t* s) {
+  if (!s) return GP_OK;
+  (void)hipStreamSynchronize(s->stream);
+  delete s;
+  return GP_OK;
+}
+
+int gp_sparse_system_size(const gp_sparse_system_t* s) { return s ? s->n : 0; }
+
+int gp_sparse_system_info(const gp_sparse_system_t* s, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks, int64_t* block_products, int* num_subtrees, int* top_columns) {
+  if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_info: null");
+  const gp::SparseSymbolic& S = s->sym;
+  if (nnz_a_blocks) *nnz_a_blocks = S.nnzA;
+  if (nnz_l_blocks) *nnz_l_blocks = S.colptr[S.P];
+  if (block_products) *block_products = (int64_t)S.upd_a.size();
+  if (num_subtrees) *num_subtrees = S.num_subtrees;
+  if (top_columns) *top_columns = S.work_ptr[S.num_subtrees + 1] - S.work_ptr[S.num_subtrees];
+  return GP_OK;
+}
+
+int gp_sparse_system_build(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                           const double* prior_diag_host) {
+  if (!s || (!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_build: bad arguments");
+  const gp::SparseSymbolic& S = s->sym;
+  GP_HIP(hipMemsetAsync(s->L.ptr, 0, sizeof(double) * 36 * (size_t)S.colptr[S.P], s->stream));
+  GP_HIP(hipMemsetAsync(s->y.ptr, 0, sizeof(double) * (size_t)s->n, s->stream));
+  hipLaunchKernelGGL(gp::sparse_assemble_kernel, dim3((unsigned)s->dests.size()), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
+                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>());
+  hipLaunchKernelGGL(gp::sparse_sum_errors_kernel, dim3(1), dim3(256), 0, s->stream, reinterpret_cast<const double*>(records_dev), s->num_factors, s->c.as<double>());
+  const double* prior = nullptr;
+  std::vector<double> permuted;
+  if (prior_diag_host) {
+    permuted.resize((size_t)s->n);
+    for (int k = 0; k < S.P; k++)
+      for (int r = 0; r < 6; r++) permuted[6 * (size_t)k + r] = prior_diag_host[6 * (size_t)S.perm[k] + r];
+    GP_HIP(hipMemcpyAsync(s->prior.ptr, permuted.data(), sizeof(double) * (size_t)s->n, hipMemcpyHostToDevice, s->stream));
+    prior = s->prior.as<double>();
+  }
+  if (lambda > 0.0 || prior) {
+    hipLaunchKernelGGL(gp::sparse_damp_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->L.as<double>(), s->view.colptr, s->n, lambda, diagonal_damping,
+                       min_diagonal, max_diagonal, prior);
+  }
+  GP_HIP(hipGetLastError());
+  if (prior_diag_host) GP_HIP(hipStreamSynchronize(s->stream));  // `permuted` goes away
+  s->built = true;
+  return GP_OK;
+}
+
+// the system as a dense symmetric column-major [n][n] in SLOT order (for checkers), b [n] (slot order), c
+int gp_sparse_system_download(const gp_sparse_system_t* s, double* A_host, double* b_host, double* c_host) {
+  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_download: build the system first");
+  const gp::SparseSymbolic& S = s->sym;
+  const size_t n = (size_t)s->n;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (A_host) {
+    std::vector<double> L(36 * (size_t)S.colptr[S.P]);
+    GP_HIP(hipMemcpy(L.data(), s->L.ptr, sizeof(double) * L.size(), hipMemcpyDeviceToHost));
+    std::fill(A_host, A_host + n * n, 0.0);
+    for (int k = 0; k < S.P; k++)
+      for (int p = S.colptr[k]; p < S.colptr[k + 1]; p++) {
+        const int si = S.perm[S.rowidx[p]], sk = S.perm[k];
+        for (int c = 0; c < 6; c++)
+          for (int r = 0; r < 6; r++) {
+            const double v = L[36 * (size_t)p + 6 * c + r];  // A(6 i + r, 6 k + c)
+            if (p == S.colptr[k] && r < c) continue;          // diagonal block: lower triangle holds the data
+            A_host[(6 * (size_t)sk + c) * n + 6 * (size_t)si + r] = v;
+            A_host[(6 * (size_t)si + r) * n + 6 * (size_t)sk + c] = v;
+          }
+      }
+  }
+  if (b_host) {
+    std::vector<double> y(n);
+    GP_HIP(hipMemcpy(y.data(), s->y.ptr, sizeof(double) * n, hipMemcpyDeviceToHost));
+    for (int k = 0; k < S.P; k++)
+      for (int r = 0; r < 6; r++) b_host[6 * (size_t)S.perm[k] + r] = y[6 * (size_t)k + r];
+  }
+  if (c_host) GP_HIP(hipMemcpy(c_host, s->c.ptr, sizeof(double), hipMemcpyDeviceToHost));
+  return GP_OK;
+}
+
+// SparseLinearSolver::solve(A, b): A x = b by block-sparse LL^T.  The assembled blocks are overwritten by the factor (build again
+// before the next solve).  x in slot order.
+int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_out) {
+  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_solve: build the system first");
+  const gp::SparseSymbolic& S = s->sym;
+  const int nsub = S.num_subtrees;
+  const bool has_top = S.work_ptr[nsub + 1] > S.work_ptr[nsub];
+  GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
+  if (nsub > 0) hipLaunchKernelGGL(gp::sparse_factor_kernel, dim3(nsub), dim3(gp::kSparseThreads), 0, s->stream, s->view, 0);
+  if (has_top) hipLaunchKernelGGL(gp::sparse_factor_kernel, dim3(1), dim3(gp::kSparseThreads), 0, s->stream, s->view, nsub);
+  if (has_top) hipLaunchKernelGGL(gp::sparse_backsolve_kernel, dim3(1), dim3(64), 0, s->stream, s->view, nsub);
+  if (nsub > 0) hipLaunchKernelGGL(gp::sparse_backsolve_kernel, dim3(nsub), dim3(64), 0, s->stream, s->view, 0);
+  hipLaunchKernelGGL(gp::sparse_unpermute_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), s->d_perm, S.P, s->x_slots.as<double>());
+  GP_HIP(hipGetLastError());
+  s->built = false;
+  int h_status = 0;
+  GP_HIP(hipMemcpyAsync(&h_status, s->status.ptr, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  if (x_dev_out) GP_HIP(hipMemcpyAsync(x_dev_out, s->x_slots.ptr, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->stream));
+  if (x_host) GP_HIP(hipMemcpyAsync(x_host, s->x_slots.ptr, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (h_status != 0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_solve: the system is not positive definite (indeterminate linear system)");
+  return GP_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,8 @@
   DenseLinearSystemGPU  <- DenseLinearSystemBuilder (optimizers/linear_system_builder.cpp:39-48)
                            + buildDampedSystem       (optimizers/levenberg_marquardt_ext.cpp:146-161)
                            + DenseLinearSolver::solve (optimizers/linear_solver.hpp:18-22)
+  SparseLinearSystemGPU <- SparseLinearSystemBuilder<6> (optimizers/linear_system_builder.hpp:41-72) + buildDampedSystem
+                           + SparseLinearSolver::solve (optimizers/linear_solver.hpp:24-29): block-sparse LL^T over the pose graph
   linearize_on_device   -- one batched linearise whose records stay in HBM (what the solver consumes)
 
 Poses that are variables get a slot (0..num_slots-1); a factor key without a slot (a fixed pose) drops out of the system.
@@ -88,4 +90,76 @@ class DenseLinearSystemGPU:
         """x with A x = b (consumes the built system); raises GPError when A is not positive definite."""
         x = np.zeros(self.size)
         _capi.check(self._lib.gp_dense_system_solve(self._h, x.ctypes.data, None), "gp_dense_system_solve")
+        return x
+
+
+def sparse_symbolic(num_slots, factor_slots, ordering=0):
+    """The symbolic phase of SparseLinearSystemGPU alone (host code, no device needed): dict(perm, parent, nnz_a_blocks,
+    nnz_l_blocks, num_subtrees, top_columns)."""
+    lib = _capi.load()
+    fs = np.ascontiguousarray(np.asarray(factor_slots, dtype=np.int32).reshape(-1, 2))
+    perm, parent = np.zeros(num_slots, np.int32), np.zeros(num_slots, np.int32)
+    na, nl, ns, nt = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+    _capi.check(lib.gp_sparse_symbolic(int(num_slots), fs.ctypes.data, len(fs), int(ordering), perm.ctypes.data, parent.ctypes.data, C.byref(na), C.byref(nl), C.byref(ns),
+                                       C.byref(nt)), "gp_sparse_symbolic")
+    return dict(perm=perm, parent=parent, nnz_a_blocks=na.value, nnz_l_blocks=nl.value, num_subtrees=ns.value, top_columns=nt.value)
+
+
+class SparseLinearSystemGPU:
+    """A x = b over 6-dof pose slots as a block-sparse lower triangle, solved by a block-sparse LL^T on the device.
+
+    factor_slots as for DenseLinearSystemGPU; ordering: "natural" (slot order = elimination order) or "nd" (nested dissection)."""
+
+    ORDERINGS = {"natural": 0, "nd": 1}
+
+    def __init__(self, num_slots, factor_slots, ordering="nd", stream=None):
+        self._lib = _capi.load()
+        self.num_slots = int(num_slots)
+        self.factor_slots = np.ascontiguousarray(np.asarray(factor_slots, dtype=np.int32).reshape(-1, 2))
+        self.stream = stream
+        h = C.c_void_p()
+        _capi.check(self._lib.gp_sparse_system_create(self.num_slots, self.factor_slots.ctypes.data, len(self.factor_slots), self.ORDERINGS[ordering], stream, C.byref(h)),
+                    "gp_sparse_system_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.gp_sparse_system_destroy(h)
+            self._h = None
+
+    @property
+    def size(self):
+        return 6 * self.num_slots
+
+    def info(self):
+        na, nl, bp, ns, nt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        _capi.check(self._lib.gp_sparse_system_info(self._h, C.byref(na), C.byref(nl), C.byref(bp), C.byref(ns), C.byref(nt)), "gp_sparse_system_info")
+        return dict(nnz_a_blocks=na.value, nnz_l_blocks=nl.value, block_products=bp.value, num_subtrees=ns.value, top_columns=nt.value)
+
+    def build(self, records_dev, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, prior_diag=None):
+        if tuple(records_dev.shape) != (len(self.factor_slots), _capi.LINEARIZED6_DOUBLES) or not records_dev.is_contiguous():
+            raise ValueError("records_dev must be a contiguous [num_factors, 122] float64 device tensor")
+        prior = None
+        if prior_diag is not None:
+            prior = np.ascontiguousarray(prior_diag, dtype=np.float64)
+            if prior.shape != (self.size,):
+                raise ValueError("prior_diag must have 6 * num_slots entries")
+        _capi.check(
+            self._lib.gp_sparse_system_build(self._h, C.c_void_p(records_dev.data_ptr()), float(lam), int(bool(diagonal_damping)), float(min_diagonal), float(max_diagonal),
+                                             prior.ctypes.data if prior is not None else None),
+            "gp_sparse_system_build",
+        )
+        return self
+
+    def download(self):
+        """(A dense symmetric [n, n], b, c) in slot order -- for checkers"""
+        n = self.size
+        A, b, c = np.zeros((n, n)), np.zeros(n), np.zeros(1)
+        _capi.check(self._lib.gp_sparse_system_download(self._h, A.ctypes.data, b.ctypes.data, c.ctypes.data), "gp_sparse_system_download")
+        return A.T.copy(), b, float(c[0])
+
+    def solve(self):
+        x = np.zeros(self.size)
+        _capi.check(self._lib.gp_sparse_system_solve(self._h, x.ctypes.data, None), "gp_sparse_system_solve")
         return x

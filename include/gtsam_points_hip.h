@@ -352,6 +352,33 @@ int gp_dense_system_download(const gp_dense_system_t* sys, double* A_host, doubl
 /* x (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
 int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev);
 
+/* ---- the same step, block-sparse: SparseLinearSystemBuilder<6> + SparseLinearSolver ----
+ * SparseLinearSystemBuilder<BLOCK_SIZE> (include/gtsam_points/optimizers/linear_system_builder.hpp:41-72): A as a lower-triangular
+ *   block-sparse matrix in a given ordering, b, c;  SparseLinearSolver::solve(A, b) (optimizers/linear_solver.hpp:24-29), called from
+ *   levenberg_marquardt_ext.cpp:200-220.  Here: 6x6 blocks in a block-column structure that already holds the fill of the factor,
+ *   left-looking block LL^T in f64 scheduled over the elimination tree (independent subtrees = one workgroup each, then the
+ *   separator columns), forward substitution fused, four launches per solve; every block is a gather in a fixed order (deterministic).
+ * ordering: 0 = natural (the slot order is the elimination order: "the ordering from the factor key list"),
+ *           1 = nested dissection by BFS bisection of the pose graph (shallow elimination tree: chains become ~log2(P) levels).
+ * Same slot / record conventions as gp_dense_system_*; no limit on num_slots. */
+typedef struct gp_sparse_system gp_sparse_system_t;
+int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_factors, int ordering, gp_stream_t stream, gp_sparse_system_t** out);
+int gp_sparse_system_destroy(gp_sparse_system_t* sys);
+int gp_sparse_system_size(const gp_sparse_system_t* sys); /* 6 * num_slots */
+/* structure: blocks of A (lower triangle incl. diagonal), blocks of L (incl. fill), 6x6 block products per factorisation,
+ * independent subtrees, columns in the top part; any pointer may be NULL */
+int gp_sparse_system_info(const gp_sparse_system_t* sys, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks, int64_t* block_products, int* num_subtrees, int* top_columns);
+int gp_sparse_system_build(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                           const double* prior_diag_host);
+/* for checkers: A expanded to a full symmetric column-major [n][n] in slot order, b [n], c; any pointer may be NULL.  Synchronous. */
+int gp_sparse_system_download(const gp_sparse_system_t* sys, double* A_host, double* b_host, double* c_host);
+/* x in slot order (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
+int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_dev);
+/* the symbolic phase alone (pure host code, no device needed): elimination order perm[k] = slot eliminated k-th, elimination tree
+ * parent[k] (-1 = root), block counts and the schedule; any output pointer may be NULL */
+int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
+                       int* num_subtrees, int* top_columns);
+
 /* kernel selection (not part of the reference API): 0 = reference-shaped kernel (reference bucket table, 92 explicit sums: also
  * the path of non-orthonormal poses and the in-library cross-check), 1 / 2 = pipeline kernel over the hashed line table in f64 /
  * with f32 outer products, 3 / 4 = pipeline kernel over the occupancy-block grid in f64 / with f32 outer products.  Default 4:

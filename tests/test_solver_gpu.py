@@ -171,3 +171,120 @@ def test_lm_with_device_solve_reaches_the_alignment_gate(gpu, kitti07):
     for k in range(1, 5):
         ang, trans = pose_error(np.linalg.inv(values[0]) @ values[k], np.linalg.inv(gt[0]) @ gt[k])
         assert ang < 0.015 and trans < 0.15, (k, ang, trans)
+
+
+# ---- block-sparse LL^T over the pose graph (gp_sparse.hip): the dense path and numpy are the checkers ---------------------------
+
+
+def _random_records(pairs, rng, rows=40):
+    rec = np.zeros((len(pairs), 122))
+    for k in range(len(pairs)):
+        J = rng.normal(size=(rows, 12))
+        H = J.T @ J  # PSD 12x12: [[Ht, Hts], [Hts^T, Hs]]
+        rec[k, 0], rec[k, 1] = rows, rng.uniform(1, 2)
+        rec[k, 2:38], rec[k, 38:74], rec[k, 74:110] = H[:6, :6].T.reshape(36), H[6:, 6:].T.reshape(36), H[:6, 6:].T.reshape(36)
+        rec[k, 110:122] = rng.normal(size=12)
+    return rec
+
+
+@pytest.mark.parametrize("ordering", ["natural", "nd"])
+def test_sparse_system_matches_dense_and_numpy(gpu, kitti07, ordering):
+    _, _, pairs, factors, values = _graph(gpu, kitti07)
+    rec_dev = gpu.linearize_on_device(factors, values)
+    rec = rec_dev.cpu().numpy()
+    slots = [(i - 1, j - 1) for i, j in pairs]  # pose 0 fixed
+    sp = gpu.SparseLinearSystemGPU(4, slots, ordering=ordering)
+    A, b, c = sp.build(rec_dev).download()
+    Ah, bh, ch = _host_system(rec, slots, 4)
+    assert np.abs(A - Ah).max() <= 1e-12 * np.abs(Ah).max() and np.abs(b - bh).max() <= 1e-12 * np.abs(bh).max() and abs(c - ch) <= 1e-12 * abs(ch)
+    for lam, diag in [(0.0, False), (1e-3, False), (10.0, True)]:
+        Ad = sp.build(rec_dev, lam=lam, diagonal_damping=diag).download()[0]
+        want = Ah + (lam * np.diag(np.clip(np.diag(Ah), 1e-6, 1e32)) if diag else lam * np.eye(24))
+        assert np.abs(Ad - want).max() <= 1e-12 * np.abs(want).max()
+        x = sp.build(rec_dev, lam=lam, diagonal_damping=diag).solve()
+        xd = gpu.DenseLinearSystemGPU(4, slots).build(rec_dev, lam=lam, diagonal_damping=diag).solve()
+        xh = np.linalg.solve(want, bh)
+        assert np.linalg.norm(x - xh) <= 1e-9 * np.linalg.norm(xh), (lam, diag)
+        assert np.linalg.norm(x - xd) <= 1e-9 * np.linalg.norm(xd), (lam, diag)
+    # deterministic
+    assert np.array_equal(sp.build(rec_dev, lam=1e-3).solve(), sp.build(rec_dev, lam=1e-3).solve())
+    # gauge freedom -> indeterminate, reported; a prior fixes it
+    free = gpu.SparseLinearSystemGPU(5, pairs, ordering=ordering)
+    with pytest.raises(gpu.GPError):
+        free.build(rec_dev).solve()
+    prior = np.zeros(30)
+    prior[:6] = 1e6
+    x = free.build(rec_dev, prior_diag=prior).solve()
+    Af, bf, _ = _host_system(rec, pairs, 5)
+    xf = np.linalg.solve(Af + np.diag(prior), bf)
+    assert np.linalg.norm(x - xf) <= 1e-8 * np.linalg.norm(xf)
+
+
+@pytest.mark.parametrize("ordering", ["natural", "nd"])
+@pytest.mark.parametrize("case", ["chain512", "loops300", "grid", "unary+isolated"])
+def test_sparse_solve_on_synthetic_graphs(gpu, case, ordering):
+    import torch
+
+    rng = np.random.default_rng(11)
+    if case == "chain512":
+        P = 512
+        pairs = [(-1, 0)] + [(i, i + 1) for i in range(P - 1)]
+    elif case == "loops300":
+        P = 300
+        pairs = [(-1, 0)] + [(i, i + d) for i in range(P) for d in (1, 2) if i + d < P] + [(int(a), int(b)) for a, b in rng.integers(0, P, (40, 2)) if a != b]
+    elif case == "grid":
+        w = 14
+        P = w * w
+        pairs = [(r * w + c, r * w + c + 1) for r in range(w) for c in range(w - 1)] + [(r * w + c, (r + 1) * w + c) for r in range(w - 1) for c in range(w)]
+    else:
+        P = 12  # two separate chains, poses tied to fixed ones, and nothing but a unary factor on pose 11
+        pairs = [(-1, 0), (0, 1), (1, 2), (-1, 5), (5, 6), (6, 7), (7, 5), (-1, 11), (-1, 3), (3, 4), (-1, 8), (8, 9), (9, 10)]
+    rec = _random_records(pairs, rng)
+    rec_dev = torch.from_numpy(rec).cuda()
+    sp = gpu.SparseLinearSystemGPU(P, pairs, ordering=ordering)
+    info = sp.info()
+    assert info["nnz_l_blocks"] >= info["nnz_a_blocks"] >= P
+    x = sp.build(rec_dev, lam=1e-2).solve()
+    Ah, bh, _ = _host_system(rec, pairs, P)
+    xh = np.linalg.solve(Ah + 1e-2 * np.eye(6 * P), bh)
+    assert np.linalg.norm(x - xh) <= 1e-9 * np.linalg.norm(xh), info
+    A = sp.build(rec_dev, lam=1e-2).download()[0]
+    assert np.abs(A - (Ah + 1e-2 * np.eye(6 * P))).max() <= 1e-12 * np.abs(Ah).max()
+
+
+def test_sparse_lm_reaches_the_alignment_gate(gpu, kitti07):
+    """the LM loop of test_lm_with_device_solve_reaches_the_alignment_gate with the block-sparse solver"""
+    clouds, maps, pairs, factors, values0 = _graph(gpu, kitti07)
+    slots = [(i - 1, j - 1) for i, j in pairs]
+    sys = gpu.SparseLinearSystemGPU(4, slots, ordering="nd")
+    fset = gpu.NonlinearFactorSetGPU()
+    for f in factors:
+        fset.add(f)
+    values, lam = dict(values0), 1e-5
+    fset.linearize(values)
+    err = sum(f.error(values) for f in factors)
+    for _ in range(30):
+        rec_dev = gpu.linearize_on_device(factors, values)
+        improved = False
+        for _try in range(12):
+            dx = sys.build(rec_dev, lam=lam, diagonal_damping=True).solve()
+            new_values = dict(values)
+            for k in range(1, 5):
+                new_values[k] = values[k] @ expmap(dx[6 * (k - 1) : 6 * k])
+            fset.linearize(values)
+            fset.error(new_values)
+            new_err = sum(f.error(new_values) for f in factors)
+            if new_err < err:
+                improved, lam = True, max(lam / 10.0, 1e-12)
+                break
+            lam *= 10.0
+        if not improved:
+            break
+        rel = (err - new_err) / max(err, 1e-300)
+        values, err = new_values, new_err
+        if rel < 1e-4:
+            break
+    gt = [np.asarray(T, dtype=np.float64) for T in kitti07["poses"]]
+    for k in range(1, 5):
+        ang, trans = pose_error(np.linalg.inv(values[0]) @ values[k], np.linalg.inv(gt[0]) @ gt[k])
+        assert ang < 0.015 and trans < 0.15, (k, ang, trans)
