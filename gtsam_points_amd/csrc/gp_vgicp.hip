@@ -308,12 +308,22 @@ __device__ __forceinline__ double pick9(int i, double a0, double a1, double a2, 
 // add, ONE barrier, and wave 0 alone does the rest out of LDS with wave-level synchronisation; the pose is requested first of all.
 __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
                                                                                 const InlinePoses inl, const double* __restrict__ partials,
-                                                                                gp_linearized6* __restrict__ out, const DoneFlags done) {
+                                                                                gp_linearized6* __restrict__ out, const DoneFlags done, const int parts) {
   static_assert(ACC_STRIDE == 32 && kFinalizeThreads == 1024, "lane = (slice parity, component); 16 waves x 2 slices");
-  const int fi = blockIdx.x;
+  // parts > 1 (synchronous single-factor calls with many tiles): every record entry is LINEAR in the 29 sums, so `parts` workgroups
+  // each expand their share of the tiles into a complete record of their own (slot fi * parts + part, own completion word) and the
+  // host adds the records in slot order -- the 250 KB of partials of a 1 M-point factor then go through `parts` compute units'
+  // L1s instead of one (that was 4.9 of the kernel's 7.1 us)
+  const int fi = blockIdx.x / parts, part = blockIdx.x - fi * parts;
   const Pose T = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);  // in flight while the partials arrive
-  const int tile_begin = inl.use ? inl.factor.tile_begin : factors[fi].tile_begin;
-  const int tile_count = inl.use ? inl.factor.tile_count : factors[fi].tile_count;
+  int tile_begin = inl.use ? inl.factor.tile_begin : factors[fi].tile_begin;
+  int tile_count = inl.use ? inl.factor.tile_count : factors[fi].tile_count;
+  if (parts > 1) {
+    const int per = (tile_count + parts - 1) / parts;
+    const int lo = min(part * per, tile_count), hi = min(lo + per, tile_count);
+    tile_begin += lo;
+    tile_count = hi - lo;
+  }
   __shared__ double wsum[16][32];
   __shared__ double sum[32];
   __shared__ double Rl[9], Xl[9];  // R and [t]x, row-major
@@ -431,14 +441,14 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(
   GP_FIN_TRACE(3);
   // the record leaves in two coalesced sweeps of 8-byte stores (it may be only 8-byte aligned, integrated_vgicp_factor_gpu.cpp:219-220;
   // when `out` is host-mapped memory, scattered stores would each be their own PCIe write)
-  double* out_rec = reinterpret_cast<double*>(out + fi);
+  double* out_rec = reinterpret_cast<double*>(out + blockIdx.x);
   out_rec[t] = dst[t];
   if (t + 64 < 122) out_rec[t + 64] = dst[t + 64];
   if (done.flags) {
     GP_FIN_TRACE(4);
     __threadfence_system();  // the record is visible to the host before the word that announces it (one wave: no barrier needed)
     GP_FIN_TRACE(5);
-    if (t == 0) __hip_atomic_store(done.flags + fi, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) __hip_atomic_store(done.flags + blockIdx.x, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     GP_FIN_TRACE(6);
   }
 }
@@ -490,7 +500,7 @@ int launch_finalize_single(hipStream_t stream, const double* pose_dev, const dou
   if (general)
     hipLaunchKernelGGL(vgicp_finalize_kernel<true>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
   else
-    hipLaunchKernelGGL(vgicp_finalize_rigid_kernel, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
+    hipLaunchKernelGGL(vgicp_finalize_rigid_kernel, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done, 1);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_kernel", __FILE__, __LINE__);
 }
@@ -585,6 +595,8 @@ VariantDesc variant_desc(int v) {
   }
 }
 constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
+constexpr int kFinalizeParts = 4;   // workgroups sharing the finalize of a synchronous single-factor call (vgicp_finalize_rigid_kernel)
+constexpr int kFinalizeSplitTiles = 256;  // ... when the factor has at least this many tiles
 
 // where a launch takes its poses from
 struct PoseSource {
@@ -641,11 +653,11 @@ int build_table(gp_vgicp_batch* b) {
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
   GP_TRY(b->d_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
   GP_TRY(b->h_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
-  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * (size_t)std::max(F, 1)));
+  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * (size_t)std::max(F, kFinalizeParts)));
   GP_HIP(hipHostGetDevicePointer(&b->h_out_dev, b->h_out.ptr, 0));
   {
     const size_t before = b->h_done.bytes;
-    GP_TRY(b->h_done.ensure(sizeof(unsigned long long) * (size_t)std::max(F, 1)));
+    GP_TRY(b->h_done.ensure(sizeof(unsigned long long) * (size_t)std::max(F, kFinalizeParts)));
     if (b->h_done.bytes != before) memset(b->h_done.ptr, 0, b->h_done.bytes);
     GP_HIP(hipHostGetDevicePointer(&b->h_done_dev, b->h_done.ptr, 0));
   }
@@ -735,26 +747,26 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
 }
 
 template <bool GENERAL>
-int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev, gp::DoneFlags done = {}) {
+int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev, gp::DoneFlags done = {}, int parts = 1) {
   if constexpr (GENERAL)
     hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
                        ps.d_lin, ps.inl, partials, out_dev, done);
   else
-    hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
-                       ps.d_lin, ps.inl, partials, out_dev, done);
+    hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel, dim3((int)b->factors.size() * parts), dim3(gp::kFinalizeThreads), 0, b->stream,
+                       b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev, done, parts);
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
 
 // device work of one linearisation pass.  rigid == true: 29-sum kernel + adjoint expansion; false: 92-sum kernel
 // (exact for any 3x3 block, like the reference's explicit J_s).
-int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid, gp::DoneFlags done = {}) {
+int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid, gp::DoneFlags done = {}, int parts = 1) {
   if (b->factors.empty()) return GP_OK;
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
   if (rigid) {
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
-    return launch_finalize<false>(b, ps, partials, out_dev, done);
+    return launch_finalize<false>(b, ps, partials, out_dev, done, parts);
   }
   GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
   return launch_finalize<true>(b, ps, partials, out_dev, done);
@@ -1068,9 +1080,23 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, g_trace_host ? g_trace_host + 2047 * 16 : nullptr};
-  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), poses_are_rigid(poses_host, F), done));
-  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream));
-  memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
+  const bool rigid = poses_are_rigid(poses_host, F);
+  const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? kFinalizeParts : 1;
+  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, parts));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream));
+  if (parts == 1) {
+    memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
+  } else {
+    // the partial records add up entry by entry (all 122 scalars are linear in the tile sums), in slot order
+    const double* p = static_cast<const double*>(b->h_out.ptr);
+    double* o = reinterpret_cast<double*>(out_host);
+    constexpr int N = (int)(sizeof(gp_linearized6) / sizeof(double));
+    for (int k = 0; k < N; k++) {
+      double a = p[k];
+      for (int q = 1; q < parts; q++) a += p[(size_t)q * N + k];
+      o[k] = a;
+    }
+  }
   return GP_OK;
 }
 
@@ -1093,8 +1119,10 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host,
   if (table_is_stale(b)) GP_TRY(build_table(b));
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
+  // the device work of the SYNCHRONOUS call (gp_vgicp_batch_linearize), incl. its split finalize for a single large factor
+  const int parts = (F == 1 && poses_are_rigid(poses_host, F) && b->num_tiles >= kFinalizeSplitTiles) ? kFinalizeParts : 1;
   gp::DeviceArray d_out;
-  GP_TRY(d_out.alloc(sizeof(gp_linearized6) * F));
+  GP_TRY(d_out.alloc(sizeof(gp_linearized6) * F * (size_t)parts));
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
   double* partials = nullptr;
@@ -1104,11 +1132,11 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host,
   GP_HIP(hipEventCreate(&e0));
   GP_HIP(hipEventCreate(&e1));
   GP_HIP(hipEventCreate(&e2));
-  GP_TRY(launch_linearize(b, ps, d_out.as<gp_linearized6>(), rigid));  // warm-up
+  GP_TRY(launch_linearize(b, ps, d_out.as<gp_linearized6>(), rigid, {}, parts));  // warm-up
   GP_HIP(hipStreamSynchronize(b->stream));
   // whole pass, back to back
   GP_HIP(hipEventRecord(e0, b->stream));
-  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, ps, d_out.as<gp_linearized6>(), rigid));
+  for (int i = 0; i < iters; i++) GP_TRY(launch_linearize(b, ps, d_out.as<gp_linearized6>(), rigid, {}, parts));
   GP_HIP(hipEventRecord(e1, b->stream));
   GP_HIP(hipEventSynchronize(e1));
   float t_total = 0.f;
@@ -1118,7 +1146,7 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host,
   for (int i = 0; i < iters; i++) GP_TRY(rigid ? launch_tiles<gp::MODE_LIN>(b, ps, partials) : launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
   GP_HIP(hipEventRecord(e1, b->stream));
   for (int i = 0; i < iters; i++)
-    GP_TRY(rigid ? launch_finalize<false>(b, ps, partials, d_out.as<gp_linearized6>()) : launch_finalize<true>(b, ps, partials, d_out.as<gp_linearized6>()));
+    GP_TRY(rigid ? launch_finalize<false>(b, ps, partials, d_out.as<gp_linearized6>(), {}, parts) : launch_finalize<true>(b, ps, partials, d_out.as<gp_linearized6>()));
   GP_HIP(hipEventRecord(e2, b->stream));
   GP_HIP(hipEventSynchronize(e2));
   float t_main = 0.f, t_fin = 0.f;
