@@ -595,7 +595,15 @@ VariantDesc variant_desc(int v) {
   }
 }
 constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
-constexpr int kFinalizeParts = 4;   // workgroups sharing the finalize of a synchronous single-factor call (vgicp_finalize_rigid_kernel)
+constexpr int kFinalizePartsMax = 16;
+static int finalize_parts() {  // workgroups sharing the finalize of a synchronous single-factor call (vgicp_finalize_rigid_kernel)
+  static const int v = [] {
+    const char* e = getenv("GP_FINALIZE_PARTS");
+    const int p = e ? atoi(e) : 8;  // A/B on C2 (scripts/r02_gpu20.sh): 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 (and the host step suffers)
+    return p < 1 ? 1 : (p > kFinalizePartsMax ? kFinalizePartsMax : p);
+  }();
+  return v;
+}
 constexpr int kFinalizeSplitTiles = 256;  // ... when the factor has at least this many tiles
 
 // where a launch takes its poses from
@@ -653,11 +661,11 @@ int build_table(gp_vgicp_batch* b) {
   GP_TRY(b->d_tiles.ensure(sizeof(gp::TileDesc) * (size_t)std::max(b->num_tiles, 1)));
   GP_TRY(b->d_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
   GP_TRY(b->h_poses.ensure(sizeof(double) * 32 * (size_t)std::max(F, 1)));
-  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * (size_t)std::max(F, kFinalizeParts)));
+  GP_TRY(b->h_out.ensure(sizeof(gp_linearized6) * (size_t)std::max(F, kFinalizePartsMax)));
   GP_HIP(hipHostGetDevicePointer(&b->h_out_dev, b->h_out.ptr, 0));
   {
     const size_t before = b->h_done.bytes;
-    GP_TRY(b->h_done.ensure(sizeof(unsigned long long) * (size_t)std::max(F, kFinalizeParts)));
+    GP_TRY(b->h_done.ensure(sizeof(unsigned long long) * (size_t)std::max(F, kFinalizePartsMax)));
     if (b->h_done.bytes != before) memset(b->h_done.ptr, 0, b->h_done.bytes);
     GP_HIP(hipHostGetDevicePointer(&b->h_done_dev, b->h_done.ptr, 0));
   }
@@ -1081,7 +1089,7 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, g_trace_host ? g_trace_host + 2047 * 16 : nullptr};
   const bool rigid = poses_are_rigid(poses_host, F);
-  const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? kFinalizeParts : 1;
+  const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
   GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, parts));
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream));
   if (parts == 1) {
@@ -1120,7 +1128,7 @@ int gp_vgicp_batch_time_linearize(gp_vgicp_batch_t* b, const double* poses_host,
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
   // the device work of the SYNCHRONOUS call (gp_vgicp_batch_linearize), incl. its split finalize for a single large factor
-  const int parts = (F == 1 && poses_are_rigid(poses_host, F) && b->num_tiles >= kFinalizeSplitTiles) ? kFinalizeParts : 1;
+  const int parts = (F == 1 && poses_are_rigid(poses_host, F) && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
   gp::DeviceArray d_out;
   GP_TRY(d_out.alloc(sizeof(gp_linearized6) * F * (size_t)parts));
   PoseSource ps;
