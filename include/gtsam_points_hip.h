@@ -27,6 +27,11 @@
  *     only the upper triangle of H, integrated_matching_cost_factor.cpp:49).
  *   - gp_stream_t is a hipStream_t (the reference's CUstream_st*).  NULL = default stream.
  *   - Handles are thread-compatible (external synchronisation per handle).
+ *   - Ownership: handles hold raw pointers, not references.  A factor points at its voxel map and its source arrays, a batch /
+ *     multi-batch / factor set at its factors: destroy in the order batch -> factor -> map, and keep the source arrays alive as
+ *     long as a factor uses them (the reference holds shared_ptrs; the C++ mirror does the same on top of these handles).
+ *     gp_vgicp_factor_destroy / gp_vgicp_batch_destroy do not synchronise a caller-owned stream (the reference's clone() drops it
+ *     first): finish the work on it before destroying.
  */
 #ifndef GTSAM_POINTS_HIP_H
 #define GTSAM_POINTS_HIP_H
@@ -120,7 +125,12 @@ typedef struct gp_voxelmap gp_voxelmap_t;
 /* GaussianVoxelMapGPU(resolution, init_num_buckets=16384, max_bucket_scan_count=10,
  *                     target_points_drop_rate=1e-3, stream), gaussian_voxelmap_gpu.cu:176-198.
  * resolution is double so that voxel coordinates are computed exactly as the CPU map does
- * (fast_floor(x * (1.0/leaf)), gaussian_voxelmap_cpu.cpp:59-61). */
+ * (fast_floor(x * (1.0/leaf)), gaussian_voxelmap_cpu.cpp:59-61).
+ * Deviation: the default (binned) build keeps EVERY voxel -- like the CPU map -- and sizes the reference-visible bucket table by
+ * doubling from init_num_buckets until every voxel is inserted within max_bucket_scan_count probes; target_points_drop_rate is
+ * honoured only by the reference-shaped hashed build (gp_debug_set_map_build(1) and the fallback for huge bounding boxes), whose
+ * doubling sequence starts at the first size >= N/16, so with a drop rate > 0 num_buckets and the set of dropped points can
+ * differ from the reference's. */
 int gp_voxelmap_create(double resolution, int init_num_buckets, int max_bucket_scan_count, double target_points_drop_rate, gp_stream_t stream, gp_voxelmap_t** out);
 int gp_voxelmap_destroy(gp_voxelmap_t* map);
 /* insert(const PointCloud&): one-shot build from device arrays, gaussian_voxelmap_gpu.cu:211-307.
