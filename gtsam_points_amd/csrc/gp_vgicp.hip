@@ -599,7 +599,7 @@ constexpr int kFinalizePartsMax = 16;
 static int finalize_parts() {  // workgroups sharing the finalize of a synchronous single-factor call (vgicp_finalize_rigid_kernel)
   static const int v = [] {
     const char* e = getenv("GP_FINALIZE_PARTS");
-    const int p = e ? atoi(e) : 8;  // A/B on C2 (scripts/r02_gpu20.sh): 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 (and the host step suffers)
+    const int p = e ? atoi(e) : 8;  // A/B on C2 (scripts/r02_finalize_parts.sh): 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 (and the host step suffers)
     return p < 1 ? 1 : (p > kFinalizePartsMax ? kFinalizePartsMax : p);
   }();
   return v;
@@ -843,7 +843,8 @@ int ensure_self_batch(gp_vgicp_factor* f) {
 
 extern "C" {
 
-// timeline hook: kernel5 stores 8 s_memtime stamps per workgroup into dev_buffer ([num_tiles][8] uint64); NULL disables
+// timeline hook: the traced build of the default tile kernel stores 8 s_memtime stamps + HW_ID / XCC_ID per workgroup into
+// dev_buffer ([2048][16] uint64, row = tile index); row 2047 receives the stamps of the finalize kernel of synchronous calls.  NULL disables
 int gp_debug_set_trace_buffer(void* dev_buffer) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buffer);
   GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gp::g_trace), &p, sizeof(p)));

@@ -1,5 +1,5 @@
 """Workloads for profiling the kernels next to the headline: the voxel-map build (2 M points, 0.5 m) and BASELINE configs[4]
-(k-NN covariances + GICP linearise at 1 M points).  Run under rocprofv3 --kernel-trace --stats (scripts/r02_gpu6.sh).
+(k-NN covariances + GICP linearise at 1 M points).  Run under rocprofv3 --kernel-trace --stats (scripts/r02_evidence.sh).
 With `counters` the binned search counts its own work (queries, f32/f64 distance evaluations, block entries, cells) instead.
 Usage: python scripts/r02_profile_aux.py [map|c5|counters] [iters]"""
 import os
