@@ -264,7 +264,7 @@ def main():
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_pipeline_kernel<MODE_LIN, f32 outer products, 4 chunks/wave, block grid, lean start>",
+        kernel="vgicp_pipeline_kernel<MODE_LIN, f32 outer products, 4 chunks/wave, block grid, look-ahead lookup>",
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",
@@ -344,7 +344,7 @@ def main():
             scaling="weak",
             vs_baseline=None,
             dtype="f64",
-            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel variant 4)",
+            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel variant 8)",
             data="synthetic",
             config=dict(
                 workload="BASELINE configs[1]: single VGICP factor per GPU, 1M synthetic source pts vs 2M-pt GaussianVoxelMap @0.5 m",

@@ -566,7 +566,7 @@ namespace {
 //   1  pipeline kernel, f64 throughout, hashed line table          (the round-1 default)
 //   2  pipeline kernel, f32 outer products / accumulators on f64-accurate M, r, q, hashed line table
 //   3  pipeline kernel, f64 throughout, occupancy-block grid
-//   4  pipeline kernel, f32 outer products, occupancy-block grid    (default)
+//   4  pipeline kernel, f32 outer products, occupancy-block grid    (the default until the look-ahead kernel, variant 8)
 // Variants 3 / 4 fall back to 1 / 2 for a batch in which some map has no grid (bounding box beyond the block budget).
 // Measured and removed in round 2: the deep pipeline (lookups of the next chunks overlapped with the
 // algebra) and the source-frame formulation (per-voxel pre-pass).
@@ -575,13 +575,16 @@ namespace {
 //      so that a 15 k-point scan is not left to 15 workgroups.
 //   5  as 4 without the lean start, always 1024-point tiles (the first round-2 kernel; A/B)
 //   6 / 7  as 4 with 512- / 256-point tiles forced (A/B)
-int g_variant = 4;
+//   8  as 4 with the look-ahead lookup (AHEAD in gp_vgicp_tile.hpp): hop 1 of chunk j+1 travels with hop 2 of chunk j.   (default)
+//      Same arithmetic in the same order as 4: bit-identical results.  C2 -1..3 %, C3 -5 %, C4 -1.5 % tile-kernel time.
+int g_variant = 8;
 int g_stagger = 0;
 bool g_trace_on = false;
 unsigned long long* g_trace_host = nullptr;  // host copy of the trace buffer pointer (finalize stamps go to row 2047)
 struct VariantDesc {
   bool f32, grid, lean;
   int ppt;  // 64-point chunks per wave (0 = chosen per batch)
+  bool ahead = false;  // hop 1 of the next chunk travels with hop 2 of this one (linearise only)
 };
 VariantDesc variant_desc(int v) {
   switch (v) {
@@ -591,6 +594,7 @@ VariantDesc variant_desc(int v) {
     case 5: return {true, true, false, 4};
     case 6: return {true, true, true, 2};
     case 7: return {true, true, true, 1};
+    case 8: return {true, true, true, 0, true};
     default: return {true, true, true, 0};
   }
 }
@@ -738,6 +742,19 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       GP_LAUNCH_PIPE(false, 4, true, false, false);
     } else if (!vd.lean) {
       GP_LAUNCH_PIPE(true, 4, true, false, false);
+    } else if (vd.ahead && MODE == gp::MODE_LIN && b->ppt >= 2 && !(g_trace_on && b->ppt == 4)) {
+      if constexpr (MODE == gp::MODE_LIN) {
+        if (b->ppt == 4)
+          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 4, true, false, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
+                             ps.d_eval, inl, partials);
+        else
+          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 2, true, false, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
+                             ps.d_eval, inl, partials);
+      }
+    } else if (vd.ahead && MODE == gp::MODE_LIN && b->ppt == 4) {  // timeline build of the look-ahead kernel
+      if constexpr (MODE == gp::MODE_LIN)
+        hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 4, true, true, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
+                           ps.d_eval, inl, partials);
     } else if (b->ppt == 1) {
       GP_LAUNCH_PIPE(true, 1, true, false, true);
     } else if (b->ppt == 2) {
@@ -854,7 +871,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 7) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..7");
+  if (variant < 0 || variant > 8) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..8");
   g_variant = variant;
   return GP_OK;
 }

@@ -274,6 +274,8 @@ template <int WAIT_YOUNGER = 0>
 __device__ __forceinline__ void grid_wait(v4i& blk) {
   if constexpr (WAIT_YOUNGER == 0) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk) : : "memory");
+  } else if constexpr (WAIT_YOUNGER == 1) {
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(blk) : : "memory");
   } else {
     static_assert(WAIT_YOUNGER == 3, "one chunk request = 3 DMA instructions");
     asm volatile("s_waitcnt vmcnt(3)" : "+v"(blk) : : "memory");
@@ -289,7 +291,11 @@ __device__ __forceinline__ void grid_wait(v4i& blk) {
 // scratch traffic counts in vmcnt and would break the hand-placed waits (tests/test_build_cpu.py checks the resource usage).
 // LEAN: the prologue requests only chunk 0 (everybody's first burst is half as large, so it lands sooner); chunk 1 is requested
 // right behind the first lookup's hop 1.
-template <int MODE, bool OUTER_F32, int PPT, bool GRID, bool TRACE = false, bool LEAN = false>
+// AHEAD (block grid, f32 outer products, linearise): hop 1 of chunk j+1 is issued BEFORE hop 1 of chunk j is consumed, so it travels
+// together with hop 2 of chunk j -- one exposed round trip per step instead of two.  What chunk j+1 needs after its lookup (cell bit,
+// centre - l and q as floats, the block entry: 12 registers) stays live through the algebra of chunk j; the kernel has the room
+// (105 VGPRs without it, 128 allowed at four waves per SIMD).
+template <int MODE, bool OUTER_F32, int PPT, bool GRID, bool TRACE = false, bool LEAN = false, bool AHEAD = false>
 __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) vgicp_pipeline_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                              const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                              double* __restrict__ partials) {
@@ -330,7 +336,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
 
   if (ring) {
     chunk_dma(points, covs, first, wbase, lane);
-    if (PPT > 1 && !LEAN) chunk_dma(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
+    if (PPT > 1 && (!LEAN || AHEAD)) chunk_dma(points, covs, first + kChunkPoints, wbase + kChunkBytes, lane);
   }
 
   const Pose Tl = inl.use ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
@@ -450,7 +456,87 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
     }
   };
 
-  if (ring) {
+  if constexpr (AHEAD) {
+    static_assert(GRID && OUTER_F32 && MODE == MODE_LIN, "the look-ahead pipeline exists for the default linearise kernel");
+  }
+  struct Ahead {  // what a chunk carries from its front half (transform, hop 1 issued) to its back half (hop 2, algebra)
+    v4i blk;
+    float ex, ey, ez, qx, qy, qz;
+    int pos;  // bit of the voxel inside its block; < 0: outside the grid's box, or rejected by the surface validation
+  };
+  auto front = [&](int j, Ahead& P) {
+    const float* lp = reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes);
+    const double dx = (double)lp[3 * lane], dy = (double)lp[3 * lane + 1], dz = (double)lp[3 * lane + 2];
+    const double lx = Tl.r00 * dx + Tl.r01 * dy + Tl.r02 * dz + Tl.tx;
+    const double ly = Tl.r10 * dx + Tl.r11 * dy + Tl.r12 * dz + Tl.ty;
+    const double lz = Tl.r20 * dx + Tl.r21 * dy + Tl.r22 * dz + Tl.tz;
+    const double ux = lx * f.map.inv_leaf, uy = ly * f.map.inv_leaf, uz = lz * f.map.inv_leaf;
+    const double fx = __builtin_floor(ux), fy = __builtin_floor(uy), fz = __builtin_floor(uz);
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    P.ex = (float)(f.map.leaf * ((fx + 0.5) - ux));
+    P.ey = (float)(f.map.leaf * ((fy + 0.5) - uy));
+    P.ez = (float)(f.map.leaf * ((fz + 0.5) - uz));
+    P.qx = (float)lx;
+    P.qy = (float)ly;
+    P.qz = (float)lz;
+    bool live = true;
+    if (f.surface_validation && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + (size_t)j * kChunkPoints + lane))) live = false;
+    const int bx = (cx >> 2) - f.map.glo[0], by = (cy >> 2) - f.map.glo[1], bz = (cz >> 2) - f.map.glo[2];
+    const bool inbox = (unsigned)bx < (unsigned)f.map.gdim[0] && (unsigned)by < (unsigned)f.map.gdim[1] && (unsigned)bz < (unsigned)f.map.gdim[2];
+    const unsigned lin = inbox ? ((unsigned)bz * (unsigned)f.map.gdim[1] + (unsigned)by) * (unsigned)f.map.gdim[0] + (unsigned)bx : 0u;
+    P.pos = (inbox && live) ? (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3)) : -1;
+    grid_issue(gblocks + 16 * (size_t)lin, P.blk);
+  };
+  auto back = [&](int j, Ahead& P) {  // P.blk has landed
+    const unsigned long long bits = ((unsigned long long)(unsigned)P.blk.y << 32) | (unsigned long long)(unsigned)P.blk.x;
+    const int pos = P.pos < 0 ? 0 : P.pos;
+    const bool hit = P.pos >= 0 && ((bits >> pos) & 1ull);
+    const int idx = P.blk.z + __popcll(bits & ((1ull << pos) - 1ull));
+    v4f head;
+    v2d c01, c23, c45;
+    record_issue(hit ? records + 64 * (size_t)idx : records, head, c01, c23, c45);
+    if (j + 2 < PPT) {
+      chunk_dma(points, covs, first + (size_t)(j + 2) * kChunkPoints, wbase + ((j + 2) % STAGES) * kChunkBytes, lane);
+      record_wait<3>(head, c01, c23, c45);  // the record -- and hop 1 of chunk j+1, which is older -- are here; chunk j+2 keeps travelling
+    } else {
+      record_wait<0>(head, c01, c23, c45);
+    }
+    double a[6];
+    load_cov6(reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes) + kChunkPoints * 3 + 9 * lane, a);
+    if (hit) accumulate_core<MODE, acc_t, float>(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
+  };
+
+  if (ring && AHEAD) {
+    if constexpr (AHEAD) {
+      Ahead P[2];
+      // in flight: chunk 0, chunk 1 (3 requests each)
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // chunk 0 is in LDS
+      GP_TRACE(1);
+      front(0, P[0]);                                    // in flight: chunk 1, hop 1 of chunk 0
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        if (j + 1 < PPT) {
+          // chunk j+1 must be in LDS.  j == 0: it is older than hop 1 of chunk 0, which may keep travelling; j >= 1: the only requests
+          // in flight are chunk j+1's (step j-1 waited for its record, and hop 1 of chunk j is older than that)
+          if (j == 0) {
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          front(j + 1, P[(j + 1) & 1]);
+          grid_wait<1>(P[j & 1].blk);  // hop 1 of chunk j (older than the one just issued)
+        } else {
+          grid_wait<0>(P[j & 1].blk);
+        }
+        if (j == 0) GP_TRACE(2);
+        if (j == 1) GP_TRACE(4);
+        back(j, P[j & 1]);
+        if (j == 0) GP_TRACE(3);
+        if (j == 1) GP_TRACE(5);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else if (ring) {
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
       // only chunk j+1's request may be younger than chunk j (normally already satisfied: step j-1 waited for its gather,

@@ -391,7 +391,8 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
 
 /* kernel selection (not part of the reference API): 0 = reference-shaped kernel (reference bucket table, 92 explicit sums: also
  * the path of non-orthonormal poses and the in-library cross-check), 1 / 2 = pipeline kernel over the hashed line table in f64 /
- * with f32 outer products, 3 / 4 = pipeline kernel over the occupancy-block grid in f64 / with f32 outer products.  Default 4:
+ * with f32 outer products, 3 / 4 = pipeline kernel over the occupancy-block grid in f64 / with f32 outer products, 5 / 6 / 7 = A/B
+ * forms of 4 (no lean start; 512- / 256-point tiles), 8 = 4 with the look-ahead lookup (bit-identical results).  Default 8:
  * M = (C_B + R C_A R^T)^-1, the transform and the residual are f64 in every variant; "f32 outer products" computes what follows
  * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md section 8 */
 int gp_debug_set_variant(int variant);

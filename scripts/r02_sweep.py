@@ -57,7 +57,7 @@ def run_case(name, d, res, delta, Lo, iters=50):
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
     out = np.zeros((1, 122))
     for v in variants:
-        for st in (staggers if v in (2, 4, 5) else [0]):
+        for st in (staggers if v in (2, 4, 5, 8) else [0]):
             _capi.check(lib.gp_debug_set_variant(v), "variant")
             _capi.check(lib.gp_debug_set_stagger(st), "stagger")
             batch, s = make_batch(f)
@@ -77,12 +77,12 @@ def run_case(name, d, res, delta, Lo, iters=50):
             lib.gp_vgicp_batch_destroy(batch)
             lib.gp_stream_destroy(s)
     lib.gp_debug_set_stagger(0)
-    lib.gp_debug_set_variant(4)
+    lib.gp_debug_set_variant(8)
     return f, vm, src, tgt
 
 
 def trace_case(f, delta, stagger, label):
-    lib.gp_debug_set_variant(4)
+    lib.gp_debug_set_variant(8)
     lib.gp_debug_set_stagger(stagger)
     batch, s = make_batch(f)
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
@@ -149,5 +149,5 @@ run_case("kitti00_dec8", dk, 0.5, dlt, Lok, iters=200)
 if BIG:
     # the real kernel on a working set beyond the 256 MiB Infinity Cache: 8 M source points (384 MB) vs the same 2 M-point map
     big = synthetic.make_c2_workload(8_000_000, 2_000_000, seed=42)
-    variants = [4, 3]
+    variants = [8, 4, 3]
     run_case("c2_8M_source", big, 0.5, big["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015]), None, iters=20)

@@ -222,7 +222,7 @@ def test_unsymmetrised_covariances(gpu, kitti00):
                 assert rel_err(getattr(L, k), getattr(Lo, k)) <= PARITY_TOL, (variant, k)
             assert abs(L.error - Lo.error) <= PARITY_TOL * Lo.error
     finally:
-        lib.gp_debug_set_variant(4)
+        lib.gp_debug_set_variant(8)
     # GICP reads both clouds' covariances the same way
     fg = gpu.IntegratedGICPFactorGPU(0, 1, tgt, src)
     Lg = fg.linearize_delta(delta)
