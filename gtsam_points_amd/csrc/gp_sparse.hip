@@ -121,6 +121,12 @@ static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vec
       }
     }
     if (cut < 0) cut = depth / 2;
+    if (4 * (size_t)width[cut] > nodes.size()) {
+      // the separator would be a quarter of the piece or more (band-like pieces a few separators wide): dissecting further only
+      // moves columns into the sequential top part.  The piece is eliminated in BFS order instead (a band ordering: low fill).
+      for (int v : seq) order->push_back(v);
+      return;
+    }
     std::vector<int> A, B, S;
     for (int v : nodes) (level[v] < cut ? A : (level[v] > cut ? B : S)).push_back(v);
     rec(A);
