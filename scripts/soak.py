@@ -23,6 +23,8 @@ for it in range(3000):
         gpa.overlap_gpu([vm, vm], src, [np.eye(4), d["T_true"]])
         gpa.merge_frames_gpu([np.eye(4), d["T_true"]], [tgt, src], 0.3)
         rec = gpa.linearize_on_device([f], values); gpa.DenseLinearSystemGPU(1, [(-1, 0)]).build(rec, lam=1e-3).solve()
+        gpa.SparseLinearSystemGPU(1, [(-1, 0)]).build(rec, lam=1e-3).solve()
+        fg = gpa.IntegratedGICPFactorGPU(0, 1, tgt, src); fg.linearize_delta(d["T_true"])
     if it % 500 == 0:
         src.offload_gpu(); vm.offload_gpu()
 m1 = free_mb()
