@@ -579,6 +579,7 @@ namespace {
 //      Same arithmetic in the same order as 4: bit-identical results.  C2 -1..3 %, C3 -5 %, C4 -1.5 % tile-kernel time.
 int g_variant = 8;
 int g_stagger = 0;
+int g_xcd_chunk = 0;
 bool g_trace_on = false;
 unsigned long long* g_trace_host = nullptr;  // host copy of the trace buffer pointer (finalize stamps go to row 2047)
 struct VariantDesc {
@@ -703,7 +704,11 @@ int partials_ptr(gp_vgicp_batch* b, double** out) {
   return GP_OK;
 }
 
-inline int grid_tiles(int num_tiles) {
+inline int grid_tiles(int num_tiles, int xcd_chunk = 0) {
+  if (xcd_chunk > 0) {
+    const int group = gp::kNumXCD * xcd_chunk;
+    return (num_tiles + group - 1) / group * group;
+  }
   const int per = (num_tiles + gp::kNumXCD - 1) / gp::kNumXCD;
   return per * gp::kNumXCD;
 }
@@ -719,11 +724,14 @@ bool poses_are_rigid(const double* poses_host, size_t F) {
 template <int MODE>
 int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   if (b->num_tiles <= 0) return GP_OK;
-  const dim3 grid_dim(grid_tiles(b->num_tiles)), block(gp::kBlockThreads);
+  // the reference-shaped kernels (variant 0, the 92-sum path) keep the contiguous map
+  const int chunk = (MODE == gp::MODE_LIN_GENERAL || b->variant == 0) ? 0 : g_xcd_chunk;
+  const dim3 grid_dim(grid_tiles(b->num_tiles, chunk)), block(gp::kBlockThreads);
   const gp::FactorDesc* fd = b->d_factors.as<gp::FactorDesc>();
   const gp::TileDesc* td = b->d_tiles.as<gp::TileDesc>();
   gp::InlinePoses inl = ps.inl;
   inl.stagger = g_stagger;
+  inl.xcd_chunk = chunk;
   if constexpr (MODE == gp::MODE_LIN_GENERAL) {
     // the general (non-orthonormal pose) path always uses the reference-shaped kernel
     hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
@@ -873,6 +881,12 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 int gp_debug_set_variant(int variant) {
   if (variant < 0 || variant > 8) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..8");
   g_variant = variant;
+  return GP_OK;
+}
+
+int gp_debug_set_xcd_chunk(int tiles) {
+  if (tiles < 0 || tiles > 4096) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_xcd_chunk: 0 (contiguous eighths) .. 4096 tiles per run");
+  g_xcd_chunk = tiles;
   return GP_OK;
 }
 

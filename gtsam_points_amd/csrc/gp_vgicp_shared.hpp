@@ -30,7 +30,9 @@ struct InlinePoses {
   FactorDesc factor;
   int use;
   int tile_points;
-  int stagger;  // tuning knob of the pipeline kernel: odd wave slots start `stagger` x 512 clocks late (0 = off)
+  int stagger;    // tuning knob of the pipeline kernel: odd wave slots start `stagger` x 512 clocks late (0 = off)
+  int xcd_chunk;  // workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list; c > 0 = the
+                  // tile list is dealt to the XCDs in runs of c tiles (round robin), which evens out what the XCDs have to do
 };
 
 struct TileDesc {

@@ -303,12 +303,23 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
   constexpr int NACC = MODE == MODE_ERR ? 2 : ACC_SIZE;
   constexpr int STAGES = 3;
   __shared__ __attribute__((aligned(16))) char smem[4 * STAGES * kChunkBytes];  // 36 KB
-  const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
-  const int tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;  // XCD-aware workgroup -> tile map
+  // XCD-aware workgroup -> tile map (workgroup b runs on XCD b % 8)
+  int tile_idx;
+  if (inl.xcd_chunk > 0) {
+    const int c = inl.xcd_chunk, x = blockIdx.x % kNumXCD, q = blockIdx.x / kNumXCD;
+    tile_idx = ((q / c) * kNumXCD + x) * c + (q % c);
+  } else {
+    const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+    tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
+  }
   if (tile_idx >= num_tiles) return;
   unsigned long long* trace = TRACE ? g_trace : nullptr;
   GP_TRACE(0);
   if constexpr (TRACE) {
+    // s_memtime (the stamps above) runs at the shader clock but is not synchronised across compute units: only differences inside
+    // one workgroup mean anything.  s_memrealtime is the 100 MHz constant clock shared by the whole device: start / end of every
+    // workgroup on one time axis (10 ns resolution) for the ramp and the tail of the launch.
+    if (trace && threadIdx.x == 0) trace[(size_t)tile_idx * 16 + 10] = __builtin_amdgcn_s_memrealtime();
     if (trace && threadIdx.x == 0) {
       trace[(size_t)tile_idx * 16 + 8] = __builtin_amdgcn_s_getreg(GP_GETREG_HW_ID);
       trace[(size_t)tile_idx * 16 + 9] = __builtin_amdgcn_s_getreg(GP_GETREG_XCC_ID);
@@ -639,6 +650,9 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
     ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = sum;
   }
   GP_TRACE(7);
+  if constexpr (TRACE) {
+    if (trace && threadIdx.x == 0) trace[(size_t)tile_idx * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 }  // namespace gp

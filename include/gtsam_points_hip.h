@@ -396,6 +396,9 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
  * M = (C_B + R C_A R^T)^-1, the transform and the residual are f64 in every variant; "f32 outer products" computes what follows
  * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md section 8 */
 int gp_debug_set_variant(int variant);
+/* workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles are
+ * dealt to the XCDs round robin */
+int gp_debug_set_xcd_chunk(int tiles);
 /* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
  * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
 int gp_debug_set_map_build(int hashed);

@@ -95,9 +95,17 @@ def trace_case(f, delta, stagger, label):
     lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
     torch.cuda.synchronize()
     lib.gp_debug_set_trace_buffer(None)
-    raw = trace.cpu().numpy()
+    raw = trace.cpu().numpy()[:2047]  # (row 2047 belongs to the finalize kernel: scripts/trace_finalize.py)
     raw = raw[raw[:, 0] > 0]
+    # rows stamped by an earlier launch (a workgroup whose tile index is not used by the traced launch keeps its old stamps)
     t = raw[:, :8].astype(np.float64)
+    # one time axis for the whole device: the 100 MHz constant clock (s_memrealtime), 10 ns per tick
+    rs, re_ = raw[:, 10].astype(np.float64) / 100.0, raw[:, 11].astype(np.float64) / 100.0
+    ok = np.abs(rs - np.median(rs)) < 100.0  # (a row of a tile index the traced launch did not use keeps older stamps)
+    rs, re_ = rs[ok] - rs[ok].min(), re_[ok] - rs[ok].min()
+    device_axis = dict(wgs=int(ok.sum()), start_p50_us=round(float(np.median(rs)), 2), start_p90_us=round(float(np.percentile(rs, 90)), 2), start_max_us=round(float(rs.max()), 2),
+                       end_min_us=round(float(re_.min()), 2), end_p10_us=round(float(np.percentile(re_, 10)), 2), end_p50_us=round(float(np.median(re_)), 2),
+                       end_p90_us=round(float(np.percentile(re_, 90)), 2), end_max_us=round(float(re_.max()), 2), life_p50_us=round(float(np.median(re_ - rs)), 2))
     hw = raw[:, 8]
     xcc = raw[:, 9] & 0xF
     wave_slot, simd, cu, sh, se = hw & 0xF, (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
@@ -108,19 +116,36 @@ def trace_case(f, delta, stagger, label):
     for x in sorted(set(xcc.tolist())):
         r = t[xcc == x]
         s0 = r[:, 0].min()
-        doms.append(dict(xcc=int(x), wgs=int(len(r)), start_skew_us=round(float((r[:, 0].max() - s0) / 2100), 2), last_end_us=round(float((r[:, 7].max() - s0) / 2100), 2),
-                         median_life_us=round(float(np.median(r[:, 7] - r[:, 0]) / 2100), 2)))
+        life = (r[:, 7] - r[:, 0]) / 2100
+        doms.append(dict(xcc=int(x), wgs=int(len(r)), start_skew_us=round(float((r[:, 0].max() - s0) / 2100), 2), start_p50_us=round(float(np.median(r[:, 0] - s0) / 2100), 2),
+                         first_end_us=round(float((r[:, 7].min() - s0) / 2100), 2), last_end_us=round(float((r[:, 7].max() - s0) / 2100), 2),
+                         median_life_us=round(float(np.median(life)), 2), p90_life_us=round(float(np.percentile(life, 90)), 2), max_life_us=round(float(life.max()), 2)))
     # placement: workgroups per (xcc, se, sh, cu), and which tile indices share a CU
     keys = xcc * 4096 + se * 512 + sh * 256 + cu
     uniq, counts = np.unique(keys, return_counts=True)
-    tile_ids = np.nonzero(trace.cpu().numpy()[:, 0] > 0)[0]
+    # end of the last workgroup of every CU on the device-wide axis, by how many workgroups the CU got, and per XCC
+    re_all = raw[:, 11].astype(np.float64) / 100.0 - (raw[:, 10].astype(np.float64) / 100.0)[ok].min()
+    cu_end = {}
+    for k_, e_, good in zip(keys.tolist(), re_all.tolist(), ok.tolist()):
+        if good:
+            cu_end[k_] = max(cu_end.get(k_, 0.0), e_)
+    cnt = dict(zip(uniq.tolist(), counts.tolist()))
+    by_load = {}
+    for k_, e_ in cu_end.items():
+        by_load.setdefault(cnt[k_], []).append(e_)
+    device_axis["cu_last_end_by_wgs_per_cu"] = {str(n): dict(cus=len(v), p50=round(float(np.median(v)), 2), p90=round(float(np.percentile(v, 90)), 2), max=round(float(max(v)), 2)) for n, v in sorted(by_load.items())}
+    by_xcc = {}
+    for k_, e_ in cu_end.items():
+        by_xcc.setdefault(k_ // 4096, []).append(e_)
+    device_axis["cu_last_end_by_xcc"] = {str(x): dict(p50=round(float(np.median(v)), 2), max=round(float(max(v)), 2)) for x, v in sorted(by_xcc.items())}
+    tile_ids = np.nonzero(trace.cpu().numpy()[:2047, 0] > 0)[0]
     same_cu = {}
     for k_, tid in zip(keys.tolist(), tile_ids.tolist()):
         same_cu.setdefault(k_, []).append(tid)
     example = [v for v in same_cu.values()][:4]
     print(json.dumps(dict(trace=label, stagger=stagger, wgs=int(len(t)), phases=names,
                           phase_median_us=[round(float(np.median(dur[:, k])), 3) for k in range(7)], phase_p90_us=[round(float(np.percentile(dur[:, k], 90)), 3) for k in range(7)],
-                          domains=doms, cus_used=int(len(uniq)), wgs_per_cu_hist=np.bincount(counts).tolist(), wave_slot_hist=np.bincount(wave_slot.astype(np.int64), minlength=16).tolist(),
+                          device_axis=device_axis, domains=doms, cus_used=int(len(uniq)), wgs_per_cu_hist=np.bincount(counts).tolist(), wave_slot_hist=np.bincount(wave_slot.astype(np.int64), minlength=16).tolist(),
                           simd_hist=np.bincount(simd.astype(np.int64), minlength=4).tolist(), tiles_sharing_a_cu_examples=example)), flush=True)
     lib.gp_vgicp_batch_destroy(batch)
     lib.gp_stream_destroy(s)
