@@ -32,8 +32,9 @@ int hip_fail(hipError_t err, const char* expr, const char* file, int line);
 // Per-thread cache of stream-ordered blocks.  hipMallocAsync / hipFreeAsync cost 20-50 us apiece on this stack even when the pool
 // holds the memory, and the structure builds (bin_points, voxel-map insert, k-NN grid) take ~15 scratch arrays each: the allocator
 // calls were 1-2 ms of a 3 ms covariance estimation.  A released block is parked here, tagged with the stream in whose order it
-// was released (nullptr: the owner synchronised the device first, so any stream may take it), and handed to the next request of
-// the same device and stream whose size it fits (<= 2x).  Bounded: kMaxEntries blocks / kMaxBytes; beyond that blocks go back to
+// was released (kSyncedRelease: the owner synchronised the work that used it first, so any stream may take it), and handed to the next
+// request of the same device and stream whose size it fits (<= 2x).  A block released in the order of the NULL stream is only handed
+// back to requests on the NULL stream: non-blocking streams are not ordered behind it.  Bounded: kMaxEntries blocks / kMaxBytes; beyond that blocks go back to
 // the pool.  gp_trim_device_cache() empties it.
 struct BlockCache {
   struct Entry {
@@ -42,6 +43,7 @@ struct BlockCache {
     hipStream_t stream;
     int device;
   };
+  static hipStream_t synced_release() { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(1)); }  // tag, never a real stream
   static constexpr size_t kMaxEntries = 96;
   static constexpr size_t kMaxBytes = size_t(4) << 30;
   std::vector<Entry> entries;
@@ -54,7 +56,7 @@ struct BlockCache {
     int best = -1;
     for (int i = 0; i < (int)entries.size(); i++) {
       const Entry& e = entries[i];
-      if (e.device != device || (e.stream != nullptr && e.stream != stream) || e.bytes < n || e.bytes > 2 * n + 4096) continue;
+      if (e.device != device || (e.stream != synced_release() && e.stream != stream) || e.bytes < n || e.bytes > 2 * n + 4096) continue;
       if (best < 0 || e.bytes < entries[best].bytes) best = i;
     }
     if (best < 0) return nullptr;
@@ -133,11 +135,12 @@ struct DeviceArray {
     return GP_OK;
   }
   // library-owned arrays that outlive the call (voxel maps, bins): pooled like the reference's cudaMallocAsync'ed members, but
-  // returned to the pool on the NULL stream -- the creating stream is the caller's and may be gone by then; owners synchronise
-  // the device before they let go of such arrays (gp_voxelmap_destroy)
+  // not released in the order of the creating stream -- it is the caller's and may be gone by then; owners synchronise the work
+  // that used such arrays before they let go of them (gp_voxelmap_destroy synchronises the device), so the block may be re-used on
+  // any stream
   int alloc_pooled(size_t n, hipStream_t stream) {
     const int rc = alloc_async(n, stream);
-    pool_stream = nullptr;
+    pool_stream = BlockCache::synced_release();
     return rc;
   }
   // for owners that know every use of the array was ordered on `stream`: return it to the pool in that stream's order
@@ -149,7 +152,7 @@ struct DeviceArray {
   void release() {
     if (ptr) {
       if (pooled) {
-        if (!BlockCache::get().put(ptr, bytes, pool_stream, device)) (void)hipFreeAsync(ptr, pool_stream);
+        if (!BlockCache::get().put(ptr, bytes, pool_stream, device)) (void)hipFreeAsync(ptr, pool_stream == BlockCache::synced_release() ? nullptr : pool_stream);
       } else {
         (void)hipFree(ptr);
       }
