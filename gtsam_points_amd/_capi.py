@@ -181,6 +181,7 @@ _SIGNATURES = {
     "gp_debug_set_map_build": (C.c_int, [C.c_int]),
     "gp_trim_device_cache": (C.c_int, []),
     "gp_debug_set_xcd_chunk": (C.c_int, [C.c_int]),
+    "gp_debug_set_tile_interleave": (C.c_int, [C.c_int]),
     "gp_debug_set_knn_structure": (C.c_int, [C.c_int]),
     "gp_debug_knn_counters": (C.c_int, [C.c_int, C.c_void_p]),
     "gp_debug_set_trace_buffer": (C.c_int, [C.c_void_p]),

@@ -39,6 +39,8 @@ struct TileDesc {
   int factor;
   int begin;  // first point
   int count;  // <= kTilePoints
+  int row;    // row of the partials array this tile writes (rows of a factor are contiguous, the finalize kernels rely on it; the
+              // EXECUTION order of the tile list may differ: tiles of factors that share a source cloud are interleaved)
 };
 
 __device__ __forceinline__ int xcd_swizzle(int b, int num_tiles) {

@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
     tile.factor = 0;
     tile.begin = tile_idx * inl.tile_points;
     tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+    tile.row = tile_idx;
   } else {
     tile = tiles[tile_idx];
   }
@@ -647,7 +648,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
       const double* w3 = reinterpret_cast<const double*>(smem + 4 * STAGES * kChunkBytes - 32 * 8);
       sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
     }
-    ((GP_GLOBAL double*)partials)[(size_t)tile_idx * ACC_STRIDE + threadIdx.x] = sum;
+    ((GP_GLOBAL double*)partials)[(size_t)tile.row * ACC_STRIDE + threadIdx.x] = sum;
   }
   GP_TRACE(7);
   if constexpr (TRACE) {

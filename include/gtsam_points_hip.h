@@ -399,6 +399,8 @@ int gp_debug_set_variant(int variant);
 /* workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles are
  * dealt to the XCDs round robin */
 int gp_debug_set_xcd_chunk(int tiles);
+/* execution order of a batch's tiles: 1 = consecutive factors that share a source cloud take turns tile by tile, 0 (default) = factor-major */
+int gp_debug_set_tile_interleave(int on);
 /* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
  * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
 int gp_debug_set_map_build(int hashed);

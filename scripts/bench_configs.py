@@ -23,6 +23,8 @@ from gtsam_points_amd import _capi, synthetic  # noqa: E402
 lib = gpa.load()
 if os.environ.get("GP_VARIANT"):  # tuning: pick a tile-kernel variant (gp_debug_set_variant)
     _capi.check(lib.gp_debug_set_variant(int(os.environ["GP_VARIANT"])), "variant")
+if os.environ.get("GP_TILE_INTERLEAVE"):  # tuning: execution order of the tiles of factors that share a source cloud
+    _capi.check(lib.gp_debug_set_tile_interleave(int(os.environ["GP_TILE_INTERLEAVE"])), "interleave")
 if os.environ.get("GP_XCD_CHUNK"):  # tuning: workgroup -> tile map (gp_debug_set_xcd_chunk)
     _capi.check(lib.gp_debug_set_xcd_chunk(int(os.environ["GP_XCD_CHUNK"])), "xcd chunk")
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else {"C1", "C3", "C4", "C5"}
