@@ -23,6 +23,7 @@
 
 #include "gp_host.hpp"
 #include "gp_vgicp_tile.hpp"
+#include "gp_vgicp_tile2.hpp"
 
 namespace gp {
 
@@ -547,6 +548,7 @@ struct gp_vgicp_batch {
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
   bool use_grid = false;  // every factor's map carries an occupancy-block grid (else the hashed line table is used)
+  bool gen2_ok = false;   // ... every map's records fit 32-bit byte offsets and no factor validates surfaces (vgicp_pipeline2_kernel)
   int ppt = 4;            // 64-point chunks per wave of the pipeline kernel (tile = 256 x ppt points)
   std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
@@ -588,6 +590,7 @@ struct VariantDesc {
   bool f32, grid, lean;
   int ppt;  // 64-point chunks per wave (0 = chosen per batch)
   bool ahead = false;  // hop 1 of the next chunk travels with hop 2 of this one (linearise only)
+  int gen2 = 0;        // 1 / 2: vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp) with schedule 0 / 1 for the linearise, else as variant 8
 };
 VariantDesc variant_desc(int v) {
   switch (v) {
@@ -598,6 +601,8 @@ VariantDesc variant_desc(int v) {
     case 6: return {true, true, true, 2};
     case 7: return {true, true, true, 1};
     case 8: return {true, true, true, 0, true};
+    case 9: return {true, true, true, 0, true, 1};
+    case 10: return {true, true, true, 0, true, 2};
     default: return {true, true, true, 0};
   }
 }
@@ -646,6 +651,7 @@ int build_table(gp_vgicp_batch* b) {
     b->tile_points = 64 * 4 * ppt;
   }
   b->use_grid = true;
+  b->gen2_ok = true;
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -657,6 +663,7 @@ int build_table(gp_vgicp_batch* b) {
     d.n = f->n;
     d.surface_validation = (f->surface_validation && f->normals) ? 1 : 0;
     if (!d.map.gblocks) b->use_grid = false;
+    if (!d.map.gblocks || (int64_t)d.map.num_voxels * 64 >= (int64_t)1 << 32 || d.surface_validation) b->gen2_ok = false;
     d.tile_begin = (int)tiles.size();
     for (int p = 0; p < f->n; p += b->tile_points) tiles.push_back(gp::TileDesc{i, p, std::min(b->tile_points, f->n - p), (int)tiles.size()});
     d.tile_count = (int)tiles.size() - d.tile_begin;
@@ -767,6 +774,27 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       GP_LAUNCH_PIPE(false, 4, true, false, false);
     } else if (!vd.lean) {
       GP_LAUNCH_PIPE(true, 4, true, false, false);
+    } else if (vd.gen2 && MODE == gp::MODE_LIN && b->ppt >= 2 && b->gen2_ok) {
+      if constexpr (MODE == gp::MODE_LIN) {
+#define GP_LAUNCH_PIPE2(PPT, SCHED, INL, TRACE)                                                                                                         \
+  hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<PPT, SCHED, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
+#define GP_LAUNCH_PIPE2_S(PPT, INL, TRACE)             \
+  do {                                                 \
+    if (vd.gen2 == 1) GP_LAUNCH_PIPE2(PPT, 0, INL, TRACE); \
+    else GP_LAUNCH_PIPE2(PPT, 1, INL, TRACE);              \
+  } while (0)
+        if (b->ppt == 4 && g_trace_on && inl.use) {
+          GP_LAUNCH_PIPE2_S(4, true, true);
+        } else if (b->ppt == 4) {
+          if (inl.use) GP_LAUNCH_PIPE2_S(4, true, false);
+          else GP_LAUNCH_PIPE2_S(4, false, false);
+        } else {
+          if (inl.use) GP_LAUNCH_PIPE2_S(2, true, false);
+          else GP_LAUNCH_PIPE2_S(2, false, false);
+        }
+#undef GP_LAUNCH_PIPE2_S
+#undef GP_LAUNCH_PIPE2
+      }
     } else if (vd.ahead && MODE == gp::MODE_LIN && b->ppt >= 2 && !(g_trace_on && b->ppt == 4)) {
       if constexpr (MODE == gp::MODE_LIN) {
         if (b->ppt == 4)
@@ -896,7 +924,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 8) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..8");
+  if (variant < 0 || variant > 10) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..10");
   g_variant = variant;
   return GP_OK;
 }

@@ -1,0 +1,432 @@
+// gp_vgicp_tile2.hpp -- second generation of the rigid-pose linearise kernel (block-grid maps, f32 outer products).
+//
+// Same pipeline idea as vgicp_pipeline_kernel (gp_vgicp_tile.hpp): LDS-DMA source ring, two-hop lookup with hand-placed waits,
+// 29 sums, f32 transposition + f64 reduction.  What changed, and why (ISA of the round-2 default kernel, DESIGN.md section 8:
+// a 64-point wave step is ~1000 VALU cycles, 62 % of them f64-rate instructions, ~13 % integer / address arithmetic):
+//   * every address of the step is "wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane offset": the source ring is requested
+//     with FOUR 12-B-per-lane DMA instructions per chunk (one for the 64 points, three for the 64 covariances -- each instruction
+//     reads one array, so no per-lane base select), the block entry and the record with the saddr form of global_load.  The
+//     round-2 kernel spent 7 v_mad_u64_u32 + 7 v_lshl_add_u64 + 3 v_lshlrev_b64 per step on 64-bit per-lane addresses; the
+//     per-chunk advance of the bases is now scalar arithmetic;
+//   * 12-B DMA rows need no 16-B alignment of the caller's arrays: every full wave takes the ring;
+//   * f64 diet: transform as three 3-deep fma chains (9 instead of 12 instructions), centre - l = fma(-leaf, fract(u), leaf/2)
+//     (6 instead of 9), one Newton step behind v_rcp_f64 (2^-46 relative: eight orders inside what the f32 outer products keep);
+//   * block index with 24-bit multiply-adds (the grid has < 2^24 blocks);
+//   * schedule (SCHED): 0 = the round-2 look-ahead order (both first chunks requested up front, front half of chunk j+1 before hop 1
+//     of chunk j is consumed); 1 = lean start (the first burst is ONE chunk per wave; chunk 1 follows the first hop 1) with the
+//     front half of chunk j+1 behind the record wait of chunk j, so that its hop 1 travels under the algebra of chunk j.
+// Arithmetic differs from variants 4 / 8 at the 1e-16 level (fma contraction, fract), not bit for bit; parity tests are the same.
+#pragma once
+
+#include "gp_vgicp_tile.hpp"
+
+namespace gp {
+
+constexpr int kChunkDmaOps2 = 4;  // 4 x 64 lanes x 12 B
+
+// a wave-uniform pointer the compiler may have left in vector registers (a descriptor field selected between the kernel arguments
+// and a table in memory): pin it to an SGPR pair so that the saddr addressing forms can take it
+template <typename T>
+__device__ __forceinline__ const GP_GLOBAL T* uniform_ptr(const GP_GLOBAL T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const GP_GLOBAL T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uniform_f64(double x) {
+  const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// one 64-point chunk into an LDS stage: points [64][3] at +0, covariances [64][9] at +768.  `upts` / `ucov` are wave-uniform
+// (the chunk's first row, in SGPR pairs), `voff` = lane * 12.  Issued from inline asm: (i) the saddr form is guaranteed (the builtin
+// fell back to 64-bit per-lane addresses for every chunk but the first), (ii) hipcc does not track these requests, so it cannot put
+// a vmcnt(0) of its own in front of the first LDS read (it did, behind the builtin).  The instruction offset applies to the global
+// AND the LDS address; M0 (LDS base of the request) is saved and restored, the compiler may hold something in it.
+__device__ __forceinline__ void chunk_dma12(const GP_GLOBAL char* upts, const GP_GLOBAL char* ucov, unsigned voff, char* stage) {
+  const unsigned lds_pts = (unsigned)(size_t)(GP_LDS char*)stage, lds_cov = lds_pts + 768u;
+  unsigned saved;
+  asm volatile(
+    "s_mov_b32 %0, m0\n\t"
+    "s_mov_b32 m0, %4\n\t"
+    "global_load_lds_dwordx3 %1, %2\n\t"
+    "s_mov_b32 m0, %5\n\t"
+    "global_load_lds_dwordx3 %1, %3\n\t"
+    "global_load_lds_dwordx3 %1, %3 offset:768\n\t"
+    "global_load_lds_dwordx3 %1, %3 offset:1536\n\t"
+    "s_mov_b32 m0, %0"
+    : "=&s"(saved)
+    : "v"(voff), "s"(upts), "s"(ucov), "s"(lds_pts), "s"(lds_cov)
+    : "memory");
+}
+
+// 24-bit multiply-add (the block grid has < 2^24 blocks): hipcc turned __umul24(a, b) + c into a v_mad_u64_u32
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// saddr-form lookups: wave-uniform base in an SGPR pair, 32-bit byte offset per lane
+__device__ __forceinline__ void grid_issue_s(const GP_GLOBAL char* base, unsigned off, v4i& blk) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(blk) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void record_issue_s(const GP_GLOBAL char* base, unsigned off, v4f& head, v2d& c01, v2d& c23, v2d& c45) {
+  asm volatile(
+    "global_load_dwordx4 %0, %4, %5\n\t"
+    "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+    "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+    "global_load_dwordx4 %3, %4, %5 offset:48"
+    : "=&v"(head), "=&v"(c01), "=&v"(c23), "=&v"(c45)
+    : "v"(off), "s"(base)
+    : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  static_assert(N >= 0 && N <= 8, "counts used by the schedules below");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  static_assert(N == 0 || N == 1 || N == 3 || N == 4 || N == 7, "add the count");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_blk(v4i& blk) {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk) : : "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(blk) : : "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(blk) : : "memory");
+  static_assert(N == 0 || N == 1 || N == 4, "add the count");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& c45) {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
+  static_assert(N == 0 || N == 4, "add the count");
+}
+
+// M = (C_B + R C_A R^T)^-1 in f64 and the 29 sums in f32: accumulate_core of gp_vgicp_tile.hpp with one Newton step behind the
+// hardware reciprocal (v_rcp_f64 is good to ~2^-23, one step gives 2^-46)
+__device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a, const v2d& c01, const v2d& c23, const v2d& c45, float RX, float RY, float RZ, float QX,
+                                                 float QY, float QZ, float* acc) {
+  float M0, M1, M2, M3, M4, M5;
+  {
+    const double a00 = a[0], a01 = a[1], a02 = a[2], a11 = a[3], a12 = a[4], a22 = a[5];
+    const double rc00 = Tl.r00 * a00 + Tl.r01 * a01 + Tl.r02 * a02, rc01 = Tl.r00 * a01 + Tl.r01 * a11 + Tl.r02 * a12, rc02 = Tl.r00 * a02 + Tl.r01 * a12 + Tl.r02 * a22;
+    const double rc10 = Tl.r10 * a00 + Tl.r11 * a01 + Tl.r12 * a02, rc11 = Tl.r10 * a01 + Tl.r11 * a11 + Tl.r12 * a12, rc12 = Tl.r10 * a02 + Tl.r11 * a12 + Tl.r12 * a22;
+    const double rc20 = Tl.r20 * a00 + Tl.r21 * a01 + Tl.r22 * a02, rc21 = Tl.r20 * a01 + Tl.r21 * a11 + Tl.r22 * a12, rc22 = Tl.r20 * a02 + Tl.r21 * a12 + Tl.r22 * a22;
+    const double s00 = c01.x + rc00 * Tl.r00 + rc01 * Tl.r01 + rc02 * Tl.r02;
+    const double s01 = c01.y + rc00 * Tl.r10 + rc01 * Tl.r11 + rc02 * Tl.r12;
+    const double s02 = c23.x + rc00 * Tl.r20 + rc01 * Tl.r21 + rc02 * Tl.r22;
+    const double s11 = c23.y + rc10 * Tl.r10 + rc11 * Tl.r11 + rc12 * Tl.r12;
+    const double s12 = c45.x + rc10 * Tl.r20 + rc11 * Tl.r21 + rc12 * Tl.r22;
+    const double s22 = c45.y + rc20 * Tl.r20 + rc21 * Tl.r21 + rc22 * Tl.r22;
+    const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
+    const double det = s00 * i00 + s01 * i01 + s02 * i02;
+    double x = __builtin_amdgcn_rcp(det);
+    x = x * (2.0 - det * x);
+    M0 = (float)(i00 * x);
+    M1 = (float)(i01 * x);
+    M2 = (float)(i02 * x);
+    M3 = (float)((s00 * s22 - s02 * s02) * x);
+    M4 = (float)((s01 * s02 - s00 * s12) * x);
+    M5 = (float)((s00 * s11 - s01 * s01) * x);
+  }
+  const float mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+  acc[ACC_COUNT] += 1.0f;
+  acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+  acc[ACC_M + 0] += M0;
+  acc[ACC_M + 1] += M1;
+  acc[ACC_M + 2] += M2;
+  acc[ACC_M + 3] += M3;
+  acc[ACC_M + 4] += M4;
+  acc[ACC_M + 5] += M5;
+  const float k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
+  const float k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
+  const float k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+  acc[ACC_K + 0] += k00;
+  acc[ACC_K + 1] += k01;
+  acc[ACC_K + 2] += k02;
+  acc[ACC_K + 3] += k10;
+  acc[ACC_K + 4] += k11;
+  acc[ACC_K + 5] += k12;
+  acc[ACC_K + 6] += k20;
+  acc[ACC_K + 7] += k21;
+  acc[ACC_K + 8] += k22;
+  acc[ACC_TL + 0] += QZ * k10 - QY * k20;
+  acc[ACC_TL + 1] += QZ * k11 - QY * k21;
+  acc[ACC_TL + 2] += QZ * k12 - QY * k22;
+  acc[ACC_TL + 3] += QX * k21 - QZ * k01;
+  acc[ACC_TL + 4] += QX * k22 - QZ * k02;
+  acc[ACC_TL + 5] += QY * k02 - QX * k12;
+  acc[ACC_QXMR + 0] += QY * mrz - QZ * mry;
+  acc[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
+  acc[ACC_QXMR + 2] += QX * mry - QY * mrx;
+  acc[ACC_MR + 0] += mrx;
+  acc[ACC_MR + 1] += mry;
+  acc[ACC_MR + 2] += mrz;
+}
+
+// INL: a single-factor launch; the factor descriptor, the pose and the tile geometry come out of the kernel arguments through scalar
+// loads.  (With a run-time `inl.use ? inl.factor : factors[...]` hipcc selects between the two ADDRESSES and reads the descriptor
+// with flat loads: a vector-memory round trip in front of the first source request, also for the in-argument copy.)
+template <int PPT, int SCHED, bool INL, bool TRACE = false>
+__global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                                  const double* __restrict__ poses_lin, const double* __restrict__ /*poses_eval*/, const InlinePoses inl,
+                                                                  double* __restrict__ partials) {
+  static_assert(PPT == 2 || PPT == 4, "512- and 1024-point tiles");
+  static_assert(SCHED == 0 || SCHED == 1, "see the header");
+  constexpr int STAGES = 3;
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGES * kChunkBytes];  // 36 KB
+  int tile_idx;
+  if (inl.xcd_chunk > 0) {
+    const int c = inl.xcd_chunk, x = blockIdx.x % kNumXCD, q = blockIdx.x / kNumXCD;
+    tile_idx = ((q / c) * kNumXCD + x) * c + (q % c);
+  } else {
+    const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+    tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
+  }
+  if (tile_idx >= num_tiles) return;
+  unsigned long long* trace = TRACE ? g_trace : nullptr;
+  GP_TRACE(0);
+  if constexpr (TRACE) {
+    if (trace && threadIdx.x == 0) {
+      trace[(size_t)tile_idx * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+      trace[(size_t)tile_idx * 16 + 8] = __builtin_amdgcn_s_getreg(GP_GETREG_HW_ID);
+      trace[(size_t)tile_idx * 16 + 9] = __builtin_amdgcn_s_getreg(GP_GETREG_XCC_ID);
+    }
+  }
+  TileDesc tile;
+  FactorDesc f;
+  if constexpr (INL) {
+    tile.factor = 0;
+    tile.begin = tile_idx * inl.tile_points;
+    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+    tile.row = tile_idx;
+    f = inl.factor;
+  } else {
+    tile = tiles[tile_idx];
+    f = factors[tile.factor];
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t first = (size_t)tile.begin + (size_t)wave * (PPT * kChunkPoints);  // the wave's first point (wave-uniform)
+  int wcount = __builtin_amdgcn_readfirstlane(tile.count) - wave * (PPT * kChunkPoints);
+  wcount = wcount < 0 ? 0 : (wcount > PPT * kChunkPoints ? PPT * kChunkPoints : wcount);
+  const bool ring = wcount == PPT * kChunkPoints;
+  char* wbase = smem + wave * (STAGES * kChunkBytes);
+  const GP_GLOBAL char* upts = uniform_ptr((const GP_GLOBAL char*)as_global(f.points) + 12 * first);
+  const GP_GLOBAL char* ucov = uniform_ptr((const GP_GLOBAL char*)as_global(f.covs) + 36 * first);
+  const unsigned voff = (unsigned)lane * 12u;
+  auto dma = [&](int j) { chunk_dma12(upts + (size_t)j * (kChunkPoints * 12), ucov + (size_t)j * (kChunkPoints * 36), voff, wbase + (j % STAGES) * kChunkBytes); };
+
+  if (ring) {
+    dma(0);
+    if (SCHED == 0) dma(1);
+  }
+
+  const Pose Tl = INL ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const double leaf = uniform_f64(f.map.leaf), inv_leaf = uniform_f64(f.map.inv_leaf), half_leaf = uniform_f64(0.5 * f.map.leaf);
+  const int glo0 = f.map.glo[0], glo1 = f.map.glo[1], glo2 = f.map.glo[2];
+  const unsigned gd0 = (unsigned)f.map.gdim[0], gd1 = (unsigned)f.map.gdim[1], gd2 = (unsigned)f.map.gdim[2];
+  const GP_GLOBAL char* gblocks = uniform_ptr((const GP_GLOBAL char*)f.map.gblocks);
+  const GP_GLOBAL char* records = uniform_ptr((const GP_GLOBAL char*)f.map.records);
+
+  // the translation lives in vector registers: a VOP3 instruction reads ONE scalar operand, so fma(r02, dz, tx) with both in SGPRs
+  // costs a v_mov_b64 per row per chunk; the kernel has the six registers to spare (108 of 128 without them)
+  double tvx, tvy, tvz;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(tvx) : "s"(Tl.tx));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(tvy) : "s"(Tl.ty));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(tvz) : "s"(Tl.tz));
+
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc[k] = 0.f;
+
+  struct Ahead {  // what a chunk carries from its front half (transform, hop 1 issued) to its back half (hop 2, algebra)
+    v4i blk;
+    float ex, ey, ez, qx, qy, qz;
+    int pos;  // bit of the voxel inside its block; < 0: outside the grid's box or an inactive lane
+  };
+  // front half: transform, voxel coordinate, hop 1 issued
+  auto front = [&](float pxf, float pyf, float pzf, bool active, Ahead& P) {
+    const double dx = (double)pxf, dy = (double)pyf, dz = (double)pzf;
+    const double lx = __builtin_fma(Tl.r00, dx, __builtin_fma(Tl.r01, dy, __builtin_fma(Tl.r02, dz, tvx)));
+    const double ly = __builtin_fma(Tl.r10, dx, __builtin_fma(Tl.r11, dy, __builtin_fma(Tl.r12, dz, tvy)));
+    const double lz = __builtin_fma(Tl.r20, dx, __builtin_fma(Tl.r21, dy, __builtin_fma(Tl.r22, dz, tvz)));
+    // voxel coordinate = floor(l * (1 / leaf)): the CPU map's rule (util/fast_floor.hpp:12-15, gaussian_voxelmap_cpu.cpp:59-61);
+    // centre - l = leaf (floor(u) + 0.5 - u) = leaf/2 - leaf fract(u): the large coordinates never meet
+    const double ux = lx * inv_leaf, uy = ly * inv_leaf, uz = lz * inv_leaf;
+    const int cx = (int)__builtin_floor(ux), cy = (int)__builtin_floor(uy), cz = (int)__builtin_floor(uz);
+    P.ex = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf);
+    P.ey = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf);
+    P.ez = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf);
+    P.qx = (float)lx;
+    P.qy = (float)ly;
+    P.qz = (float)lz;
+    const bool live = active;  // (factors with surface validation stay on the round-2 kernel: its normals read is a compiler-tracked load)
+    const unsigned bx = (unsigned)((cx >> 2) - glo0), by = (unsigned)((cy >> 2) - glo1), bz = (unsigned)((cz >> 2) - glo2);
+    const bool inbox = (bx < gd0) & (by < gd1) & (bz < gd2);
+    const unsigned lin = inbox ? mad24(mad24(bz, gd1, by), gd0, bx) : 0u;  // < 2^24 blocks
+    P.pos = (inbox && live) ? (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3)) : -1;
+    grid_issue_s(gblocks, lin * 16u, P.blk);
+  };
+  auto front_ring = [&](int j, Ahead& P) {
+    const float* lp = reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes);
+    front(lp[3 * lane], lp[3 * lane + 1], lp[3 * lane + 2], true, P);
+  };
+  // back half, part 1: P.blk has landed -> record requested
+  auto back_issue = [&](const Ahead& P, v4f& head, v2d& c01, v2d& c23, v2d& c45) -> bool {
+    const unsigned long long bits = ((unsigned long long)(unsigned)P.blk.y << 32) | (unsigned long long)(unsigned)P.blk.x;
+    const int pos = P.pos < 0 ? 0 : P.pos;
+    const bool hit = P.pos >= 0 && ((bits >> pos) & 1ull);
+    const int idx = P.blk.z + __popcll(bits & ((1ull << pos) - 1ull));
+    record_issue_s(records, hit ? (unsigned)idx << 6 : 0u, head, c01, c23, c45);
+    return hit;
+  };
+  auto algebra_ring = [&](int j, const Ahead& P, bool hit, const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45) {
+    double a[6];
+    load_cov6(reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes) + kChunkPoints * 3 + 9 * lane, a);
+    if (hit) accumulate_core2(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
+  };
+
+  if (ring) {
+    Ahead P[2];
+    v4f head;
+    v2d c01, c23, c45;
+    if constexpr (SCHED == 0) {
+      // in flight: chunk 0, chunk 1 (4 requests each; the first of a chunk carries its points)
+      vm_wait<7>();  // the points of chunk 0 are in LDS
+      GP_TRACE(1);
+      front_ring(0, P[0]);  // in flight: C0 x3, chunk 1 x4, hop 1 of chunk 0
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        if (j + 1 < PPT) {
+          // the points of chunk j+1: j == 0: [C0 x3, P1, C1 x3, H0]; j >= 1: [P(j+1), C(j+1) x3] (hop 1 of chunk j is older than the
+          // record of chunk j-1, which step j-1 waited for)
+          if (j == 0) vm_wait<4>();
+          else vm_wait<3>();
+          front_ring(j + 1, P[(j + 1) & 1]);
+          if (j == 0) vm_wait_blk<1>(P[0].blk);  // [C1 x3, H0, H1]: hop 1 of chunk 0
+          else vm_wait_blk<4>(P[j & 1].blk);     // already here: nothing to wait for
+        } else {
+          vm_wait_blk<0>(P[j & 1].blk);
+        }
+        if (j == 0) GP_TRACE(2);
+        if (j == 1) GP_TRACE(4);
+        const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
+        if (j + 2 < PPT) {
+          dma(j + 2);
+          vm_wait_rec<4>(head, c01, c23, c45);  // the record -- and hop 1 of chunk j+1, which is older -- are here; chunk j+2 keeps travelling
+        } else {
+          vm_wait_rec<0>(head, c01, c23, c45);
+        }
+        algebra_ring(j, P[j & 1], hit, head, c01, c23, c45);
+        if (j == 0) GP_TRACE(3);
+        if (j == 1) GP_TRACE(5);
+      }
+    } else {
+      // in flight: chunk 0
+      vm_wait<3>();  // its points are in LDS
+      GP_TRACE(1);
+      front_ring(0, P[0]);  // in flight: C0 x3, H0
+      dma(1);               // ... and chunk 1 x4
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        // hop 1 of chunk j; the only younger requests are those of chunk j+1 (if there is one)
+        if (j + 1 < PPT) vm_wait_blk<4>(P[j & 1].blk);
+        else vm_wait_blk<0>(P[j & 1].blk);
+        if (j == 0) GP_TRACE(2);
+        if (j == 1) GP_TRACE(4);
+        const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
+        vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
+        if (j + 1 < PPT) {
+          front_ring(j + 1, P[(j + 1) & 1]);  // its hop 1 travels under the algebra of chunk j
+          if (j + 2 < PPT) dma(j + 2);        // stage of chunk j-1
+        }
+        algebra_ring(j, P[j & 1], hit, head, c01, c23, c45);
+        if (j == 0) GP_TRACE(3);
+        if (j == 1) GP_TRACE(5);
+      }
+    }
+    vm_wait<0>();
+  } else {
+    // a partial wave (last tile of a factor): per-lane loads, same arithmetic in the same order.  The loads are issued from inline asm
+    // like everything else here: a load hipcc tracks itself makes it guard registers of the ring path with vmcnt(0) waits of its own
+    // (its dataflow sees a path from this loop into the ring code), which would drain the source requests in flight there.
+    const GP_GLOBAL float* points = as_global(f.points);
+    const GP_GLOBAL float* covs = as_global(f.covs);
+    for (int j = 0; j < PPT; j++) {
+      const int nj = wcount - j * kChunkPoints;  // wave-uniform
+      if (nj <= 0) break;
+      const bool active = lane < nj;
+      const size_t i = first + (size_t)j * kChunkPoints + (active ? lane : 0);
+      v3f pt;
+      v4f ca, cb;
+      float cc;
+      asm volatile(
+        "global_load_dwordx3 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %5, off\n\t"
+        "global_load_dwordx4 %2, %5, off offset:16\n\t"
+        "global_load_dword %3, %5, off offset:32\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(pt), "=&v"(ca), "=&v"(cb), "=&v"(cc)
+        : "v"(points + 3 * i), "v"(covs + 9 * i)
+        : "memory");
+      const float c9[9] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w, cc};
+      Ahead P;
+      v4f head;
+      v2d c01, c23, c45;
+      front(pt.x, pt.y, pt.z, active, P);
+      vm_wait_blk<0>(P.blk);
+      const bool hit = back_issue(P, head, c01, c23, c45);
+      vm_wait_rec<0>(head, c01, c23, c45);
+      double a[6];
+      load_cov6(c9, a);
+      if (hit) accumulate_core2(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
+    }
+  }
+
+  GP_TRACE(6);
+  // ---- reduction: the wave's drained ring becomes a 32 x 64 f32 transposition buffer (row stride 66 floats: conflict-free both
+  // ways), every lane sums 32 values of one component in f64, lane pairs meet with one swap; the 4-wave sum goes through the
+  // last 256 B of each wave's region; one 32-double partial per tile (fixed order: bit-reproducible) ----
+  constexpr int kRowStrideF = 66;
+  static_assert(32 * kRowStrideF * 4 + 32 * 8 <= STAGES * kChunkBytes, "f32 transposition buffer + wave sums must fit the wave's ring");
+  float* wtf = reinterpret_cast<float*>(wbase);
+  double* wsums = reinterpret_cast<double*>(wbase + STAGES * kChunkBytes - 32 * 8);
+#pragma unroll
+  for (int k = 0; k < 32; k++) wtf[k * kRowStrideF + lane] = acc[k];
+  {
+    const int comp = lane >> 1, part = lane & 1;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      s0 += (double)wtf[comp * kRowStrideF + 2 * i + part];
+      s1 += (double)wtf[comp * kRowStrideF + 2 * (i + 1) + part];
+      s2 += (double)wtf[comp * kRowStrideF + 2 * (i + 2) + part];
+      s3 += (double)wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+    }
+    double v = (s0 + s1) + (s2 + s3);
+    v += __shfl_xor(v, 1, 64);
+    if (part == 0) wsums[comp] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double sum = 0.0;
+    if (threadIdx.x < ACC_SIZE) {
+      const double* w0 = reinterpret_cast<const double*>(smem + 1 * STAGES * kChunkBytes - 32 * 8);
+      const double* w1 = reinterpret_cast<const double*>(smem + 2 * STAGES * kChunkBytes - 32 * 8);
+      const double* w2 = reinterpret_cast<const double*>(smem + 3 * STAGES * kChunkBytes - 32 * 8);
+      const double* w3 = reinterpret_cast<const double*>(smem + 4 * STAGES * kChunkBytes - 32 * 8);
+      sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
+    }
+    ((GP_GLOBAL double*)partials)[(size_t)tile.row * ACC_STRIDE + threadIdx.x] = sum;
+  }
+  GP_TRACE(7);
+  if constexpr (TRACE) {
+    if (trace && threadIdx.x == 0) trace[(size_t)tile_idx * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+}  // namespace gp

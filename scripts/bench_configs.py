@@ -27,11 +27,19 @@ if os.environ.get("GP_TILE_INTERLEAVE"):  # tuning: execution order of the tiles
     _capi.check(lib.gp_debug_set_tile_interleave(int(os.environ["GP_TILE_INTERLEAVE"])), "interleave")
 if os.environ.get("GP_XCD_CHUNK"):  # tuning: workgroup -> tile map (gp_debug_set_xcd_chunk)
     _capi.check(lib.gp_debug_set_xcd_chunk(int(os.environ["GP_XCD_CHUNK"])), "xcd chunk")
+VARIANTS = [int(v) for v in os.environ["GP_VARIANTS"].split(",")] if os.environ.get("GP_VARIANTS") else [None]  # A/B of tile-kernel variants in one process
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else {"C1", "C3", "C4", "C5"}
 BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
 
 
 def run(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iters=20):
+    for v in VARIANTS:
+        if v is not None:
+            _capi.check(lib.gp_debug_set_variant(v), "variant")
+        run_variant(name if v is None else f"{name} [variant {v}]", clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iters)
+
+
+def run_variant(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_sample, iters=20):
     factors = [gpa.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
     F = len(factors)
     arr = (C.c_void_p * F)(*[f._h.value for f in factors])

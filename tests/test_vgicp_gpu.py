@@ -80,7 +80,7 @@ DEFAULT_VARIANT = 8
 MIXED_TOL = 1e-6  # variants with f32 outer products (2, 4): measured <= 1e-7, gate 1e-5
 
 
-@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (1, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (4, MIXED_TOL), (5, MIXED_TOL), (6, MIXED_TOL), (7, MIXED_TOL), (8, MIXED_TOL)])
+@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (1, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (4, MIXED_TOL), (5, MIXED_TOL), (6, MIXED_TOL), (7, MIXED_TOL), (8, MIXED_TOL), (9, MIXED_TOL), (10, MIXED_TOL)])
 def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
     """gp_debug_set_variant: 0 reference-shaped kernel, 1 / 2 pipeline kernel over the hashed line table (f64 / f32 outer products),
     3 / 4 pipeline kernel over the occupancy-block grid (f64 / f32 outer products; 4 is the default) -- linearise and error
@@ -421,6 +421,36 @@ def test_linearity_and_determinism_at_1m(gpu):
     assert vm.voxelmap_info.num_voxels == vo.num_voxels
     assert_linearized_close(L, fo.linearize(delta), PARITY_TOL, "1M")
     assert L.num_inliers > 0.5 * len(d["source_points"])
+
+
+@pytest.mark.parametrize("variant", [9, 10])
+@pytest.mark.parametrize("n_src", [400_000, 1_000_077])
+def test_second_generation_kernel_at_size(gpu, variant, n_src):
+    """vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp; variants 9 / 10 = schedule 0 / 1) only takes over when the batch has >= 768 tiles of
+    512 or 1024 points, which no fixture reaches: 400 k points -> 782 tiles of 512 (two chunks per wave), 1,000,077 points -> 977 tiles
+    of 1024 with a partial last tile (a full wave, a partial wave through the per-lane path, an empty wave).  Against the oracle, plus
+    bit-reproducibility and agreement with the round-2 kernel far below the parity tolerance."""
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_c2_workload(n_src, 500_000, seed=7)
+    lib = gpu.load()
+    delta = d["T_true"] @ expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    _, src, vm = _build(gpu, d, 0.5)
+    try:
+        gpu._capi.check(lib.gp_debug_set_variant(8), "variant")
+        L8 = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, src), delta)
+        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
+        f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+        L = _sync_linearize(gpu, f, delta)
+        L2 = _sync_linearize(gpu, f, delta)
+    finally:
+        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    for k in BLOCKS:
+        assert np.array_equal(getattr(L, k), getattr(L2, k))
+        assert rel_err(getattr(L, k), getattr(L8, k)) < 1e-9, k  # same algorithm, arithmetic differs at the 1e-16 level per point
+    assert L.num_inliers == L8.num_inliers
+    _, fo = _oracle(d, 0.5, oracle.max_threads())
+    assert_linearized_close(L, fo.linearize(delta), MIXED_TOL, f"variant {variant}, {n_src} points")
 
 
 def test_alignment_gate_gpu(gpu, kitti07):
