@@ -590,7 +590,7 @@ struct VariantDesc {
   bool f32, grid, lean;
   int ppt;  // 64-point chunks per wave (0 = chosen per batch)
   bool ahead = false;  // hop 1 of the next chunk travels with hop 2 of this one (linearise only)
-  int gen2 = 0;        // 1 / 2: vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp) with schedule 0 / 1 for the linearise, else as variant 8
+  int gen2 = 0;        // 1 .. 4: vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp) with schedule 0 .. 3 for the linearise, else as variant 8
 };
 VariantDesc variant_desc(int v) {
   switch (v) {
@@ -603,6 +603,9 @@ VariantDesc variant_desc(int v) {
     case 8: return {true, true, true, 0, true};
     case 9: return {true, true, true, 0, true, 1};
     case 10: return {true, true, true, 0, true, 2};
+    case 11: return {true, true, true, 0, true, 3};
+    case 12: return {true, true, true, 0, true, 4};
+    case 13: return {true, true, true, 0, true, 5};
     default: return {true, true, true, 0};
   }
 }
@@ -780,8 +783,11 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<PPT, SCHED, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
 #define GP_LAUNCH_PIPE2_S(PPT, INL, TRACE)             \
   do {                                                 \
-    if (vd.gen2 == 1) GP_LAUNCH_PIPE2(PPT, 0, INL, TRACE); \
-    else GP_LAUNCH_PIPE2(PPT, 1, INL, TRACE);              \
+    if (vd.gen2 == 1) GP_LAUNCH_PIPE2(PPT, 0, INL, TRACE);      \
+    else if (vd.gen2 == 2) GP_LAUNCH_PIPE2(PPT, 1, INL, TRACE); \
+    else if (vd.gen2 == 3) GP_LAUNCH_PIPE2(PPT, 2, INL, TRACE); \
+    else if (vd.gen2 == 4) GP_LAUNCH_PIPE2(PPT, 3, INL, TRACE); \
+    else GP_LAUNCH_PIPE2(PPT, 4, INL, TRACE);                   \
   } while (0)
         if (b->ppt == 4 && g_trace_on && inl.use) {
           GP_LAUNCH_PIPE2_S(4, true, true);
@@ -924,7 +930,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 10) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..10");
+  if (variant < 0 || variant > 13) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..13");
   g_variant = variant;
   return GP_OK;
 }

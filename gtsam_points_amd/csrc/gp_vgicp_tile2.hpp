@@ -8,13 +8,14 @@
 //     reads one array, so no per-lane base select), the block entry and the record with the saddr form of global_load.  The
 //     round-2 kernel spent 7 v_mad_u64_u32 + 7 v_lshl_add_u64 + 3 v_lshlrev_b64 per step on 64-bit per-lane addresses; the
 //     per-chunk advance of the bases is now scalar arithmetic;
-//   * 12-B DMA rows need no 16-B alignment of the caller's arrays: every full wave takes the ring;
+//   * 12-B DMA rows need no 16-B alignment of the caller's arrays: every full wave takes the ring; LDS per workgroup 34 KB (was 36);
 //   * f64 diet: transform as three 3-deep fma chains (9 instead of 12 instructions), centre - l = fma(-leaf, fract(u), leaf/2)
 //     (6 instead of 9), one Newton step behind v_rcp_f64 (2^-46 relative: eight orders inside what the f32 outer products keep);
 //   * block index with 24-bit multiply-adds (the grid has < 2^24 blocks);
 //   * schedule (SCHED): 0 = the round-2 look-ahead order (both first chunks requested up front, front half of chunk j+1 before hop 1
 //     of chunk j is consumed); 1 = lean start (the first burst is ONE chunk per wave; chunk 1 follows the first hop 1) with the
-//     front half of chunk j+1 behind the record wait of chunk j, so that its hop 1 travels under the algebra of chunk j.
+//     front half of chunk j+1 behind the record wait of chunk j, so that its hop 1 travels under the algebra of chunk j; 2 = 1 with a
+//     points-first prologue (see the kernel); 3 = 2 with f32 in-lane sums in the reduction; 4 = 3 with the non-temporal policy on the stream.
 // Arithmetic differs from variants 4 / 8 at the 1e-16 level (fma contraction, fract), not bit for bit; parity tests are the same.
 #pragma once
 
@@ -38,26 +39,77 @@ __device__ __forceinline__ double uniform_f64(double x) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// one 64-point chunk into an LDS stage: points [64][3] at +0, covariances [64][9] at +768.  `upts` / `ucov` are wave-uniform
-// (the chunk's first row, in SGPR pairs), `voff` = lane * 12.  Issued from inline asm: (i) the saddr form is guaranteed (the builtin
-// fell back to 64-bit per-lane addresses for every chunk but the first), (ii) hipcc does not track these requests, so it cannot put
-// a vmcnt(0) of its own in front of the first LDS read (it did, behind the builtin).  The instruction offset applies to the global
-// AND the LDS address; M0 (LDS base of the request) is saved and restored, the compiler may hold something in it.
-__device__ __forceinline__ void chunk_dma12(const GP_GLOBAL char* upts, const GP_GLOBAL char* ucov, unsigned voff, char* stage) {
-  const unsigned lds_pts = (unsigned)(size_t)(GP_LDS char*)stage, lds_cov = lds_pts + 768u;
+// LDS layout of global_load_lds_dwordx3, measured on gfx950 (scripts/probe/lds_dma_layout.hip): lane L's 12 bytes land at
+// M0 + instruction offset + 16 * L -- a SIXTEEN-byte lane stride with a 4-byte hole, not lane x 12 -- and the instruction offset
+// moves the global and the LDS address alike.  One instruction therefore fills 64 slots of 16 B (1 KB of LDS for 768 B of data):
+//   points       64 slots: slot p = point p                       -> one ds_read_b96 per lane, conflict-free
+//   covariances  3 x 64 slots: slot q = 12-B piece q of the 2304 contiguous bytes, point p = slots 3p, 3p+1, 3p+2 (its three
+//                columns) -> three ds_read_b96 at a 48-B lane stride (12 dwords: conflict-free within the 8-lane groups of a b96 read)
+// A wave's ring: 2 point slots-arrays (1 KB each) + 2 covariance arrays (3 KB each) = 8 KB; the reduction needs 8.5 KB.
+constexpr int kPtsSlotBytes = 1024, kCovSlotBytes = 3072, kWaveLdsBytes = 8704;
+static_assert(2 * kPtsSlotBytes + 2 * kCovSlotBytes <= kWaveLdsBytes, "ring must fit the wave's LDS region");
+
+// one 64-point chunk: `upts` / `ucov` are wave-uniform (the chunk's first row, in SGPR pairs), `voff` = lane * 12.  Issued from inline
+// asm: (i) the saddr form is guaranteed (the builtin fell back to 64-bit per-lane addresses for every chunk but the first), (ii)
+// hipcc does not track these requests, so it cannot put a vmcnt(0) of its own in front of the first LDS read (it did, behind the
+// builtin).  Covariance instruction k reads global bytes [768 k, 768 (k+1)) into slots [64 k, 64 (k+1)): its M0 is the array base +
+// 256 k, because the instruction offset 768 k is added to the LDS address as well.  M0 is saved and restored.
+// NT: the non-temporal policy on the source stream (it is read once per launch; the block grid and the records are what should stay in L2)
+template <bool NT>
+__device__ __forceinline__ void chunk_dma12_pts(const GP_GLOBAL char* upts, unsigned voff, char* pslot) {
+  const unsigned lds_pts = (unsigned)(size_t)(GP_LDS char*)pslot;
   unsigned saved;
-  asm volatile(
-    "s_mov_b32 %0, m0\n\t"
-    "s_mov_b32 m0, %4\n\t"
-    "global_load_lds_dwordx3 %1, %2\n\t"
-    "s_mov_b32 m0, %5\n\t"
-    "global_load_lds_dwordx3 %1, %3\n\t"
-    "global_load_lds_dwordx3 %1, %3 offset:768\n\t"
-    "global_load_lds_dwordx3 %1, %3 offset:1536\n\t"
-    "s_mov_b32 m0, %0"
-    : "=&s"(saved)
-    : "v"(voff), "s"(upts), "s"(ucov), "s"(lds_pts), "s"(lds_cov)
-    : "memory");
+  if constexpr (NT) {
+    asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "global_load_lds_dwordx3 %1, %2 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(voff), "s"(upts), "s"(lds_pts)
+      : "memory");
+  } else {
+    asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "global_load_lds_dwordx3 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(voff), "s"(upts), "s"(lds_pts)
+      : "memory");
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void chunk_dma12_cov(const GP_GLOBAL char* ucov, unsigned voff, char* cslot) {
+  const unsigned lds_c0 = (unsigned)(size_t)(GP_LDS char*)cslot, lds_c1 = lds_c0 + 256u, lds_c2 = lds_c0 + 512u;
+  unsigned saved;
+  if constexpr (NT) {
+    asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "global_load_lds_dwordx3 %1, %2 nt\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:768 nt\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:1536 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(voff), "s"(ucov), "s"(lds_c0), "s"(lds_c1), "s"(lds_c2)
+      : "memory");
+  } else {
+    asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "global_load_lds_dwordx3 %1, %2\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:768\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:1536\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(voff), "s"(ucov), "s"(lds_c0), "s"(lds_c1), "s"(lds_c2)
+      : "memory");
+  }
 }
 
 // 24-bit multiply-add (the block grid has < 2^24 blocks): hipcc turned __umul24(a, b) + c into a v_mad_u64_u32
@@ -101,8 +153,9 @@ __device__ __forceinline__ void vm_wait_blk(v4i& blk) {
 template <int N>
 __device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& c45) {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
-  static_assert(N == 0 || N == 4, "add the count");
+  static_assert(N == 0 || N == 3 || N == 4, "add the count");
 }
 
 // M = (C_B + R C_A R^T)^-1 in f64 and the 29 sums in f32: accumulate_core of gp_vgicp_tile.hpp with one Newton step behind the
@@ -175,9 +228,8 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
                                                                   const double* __restrict__ poses_lin, const double* __restrict__ /*poses_eval*/, const InlinePoses inl,
                                                                   double* __restrict__ partials) {
   static_assert(PPT == 2 || PPT == 4, "512- and 1024-point tiles");
-  static_assert(SCHED == 0 || SCHED == 1, "see the header");
-  constexpr int STAGES = 3;
-  __shared__ __attribute__((aligned(16))) char smem[4 * STAGES * kChunkBytes];  // 36 KB
+  static_assert(SCHED >= 0 && SCHED <= 4, "see the header");
+  __shared__ __attribute__((aligned(16))) char smem[4 * kWaveLdsBytes];  // 34 KB
   int tile_idx;
   if (inl.xcd_chunk > 0) {
     const int c = inl.xcd_chunk, x = blockIdx.x % kNumXCD, q = blockIdx.x / kNumXCD;
@@ -214,15 +266,27 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   int wcount = __builtin_amdgcn_readfirstlane(tile.count) - wave * (PPT * kChunkPoints);
   wcount = wcount < 0 ? 0 : (wcount > PPT * kChunkPoints ? PPT * kChunkPoints : wcount);
   const bool ring = wcount == PPT * kChunkPoints;
-  char* wbase = smem + wave * (STAGES * kChunkBytes);
+  char* wbase = smem + wave * kWaveLdsBytes;
+  auto pslot = [&](int j) { return wbase + (j & 1) * kPtsSlotBytes; };
+  auto cslot = [&](int j) { return wbase + 2 * kPtsSlotBytes + (j & 1) * kCovSlotBytes; };
   const GP_GLOBAL char* upts = uniform_ptr((const GP_GLOBAL char*)as_global(f.points) + 12 * first);
   const GP_GLOBAL char* ucov = uniform_ptr((const GP_GLOBAL char*)as_global(f.covs) + 36 * first);
   const unsigned voff = (unsigned)lane * 12u;
-  auto dma = [&](int j) { chunk_dma12(upts + (size_t)j * (kChunkPoints * 12), ucov + (size_t)j * (kChunkPoints * 36), voff, wbase + (j % STAGES) * kChunkBytes); };
+  constexpr bool NT = SCHED == 4;
+  auto dma_pts = [&](int j) { chunk_dma12_pts<NT>(upts + (size_t)j * (kChunkPoints * 12), voff, pslot(j)); };
+  auto dma_cov = [&](int j) { chunk_dma12_cov<NT>(ucov + (size_t)j * (kChunkPoints * 36), voff, cslot(j)); };
+  auto dma = [&](int j) {
+    dma_pts(j);
+    dma_cov(j);
+  };
 
   if (ring) {
-    dma(0);
-    if (SCHED == 0) dma(1);
+    if (SCHED >= 2) {
+      dma_pts(0);
+    } else {
+      dma(0);
+      if (SCHED == 0) dma(1);
+    }
   }
 
   const Pose Tl = INL ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
@@ -272,8 +336,8 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     grid_issue_s(gblocks, lin * 16u, P.blk);
   };
   auto front_ring = [&](int j, Ahead& P) {
-    const float* lp = reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes);
-    front(lp[3 * lane], lp[3 * lane + 1], lp[3 * lane + 2], true, P);
+    const v3f pt = *reinterpret_cast<const v3f*>(pslot(j) + 16 * lane);
+    front(pt.x, pt.y, pt.z, true, P);
   };
   // back half, part 1: P.blk has landed -> record requested
   auto back_issue = [&](const Ahead& P, v4f& head, v2d& c01, v2d& c23, v2d& c45) -> bool {
@@ -284,9 +348,14 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     record_issue_s(records, hit ? (unsigned)idx << 6 : 0u, head, c01, c23, c45);
     return hit;
   };
-  auto algebra_ring = [&](int j, const Ahead& P, bool hit, const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45) {
-    double a[6];
-    load_cov6(reinterpret_cast<const float*>(wbase + (j % STAGES) * kChunkBytes) + kChunkPoints * 3 + 9 * lane, a);
+  // the covariance of this lane's point out of the ring (three 12-B columns), symmetrised like load_cov6 does
+  auto cov_ring = [&](int j, double* a) {
+    const char* c = cslot(j) + 48 * lane;
+    const v3f c0 = *reinterpret_cast<const v3f*>(c), c1 = *reinterpret_cast<const v3f*>(c + 16), c2 = *reinterpret_cast<const v3f*>(c + 32);
+    const float c9[9] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z};
+    load_cov6(c9, a);
+  };
+  auto algebra = [&](const double* a, const Ahead& P, bool hit, const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45) {
     if (hit) accumulate_core2(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
   };
 
@@ -294,6 +363,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     Ahead P[2];
     v4f head;
     v2d c01, c23, c45;
+    double a[6];
     if constexpr (SCHED == 0) {
       // in flight: chunk 0, chunk 1 (4 requests each; the first of a chunk carries its points)
       vm_wait<7>();  // the points of chunk 0 are in LDS
@@ -315,13 +385,48 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
         if (j == 0) GP_TRACE(2);
         if (j == 1) GP_TRACE(4);
         const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
+        cov_ring(j, a);  // (older than everything in flight but the record) -- read before chunk j+2 is requested into its place
         if (j + 2 < PPT) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           dma(j + 2);
           vm_wait_rec<4>(head, c01, c23, c45);  // the record -- and hop 1 of chunk j+1, which is older -- are here; chunk j+2 keeps travelling
         } else {
           vm_wait_rec<0>(head, c01, c23, c45);
         }
-        algebra_ring(j, P[j & 1], hit, head, c01, c23, c45);
+        algebra(a, P[j & 1], hit, head, c01, c23, c45);
+        if (j == 0) GP_TRACE(3);
+        if (j == 1) GP_TRACE(5);
+      }
+    } else if constexpr (SCHED >= 2) {
+      // points first: only the 768 B of chunk 0's points are in flight, so the first transform and hop 1 do not queue behind everybody's
+      // covariances; those follow hop 1 (they are needed behind hop 2), the points of chunk 1 go out before hop 2 and its covariances
+      // behind it, so that the wait for the first record does not drag a source request that was issued a moment ago
+      vm_wait<0>();
+      GP_TRACE(1);
+      front_ring(0, P[0]);  // in flight: H0
+      dma_cov(0);
+      if (PPT > 1) dma_pts(1);  // in flight: H0, C0 x3, P1
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        if (j == 0) vm_wait_blk<4>(P[0].blk);            // [H0, C0 x3, P1]
+        else if (j + 1 < PPT) vm_wait_blk<4>(P[j & 1].blk);  // [H(j), chunk j+1 x4]
+        else vm_wait_blk<0>(P[j & 1].blk);
+        if (j == 0) GP_TRACE(2);
+        if (j == 1) GP_TRACE(4);
+        const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
+        if (j == 0) {
+          dma_cov(1);                           // [C0 x3, P1, R0 x4, C1 x3]
+          vm_wait_rec<3>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the points of chunk 1
+        } else {
+          vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
+        }
+        if (j + 1 < PPT) front_ring(j + 1, P[(j + 1) & 1]);  // its hop 1 travels under the algebra of chunk j
+        cov_ring(j, a);
+        if (j + 2 < PPT) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma(j + 2);
+        }
+        algebra(a, P[j & 1], hit, head, c01, c23, c45);
         if (j == 0) GP_TRACE(3);
         if (j == 1) GP_TRACE(5);
       }
@@ -340,11 +445,13 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
         if (j == 1) GP_TRACE(4);
         const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
         vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
-        if (j + 1 < PPT) {
-          front_ring(j + 1, P[(j + 1) & 1]);  // its hop 1 travels under the algebra of chunk j
-          if (j + 2 < PPT) dma(j + 2);        // stage of chunk j-1
+        if (j + 1 < PPT) front_ring(j + 1, P[(j + 1) & 1]);  // its hop 1 travels under the algebra of chunk j
+        cov_ring(j, a);
+        if (j + 2 < PPT) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma(j + 2);
         }
-        algebra_ring(j, P[j & 1], hit, head, c01, c23, c45);
+        algebra(a, P[j & 1], hit, head, c01, c23, c45);
         if (j == 0) GP_TRACE(3);
         if (j == 1) GP_TRACE(5);
       }
@@ -392,22 +499,37 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   // ways), every lane sums 32 values of one component in f64, lane pairs meet with one swap; the 4-wave sum goes through the
   // last 256 B of each wave's region; one 32-double partial per tile (fixed order: bit-reproducible) ----
   constexpr int kRowStrideF = 66;
-  static_assert(32 * kRowStrideF * 4 + 32 * 8 <= STAGES * kChunkBytes, "f32 transposition buffer + wave sums must fit the wave's ring");
+  static_assert(32 * kRowStrideF * 4 + 32 * 8 <= kWaveLdsBytes, "f32 transposition buffer + wave sums must fit the wave's LDS region");
   float* wtf = reinterpret_cast<float*>(wbase);
-  double* wsums = reinterpret_cast<double*>(wbase + STAGES * kChunkBytes - 32 * 8);
+  double* wsums = reinterpret_cast<double*>(wbase + kWaveLdsBytes - 32 * 8);
 #pragma unroll
   for (int k = 0; k < 32; k++) wtf[k * kRowStrideF + lane] = acc[k];
   {
     const int comp = lane >> 1, part = lane & 1;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double v;
+    if constexpr (SCHED >= 3) {
+      // four f32 partial sums of 4 values each (every value is itself the sum of <= PPT points), met in f64: a third of the issue
+      // cycles of sixteen cvt + f64 adds; the rounding it adds (2^-24 relative per wave partial, random sign) averages out over the tiles
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; i += 4) {
-      s0 += (double)wtf[comp * kRowStrideF + 2 * i + part];
-      s1 += (double)wtf[comp * kRowStrideF + 2 * (i + 1) + part];
-      s2 += (double)wtf[comp * kRowStrideF + 2 * (i + 2) + part];
-      s3 += (double)wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+      for (int i = 0; i < 32; i += 4) {
+        s0 += wtf[comp * kRowStrideF + 2 * i + part];
+        s1 += wtf[comp * kRowStrideF + 2 * (i + 1) + part];
+        s2 += wtf[comp * kRowStrideF + 2 * (i + 2) + part];
+        s3 += wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+      }
+      v = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    } else {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; i += 4) {
+        s0 += (double)wtf[comp * kRowStrideF + 2 * i + part];
+        s1 += (double)wtf[comp * kRowStrideF + 2 * (i + 1) + part];
+        s2 += (double)wtf[comp * kRowStrideF + 2 * (i + 2) + part];
+        s3 += (double)wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+      }
+      v = (s0 + s1) + (s2 + s3);
     }
-    double v = (s0 + s1) + (s2 + s3);
     v += __shfl_xor(v, 1, 64);
     if (part == 0) wsums[comp] = v;
   }
@@ -415,10 +537,10 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   if (threadIdx.x < ACC_STRIDE) {
     double sum = 0.0;
     if (threadIdx.x < ACC_SIZE) {
-      const double* w0 = reinterpret_cast<const double*>(smem + 1 * STAGES * kChunkBytes - 32 * 8);
-      const double* w1 = reinterpret_cast<const double*>(smem + 2 * STAGES * kChunkBytes - 32 * 8);
-      const double* w2 = reinterpret_cast<const double*>(smem + 3 * STAGES * kChunkBytes - 32 * 8);
-      const double* w3 = reinterpret_cast<const double*>(smem + 4 * STAGES * kChunkBytes - 32 * 8);
+      const double* w0 = reinterpret_cast<const double*>(smem + 1 * kWaveLdsBytes - 32 * 8);
+      const double* w1 = reinterpret_cast<const double*>(smem + 2 * kWaveLdsBytes - 32 * 8);
+      const double* w2 = reinterpret_cast<const double*>(smem + 3 * kWaveLdsBytes - 32 * 8);
+      const double* w3 = reinterpret_cast<const double*>(smem + 4 * kWaveLdsBytes - 32 * 8);
       sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
     }
     ((GP_GLOBAL double*)partials)[(size_t)tile.row * ACC_STRIDE + threadIdx.x] = sum;

@@ -57,7 +57,7 @@ def run_case(name, d, res, delta, Lo, iters=50):
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
     out = np.zeros((1, 122))
     for v in variants:
-        for st in (staggers if v in (2, 4, 5, 8) else [0]):
+        for st in (staggers if v in (2, 4, 5, 8) else [0]) if len(staggers) > 1 else [0]:
             _capi.check(lib.gp_debug_set_variant(v), "variant")
             _capi.check(lib.gp_debug_set_stagger(st), "stagger")
             batch, s = make_batch(f)
@@ -81,8 +81,8 @@ def run_case(name, d, res, delta, Lo, iters=50):
     return f, vm, src, tgt
 
 
-def trace_case(f, delta, stagger, label):
-    lib.gp_debug_set_variant(8)
+def trace_case(f, delta, stagger, label, variant=8):
+    lib.gp_debug_set_variant(variant)
     lib.gp_debug_set_stagger(stagger)
     batch, s = make_batch(f)
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
@@ -150,6 +150,7 @@ def trace_case(f, delta, stagger, label):
     lib.gp_vgicp_batch_destroy(batch)
     lib.gp_stream_destroy(s)
     lib.gp_debug_set_stagger(0)
+    lib.gp_debug_set_variant(8)
 
 
 d = synthetic.make_c2_workload()
@@ -159,6 +160,8 @@ om.insert(d["target_points"], d["target_covs"])
 Lo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], oracle.max_threads()).linearize(delta)
 f, vm, src, tgt = run_case("c2_1M", d, 0.5, delta, Lo)
 trace_case(f, delta, 0, "c2_1M default")
+for v in [v for v in variants if v >= 9]:
+    trace_case(f, delta, 0, f"c2_1M variant {v}", v)
 for st in [s for s in staggers if s > 0][:2]:
     trace_case(f, delta, st, "c2_1M staggered")
 
@@ -174,5 +177,5 @@ run_case("kitti00_dec8", dk, 0.5, dlt, Lok, iters=200)
 if BIG:
     # the real kernel on a working set beyond the 256 MiB Infinity Cache: 8 M source points (384 MB) vs the same 2 M-point map
     big = synthetic.make_c2_workload(8_000_000, 2_000_000, seed=42)
-    variants = [8, 4, 3]
+    variants = sorted(set(variants) | {8}, reverse=True) if max(variants) >= 9 else [8, 4, 3]
     run_case("c2_8M_source", big, 0.5, big["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015]), None, iters=20)

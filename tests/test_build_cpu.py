@@ -29,7 +29,7 @@ def test_pipeline_kernels_do_not_spill():
     ks2 = {k: v for k, v in _kernels().items() if "vgicp_pipeline2_kernel" in k}
     assert len(ks2) >= 8  # tile size x schedule x descriptor source (gp_vgicp_tile2.hpp)
     for name, r in ks2.items():
-        assert r["scratch"] == 0 and r["vspill"] == 0 and r["lds"] == 36864 and r["occupancy"] >= 4, (name, r)
+        assert r["scratch"] == 0 and r["vspill"] == 0 and r["lds"] == 34816 and r["occupancy"] >= 4, (name, r)
     for name, r in ks.items():
         assert r["scratch"] == 0 and r["vspill"] == 0, (name, r)
         assert r["lds"] == 36864, (name, r)  # 4 waves x 3 stages x 3 KB
