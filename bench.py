@@ -12,7 +12,7 @@ Inputs (source cloud, voxel map) are resident in HBM before the timed region.  v
 Weak scaling: per-GPU work is fixed as N grows.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (vgicp_pipeline_kernel): algorithmic bytes (SURVEY.md 8(d):
+  roofline     -- dominant kernel (vgicp_pipeline2_kernel): algorithmic bytes (SURVEY.md 8(d):
                   48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration measured with HIP events on the
                   stream it is launched on; peak 8 TB/s HBM3E.
   cpu_baseline -- the reference's own CPU factor (oracle/_ref/libref.so, kind "reference"; the C restatement, kind "port", when
@@ -264,7 +264,7 @@ def main():
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_pipeline_kernel<MODE_LIN, f32 outer products, 4 chunks/wave, block grid, look-ahead lookup>",
+        kernel="vgicp_pipeline2_kernel<4 chunks/wave, non-temporal source stream, in-argument descriptor> (gp_vgicp_tile2.hpp)",
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",
@@ -344,7 +344,7 @@ def main():
             scaling="weak",
             vs_baseline=None,
             dtype="f64",
-            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel variant 8)",
+            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel variant 11)",
             data="synthetic",
             config=dict(
                 workload="BASELINE configs[1]: single VGICP factor per GPU, 1M synthetic source pts vs 2M-pt GaussianVoxelMap @0.5 m",

@@ -11,6 +11,12 @@
 
 #include "gp_device.hpp"
 
+struct gp_vgicp_batch;
+namespace gp {
+// gp_vgicp.hip: sibling batches on the same device re-read this batch's source clouds (gp_multi.hip, several shards per device)
+void batch_set_sources_shared(gp_vgicp_batch* batch, bool shared);
+}  // namespace gp
+
 namespace gp {
 
 void set_error(const std::string& msg);

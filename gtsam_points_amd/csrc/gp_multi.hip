@@ -400,6 +400,7 @@ int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_facto
     std::vector<gp_vgicp_factor_t*> mine;
     for (int i : s.index) mine.push_back(factors[i]);
     if ((rc = gp_vgicp_batch_create(mine.data(), (int)mine.size(), s.stream, &s.batch)) != GP_OK) break;
+    if (!distinct) gp::batch_set_sources_shared(s.batch, true);  // sibling shards on this device re-read the clouds: keep the stream cacheable
     const size_t rows = mb->use_rccl ? std::max<size_t>(F, 1) : std::max<size_t>(s.index.size(), 1);
     if ((rc = s.d_stack.alloc(sizeof(double) * kRecordDoubles * rows)) != GP_OK || (rc = s.d_err.alloc(sizeof(double) * rows)) != GP_OK) break;
     if (mb->use_rccl && !s.contiguous) {

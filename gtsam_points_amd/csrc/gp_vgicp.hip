@@ -549,6 +549,9 @@ struct gp_vgicp_batch {
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
   bool use_grid = false;  // every factor's map carries an occupancy-block grid (else the hashed line table is used)
   bool gen2_ok = false;   // ... every map's records fit 32-bit byte offsets and no factor validates surfaces (vgicp_pipeline2_kernel)
+  bool stream_once = false;  // no two factors of the batch read the same source cloud (and no sibling batch on this device does: gp_multi.hip
+                             // clears shares_device_ok): the source stream may use the non-temporal policy
+  bool shares_device_ok = true;
   int ppt = 4;            // 64-point chunks per wave of the pipeline kernel (tile = 256 x ppt points)
   std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
@@ -580,7 +583,11 @@ namespace {
 //   6 / 7  as 4 with 512- / 256-point tiles forced (A/B)
 //   8  as 4 with the look-ahead lookup (AHEAD in gp_vgicp_tile.hpp): hop 1 of chunk j+1 travels with hop 2 of chunk j.   (default)
 //      Same arithmetic in the same order as 4: bit-identical results.  C2 -1..3 %, C3 -5 %, C4 -1.5 % tile-kernel time.
-int g_variant = 8;
+//   9 / 10 / 11  the second-generation linearise kernel (gp_vgicp_tile2.hpp: saddr addressing, 12-B LDS-DMA rows, scalar descriptor path,
+//      f64 diet, points-first lean start, f32 in-lane reduction sums) with the default / the non-temporal / the per-batch policy on
+//      the source stream; error evaluation, 256-point tiles, maps without a grid and factors with surface validation run as variant 8.
+//      11 is the default: C2 14.5 -> 12.3 us (0.48 -> 0.57 of 8 TB/s), C3 61 -> 55 us, C4 shard 230 -> 215 us (profiles/r02_gen2_ab.txt).
+int g_variant = 11;
 int g_stagger = 0;
 int g_xcd_chunk = 0;
 int g_tile_interleave = 0;  // measured on C3 / C4: no effect beyond noise (0.2305 vs 0.2318 ms on the C4 shard), so the plain factor-major order stays
@@ -590,7 +597,8 @@ struct VariantDesc {
   bool f32, grid, lean;
   int ppt;  // 64-point chunks per wave (0 = chosen per batch)
   bool ahead = false;  // hop 1 of the next chunk travels with hop 2 of this one (linearise only)
-  int gen2 = 0;        // 1 .. 4: vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp) with schedule 0 .. 3 for the linearise, else as variant 8
+  int gen2 = 0;        // vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp) for the linearise, else as variant 8; source stream policy: 1 default,
+                       // 2 non-temporal, 3 chosen per batch (non-temporal when no two factors of the batch read the same source cloud)
 };
 VariantDesc variant_desc(int v) {
   switch (v) {
@@ -604,8 +612,6 @@ VariantDesc variant_desc(int v) {
     case 9: return {true, true, true, 0, true, 1};
     case 10: return {true, true, true, 0, true, 2};
     case 11: return {true, true, true, 0, true, 3};
-    case 12: return {true, true, true, 0, true, 4};
-    case 13: return {true, true, true, 0, true, 5};
     default: return {true, true, true, 0};
   }
 }
@@ -673,6 +679,12 @@ int build_table(gp_vgicp_batch* b) {
     b->total_points += f->n;
   }
   b->num_tiles = (int)tiles.size();
+  {
+    std::vector<const float*> srcs;
+    for (const auto& d : descs) srcs.push_back(d.points);
+    std::sort(srcs.begin(), srcs.end());
+    b->stream_once = b->shares_device_ok && std::adjacent_find(srcs.begin(), srcs.end()) == srcs.end();
+  }
   if (g_tile_interleave) {
     // execution order: consecutive factors that read the SAME source cloud (a submap matched against several targets, BASELINE
     // configs[3]) take turns tile by tile, so the workgroups that run side by side on an XCD read the same source bytes at the same
@@ -779,16 +791,14 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       GP_LAUNCH_PIPE(true, 4, true, false, false);
     } else if (vd.gen2 && MODE == gp::MODE_LIN && b->ppt >= 2 && b->gen2_ok) {
       if constexpr (MODE == gp::MODE_LIN) {
-#define GP_LAUNCH_PIPE2(PPT, SCHED, INL, TRACE)                                                                                                         \
-  hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<PPT, SCHED, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
-#define GP_LAUNCH_PIPE2_S(PPT, INL, TRACE)             \
-  do {                                                 \
-    if (vd.gen2 == 1) GP_LAUNCH_PIPE2(PPT, 0, INL, TRACE);      \
-    else if (vd.gen2 == 2) GP_LAUNCH_PIPE2(PPT, 1, INL, TRACE); \
-    else if (vd.gen2 == 3) GP_LAUNCH_PIPE2(PPT, 2, INL, TRACE); \
-    else if (vd.gen2 == 4) GP_LAUNCH_PIPE2(PPT, 3, INL, TRACE); \
-    else GP_LAUNCH_PIPE2(PPT, 4, INL, TRACE);                   \
+#define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE)                                                                                                           \
+  hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<PPT, NT, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
+#define GP_LAUNCH_PIPE2_S(PPT, INL, TRACE)       \
+  do {                                           \
+    if (nt) GP_LAUNCH_PIPE2(PPT, true, INL, TRACE); \
+    else GP_LAUNCH_PIPE2(PPT, false, INL, TRACE);   \
   } while (0)
+        const bool nt = vd.gen2 == 2 || (vd.gen2 == 3 && b->stream_once);
         if (b->ppt == 4 && g_trace_on && inl.use) {
           GP_LAUNCH_PIPE2_S(4, true, true);
         } else if (b->ppt == 4) {
@@ -930,7 +940,7 @@ int gp_debug_set_trace_buffer(void* dev_buffer) {
 }
 
 int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 13) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..13");
+  if (variant < 0 || variant > 11) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..11");
   g_variant = variant;
   return GP_OK;
 }
@@ -1118,6 +1128,18 @@ int gp_vgicp_batch_create(gp_vgicp_factor_t* const* factors, int num_factors, gp
   }
   *out = b;
   return GP_OK;
+}
+
+// gp_multi.hip: several shards of one multi-batch run on this device and read the same source clouds one after the other, so the source
+// stream of this batch must stay cacheable (no non-temporal policy)
+extern "C++" {
+namespace gp {
+void batch_set_sources_shared(gp_vgicp_batch* batch, bool shared) {
+  if (!batch || batch->shares_device_ok == !shared) return;
+  batch->shares_device_ok = !shared;
+  batch->table_dirty = true;
+}
+}  // namespace gp
 }
 
 int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch) {

@@ -12,10 +12,15 @@
 //   * f64 diet: transform as three 3-deep fma chains (9 instead of 12 instructions), centre - l = fma(-leaf, fract(u), leaf/2)
 //     (6 instead of 9), one Newton step behind v_rcp_f64 (2^-46 relative: eight orders inside what the f32 outer products keep);
 //   * block index with 24-bit multiply-adds (the grid has < 2^24 blocks);
-//   * schedule (SCHED): 0 = the round-2 look-ahead order (both first chunks requested up front, front half of chunk j+1 before hop 1
-//     of chunk j is consumed); 1 = lean start (the first burst is ONE chunk per wave; chunk 1 follows the first hop 1) with the
-//     front half of chunk j+1 behind the record wait of chunk j, so that its hop 1 travels under the algebra of chunk j; 2 = 1 with a
-//     points-first prologue (see the kernel); 3 = 2 with f32 in-lane sums in the reduction; 4 = 3 with the non-temporal policy on the stream.
+//   * schedule: lean, points-first start -- the first burst of a wave is the 768 B of chunk 0's points, so the first transform and hop 1
+//     do not queue behind everybody's covariances; those follow hop 1, the points of chunk 1 go out before hop 2 and its covariances
+//     behind it -- and the front half of chunk j+1 (transform, hop 1 issued) sits behind the record wait of chunk j, so that its hop 1
+//     travels under the algebra of chunk j.  The alternatives (the round-2 look-ahead order with both chunks requested up front; the
+//     lean start without points first) were measured with this kernel and removed: profiles/r02_gen2_ab.txt;
+//   * reduction: four f32 in-lane partial sums per component instead of sixteen cvt + f64 adds (a third of its issue cycles);
+//   * NT: the non-temporal policy on the source stream, chosen per batch by the host: +3.5 % on C2 / +4.5 % on the C4 shard, where
+//     every source cloud is read by one factor of the launch, -29 % on C3, where four factors share a cloud and the re-reads would
+//     have hit L2.
 // Arithmetic differs from variants 4 / 8 at the 1e-16 level (fma contraction, fract), not bit for bit; parity tests are the same.
 #pragma once
 
@@ -223,12 +228,11 @@ __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a
 // INL: a single-factor launch; the factor descriptor, the pose and the tile geometry come out of the kernel arguments through scalar
 // loads.  (With a run-time `inl.use ? inl.factor : factors[...]` hipcc selects between the two ADDRESSES and reads the descriptor
 // with flat loads: a vector-memory round trip in front of the first source request, also for the in-argument copy.)
-template <int PPT, int SCHED, bool INL, bool TRACE = false>
+template <int PPT, bool NT, bool INL, bool TRACE = false>
 __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                   const double* __restrict__ poses_lin, const double* __restrict__ /*poses_eval*/, const InlinePoses inl,
                                                                   double* __restrict__ partials) {
   static_assert(PPT == 2 || PPT == 4, "512- and 1024-point tiles");
-  static_assert(SCHED >= 0 && SCHED <= 4, "see the header");
   __shared__ __attribute__((aligned(16))) char smem[4 * kWaveLdsBytes];  // 34 KB
   int tile_idx;
   if (inl.xcd_chunk > 0) {
@@ -272,7 +276,6 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   const GP_GLOBAL char* upts = uniform_ptr((const GP_GLOBAL char*)as_global(f.points) + 12 * first);
   const GP_GLOBAL char* ucov = uniform_ptr((const GP_GLOBAL char*)as_global(f.covs) + 36 * first);
   const unsigned voff = (unsigned)lane * 12u;
-  constexpr bool NT = SCHED == 4;
   auto dma_pts = [&](int j) { chunk_dma12_pts<NT>(upts + (size_t)j * (kChunkPoints * 12), voff, pslot(j)); };
   auto dma_cov = [&](int j) { chunk_dma12_cov<NT>(ucov + (size_t)j * (kChunkPoints * 36), voff, cslot(j)); };
   auto dma = [&](int j) {
@@ -280,14 +283,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     dma_cov(j);
   };
 
-  if (ring) {
-    if (SCHED >= 2) {
-      dma_pts(0);
-    } else {
-      dma(0);
-      if (SCHED == 0) dma(1);
-    }
-  }
+  if (ring) dma_pts(0);
 
   const Pose Tl = INL ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
   const double leaf = uniform_f64(f.map.leaf), inv_leaf = uniform_f64(f.map.inv_leaf), half_leaf = uniform_f64(0.5 * f.map.leaf);
@@ -364,40 +360,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     v4f head;
     v2d c01, c23, c45;
     double a[6];
-    if constexpr (SCHED == 0) {
-      // in flight: chunk 0, chunk 1 (4 requests each; the first of a chunk carries its points)
-      vm_wait<7>();  // the points of chunk 0 are in LDS
-      GP_TRACE(1);
-      front_ring(0, P[0]);  // in flight: C0 x3, chunk 1 x4, hop 1 of chunk 0
-#pragma unroll
-      for (int j = 0; j < PPT; j++) {
-        if (j + 1 < PPT) {
-          // the points of chunk j+1: j == 0: [C0 x3, P1, C1 x3, H0]; j >= 1: [P(j+1), C(j+1) x3] (hop 1 of chunk j is older than the
-          // record of chunk j-1, which step j-1 waited for)
-          if (j == 0) vm_wait<4>();
-          else vm_wait<3>();
-          front_ring(j + 1, P[(j + 1) & 1]);
-          if (j == 0) vm_wait_blk<1>(P[0].blk);  // [C1 x3, H0, H1]: hop 1 of chunk 0
-          else vm_wait_blk<4>(P[j & 1].blk);     // already here: nothing to wait for
-        } else {
-          vm_wait_blk<0>(P[j & 1].blk);
-        }
-        if (j == 0) GP_TRACE(2);
-        if (j == 1) GP_TRACE(4);
-        const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
-        cov_ring(j, a);  // (older than everything in flight but the record) -- read before chunk j+2 is requested into its place
-        if (j + 2 < PPT) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          dma(j + 2);
-          vm_wait_rec<4>(head, c01, c23, c45);  // the record -- and hop 1 of chunk j+1, which is older -- are here; chunk j+2 keeps travelling
-        } else {
-          vm_wait_rec<0>(head, c01, c23, c45);
-        }
-        algebra(a, P[j & 1], hit, head, c01, c23, c45);
-        if (j == 0) GP_TRACE(3);
-        if (j == 1) GP_TRACE(5);
-      }
-    } else if constexpr (SCHED >= 2) {
+    {
       // points first: only the 768 B of chunk 0's points are in flight, so the first transform and hop 1 do not queue behind everybody's
       // covariances; those follow hop 1 (they are needed behind hop 2), the points of chunk 1 go out before hop 2 and its covariances
       // behind it, so that the wait for the first record does not drag a source request that was issued a moment ago
@@ -420,31 +383,6 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
         } else {
           vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
         }
-        if (j + 1 < PPT) front_ring(j + 1, P[(j + 1) & 1]);  // its hop 1 travels under the algebra of chunk j
-        cov_ring(j, a);
-        if (j + 2 < PPT) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          dma(j + 2);
-        }
-        algebra(a, P[j & 1], hit, head, c01, c23, c45);
-        if (j == 0) GP_TRACE(3);
-        if (j == 1) GP_TRACE(5);
-      }
-    } else {
-      // in flight: chunk 0
-      vm_wait<3>();  // its points are in LDS
-      GP_TRACE(1);
-      front_ring(0, P[0]);  // in flight: C0 x3, H0
-      dma(1);               // ... and chunk 1 x4
-#pragma unroll
-      for (int j = 0; j < PPT; j++) {
-        // hop 1 of chunk j; the only younger requests are those of chunk j+1 (if there is one)
-        if (j + 1 < PPT) vm_wait_blk<4>(P[j & 1].blk);
-        else vm_wait_blk<0>(P[j & 1].blk);
-        if (j == 0) GP_TRACE(2);
-        if (j == 1) GP_TRACE(4);
-        const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
-        vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
         if (j + 1 < PPT) front_ring(j + 1, P[(j + 1) & 1]);  // its hop 1 travels under the algebra of chunk j
         cov_ring(j, a);
         if (j + 2 < PPT) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
@@ -507,7 +445,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   {
     const int comp = lane >> 1, part = lane & 1;
     double v;
-    if constexpr (SCHED >= 3) {
+    {
       // four f32 partial sums of 4 values each (every value is itself the sum of <= PPT points), met in f64: a third of the issue
       // cycles of sixteen cvt + f64 adds; the rounding it adds (2^-24 relative per wave partial, random sign) averages out over the tiles
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -519,16 +457,6 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
         s3 += wtf[comp * kRowStrideF + 2 * (i + 3) + part];
       }
       v = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
-    } else {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 32; i += 4) {
-        s0 += (double)wtf[comp * kRowStrideF + 2 * i + part];
-        s1 += (double)wtf[comp * kRowStrideF + 2 * (i + 1) + part];
-        s2 += (double)wtf[comp * kRowStrideF + 2 * (i + 2) + part];
-        s3 += (double)wtf[comp * kRowStrideF + 2 * (i + 3) + part];
-      }
-      v = (s0 + s1) + (s2 + s3);
     }
     v += __shfl_xor(v, 1, 64);
     if (part == 0) wsums[comp] = v;

@@ -16,7 +16,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(list)
 for row in csv.DictReader(open(sys.argv[1])):
-    if "vgicp_pipeline_kernel" in row["Kernel_Name"]:
+    if "vgicp_pipeline" in row["Kernel_Name"]:
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, v in acc.items():
     print(f"{k:40s} mean/launch {sum(v)/len(v):16.1f}  (n={len(v)})")

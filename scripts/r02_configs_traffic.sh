@@ -12,7 +12,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(list)
 for row in csv.DictReader(open(sys.argv[1])):
-    if "vgicp_pipeline_kernel" in row["Kernel_Name"] and row["Counter_Name"] == sys.argv[2]:
+    if "vgicp_pipeline" in row["Kernel_Name"] and row["Counter_Name"] == sys.argv[2]:
         acc[int(row["Grid_Size"])].append(float(row["Counter_Value"]))
 for g, v in sorted(acc.items()):
     print(f"{sys.argv[2]:10s} tile kernel, grid {g:8d} threads ({g // 256} workgroups): mean {sum(v)/len(v):12.1f} KiB per launch (n={len(v)})")

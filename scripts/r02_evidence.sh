@@ -21,7 +21,7 @@ done
 ff=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 [ -n "$ff" ] && [ -n "$fw" ] && python scripts/pmc_summary.py "$ff" "$fw" 1000000 $O/hbm_traffic.json > $O/pmc_summary.txt; tail -1 $O/pmc_summary.txt | cut -c1-300
 # SQ / TCP / TCC counters of the default tile kernel
-bash scripts/pmc_tile.sh 8 > /dev/null 2>&1; cp gpurun_out/pmc_tile_v8.txt $O/pmc_tile_sq.txt; head -12 $O/pmc_tile_sq.txt
+bash scripts/pmc_tile.sh 11 > /dev/null 2>&1; cp gpurun_out/pmc_tile_v11.txt $O/pmc_tile_sq.txt; head -12 $O/pmc_tile_sq.txt
 # the other BASELINE configurations
 timeout 1500 python scripts/bench_configs.py > $O/configs.jsonl 2> $O/configs.err; cut -c1-260 $O/configs.jsonl
 # L2 hit rate of the tile kernel on the C4 shard
@@ -32,7 +32,7 @@ import csv, sys
 from collections import defaultdict
 acc = defaultdict(list)
 for row in csv.DictReader(open(sys.argv[1])):
-    if "vgicp_pipeline_kernel" in row["Kernel_Name"]:
+    if "vgicp_pipeline" in row["Kernel_Name"]:
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 for k, v in m.items():
@@ -42,7 +42,7 @@ if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
 PY
 cat $O/c4_tcc.txt
 # tile-kernel variants, per-workgroup timeline, 8 M-point source
-timeout 900 python scripts/r02_sweep.py 1,2,3,4,5,8 0 --big > $O/sweep.jsonl 2> $O/sweep.err; cut -c1-200 $O/sweep.jsonl | tail -12
+timeout 900 python scripts/r02_sweep.py 1,2,3,4,8,9,10,11 0 --big > $O/sweep.jsonl 2> $O/sweep.err; cut -c1-200 $O/sweep.jsonl | tail -12
 # C5: work counters, kernel times, PMC of the two kernels
 timeout 300 python scripts/r02_profile_aux.py counters 2>/dev/null | grep "^{" > $O/c5_counters.jsonl; cat $O/c5_counters.jsonl
 rm -rf /tmp/pk && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o c5 -- python scripts/r02_profile_aux.py c5 10 > $O/c5_prof.log 2>&1

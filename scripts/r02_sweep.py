@@ -77,7 +77,7 @@ def run_case(name, d, res, delta, Lo, iters=50):
             lib.gp_vgicp_batch_destroy(batch)
             lib.gp_stream_destroy(s)
     lib.gp_debug_set_stagger(0)
-    lib.gp_debug_set_variant(8)
+    lib.gp_debug_set_variant(11)
     return f, vm, src, tgt
 
 
@@ -150,7 +150,7 @@ def trace_case(f, delta, stagger, label, variant=8):
     lib.gp_vgicp_batch_destroy(batch)
     lib.gp_stream_destroy(s)
     lib.gp_debug_set_stagger(0)
-    lib.gp_debug_set_variant(8)
+    lib.gp_debug_set_variant(11)
 
 
 d = synthetic.make_c2_workload()

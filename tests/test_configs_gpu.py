@@ -209,7 +209,7 @@ def test_unsymmetrised_covariances(gpu, kitti00):
     Lo = oracle.OracleVGICPFactor(om, kitti00["source_points"], sc, 2).linearize(delta)
     lib = gpu.load()
     try:
-        for variant in [0, 1, 4]:  # reference-shaped kernel, hashed f64 pipeline, default
+        for variant in [0, 1, 4, 11]:  # reference-shaped kernel, hashed f64 pipeline, the round-2 grid kernel, default
             gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
             vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
             vm.insert(tgt)
@@ -222,7 +222,7 @@ def test_unsymmetrised_covariances(gpu, kitti00):
                 assert rel_err(getattr(L, k), getattr(Lo, k)) <= PARITY_TOL, (variant, k)
             assert abs(L.error - Lo.error) <= PARITY_TOL * Lo.error
     finally:
-        lib.gp_debug_set_variant(8)
+        lib.gp_debug_set_variant(11)
     # GICP reads both clouds' covariances the same way
     fg = gpu.IntegratedGICPFactorGPU(0, 1, tgt, src)
     Lg = fg.linearize_delta(delta)
