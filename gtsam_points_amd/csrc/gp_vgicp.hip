@@ -585,7 +585,8 @@ namespace {
 //      Same arithmetic in the same order as 4: bit-identical results.  C2 -1..3 %, C3 -5 %, C4 -1.5 % tile-kernel time.
 //   9 / 10 / 11  the second-generation linearise kernel (gp_vgicp_tile2.hpp: saddr addressing, 12-B LDS-DMA rows, scalar descriptor path,
 //      f64 diet, points-first lean start, f32 in-lane reduction sums) with the default / the non-temporal / the per-batch policy on
-//      the source stream; error evaluation, 256-point tiles, maps without a grid and factors with surface validation run as variant 8.
+//      the source stream, for the linearise and the error evaluation; 256-point tiles, maps without a grid and factors with surface
+//      validation run as variant 8.
 //      11 is the default: C2 14.5 -> 12.3 us (0.48 -> 0.57 of 8 TB/s), C3 61 -> 55 us, C4 shard 230 -> 215 us (profiles/r02_gen2_ab.txt).
 int g_variant = 11;
 int g_stagger = 0;
@@ -789,18 +790,18 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       GP_LAUNCH_PIPE(false, 4, true, false, false);
     } else if (!vd.lean) {
       GP_LAUNCH_PIPE(true, 4, true, false, false);
-    } else if (vd.gen2 && MODE == gp::MODE_LIN && b->ppt >= 2 && b->gen2_ok) {
-      if constexpr (MODE == gp::MODE_LIN) {
-#define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE)                                                                                                           \
-  hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<PPT, NT, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
+    } else if (vd.gen2 && b->ppt >= 2 && b->gen2_ok) {
+      {
+#define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE)                                                                                                                 \
+  hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<MODE, PPT, NT, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
 #define GP_LAUNCH_PIPE2_S(PPT, INL, TRACE)       \
   do {                                           \
     if (nt) GP_LAUNCH_PIPE2(PPT, true, INL, TRACE); \
     else GP_LAUNCH_PIPE2(PPT, false, INL, TRACE);   \
   } while (0)
         const bool nt = vd.gen2 == 2 || (vd.gen2 == 3 && b->stream_once);
-        if (b->ppt == 4 && g_trace_on && inl.use) {
-          GP_LAUNCH_PIPE2_S(4, true, true);
+        if (b->ppt == 4 && g_trace_on && inl.use && MODE == gp::MODE_LIN) {
+          if constexpr (MODE == gp::MODE_LIN) GP_LAUNCH_PIPE2_S(4, true, true);
         } else if (b->ppt == 4) {
           if (inl.use) GP_LAUNCH_PIPE2_S(4, true, false);
           else GP_LAUNCH_PIPE2_S(4, false, false);

@@ -165,6 +165,7 @@ __device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& 
 
 // M = (C_B + R C_A R^T)^-1 in f64 and the 29 sums in f32: accumulate_core of gp_vgicp_tile.hpp with one Newton step behind the
 // hardware reciprocal (v_rcp_f64 is good to ~2^-23, one step gives 2^-46)
+template <int MODE>
 __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a, const v2d& c01, const v2d& c23, const v2d& c45, float RX, float RY, float RZ, float QX,
                                                  float QY, float QZ, float* acc) {
   float M0, M1, M2, M3, M4, M5;
@@ -193,6 +194,7 @@ __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a
   const float mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
   acc[ACC_COUNT] += 1.0f;
   acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+  if constexpr (MODE == MODE_ERR) return;
   acc[ACC_M + 0] += M0;
   acc[ACC_M + 1] += M1;
   acc[ACC_M + 2] += M2;
@@ -228,11 +230,15 @@ __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a
 // INL: a single-factor launch; the factor descriptor, the pose and the tile geometry come out of the kernel arguments through scalar
 // loads.  (With a run-time `inl.use ? inl.factor : factors[...]` hipcc selects between the two ADDRESSES and reads the descriptor
 // with flat loads: a vector-memory round trip in front of the first source request, also for the in-argument copy.)
-template <int PPT, bool NT, bool INL, bool TRACE = false>
+// MODE_ERR (vgicp_error_kernel, vgicp_derivatives.cuh:85-139): correspondence and M at the linearisation pose, residual at the evaluation
+// pose: r = mu_B - T_e p = (centre - l) + mean_local + (l - l_e), the last term formed in f64 in the front half; 2 sums.
+template <int MODE, int PPT, bool NT, bool INL, bool TRACE = false>
 __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
-                                                                  const double* __restrict__ poses_lin, const double* __restrict__ /*poses_eval*/, const InlinePoses inl,
+                                                                  const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                                   double* __restrict__ partials) {
   static_assert(PPT == 2 || PPT == 4, "512- and 1024-point tiles");
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "rigid linearise and error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * kWaveLdsBytes];  // 34 KB
   int tile_idx;
   if (inl.xcd_chunk > 0) {
@@ -286,6 +292,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   if (ring) dma_pts(0);
 
   const Pose Tl = INL ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)tile.factor);
+  const Pose Te = MODE == MODE_ERR ? (INL ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)tile.factor)) : Tl;
   const double leaf = uniform_f64(f.map.leaf), inv_leaf = uniform_f64(f.map.inv_leaf), half_leaf = uniform_f64(0.5 * f.map.leaf);
   const int glo0 = f.map.glo[0], glo1 = f.map.glo[1], glo2 = f.map.glo[2];
   const unsigned gd0 = (unsigned)f.map.gdim[0], gd1 = (unsigned)f.map.gdim[1], gd2 = (unsigned)f.map.gdim[2];
@@ -299,9 +306,9 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   asm volatile("v_mov_b64 %0, %1" : "=v"(tvy) : "s"(Tl.ty));
   asm volatile("v_mov_b64 %0, %1" : "=v"(tvz) : "s"(Tl.tz));
 
-  float acc[32];
+  float acc[NACC];
 #pragma unroll
-  for (int k = 0; k < 32; k++) acc[k] = 0.f;
+  for (int k = 0; k < NACC; k++) acc[k] = 0.f;
 
   struct Ahead {  // what a chunk carries from its front half (transform, hop 1 issued) to its back half (hop 2, algebra)
     v4i blk;
@@ -318,12 +325,20 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     // centre - l = leaf (floor(u) + 0.5 - u) = leaf/2 - leaf fract(u): the large coordinates never meet
     const double ux = lx * inv_leaf, uy = ly * inv_leaf, uz = lz * inv_leaf;
     const int cx = (int)__builtin_floor(ux), cy = (int)__builtin_floor(uy), cz = (int)__builtin_floor(uz);
-    P.ex = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf);
-    P.ey = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf);
-    P.ez = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf);
-    P.qx = (float)lx;
-    P.qy = (float)ly;
-    P.qz = (float)lz;
+    if constexpr (MODE == MODE_ERR) {
+      const double ex_ = Te.r00 * dx + Te.r01 * dy + Te.r02 * dz + Te.tx, ey_ = Te.r10 * dx + Te.r11 * dy + Te.r12 * dz + Te.ty, ez_ = Te.r20 * dx + Te.r21 * dy + Te.r22 * dz + Te.tz;
+      P.ex = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf) + (lx - ex_));
+      P.ey = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf) + (ly - ey_));
+      P.ez = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf) + (lz - ez_));
+      P.qx = P.qy = P.qz = 0.f;
+    } else {
+      P.ex = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf);
+      P.ey = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf);
+      P.ez = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf);
+      P.qx = (float)lx;
+      P.qy = (float)ly;
+      P.qz = (float)lz;
+    }
     const bool live = active;  // (factors with surface validation stay on the round-2 kernel: its normals read is a compiler-tracked load)
     const unsigned bx = (unsigned)((cx >> 2) - glo0), by = (unsigned)((cy >> 2) - glo1), bz = (unsigned)((cz >> 2) - glo2);
     const bool inbox = (bx < gd0) & (by < gd1) & (bz < gd2);
@@ -352,7 +367,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     load_cov6(c9, a);
   };
   auto algebra = [&](const double* a, const Ahead& P, bool hit, const v4f& head, const v2d& c01, const v2d& c23, const v2d& c45) {
-    if (hit) accumulate_core2(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
+    if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
   };
 
   if (ring) {
@@ -428,7 +443,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
       vm_wait_rec<0>(head, c01, c23, c45);
       double a[6];
       load_cov6(c9, a);
-      if (hit) accumulate_core2(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
+      if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
     }
   }
 
@@ -440,31 +455,36 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
   static_assert(32 * kRowStrideF * 4 + 32 * 8 <= kWaveLdsBytes, "f32 transposition buffer + wave sums must fit the wave's LDS region");
   float* wtf = reinterpret_cast<float*>(wbase);
   double* wsums = reinterpret_cast<double*>(wbase + kWaveLdsBytes - 32 * 8);
+  if constexpr (MODE == MODE_ERR) {
 #pragma unroll
-  for (int k = 0; k < 32; k++) wtf[k * kRowStrideF + lane] = acc[k];
-  {
-    const int comp = lane >> 1, part = lane & 1;
-    double v;
-    {
-      // four f32 partial sums of 4 values each (every value is itself the sum of <= PPT points), met in f64: a third of the issue
-      // cycles of sixteen cvt + f64 adds; the rounding it adds (2^-24 relative per wave partial, random sign) averages out over the tiles
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = 0; k < 2; k++) {
+      double v = (double)acc[k];
 #pragma unroll
-      for (int i = 0; i < 32; i += 4) {
-        s0 += wtf[comp * kRowStrideF + 2 * i + part];
-        s1 += wtf[comp * kRowStrideF + 2 * (i + 1) + part];
-        s2 += wtf[comp * kRowStrideF + 2 * (i + 2) + part];
-        s3 += wtf[comp * kRowStrideF + 2 * (i + 3) + part];
-      }
-      v = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) wsums[k] = v;
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; k++) wtf[k * kRowStrideF + lane] = acc[k];
+    const int comp = lane >> 1, part = lane & 1;
+    // four f32 partial sums of 4 values each (every value is itself the sum of <= PPT points), met in f64: a third of the issue
+    // cycles of sixteen cvt + f64 adds; the rounding it adds (2^-24 relative per wave partial, random sign) averages out over the tiles
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      s0 += wtf[comp * kRowStrideF + 2 * i + part];
+      s1 += wtf[comp * kRowStrideF + 2 * (i + 1) + part];
+      s2 += wtf[comp * kRowStrideF + 2 * (i + 2) + part];
+      s3 += wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+    }
+    double v = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
     v += __shfl_xor(v, 1, 64);
     if (part == 0) wsums[comp] = v;
   }
   __syncthreads();
   if (threadIdx.x < ACC_STRIDE) {
     double sum = 0.0;
-    if (threadIdx.x < ACC_SIZE) {
+    if (threadIdx.x < (MODE == MODE_ERR ? 2 : ACC_SIZE)) {
       const double* w0 = reinterpret_cast<const double*>(smem + 1 * kWaveLdsBytes - 32 * 8);
       const double* w1 = reinterpret_cast<const double*>(smem + 2 * kWaveLdsBytes - 32 * 8);
       const double* w2 = reinterpret_cast<const double*>(smem + 3 * kWaveLdsBytes - 32 * 8);

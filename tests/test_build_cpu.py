@@ -37,3 +37,14 @@ def test_pipeline_kernels_do_not_spill():
         f32_outer = "ILi0ELb1E" in name or "ILi1ELb1E" in name
         want = 4 if (f32_outer or not mode_lin) else 3  # __launch_bounds__(256, ...) in gp_vgicp_tile.hpp
         assert r["occupancy"] >= want, (name, r)
+
+
+def test_second_generation_kernel_has_no_compiler_vmcnt_waits():
+    """gp_vgicp_tile2.hpp counts its vector-memory requests by hand; a `s_waitcnt vmcnt` inserted by hipcc (for a load it tracks itself)
+    would drain the source requests in flight.  The Makefile summarises the device assembly (csrc/count_waits.py)."""
+    path = os.path.join(ROOT, "gtsam_points_amd", "csrc", "gp_vgicp.waits.txt")
+    assert os.path.exists(path), "build the HIP library first"
+    rows = [l.split() for l in open(path) if l.strip()]
+    assert len(rows) >= 16  # MODE x tile size x stream policy x descriptor source
+    for name, _, n in rows:
+        assert int(n) == 0, name

@@ -451,6 +451,21 @@ def test_second_generation_kernel_at_size(gpu, variant, n_src):
     assert L.num_inliers == L8.num_inliers
     _, fo = _oracle(d, 0.5, oracle.max_threads())
     assert_linearized_close(L, fo.linearize(delta), MIXED_TOL, f"variant {variant}, {n_src} points")
+    # the error evaluation runs through the same kernel family: correspondences and M at `delta`, residual at `de`
+    de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
+    try:
+        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
+        err, err2 = C.c_double(), C.c_double()
+        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err2)), "compute_error")
+        e_lin = C.c_double()
+        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(delta), C.byref(e_lin)), "compute_error")
+    finally:
+        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    eo = fo.error(de)
+    assert err.value == err2.value
+    assert abs(err.value - eo) <= MIXED_TOL * abs(eo), (err.value, eo)
+    assert abs(e_lin.value - L.error) <= 1e-7 * abs(L.error)  # evaluated at the linearisation pose it is the linearise's own error
 
 
 def test_alignment_gate_gpu(gpu, kitti07):
