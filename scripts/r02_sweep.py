@@ -69,8 +69,13 @@ def run_case(name, d, res, delta, Lo, iters=50):
             for _ in range(200):
                 lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
             wall = (time.perf_counter() - t0) / 200 * 1e3
+            eout = np.zeros(1)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                lib.gp_vgicp_batch_compute_error(batch, pose.ctypes.data, pose.ctypes.data, eout.ctypes.data)
+            err_wall = (time.perf_counter() - t0) / 200 * 1e3
             alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
-            print(json.dumps(dict(case=name, variant=v, stagger=st, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5), fin_ms=round(best[2], 5), sync_call_ms=round(wall, 5),
+            print(json.dumps(dict(case=name, variant=v, stagger=st, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5), fin_ms=round(best[2], 5), sync_call_ms=round(wall, 5), error_sync_call_ms=round(err_wall, 5),
                                   frac=round(alg / (best[0] * 1e-3) / 8e12, 4), alg_bytes=alg, max_rel_err=max(errs.values()) if errs else None,
                                   inliers_ok=(L.num_inliers == Lo.num_inliers) if Lo is not None else None, has_grid=int(lib.gp_voxelmap_has_block_grid(vm._h)),
                                   voxels=vm.voxelmap_info.num_voxels, map_build_ms=round(t_map * 1e3, 3))), flush=True)
