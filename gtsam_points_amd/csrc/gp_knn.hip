@@ -1677,7 +1677,7 @@ int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_line
   }
   const gp::DoneFlags done{static_cast<unsigned long long*>(f->h_done_dev), ++f->seq};
   GP_TRY(gp::launch_finalize_single(f->stream, nullptr, pose, f->partials.as<double>(), f->num_tiles, reinterpret_cast<gp_linearized6*>(f->h_out_dev), !rigid, done));
-  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(f->h_done.ptr), 1, done.seq, f->stream));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(f->h_done.ptr), 1, done.seq, f->stream, 100 + (long)f->num_tiles * (long)f->tile_points / 1000));  // spin budget ~4x the kernel (0.2 ns per point)
   memcpy(out_host, f->h_out.ptr, sizeof(gp_linearized6));
   return GP_OK;
 }
@@ -1693,7 +1693,7 @@ int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16],
   }
   const gp::DoneFlags done{static_cast<unsigned long long*>(f->h_done_dev), ++f->seq};
   GP_TRY(gp::launch_finalize_error_single(f->stream, f->partials.as<double>(), f->num_tiles, reinterpret_cast<double*>(f->h_out_dev), done));
-  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(f->h_done.ptr), 1, done.seq, f->stream));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(f->h_done.ptr), 1, done.seq, f->stream, 100 + (long)f->num_tiles * (long)f->tile_points / 1000));  // spin budget ~4x the kernel (0.2 ns per point)
   memcpy(out_host, f->h_out.ptr, sizeof(double));
   return GP_OK;
 }

@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(con
   signal_done(done, fi, threadIdx.x == 0);
 }
 
-int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream) {
+int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream, long spin_us) {
   const volatile unsigned long long* fl = flags_host;
   const auto t0 = std::chrono::steady_clock::now();
   size_t next = 0;
@@ -485,8 +485,10 @@ int wait_done(const unsigned long long* flags_host, size_t count, unsigned long 
       return GP_OK;
     }
     __builtin_ia32_pause();
-    // large batches (and failed kernels, whose words never arrive) are left to the runtime after 100 us of spinning
-    if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+    // failed kernels, whose words never arrive, are left to the runtime once the spin budget of the call is used up (the caller sizes
+    // it on the work: a 100 us budget sent every pass of the 256- and 512-factor batches into hipStreamSynchronize, whose wake-up
+    // costs tens of microseconds)
+    if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
   }
   GP_HIP(hipStreamSynchronize(stream));
   return GP_OK;
@@ -589,6 +591,10 @@ namespace {
 //      validation run as variant 8.
 //      11 is the default: C2 14.5 -> 12.3 us (0.48 -> 0.57 of 8 TB/s), C3 61 -> 55 us, C4 shard 230 -> 215 us (profiles/r02_gen2_ab.txt).
 int g_variant = 11;
+const bool g_zero_copy_poses = [] {  // A/B switch of the pose hand-over of the synchronous batched calls (stage_poses)
+  const char* e = getenv("GP_POSES_ZERO_COPY");
+  return !e || atoi(e) != 0;
+}();
 int g_stagger = 0;
 int g_xcd_chunk = 0;
 int g_tile_interleave = 0;  // measured on C3 / C4: no effect beyond noise (0.2305 vs 0.2318 ms on the C4 shard), so the plain factor-major order stays
@@ -879,7 +885,15 @@ int launch_error(gp_vgicp_batch* b, const PoseSource& ps, double* out_dev, gp::D
 }
 
 // poses for a launch: a single factor carries them in the kernel arguments; a batch uploads them with one H2D
-int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSource* ps) {
+// how long a synchronous call polls its completion words before it hands over to hipStreamSynchronize: 100 us + 50 ps per source point
+// (4x what the tile kernel takes), so that a healthy pass never gets there
+long spin_budget_us(const gp_vgicp_batch* b) { return 100 + (long)(b->total_points / 20000); }
+
+// zero_copy (the SYNCHRONOUS entry points, which return only after the kernels have finished): the kernels read the poses straight
+// out of the pinned staging buffer over the fabric -- one 128-B scalar read per workgroup, hidden behind the other workgroups -- instead
+// of behind a copy-engine transfer (an API call, an event and ~10 us of SDMA start-up in front of the first kernel).  The asynchronous
+// issue_* entry points keep the H2D copy: the caller may re-stage poses while the kernels of the previous pass are still running.
+int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSource* ps, bool zero_copy = false) {
   const size_t F = b->factors.size();
   if (F == 1) {
     memcpy(ps->inl.lin, lin, sizeof(double) * 16);
@@ -899,6 +913,14 @@ int stage_poses(gp_vgicp_batch* b, const double* lin, const double* eval, PoseSo
   double* h = b->h_poses.as<double>();
   memcpy(h, lin, sizeof(double) * 16 * F);
   if (eval) memcpy(h + 16 * F, eval, sizeof(double) * 16 * F);
+  if (zero_copy && g_zero_copy_poses) {
+    void* hd = nullptr;
+    GP_HIP(hipHostGetDevicePointer(&hd, h, 0));
+    ps->d_lin = static_cast<const double*>(hd);
+    ps->d_eval = eval ? static_cast<const double*>(hd) + 16 * F : nullptr;
+    ps->inl.use = 0;
+    return GP_OK;
+  }
   GP_HIP(hipMemcpyAsync(b->d_poses.ptr, h, sizeof(double) * 16 * F * (eval ? 2 : 1), hipMemcpyHostToDevice, b->stream));
   GP_HIP(hipEventRecord(b->h2d_done, b->stream));
   ps->d_lin = b->d_poses.as<double>();
@@ -1197,12 +1219,12 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   if (F == 0) return GP_OK;
   if (table_is_stale(b)) GP_TRY(build_table(b));
   PoseSource ps;
-  GP_TRY(stage_poses(b, poses_host, nullptr, &ps));
+  GP_TRY(stage_poses(b, poses_host, nullptr, &ps, true));
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, g_trace_host ? g_trace_host + 2047 * 16 : nullptr};
   const bool rigid = poses_are_rigid(poses_host, F);
   const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
   GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, parts));
-  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
   if (parts == 1) {
     memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
   } else {
@@ -1225,10 +1247,10 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
   if (F == 0) return GP_OK;
   if (table_is_stale(b)) GP_TRY(build_table(b));
   PoseSource ps;
-  GP_TRY(stage_poses(b, poses_lin_host, poses_eval_host, &ps));
+  GP_TRY(stage_poses(b, poses_lin_host, poses_eval_host, &ps, true));
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
   GP_TRY(launch_error(b, ps, reinterpret_cast<double*>(b->h_out_dev), done));
-  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream));
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream, spin_budget_us(b)));
   memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
   return GP_OK;
 }

@@ -179,7 +179,7 @@ __device__ __forceinline__ void signal_done(const DoneFlags& done, int slot, boo
   GP_FIN_TRACE(6);
 }
 // host side: spin on the words (bounded), then fall back to the stream -- which also surfaces a failed kernel as an error
-int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream);
+int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream, long spin_us = 100);
 
 int launch_finalize_single(hipStream_t stream, const double* pose_dev, const double* pose_host, const double* partials, int num_tiles, gp_linearized6* out_dev,
                            bool general = false, DoneFlags done = {});
