@@ -464,6 +464,15 @@ def test_second_generation_kernel_at_size(gpu, variant, n_src):
         lib.gp_debug_set_variant(DEFAULT_VARIANT)
     eo = fo.error(de)
     assert err.value == err2.value
+    if variant == DEFAULT_VARIANT:
+        # a view that starts 12 / 36 bytes into an allocation: the 12-B DMA rows of this kernel take any 4-B aligned array, and the
+        # same points must give the same record bit for bit
+        whole = gpu.PointCloudGPU(np.concatenate([d["source_points"][:1], d["source_points"]]), np.concatenate([d["source_covs"][:1], d["source_covs"]]))
+        view = gpu.PointCloudGPU.from_device(whole.points_gpu[1:], whole.covs_gpu[1:])
+        assert view.points_gpu.data_ptr() % 16 != 0
+        Lv = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, view), delta)
+        for k in BLOCKS:
+            assert np.array_equal(getattr(Lv, k), getattr(L, k)), k
     assert abs(err.value - eo) <= MIXED_TOL * abs(eo), (err.value, eo)
     assert abs(e_lin.value - L.error) <= 1e-7 * abs(L.error)  # evaluated at the linearisation pose it is the linearise's own error
 
