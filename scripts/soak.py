@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gtsam_points_amd as gpa
 from gtsam_points_amd import _capi, synthetic
 lib = gpa.load()
-d = synthetic.make_pair(120000, 200000, seed=5)
+NS, NT = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (120000, 200000)  # >= 393216 source points: the second-generation tile kernel
+d = synthetic.make_pair(NS, NT, seed=5)
 tgt = gpa.PointCloudGPU(d["target_points"], d["target_covs"]); src = gpa.PointCloudGPU(d["source_points"], d["source_covs"])
 vm = gpa.GaussianVoxelMapGPU(0.5); vm.insert(tgt)
 f = gpa.IntegratedVGICPFactorGPU(0, 1, vm, src); f.set_enable_offloading(True)
