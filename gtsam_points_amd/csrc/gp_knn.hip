@@ -1162,9 +1162,30 @@ struct GicpPoses {
   double lin[16], eval[16];
 };
 
-template <int MODE>  // MODE_LIN (rigid pose: 29 sums + adjoint finalize), MODE_ERR, MODE_LIN_GENERAL (any 3x3 block: 92 explicit sums)
+// correspondence pass of the GICP factor (IntegratedGICPFactor_::update_correspondences, integrated_gicp_factor_impl.hpp:132-172):
+// corr[i] = index of the nearest target point of T_lin p_i with squared distance < max, or -1.  ONE query per lane and nothing else in
+// the kernel: the fused search + algebra kernel below holds 32 f64 accumulators and the algebra's temporaries next to the search state
+// (157 VGPRs: three waves per SIMD, and a 1 M-point cloud only brings 3.8), and the search is a chain of dependent round trips that
+// only occupancy hides.  The stored correspondences are also what the reference's error() evaluates on (it does not search again).
+// (92 VGPRs, five waves per SIMD.  Capped at 80 VGPRs -- six waves, eleven registers spilled -- it measured 2 % faster: not worth the scratch.)
+__global__ void __launch_bounds__(256) gicp_correspond_kernel(GicpDesc f, const GicpPoses poses, int* __restrict__ corr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= f.n) return;
+  const Pose Tl = load_pose(poses.lin);
+  const double px = (double)f.points[3 * (size_t)i], py = (double)f.points[3 * (size_t)i + 1], pz = (double)f.points[3 * (size_t)i + 2];
+  const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
+  const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
+  const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
+  TopK<1> top;
+  top.init(1, f.max_sq_dist);
+  knn_query_any<1>(f.grid, lx, ly, lz, 1, top);
+  corr[i] = top.found ? top.idx[0] : -1;
+}
+
+// CORR: the correspondences come from gicp_correspond_kernel (corr[]) instead of a search of this kernel's own
+template <int MODE, bool CORR = false>  // MODE_LIN (rigid pose: 29 sums + adjoint finalize), MODE_ERR, MODE_LIN_GENERAL (any 3x3 block: 92 explicit sums)
 __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const GicpPoses poses,
-                                                        int tile_points, double* __restrict__ partials) {
+                                                        int tile_points, double* __restrict__ partials, const int* __restrict__ corr = nullptr) {
   constexpr int NACC = MODE == MODE_ERR ? 2 : (MODE == MODE_LIN ? ACC_SIZE : ACCG_SIZE);
   constexpr int STRIDE = MODE == MODE_LIN_GENERAL ? ACCG_STRIDE : ACC_STRIDE;
   constexpr int NREG = MODE == MODE_LIN_GENERAL ? ACCG_SIZE : 32;
@@ -1181,11 +1202,18 @@ __global__ void __launch_bounds__(256) gicp_tile_kernel(GicpDesc f, const GicpPo
     const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;
     const double lz = Tl.r20 * px + Tl.r21 * py + Tl.r22 * pz + Tl.tz;
     // correspondence: nearest target point with sq_dist < max (integrated_gicp_factor_impl.hpp:166-170)
-    TopK<1> top;
-    top.init(1, f.max_sq_dist);
-    knn_query_any<1>(f.grid, lx, ly, lz, 1, top);
-    if (top.found == 0) continue;
-    const size_t j = (size_t)top.idx[0];
+    size_t j;
+    if constexpr (CORR) {
+      const int c = corr[i];
+      if (c < 0) continue;
+      j = (size_t)c;
+    } else {
+      TopK<1> top;
+      top.init(1, f.max_sq_dist);
+      knn_query_any<1>(f.grid, lx, ly, lz, 1, top);
+      if (top.found == 0) continue;
+      j = (size_t)top.idx[0];
+    }
     const float* cp = f.covs + 9 * (size_t)i;
     const float* cq = f.target_covs + 9 * j;
     // reuse the VGICP per-point algebra: the "voxel" is the matched target point (mu_B, C_B)
@@ -1314,7 +1342,28 @@ struct gp_gicp_factor {
   gp::PinnedArray h_done;  // completion word of the synchronous calls (gp_vgicp_shared.hpp: DoneFlags)
   void* h_done_dev = nullptr;
   unsigned long long seq = 0;
+  gp::DeviceArray corr;          // [n] correspondences of the last correspondence pass (gicp_correspond_kernel)
+  double corr_pose[16] = {0};    // ... and the linearisation pose they belong to
+  bool corr_valid = false;
 };
+
+// correspondences at `pose_lin`.  A linearise always searches (IntegratedGICPFactor_::linearize calls update_correspondences every time,
+// the default update tolerances being zero); an error evaluation re-uses the stored correspondences when they belong to its
+// linearisation pose -- the reference's error() evaluates on the correspondences of the last linearise (impl.hpp:183-185).
+static int gicp_correspond(gp_gicp_factor* f, const gp::GicpPoses& P, bool reuse) {
+  static const bool split = [] { const char* e = getenv("GP_GICP_SPLIT"); return !e || atoi(e) != 0; }();
+  if (!split || f->desc.n <= 0) return 0;
+  if (!f->corr.ptr) {
+    if (f->corr.alloc(sizeof(int) * (size_t)f->desc.n) != GP_OK) return 0;  // no memory for the index array: the fused kernel still works
+    f->corr_valid = false;
+  }
+  if (!reuse || !f->corr_valid || memcmp(f->corr_pose, P.lin, sizeof(double) * 16) != 0) {
+    hipLaunchKernelGGL(gp::gicp_correspond_kernel, dim3((f->desc.n + 255) / 256), dim3(256), 0, f->stream, f->desc, P, f->corr.as<int>());
+    memcpy(f->corr_pose, P.lin, sizeof(double) * 16);
+    f->corr_valid = true;
+  }
+  return 1;
+}
 
 extern "C" {
 
@@ -1669,10 +1718,15 @@ int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_line
   // quaternions, src/test/test_matching_cost_factors.cpp:50-55) takes the 92-sum path with the explicit J_s, like the VGICP factor
   const bool rigid = gp::pose_is_rigid(pose);
   if (f->num_tiles > 0) {
-    if (rigid)
-      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>());
+    const int* corr = gicp_correspond(f, P, false) ? f->corr.as<int>() : nullptr;
+    if (rigid && corr)
+      hipLaunchKernelGGL((gp::gicp_tile_kernel<gp::MODE_LIN, true>), dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>(), corr);
+    else if (rigid)
+      hipLaunchKernelGGL((gp::gicp_tile_kernel<gp::MODE_LIN, false>), dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>(), corr);
+    else if (corr)
+      hipLaunchKernelGGL((gp::gicp_tile_kernel<gp::MODE_LIN_GENERAL, true>), dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>(), corr);
     else
-      hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_LIN_GENERAL>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>());
+      hipLaunchKernelGGL((gp::gicp_tile_kernel<gp::MODE_LIN_GENERAL, false>), dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>(), corr);
     GP_HIP(hipGetLastError());
   }
   const gp::DoneFlags done{static_cast<unsigned long long*>(f->h_done_dev), ++f->seq};
@@ -1688,7 +1742,11 @@ int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16],
   memcpy(P.lin, pose_lin, sizeof(double) * 16);
   memcpy(P.eval, pose_eval, sizeof(double) * 16);
   if (f->num_tiles > 0) {
-    hipLaunchKernelGGL(gp::gicp_tile_kernel<gp::MODE_ERR>, dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>());
+    const int* corr = gicp_correspond(f, P, true) ? f->corr.as<int>() : nullptr;
+    if (corr)
+      hipLaunchKernelGGL((gp::gicp_tile_kernel<gp::MODE_ERR, true>), dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>(), corr);
+    else
+      hipLaunchKernelGGL((gp::gicp_tile_kernel<gp::MODE_ERR, false>), dim3(f->num_tiles), dim3(256), 0, f->stream, f->desc, P, f->tile_points, f->partials.as<double>(), corr);
     GP_HIP(hipGetLastError());
   }
   const gp::DoneFlags done{static_cast<unsigned long long*>(f->h_done_dev), ++f->seq};

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import assert_linearized_close, expmap
+from helpers import BLOCKS, assert_linearized_close, expmap
 
 pytestmark = pytest.mark.gpu
 PARITY_TOL = 1e-7
@@ -75,6 +75,19 @@ def test_gicp_linearize_matches_oracle(gpu, kitti00, xi):
     assert abs(e - eo) < PARITY_TOL * eo
     hf = f.linearize({0: np.eye(4), 1: delta})
     assert np.array_equal(hf.G[(1, 1)], L.H_source) and hf.keys == [0, 1]
+    # the correspondences are kept between calls (the error evaluation above re-used those of the linearise); an error evaluation whose
+    # linearisation pose is NOT the stored one must search again, and a second linearise at the first pose must give the first record
+    import ctypes as C
+
+    d2 = delta @ expmap([0.01, 0.0, -0.01, 0.05, 0.0, 0.02])
+    out = C.c_double()
+    gpu._capi.check(f._lib.gp_gicp_factor_compute_error(f._h, gpu.types._pose16(d2), gpu.types._pose16(de), C.byref(out)), "gicp compute_error")
+    fo.linearize(d2)
+    eo2 = fo.evaluate(de).error
+    assert abs(out.value - eo2) < PARITY_TOL * eo2
+    L2 = f.linearize_delta(delta)
+    for k in BLOCKS:
+        assert np.array_equal(getattr(L2, k), getattr(L, k)), k
 
 
 def test_binned_and_hashed_structures_agree(gpu, kitti00):
