@@ -56,7 +56,7 @@ from collections import defaultdict
 acc = defaultdict(list)
 for row in csv.DictReader(open(sys.argv[1])):
     n = row["Kernel_Name"]
-    if "covariance_kernel" in n or "gicp_tile_kernel" in n:
+    if "covariance_kernel" in n or "gicp_tile_kernel" in n or "gicp_correspond_kernel" in n:
         acc[(n.split("(")[0][-40:], row["Counter_Name"])].append(float(row["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
     print(f"{k:42s} {c:34s} mean/launch {sum(v)/len(v):16.1f}  (n={len(v)})")
