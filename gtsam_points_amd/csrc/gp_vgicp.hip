@@ -587,8 +587,8 @@ namespace {
 //      Same arithmetic in the same order as 4: bit-identical results.  C2 -1..3 %, C3 -5 %, C4 -1.5 % tile-kernel time.
 //   9 / 10 / 11  the second-generation linearise kernel (gp_vgicp_tile2.hpp: saddr addressing, 12-B LDS-DMA rows, scalar descriptor path,
 //      f64 diet, points-first lean start, f32 in-lane reduction sums) with the default / the non-temporal / the per-batch policy on
-//      the source stream, for the linearise and the error evaluation; 256-point tiles, maps without a grid and factors with surface
-//      validation run as variant 8.
+//      the source stream, for the linearise and the error evaluation; maps without a grid and factors with surface validation run as
+//      variant 8.
 //      11 is the default: C2 14.5 -> 12.3 us (0.48 -> 0.57 of 8 TB/s), C3 61 -> 55 us, C4 shard 230 -> 215 us (profiles/r02_gen2_ab.txt).
 int g_variant = 11;
 const bool g_zero_copy_poses = [] {  // A/B switch of the pose hand-over of the synchronous batched calls (stage_poses)
@@ -796,7 +796,7 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       GP_LAUNCH_PIPE(false, 4, true, false, false);
     } else if (!vd.lean) {
       GP_LAUNCH_PIPE(true, 4, true, false, false);
-    } else if (vd.gen2 && b->ppt >= 2 && b->gen2_ok) {
+    } else if (vd.gen2 && b->gen2_ok) {
       {
 #define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE)                                                                                                                 \
   hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<MODE, PPT, NT, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
@@ -811,9 +811,12 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
         } else if (b->ppt == 4) {
           if (inl.use) GP_LAUNCH_PIPE2_S(4, true, false);
           else GP_LAUNCH_PIPE2_S(4, false, false);
-        } else {
+        } else if (b->ppt == 2) {
           if (inl.use) GP_LAUNCH_PIPE2_S(2, true, false);
           else GP_LAUNCH_PIPE2_S(2, false, false);
+        } else {
+          if (inl.use) GP_LAUNCH_PIPE2_S(1, true, false);
+          else GP_LAUNCH_PIPE2_S(1, false, false);
         }
 #undef GP_LAUNCH_PIPE2_S
 #undef GP_LAUNCH_PIPE2

@@ -152,8 +152,9 @@ template <int N>
 __device__ __forceinline__ void vm_wait_blk(v4i& blk) {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk) : : "memory");
   if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(blk) : : "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(blk) : : "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(blk) : : "memory");
-  static_assert(N == 0 || N == 1 || N == 4, "add the count");
+  static_assert(N == 0 || N == 1 || N == 3 || N == 4, "add the count");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& c45) {
@@ -236,7 +237,7 @@ template <int MODE, int PPT, bool NT, bool INL, bool TRACE = false>
 __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                   const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                                   double* __restrict__ partials) {
-  static_assert(PPT == 2 || PPT == 4, "512- and 1024-point tiles");
+  static_assert(PPT == 1 || PPT == 2 || PPT == 4, "256-, 512- and 1024-point tiles");
   static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "rigid linearise and error evaluation");
   constexpr int NACC = MODE == MODE_ERR ? 2 : 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * kWaveLdsBytes];  // 34 KB
@@ -386,13 +387,14 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
       if (PPT > 1) dma_pts(1);  // in flight: H0, C0 x3, P1
 #pragma unroll
       for (int j = 0; j < PPT; j++) {
-        if (j == 0) vm_wait_blk<4>(P[0].blk);            // [H0, C0 x3, P1]
+        if (j == 0 && PPT > 1) vm_wait_blk<4>(P[0].blk);    // [H0, C0 x3, P1]
+        else if (j == 0) vm_wait_blk<3>(P[0].blk);            // [H0, C0 x3] (one chunk per wave)
         else if (j + 1 < PPT) vm_wait_blk<4>(P[j & 1].blk);  // [H(j), chunk j+1 x4]
         else vm_wait_blk<0>(P[j & 1].blk);
         if (j == 0) GP_TRACE(2);
         if (j == 1) GP_TRACE(4);
         const bool hit = back_issue(P[j & 1], head, c01, c23, c45);
-        if (j == 0) {
+        if (j == 0 && PPT > 1) {
           dma_cov(1);                           // [C0 x3, P1, R0 x4, C1 x3]
           vm_wait_rec<3>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the points of chunk 1
         } else {
