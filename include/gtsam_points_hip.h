@@ -340,6 +340,10 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
                           double max_correspondence_distance_sq, gp_stream_t stream, gp_gicp_factor_t** out);
 int gp_gicp_factor_destroy(gp_gicp_factor_t* f);
 int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host);           /* update_correspondences + evaluate */
+/* evaluate(delta_eval) on the correspondences and Mahalanobis matrices of pose_lin.  The correspondences of the last linearise (or error
+ * evaluation) are kept on the device: when pose_lin is bit for bit the pose they were computed at they are re-used -- the reference's
+ * error() likewise evaluates on the stored correspondences (impl/integrated_gicp_factor_impl.hpp:183-185) -- otherwise the search runs
+ * again at pose_lin.  gp_gicp_factor_linearize always searches, as update_correspondences does with its default (zero) tolerances. */
 int gp_gicp_factor_compute_error(gp_gicp_factor_t* f, const double pose_lin[16], const double pose_eval[16], double* out_host);
 
 /* ---- the step after the path: damped normal equations assembled and solved on the device ----
@@ -392,9 +396,15 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
 /* kernel selection (not part of the reference API): 0 = reference-shaped kernel (reference bucket table, 92 explicit sums: also
  * the path of non-orthonormal poses and the in-library cross-check), 1 / 2 = pipeline kernel over the hashed line table in f64 /
  * with f32 outer products, 3 / 4 = pipeline kernel over the occupancy-block grid in f64 / with f32 outer products, 5 / 6 / 7 = A/B
- * forms of 4 (no lean start; 512- / 256-point tiles), 8 = 4 with the look-ahead lookup (bit-identical results).  Default 8:
+ * forms of 4 (no lean start; 512- / 256-point tiles), 8 = 4 with the look-ahead lookup (bit-identical results), 9 / 10 / 11 = the
+ * second-generation kernel (csrc/gp_vgicp_tile2.hpp) with the default / the non-temporal / the per-batch policy on the source
+ * stream; maps without a block grid and factors with surface validation run as 8 under 9-11.  Default 11:
  * M = (C_B + R C_A R^T)^-1, the transform and the residual are f64 in every variant; "f32 outer products" computes what follows
- * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md section 8 */
+ * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md sections 4.1, 8.
+ * Environment switches read once at first use (A/B only): GP_POSES_ZERO_COPY=0 (synchronous batched calls upload poses with
+ * hipMemcpyAsync instead of letting the kernels read the pinned staging buffer), GP_FINALIZE_PARTS=n (workgroups sharing the finalize
+ * of a synchronous single-factor call, default 8), GP_GICP_SPLIT=0 (GICP factor: fused search + algebra kernel instead of the
+ * correspondence kernel + algebra kernel). */
 int gp_debug_set_variant(int variant);
 /* workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles are
  * dealt to the XCDs round robin */
