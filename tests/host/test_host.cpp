@@ -120,6 +120,42 @@ int main() {
   source->add_covs_gpu(sc);
   CHECK(target->has_points_gpu() && target->check_covs_gpu());  // the reference's own PointCloud members (types/point_cloud.cpp)
 
+  {
+    // PointCloudGPU's CPU + GPU forms, clone() and download_points() (types/point_cloud_gpu.hpp:41-129, test_types.cpp's frame checks)
+    PointCloudGPU both(sp);  // constructor = add_points: CPU storage (Vector4d, w = 1) and GPU storage
+    CHECK(both.has_points() && both.has_points_gpu() && both.size() == sp.size());
+    CHECK(both.points[7](0) == (double)sp[7](0) && both.points[7](2) == (double)sp[7](2) && both.points[7](3) == 1.0);
+    both.add_covs(sc);
+    CHECK(both.has_covs() && both.has_covs_gpu() && both.covs[5](1, 2) == (double)sc[5](1, 2) && both.covs[5](3, 3) == 0.0);
+    std::vector<double> stamps(sp.size());
+    for (size_t i = 0; i < stamps.size(); i++) stamps[i] = 1e-4 * (double)i;
+    both.add_times(stamps);
+    CHECK(both.has_times() && both.has_times_gpu() && both.times[10] == stamps[10]);
+    std::vector<float> t_back(sp.size());
+    CHECK(gp_memcpy_d2h(t_back.data(), both.times_gpu, sizeof(float) * t_back.size(), nullptr) == GP_OK && gp_stream_synchronize(nullptr) == GP_OK);
+    CHECK(t_back[10] == (float)stamps[10] && t_back.back() == (float)stamps.back());
+    auto copy = PointCloudGPU::clone(both);
+    CHECK(copy->size() == both.size() && copy->has_points() && copy->has_points_gpu() && copy->has_covs_gpu() && copy->has_times_gpu());
+    CHECK(copy->points_gpu != both.points_gpu && copy->points != both.points);  // deep copy
+    const auto p0 = download_points_gpu(both), p1 = download_points_gpu(*copy);
+    const auto c0 = download_covs_gpu(both), c1 = download_covs_gpu(*copy);
+    bool same = p0.size() == p1.size() && c0.size() == c1.size();
+    for (size_t i = 0; same && i < p0.size(); i += 97) same = p0[i](0) == p1[i](0) && p0[i](2) == p1[i](2) && c0[i](2, 1) == c1[i](2, 1);
+    CHECK(same);
+    // a frame that lives on the device only (no host attributes): clone() copies device to device, download_points() fills the CPU side
+    auto dev_only = std::make_shared<PointCloudGPU>();
+    dev_only->add_points_gpu(sp);
+    dev_only->add_covs_gpu(sc);
+    CHECK(!dev_only->has_points() && dev_only->has_points_gpu());
+    auto copy2 = PointCloudGPU::clone(*dev_only);
+    CHECK(copy2->has_points_gpu() && copy2->has_covs_gpu() && copy2->points_gpu != dev_only->points_gpu);
+    const auto p2 = download_points_gpu(*copy2);
+    CHECK(p2.size() == sp.size() && p2[123](1) == sp[123](1));
+    copy2->download_points();
+    CHECK(copy2->has_points() && copy2->points[123](1) == (double)sp[123](1) && copy2->points[123](3) == 1.0);
+    CHECK(copy2->offload_gpu() && !copy2->loaded_on_gpu() && copy2->reload_gpu() && copy2->has_covs_gpu());  // offload / reload of a cloned frame
+  }
+
   auto voxels = std::make_shared<GaussianVoxelMapGPU>(0.5f);
   voxels->insert(*target);
   CHECK(voxels->voxelmap_info.num_voxels > 100 && voxels->buckets != nullptr && voxels->loaded_on_gpu());
