@@ -51,7 +51,7 @@ class PointCloudGPU(OffloadableGPU):
     intensities_gpu float[N].  Like the reference class (a PointCloudCPU with device mirrors) it keeps the host arrays it was
     given, so that offload_gpu() / reload_gpu() (types/point_cloud_gpu.cu:304-370) can drop and restore the device side."""
 
-    _ATTRS = ("points", "covs", "normals", "intensities")
+    _ATTRS = ("points", "covs", "normals", "intensities", "times")
 
     def __init__(self, points=None, covs=None, normals=None, intensities=None, device="cuda:0"):
         import torch
@@ -62,6 +62,7 @@ class PointCloudGPU(OffloadableGPU):
         self.covs_gpu = None
         self.normals_gpu = None
         self.intensities_gpu = None
+        self.times_gpu = None
         self.num_points = 0
         self._host = {}       # attribute -> the host array as given (None for device-only attributes)
         self.generation = 0   # bumped whenever the device arrays are re-allocated (factors re-read the pointers)
@@ -161,12 +162,33 @@ class PointCloudGPU(OffloadableGPU):
             self._host["intensities"] = np.asarray(intensities)
         self.generation += 1
 
+    def add_times(self, times):  # add_times_gpu, types/point_cloud_gpu.cu:88-105: float timestamps on the device
+        self.times_gpu = self._upload(times if self._is_tensor(times) else np.asarray(times).reshape(-1, 1), 1)
+        if not self._is_tensor(times):
+            self._host["times"] = np.asarray(times)
+        self.generation += 1
+
+    @staticmethod
+    def clone(frame):
+        """PointCloudGPU::clone (types/point_cloud_gpu.cu:26-62): a deep copy.  Host attributes are uploaded again; attributes the
+        source holds on the device only are copied device to device (the reference leaves those out: its TODO at :29)."""
+        out = PointCloudGPU(device=str(frame.device))
+        adders = {"points": out.add_points, "covs": out.add_covs, "normals": out.add_normals, "intensities": out.add_intensities, "times": out.add_times}
+        for a in PointCloudGPU._ATTRS:
+            if frame._host.get(a) is not None:
+                adders[a](np.array(frame._host[a], copy=True))
+            elif getattr(frame, a + "_gpu") is not None:
+                setattr(out, a + "_gpu", getattr(frame, a + "_gpu").clone())
+                out.generation += 1
+        out.num_points = frame.num_points
+        return out
+
     # ---- OffloadableGPU (types/point_cloud_gpu.cu:281-370) ----
     def loaded_on_gpu(self):
         return any(getattr(self, a + "_gpu") is not None for a in self._ATTRS)
 
     def memory_usage_gpu(self):
-        width = {"points": 12, "covs": 36, "normals": 12, "intensities": 4}
+        width = {"points": 12, "covs": 36, "normals": 12, "intensities": 4, "times": 4}
         return sum(width[a] * self.num_points for a in self._ATTRS if getattr(self, a + "_gpu") is not None)
 
     def download(self, attr):
@@ -175,7 +197,7 @@ class PointCloudGPU(OffloadableGPU):
         if t is None:
             raise _capi.GPError(f"error: frame does not have {attr} on GPU!!")
         a = t.cpu().numpy()
-        return a.reshape(-1, 3, 3).transpose(0, 2, 1).copy() if attr == "covs" else (a.reshape(-1) if attr == "intensities" else a)
+        return a.reshape(-1, 3, 3).transpose(0, 2, 1).copy() if attr == "covs" else (a.reshape(-1) if attr in ("intensities", "times") else a)
 
     def offload_gpu(self, stream=None):
         """frees the device arrays (:304-336); returns False when there was nothing to offload.  An attribute that only ever
@@ -195,7 +217,7 @@ class PointCloudGPU(OffloadableGPU):
         if self.loaded_on_gpu():
             return False
         host, self._host = self._host, {}
-        adders = {"points": self.add_points, "covs": self.add_covs, "normals": self.add_normals, "intensities": self.add_intensities}
+        adders = {"points": self.add_points, "covs": self.add_covs, "normals": self.add_normals, "intensities": self.add_intensities, "times": self.add_times}
         reloaded = False
         for a in self._ATTRS:
             if host.get(a) is not None:

@@ -106,3 +106,24 @@ def test_upload_pack_kernels_are_exact(gpu):
     assert empty.size() == 0
     with pytest.raises(ValueError):
         gpu.PointCloudGPU(np.zeros((4, 5)))
+
+
+def test_clone_and_times(gpu, kitti00):
+    """PointCloudGPU::clone (types/point_cloud_gpu.cu:26-62) and add_times_gpu (:88-105): a deep copy with every attribute, also of a
+    frame that lives on the device only; offload / reload keep working on the copy"""
+    p, c = kitti00["source_points"], kitti00["source_covs"]
+    t = np.linspace(0.0, 0.1, len(p))
+    a = gpu.PointCloudGPU(p, c)
+    a.add_times(t)
+    assert a.memory_usage_gpu() == (12 + 36 + 4) * len(p)
+    b = gpu.PointCloudGPU.clone(a)
+    assert b.size() == a.size() and b.points_gpu.data_ptr() != a.points_gpu.data_ptr()
+    for attr in ("points", "covs", "times"):
+        np.testing.assert_array_equal(b.download(attr), a.download(attr))
+    np.testing.assert_array_equal(b.download("times"), t.astype(np.float32))
+    dev = gpu.PointCloudGPU.from_device(a.points_gpu, a.covs_gpu)
+    d = gpu.PointCloudGPU.clone(dev)
+    assert d.points_gpu.data_ptr() != a.points_gpu.data_ptr()
+    np.testing.assert_array_equal(d.download("covs"), a.download("covs"))
+    assert d.offload_gpu() and not d.loaded_on_gpu() and d.reload_gpu()
+    np.testing.assert_array_equal(d.download("points"), a.download("points"))
