@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) overlap_jobs_kernel(const OverlapJob* __r
       const double qx = T.r00 * px + T.r01 * py + T.r02 * pz + T.tx;
       const double qy = T.r10 * px + T.r11 * py + T.r12 * pz + T.ty;
       const double qz = T.r20 * px + T.r21 * py + T.r22 * pz + T.tz;
-      hit = lookup_voxel(t.map, fast_floor(qx * t.map.inv_leaf), fast_floor(qy * t.map.inv_leaf), fast_floor(qz * t.map.inv_leaf)) >= 0;
+      hit = finite3(qx, qy, qz) && lookup_voxel(t.map, fast_floor(qx * t.map.inv_leaf), fast_floor(qy * t.map.inv_leaf), fast_floor(qz * t.map.inv_leaf)) >= 0;
     }
   }
   const unsigned long long hits = __ballot(hit);

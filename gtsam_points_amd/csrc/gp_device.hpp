@@ -126,6 +126,18 @@ __host__ __device__ __forceinline__ uint32_t coord_hash32(int x, int y, int z) {
 
 // fast_floor in DOUBLE, util/fast_floor.hpp:12-15 (the CPU map's rule; the reference GPU map floors
 // float(x)/float(res), vector3_hash.cuh:41-50, which flips ~5e-5 of points across voxel faces)
+// LiDAR clouds carry NaN / inf returns.  A non-finite coordinate has no voxel (the reference floors it into an undefined integer that no
+// table holds); on the device the float -> int conversion of a NaN is 0, i.e. voxel (0, 0, 0), which may well exist: every lookup of a
+// transformed point is guarded with one of these, so that such a point contributes nothing (no correspondence, not an inlier, no overlap)
+__host__ __device__ __forceinline__ bool finite3(float x, float y, float z) {
+  const float s = (x + y) + z;  // NaN if any of them is NaN or two infinities cancel, +-inf if one is infinite
+  return s - s == 0.0f;
+}
+__host__ __device__ __forceinline__ bool finite3(double x, double y, double z) {
+  const double s = (x + y) + z;
+  return s - s == 0.0;
+}
+
 __host__ __device__ __forceinline__ int fast_floor(double x) {
   const int n = (int)x;
   return n - (x < (double)n);

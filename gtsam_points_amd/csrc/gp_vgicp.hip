@@ -39,6 +39,7 @@ template <int MODE>
 __device__ __forceinline__ void accumulate_point(const FactorDesc& f, const Pose& Tl, const Pose& Te, int i, double* acc) {
   const float* __restrict__ pp = f.points + 3 * (size_t)i;
   const double px = (double)pp[0], py = (double)pp[1], pz = (double)pp[2];
+  if (!finite3(px, py, pz)) return;  // a NaN / inf return has no voxel
   // correspondence at the LINEARISATION pose (lookup kernel is built with d_xl, integrated_vgicp_derivatives_compute.cu:25)
   const double lx = Tl.r00 * px + Tl.r01 * py + Tl.r02 * pz + Tl.tx;
   const double ly = Tl.r10 * px + Tl.r11 * py + Tl.r12 * pz + Tl.ty;

@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
       ez = (rq_t)(f.map.leaf * ((fz + 0.5) - uz));
     }
     const rq_t qx = (rq_t)lx, qy = (rq_t)ly, qz = (rq_t)lz;
-    bool live = active;
+    bool live = active && finite3(px, py, pz);
     if (f.surface_validation && live && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + (size_t)j * kChunkPoints + lane))) live = false;
     int idx = -1;
     if constexpr (GRID) {
@@ -491,8 +491,8 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
     P.qx = (float)lx;
     P.qy = (float)ly;
     P.qz = (float)lz;
-    bool live = true;
-    if (f.surface_validation && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + (size_t)j * kChunkPoints + lane))) live = false;
+    bool live = finite3(lp[3 * lane], lp[3 * lane + 1], lp[3 * lane + 2]);
+    if (f.surface_validation && live && surface_rejected(Tl, lx, ly, lz, f.normals + 3 * (first + (size_t)j * kChunkPoints + lane))) live = false;
     const int bx = (cx >> 2) - f.map.glo[0], by = (cy >> 2) - f.map.glo[1], bz = (cz >> 2) - f.map.glo[2];
     const bool inbox = (unsigned)bx < (unsigned)f.map.gdim[0] && (unsigned)by < (unsigned)f.map.gdim[1] && (unsigned)bz < (unsigned)f.map.gdim[2];
     const unsigned lin = inbox ? ((unsigned)bz * (unsigned)f.map.gdim[1] + (unsigned)by) * (unsigned)f.map.gdim[0] + (unsigned)bx : 0u;

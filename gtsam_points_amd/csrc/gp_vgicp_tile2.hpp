@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
       P.qy = (float)ly;
       P.qz = (float)lz;
     }
-    const bool live = active;  // (factors with surface validation stay on the round-2 kernel: its normals read is a compiler-tracked load)
+    const bool live = active && finite3(pxf, pyf, pzf);  // (factors with surface validation stay on the round-2 kernel: its normals read is a compiler-tracked load)
     const unsigned bx = (unsigned)((cx >> 2) - glo0), by = (unsigned)((cy >> 2) - glo1), bz = (unsigned)((cz >> 2) - glo2);
     const bool inbox = (bx < gd0) & (by < gd1) & (bz < gd2);
     const unsigned lin = inbox ? mad24(mad24(bz, gd1, by), gd0, bx) : 0u;  // < 2^24 blocks

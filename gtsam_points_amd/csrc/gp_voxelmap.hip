@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(256) lookup_kernel(const float* __restrict__ p
     const double qx = T.r00 * px + T.r01 * py + T.r02 * pz + T.tx;
     const double qy = T.r10 * px + T.r11 * py + T.r12 * pz + T.ty;
     const double qz = T.r20 * px + T.r21 * py + T.r22 * pz + T.tz;
-    bool rejected = false;
-    if (normals) rejected = surface_rejected(T, qx, qy, qz, normals + 3 * (size_t)i);
+    bool rejected = !finite3(qx, qy, qz);  // a NaN / inf return lies in no voxel
+    if (normals && !rejected) rejected = surface_rejected(T, qx, qy, qz, normals + 3 * (size_t)i);
     if (!rejected) v = lookup_voxel(map, fast_floor(qx * map.inv_leaf), fast_floor(qy * map.inv_leaf), fast_floor(qz * map.inv_leaf));
     if (out) out[i] = v;
   }

@@ -229,7 +229,8 @@ typedef struct gp_vgicp_factor gp_vgicp_factor_t;
 
 /* IntegratedVGICPDerivatives(target, source, stream, temp_buffer), integrated_vgicp_derivatives.cu:19-47.
  * Borrows the map handle and the three device arrays (normals_dev may be NULL).  stream==NULL -> the factor
- * creates and owns a non-blocking stream (:36-39); temp_buffer==NULL -> it owns its scratch (:41-43). */
+ * creates and owns a non-blocking stream (:36-39); temp_buffer==NULL -> it owns its scratch (:41-43).
+ * Source points with a NaN / inf coordinate have no correspondence (they count neither as inliers nor towards H, b, the error). */
 int gp_vgicp_factor_create(const gp_voxelmap_t* target, const float* points_dev, const float* covs_dev, const float* normals_dev, int num_points, gp_stream_t stream, gp_temp_buffer_t* temp_buffer, gp_vgicp_factor_t** out);
 int gp_vgicp_factor_destroy(gp_vgicp_factor_t* f);
 int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable); /* set_enable_surface_validation */

@@ -477,6 +477,54 @@ def test_second_generation_kernel_at_size(gpu, variant, n_src):
     assert abs(e_lin.value - L.error) <= 1e-7 * abs(L.error)  # evaluated at the linearisation pose it is the linearise's own error
 
 
+@pytest.mark.parametrize("variant", [0, 4, 8, 11])
+def test_non_finite_source_points_are_skipped(gpu, kitti00, variant):
+    """LiDAR clouds carry NaN / inf returns.  A non-finite source point has no voxel: the reference floors it into an undefined integer
+    coordinate that no table holds; on the device the conversion of a NaN is 0, i.e. voxel (0, 0, 0) -- which this map contains -- so
+    the kernels guard the lookup.  Linearise, error evaluation and the overlap count must equal those of the cloud without them."""
+    p, c = kitti00["source_points"].copy(), kitti00["source_covs"].copy()
+    rng = np.random.default_rng(3)
+    # (the sensor's own position is empty in a scan: give the target map a voxel (0, 0, 0) for the NaNs to fall into)
+    tp = np.concatenate([kitti00["target_points"], rng.uniform(0.05, 0.45, (24, 3)).astype(np.float32)])
+    tc = np.concatenate([kitti00["target_covs"], np.tile(np.eye(3, dtype=np.float32) * 0.01, (24, 1, 1)).reshape(24, *kitti00["target_covs"].shape[1:])])
+    assert np.any(np.all(np.floor(tp / 0.5) == 0, axis=1))
+    bad = np.array([5, 64, 700, 1023, 1024, 4099, len(p) - 1])
+    p[bad[0]] = np.nan
+    p[bad[1], 0] = np.inf
+    p[bad[2], 2] = -np.inf
+    p[bad[3], 1] = np.nan
+    p[bad[4]] = [np.inf, -np.inf, np.nan]
+    p[bad[5], 0] = np.nan
+    p[bad[6], 2] = np.nan
+    keep = np.ones(len(p), bool)
+    keep[bad] = False
+    lib = gpu.load()
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
+    tgt = gpu.PointCloudGPU(tp, tc)
+    vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+    vm.insert(tgt)
+    try:
+        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
+        out = {}
+        for name, (pp, cc) in dict(dirty=(p, c), clean=(p[keep], c[keep])).items():
+            src = gpu.PointCloudGPU(pp, cc)
+            f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+            L = _sync_linearize(gpu, f, delta)
+            err = C.c_double()
+            gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+            out[name] = (L, err.value, gpu.overlap_gpu(vm, src, delta))
+    finally:
+        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    (Ld, ed, od), (Lc, ec, oc) = out["dirty"], out["clean"]
+    assert Ld.num_inliers == Lc.num_inliers
+    for k in BLOCKS:
+        assert np.all(np.isfinite(getattr(Ld, k)))
+        assert rel_err(getattr(Ld, k), getattr(Lc, k)) < 1e-7, k  # (the points sit in different lanes / tiles: regrouped f32 sums)
+    assert np.isfinite(ed) and abs(ed - ec) <= 1e-7 * abs(ec)
+    assert abs(od * len(p) - oc * keep.sum()) < 0.5  # the same number of points falls into a voxel
+
+
 def test_alignment_gate_gpu(gpu, kitti07):
     """the reference's VGICP_CUDA end-to-end gate (test_matching_cost_factors.cpp:196-230): LM through the
     linearisation hook, rot < 0.015 rad, trans < 0.15 m"""
