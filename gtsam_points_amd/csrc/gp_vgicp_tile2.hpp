@@ -1,4 +1,7 @@
-// gp_vgicp_tile2.hpp -- second generation of the rigid-pose linearise kernel (block-grid maps, f32 outer products).
+// gp_vgicp_tile2.hpp -- second generation of the rigid-pose tile kernel: linearise and error evaluation over block-grid maps, f32 outer
+// products, 1024- / 512- / 256-point tiles (the default kernel since late round 2; replaces vgicp_derivatives_kernel / vgicp_error_kernel of
+// include/gtsam_points/cuda/kernels/vgicp_derivatives.cuh:15-139 together with lookup_voxels.cuh:19-97 and the CUB reduction of
+// src/gtsam_points/factors/integrated_vgicp_derivatives_{linearize,compute}.cu).
 //
 // Same pipeline idea as vgicp_pipeline_kernel (gp_vgicp_tile.hpp): LDS-DMA source ring, two-hop lookup with hand-placed waits,
 // 29 sums, f32 transposition + f64 reduction.  What changed, and why (ISA of the round-2 default kernel, DESIGN.md section 8:
@@ -28,8 +31,6 @@
 
 namespace gp {
 
-constexpr int kChunkDmaOps2 = 4;  // 4 x 64 lanes x 12 B
-
 // a wave-uniform pointer the compiler may have left in vector registers (a descriptor field selected between the kernel arguments
 // and a table in memory): pin it to an SGPR pair so that the saddr addressing forms can take it
 template <typename T>
@@ -50,7 +51,7 @@ __device__ __forceinline__ double uniform_f64(double x) {
 //   points       64 slots: slot p = point p                       -> one ds_read_b96 per lane, conflict-free
 //   covariances  3 x 64 slots: slot q = 12-B piece q of the 2304 contiguous bytes, point p = slots 3p, 3p+1, 3p+2 (its three
 //                columns) -> three ds_read_b96 at a 48-B lane stride (12 dwords: conflict-free within the 8-lane groups of a b96 read)
-// A wave's ring: 2 point slots-arrays (1 KB each) + 2 covariance arrays (3 KB each) = 8 KB; the reduction needs 8.5 KB.
+// A wave's ring: 2 point arrays (1 KB each) + 2 covariance arrays (3 KB each) = 8 KB; the reduction needs 8.5 KB.
 constexpr int kPtsSlotBytes = 1024, kCovSlotBytes = 3072, kWaveLdsBytes = 8704;
 static_assert(2 * kPtsSlotBytes + 2 * kCovSlotBytes <= kWaveLdsBytes, "ring must fit the wave's LDS region");
 
