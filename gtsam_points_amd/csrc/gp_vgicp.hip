@@ -309,10 +309,14 @@ __device__ __forceinline__ double pick9(int i, double a0, double a1, double a2, 
 // nothing: sixteen waves meeting at four barriers, 6x6 tables indexed at run time (= scratch memory round trips) and a pose fetched
 // when it was needed.  Here all sixteen waves load and tree-add their rows, the two slices of a wave meet through one cross-lane
 // add, ONE barrier, and wave 0 alone does the rest out of LDS with wave-level synchronisation; the pose is requested first of all.
-__global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
-                                                                                const InlinePoses inl, const double* __restrict__ partials,
-                                                                                gp_linearized6* __restrict__ out, const DoneFlags done, const int parts) {
-  static_assert(ACC_STRIDE == 32 && kFinalizeThreads == 1024, "lane = (slice parity, component); 16 waves x 2 slices");
+// THREADS: 1024 (one workgroup sums all the tiles of a factor) or 256 (the split form: an eighth of a large factor's tiles per workgroup --
+// four waves meet at the barrier instead of sixteen, each lane requests 16 rows instead of 4, all of them in flight together)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ poses,
+                                                                       const InlinePoses inl, const double* __restrict__ partials,
+                                                                       gp_linearized6* __restrict__ out, const DoneFlags done, const int parts) {
+  static_assert(ACC_STRIDE == 32 && (THREADS == 1024 || THREADS == 256), "lane = (slice parity, component); two slices per wave");
+  constexpr int kSlices = THREADS / 32, kWaves = THREADS / 64;
   // parts > 1 (synchronous single-factor calls with many tiles): every record entry is LINEAR in the 29 sums, so `parts` workgroups
   // each expand their share of the tiles into a complete record of their own (slot fi * parts + part, own completion word) and the
   // host adds the records in slot order -- the 250 KB of partials of a 1 M-point factor then go through `parts` compute units'
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(
     tile_begin += lo;
     tile_count = hi - lo;
   }
-  __shared__ double wsum[16][32];
+  __shared__ double wsum[kWaves][32];
   __shared__ double sum[32];
   __shared__ double Rl[9], Xl[9];  // R and [t]x, row-major
   __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
@@ -340,11 +344,11 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(
     // fixed summation order (deterministic).  All of a lane's rows are requested in ONE batch of up to 32 independent loads
     const double* base = partials + (size_t)tile_begin * ACC_STRIDE + comp;
     double total = 0.0;
-    for (int t0 = slice; t0 < tile_count; t0 += 32 * 32) {
+    for (int t0 = slice; t0 < tile_count; t0 += 32 * kSlices) {
       double v[32];
 #pragma unroll
       for (int k = 0; k < 32; k++) {
-        const int t = t0 + k * 32;
+        const int t = t0 + k * kSlices;
         v[k] = t < tile_count ? base[(size_t)t * ACC_STRIDE] : 0.0;
       }
 #pragma unroll
@@ -361,11 +365,11 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_rigid_kernel(
   __syncthreads();
   if (wave != 0) return;  // (a finished wave no longer takes part in barriers; none follow anyway)
   if (lane < 32) {
-    double v[16];
+    double v[kWaves];
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = wsum[k][lane];
+    for (int k = 0; k < kWaves; k++) v[k] = wsum[k][lane];
 #pragma unroll
-    for (int w = 8; w > 0; w >>= 1) {
+    for (int w = kWaves / 2; w > 0; w >>= 1) {
 #pragma unroll
       for (int k = 0; k < w; k++) v[k] += v[k + w];
     }
@@ -505,7 +509,7 @@ int launch_finalize_single(hipStream_t stream, const double* pose_dev, const dou
   if (general)
     hipLaunchKernelGGL(vgicp_finalize_kernel<true>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done);
   else
-    hipLaunchKernelGGL(vgicp_finalize_rigid_kernel, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done, 1);
+    hipLaunchKernelGGL(vgicp_finalize_rigid_kernel<kFinalizeThreads>, dim3(1), dim3(kFinalizeThreads), 0, stream, (const FactorDesc*)nullptr, pose_dev, inl, partials, out_dev, done, 1);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GP_OK : hip_fail(e, "vgicp_finalize_kernel", __FILE__, __LINE__);
 }
@@ -853,12 +857,18 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
 
 template <bool GENERAL>
 int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* partials, gp_linearized6* out_dev, gp::DoneFlags done = {}, int parts = 1) {
-  if constexpr (GENERAL)
+  if constexpr (GENERAL) {
     hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
                        ps.d_lin, ps.inl, partials, out_dev, done);
-  else
-    hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel, dim3((int)b->factors.size() * parts), dim3(gp::kFinalizeThreads), 0, b->stream,
-                       b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev, done, parts);
+  } else {
+    static const bool narrow = [] { const char* e = getenv("GP_FINALIZE_NARROW"); return !e || atoi(e) != 0; }();  // A/B: 0 = 1024-thread parts
+    if (parts > 1 && narrow)
+      hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<256>, dim3((int)b->factors.size() * parts), dim3(256), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), ps.d_lin,
+                         ps.inl, partials, out_dev, done, parts);
+    else
+      hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<gp::kFinalizeThreads>, dim3((int)b->factors.size() * parts), dim3(gp::kFinalizeThreads), 0, b->stream,
+                         b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev, done, parts);
+  }
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
