@@ -321,12 +321,16 @@ __global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const Fac
   // each expand their share of the tiles into a complete record of their own (slot fi * parts + part, own completion word) and the
   // host adds the records in slot order -- the 250 KB of partials of a 1 M-point factor then go through `parts` compute units'
   // L1s instead of one (that was 4.9 of the kernel's 7.1 us)
-  const int fi = blockIdx.x / parts, part = blockIdx.x - fi * parts;
+  // parts < 0: |parts| parts, and a part delivers its 32 SUMS instead of a record: the host adds the parts' sums and expands them
+  // (expand_rigid_host) -- the expansion is the same for every part, so it runs once, off the device's critical path
+  const bool sums_only = parts < 0;
+  const int nparts = sums_only ? -parts : parts;
+  const int fi = blockIdx.x / nparts, part = blockIdx.x - fi * nparts;
   const Pose T = inl.use ? load_pose(inl.lin) : load_pose(poses + 16 * (size_t)fi);  // in flight while the partials arrive
   int tile_begin = inl.use ? inl.factor.tile_begin : factors[fi].tile_begin;
   int tile_count = inl.use ? inl.factor.tile_count : factors[fi].tile_count;
-  if (parts > 1) {
-    const int per = (tile_count + parts - 1) / parts;
+  if (nparts > 1) {
+    const int per = (tile_count + nparts - 1) / nparts;
     const int lo = min(part * per, tile_count), hi = min(lo + per, tile_count);
     tile_begin += lo;
     tile_count = hi - lo;
@@ -381,6 +385,19 @@ __global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const Fac
   }
   GP_WAVE_SYNC();
   GP_FIN_TRACE(2);
+  if (sums_only) {
+    double* out_rec = reinterpret_cast<double*>(out + blockIdx.x);
+    if (lane < 32) out_rec[lane] = sum[lane];
+    GP_FIN_TRACE(3);
+    if (done.flags) {
+      GP_FIN_TRACE(4);
+      __threadfence_system();
+      GP_FIN_TRACE(5);
+      if (lane == 0) __hip_atomic_store(done.flags + blockIdx.x, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      GP_FIN_TRACE(6);
+    }
+    return;
+  }
   const int t = lane;
   const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
   constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
@@ -862,11 +879,12 @@ int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* parti
                        ps.d_lin, ps.inl, partials, out_dev, done);
   } else {
     static const bool narrow = [] { const char* e = getenv("GP_FINALIZE_NARROW"); return !e || atoi(e) != 0; }();  // A/B: 0 = 1024-thread parts
-    if (parts > 1 && narrow)
-      hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<256>, dim3((int)b->factors.size() * parts), dim3(256), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), ps.d_lin,
+    const int nparts = parts < 0 ? -parts : parts;  // (parts < 0: the parts deliver their sums, the host expands)
+    if (nparts > 1 && narrow)
+      hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<256>, dim3((int)b->factors.size() * nparts), dim3(256), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), ps.d_lin,
                          ps.inl, partials, out_dev, done, parts);
     else
-      hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<gp::kFinalizeThreads>, dim3((int)b->factors.size() * parts), dim3(gp::kFinalizeThreads), 0, b->stream,
+      hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<gp::kFinalizeThreads>, dim3((int)b->factors.size() * nparts), dim3(gp::kFinalizeThreads), 0, b->stream,
                          b->d_factors.as<gp::FactorDesc>(), ps.d_lin, ps.inl, partials, out_dev, done, parts);
   }
   GP_HIP(hipGetLastError());
@@ -1226,6 +1244,60 @@ int gp_vgicp_batch_sync(gp_vgicp_batch_t* b) {
   return GP_OK;
 }
 
+// the 6x6 expansion of the rigid finalize kernel on the host (same formulas: H_t from the 29 sums, Ad(delta), H_ts = -H_t Ad, H_s = Ad^T H_t Ad,
+// b_s = -Ad^T b_t): used by the synchronous single-factor call, whose finalize parts then deliver only their sums
+static void expand_rigid_host(const double* sum, const double* pose /*col-major 4x4*/, double* dst /*[122]*/) {
+  constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
+  const double Rl[9] = {pose[0], pose[4], pose[8], pose[1], pose[5], pose[9], pose[2], pose[6], pose[10]};  // row-major R
+  const double tx = pose[12], ty = pose[13], tz = pose[14];
+  const double Xl[9] = {0.0, -tz, ty, tz, 0.0, -tx, -ty, tx, 0.0};  // [t]x, row-major
+  auto sym3 = [](int a, int b) {
+    const int i = a < b ? a : b, j = a < b ? b : a;
+    return (i * (5 - i)) / 2 + j;
+  };
+  double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      double h;
+      if (r < 3 && c < 3) h = sum[gp::ACC_TL + sym3(r, c)];
+      else if (r >= 3 && c < 3) h = -sum[gp::ACC_K + (r - 3) * 3 + c];
+      else if (r < 3) h = -sum[gp::ACC_K + (c - 3) * 3 + r];
+      else h = sum[gp::ACC_M + sym3(r - 3, c - 3)];
+      Ht[r][c] = h;
+      dst[OFF_HT + c * 6 + r] = h;
+      double a;
+      if (r < 3 && c < 3) a = Rl[r * 3 + c];
+      else if (r < 3) a = 0.0;
+      else if (c >= 3) a = Rl[(r - 3) * 3 + (c - 3)];
+      else a = Xl[(r - 3) * 3] * Rl[c] + Xl[(r - 3) * 3 + 1] * Rl[3 + c] + Xl[(r - 3) * 3 + 2] * Rl[6 + c];
+      Ad[r][c] = a;
+    }
+  for (int k = 0; k < 6; k++) {
+    bt[k] = k < 3 ? sum[gp::ACC_QXMR + k] : sum[gp::ACC_MR + k - 3];
+    dst[OFF_BT + k] = bt[k];
+  }
+  dst[0] = sum[gp::ACC_COUNT];
+  dst[1] = sum[gp::ACC_ERR];
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      double a = 0.0;
+      for (int k = 0; k < 6; k++) a += Ht[r][k] * Ad[k][c];
+      HtA[r][c] = a;
+      dst[OFF_HTS + c * 6 + r] = -a;
+    }
+  for (int k6 = 0; k6 < 6; k6++) {
+    double a = 0.0;
+    for (int k = 0; k < 6; k++) a += Ad[k][k6] * bt[k];
+    dst[OFF_BS + k6] = -a;
+  }
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      double a = 0.0;
+      for (int k = 0; k < 6; k++) a += Ad[k][r] * HtA[k][c];
+      dst[OFF_HS + c * 6 + r] = a;
+    }
+}
+
 // synchronous: the finalize kernel stores the records straight into host-mapped pinned memory (no D2H copy op)
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host) {
   if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
@@ -1237,19 +1309,32 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, g_trace_host ? g_trace_host + 2047 * 16 : nullptr};
   const bool rigid = poses_are_rigid(poses_host, F);
   const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
-  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, parts));
+  static const bool host_expand = [] { const char* e = getenv("GP_FINALIZE_HOST_EXPAND"); return !e || atoi(e) != 0; }();  // A/B: 0 = the parts expand
+  const bool sums_only = parts > 1 && host_expand;
+  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts));
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
   if (parts == 1) {
     memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
   } else {
-    // the partial records add up entry by entry (all 122 scalars are linear in the tile sums), in slot order
     const double* p = static_cast<const double*>(b->h_out.ptr);
     double* o = reinterpret_cast<double*>(out_host);
     constexpr int N = (int)(sizeof(gp_linearized6) / sizeof(double));
-    for (int k = 0; k < N; k++) {
-      double a = p[k];
-      for (int q = 1; q < parts; q++) a += p[(size_t)q * N + k];
-      o[k] = a;
+    if (sums_only) {
+      // the parts' 32 sums add up in slot order; one expansion on the host
+      double total[32];
+      for (int k = 0; k < 32; k++) {
+        double a = p[k];
+        for (int q = 1; q < parts; q++) a += p[(size_t)q * N + k];
+        total[k] = a;
+      }
+      expand_rigid_host(total, poses_host, o);
+    } else {
+      // the partial records add up entry by entry (all 122 scalars are linear in the tile sums), in slot order
+      for (int k = 0; k < N; k++) {
+        double a = p[k];
+        for (int q = 1; q < parts; q++) a += p[(size_t)q * N + k];
+        o[k] = a;
+      }
     }
   }
   return GP_OK;

@@ -404,7 +404,8 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
  * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md sections 4.1, 8.
  * Environment switches read once at first use (A/B only): GP_POSES_ZERO_COPY=0 (synchronous batched calls upload poses with
  * hipMemcpyAsync instead of letting the kernels read the pinned staging buffer), GP_FINALIZE_PARTS=n (workgroups sharing the finalize
- * of a synchronous single-factor call, default 8), GP_FINALIZE_NARROW=0 (those workgroups with 1024 instead of 256 threads), GP_GICP_SPLIT=0 (GICP factor: fused search + algebra kernel instead of the
+ * of a synchronous single-factor call, default 8), GP_FINALIZE_NARROW=0 (those workgroups with 1024 instead of 256 threads), GP_FINALIZE_HOST_EXPAND=0 (they expand the 6x6 blocks themselves
+ * instead of handing their sums to the host), GP_GICP_SPLIT=0 (GICP factor: fused search + algebra kernel instead of the
  * correspondence kernel + algebra kernel). */
 int gp_debug_set_variant(int variant);
 /* workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles are
