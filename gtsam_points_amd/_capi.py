@@ -167,6 +167,7 @@ _SIGNATURES = {
     "gp_vgicp_batch_issue_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_sync": (C.c_int, [C.c_void_p]),
     "gp_vgicp_batch_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_batch_linearize_view": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_vgicp_batch_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_point_grid_create": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_point_grid_destroy": (C.c_int, [C.c_void_p]),

@@ -576,6 +576,7 @@ struct gp_vgicp_batch {
   bool stream_once = false;  // no two factors of the batch read the same source cloud (and no sibling batch on this device does: gp_multi.hip
                              // clears shares_device_ok): the source stream may use the non-temporal policy
   bool shares_device_ok = true;
+  gp_linearized6 view_store{};  // gp_vgicp_batch_linearize_view of a single large factor: the record the host combined from the finalize parts
   int ppt = 4;            // 64-point chunks per wave of the pipeline kernel (tile = 256 x ppt points)
   std::vector<gp::FactorDesc> h_descs;  // host copy of the factor table (a single factor rides in the kernel arguments)
   gp::PinnedArray h_poses;
@@ -1298,11 +1299,15 @@ static void expand_rigid_host(const double* sum, const double* pose /*col-major 
     }
 }
 
-// synchronous: the finalize kernel stores the records straight into host-mapped pinned memory (no D2H copy op)
-int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host) {
-  if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
+// synchronous: the finalize kernel stores the records straight into host-mapped pinned memory (no D2H copy op).
+// out_host != nullptr: the records are copied there; view != nullptr: *view points at them where they lie (the batch's own pinned
+// buffer, or `view_store` for the single large factor whose parts the host combines) until the next call on the batch.
+static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host, const gp_linearized6** view) {
   const size_t F = b->factors.size();
+  if (view) *view = nullptr;
   if (F == 0) return GP_OK;
+  gp_linearized6 local;
+  if (!out_host && F == 1) out_host = view ? &b->view_store : &local;  // (the combined record of a split finalize needs a home)
   if (table_is_stale(b)) GP_TRY(build_table(b));
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps, true));
@@ -1314,8 +1319,10 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
   GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts));
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
   if (parts == 1) {
-    memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
+    if (view) *view = static_cast<const gp_linearized6*>(b->h_out.ptr);
+    if (out_host && !(view && F == 1)) memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);
   } else {
+    if (view) *view = out_host;  // F == 1: caller's array or view_store
     const double* p = static_cast<const double*>(b->h_out.ptr);
     double* o = reinterpret_cast<double*>(out_host);
     constexpr int N = (int)(sizeof(gp_linearized6) / sizeof(double));
@@ -1338,6 +1345,16 @@ int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_l
     }
   }
   return GP_OK;
+}
+
+int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host) {
+  if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
+  return batch_linearize_sync(b, poses_host, out_host, nullptr);
+}
+
+int gp_vgicp_batch_linearize_view(gp_vgicp_batch_t* b, const double* poses_host, const gp_linearized6** out_view) {
+  if (!b || !poses_host || !out_view) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize_view: null");
+  return batch_linearize_sync(b, poses_host, nullptr, out_view);
 }
 
 int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_host, const double* poses_eval_host, double* out_host) {

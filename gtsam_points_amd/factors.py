@@ -454,8 +454,10 @@ class NonlinearFactorSetGPU:
             poses = np.zeros((F, 16))
             for i, f in enumerate(self.factors):
                 f.set_linearization_point(values, poses[i])
-            out = np.zeros((F, _capi.LINEARIZED6_DOUBLES))
-            _capi.check(self._lib.gp_vgicp_batch_linearize(self._ensure_batch(), poses.ctypes.data, out.ctypes.data), "gp_vgicp_batch_linearize")
+            view = C.c_void_p()
+            _capi.check(self._lib.gp_vgicp_batch_linearize_view(self._ensure_batch(), poses.ctypes.data, C.byref(view)), "gp_vgicp_batch_linearize_view")
+            # the records where the finalize kernel stored them (valid until the next call on the batch): consumed without a copy
+            out = np.ctypeslib.as_array(C.cast(view, C.POINTER(C.c_double)), shape=(F, _capi.LINEARIZED6_DOUBLES))
             self._lin_poses = poses
             for i, f in enumerate(self.factors):
                 f.store_linearized(out[i])

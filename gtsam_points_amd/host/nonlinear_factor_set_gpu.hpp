@@ -68,11 +68,15 @@ public:
       f->set_linearization_point(values, lin_in_cpu.data() + cur);
       cur += f->linearization_input_size();
     }
+    const unsigned char* results = lin_out_cpu.data();
     if (ensure_batch()) {  // fast path: every factor is an IntegratedVGICPFactorGPU (input = 128-B pose, output = 976-B record)
       if (multi) {
         check_error << gp_vgicp_multi_batch_linearize(multi, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<gp_linearized6*>(lin_out_cpu.data()));
       } else {
-        check_error << gp_vgicp_batch_linearize(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), reinterpret_cast<gp_linearized6*>(lin_out_cpu.data()));
+        // the records are consumed where the finalize kernel stored them (the batch's pinned buffer): no copy into lin_out_cpu first
+        const gp_linearized6* view = nullptr;
+        check_error << gp_vgicp_batch_linearize_view(batch, reinterpret_cast<const double*>(lin_in_cpu.data()), &view);
+        if (view) results = reinterpret_cast<const unsigned char*>(view);
       }
     } else {
       resize(&d_lin_in, &d_lin_in_size, in_size);
@@ -91,7 +95,7 @@ public:
     }
     cur = 0;
     for (auto& f : factors) {
-      f->store_linearized(lin_out_cpu.data() + cur);
+      f->store_linearized(results + cur);
       cur += f->linearization_output_size();
     }
   }

@@ -277,6 +277,11 @@ int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* batch, const double* po
 int gp_vgicp_batch_sync(gp_vgicp_batch_t* batch);
 /* synchronous: upload poses, compute, download F records into out_host */
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_host);
+/* the same pass without the copy into a caller array: *out_view points at the F records where the finalize kernel stored them (the
+ * batch's pinned, host-mapped result buffer), valid until the next call on this batch.  The 976 bytes per factor are then read once,
+ * by their consumer (NonlinearFactorSetGPU's store_linearized loop), instead of copied first: 6 us of a 98 us 256-factor pass,
+ * 12 us of a 289 us 512-factor pass (profiles/r02_sync_batch_overheads.txt) */
+int gp_vgicp_batch_linearize_view(gp_vgicp_batch_t* batch, const double* poses_host, const gp_linearized6** out_view);
 int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* batch, const double* poses_lin_host, const double* poses_eval_host, double* out_host);
 /* timing hook for bench.py: re-runs only the device work (pose upload excluded) `iters` times on the batch stream
  * between two hipEvents and returns the average milliseconds per pass, and separately the two kernels' times */

@@ -525,6 +525,45 @@ def test_non_finite_source_points_are_skipped(gpu, kitti00, variant):
     assert abs(od * len(p) - oc * keep.sum()) < 0.5  # the same number of points falls into a voxel
 
 
+def test_batch_linearize_view(gpu, kitti07):
+    """gp_vgicp_batch_linearize_view: the records where the finalize kernel stored them, bit for bit those of the copying call -- for a
+    batch of several factors, and for a single large factor whose finalize parts the host combines (view into the batch's own record)"""
+    lib = gpu.load()
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(3)]
+    maps = []
+    for c in clouds:
+        m = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(c)
+        maps.append(m)
+    factors = [gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in [(0, 1), (1, 2), (0, 2)]]
+    poses = np.stack([np.ascontiguousarray((np.linalg.inv(kitti07["poses"][i]) @ kitti07["poses"][j]).T).reshape(16) for i, j in [(0, 1), (1, 2), (0, 2)]]).copy()
+
+    def both(fs, ps):
+        F = len(fs)
+        arr = (C.c_void_p * F)(*[f._h.value for f in fs])
+        batch, s = C.c_void_p(), C.c_void_p()
+        gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+        gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+        out = np.zeros((F, 122))
+        gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, ps.ctypes.data, out.ctypes.data), "linearize")
+        view = C.c_void_p()
+        gpu._capi.check(lib.gp_vgicp_batch_linearize_view(batch, ps.ctypes.data, C.byref(view)), "linearize_view")
+        got = np.ctypeslib.as_array(C.cast(view, C.POINTER(C.c_double)), shape=(F, 122)).copy()
+        lib.gp_vgicp_batch_destroy(batch)
+        lib.gp_stream_destroy(s)
+        return out, got
+
+    out, got = both(factors, poses)
+    assert np.array_equal(out, got) and out[:, 0].min() > 1000
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_c2_workload(300_000, 300_000, seed=11)  # >= 256 tiles: the split finalize
+    _, src, vm = _build(gpu, d, 0.5)
+    big = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    out, got = both([big], np.ascontiguousarray(d["T_true"].T).reshape(1, 16).copy())
+    assert np.array_equal(out, got) and out[0, 0] > 100_000
+
+
 def test_alignment_gate_gpu(gpu, kitti07):
     """the reference's VGICP_CUDA end-to-end gate (test_matching_cost_factors.cpp:196-230): LM through the
     linearisation hook, rot < 0.015 rad, trans < 0.15 m"""
