@@ -167,6 +167,18 @@ __global__ void __launch_bounds__(256) pattern_coop_kernel(const float* __restri
   if (acc == 123.456f) sink[0] = acc;
 }
 
+// one wave that keeps the device "busy" for `us` microseconds (s_memrealtime: the 100 MHz constant clock): probe of whether the tile
+// kernel's slower start behind an idle queue follows the device's utilisation
+__global__ void spin_kernel(unsigned long long ticks, unsigned long long* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t = t0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(8);
+    t = __builtin_amdgcn_s_memrealtime();
+  }
+  if (sink && t == 1) sink[0] = t;
+}
+
 // issue-rate micro-benchmark: 8 independent chains of one VALU instruction, 512 instructions per lane per launch.
 template <int OP>
 __global__ void __launch_bounds__(256) alu_rate_kernel(float* __restrict__ sink, int reps) {
@@ -298,6 +310,13 @@ int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n,
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipStreamDestroy(s);
+  return GP_OK;
+}
+
+/* measurement hook: one wave spins for `microseconds` on `stream` (asynchronous) */
+int gp_debug_spin(double microseconds, gp_stream_t stream) {
+  hipLaunchKernelGGL(gp::spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0), (unsigned long long*)nullptr);
+  GP_HIP(hipGetLastError());
   return GP_OK;
 }
 

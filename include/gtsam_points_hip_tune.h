@@ -17,6 +17,9 @@ extern "C" {
  * 3-12 source + voxel-gather access patterns, 100-115 VALU issue rates; see scripts/stream_bench.py, scripts/alu_rate.py */
 int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n, int mode, int iters, float* ms);
 /* profiling hook: streams 48*n bytes with strided dword loads (calibrates the rocprofv3 FETCH_SIZE scale) */
+/* one wave that spins for `microseconds` on `stream` (asynchronous): keeps the device busy across a host-side gap (probe of the idle-queue
+ * effect on the tile kernel's duration) */
+int gp_debug_spin(double microseconds, gp_stream_t stream);
 int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
 
 #ifdef __cplusplus

@@ -16,8 +16,13 @@ arr = (C.c_void_p * 1)(f._h.value); batch, s = C.c_void_p(), C.c_void_p()
 lib.gp_stream_create(C.byref(s)); _capi.check(lib.gp_vgicp_batch_create(arr, 1, s, C.byref(batch)), "batch")
 pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy(); out = np.zeros((1, 122))
 for _ in range(20): lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
+KEEP = float(os.environ.get("GP_PROBE_SPIN_US", "0"))  # > 0: a one-wave spinner of that many microseconds on a second stream before every pass
+tune = _capi.load_tune() if KEEP > 0 else None
+s2 = C.c_void_p(); lib.gp_stream_create(C.byref(s2))
 for gap in [0, 2, 5, 10, 20, 50, 200, 1000]:
     for _ in range(40):
+        if tune is not None:
+            tune.gp_debug_spin(KEEP, s2)
         lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
         t = time.perf_counter()
         while (time.perf_counter() - t) * 1e6 < gap: pass

@@ -1,13 +1,15 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O; cd $GRAFT_REPO_ROOT
-rm -rf /tmp/ig && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ig -o ig -- python scripts/probe/idle_gap_probe.py > /tmp/ig.log 2>&1
+O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O; : > $O/r02_idle_gap.txt; cd $GRAFT_REPO_ROOT
+for spin in ${SPINS:-0}; do
+echo "=== spinner of $spin us on a second stream before every pass ===" | tee -a $O/r02_idle_gap.txt
+rm -rf /tmp/ig && GP_PROBE_SPIN_US=$spin timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ig -o ig -- python scripts/probe/idle_gap_probe.py > /tmp/ig.log 2>&1
 f=$(find /tmp/ig -name "*kernel_trace.csv" | head -1)
-python - "$f" <<'PY' | tee $O/r02_idle_gap.txt
+python - "$f" <<'PY' | tee -a $O/r02_idle_gap.txt
 import csv, sys
 import numpy as np
-rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+rows = sorted((r for r in csv.DictReader(open(sys.argv[1])) if "spin_kernel" not in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 pts = []
 prev = None
 for r in rows:
@@ -21,3 +23,4 @@ for lo, hi in [(0, 8), (8, 12), (12, 16), (16, 25), (25, 40), (40, 80), (80, 400
     if m.sum():
         print(f"  gap {lo:6.0f} .. {hi:8.0f} us: n={int(m.sum()):4d}  duration mean {pts[m, 1].mean():6.2f} median {np.median(pts[m, 1]):6.2f} min {pts[m, 1].min():6.2f} us")
 PY
+done
