@@ -178,6 +178,7 @@ _SIGNATURES = {
     "gp_gicp_factor_linearize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(Linearized6)]),
     "gp_gicp_factor_compute_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gp_debug_set_variant": (C.c_int, [C.c_int]),
+    "gp_debug_expand_rigid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_debug_set_stagger": (C.c_int, [C.c_int]),
     "gp_debug_set_map_build": (C.c_int, [C.c_int]),
     "gp_trim_device_cache": (C.c_int, []),

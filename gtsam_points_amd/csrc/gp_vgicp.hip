@@ -1347,6 +1347,13 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
   return GP_OK;
 }
 
+// host-side check hook (no device needed): the expansion the synchronous single-factor call runs on the added sums of its finalize parts
+int gp_debug_expand_rigid(const double sums[32], const double pose[16], gp_linearized6* out) {
+  if (!sums || !pose || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_expand_rigid: null");
+  expand_rigid_host(sums, pose, reinterpret_cast<double*>(out));
+  return GP_OK;
+}
+
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* b, const double* poses_host, gp_linearized6* out_host) {
   if (!b || !poses_host || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_linearize: null");
   return batch_linearize_sync(b, poses_host, out_host, nullptr);

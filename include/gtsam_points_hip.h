@@ -413,6 +413,11 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
  * instead of handing their sums to the host), GP_GICP_SPLIT=0 (GICP factor: fused search + algebra kernel instead of the
  * correspondence kernel + algebra kernel). */
 int gp_debug_set_variant(int variant);
+/* host-side check hook (runs without a device): the 29 target-side sums of a rigid pass (ACC layout of csrc/gp_device.hpp: count, error,
+ * M[6], K[9], TL[6], q x Mr [3], Mr [3]) and the pose delta (column-major 4x4) -> the complete record, i.e. H_t from the sums and
+ * H_s = Ad^T H_t Ad, H_ts = -H_t Ad, b_s = -Ad^T b_t (integrated_vgicp_factor_gpu.cpp:199-213 consumes them).  This is the expansion the
+ * synchronous single-factor call runs on the host on the added sums of its finalize parts. */
+int gp_debug_expand_rigid(const double sums[32], const double pose[16], gp_linearized6* out);
 /* workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles are
  * dealt to the XCDs round robin */
 int gp_debug_set_xcd_chunk(int tiles);

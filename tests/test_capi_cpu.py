@@ -63,3 +63,66 @@ def test_product_does_not_touch_the_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt and "vgicp_oracle" not in txt, os.path.join(dirpath, fn)
+
+
+def test_host_side_expansion_of_the_rigid_sums():
+    """gp_debug_expand_rigid = the expansion the synchronous single-factor call runs on the host (split finalize): fed with the 29
+    target-side sums of random correspondences (M = SPD 3x3, q, r), it must return H_t = sum J_t^T M J_t etc. with
+    J_t = [-[q]x, I], J_s = -J_t Ad(delta) -- checked against the direct numpy evaluation with the explicit J_s = [R [p]x, -R]
+    (vgicp_derivatives.cuh:57-70).  Pure host code: runs without a device."""
+    import numpy as np
+
+    from gtsam_points_amd import _capi
+
+    lib = _capi.load()
+    rng = np.random.default_rng(5)
+
+    def hat(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    w = rng.normal(size=3) * 0.3
+    th = np.linalg.norm(w)
+    K = hat(w / th)
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    t = rng.normal(size=3)
+    delta = np.eye(4)
+    delta[:3, :3], delta[:3, 3] = R, t
+    n = 200
+    sums = np.zeros(32)
+    Ht, Hs, Hts, bt, bs = np.zeros((6, 6)), np.zeros((6, 6)), np.zeros((6, 6)), np.zeros(6), np.zeros(6)
+    err = 0.0
+    for _ in range(n):
+        p = rng.normal(size=3) * 5
+        q = R @ p + t
+        r = rng.normal(size=3) * 0.1
+        A = rng.normal(size=(3, 3))
+        M = A @ A.T + 0.1 * np.eye(3)
+        Jt = np.hstack([-hat(q), np.eye(3)])
+        Js = np.hstack([R @ hat(p), -R])
+        Ht += Jt.T @ M @ Jt
+        Hs += Js.T @ M @ Js
+        Hts += Jt.T @ M @ Js
+        bt += Jt.T @ M @ r
+        bs += Js.T @ M @ r
+        err += r @ M @ r
+        # the kernel's 29 sums (gp_device.hpp ACC layout): count, error, M (xx xy xz yy yz zz), K = M [q]x (row-major), TL = -[q]x K (upper), q x Mr, Mr
+        S = hat(q)
+        Kq = M @ S
+        TL = -S @ Kq
+        Mr = M @ r
+        sums[0] += 1
+        sums[1] += r @ M @ r
+        sums[2:8] += [M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]]
+        sums[8:17] += Kq.reshape(9)
+        sums[17:23] += [TL[0, 0], TL[0, 1], TL[0, 2], TL[1, 1], TL[1, 2], TL[2, 2]]
+        sums[23:26] += np.cross(q, Mr)
+        sums[26:29] += Mr
+    pose = np.ascontiguousarray(delta.T).reshape(16).copy()
+    out = np.zeros(122)
+    assert lib.gp_debug_expand_rigid(sums.ctypes.data, pose.ctypes.data, out.ctypes.data) == 0
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert out[0] == n and abs(out[1] - err) < 1e-12 * err
+    assert rel(out[2:38].reshape(6, 6).T, Ht) < 1e-13
+    assert rel(out[38:74].reshape(6, 6).T, Hs) < 1e-12
+    assert rel(out[74:110].reshape(6, 6).T, Hts) < 1e-12
+    assert rel(out[110:116], bt) < 1e-13 and rel(out[116:122], bs) < 1e-12
