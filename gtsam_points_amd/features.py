@@ -105,6 +105,7 @@ class IntegratedGICPFactorGPU:
         l = LinearizedSystem6(rec)
         self._num_inliers = l.num_inliers
         self.linearization_point = np.asarray(delta, dtype=np.float64)
+        self._linearized = True
         return l
 
     def linearize(self, values):
@@ -114,8 +115,14 @@ class IntegratedGICPFactorGPU:
         return HessianFactor(self._keys, {(0, 0): l.H_source}, [-l.b_source], l.error)
 
     def error(self, values):
+        """evaluate(delta) on the correspondences of the last linearise; without one they are computed at `delta` itself first
+        (integrated_gicp_factor_impl.hpp:226-228: update_correspondences(delta) when none are stored)"""
+        delta = self.calc_delta(values)
+        if not getattr(self, "_linearized", False):
+            self.linearization_point = np.asarray(delta, dtype=np.float64)
+            self._linearized = True
         out = C.c_double()
-        _capi.check(self._lib.gp_gicp_factor_compute_error(self._h, _pose16(self.linearization_point), _pose16(self.calc_delta(values)), C.byref(out)), "gp_gicp_factor_compute_error")
+        _capi.check(self._lib.gp_gicp_factor_compute_error(self._h, _pose16(self.linearization_point), _pose16(delta), C.byref(out)), "gp_gicp_factor_compute_error")
         return out.value
 
     def num_inliers(self):
