@@ -272,6 +272,8 @@ def main():
         traffic=_load_traffic(),
         algorithmic_bytes=alg_bytes,
         kernel_ms=round(ms_main.value, 5),
+        kernel_ms_note="HIP events over back-to-back launches on the launch stream; behind the idle queue of a synchronous step the same kernel takes "
+                       "1.3-1.5 us longer (rocprofv3 per-dispatch durations by launch pattern: profiles/r02_kernel_trace_split.txt, DESIGN.md section 6)",
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
     )
