@@ -50,15 +50,17 @@ def run_variant(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_samp
     out = np.zeros((F, 122))
     for _ in range(3):
         _capi.check(lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data), "lin")
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data)
-    ms = (time.perf_counter() - t0) / iters * 1e3
+    def wall(call):  # per-call host-to-host times: the median is the figure, mean and max show a hiccup of the box when there is one
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            call()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts)), float(np.mean(ts)), float(np.max(ts))
+
     view = C.c_void_p()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        lib.gp_vgicp_batch_linearize_view(batch, poses.ctypes.data, C.byref(view))
-    ms_view = (time.perf_counter() - t0) / iters * 1e3
+    ms, ms_mean, ms_max = wall(lambda: lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data))
+    ms_view, ms_view_mean, ms_view_max = wall(lambda: lib.gp_vgicp_batch_linearize_view(batch, poses.ctypes.data, C.byref(view)))
     got = np.ctypeslib.as_array(C.cast(view, C.POINTER(C.c_double)), shape=(F, 122))
     assert np.array_equal(got, out)  # the view holds the same records the copying call delivered
     a, b, c = C.c_float(), C.c_float(), C.c_float()
@@ -94,7 +96,8 @@ def run_variant(name, clouds, maps, pairs, deltas, host_clouds, res, oracle_samp
         for blk in BLOCKS:
             worst = max(worst, float(np.linalg.norm(getattr(L, blk) - getattr(Lo, blk)) / np.linalg.norm(getattr(Lo, blk))))
     res_d = dict(
-        config=name, factors=F, points=npts, ms_per_linearize=round(ms, 4), ms_per_linearize_view=round(ms_view, 4), corr_per_s=round(npts / ms * 1e3, 1), tile_kernel_ms=round(b.value, 5),
+        config=name, factors=F, points=npts, ms_per_linearize=round(ms, 4), ms_per_linearize_view=round(ms_view, 4), ms_per_linearize_mean_max=[round(ms_mean, 4), round(ms_max, 4)],
+        ms_per_linearize_view_mean_max=[round(ms_view_mean, 4), round(ms_view_max, 4)], corr_per_s=round(npts / ms * 1e3, 1), tile_kernel_ms=round(b.value, 5),
         finalize_kernel_ms=round(c.value, 5), device_pass_ms=round(a.value, 5), algorithmic_bytes=alg, roofline_frac=round(alg / (b.value * 1e-3) / 8e12, 4),
         parity_max_rel_err=worst, parity_factors_checked=len(oracle_sample),
         cpu_oracle_ms_per_factor=round(t_cpu / max(len(oracle_sample), 1) * 1e3, 3), cpu_threads=oracle.max_threads(),
