@@ -22,6 +22,11 @@ Extra objects on the JSON line:
                   references replicated onto it (gtsam_points_amd.synthetic.c4_factor_pairs / make_c4_submaps, plan from
                   gp_shard_plan_create); one step = every rank's batched linearise into its rows of the zeroed [4096 x 122] f64
                   stack + ONE all-reduce (RCCL) + D2H.  Strong scaling: total work is fixed as N grows.  --no-c4 skips it.
+  configs      -- the remaining BASELINE configs under the driver's clock (rank 0, N = 1; --no-configs skips them): C1 the two full
+                  data/kitti_00 scans @0.5 m (covariances from gp_estimate_covariances), C3 the 256-factor submap graph as ONE batched
+                  call through gp_vgicp_batch_linearize_view, C5 k-NN covariance estimation + GICP linearise at 1 M points.  Each
+                  with ms, corr/s (points/s), a roofline object for its dominant kernel, parity against and the time of the
+                  REFERENCE's own CPU code (oracle/_ref/libref.so; the C restatement when that is absent).
 """
 import argparse
 import ctypes as C
@@ -46,12 +51,71 @@ def _load_traffic():
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("tile_kernel_hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get("tile_kernel_hbm_bytes_per_launch"), f"profiles/hbm_traffic.json ({d.get('source', 'builder-run rocprofv3 --pmc passes')}); NOT measured in this run"
     except Exception:
-        return None
+        return None, None
 
 
-def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, stream):
+def run_c4_inlib(lib, gpa, _capi, synthetic, torch, home_device, steps):
+    """The same 4096-factor configuration through the IN-LIBRARY sharded path a C++ optimizer process would use
+    (gp_vgicp_multi_batch_*: ONE process drives every visible device, ncclCommInitAll, one ncclAllReduce of the [4096 x 122] f64
+    stack per linearise; replaces the per-factor loop of src/gtsam_points/cuda/nonlinear_factor_set_gpu.cpp:64-139).  Only run
+    when the process sees more than one device; rank 0 only.  Returns a dict (never raises: an error is reported as a string)."""
+    from gtsam_points_amd.distributed import MultiDeviceBatch, partition_factors
+
+    ndev = torch.cuda.device_count()
+    try:
+        t_setup = time.time()
+        pairs = synthetic.c4_factor_pairs()
+        F = len(pairs)
+        parts = partition_factors([synthetic.C4_POINTS] * F, ndev)
+        sub = synthetic.make_c4_submaps(range(synthetic.C4_SUBMAPS))
+        factors, keep = [], []
+        for dev, (b, e) in enumerate(parts):
+            torch.cuda.set_device(dev)
+            _capi.check(lib.gp_set_device(dev), "gp_set_device")
+            mine = pairs[b:e]
+            clouds = {i: gpa.PointCloudGPU(sub[i][0], sub[i][1], device=f"cuda:{dev}") for i in sorted({i for p in mine for i in p})}
+            maps = {}
+            for t in sorted({t for t, _ in mine}):
+                m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+                m.insert(clouds[t])
+                maps[t] = m
+            factors += [gpa.IntegratedVGICPFactorGPU(t, s, maps[t], clouds[s]) for t, s in mine]
+            keep.append((clouds, maps))
+        torch.cuda.set_device(home_device)
+        _capi.check(lib.gp_set_device(home_device.index), "gp_set_device")
+        mb = MultiDeviceBatch(factors, use_rccl=1)
+        poses = np.stack([np.ascontiguousarray(synthetic.c4_delta(sub, t, s).T).reshape(16) for t, s in pairs]).copy()
+        out = np.zeros((F, 122))
+        t_setup = time.time() - t_setup
+        for _ in range(3):
+            mb.linearize_flat(poses, out)
+        comp, exch = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mb.linearize_flat(poses, out)
+            tm = mb.last_timing()
+            comp.append(tm["ms_compute"])
+            exch.append(tm["ms_exchange"])
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res = dict(devices=ndev, shards=mb.num_shards, uses_rccl=bool(mb.uses_rccl), inlib_ms=round(ms, 4), inlib_compute_ms=round(float(np.median(comp)), 4),
+                   inlib_allreduce_ms=round(float(np.median(exch)), 4), value=round(F * synthetic.C4_POINTS / (ms * 1e-3), 1), unit="point-correspondences/s",
+                   inlier_fraction=round(float(out[:, 0].sum()) / (F * synthetic.C4_POINTS), 4), setup_s=round(t_setup, 1),
+                   note="host wall per gp_vgicp_multi_batch_linearize (poses in host memory -> all 4096 records in host memory); compute / exchange from the library's own HIP events")
+        del mb, factors, keep
+        return res
+    except Exception as exc:  # the headline must survive a failure of this optional leg
+        try:
+            torch.cuda.set_device(home_device)
+            lib.gp_set_device(home_device.index)
+        except Exception:
+            pass
+        return dict(devices=ndev, error=f"{type(exc).__name__}: {exc}")
+
+
+def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, stream, dist_on=False):
     """BASELINE configs[3]: 4096 pairwise factors sharded over the ranks (see the module docstring).  Returns the `c4` object
     (rank 0) or None."""
     from gtsam_points_amd.distributed import RECORD_DOUBLES, ShardedLinearizer, partition_factors
@@ -83,7 +147,7 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
     def issue(poses_local, view):
         _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses_local.ctypes.data, C.c_void_p(view.data_ptr())), "gp_vgicp_batch_issue_linearize")
 
-    sharded = ShardedLinearizer(F, (begin, end), device, issue)
+    sharded = ShardedLinearizer(F, (begin, end), device, issue, always_exchange=dist_on)
     host_out = torch.zeros((F, RECORD_DOUBLES), dtype=torch.float64).pin_memory()
 
     def step():
@@ -92,7 +156,7 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         stream.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -106,7 +170,7 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
     elapsed = time.perf_counter() - t0
     # the exchange alone: all-reduce of the stacked records (+ zeroing), HIP events on the stream it is issued on
     ar_ms = 0.0
-    if world > 1:
+    if dist_on:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         e0.record(stream)
@@ -122,7 +186,7 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         _capi.check(lib.gp_vgicp_batch_time_linearize(batch, poses.ctypes.data, 10, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
         alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
     stats = torch.tensor([elapsed, ms_main.value, float(alg), float(n_local)], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -132,6 +196,12 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
     elapsed_max, tile_ms_max, alg_sum = float(mx[0]), float(mx[1]), float(sm[2])
     inliers = float(host_out[:, 0].sum())
     lib.gp_vgicp_batch_destroy(batch)
+    del factors, maps, clouds
+    inlib = None
+    if rank == 0 and torch.cuda.device_count() > 1 and not args.no_c4_inlib:
+        inlib = run_c4_inlib(lib, gpa, _capi, synthetic, torch, device, max(args.c4_steps // 3, 5))
+    if dist_on:
+        dist.barrier()  # the other ranks wait for rank 0's in-library leg
     if rank != 0:
         return None
     points = F * synthetic.C4_POINTS
@@ -142,10 +212,198 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         ms_per_linearize=round(ms, 4), value=round(points / (ms * 1e-3), 1), unit="point-correspondences/s",
         allreduce_ms=round(ar_ms, 4), stack_bytes=F * RECORD_DOUBLES * 8,
         tile_kernel_ms_slowest_rank=round(tile_ms_max, 5), algorithmic_bytes_total=int(alg_sum),
-        roofline_frac_per_gpu=round(alg_sum / world / (tile_ms_max * 1e-3) / 8e12, 4) if tile_ms_max > 0 else None,
+        algorithmic_frac_per_gpu=round(alg_sum / world / (tile_ms_max * 1e-3) / 8e12, 4) if tile_ms_max > 0 else None,
+        algorithmic_frac_note="algorithmic bytes (SURVEY.md 8(d)) charge every factor its own 48 B/pt source stream although each source cloud serves 8 factors "
+                              "(unique data ~0.9 GB of 7.9 GB) and ~half of the points miss: NOT an HBM fraction, no roofline credit claimed",
+        inlib=inlib,
         factors_rank0=n_local, inlier_fraction=round(inliers / points, 4), setup_s=round(t_setup, 1),
         step="per rank: zero [4096 x 122] f64 stack -> batched tile + finalize kernels into own rows -> ONE all-reduce (RCCL) -> D2H -> sync",
     )
+
+
+BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
+
+
+def _parity(L, Lo):
+    out = {k: float(np.linalg.norm(getattr(L, k) - getattr(Lo, k)) / max(np.linalg.norm(getattr(Lo, k)), 1e-300)) for k in BLOCKS}
+    out["error"] = float(abs(L.error - Lo.error) / max(abs(Lo.error), 1e-300))
+    out["num_inliers_equal"] = bool(L.num_inliers == Lo.num_inliers)
+    return out
+
+
+def _median_ms(call, iters):
+    ts = []
+    for _ in range(iters):
+        t = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e3
+
+
+def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
+    """BASELINE configs[0], [2], [4] (C1, C3, C5 of SURVEY.md 8(d)) under the driver's clock.  GPU side = the product's synchronous entry
+    points; CPU side = the reference's own code (oracle/_ref/libref.so) on all host cores, on a bounded sample, as checker and baseline."""
+    import oracle  # checker / baseline only
+    from oracle import refcapi
+
+    use_ref = refcapi.available()
+    cores = oracle.max_threads()
+    kind = "reference" if use_ref else "port"
+    VoxelMap = refcapi.RefVoxelMap if use_ref else oracle.OracleVoxelMap
+    VGICP = refcapi.RefVGICPFactor if use_ref else oracle.OracleVGICPFactor
+    GICP = refcapi.RefGICPFactor if use_ref else oracle.OracleGICPFactor
+    sptr = C.c_void_p(stream.cuda_stream)
+    out = {}
+
+    def time_batch(factors, poses, iters, view=True):
+        F = len(factors)
+        arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+        batch = C.c_void_p()
+        _capi.check(lib.gp_vgicp_batch_create(arr, F, sptr, C.byref(batch)), "gp_vgicp_batch_create")
+        recs = np.zeros((F, _capi.LINEARIZED6_DOUBLES))
+        vptr = C.c_void_p()
+        pp, rp = C.c_void_p(poses.ctypes.data), C.c_void_p(recs.ctypes.data)
+        for _ in range(5):
+            _capi.check(lib.gp_vgicp_batch_linearize(batch, pp, rp), "gp_vgicp_batch_linearize")
+        ms_copy = _median_ms(lambda: lib.gp_vgicp_batch_linearize(batch, pp, rp), iters)
+        ms_view = _median_ms(lambda: lib.gp_vgicp_batch_linearize_view(batch, pp, C.byref(vptr)), iters)
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pp, min(iters, 50), C.byref(a), C.byref(b), C.byref(c)), "time_linearize")
+        alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+        npts = int(lib.gp_vgicp_batch_total_points(batch))
+        lib.gp_vgicp_batch_destroy(batch)
+        roof = dict(bound="hbm", kernel="vgicp_pipeline2_kernel (batched tile table)" if F > 1 else "vgicp_pipeline2_kernel (in-argument descriptor)",
+                    achieved=round(alg / (b.value * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (b.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    algorithmic_bytes=alg, kernel_ms=round(b.value, 5), finalize_kernel_ms=round(c.value, 5), device_pass_ms=round(a.value, 5), traffic=None)
+        return recs, ms_copy, ms_view, npts, roof
+
+    # ---- C1: the two full data/kitti_00 scans (shipped as tests/golden/kitti_00/*.bin), 0.5 m voxels, single linearise ----
+    gdir = os.path.join(ROOT, "tests", "golden", "kitti_00")
+    if os.path.exists(os.path.join(gdir, "000000.bin")):
+        tp = np.fromfile(os.path.join(gdir, "000000.bin"), dtype=np.float32).reshape(-1, 3)
+        sp = np.fromfile(os.path.join(gdir, "000001.bin"), dtype=np.float32).reshape(-1, 3)
+        tgt, src = gpa.PointCloudGPU(tp, device=device), gpa.PointCloudGPU(sp, device=device)
+        gpa.estimate_covariances_gpu(tgt, 10)
+        gpa.estimate_covariances_gpu(src, 10)
+        vm = gpa.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+        vm.insert(tgt)
+        f = gpa.IntegratedVGICPFactorGPU(0, 1, vm, src, stream=sptr)
+        delta = synthetic.expmap(synthetic.C1B_PERTURBATION)
+        pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
+        recs, ms_copy, ms_view, npts, roof = time_batch([f], pose, 200)
+        roof["note"] = "launch-bound: 124,605 points are 487 workgroups of 256 points; the kernel is a few microseconds whatever its bytes"
+        tc, sc = tgt.download("covs"), src.download("covs")  # float32 exactly as the kernels read them
+        om = VoxelMap(0.5)
+        om.insert(tp, tc)
+        fo = VGICP(om, sp, sc, cores)
+        Lo = fo.linearize(delta)
+        cpu_ms = _median_ms(lambda: fo.linearize(delta), 10)
+        f1 = VGICP(om, sp, sc, 1)
+        cpu1_ms = _median_ms(lambda: f1.linearize(delta), 3)
+        out["C1"] = dict(
+            workload="BASELINE configs[0]: two full data/kitti_00 scans (124,668 / 124,605 pts), covariances k=10 from gp_estimate_covariances, 0.5 m voxels, single linearise",
+            points=npts, num_voxels=vm.voxelmap_info.num_voxels, ms=round(ms_copy, 5), ms_view=round(ms_view, 5), corr_per_s=round(npts / ms_copy * 1e3, 1), roofline=roof,
+            cpu_baseline=dict(value=round(npts / cpu_ms * 1e3, 1), unit="point-correspondences/s", cores=cores, kind=kind, ms=round(cpu_ms, 3), ms_1thread=round(cpu1_ms, 3),
+                              sample="10 full linearize() passes of the same factor (the reference's default is 1 thread: ms_1thread)"),
+            parity_vs_reference=_parity(gpa.LinearizedSystem6.from_doubles(recs[0]), Lo), inlier_fraction=round(float(recs[0, 0]) / npts, 4))
+        del f, vm, tgt, src
+
+    # ---- C3: 256-factor submap graph, ONE batched call ----
+    t0 = time.time()
+    g = synthetic.make_c3_graph()
+    clouds = [gpa.PointCloudGPU(p, c, device=device) for p, c in g["clouds"]]
+    maps = []
+    for c in clouds:
+        m = gpa.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(c)
+        maps.append(m)
+    factors = [gpa.IntegratedVGICPFactorGPU(t, s_, maps[t], clouds[s_], stream=sptr) for t, s_ in g["pairs"]]
+    poses = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in g["deltas"]]).copy()
+    t_setup = time.time() - t0
+    recs, ms_copy, ms_view, npts, roof = time_batch(factors, poses, 50)
+    roof["note"] = ("algorithmic bytes charge every factor its own source cloud (SURVEY.md 8(d)); four factors share each cloud and the re-reads hit L2, "
+                    "so this fraction is not an HBM fraction")
+    sample = list(range(0, len(factors), 8))  # every 8th factor: 32 reference linearisations
+    omaps, worst, t_cpu = {}, 0.0, 0.0
+    for k in sample:
+        t, s_ = g["pairs"][k]
+        if t not in omaps:
+            omaps[t] = VoxelMap(1.0)
+            omaps[t].insert(*g["clouds"][t])
+        fo = VGICP(omaps[t], g["clouds"][s_][0], g["clouds"][s_][1], cores)
+        fo.linearize(g["deltas"][k])
+        tt = time.perf_counter()
+        Lo = fo.linearize(g["deltas"][k])
+        t_cpu += time.perf_counter() - tt
+        par = _parity(gpa.LinearizedSystem6.from_doubles(recs[k]), Lo)
+        worst = max(worst, max(par[b] for b in BLOCKS), par["error"])
+        assert par["num_inliers_equal"], k
+    cpu_ms_graph = t_cpu / len(sample) * len(factors) * 1e3
+    out["C3"] = dict(
+        workload="BASELINE configs[2]: 256-factor submap graph (64 submaps x ~22k pts, factors i -> i+1..i+4 and back, 1.0 m voxels), ONE batched linearise "
+                 "through gp_vgicp_batch_linearize_view",
+        factors=len(factors), points=npts, ms=round(ms_view, 5), ms_with_copy=round(ms_copy, 5), corr_per_s=round(npts / ms_view * 1e3, 1), roofline=roof,
+        cpu_baseline=dict(value=round(npts / cpu_ms_graph * 1e3, 1), unit="point-correspondences/s", cores=cores, kind=kind, ms=round(cpu_ms_graph, 2),
+                          sample=f"{len(sample)} of the 256 factors (every 8th), one linearize() each after a warm-up, {cores} threads per factor, sequential over factors "
+                                 "as graph_.linearize does; scaled x8"),
+        parity_vs_reference_max=worst, parity_factors_checked=len(sample), inlier_fraction=round(float(recs[:, 0].sum()) / npts, 4), setup_s=round(t_setup, 1))
+    del factors, maps, clouds
+
+    # ---- C5: k-NN covariance estimation (k = 10) + IntegratedGICPFactor linearise, 1 M points ----
+    d = synthetic.make_c2_workload(1_000_000, 1_000_000, seed=42)
+    tgt, src = gpa.PointCloudGPU(d["target_points"], device=device), gpa.PointCloudGPU(d["source_points"], device=device)
+    torch.cuda.synchronize()
+    for fr in (tgt, src):
+        gpa.estimate_covariances_gpu(fr, 10)
+    ts = []
+    for fr in (tgt, src, tgt, src, src):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        short = gpa.estimate_covariances_gpu(fr, 10)
+        ts.append(time.perf_counter() - t)
+    cov_ms = float(np.median(ts)) * 1e3
+    kt = gpa.features.covariance_kernel_times(src, 10) if hasattr(gpa.features, "covariance_kernel_times") else None
+    got = src.download("covs").astype(np.float64)
+    if use_ref:
+        t = time.perf_counter()
+        ref_cov = refcapi.ref_estimate_covariances(d["source_points"], 10, cores)
+        cov_cpu_ms = (time.perf_counter() - t) * 1e3
+    else:
+        t = time.perf_counter()
+        ref_cov, _ = oracle.estimate_covariances(d["source_points"], 10, cores)
+        cov_cpu_ms = (time.perf_counter() - t) * 1e3
+    rel = np.linalg.norm((got - ref_cov).reshape(len(got), -1), axis=1) / np.linalg.norm(ref_cov.reshape(len(got), -1), axis=1)
+    fg = gpa.IntegratedGICPFactorGPU(0, 1, tgt, src)
+    delta5 = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    fg.linearize_delta(delta5)
+    gicp_ms = _median_ms(lambda: fg.linearize_delta(delta5), 20)
+    L = fg.linearize_delta(delta5)
+    tc, sc = tgt.download("covs"), src.download("covs")
+    fo = GICP(d["target_points"], tc, d["source_points"], sc, cores)
+    Lo = fo.linearize(delta5)
+    gicp_cpu_ms = _median_ms(lambda: fo.linearize(delta5), 3)
+    cov_roof = dict(bound="issue", kernel="covariance_kernel<10> (gp_knn.hip)", unit="ms",
+                    note="not HBM-bound: the cloud (16 MB as float4) is re-read out of L1/L2; the stated bound is the vector-memory address path of the divergent per-lane "
+                         "candidate gathers + the f64 insertions and the eigen-decomposition (DESIGN.md section 4.8)",
+                    compulsory_bytes=48 * 1_000_000, hbm_frac_of_compulsory=round(48e6 / (cov_ms * 1e-3) / 8e12, 5))
+    if kt:
+        cov_roof.update(kt)
+    out["C5"] = dict(
+        workload="BASELINE configs[4]: k-NN covariance estimation (k=10, exact) + IntegratedGICPFactor linearise, 1 M source pts vs 1 M target pts",
+        points=1_000_000,
+        covariances=dict(ms=round(cov_ms, 4), points_per_s=round(1e6 / cov_ms * 1e3, 1), num_short=int(short), roofline=cov_roof,
+                         cpu_baseline=dict(value=round(1e6 / cov_cpu_ms * 1e3, 1), unit="points/s", cores=cores, kind=kind, ms=round(cov_cpu_ms, 2),
+                                           sample="one estimate_covariances pass over the same 1 M points (kd-tree build + 10-NN + eigen-regularisation; the 3x3 eigen-solver under the "
+                                                  "reference code is the stand-in Jacobi iteration of oracle/ref_shim, not Eigen's closed form)"),
+                         parity_vs_reference=dict(rel_err_median=float(np.median(rel)), frac_within_1e5=float((rel < 1e-5).mean()))),
+        gicp=dict(ms=round(gicp_ms, 4), corr_per_s=round(1e6 / gicp_ms * 1e3, 1),
+                  roofline=dict(bound="issue", kernel="gicp_correspond_kernel + gicp_tile_kernel<CORR> (gp_knn.hip)", unit="ms",
+                                note="1-NN walk of the cell grid per point, then the VGICP algebra on the matched target point; arithmetic- and divergence-bound (DESIGN.md 4.8)",
+                                compulsory_bytes=96 * 1_000_000, hbm_frac_of_compulsory=round(96e6 / (gicp_ms * 1e-3) / 8e12, 5)),
+                  cpu_baseline=dict(value=round(1e6 / gicp_cpu_ms * 1e3, 1), unit="point-correspondences/s", cores=cores, kind=kind, ms=round(gicp_cpu_ms, 2),
+                                    sample="3 linearize() passes (1-NN kd-tree search + evaluate) of the same factor"),
+                  parity_vs_reference=_parity(L, Lo), inlier_fraction=round(L.num_inliers / 1e6, 4)))
+    return out
 
 
 def main():
@@ -161,6 +419,8 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=50)
     ap.add_argument("--no-c4", action="store_true", help="skip the sharded 4096-factor configuration (BASELINE configs[3])")
     ap.add_argument("--c4-steps", type=int, default=30)
+    ap.add_argument("--no-c4-inlib", action="store_true", help="skip the single-process multi-device leg of c4 (run by rank 0 when it sees > 1 device)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C5 objects (BASELINE configs[0], [2], [4])")
     args = ap.parse_args()
 
     import torch
@@ -177,8 +437,13 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node; lets a 1-GPU box rehearse N > 1
     torch.cuda.set_device(dev_index)
     device = torch.device(f"cuda:{dev_index}")
-    if world > 1:
+    # GP_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, ShardedLinearizer, all-reduce of the record stack) with ONE rank -- how a
+    # 1-GPU box runs the RCCL initialisation and a 1-rank ncclAllReduce that the gloo rehearsal cannot (tests/test_multi_gpu.py)
+    dist_on = world > 1 or bool(os.environ.get("GP_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("GP_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; "gloo" only for the 1-GPU rehearsal
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -215,7 +480,7 @@ def main():
     host_out = torch.zeros((world, REC), dtype=torch.float64).pin_memory()
     out_np = host_out.numpy()
 
-    if world == 1:
+    if not dist_on:
         # the product's synchronous entry point: pose in host memory -> records in host memory
         linearize = lib.gp_vgicp_batch_linearize  # bound once: the step is ~40 us, attribute lookups and .ctypes views are not free
         pose_ptr, out_ptr = C.c_void_p(pose.ctypes.data), C.c_void_p(out_np.ctypes.data)
@@ -230,7 +495,7 @@ def main():
         def issue(poses_local, view):
             _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses_local.ctypes.data, C.c_void_p(view.data_ptr())), "gp_vgicp_batch_issue_linearize")
 
-        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue)
+        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue, always_exchange=True)
 
         def step():
             stacked = sharded.linearize(pose)  # zero, local kernels, RCCL all-reduce over xGMI
@@ -238,7 +503,7 @@ def main():
             stream.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -250,7 +515,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -269,7 +534,8 @@ def main():
         peak=HBM_PEAK_GBS,
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 5),
-        traffic=_load_traffic(),
+        traffic=_load_traffic()[0],
+        traffic_source=_load_traffic()[1],
         algorithmic_bytes=alg_bytes,
         kernel_ms=round(ms_main.value, 5),
         kernel_ms_note="HIP events over back-to-back launches on the launch stream; behind the idle queue of a synchronous step the same kernel takes "
@@ -284,7 +550,10 @@ def main():
     rec = gpa.LinearizedSystem6.from_doubles(host_out[rank].numpy())
     c4 = None
     if not args.no_c4:
-        c4 = run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, stream)
+        c4 = run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, stream, dist_on)
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        configs = run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream)
     result = None
     if rank == 0:
         cpu_baseline = None
@@ -356,18 +625,20 @@ def main():
                 num_voxels=info.num_voxels,
                 num_buckets=info.num_buckets,
                 inlier_fraction=round(rec.num_inliers / args.source_points, 4),
-                parallelism=f"{world} x 1 factor/GPU; RCCL all-reduce of stacked [N x 122] f64 records" if world > 1 else "1 GPU",
+                parallelism=f"{world} x 1 factor/GPU; RCCL all-reduce of stacked [N x 122] f64 records" if dist_on else "1 GPU",
+                exchange=(f"torch.distributed backend {dist.get_backend()}, world {world}" if dist_on else None),
                 step="poses (host) -> tile kernel -> finalize kernel -> [N>1: RCCL all-reduce of the stacked records] -> records in host memory, synchronised",
             ),
             roofline=roofline,
             cpu_baseline=cpu_baseline,
             parity_vs_oracle=parity,
             c4=c4,
+            configs=configs,
             setup=dict(generate_s=round(t_gen, 2), voxelmap_build_s=round(t_map, 4)),
         )
         print(json.dumps(result), flush=True)
     lib.gp_vgicp_batch_destroy(batch)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -94,6 +94,13 @@ class MultiDeviceBatch:
         _capi.check(self._lib.gp_vgicp_multi_batch_linearize(self._h, poses.ctypes.data, out.ctypes.data), "gp_vgicp_multi_batch_linearize")
         return out
 
+    def linearize_flat(self, poses_flat, out):
+        """the call without per-call staging: poses_flat [F x 16] f64 (each pose column-major), out [F x 122] f64, both C-contiguous numpy arrays"""
+        from . import _capi
+
+        _capi.check(self._lib.gp_vgicp_multi_batch_linearize(self._h, poses_flat.ctypes.data, out.ctypes.data), "gp_vgicp_multi_batch_linearize")
+        return out
+
     def compute_error(self, deltas_lin, deltas_eval):
         from . import _capi
 
@@ -118,7 +125,7 @@ class ShardedLinearizer:
                                        stacked buffer (on GPUs: gp_vgicp_batch_issue_linearize with out_dev = view pointer)
     """
 
-    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None):
+    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False):
         """stream: the torch.cuda.Stream the `issue` callback launches its kernels on (a torch.cuda.ExternalStream around the
         batch's hipStream_t when the batch owns its stream).  The zeroing of the stack, the kernels and the all-reduce are then
         all ordered on that one stream; None = torch's current stream (CPU / gloo, or a batch created on torch's stream)."""
@@ -129,17 +136,19 @@ class ShardedLinearizer:
         self.issue = issue
         self.group = group
         self.stream = stream
+        self.always_exchange = bool(always_exchange)  # run the zeroing + all-reduce with ONE rank as well (a 1-rank communicator is valid: RCCL smoke on a 1-GPU box)
         self.stacked = torch.zeros((self.total, RECORD_DOUBLES), dtype=torch.float64, device=device)
 
     def _run(self, poses_local):
         import torch.distributed as dist
 
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world > 1:
+        exchange = world > 1 or (self.always_exchange and dist.is_initialized())
+        if exchange:
             self.stacked.zero_()
         if self.end > self.begin:
             self.issue(poses_local, self.stacked[self.begin : self.end])
-        if world > 1:
+        if exchange:
             dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked
 

@@ -26,6 +26,25 @@ std::vector<V> download_array(const void* dev, size_t n, CUstream_st* stream) {
   return out;
 }
 
+// make_sure_loaded_on_gpu (types/gaussian_voxelmap_gpu_funcs.cu:21-40): an offloaded operand is touch()-reloaded before the lookup --
+// "a bit hacky" upstream as well (const_cast), but overlap-based keyframe / loop selection must work with offloading enabled
+void make_sure_loaded_on_gpu(const GaussianVoxelMapGPU* target, CUstream_st* stream) {
+  if (target && !target->loaded_on_gpu()) const_cast<GaussianVoxelMapGPU*>(target)->touch(stream);
+}
+void make_sure_loaded_on_gpu(const PointCloud::ConstPtr& source, CUstream_st* stream) {
+  if (source->points_gpu) return;  // already on the GPU
+  auto source_gpu = std::dynamic_pointer_cast<const PointCloudGPU>(source);
+  if (!source_gpu) {
+    std::cerr << "error: Source point cloud is not a PointCloudGPU!!" << std::endl;  // :34-37
+    abort();
+  }
+  const_cast<PointCloudGPU*>(source_gpu.get())->touch(stream);
+  if (!source->points_gpu) {
+    std::cerr << "error: GPU source points have not been allocated!!" << std::endl;
+    abort();
+  }
+}
+
 }  // namespace
 
 // ---- overlap_gpu (types/gaussian_voxelmap_gpu_funcs.cu:192-406) ----------------------------------------------------------------
@@ -41,10 +60,12 @@ double overlap_gpu(const GaussianVoxelMap::ConstPtr& target, const PointCloud::C
 
 double overlap_gpu(const GaussianVoxelMap::ConstPtr& target_, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& T_target_source, CUstream_st* stream) {
   const GaussianVoxelMapGPU* target = cast_gpu(target_);
-  if (!target || !source->points_gpu) {
-    std::cerr << "error: target voxelmap or source points are not on the GPU!!" << std::endl;  // :194-203
+  if (!target) {
+    std::cerr << "error: Failed to cast target voxelmap to GaussianVoxelMapGPU!!" << std::endl;  // :199-203
     abort();
   }
+  make_sure_loaded_on_gpu(target, stream);  // :205-206, :251-252
+  make_sure_loaded_on_gpu(source, stream);
   int hits = 0;
   check_error << gp_voxelmap_overlap(target->handle(), as_floats(source->points_gpu), static_cast<int>(source->size()), pose16(T_target_source).data(), &hits,
                                      gp_stream(stream));
@@ -56,8 +77,10 @@ double overlap_gpu(const GaussianVoxelMap::ConstPtr& target_, const PointCloud::
 // GaussianVoxelMapGPU-owning PointCloudGPU is not a concept of the mirror, so the target's points are voxelised here at 1.0 m,
 // the resolution the reference's tests use for submaps (test_matching_cost_factors.cpp:84,89)
 double overlap_gpu(const PointCloud::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& T_target_source, CUstream_st* stream) {
-  if (!target->points_gpu || !target->covs_gpu || !source->points_gpu) {
-    std::cerr << "error: target / source points are not on the GPU!!" << std::endl;
+  make_sure_loaded_on_gpu(target, stream);
+  make_sure_loaded_on_gpu(source, stream);
+  if (!target->covs_gpu) {
+    std::cerr << "error: target covariances are not on the GPU!!" << std::endl;
     abort();
   }
   auto map = std::make_shared<GaussianVoxelMapGPU>(1.0f, 8192 * 2, 10, 1e-3, stream);
@@ -68,15 +91,13 @@ double overlap_gpu(const PointCloud::ConstPtr& target, const PointCloud::ConstPt
 // fraction of source points inside a voxel of ANY target (:265-335): one launch for all targets
 double overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& targets_, const PointCloud::ConstPtr& source, const std::vector<Eigen::Isometry3d>& Ts_target_source,
                    CUstream_st* stream) {
-  if (!source->points_gpu) {
-    std::cerr << "error: GPU source points have not been allocated!!" << std::endl;  // :270-273
-    abort();
-  }
+  make_sure_loaded_on_gpu(source, stream);  // :270-273 (abort()s when the source is no PointCloudGPU and has no device points)
   std::vector<const gp_voxelmap_t*> handles(targets_.size());
   std::vector<double> deltas(16 * targets_.size());
   for (size_t i = 0; i < targets_.size(); i++) {
     const GaussianVoxelMapGPU* t = cast_gpu(targets_[i]);
     if (!t) std::cerr << "error: Failed to cast target voxelmap to GaussianVoxelMapGPU!!" << std::endl;  // :278-280 (no abort upstream)
+    make_sure_loaded_on_gpu(t, stream);
     handles[i] = t ? t->handle() : nullptr;
     std::memcpy(deltas.data() + 16 * i, pose16(Ts_target_source[i]).data(), sizeof(double) * 16);
   }
@@ -101,6 +122,8 @@ std::vector<double> overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& t
   for (size_t i = 0; i < P; i++) {
     const GaussianVoxelMapGPU* t = cast_gpu(targets_[i]);
     if (!t) std::cerr << "error: Failed to cast target voxelmap to GaussianVoxelMapGPU!!" << std::endl;
+    make_sure_loaded_on_gpu(t, stream);
+    make_sure_loaded_on_gpu(sources[i], stream);
     handles[i] = t ? t->handle() : nullptr;
     pts[i] = as_floats(sources[i]->points_gpu);
     ns[i] = static_cast<int>(sources[i]->size());
@@ -113,7 +136,9 @@ std::vector<double> overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& t
 }
 
 // ---- merge_frames_gpu (gaussian_voxelmap_gpu_funcs.cu:65-152) --------------------------------------------------------------------
-// the merged cloud is the voxel arrays of the down-sampling map, handed over device to device
+// the merged cloud is the voxel arrays of the down-sampling map, handed over device to device; the CPU attributes (points, covs,
+// intensities) are filled from ONE download of those arrays, so that the result is a complete frame like the reference's
+// (its add_points / add_covs / add_intensities at :146-149 go host -> device; here the device copy exists first)
 PointCloud::Ptr merge_frames_gpu(const std::vector<Eigen::Isometry3d>& poses, const std::vector<PointCloud::ConstPtr>& frames, double downsample_resolution,
                                  CUstream_st* stream) {
   const size_t F = frames.size();
@@ -121,6 +146,7 @@ PointCloud::Ptr merge_frames_gpu(const std::vector<Eigen::Isometry3d>& poses, co
   std::vector<int> ns(F);
   std::vector<double> flat(16 * F);
   for (size_t i = 0; i < F; i++) {
+    make_sure_loaded_on_gpu(frames[i], stream);
     pts[i] = as_floats(frames[i]->points_gpu);
     covs[i] = as_floats(frames[i]->covs_gpu);
     ints[i] = frames[i]->intensities_gpu;
@@ -145,6 +171,7 @@ PointCloud::Ptr merge_frames_gpu(const std::vector<Eigen::Isometry3d>& poses, co
   check_error << gp_memcpy_d2d(it, views.voxel_intensities, 4 * V, gp_stream(stream));
   check_error << gp_stream_synchronize(gp_stream(stream));
   merged->adopt(static_cast<float*>(p), static_cast<float*>(c), static_cast<float*>(it), V);
+  merged->download_attributes(stream);  // points / covs / intensities on the CPU side as well
   check_error << gp_voxelmap_destroy(map);
   return merged;
 }

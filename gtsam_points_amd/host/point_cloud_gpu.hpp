@@ -153,6 +153,47 @@ struct PointCloudGPU : public PointCloud, public OffloadableGPU {
       for (int r = 0; r < 3; r++) points_storage[i](r) = static_cast<double>(tmp[3 * i + r]);
     this->points = points_storage.data();
   }
+  // every attribute that lives on the device only becomes a CPU attribute as well (points Vector4d w = 1, covs Matrix4d with a zero
+  // fourth row / column, intensities double: PointCloudCPU's layouts) and its packed float copy is kept for reload_gpu().
+  // merge_frames_gpu returns its result through this: the reference builds that frame with add_points / add_covs / add_intensities
+  // (gaussian_voxelmap_gpu_funcs.cu:146-149), so callers read merged->points[i] on the host.
+  void download_attributes(CUstream_st* stream = 0) {
+    const size_t n = (size_t)num_points;
+    if (points_gpu && !this->points) {
+      fetch_if_missing(points_host, as_floats(points_gpu), 3, stream);
+      points_storage.assign(n, Eigen::Vector4d(0.0, 0.0, 0.0, 1.0));
+      for (size_t i = 0; i < n; i++)
+        for (int r = 0; r < 3; r++) points_storage[i](r) = static_cast<double>(points_host[3 * i + r]);
+      this->points = points_storage.data();
+    }
+    if (covs_gpu && !this->covs) {
+      fetch_if_missing(covs_host, as_floats(covs_gpu), 9, stream);
+      covs_storage.assign(n, Eigen::Matrix4d::Zero());
+      for (size_t i = 0; i < n; i++)
+        for (int col = 0; col < 3; col++)
+          for (int r = 0; r < 3; r++) covs_storage[i](r, col) = static_cast<double>(covs_host[9 * i + 3 * col + r]);
+      this->covs = covs_storage.data();
+    }
+    if (normals_gpu && !this->normals) {
+      fetch_if_missing(normals_host, as_floats(normals_gpu), 3, stream);
+      normals_storage.assign(n, Eigen::Vector4d::Zero());
+      for (size_t i = 0; i < n; i++)
+        for (int r = 0; r < 3; r++) normals_storage[i](r) = static_cast<double>(normals_host[3 * i + r]);
+      this->normals = normals_storage.data();
+    }
+    if (intensities_gpu && !this->intensities) {
+      fetch_if_missing(intensities_host, intensities_gpu, 1, stream);
+      intensities_storage.assign(n, 0.0);
+      for (size_t i = 0; i < n; i++) intensities_storage[i] = static_cast<double>(intensities_host[i]);
+      this->intensities = intensities_storage.data();
+    }
+    if (times_gpu && !this->times) {
+      fetch_if_missing(times_host, times_gpu, 1, stream);
+      times_storage.assign(n, 0.0);
+      for (size_t i = 0; i < n; i++) times_storage[i] = static_cast<double>(times_host[i]);
+      this->times = times_storage.data();
+    }
+  }
   ~PointCloudGPU() override {
     release(reinterpret_cast<void**>(&times_gpu));
     release(reinterpret_cast<void**>(&points_gpu));
@@ -198,10 +239,15 @@ struct PointCloudGPU : public PointCloud, public OffloadableGPU {
   }
   template <typename T>
   void add_intensities_gpu(const T* intensities, int n, CUstream_st* stream = 0) {
-    intensities_host.assign(intensities, intensities + n);
+    // a null source allocates (zero-filled) like add_times_gpu; the reference's add_intensities(nullptr, n) reaches here
+    intensities_host.assign((size_t)n, 0.0f);
+    if (intensities)
+      for (int i = 0; i < n; i++) intensities_host[i] = static_cast<float>(intensities[i]);
     replace(reinterpret_cast<void**>(&intensities_gpu), sizeof(float) * intensities_host.size());
-    check_error << gp_memcpy_h2d(intensities_gpu, intensities_host.data(), sizeof(float) * intensities_host.size(), gp_stream(stream));
-    check_error << gp_stream_synchronize(gp_stream(stream));  // stream sync per attribute, as the reference does
+    if (n > 0) {
+      check_error << gp_memcpy_h2d(intensities_gpu, intensities_host.data(), sizeof(float) * intensities_host.size(), gp_stream(stream));
+      check_error << gp_stream_synchronize(gp_stream(stream));  // stream sync per attribute, as the reference does
+    }
     generation++;
   }
   template <typename T>

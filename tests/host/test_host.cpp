@@ -212,6 +212,27 @@ int main() {
     auto merged = merge_frames_gpu({I_iso, T_iso}, std::vector<PointCloud::ConstPtr>{target, source4}, 0.25);
     CHECK(merged->size() > 1000 && merged->size() < (size_t)(2 * N) && merged->points_gpu && merged->covs_gpu);
     CHECK(overlap_gpu(voxels, merged, I_iso) > 0.9);  // both frames land on the target's surfaces
+    // the merged frame is a complete frame like the reference's (add_points / add_covs / add_intensities, gaussian_voxelmap_gpu_funcs.cu:146-149):
+    // CPU attributes present and equal to the device arrays
+    CHECK(merged->has_points() && merged->has_covs() && merged->has_intensities());
+    const auto mp = download_points_gpu(*merged);
+    const auto mc = download_covs_gpu(*merged);
+    CHECK(mp.size() == merged->size() && mc.size() == merged->size());
+    bool same_host = true;
+    for (size_t i = 0; i < merged->size(); i++) {
+      for (int r = 0; r < 3; r++) same_host = same_host && merged->points[i](r) == (double)mp[i](r);
+      same_host = same_host && merged->points[i](3) == 1.0 && merged->covs[i](3, 3) == 0.0;
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) same_host = same_host && merged->covs[i](r, c) == (double)mc[i](r, c);
+    }
+    CHECK(same_host);
+    // a null intensity source allocates zeros, like add_times_gpu
+    PointCloudGPU blank;
+    blank.add_points(sp);
+    blank.add_intensities(static_cast<const float*>(nullptr), N);
+    CHECK(blank.has_intensities() && blank.has_intensities_gpu() && blank.intensities[3] == 0.0);
+    const auto zi = download_intensities_gpu(blank);
+    CHECK(zi.size() == (size_t)N && zi[3] == 0.0f && zi.back() == 0.0f);
   }
 
   // OffloadableGPU round trip on a cloud (the reference's own touch() / access counter, types/offloadable.cpp)
@@ -223,6 +244,18 @@ int main() {
     CHECK(source->touch() && source->loaded_on_gpu() && !source->reload_gpu());
     CHECK(OffloadableGPU::current_access_time() == t0 + 1 && source->last_accessed_time() == t0);
     CHECK(overlap_gpu(voxels, source, T_iso) == before);
+    // make_sure_loaded_on_gpu (gaussian_voxelmap_gpu_funcs.cu:21-40): overlap_gpu itself brings offloaded operands back -- every overload
+    CHECK(source->offload_gpu() && voxels->offload_gpu() && !source->loaded_on_gpu() && !voxels->loaded_on_gpu());
+    CHECK(overlap_gpu(voxels, source, T_iso) == before && source->loaded_on_gpu() && voxels->loaded_on_gpu());
+    std::vector<GaussianVoxelMap::ConstPtr> two{voxels, voxels};
+    CHECK(source->offload_gpu() && voxels->offload_gpu());
+    CHECK(std::fabs(overlap_gpu(two, source, std::vector<Eigen::Isometry3d>{T_iso, T_iso}) - before) < 1e-12 && source->loaded_on_gpu() && voxels->loaded_on_gpu());
+    CHECK(source->offload_gpu() && voxels->offload_gpu());
+    const auto r2 = overlap_gpu(two, std::vector<PointCloud::ConstPtr>{source, source}, std::vector<Eigen::Isometry3d>{T_iso, T_iso});
+    CHECK(r2.size() == 2 && r2[0] == before && r2[1] == before && source->loaded_on_gpu());
+    CHECK(source->offload_gpu());
+    auto m2 = merge_frames_gpu({I_iso}, std::vector<PointCloud::ConstPtr>{source}, 0.25);
+    CHECK(m2->size() > 500 && source->loaded_on_gpu());
   }
 
   // factor through the round-robin pool + the REFERENCE's linearisation hook, as the applications do

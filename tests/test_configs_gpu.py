@@ -5,7 +5,8 @@ run through the C-ABI here and checked against the reference-pinned oracle -- ev
       identity and the C1(b) perturbation: committed golden vectors (tests/golden/make_fixtures.py) + the oracle
   C2  lives in test_vgicp_gpu.py::test_linearity_and_determinism_at_1m (1 M vs 2 M points) and in bench.py
   C3  256-factor submap graph, ONE batched linearise: all 256 factors vs the oracle
-  C4  one GPU's shard of the 4096-factor configuration: 512 factors x 32768 points, all 512 vs the oracle
+  C4  the whole 4096-factor configuration (512 submaps x 32768 points): one plain batch == the in-library 8-shard plan bit for
+      bit, all 4096 records and error evaluations vs the oracle
   C5  k-NN covariances of 1 M points + the GICP linearise of 1 M vs 1 M points
   +   covariances that are NOT symmetric (lower triangle 1-2 ulp off the upper), the case the symmetrised fixtures never exercise
 
@@ -140,18 +141,86 @@ def test_c3_256_factor_graph_every_factor(gpu):
     assert inl > 0.5 * total  # the graph really overlaps
 
 
-def test_c4_shard_512_factors_every_factor(gpu):
-    """the shard one GPU of eight holds in BASELINE configs[3]: the 512 factors whose sources are submaps 0..63, i.e.
-    pairs[0:512] of the 4096-factor list (8 outgoing factors per source submap), 32768 points per submap, 1.0 m voxels"""
+def test_c4_all_4096_factors_plain_and_sharded(gpu):
+    """BASELINE configs[3], the WHOLE configuration: 4096 factors (512 submaps x 32768 points, 8 outgoing factors per source
+    submap, 1.0 m voxels).  Every factor is linearised twice on the GPU -- through one plain batch of 4096 and through the
+    in-library sharded path (gp_vgicp_multi_batch_* with the 8-shard gp_shard_plan a node of eight GPUs would use; on a 1-GPU box
+    the eight shards share the device, on a multi-GPU node they spread) -- the two must agree bit for bit, and every one of the 4096
+    records and error evaluations is held against the oracle (the loop being replaced:
+    src/gtsam_points/cuda/nonlinear_factor_set_gpu.cpp:64-139)."""
     from gtsam_points_amd import synthetic
+    from gtsam_points_amd.distributed import MultiDeviceBatch, partition_factors
 
-    pairs = synthetic.c4_factor_pairs()[:512]
-    need = sorted({i for p in pairs for i in p})
-    sub = synthetic.make_c4_submaps(need)
-    host = {i: (sub[i][0], sub[i][1]) for i in need}
+    pairs = synthetic.c4_factor_pairs()
+    F = len(pairs)
+    assert F == 4096
+    sub = synthetic.make_c4_submaps(range(synthetic.C4_SUBMAPS))
+    clouds = {i: gpu.PointCloudGPU(sub[i][0], sub[i][1]) for i in range(synthetic.C4_SUBMAPS)}
+    maps = {}
+    for t in sorted({t for t, _ in pairs}):
+        m = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(clouds[t])
+        maps[t] = m
+    factors = [gpu.IntegratedVGICPFactorGPU(t, s, maps[t], clouds[s]) for t, s in pairs]
     deltas = [synthetic.c4_delta(sub, t, s) for t, s in pairs]
-    worst, inl = _check_all_factors(gpu, host, pairs, deltas, 1.0, "C4 shard")
-    assert inl > 0.4 * 512 * synthetic.C4_POINTS
+    rng = np.random.default_rng(77)
+    deltas_e = [d @ expmap(rng.uniform(-0.005, 0.005, 6)) for d in deltas]
+
+    # plain batch: one table of 4096 factors
+    lib = gpu.load()
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch, s = C.c_void_p(), C.c_void_p()
+    gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+    gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+    poses = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas]).copy()
+    poses_e = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas_e]).copy()
+    plain, plain_err = np.zeros((F, 122)), np.zeros(F)
+    gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, plain.ctypes.data), "batch_linearize")
+    gpu._capi.check(lib.gp_vgicp_batch_compute_error(batch, poses.ctypes.data, poses_e.ctypes.data, plain_err.ctypes.data), "batch_error")
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+
+    # the in-library sharded path with the plan of an 8-GPU node
+    parts = partition_factors([synthetic.C4_POINTS] * F, 8)
+    assert [e - b for b, e in parts] == [512] * 8  # equal weights: eight shards of 64 source submaps each
+    shard_of = np.zeros(F, np.int32)
+    for k, (b, e) in enumerate(parts):
+        shard_of[b:e] = k
+    mb = MultiDeviceBatch(factors, shard_of=shard_of, num_shards=8, use_rccl=0)
+    assert mb.num_shards == 8 and all(mb.shard_info(k)["num_factors"] == 512 for k in range(8))
+    sharded = mb.linearize(deltas)
+    sharded_err = mb.compute_error(deltas, deltas_e)
+    assert np.array_equal(sharded, plain), "sharded != unsharded on the whole C4 configuration"
+    assert np.array_equal(sharded_err, plain_err)
+    del mb
+
+    # every factor against the oracle
+    omaps = {}
+    worst, worst_err, inl = 0.0, 0.0, 0
+    per_shard_inl = np.zeros(8)
+    for k, ((t, sidx), delta) in enumerate(zip(pairs, deltas)):
+        if t not in omaps:
+            om = oracle.OracleVoxelMap(1.0)
+            om.insert(sub[t][0], sub[t][1])
+            assert maps[t].voxelmap_info.num_voxels == om.num_voxels
+            omaps[t] = om
+        fo = oracle.OracleVGICPFactor(omaps[t], sub[sidx][0], sub[sidx][1], oracle.max_threads())
+        Lo = fo.linearize(delta)
+        L = gpu.LinearizedSystem6.from_doubles(plain[k])
+        assert L.num_inliers == Lo.num_inliers, k
+        inl += L.num_inliers
+        per_shard_inl[k // 512] += L.num_inliers
+        if Lo.num_inliers == 0:
+            continue
+        for blk in BLOCKS:
+            worst = max(worst, rel_err(getattr(L, blk), getattr(Lo, blk)))
+        assert abs(L.error - Lo.error) <= PARITY_TOL * abs(Lo.error), k
+        eo = fo.error(deltas_e[k])
+        worst_err = max(worst_err, abs(plain_err[k] - eo) / abs(eo))
+    assert worst <= PARITY_TOL, f"C4: worst relative error over 4096 factors {worst:.3e}"
+    assert worst_err <= PARITY_TOL, f"C4: worst error-evaluation mismatch over 4096 factors {worst_err:.3e}"
+    frac = per_shard_inl / (512 * synthetic.C4_POINTS)
+    assert inl > 0.4 * F * synthetic.C4_POINTS and frac.min() > 0.3, frac  # every shard really overlaps
 
 
 # ---- C5 ---------------------------------------------------------------------------------------------------------------------

@@ -134,3 +134,31 @@ def test_voxelmap_clone(gpu, kitti00):
     rec = gpu._capi.Linearized6()
     gpu._capi.check(lib.gp_vgicp_factor_linearize(f._h, gpu.types._pose16(delta), C.byref(rec)), "linearize")
     assert bytes(rec) == recs[0]
+
+
+def test_bench_step_through_rccl_with_one_rank(gpu):
+    """bench.py's N > 1 code path (torch.distributed backend "nccl" = RCCL, ShardedLinearizer, all-reduce of the zeroed record stack, the
+    sharded C4 leg) with world_size 1: the RCCL / environment failures a gloo rehearsal cannot catch (communicator creation with
+    HSA_ENABLE_IPC_MODE_LEGACY=0, device binding, a 1-rank ncclAllReduce on the stream the kernels are issued on) surface here, on a
+    1-GPU box.  The record that comes out must match the reference-pinned oracle like the plain synchronous call's."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GP_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--source-points", "200000", "--target-points", "400000",
+           "--cpu-seconds", "1", "--c4-steps", "2", "--no-configs", "--kernel-iters", "5"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 1 and "nccl" in r["config"]["exchange"]
+    par = r["parity_vs_oracle"]
+    assert par["num_inliers_equal"] and max(par[k] for k in ["H_target", "H_source", "H_target_source", "b_target", "b_source", "error"]) < 1e-6
+    assert r["c4"]["factors"] == 4096 and r["c4"]["allreduce_ms"] > 0 and 0.3 < r["c4"]["inlier_fraction"] < 0.9
