@@ -44,6 +44,20 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
 
 
+KERNEL_NAMES = {
+    12: "vgicp_stream_kernel<linearise, non-temporal source stream, in-argument descriptor> (gp_vgicp_stream.hpp): 1024 workgroups, balanced chunk plan",
+    11: "vgicp_pipeline2_kernel<4 chunks/wave, non-temporal source stream, in-argument descriptor> (gp_vgicp_tile2.hpp)",
+    8: "vgicp_pipeline_kernel<look-ahead> (gp_vgicp_tile.hpp)",
+    2: "vgicp_pipeline_kernel<hashed line table> (gp_vgicp_tile.hpp)",
+}
+
+
+def _effective_kernel(lib, batch):
+    v = C.c_int(-1)
+    lib.gp_vgicp_batch_get_tuning(batch, 6, C.byref(v))  # GP_TUNE_EFFECTIVE_KERNEL
+    return v.value
+
+
 def _load_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), or None.
     bench.py cannot collect PMC counters itself; scripts/gpu_check.sh does, in separate rocprofv3 --pmc passes,
@@ -272,7 +286,7 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
         alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
         npts = int(lib.gp_vgicp_batch_total_points(batch))
         lib.gp_vgicp_batch_destroy(batch)
-        roof = dict(bound="hbm", kernel="vgicp_pipeline2_kernel (batched tile table)" if F > 1 else "vgicp_pipeline2_kernel (in-argument descriptor)",
+        roof = dict(bound="hbm", kernel="vgicp_stream_kernel (batched tile table)" if F > 1 else "vgicp_stream_kernel (in-argument descriptor)",
                     achieved=round(alg / (b.value * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (b.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     algorithmic_bytes=alg, kernel_ms=round(b.value, 5), finalize_kernel_ms=round(c.value, 5), device_pass_ms=round(a.value, 5), traffic=None)
         return recs, ms_copy, ms_view, npts, roof
@@ -527,9 +541,23 @@ def main():
     _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pose.ctypes.data, args.kernel_iters, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
     alg_bytes = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
+    # the same kernel INSIDE the synchronous step (behind the queue the host leaves idle between two passes): HIP events around the two kernels of
+    # every pass of a second, untimed loop of the same steps (GP_TUNE_TIMING; the events are not in the timed region above)
+    in_step_tile, in_step_fin = None, None
+    if not dist_on:
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_TIMING, 1), "timing")
+        tt, tf = [], []
+        a_, b_ = C.c_float(), C.c_float()
+        for _ in range(max(args.steps, 20)):
+            step()
+            lib.gp_vgicp_batch_last_kernel_ms(batch, C.byref(a_), C.byref(b_))
+            tt.append(a_.value)
+            tf.append(b_.value)
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_TIMING, 0), "timing")
+        in_step_tile, in_step_fin = float(np.mean(tt)), float(np.mean(tf))
     roofline = dict(
         bound="hbm",
-        kernel="vgicp_pipeline2_kernel<4 chunks/wave, non-temporal source stream, in-argument descriptor> (gp_vgicp_tile2.hpp)",
+        kernel=KERNEL_NAMES.get(_effective_kernel(lib, batch), "?"),
         achieved=round(achieved, 2),
         peak=HBM_PEAK_GBS,
         unit="GB/s",
@@ -538,8 +566,12 @@ def main():
         traffic_source=_load_traffic()[1],
         algorithmic_bytes=alg_bytes,
         kernel_ms=round(ms_main.value, 5),
-        kernel_ms_note="HIP events over back-to-back launches on the launch stream; behind the idle queue of a synchronous step the same kernel takes "
-                       "1.3-1.5 us longer (rocprofv3 per-dispatch durations by launch pattern: profiles/r02_kernel_trace_split.txt, DESIGN.md section 6)",
+        kernel_ms_in_step=round(in_step_tile, 5) if in_step_tile else None,
+        frac_in_step=round(alg_bytes / (in_step_tile * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if in_step_tile else None,
+        finalize_kernel_ms_in_step=round(in_step_fin, 5) if in_step_fin else None,
+        kernel_ms_note="kernel_ms / frac: HIP events over back-to-back launches on the launch stream (the kernel at the device's sustained state); kernel_ms_in_step / "
+                       "frac_in_step: HIP events around the same kernel inside synchronous steps, i.e. behind the queue the host leaves idle between two passes "
+                       "(a second, untimed loop of the same steps); the rocprofv3 --stats average of this command mixes both launch patterns (profiles/, DESIGN.md section 6)",
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
     )
@@ -615,7 +647,7 @@ def main():
             scaling="weak",
             vs_baseline=None,
             dtype="f64",
-            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel variant 11)",
+            dtype_note="transform, fused covariance, its inverse, residual and all reductions in f64; the outer products after the inverse in f32 (kernel family GP_KERNEL_STREAM)",
             data="synthetic",
             config=dict(
                 workload="BASELINE configs[1]: single VGICP factor per GPU, 1M synthetic source pts vs 2M-pt GaussianVoxelMap @0.5 m",

@@ -177,18 +177,27 @@ _SIGNATURES = {
     "gp_gicp_factor_destroy": (C.c_int, [C.c_void_p]),
     "gp_gicp_factor_linearize": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(Linearized6)]),
     "gp_gicp_factor_compute_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "gp_debug_set_variant": (C.c_int, [C.c_int]),
+    "gp_point_grid_create_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_estimate_covariances_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p]),
+    "gp_gicp_factor_create_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    # per-handle tuning (no process-global switches)
+    "gp_vgicp_batch_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gp_vgicp_batch_get_tuning": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "gp_vgicp_batch_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gp_vgicp_factor_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gp_voxelmap_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gp_vgicp_batch_set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_debug_expand_rigid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gp_debug_set_stagger": (C.c_int, [C.c_int]),
-    "gp_debug_set_map_build": (C.c_int, [C.c_int]),
     "gp_trim_device_cache": (C.c_int, []),
-    "gp_debug_set_xcd_chunk": (C.c_int, [C.c_int]),
-    "gp_debug_set_tile_interleave": (C.c_int, [C.c_int]),
-    "gp_debug_set_knn_structure": (C.c_int, [C.c_int]),
-    "gp_debug_knn_counters": (C.c_int, [C.c_int, C.c_void_p]),
-    "gp_debug_set_trace_buffer": (C.c_int, [C.c_void_p]),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
+
+# tuning keys / kernel families of include/gtsam_points_hip.h
+GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM = 0, 2, 3, 8, 11, 12
+GP_TUNE_KERNEL, GP_TUNE_SOURCE_POLICY, GP_TUNE_XCD_CHUNK, GP_TUNE_STAGGER, GP_TUNE_TILE_INTERLEAVE, GP_TUNE_BALANCE, GP_TUNE_EFFECTIVE_KERNEL = 0, 1, 2, 3, 4, 5, 6
+GP_TUNE_TIMING = 7
+GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32
+KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM]
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES.keys()) + ["gp_linearized6_to_f32"])
 

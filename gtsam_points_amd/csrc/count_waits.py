@@ -10,7 +10,7 @@ import sys
 
 name, inside, counts = None, False, {}
 for line in open(sys.argv[1]):
-    m = re.match(r"^(_ZN2gp22vgicp_pipeline2_kernel\w+):", line)
+    m = re.match(r"^(_ZN2gp(?:22vgicp_pipeline2_kernel|19vgicp_stream_kernel)\w+):", line)
     if m:
         name = m.group(1)
         counts[name] = 0

@@ -250,6 +250,7 @@ struct gp_voxelmap {
   gp::DeviceArray gblocks;  // occupancy-block grid (gp::GridBlock[gdim0 * gdim1 * gdim2]); empty when the box is too large
   int glo[3] = {0, 0, 0}, gdim[3] = {0, 0, 0};
   bool has_grid = false;
+  bool force_hashed_build = false;  // gp_voxelmap_set_tuning(GP_TUNE_MAP_BUILD): the next insert() uses the hashed build
 
   // offloaded copies (OffloadableGPU)
   bool offloaded = false;

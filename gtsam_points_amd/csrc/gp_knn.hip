@@ -1284,7 +1284,6 @@ struct gp_grid_level {
   }
 };
 
-static unsigned long long* g_knn_counters = nullptr;  // device buffer of 8 counters, or null (gp_debug_knn_counters)
 
 struct gp_point_grid {
   // default: the binned structure (gp_binning.hpp) + the cell-sorted copy of the points, in up to kMaxLevels levels (cell x4 each)
@@ -1301,6 +1300,8 @@ struct gp_point_grid {
   // fallback for clouds whose bounding box is too large for the block grid: hashed multi-level grid
   std::vector<std::unique_ptr<gp_grid_level>> levels;
   hipStream_t stream = nullptr;
+  int structure = 0;                       // GP_TUNE_KNN_STRUCTURE value the grid was created with (per structure, nothing process-global)
+  unsigned long long* counters = nullptr;  // caller's device buffer of 8 work counters, or null (gp_point_grid_create_ex; measurement only)
   gp::SearchView view() const {
     gp::SearchView v{};
     v.binned = binned ? (int)bin_levels.size() : 0;
@@ -1316,7 +1317,7 @@ struct gp_point_grid {
         v.bins[l].n = b.bins.num_binned;
         v.bins[l].super = b.super.as<unsigned long long>();
         for (int a = 0; a < 3; a++) v.bins[l].sdim[a] = b.sdim[a];
-        v.bins[l].counters = g_knn_counters;
+        v.bins[l].counters = counters;
       }
     } else {
       v.hashed.num_levels = (int)levels.size();
@@ -1326,9 +1327,6 @@ struct gp_point_grid {
   }
 };
 
-static bool g_force_hashed_grid = false;  // gp_debug_set_knn_structure: A/B and tests of the fallback
-static bool g_knn_untiled = true;         // false (gp_debug_set_knn_structure(3)): row-tiled covariance pass in front of the per-lane search (measured slower)
-static int g_knn_levels = 1;  // binned levels of the next grid (cell size x4 each); the blocks of the last one serve as the coarse level
 
 struct gp_gicp_factor {
   gp_point_grid* grid = nullptr;
@@ -1440,12 +1438,23 @@ extern "C" {
 
 // levels: cell_size, 4 cell_size, 16 cell_size (coarser levels only when the cloud is large enough to need them)
 int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_stream_t stream, gp_point_grid_t** out) {
+  return gp_point_grid_create_ex(points_dev, n, cell_size, 0, nullptr, stream, out);
+}
+
+// structure: GP_TUNE_KNN_STRUCTURE value (0 binned + per-lane search, 1 hashed multi-level grid, 3 row-tiled covariance pass first, 4 two binned
+// levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
+int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
+  if (structure != 0 && structure != 1 && structure != 3 && structure != 4) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4}");
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
-  if (n > 0 && !g_force_hashed_grid) {
+  g->structure = structure;
+  g->counters = counters_dev;
+  const bool force_hashed_grid = structure == 1;
+  const int knn_levels = structure == 4 ? 2 : 1;  // binned levels (cell size x4 each); the blocks of the last one serve as the coarse level
+  if (n > 0 && !force_hashed_grid) {
     // binned levels h, 4h, 16h (one level for small clouds and for radius-bounded searches, which never leave the first shells)
-    const int want_levels = (n > 4096 && g_knn_levels > 1) ? std::min(g_knn_levels, gp::kMaxLevels) : 1;
+    const int want_levels = (n > 4096 && knn_levels > 1) ? std::min(knn_levels, gp::kMaxLevels) : 1;
     int rc = GP_OK;
     bool ok = true;
     double h = cell_size;
@@ -1541,31 +1550,6 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
   return GP_OK;
 }
 
-// measurement hook: start (enable != 0: zero the counters and count from now on) / stop-and-read (enable == 0) the work counters of the
-// binned search: out[0..5] = {shell walks (a query counts once per stage it walks), f32 distance evaluations, f64 distance evaluations,
-// block entries read, occupied cells visited, octant stages (1-NN)}.  Structures created while counting carry the counter pointer.
-int gp_debug_knn_counters(int enable, unsigned long long* out) {
-  if (enable) {
-    if (!g_knn_counters) GP_HIP(hipMalloc(reinterpret_cast<void**>(&g_knn_counters), sizeof(unsigned long long) * 8));
-    GP_HIP(hipMemset(g_knn_counters, 0, sizeof(unsigned long long) * 8));
-    return GP_OK;
-  }
-  if (g_knn_counters) {
-    GP_HIP(hipDeviceSynchronize());
-    if (out) GP_HIP(hipMemcpy(out, g_knn_counters, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost));
-    (void)hipFree(g_knn_counters);
-    g_knn_counters = nullptr;
-  }
-  return GP_OK;
-}
-
-int gp_debug_set_knn_structure(int mode) {
-  g_force_hashed_grid = mode == 1;
-  g_knn_untiled = mode != 3;
-  g_knn_levels = mode == 4 ? 2 : 1;
-  return GP_OK;
-}
-
 int gp_point_grid_destroy(gp_point_grid_t* g) {
   if (!g) return GP_OK;
   // the arenas come from the stream-ordered pool and are returned to it in the order of the creation stream: searches issued
@@ -1593,6 +1577,11 @@ int gp_knn_search(const gp_point_grid_t* g, const float* queries_dev, int nq, in
 }
 
 int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_size, float* covs_dev, int* num_short, gp_stream_t stream) {
+  return gp_estimate_covariances_ex(points_dev, n, k, cell_size, covs_dev, num_short, 0, nullptr, stream);
+}
+
+int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cell_size, float* covs_dev, int* num_short, int structure, unsigned long long* counters_dev,
+                               gp_stream_t stream) {
   if (!points_dev || n < 0 || k <= 0 || k > 32 || !covs_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_estimate_covariances: bad arguments (1 <= k <= 32)");
   if (num_short) *num_short = 0;
   if (n == 0) return GP_OK;
@@ -1601,7 +1590,7 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
   const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  GP_TRY(gp_point_grid_create(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, stream, &g));
+  GP_TRY(gp_point_grid_create_ex(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, &g));
   const double t1 = now();
   gp::DeviceArray d_short;
   int rc = d_short.alloc_async(sizeof(int), s);
@@ -1614,7 +1603,7 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
     gp::DeviceArray todo;  // [nq] positions + the count behind them
     gp::DeviceArray scan_buf;  // RowScanOut: kept [kTileKeep][nq] | bound [nq] | safe [nq]
     const int* d_todo = nullptr;
-    if (nq > 0 && g->binned && !g_knn_untiled && k <= 10) {
+    if (nq > 0 && g->binned && g->structure == 3 && k <= 10) {
       // tiled pass over the occupied cell rows of the finest level; what it cannot settle is listed for the per-lane pass
       rc = todo.alloc_async(sizeof(int) * ((size_t)nq + 1), s);
       if (rc == GP_OK) rc = scan_buf.alloc_async(sizeof(int) * (size_t)(gp::kTileKeep + 2) * nq, s);
@@ -1666,6 +1655,11 @@ int gp_estimate_covariances(const float* points_dev, int n, int k, double cell_s
 
 int gp_gicp_factor_create(const float* target_points_dev, const float* target_covs_dev, int n_target, const float* points_dev, const float* covs_dev, int n,
                           double max_correspondence_distance_sq, gp_stream_t stream, gp_gicp_factor_t** out) {
+  return gp_gicp_factor_create_ex(target_points_dev, target_covs_dev, n_target, points_dev, covs_dev, n, max_correspondence_distance_sq, 0, nullptr, stream, out);
+}
+
+int gp_gicp_factor_create_ex(const float* target_points_dev, const float* target_covs_dev, int n_target, const float* points_dev, const float* covs_dev, int n,
+                             double max_correspondence_distance_sq, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_gicp_factor_t** out) {
   if (!target_points_dev || !target_covs_dev || !points_dev || !covs_dev || n < 0 || n_target < 0 || !(max_correspondence_distance_sq > 0.0) || !out)
     return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_gicp_factor_create: bad arguments");
   auto* f = new gp_gicp_factor;
@@ -1673,7 +1667,7 @@ int gp_gicp_factor_create(const float* target_points_dev, const float* target_co
   // finest cell = 1/4 of the correspondence radius (coarser levels x4, x16); the max-distance bound ends every search
   // cell = 1/4 of the correspondence radius: the fine shells 0 and 1 settle the well-matched points, and one block edge = the
   // radius, so the block walk behind them ends at the first block shell at the latest
-  int rc = gp_point_grid_create(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 4.0, stream, &f->grid);
+  int rc = gp_point_grid_create_ex(target_points_dev, n_target, std::sqrt(max_correspondence_distance_sq) / 4.0, structure, counters_dev, stream, &f->grid);
   if (rc != GP_OK) {
     delete f;
     return rc;

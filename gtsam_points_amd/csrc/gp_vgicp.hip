@@ -24,6 +24,7 @@
 #include "gp_host.hpp"
 #include "gp_vgicp_tile.hpp"
 #include "gp_vgicp_tile2.hpp"
+#include "gp_vgicp_stream.hpp"
 
 namespace gp {
 
@@ -96,8 +97,12 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorD
   TileDesc tile;
   if (inl.use) {
     tile.factor = 0;
-    tile.begin = tile_idx * inl.tile_points;
-    tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+    if (inl.tile_points > 0) {
+      tile.begin = tile_idx * inl.tile_points;
+      tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
+    } else {  // the table of a single-factor stream batch is its plan (gp_vgicp_stream.hpp): tiles of different sizes, XCD-major
+      plan_tile(inl.plan, tile_idx / inl.plan.wgs_per_xcd, tile_idx % inl.plan.wgs_per_xcd, &tile.begin, &tile.count);
+    }
     tile.row = tile_idx;
   } else {
     tile = tiles[tile_idx];
@@ -545,6 +550,17 @@ int launch_finalize_error_single(hipStream_t stream, const double* partials, int
 
 struct gp_vgicp_batch;
 
+// Per-batch tuning (gp_vgicp_batch_set_tuning / gp_vgicp_factor_set_tuning; keys GP_TUNE_* of gtsam_points_hip.h).  Nothing here is process-global:
+// two batches on two threads may run different kernels side by side (re-entrant across handles).
+struct gp_vgicp_tuning {
+  int kernel = GP_KERNEL_STREAM;  // GP_KERNEL_*: which tile kernel family the batch prefers (it falls back where that family does not apply)
+  int source_policy = 0;          // cache policy of the source stream: 0 = per batch (non-temporal iff no two factors share a source cloud), 1 = default, 2 = non-temporal
+  int xcd_chunk = 0;              // workgroup -> tile map: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles dealt round robin
+  int stagger = 0;                // round-2 kernels: odd wave slots start `stagger` x 512 clocks late
+  int tile_interleave = 0;        // consecutive factors that share a source cloud take turns tile by tile
+  int balance = 1;                // stream kernel, single factor: 1 = the last round of workgroups takes the lighter share, 0 = flat floor split
+};
+
 struct gp_vgicp_factor {
   const gp_voxelmap* target = nullptr;
   const float* points = nullptr;
@@ -560,6 +576,7 @@ struct gp_vgicp_factor {
   gp_temp_buffer* temp_buffer = nullptr;
   bool owns_temp_buffer = false;
   gp_vgicp_batch* self_batch = nullptr;  // lazily built batch of one, used by the per-factor entry points
+  gp_vgicp_tuning tuning;                // what the self batch is created with (gp_vgicp_factor_set_tuning)
 };
 
 struct gp_vgicp_batch {
@@ -567,7 +584,15 @@ struct gp_vgicp_batch {
   hipStream_t stream = nullptr;
   gp_temp_buffer* temp_buffer = nullptr;  // partials arena when provided (per-stream scratch), else own
   int num_tiles = 0;
-  int variant = -1;       // kernel variant the tile table was built for
+  gp_vgicp_tuning tuning;
+  int family = 0;         // GP_KERNEL_* the tile table was built for (tuning.kernel after the fallbacks)
+  bool nt = false;        // source stream non-temporal (tuning.source_policy resolved)
+  bool any_sv = false;    // some factor validates surfaces
+  gp::StreamPlan plan{};  // stream kernel, single factor: how the chunks are dealt (also written into the tile table)
+  unsigned long long* trace = nullptr;  // timeline build of the tile kernel: [2048][16] uint64 device buffer (gp_vgicp_batch_set_trace_buffer)
+  bool timing = false;                  // GP_TUNE_TIMING: the synchronous linearise brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms)
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_tile_ms = 0.f, last_finalize_ms = 0.f;
   int tile_points = 0;
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
@@ -592,59 +617,22 @@ struct gp_vgicp_batch {
 
 namespace {
 
-// Kernel variant (gp_debug_set_variant):
-//   0  reference-shaped kernel (reference bucket table, one point per lane per stride, all modes) -- also the cross-check
-//   1  pipeline kernel, f64 throughout, hashed line table          (the round-1 default)
-//   2  pipeline kernel, f32 outer products / accumulators on f64-accurate M, r, q, hashed line table
-//   3  pipeline kernel, f64 throughout, occupancy-block grid
-//   4  pipeline kernel, f32 outer products, occupancy-block grid    (the default until the look-ahead kernel, variant 8)
-// Variants 3 / 4 fall back to 1 / 2 for a batch in which some map has no grid (bounding box beyond the block budget).
-// Measured and removed in round 2: the deep pipeline (lookups of the next chunks overlapped with the
-// algebra) and the source-frame formulation (per-voxel pre-pass).
-//      Variant 4 starts lean (the prologue requests chunk 0 only; chunk 1 follows the first lookup) and picks the tile size from
-//      the batch: the largest of 1024 / 512 / 256 points that still gives >= 768 tiles (3/4 of the 1024 resident workgroups),
-//      so that a 15 k-point scan is not left to 15 workgroups.
-//   5  as 4 without the lean start, always 1024-point tiles (the first round-2 kernel; A/B)
-//   6 / 7  as 4 with 512- / 256-point tiles forced (A/B)
-//   8  as 4 with the look-ahead lookup (AHEAD in gp_vgicp_tile.hpp): hop 1 of chunk j+1 travels with hop 2 of chunk j.   (default)
-//      Same arithmetic in the same order as 4: bit-identical results.  C2 -1..3 %, C3 -5 %, C4 -1.5 % tile-kernel time.
-//   9 / 10 / 11  the second-generation linearise kernel (gp_vgicp_tile2.hpp: saddr addressing, 12-B LDS-DMA rows, scalar descriptor path,
-//      f64 diet, points-first lean start, f32 in-lane reduction sums) with the default / the non-temporal / the per-batch policy on
-//      the source stream, for the linearise and the error evaluation; maps without a grid and factors with surface validation run as
-//      variant 8.
-//      11 is the default: C2 14.5 -> 12.3 us (0.48 -> 0.57 of 8 TB/s), C3 61 -> 55 us, C4 shard 230 -> 215 us (profiles/r02_gen2_ab.txt).
-int g_variant = 11;
+// Tile-kernel families (GP_KERNEL_*, per batch: gp_vgicp_batch_set_tuning(GP_TUNE_KERNEL)):
+//   GP_KERNEL_REFERENCE (0)   reference-shaped kernel (reference bucket table, one point per lane per stride, all modes): the in-library cross-check and
+//                             the 92-sum path of non-orthonormal poses
+//   GP_KERNEL_HASHED (2)      round-1/2 pipeline kernel over the hashed line table, f32 outer products: what a map without a block grid runs
+//   GP_KERNEL_GRID_F64 (3)    round-2 pipeline kernel over the block grid, f64 throughout (parity 4e-10 / 1e-15 instead of 6e-9)
+//   GP_KERNEL_LOOKAHEAD (8)   round-2 pipeline kernel, block grid, f32 outer products, look-ahead lookup: what maps with >= 2^26 voxels run
+//   GP_KERNEL_GEN2 (11)       second generation (gp_vgicp_tile2.hpp): fixed tiles of 1024 / 512 / 256 points -- kept for the A/B of round 3
+//   GP_KERNEL_STREAM (12)     third generation (gp_vgicp_stream.hpp): per-wave chunk streams, balanced single-factor launches, surface validation
+//                             in the ring.  Default.
+// A family that does not apply to a batch (no block grid, records beyond 32-bit offsets, surface validation on GEN2) falls back to LOOKAHEAD, and
+// that to HASHED.  Measured and removed (numbers: DESIGN.md section 8 of rounds 1-3): the f64 hashed kernel, the non-lean start, forced 512- / 256-point
+// tiles, the deep pipeline, the source-frame formulation.
 const bool g_zero_copy_poses = [] {  // A/B switch of the pose hand-over of the synchronous batched calls (stage_poses)
   const char* e = getenv("GP_POSES_ZERO_COPY");
   return !e || atoi(e) != 0;
 }();
-int g_stagger = 0;
-int g_xcd_chunk = 0;
-int g_tile_interleave = 0;  // measured on C3 / C4: no effect beyond noise (0.2305 vs 0.2318 ms on the C4 shard), so the plain factor-major order stays
-bool g_trace_on = false;
-unsigned long long* g_trace_host = nullptr;  // host copy of the trace buffer pointer (finalize stamps go to row 2047)
-struct VariantDesc {
-  bool f32, grid, lean;
-  int ppt;  // 64-point chunks per wave (0 = chosen per batch)
-  bool ahead = false;  // hop 1 of the next chunk travels with hop 2 of this one (linearise only)
-  int gen2 = 0;        // vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp) for the linearise, else as variant 8; source stream policy: 1 default,
-                       // 2 non-temporal, 3 chosen per batch (non-temporal when no two factors of the batch read the same source cloud)
-};
-VariantDesc variant_desc(int v) {
-  switch (v) {
-    case 1: return {false, false, false, 4};
-    case 2: return {true, false, false, 4};
-    case 3: return {false, true, false, 4};
-    case 5: return {true, true, false, 4};
-    case 6: return {true, true, true, 2};
-    case 7: return {true, true, true, 1};
-    case 8: return {true, true, true, 0, true};
-    case 9: return {true, true, true, 0, true, 1};
-    case 10: return {true, true, true, 0, true, 2};
-    case 11: return {true, true, true, 0, true, 3};
-    default: return {true, true, true, 0};
-  }
-}
 constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
 constexpr int kFinalizePartsMax = 16;
 static int finalize_parts() {  // workgroups sharing the finalize of a synchronous single-factor call (vgicp_finalize_rigid_kernel)
@@ -656,6 +644,7 @@ static int finalize_parts() {  // workgroups sharing the finalize of a synchrono
   return v;
 }
 constexpr int kFinalizeSplitTiles = 256;  // ... when the factor has at least this many tiles
+constexpr int kResidentWorkgroups = 1024;  // 256 compute units x 4 workgroups of the tile kernels (34-40 KB of LDS, <= 128 VGPRs)
 
 // where a launch takes its poses from
 struct PoseSource {
@@ -664,33 +653,44 @@ struct PoseSource {
   gp::InlinePoses inl{};
 };
 
+// Stream kernel, ONE factor of n points: the launch geometry (number of workgroups, a multiple of 8) and how the chunks are dealt.
+// At most one resident round of workgroups whatever n is; below that, four chunks per workgroup (one per wave).
+int make_stream_plan(int n, bool late_light, gp::StreamPlan* p) {
+  const int C = n / gp::kChunkPoints;
+  int G = std::min(kResidentWorkgroups, (std::max((C + 3) / 4, 1) + gp::kNumXCD - 1) / gp::kNumXCD * gp::kNumXCD);
+  const int gx = G / gp::kNumXCD;
+  p->tail = n % gp::kChunkPoints;
+  p->cx = C / gp::kNumXCD;
+  p->cr = C % gp::kNumXCD;
+  p->wgs_per_xcd = gx;
+  const int cmax = p->cx + (p->cr ? 1 : 0);
+  // the last round: the workgroups the dispatcher places when every compute unit of the XCD (32) already holds the earlier ones
+  const int cus_per_xcd = kResidentWorkgroups / 4 / gp::kNumXCD;
+  int late = std::min(gx, cus_per_xcd), early = gx - late;
+  int hi = (cmax + gx - 1) / gx;
+  if (!late_light || early == 0 || p->cx - early * hi < late * (hi - 1)) {  // the late share would fall below hi - 1 per workgroup: flat split instead
+    early = 0;
+    late = gx;
+    hi = 0;
+  }
+  p->early_wgs = early;
+  p->hi = hi;
+  const int rem0 = p->cx - early * hi, rem1 = rem0 + 1;
+  p->lo0 = rem0 / late;
+  p->extra0 = rem0 % late;
+  p->lo1 = rem1 / late;
+  p->extra1 = rem1 % late;
+  return G;
+}
+
 int build_table(gp_vgicp_batch* b) {
   const int F = (int)b->factors.size();
   std::vector<gp::FactorDesc> descs((size_t)F);
   std::vector<gp::TileDesc> tiles;
   b->total_points = 0;
-  b->variant = g_variant;
-  {
-    int ppt = b->variant >= 1 ? variant_desc(b->variant).ppt : kPipelineChunks;
-    bool all_grid = true;
-    for (const auto* f : b->factors) all_grid = all_grid && f->target->has_grid;
-    if (!all_grid) ppt = kPipelineChunks;  // the hashed-line-table kernel exists for 1024-point tiles only
-    if (ppt == 0) {  // per batch: the largest tile that still fills 3/4 of the chip's resident workgroups
-      ppt = 1;
-      for (int cand : {4, 2}) {
-        int64_t tiles = 0;
-        for (const auto* f : b->factors) tiles += (f->n + 256 * cand - 1) / (256 * cand);
-        if (tiles >= 768) {
-          ppt = cand;
-          break;
-        }
-      }
-    }
-    b->ppt = ppt;
-    b->tile_points = 64 * 4 * ppt;
-  }
   b->use_grid = true;
-  b->gen2_ok = true;
+  bool offsets32 = true;
+  b->any_sv = false;
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -702,11 +702,53 @@ int build_table(gp_vgicp_batch* b) {
     d.n = f->n;
     d.surface_validation = (f->surface_validation && f->normals) ? 1 : 0;
     if (!d.map.gblocks) b->use_grid = false;
-    if (!d.map.gblocks || (int64_t)d.map.num_voxels * 64 >= (int64_t)1 << 32 || d.surface_validation) b->gen2_ok = false;
-    d.tile_begin = (int)tiles.size();
-    for (int p = 0; p < f->n; p += b->tile_points) tiles.push_back(gp::TileDesc{i, p, std::min(b->tile_points, f->n - p), (int)tiles.size()});
-    d.tile_count = (int)tiles.size() - d.tile_begin;
+    if ((int64_t)d.map.num_voxels * 64 >= (int64_t)1 << 32) offsets32 = false;
+    if (d.surface_validation) b->any_sv = true;
     b->total_points += f->n;
+  }
+  // the family this batch really runs
+  int fam = b->tuning.kernel;
+  if ((fam == GP_KERNEL_STREAM || fam == GP_KERNEL_GEN2) && (!b->use_grid || !offsets32)) fam = GP_KERNEL_LOOKAHEAD;
+  if (fam == GP_KERNEL_GEN2 && b->any_sv) fam = GP_KERNEL_LOOKAHEAD;  // (the second generation has no normals row)
+  if ((fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_GRID_F64) && !b->use_grid) fam = GP_KERNEL_HASHED;
+  b->family = fam;
+  b->gen2_ok = fam == GP_KERNEL_GEN2 || fam == GP_KERNEL_STREAM;
+  // tiles
+  if (fam == GP_KERNEL_STREAM && F == 1) {
+    // one factor: the balanced plan; the table holds the same tiles the in-argument launch derives from the plan (plan_tile)
+    const int G = make_stream_plan(descs[0].n, b->tuning.balance != 0, &b->plan);
+    b->ppt = 4;
+    b->tile_points = 0;
+    descs[0].tile_begin = 0;
+    for (int x = 0; x < gp::kNumXCD; x++)
+      for (int q = 0; q < b->plan.wgs_per_xcd; q++) {
+        int begin = 0, count = 0;
+        gp::plan_tile(b->plan, x, q, &begin, &count);
+        tiles.push_back(gp::TileDesc{0, begin, count, (int)tiles.size()});
+      }
+    descs[0].tile_count = G;
+  } else {
+    int ppt = kPipelineChunks;  // the hashed-line-table, reference-shaped and f64 kernels exist for 1024-point tiles only
+    if (fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_GEN2 || fam == GP_KERNEL_STREAM) {
+      // per batch: the largest tile that still fills 3/4 of the chip's resident workgroups, so that a 15 k-point scan is not left to 15 workgroups
+      ppt = 1;
+      for (int cand : {4, 2}) {
+        int64_t count = 0;
+        for (const auto* f : b->factors) count += (f->n + 256 * cand - 1) / (256 * cand);
+        if (count >= kResidentWorkgroups * 3 / 4) {
+          ppt = cand;
+          break;
+        }
+      }
+    }
+    b->ppt = ppt;
+    b->tile_points = 64 * 4 * ppt;
+    for (int i = 0; i < F; i++) {
+      gp::FactorDesc& d = descs[i];
+      d.tile_begin = (int)tiles.size();
+      for (int p = 0; p < d.n; p += b->tile_points) tiles.push_back(gp::TileDesc{i, p, std::min(b->tile_points, d.n - p), (int)tiles.size()});
+      d.tile_count = (int)tiles.size() - d.tile_begin;
+    }
   }
   b->num_tiles = (int)tiles.size();
   {
@@ -714,8 +756,9 @@ int build_table(gp_vgicp_batch* b) {
     for (const auto& d : descs) srcs.push_back(d.points);
     std::sort(srcs.begin(), srcs.end());
     b->stream_once = b->shares_device_ok && std::adjacent_find(srcs.begin(), srcs.end()) == srcs.end();
+    b->nt = b->tuning.source_policy == 2 || (b->tuning.source_policy == 0 && b->stream_once);
   }
-  if (g_tile_interleave) {
+  if (b->tuning.tile_interleave && !(fam == GP_KERNEL_STREAM && F == 1)) {
     // execution order: consecutive factors that read the SAME source cloud (a submap matched against several targets, BASELINE
     // configs[3]) take turns tile by tile, so the workgroups that run side by side on an XCD read the same source bytes at the same
     // time -- one of them misses L2, the others hit.  Partial rows stay factor-major (TileDesc::row).
@@ -753,10 +796,10 @@ int build_table(gp_vgicp_batch* b) {
   return GP_OK;
 }
 
-// the factor table caches device pointers: rebuild it when the variant changed, a flag or source pointer of a factor changed,
-// or a target map was re-inserted / offloaded / reloaded since (OffloadableGPU protocol)
+// the factor table caches device pointers: rebuild it when the tuning changed (set_tuning marks it dirty), a flag or source pointer of a
+// factor changed, or a target map was re-inserted / offloaded / reloaded since (OffloadableGPU protocol)
 bool table_is_stale(const gp_vgicp_batch* b) {
-  if (b->table_dirty || b->variant != g_variant || b->seen.size() != b->factors.size()) return true;
+  if (b->table_dirty || b->seen.size() != b->factors.size()) return true;
   for (size_t i = 0; i < b->factors.size(); i++)
     if (b->seen[i] != b->factors[i]->generation + b->factors[i]->target->generation) return true;
   return false;
@@ -793,82 +836,92 @@ bool poses_are_rigid(const double* poses_host, size_t F) {
 template <int MODE>
 int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   if (b->num_tiles <= 0) return GP_OK;
-  // the reference-shaped kernels (variant 0, the 92-sum path) keep the contiguous map
-  const int chunk = (MODE == gp::MODE_LIN_GENERAL || b->variant == 0) ? 0 : g_xcd_chunk;
+  const int fam = MODE == gp::MODE_LIN_GENERAL ? GP_KERNEL_REFERENCE : b->family;
+  const bool single_plan = fam == GP_KERNEL_STREAM && b->factors.size() == 1;  // the tile list IS the plan: the contiguous map, whatever xcd_chunk says
+  // the reference-shaped kernels (the 92-sum path included) keep the contiguous map
+  const int chunk = (fam == GP_KERNEL_REFERENCE || single_plan) ? 0 : b->tuning.xcd_chunk;
   const dim3 grid_dim(grid_tiles(b->num_tiles, chunk)), block(gp::kBlockThreads);
   const gp::FactorDesc* fd = b->d_factors.as<gp::FactorDesc>();
   const gp::TileDesc* td = b->d_tiles.as<gp::TileDesc>();
   gp::InlinePoses inl = ps.inl;
-  inl.stagger = g_stagger;
+  inl.stagger = b->tuning.stagger;
   inl.xcd_chunk = chunk;
+  inl.tile_points = b->tile_points;
+  inl.plan = b->plan;
+  inl.trace = b->trace;
+  const bool traced = b->trace != nullptr && inl.use && MODE == gp::MODE_LIN;  // the timeline builds exist for single-factor linearise launches
+#define GP_ARGS grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials
   if constexpr (MODE == gp::MODE_LIN_GENERAL) {
-    // the general (non-orthonormal pose) path always uses the reference-shaped kernel
-    hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
-  } else {
-    const VariantDesc vd = variant_desc(b->variant);
-    const bool grid = vd.grid && b->use_grid;
-#define GP_LAUNCH_PIPE(F32, PPT, GRID, TRACE, LEAN)                                                                                                         \
-  hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, F32, PPT, GRID, TRACE, LEAN>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, \
-                     partials)
-    if (b->variant == 0) {
-      hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials);
-    } else if (!grid) {  // hashed line table (variants 1 / 2, or a map without a block grid): 1024-point tiles
-      if (vd.f32) GP_LAUNCH_PIPE(true, 4, false, false, false);
-      else GP_LAUNCH_PIPE(false, 4, false, false, false);
-    } else if (!vd.f32) {
-      GP_LAUNCH_PIPE(false, 4, true, false, false);
-    } else if (!vd.lean) {
-      GP_LAUNCH_PIPE(true, 4, true, false, false);
-    } else if (vd.gen2 && b->gen2_ok) {
-      {
-#define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE)                                                                                                                 \
-  hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<MODE, PPT, NT, INL, TRACE>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials)
-#define GP_LAUNCH_PIPE2_S(PPT, INL, TRACE)       \
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, GP_ARGS);
+  } else if (fam == GP_KERNEL_REFERENCE) {
+    hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, GP_ARGS);
+  } else if (fam == GP_KERNEL_STREAM) {
+#define GP_LAUNCH_STREAM(NT, INL, SV, TRACE) hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, NT, INL, SV, TRACE>), GP_ARGS)
+#define GP_LAUNCH_STREAM_S(INL, SV)              \
   do {                                           \
-    if (nt) GP_LAUNCH_PIPE2(PPT, true, INL, TRACE); \
-    else GP_LAUNCH_PIPE2(PPT, false, INL, TRACE);   \
+    if (b->nt) GP_LAUNCH_STREAM(true, INL, SV, false); \
+    else GP_LAUNCH_STREAM(false, INL, SV, false);      \
   } while (0)
-        const bool nt = vd.gen2 == 2 || (vd.gen2 == 3 && b->stream_once);
-        if (b->ppt == 4 && g_trace_on && inl.use && MODE == gp::MODE_LIN) {
-          if constexpr (MODE == gp::MODE_LIN) GP_LAUNCH_PIPE2_S(4, true, true);
-        } else if (b->ppt == 4) {
-          if (inl.use) GP_LAUNCH_PIPE2_S(4, true, false);
-          else GP_LAUNCH_PIPE2_S(4, false, false);
-        } else if (b->ppt == 2) {
-          if (inl.use) GP_LAUNCH_PIPE2_S(2, true, false);
-          else GP_LAUNCH_PIPE2_S(2, false, false);
-        } else {
-          if (inl.use) GP_LAUNCH_PIPE2_S(1, true, false);
-          else GP_LAUNCH_PIPE2_S(1, false, false);
-        }
+    if (traced && !b->any_sv) {
+      if constexpr (MODE == gp::MODE_LIN) {
+        if (b->nt) GP_LAUNCH_STREAM(true, true, false, true);
+        else GP_LAUNCH_STREAM(false, true, false, true);
+      }
+    } else if (inl.use) {
+      if (b->any_sv) GP_LAUNCH_STREAM_S(true, true);
+      else GP_LAUNCH_STREAM_S(true, false);
+    } else {
+      if (b->any_sv) GP_LAUNCH_STREAM_S(false, true);
+      else GP_LAUNCH_STREAM_S(false, false);
+    }
+#undef GP_LAUNCH_STREAM_S
+#undef GP_LAUNCH_STREAM
+  } else if (fam == GP_KERNEL_GEN2) {
+#define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE) hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<MODE, PPT, NT, INL, TRACE>), GP_ARGS)
+#define GP_LAUNCH_PIPE2_S(PPT, INL)                     \
+  do {                                                  \
+    if (b->nt) GP_LAUNCH_PIPE2(PPT, true, INL, false);  \
+    else GP_LAUNCH_PIPE2(PPT, false, INL, false);       \
+  } while (0)
+    if (b->ppt == 4 && traced) {
+      if constexpr (MODE == gp::MODE_LIN) {
+        if (b->nt) GP_LAUNCH_PIPE2(4, true, true, true);
+        else GP_LAUNCH_PIPE2(4, false, true, true);
+      }
+    } else if (b->ppt == 4) {
+      if (inl.use) GP_LAUNCH_PIPE2_S(4, true);
+      else GP_LAUNCH_PIPE2_S(4, false);
+    } else if (b->ppt == 2) {
+      if (inl.use) GP_LAUNCH_PIPE2_S(2, true);
+      else GP_LAUNCH_PIPE2_S(2, false);
+    } else {
+      if (inl.use) GP_LAUNCH_PIPE2_S(1, true);
+      else GP_LAUNCH_PIPE2_S(1, false);
+    }
 #undef GP_LAUNCH_PIPE2_S
 #undef GP_LAUNCH_PIPE2
-      }
-    } else if (vd.ahead && MODE == gp::MODE_LIN && b->ppt >= 2 && !(g_trace_on && b->ppt == 4)) {
+  } else {
+    // the round-2 family: <MODE, f32 outer products, chunks per wave, block grid, TRACE, lean start, look-ahead lookup>
+#define GP_LAUNCH_PIPE(F32, PPT, GRID, LEAN, AHEAD) hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, F32, PPT, GRID, false, LEAN, AHEAD>), GP_ARGS)
+    if (fam == GP_KERNEL_HASHED) {
+      GP_LAUNCH_PIPE(true, 4, false, false, false);
+    } else if (fam == GP_KERNEL_GRID_F64) {
+      GP_LAUNCH_PIPE(false, 4, true, false, false);
+    } else if (MODE == gp::MODE_LIN && b->ppt >= 2) {  // GP_KERNEL_LOOKAHEAD, linearise
       if constexpr (MODE == gp::MODE_LIN) {
-        if (b->ppt == 4)
-          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 4, true, false, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
-                             ps.d_eval, inl, partials);
-        else
-          hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 2, true, false, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
-                             ps.d_eval, inl, partials);
+        if (b->ppt == 4) GP_LAUNCH_PIPE(true, 4, true, true, true);
+        else GP_LAUNCH_PIPE(true, 2, true, true, true);
       }
-    } else if (vd.ahead && MODE == gp::MODE_LIN && b->ppt == 4) {  // timeline build of the look-ahead kernel
-      if constexpr (MODE == gp::MODE_LIN)
-        hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 4, true, true, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
-                           ps.d_eval, inl, partials);
     } else if (b->ppt == 1) {
-      GP_LAUNCH_PIPE(true, 1, true, false, true);
+      GP_LAUNCH_PIPE(true, 1, true, true, false);
     } else if (b->ppt == 2) {
-      GP_LAUNCH_PIPE(true, 2, true, false, true);
-    } else if (g_trace_on && MODE == gp::MODE_LIN) {  // timeline build of the default kernel (gp_debug_set_trace_buffer)
-      hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<gp::MODE_LIN, true, 4, true, true, true>), grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin,
-                         ps.d_eval, inl, partials);
+      GP_LAUNCH_PIPE(true, 2, true, true, false);
     } else {
-      GP_LAUNCH_PIPE(true, 4, true, false, true);
+      GP_LAUNCH_PIPE(true, 4, true, true, false);
     }
 #undef GP_LAUNCH_PIPE
   }
+#undef GP_ARGS
   GP_HIP(hipGetLastError());
   return GP_OK;
 }
@@ -894,16 +947,18 @@ int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* parti
 
 // device work of one linearisation pass.  rigid == true: 29-sum kernel + adjoint expansion; false: 92-sum kernel
 // (exact for any 3x3 block, like the reference's explicit J_s).
-int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid, gp::DoneFlags done = {}, int parts = 1) {
+int launch_linearize(gp_vgicp_batch* b, const PoseSource& ps, gp_linearized6* out_dev, bool rigid, gp::DoneFlags done = {}, int parts = 1, bool timed = false) {
   if (b->factors.empty()) return GP_OK;
   double* partials = nullptr;
   GP_TRY(partials_ptr(b, &partials));
-  if (rigid) {
-    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
-    return launch_finalize<false>(b, ps, partials, out_dev, done, parts);
-  }
-  GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
-  return launch_finalize<true>(b, ps, partials, out_dev, done);
+  if (timed) GP_HIP(hipEventRecord(b->ev[0], b->stream));
+  if (rigid) GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+  else GP_TRY(launch_tiles<gp::MODE_LIN_GENERAL>(b, ps, partials));
+  if (timed) GP_HIP(hipEventRecord(b->ev[1], b->stream));
+  if (rigid) GP_TRY(launch_finalize<false>(b, ps, partials, out_dev, done, parts));
+  else GP_TRY(launch_finalize<true>(b, ps, partials, out_dev, done));
+  if (timed) GP_HIP(hipEventRecord(b->ev[2], b->stream));
+  return GP_OK;
 }
 
 int launch_error(gp_vgicp_batch* b, const PoseSource& ps, double* out_dev, gp::DoneFlags done = {}) {
@@ -970,6 +1025,7 @@ int ensure_self_batch(gp_vgicp_factor* f) {
     b->factors.push_back(f);
     b->stream = f->stream;
     b->temp_buffer = f->temp_buffer;
+    b->tuning = f->tuning;
     const int rc = build_table(b);
     if (rc != GP_OK) {
       delete b;
@@ -985,36 +1041,80 @@ int ensure_self_batch(gp_vgicp_factor* f) {
 
 extern "C" {
 
-// timeline hook: the traced build of the default tile kernel stores 8 s_memtime stamps + HW_ID / XCC_ID per workgroup into
-// dev_buffer ([2048][16] uint64, row = tile index); row 2047 receives the stamps of the finalize kernel of synchronous calls.  NULL disables
-int gp_debug_set_trace_buffer(void* dev_buffer) {
-  unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buffer);
-  GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gp::g_trace), &p, sizeof(p)));
-  g_trace_on = p != nullptr;
-  g_trace_host = static_cast<unsigned long long*>(p);
+// ---- per-batch tuning (nothing process-global: SURVEY.md 8(b) "re-entrant across handles") --------------------------------------------------
+static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
+  switch (key) {
+    case GP_TUNE_KERNEL:
+      if (value != GP_KERNEL_REFERENCE && value != GP_KERNEL_HASHED && value != GP_KERNEL_GRID_F64 && value != GP_KERNEL_LOOKAHEAD && value != GP_KERNEL_GEN2 &&
+          value != GP_KERNEL_STREAM)
+        return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_KERNEL: one of GP_KERNEL_REFERENCE (0), _HASHED (2), _GRID_F64 (3), _LOOKAHEAD (8), _GEN2 (11), _STREAM (12)");
+      t->kernel = value;
+      return GP_OK;
+    case GP_TUNE_SOURCE_POLICY:
+      if (value < 0 || value > 2) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_SOURCE_POLICY: 0 (per batch), 1 (default cache policy), 2 (non-temporal)");
+      t->source_policy = value;
+      return GP_OK;
+    case GP_TUNE_XCD_CHUNK:
+      if (value < 0 || value > 4096) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_XCD_CHUNK: 0 (contiguous eighths) .. 4096 tiles per run");
+      t->xcd_chunk = value;
+      return GP_OK;
+    case GP_TUNE_STAGGER:
+      if (value < 0 || value > 64) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_STAGGER: 0..64 (x 512 clocks)");
+      t->stagger = value;
+      return GP_OK;
+    case GP_TUNE_TILE_INTERLEAVE:
+      t->tile_interleave = value ? 1 : 0;
+      return GP_OK;
+    case GP_TUNE_BALANCE:
+      t->balance = value ? 1 : 0;
+      return GP_OK;
+    default:
+      return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
+  }
+}
+
+int gp_vgicp_batch_set_tuning(gp_vgicp_batch_t* b, int key, int value) {
+  if (!b) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_set_tuning: null batch");
+  if (key == GP_TUNE_TIMING) {
+    b->timing = value != 0;
+    return GP_OK;
+  }
+  GP_TRY(apply_tuning(&b->tuning, key, value));
+  b->table_dirty = true;
   return GP_OK;
 }
 
-int gp_debug_set_variant(int variant) {
-  if (variant < 0 || variant > 11) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_variant: 0..11");
-  g_variant = variant;
+int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
+  if (!b || !value) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_get_tuning: null");
+  switch (key) {
+    case GP_TUNE_KERNEL: *value = b->tuning.kernel; return GP_OK;
+    case GP_TUNE_SOURCE_POLICY: *value = b->tuning.source_policy; return GP_OK;
+    case GP_TUNE_XCD_CHUNK: *value = b->tuning.xcd_chunk; return GP_OK;
+    case GP_TUNE_STAGGER: *value = b->tuning.stagger; return GP_OK;
+    case GP_TUNE_TILE_INTERLEAVE: *value = b->tuning.tile_interleave; return GP_OK;
+    case GP_TUNE_BALANCE: *value = b->tuning.balance; return GP_OK;
+    case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
+    default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
+  }
+}
+
+// the per-factor entry points run a batch of one: its tuning is the factor's
+int gp_vgicp_factor_set_tuning(gp_vgicp_factor_t* f, int key, int value) {
+  if (!f) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_factor_set_tuning: null factor");
+  GP_TRY(apply_tuning(&f->tuning, key, value));
+  if (f->self_batch) {
+    f->self_batch->tuning = f->tuning;
+    f->self_batch->table_dirty = true;
+  }
   return GP_OK;
 }
 
-int gp_debug_set_tile_interleave(int on) {
-  g_tile_interleave = on ? 1 : 0;
-  return GP_OK;
-}
-
-int gp_debug_set_xcd_chunk(int tiles) {
-  if (tiles < 0 || tiles > 4096) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_xcd_chunk: 0 (contiguous eighths) .. 4096 tiles per run");
-  g_xcd_chunk = tiles;
-  return GP_OK;
-}
-
-int gp_debug_set_stagger(int units) {
-  if (units < 0 || units > 64) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_set_stagger: 0..64 (x 512 clocks)");
-  g_stagger = units;
+// timeline hook (measurement): the traced build of the tile kernel of THIS batch's single-factor linearise stores 8 s_memtime stamps + HW_ID /
+// XCC_ID + two s_memrealtime stamps per workgroup into dev_buffer ([2048][16] uint64, row = tile index); row 2047 receives the stamps of the
+// finalize kernel of synchronous calls.  NULL disables.
+int gp_vgicp_batch_set_trace_buffer(gp_vgicp_batch_t* b, void* dev_buffer) {
+  if (!b) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_set_trace_buffer: null batch");
+  b->trace = static_cast<unsigned long long*>(dev_buffer);
   return GP_OK;
 }
 
@@ -1198,8 +1298,18 @@ void batch_set_sources_shared(gp_vgicp_batch* batch, bool shared) {
 }  // namespace gp
 }
 
+// measurement: durations of the tile kernel and the finalize kernel of the last synchronous linearise (GP_TUNE_TIMING = 1), HIP events on the batch's stream
+int gp_vgicp_batch_last_kernel_ms(const gp_vgicp_batch_t* batch, float* tile_ms, float* finalize_ms) {
+  if (!batch) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_last_kernel_ms: null batch");
+  if (tile_ms) *tile_ms = batch->last_tile_ms;
+  if (finalize_ms) *finalize_ms = batch->last_finalize_ms;
+  return GP_OK;
+}
+
 int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch) {
   if (!batch) return GP_OK;
+  for (auto& e : batch->ev)
+    if (e) (void)hipEventDestroy(e);
   // the staging buffers are about to be freed: the last H2D copy must have finished.  The stream itself is the caller's and may
   // already be gone (the reference's clone() drops it, integrated_vgicp_factor_gpu.cpp:122-134), so it is not synchronised here.
   if (batch->h2d_done) {
@@ -1311,13 +1421,20 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
   if (table_is_stale(b)) GP_TRY(build_table(b));
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_host, nullptr, &ps, true));
-  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, g_trace_host ? g_trace_host + 2047 * 16 : nullptr};
+  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, b->trace ? b->trace + 2047 * 16 : nullptr};
   const bool rigid = poses_are_rigid(poses_host, F);
   const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
   static const bool host_expand = [] { const char* e = getenv("GP_FINALIZE_HOST_EXPAND"); return !e || atoi(e) != 0; }();  // A/B: 0 = the parts expand
   const bool sums_only = parts > 1 && host_expand;
-  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts));
+  if (b->timing && !b->ev[0])
+    for (auto& e : b->ev) GP_HIP(hipEventCreate(&e));
+  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+  if (b->timing) {  // measurement: the two kernels of THIS synchronous pass, i.e. behind the idle queue the host left between two passes
+    GP_HIP(hipEventSynchronize(b->ev[2]));
+    GP_HIP(hipEventElapsedTime(&b->last_tile_ms, b->ev[0], b->ev[1]));
+    GP_HIP(hipEventElapsedTime(&b->last_finalize_ms, b->ev[1], b->ev[2]));
+  }
   if (parts == 1) {
     if (view) *view = static_cast<const gp_linearized6*>(b->h_out.ptr);
     if (out_host && !(view && F == 1)) memcpy(out_host, b->h_out.ptr, sizeof(gp_linearized6) * F);

@@ -22,6 +22,18 @@ struct FactorDesc {
 };
 
 
+// How the stream kernel (gp_vgicp_stream.hpp) deals the 64-point chunks of ONE factor to the workgroups of a launch.  The chunk list is cut
+// into eight contiguous shares, one per XCD (workgroup b runs on XCD b % 8); inside a share the first `early_wgs` workgroups take `hi` chunks
+// each, the remaining ones -- the last round the dispatcher places, one workgroup per compute unit -- split what is left evenly (`lo`, the
+// first `extra` of them one more).  cx / cr: chunks per share (the first `cr` shares own cx + 1); lo0 / extra0 belong to a share of cx
+// chunks, lo1 / extra1 to one of cx + 1.  tail: points behind the last full chunk (the last workgroup reads them with per-lane loads).
+struct StreamPlan {
+  int cx, cr;
+  int wgs_per_xcd, early_wgs, hi;
+  int lo0, extra0, lo1, extra1;
+  int tail;
+};
+
 // a single-factor launch carries its poses AND its factor descriptor in the kernel arguments: no H2D copy and no
 // dependent descriptor loads on the latency path (2.8 us per workgroup in the timeline traces)
 struct InlinePoses {
@@ -33,6 +45,8 @@ struct InlinePoses {
   int stagger;    // tuning knob of the pipeline kernel: odd wave slots start `stagger` x 512 clocks late (0 = off)
   int xcd_chunk;  // workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list; c > 0 = the
                   // tile list is dealt to the XCDs in runs of c tiles (round robin), which evens out what the XCDs have to do
+  StreamPlan plan;            // stream kernel, single-factor launches
+  unsigned long long* trace;  // timeline build of the tile kernels (per batch: gp_vgicp_batch_set_trace_buffer); null = off
 };
 
 struct TileDesc {

@@ -1,0 +1,388 @@
+// gp_vgicp_stream.hpp -- third generation of the rigid-pose tile kernel (round 3): the pipeline of gp_vgicp_tile2.hpp as a ROLLED loop over a
+// per-wave stream of 64-point chunks whose length is a run-time, wave-uniform number.  Replaces vgicp_derivatives_kernel / vgicp_error_kernel
+// (include/gtsam_points/cuda/kernels/vgicp_derivatives.cuh:15-139) + lookup_voxels_kernel incl. its surface validation
+// (lookup_voxels.cuh:19-97) + the CUB reductions of src/gtsam_points/factors/integrated_vgicp_derivatives_{linearize,compute}.cu.
+//
+// Why: the second-generation kernel hands out whole tiles of PPT x 256 points, so the 1 M-point headline is
+// 977 workgroups on 256 compute units -- 209 CUs carry four tiles and end at 12.2 us, 47 carry three and end at 10.5 us -- and every launch
+// larger than one round of workgroups pays the cold start of the pipeline (first points 0.8 us, first hop 1.0 us, a 2.3 us first step) once per
+// tile.  Here
+//   * a single-factor launch deals CHUNKS, not fixed tiles: at most 1024 workgroups = one resident round whatever the size of the cloud; every
+//     XCD owns a contiguous eighth of the chunk list, its early workgroups take `hi` chunks each and its last round of workgroups (the ones the
+//     dispatcher places last, one per compute unit) share what is left evenly -- every compute unit of the headline carries 61 or 62 chunks
+//     (StreamPlan, filled by the host; a workgroup's chunks are dealt to its four waves as evenly as they go);
+//   * clouds beyond one round of 4-chunk waves stay in ONE round: the waves simply stream more chunks through the same ring (an 8 M-point
+//     source is 30 chunks per wave), so the cold start is paid once per wave, not once per 1024 points;
+//   * surface validation (SV) rides in the same ring: the normals are a fourth 12-B LDS-DMA row per chunk, issued from inline asm like the rest,
+//     so that the hand-counted vmcnt scheme survives (the compiler-tracked normals load of the round-2 kernel is what kept factors with
+//     set_enable_surface_validation(true) -- and the whole batch they are in -- off the second-generation kernel);
+//   * the trace buffer and the tuning knobs arrive in the kernel arguments (per batch), not through process-global device symbols.
+// The arithmetic per point, the order of the waits and the reduction are those of gp_vgicp_tile2.hpp; the partition changes which points a
+// wave adds up, so records differ from the second generation at the 1e-16 level (fixed order per launch geometry: still bit-reproducible).
+#pragma once
+
+#include "gp_vgicp_tile2.hpp"
+
+namespace gp {
+
+// normals: one more 12-B row per chunk (64 slots of 16 B, like the points)
+template <bool NT>
+__device__ __forceinline__ void chunk_dma12_row(const GP_GLOBAL char* urow, unsigned voff, char* slot) {
+  chunk_dma12_pts<NT>(urow, voff, slot);
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait_blk_n(v4i& blk) {
+  static_assert(N == 0 || N == 3 || N == 4 || N == 5, "counts of the stream schedule");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk) : : "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(blk) : : "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(blk) : : "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(blk) : : "memory");
+}
+
+// the stream of one wave: `first` point, `n` full 64-point chunks, then `tail` (< 64) points read with per-lane loads
+struct WaveWork {
+  size_t first;
+  int n;
+  int tail;
+};
+
+// a workgroup's points [begin, begin + count) -> its four waves: the full chunks are dealt as evenly as they go (the first `extra` waves take
+// one more), the points behind the last full chunk go to the last wave
+__device__ __forceinline__ WaveWork split_tile(int begin, int count, int wave) {
+  const int chunks = count >> 6, base = chunks >> 2, extra = chunks & 3;
+  WaveWork ww;
+  ww.first = (size_t)begin + (size_t)(wave * base + (wave < extra ? wave : extra)) * kChunkPoints;
+  ww.n = base + (wave < extra ? 1 : 0);
+  ww.tail = wave == 3 ? (count & 63) : 0;
+  return ww;
+}
+
+// INL: the points workgroup (x = XCD, q = position in the XCD's share) of a single-factor launch owns -- the same tile the host writes into the
+// tile table for the launches that cannot carry the descriptor in their arguments (make_stream_plan / plan_tile_host in gp_vgicp.hip)
+__host__ __device__ __forceinline__ void plan_tile(const StreamPlan& p, int x, int q, int* begin, int* count) {
+  const int big = x < p.cr ? 1 : 0;  // this XCD owns cx + 1 chunks
+  const int xbegin = x * p.cx + (x < p.cr ? x : p.cr);
+  int n, c0;
+  if (q < p.early_wgs) {
+    n = p.hi;
+    c0 = q * p.hi;
+  } else {
+    const int k = q - p.early_wgs;
+    const int lo = big ? p.lo1 : p.lo0, extra = big ? p.extra1 : p.extra0;
+    n = lo + (k < extra ? 1 : 0);
+    c0 = p.early_wgs * p.hi + k * lo + (k < extra ? k : extra);
+  }
+  *begin = (xbegin + c0) * kChunkPoints;
+  *count = n * kChunkPoints + ((x == kNumXCD - 1 && q == p.wgs_per_xcd - 1) ? p.tail : 0);  // the very last workgroup also takes the points behind the last full chunk
+}
+
+template <int MODE, bool NT, bool INL, bool SV, bool TRACE = false>
+__global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+                                                               const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
+                                                               double* __restrict__ partials) {
+  static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "rigid linearise and error evaluation");
+  constexpr int NACC = MODE == MODE_ERR ? 2 : 32;
+  constexpr int K = 4 + (SV ? 1 : 0);  // vector-memory requests per chunk: points (+ normals) + 3 covariance rows
+  constexpr int kNrmSlotBytes = SV ? kPtsSlotBytes : 0;
+  constexpr int kWaveBytes = SV ? 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + 2 * kCovSlotBytes : kWaveLdsBytes;  // 10 KB with normals, else 8.5 KB
+  static_assert(kWaveBytes >= kWaveLdsBytes, "the reduction needs 8.5 KB of the wave's region");
+  __shared__ __attribute__((aligned(16))) char smem[4 * kWaveBytes];
+  int tile_idx;  // index into the tile list: XCD x walks a contiguous eighth of it
+  if constexpr (INL) {
+    tile_idx = (blockIdx.x % kNumXCD) * inl.plan.wgs_per_xcd + blockIdx.x / kNumXCD;
+  } else {
+    if (inl.xcd_chunk > 0) {
+      const int c = inl.xcd_chunk, x = blockIdx.x % kNumXCD, q = blockIdx.x / kNumXCD;
+      tile_idx = ((q / c) * kNumXCD + x) * c + (q % c);
+    } else {
+      const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+      tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
+    }
+    if (tile_idx >= num_tiles) return;
+  }
+  unsigned long long* trace = TRACE ? inl.trace : nullptr;
+  GP_TRACE(0);
+  if constexpr (TRACE) {
+    if (trace && threadIdx.x == 0) {
+      trace[(size_t)tile_idx * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+      trace[(size_t)tile_idx * 16 + 8] = __builtin_amdgcn_s_getreg(GP_GETREG_HW_ID);
+      trace[(size_t)tile_idx * 16 + 9] = __builtin_amdgcn_s_getreg(GP_GETREG_XCC_ID);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  FactorDesc f;
+  WaveWork ww;
+  int factor_idx = 0, row = tile_idx;
+  if constexpr (INL) {
+    f = inl.factor;
+    int begin, count;
+    plan_tile(inl.plan, blockIdx.x % kNumXCD, blockIdx.x / kNumXCD, &begin, &count);
+    ww = split_tile(begin, count, wave);
+  } else {
+    const TileDesc tile = tiles[tile_idx];
+    f = factors[tile.factor];
+    factor_idx = tile.factor;
+    row = tile.row;
+    ww = split_tile(__builtin_amdgcn_readfirstlane(tile.begin), __builtin_amdgcn_readfirstlane(tile.count), wave);
+  }
+  const int n = __builtin_amdgcn_readfirstlane(ww.n);
+  const int tail = __builtin_amdgcn_readfirstlane(ww.tail);
+  const size_t first = ww.first;
+  char* wbase = smem + wave * kWaveBytes;
+  auto pslot = [&](int par) { return wbase + par * kPtsSlotBytes; };
+  auto nslot = [&](int par) { return wbase + 2 * kPtsSlotBytes + par * kNrmSlotBytes; };
+  auto cslot = [&](int par) { return wbase + 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + par * kCovSlotBytes; };
+  const GP_GLOBAL char* upts = uniform_ptr((const GP_GLOBAL char*)as_global(f.points) + 12 * first);
+  const GP_GLOBAL char* ucov = uniform_ptr((const GP_GLOBAL char*)as_global(f.covs) + 36 * first);
+  const GP_GLOBAL char* unrm = SV ? uniform_ptr((const GP_GLOBAL char*)as_global(f.normals) + 12 * first) : nullptr;
+  const unsigned voff = (unsigned)lane * 12u;
+  // requests of chunk j (its rows start j * 64 points behind the wave's first point); par = j & 1 = which half of the ring
+  auto dma_head = [&](int j, int par) {  // what the front half of a chunk reads: its points (and normals)
+    chunk_dma12_pts<NT>(upts + (size_t)j * (kChunkPoints * 12), voff, pslot(par));
+    if constexpr (SV) chunk_dma12_row<NT>(unrm + (size_t)j * (kChunkPoints * 12), voff, nslot(par));
+  };
+  auto dma_cov = [&](int j, int par) { chunk_dma12_cov<NT>(ucov + (size_t)j * (kChunkPoints * 36), voff, cslot(par)); };
+
+  if (n > 0) dma_head(0, 0);
+
+  const Pose Tl = INL ? load_pose(inl.lin) : load_pose(poses_lin + 16 * (size_t)factor_idx);
+  const Pose Te = MODE == MODE_ERR ? (INL ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)factor_idx)) : Tl;
+  const double leaf = uniform_f64(f.map.leaf), inv_leaf = uniform_f64(f.map.inv_leaf), half_leaf = uniform_f64(0.5 * f.map.leaf);
+  const int glo0 = f.map.glo[0], glo1 = f.map.glo[1], glo2 = f.map.glo[2];
+  const unsigned gd0 = (unsigned)f.map.gdim[0], gd1 = (unsigned)f.map.gdim[1], gd2 = (unsigned)f.map.gdim[2];
+  const GP_GLOBAL char* gblocks = uniform_ptr((const GP_GLOBAL char*)f.map.gblocks);
+  const GP_GLOBAL char* records = uniform_ptr((const GP_GLOBAL char*)f.map.records);
+
+  // the translation lives in vector registers: a VOP3 instruction reads ONE scalar operand (gp_vgicp_tile2.hpp)
+  double tvx, tvy, tvz;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(tvx) : "s"(Tl.tx));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(tvy) : "s"(Tl.ty));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(tvz) : "s"(Tl.tz));
+
+  float acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] = 0.f;
+
+  struct Ahead {  // what a chunk carries from its front half (transform, hop 1 issued) to its back half (hop 2, algebra)
+    v4i blk;
+    float ex, ey, ez, qx, qy, qz;
+    int pos;  // bit of the voxel inside its block; < 0: outside the grid's box, an inactive lane, or rejected by the surface validation
+  };
+  // front half: transform, (surface validation,) voxel coordinate, hop 1 issued
+  auto front = [&](float pxf, float pyf, float pzf, float nxf, float nyf, float nzf, bool active, Ahead& P) {
+    const double dx = (double)pxf, dy = (double)pyf, dz = (double)pzf;
+    const double lx = __builtin_fma(Tl.r00, dx, __builtin_fma(Tl.r01, dy, __builtin_fma(Tl.r02, dz, tvx)));
+    const double ly = __builtin_fma(Tl.r10, dx, __builtin_fma(Tl.r11, dy, __builtin_fma(Tl.r12, dz, tvy)));
+    const double lz = __builtin_fma(Tl.r20, dx, __builtin_fma(Tl.r21, dy, __builtin_fma(Tl.r22, dz, tvz)));
+    // voxel coordinate = floor(l * (1 / leaf)): the CPU map's rule (util/fast_floor.hpp:12-15, gaussian_voxelmap_cpu.cpp:59-61);
+    // centre - l = leaf (floor(u) + 0.5 - u) = leaf/2 - leaf fract(u): the large coordinates never meet
+    const double ux = lx * inv_leaf, uy = ly * inv_leaf, uz = lz * inv_leaf;
+    const int cx = (int)__builtin_floor(ux), cy = (int)__builtin_floor(uy), cz = (int)__builtin_floor(uz);
+    if constexpr (MODE == MODE_ERR) {
+      const double ex_ = Te.r00 * dx + Te.r01 * dy + Te.r02 * dz + Te.tx, ey_ = Te.r10 * dx + Te.r11 * dy + Te.r12 * dz + Te.ty, ez_ = Te.r20 * dx + Te.r21 * dy + Te.r22 * dz + Te.tz;
+      P.ex = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf) + (lx - ex_));
+      P.ey = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf) + (ly - ey_));
+      P.ez = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf) + (lz - ez_));
+      P.qx = P.qy = P.qz = 0.f;
+    } else {
+      P.ex = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf);
+      P.ey = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf);
+      P.ez = (float)__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf);
+      P.qx = (float)lx;
+      P.qy = (float)ly;
+      P.qz = (float)lz;
+    }
+    bool live = active && finite3(pxf, pyf, pzf);
+    if constexpr (SV) {
+      // lookup_voxels.cuh:41-50: reject when normalized(q) . (R n) > cos(80 deg), at the LINEARISATION pose (the error evaluation keeps the
+      // correspondences of the linearise, vgicp_derivatives.cuh:85-139).  s / |q| > c  <=>  s > 0 and s^2 > c^2 |q|^2: no square root, no division
+      const double nx = (double)nxf, ny = (double)nyf, nz = (double)nzf;
+      const double tnx = Tl.r00 * nx + Tl.r01 * ny + Tl.r02 * nz, tny = Tl.r10 * nx + Tl.r11 * ny + Tl.r12 * nz, tnz = Tl.r20 * nx + Tl.r21 * ny + Tl.r22 * nz;
+      const double s = lx * tnx + ly * tny + lz * tnz;
+      const double qq = lx * lx + ly * ly + lz * lz;
+      if (s > 0.0 && s * s > (0.174 * 0.174) * qq) live = false;
+    }
+    const unsigned bx = (unsigned)((cx >> 2) - glo0), by = (unsigned)((cy >> 2) - glo1), bz = (unsigned)((cz >> 2) - glo2);
+    const bool inbox = (bx < gd0) & (by < gd1) & (bz < gd2);
+    const unsigned lin = inbox ? mad24(mad24(bz, gd1, by), gd0, bx) : 0u;  // < 2^24 blocks
+    P.pos = (inbox && live) ? (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3)) : -1;
+    grid_issue_s(gblocks, lin * 16u, P.blk);
+  };
+  auto front_ring = [&](int par, Ahead& P) {
+    const v3f pt = *reinterpret_cast<const v3f*>(pslot(par) + 16 * lane);
+    v3f nr = {0.f, 0.f, 0.f};
+    if constexpr (SV) nr = *reinterpret_cast<const v3f*>(nslot(par) + 16 * lane);
+    front(pt.x, pt.y, pt.z, nr.x, nr.y, nr.z, true, P);
+  };
+  // back half, part 1: P.blk has landed -> record requested
+  auto back_issue = [&](const Ahead& P, v4f& head, v2d& c01, v2d& c23, v2d& c45) -> bool {
+    const unsigned long long bits = ((unsigned long long)(unsigned)P.blk.y << 32) | (unsigned long long)(unsigned)P.blk.x;
+    const int pos = P.pos < 0 ? 0 : P.pos;
+    const bool hit = P.pos >= 0 && ((bits >> pos) & 1ull);
+    const int idx = P.blk.z + __popcll(bits & ((1ull << pos) - 1ull));
+    record_issue_s(records, hit ? (unsigned)idx << 6 : 0u, head, c01, c23, c45);
+    return hit;
+  };
+  // the covariance of this lane's point out of the ring (three 12-B columns), symmetrised like load_cov6 does
+  auto cov_ring = [&](int par, double* a) {
+    const char* c = cslot(par) + 48 * lane;
+    const v3f c0 = *reinterpret_cast<const v3f*>(c), c1 = *reinterpret_cast<const v3f*>(c + 16), c2 = *reinterpret_cast<const v3f*>(c + 32);
+    const float c9[9] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z};
+    load_cov6(c9, a);
+  };
+
+  Ahead P0, P1;
+  v4f head;
+  v2d c01, c23, c45;
+  double a[6];
+  // one step of the steady state: chunk j (ring half PAR, front half done, hop 1 in flight in `cur`); behind hop 1 only the K requests of
+  // chunk j+1 may be in flight.  Order: wait hop 1 -> hop 2 -> wait (everything) -> front half of chunk j+1 (its hop 1 travels under the
+  // algebra below) -> covariance out of LDS -> chunk j+2 requested into the places of chunk j -> algebra.
+  auto step = [&](auto par_c, int j, Ahead& cur, Ahead& nxt) {
+    constexpr int PAR = decltype(par_c)::value;
+    const bool has1 = j + 1 < n, has2 = j + 2 < n;  // wave-uniform
+    if (has1) vm_wait_blk_n<K>(cur.blk);            // [H(j), chunk j+1 x K]
+    else vm_wait_blk_n<0>(cur.blk);
+    if constexpr (TRACE) {
+      if (j == 1) GP_TRACE(4);
+    }
+    const bool hit = back_issue(cur, head, c01, c23, c45);
+    vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
+    if (has1) front_ring(PAR ^ 1, nxt);
+    cov_ring(PAR, a);
+    if (has2) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_head(j + 2, PAR);
+      dma_cov(j + 2, PAR);
+    }
+    if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, cur.ex + head.x, cur.ey + head.y, cur.ez + head.z, cur.qx, cur.qy, cur.qz, acc);
+    if constexpr (TRACE) {
+      if (j == 1) GP_TRACE(5);
+    }
+  };
+
+  if (n > 0) {
+    // points first: only chunk 0's points (and normals) are in flight, so the first transform and hop 1 do not queue behind everybody's
+    // covariances; those follow hop 1 (they are needed behind hop 2), the head of chunk 1 goes out before hop 2 and its covariances behind it
+    vm_wait<0>();
+    GP_TRACE(1);
+    front_ring(0, P0);  // in flight: H0
+    dma_cov(0, 0);
+    const bool has1 = n > 1, has2 = n > 2;
+    if (has1) dma_head(1, 1);  // in flight: H0, C0 x3, head of chunk 1 (K - 3 requests)
+    if (has1) vm_wait_blk_n<K>(P0.blk);
+    else vm_wait_blk_n<3>(P0.blk);
+    GP_TRACE(2);
+    const bool hit = back_issue(P0, head, c01, c23, c45);
+    if (has1) {
+      dma_cov(1, 1);                        // [C0 x3, head 1, R0 x4, C1 x3]
+      vm_wait_rec<3>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the head of chunk 1
+      front_ring(1, P1);
+    } else {
+      vm_wait_rec<0>(head, c01, c23, c45);
+    }
+    cov_ring(0, a);
+    if (has2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_head(2, 0);
+      dma_cov(2, 0);
+    }
+    if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, P0.ex + head.x, P0.ey + head.y, P0.ez + head.z, P0.qx, P0.qy, P0.qz, acc);
+    GP_TRACE(3);
+    for (int j = 1; j < n; j += 2) {
+      step(std::integral_constant<int, 1>{}, j, P1, P0);
+      if (j + 1 < n) step(std::integral_constant<int, 0>{}, j + 1, P0, P1);
+    }
+    vm_wait<0>();
+  }
+  if (tail > 0) {
+    // the points behind the wave's last full chunk (end of a factor): per-lane loads, same arithmetic.  The loads are issued from inline asm
+    // like everything else here: a load hipcc tracks itself makes it guard registers of the ring path with vmcnt(0) waits of its own.
+    const GP_GLOBAL float* points = as_global(f.points);
+    const GP_GLOBAL float* covs = as_global(f.covs);
+    const bool active = lane < tail;
+    const size_t i = first + (size_t)n * kChunkPoints + (active ? lane : 0);
+    v3f pt, nr = {0.f, 0.f, 0.f};
+    v4f ca, cb;
+    float cc;
+    asm volatile(
+      "global_load_dwordx3 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %5, off\n\t"
+      "global_load_dwordx4 %2, %5, off offset:16\n\t"
+      "global_load_dword %3, %5, off offset:32\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(pt), "=&v"(ca), "=&v"(cb), "=&v"(cc)
+      : "v"(points + 3 * i), "v"(covs + 9 * i)
+      : "memory");
+    if constexpr (SV) {
+      const GP_GLOBAL float* normals = as_global(f.normals);
+      asm volatile(
+        "global_load_dwordx3 %0, %1, off\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(nr)
+        : "v"(normals + 3 * i)
+        : "memory");
+    }
+    const float c9[9] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w, cc};
+    Ahead P;
+    front(pt.x, pt.y, pt.z, nr.x, nr.y, nr.z, active, P);
+    vm_wait_blk_n<0>(P.blk);
+    const bool hit = back_issue(P, head, c01, c23, c45);
+    vm_wait_rec<0>(head, c01, c23, c45);
+    load_cov6(c9, a);
+    if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, P.ex + head.x, P.ey + head.y, P.ez + head.z, P.qx, P.qy, P.qz, acc);
+  }
+
+  GP_TRACE(6);
+  // ---- reduction (gp_vgicp_tile2.hpp): the wave's drained ring becomes a 32 x 64 f32 transposition buffer (row stride 66 floats), every
+  // lane sums 32 values of one component (four f32 partial sums met in f64), lane pairs meet with one swap; the 4-wave sum goes through the
+  // last 256 B of each wave's region; one 32-double partial per workgroup (fixed order: bit-reproducible) ----
+  constexpr int kRowStrideF = 66;
+  static_assert(32 * kRowStrideF * 4 + 32 * 8 <= kWaveBytes, "f32 transposition buffer + wave sums must fit the wave's LDS region");
+  float* wtf = reinterpret_cast<float*>(wbase);
+  double* wsums = reinterpret_cast<double*>(wbase + kWaveBytes - 32 * 8);
+  if constexpr (MODE == MODE_ERR) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double v = (double)acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) wsums[k] = v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; k++) wtf[k * kRowStrideF + lane] = acc[k];
+    const int comp = lane >> 1, part = lane & 1;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      s0 += wtf[comp * kRowStrideF + 2 * i + part];
+      s1 += wtf[comp * kRowStrideF + 2 * (i + 1) + part];
+      s2 += wtf[comp * kRowStrideF + 2 * (i + 2) + part];
+      s3 += wtf[comp * kRowStrideF + 2 * (i + 3) + part];
+    }
+    double v = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    v += __shfl_xor(v, 1, 64);
+    if (part == 0) wsums[comp] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_STRIDE) {
+    double sum = 0.0;
+    if (threadIdx.x < (MODE == MODE_ERR ? 2 : ACC_SIZE)) {
+      const double* w0 = reinterpret_cast<const double*>(smem + 1 * kWaveBytes - 32 * 8);
+      const double* w1 = reinterpret_cast<const double*>(smem + 2 * kWaveBytes - 32 * 8);
+      const double* w2 = reinterpret_cast<const double*>(smem + 3 * kWaveBytes - 32 * 8);
+      const double* w3 = reinterpret_cast<const double*>(smem + 4 * kWaveBytes - 32 * 8);
+      sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
+    }
+    ((GP_GLOBAL double*)partials)[(size_t)row * ACC_STRIDE + threadIdx.x] = sum;
+  }
+  GP_TRACE(7);
+  if constexpr (TRACE) {
+    if (trace && threadIdx.x == 0) trace[(size_t)tile_idx * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+}  // namespace gp

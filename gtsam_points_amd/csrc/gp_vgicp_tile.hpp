@@ -181,7 +181,6 @@ __device__ __forceinline__ void load_cov6(P c9, double* a) {
 
 // optional per-workgroup phase timestamps (s_memtime) for timeline analysis: [num_tiles][16] uint64 (slots 0-7 phases, 8 HW_ID,
 // 9 XCC_ID), enabled by the host
-static __device__ unsigned long long* g_trace = nullptr;
 #define GP_TRACE(slot)                                                                                 \
   do {                                                                                                 \
     if constexpr (TRACE) {                                                                             \
@@ -313,7 +312,7 @@ __global__ void __launch_bounds__(256, (OUTER_F32 || MODE == MODE_ERR) ? 4 : 3) 
     tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
   }
   if (tile_idx >= num_tiles) return;
-  unsigned long long* trace = TRACE ? g_trace : nullptr;
+  unsigned long long* trace = TRACE ? inl.trace : nullptr;
   GP_TRACE(0);
   if constexpr (TRACE) {
     // s_memtime (the stamps above) runs at the shader clock but is not synchronised across compute units: only differences inside

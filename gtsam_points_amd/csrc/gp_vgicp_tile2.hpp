@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_pipeline2_kernel(const FactorDes
     tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
   }
   if (tile_idx >= num_tiles) return;
-  unsigned long long* trace = TRACE ? g_trace : nullptr;
+  unsigned long long* trace = TRACE ? inl.trace : nullptr;
   GP_TRACE(0);
   if constexpr (TRACE) {
     if (trace && threadIdx.x == 0) {

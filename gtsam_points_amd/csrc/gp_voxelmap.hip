@@ -487,7 +487,6 @@ static bool build_grid_host(int V, const int* coords, gp::GridGeom* g, std::vect
   return true;
 }
 
-static bool g_force_hashed_build = false;  // gp_debug_set_map_build: A/B and tests of the fallback path
 
 static inline gp_voxelmap* ext(gp_voxelmap* m) { return m; }
 static inline const gp_voxelmap* ext(const gp_voxelmap* m) { return m; }
@@ -575,7 +574,7 @@ int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float*
   const double inv_leaf = 1.0 / m->resolution;
   m->offloaded = false;
   m->generation++;
-  if (n > 0 && !g_force_hashed_build) {
+  if (n > 0 && !m->force_hashed_build) {
     gp::PointBins bins;
     bool too_large = false;
     GP_TRY(gp::bin_points(points_dev, n, inv_leaf, s, &bins, &too_large));
@@ -970,8 +969,11 @@ size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
 
 int gp_voxelmap_loaded_on_gpu(const gp_voxelmap_t* map) { return map && map->loaded() ? 1 : 0; }
 int gp_voxelmap_has_block_grid(const gp_voxelmap_t* map) { return map && map->has_grid ? 1 : 0; }
-int gp_debug_set_map_build(int hashed) {
-  g_force_hashed_build = hashed != 0;
+// per map: GP_TUNE_MAP_BUILD = 1 builds with the reference-shaped hashed scheme (the fallback of clouds too large for the block grid; A/B and tests)
+int gp_voxelmap_set_tuning(gp_voxelmap_t* map, int key, int value) {
+  if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_set_tuning: null map");
+  if (key != GP_TUNE_MAP_BUILD) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_set_tuning: GP_TUNE_MAP_BUILD is the only key of a voxel map");
+  map->force_hashed_build = value != 0;
   return GP_OK;
 }
 

@@ -245,6 +245,12 @@ class IntegratedVGICPFactorGPU(NonlinearFactorGPU):
     def memory_usage_gpu(self):
         return 128 + 4  # pose + count; no inlier index list exists in this implementation
 
+    def set_tuning(self, key, value):
+        """gp_vgicp_factor_set_tuning: a GP_TUNE_* knob of THIS factor's own batch of one (kernel family, source-stream policy, ...);
+        nothing process-global.  Not part of the reference API."""
+        _capi.check(self._lib.gp_vgicp_factor_set_tuning(self._h, int(key), int(value)), "gp_vgicp_factor_set_tuning")
+        return self
+
     def set_enable_surface_validation(self, enable):
         _capi.check(self._lib.gp_vgicp_factor_set_surface_validation(self._h, int(bool(enable))), "set_enable_surface_validation")
 

@@ -16,12 +16,14 @@ from .types import GaussianVoxelMapGPU, PointCloudGPU, _pose16
 class KdTreeGPU:
     """Exact nearest-neighbour search structure over a PointCloudGPU (KdTree::knn_search semantics)."""
 
-    def __init__(self, frame: PointCloudGPU, cell_size=0.25, stream=None):
+    def __init__(self, frame: PointCloudGPU, cell_size=0.25, stream=None, structure=0, counters=None):
+        """structure: GP_TUNE_KNN_STRUCTURE of this search structure (0 default); counters: torch uint64[8] device tensor of work counters (measurement)"""
         self._lib = _capi.load()
         self.frame = frame
         GaussianVoxelMapGPU._sync_torch(frame)
         h = C.c_void_p()
-        _capi.check(self._lib.gp_point_grid_create(frame.ptr(frame.points_gpu), frame.size(), float(cell_size), stream, C.byref(h)), "gp_point_grid_create")
+        _capi.check(self._lib.gp_point_grid_create_ex(frame.ptr(frame.points_gpu), frame.size(), float(cell_size), int(structure),
+                                                      C.c_void_p(counters.data_ptr()) if counters is not None else None, stream, C.byref(h)), "gp_point_grid_create_ex")
         self._h = h
         self.stream = stream
 
@@ -47,15 +49,17 @@ class KdTreeGPU:
         return idx.cpu().numpy(), d.cpu().numpy(), nf.cpu().numpy()
 
 
-def estimate_covariances_gpu(frame: PointCloudGPU, k_neighbors=10, cell_size=0.0, stream=None):
-    """estimate_covariances(points, n, k): fills frame.covs_gpu (float [N][9]); returns the number of points with < k neighbours."""
+def estimate_covariances_gpu(frame: PointCloudGPU, k_neighbors=10, cell_size=0.0, stream=None, structure=0, counters=None):
+    """estimate_covariances(points, n, k): fills frame.covs_gpu (float [N][9]); returns the number of points with < k neighbours.
+    structure / counters: per call, see KdTreeGPU (not part of the reference API)."""
     import torch
 
     lib = _capi.load()
     covs = torch.empty((frame.size(), 9), dtype=torch.float32, device=frame.device)
     GaussianVoxelMapGPU._sync_torch(frame)
     short = C.c_int(0)
-    _capi.check(lib.gp_estimate_covariances(frame.ptr(frame.points_gpu), frame.size(), int(k_neighbors), float(cell_size), C.c_void_p(covs.data_ptr()), C.byref(short), stream), "gp_estimate_covariances")
+    _capi.check(lib.gp_estimate_covariances_ex(frame.ptr(frame.points_gpu), frame.size(), int(k_neighbors), float(cell_size), C.c_void_p(covs.data_ptr()), C.byref(short),
+                                               int(structure), C.c_void_p(counters.data_ptr()) if counters is not None else None, stream), "gp_estimate_covariances_ex")
     frame.covs_gpu = covs
     return short.value
 
@@ -64,7 +68,8 @@ class IntegratedGICPFactorGPU:
     """GICP matching-cost factor on the GPU: 1-NN correspondences within max_correspondence_distance (default 1 m,
     integrated_gicp_factor_impl.hpp:30), then the same residual / Jacobian algebra as VGICP."""
 
-    def __init__(self, target_key, source_key, target: PointCloudGPU, source: PointCloudGPU, max_correspondence_distance=1.0, stream=None, _fixed_target_pose=None):
+    def __init__(self, target_key, source_key, target: PointCloudGPU, source: PointCloudGPU, max_correspondence_distance=1.0, stream=None, _fixed_target_pose=None,
+                 structure=0, counters=None):
         self._lib = _capi.load()
         self.is_binary = _fixed_target_pose is None
         self._keys = [target_key, source_key] if self.is_binary else [source_key]
@@ -76,11 +81,11 @@ class IntegratedGICPFactorGPU:
         GaussianVoxelMapGPU._sync_torch(source)
         h = C.c_void_p()
         _capi.check(
-            self._lib.gp_gicp_factor_create(
+            self._lib.gp_gicp_factor_create_ex(
                 target.ptr(target.points_gpu), target.ptr(target.covs_gpu), target.size(), source.ptr(source.points_gpu), source.ptr(source.covs_gpu), source.size(),
-                float(max_correspondence_distance) ** 2, stream, C.byref(h),
+                float(max_correspondence_distance) ** 2, int(structure), C.c_void_p(counters.data_ptr()) if counters is not None else None, stream, C.byref(h),
             ),
-            "gp_gicp_factor_create",
+            "gp_gicp_factor_create_ex",
         )
         self._h = h
         self.linearization_point = np.eye(4)

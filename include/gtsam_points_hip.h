@@ -331,6 +331,10 @@ int gp_vgicp_multi_batch_last_timing(const gp_vgicp_multi_batch_t* mb, float* ms
 
 typedef struct gp_point_grid gp_point_grid_t; /* cell-sorted copy of a cloud: the GPU stand-in for the reference's KdTree */
 int gp_point_grid_create(const float* points_dev, int num_points, double cell_size, gp_stream_t stream, gp_point_grid_t** out);
+/* as above with a GP_TUNE_KNN_STRUCTURE value for THIS structure and, for measurement, a device buffer of 8 uint64 work counters the searches on it
+ * add to (or NULL): {shell walks, f32 distance evaluations, f64 distance evaluations, block entries read, occupied cells visited, octant stages} */
+int gp_point_grid_create_ex(const float* points_dev, int num_points, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream,
+                            gp_point_grid_t** out);
 int gp_point_grid_destroy(gp_point_grid_t* grid);
 /* exact k nearest neighbours (1 <= k <= 32) of each query within max_sq_dist (strict '<', like KnnResult::push).
  * indices_dev int[nq][k] (-1 padded), sq_dists_dev double[nq][k] (may be NULL), num_found_dev int[nq] (may be NULL). Asynchronous. */
@@ -339,11 +343,16 @@ int gp_knn_search(const gp_point_grid_t* grid, const float* queries_dev, int num
 /* estimate_covariances(points, n, k): k-NN incl. the query -> sample covariance -> V diag(1e-3,1,1) V^-1; fewer than k -> identity.
  * covs_dev float[n][9] column-major; cell_size <= 0 picks 0.5 m; *num_short = points with < k neighbours. Synchronous. */
 int gp_estimate_covariances(const float* points_dev, int num_points, int k, double cell_size, float* covs_dev, int* num_short, gp_stream_t stream);
+/* as above with a GP_TUNE_KNN_STRUCTURE value and (measurement) a device buffer of 8 work counters or NULL, see gp_point_grid_create_ex */
+int gp_estimate_covariances_ex(const float* points_dev, int num_points, int k, double cell_size, float* covs_dev, int* num_short, int structure,
+                               unsigned long long* counters_dev, gp_stream_t stream);
 
 typedef struct gp_gicp_factor gp_gicp_factor_t;
 /* IntegratedGICPFactor(target, source) with its target 1-NN structure; max_correspondence_distance_sq defaults to 1.0 upstream (:30) */
 int gp_gicp_factor_create(const float* target_points_dev, const float* target_covs_dev, int num_target, const float* points_dev, const float* covs_dev, int num_points,
                           double max_correspondence_distance_sq, gp_stream_t stream, gp_gicp_factor_t** out);
+int gp_gicp_factor_create_ex(const float* target_points_dev, const float* target_covs_dev, int num_target, const float* points_dev, const float* covs_dev, int num_points,
+                             double max_correspondence_distance_sq, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_gicp_factor_t** out);
 int gp_gicp_factor_destroy(gp_gicp_factor_t* f);
 int gp_gicp_factor_linearize(gp_gicp_factor_t* f, const double pose[16], gp_linearized6* out_host);           /* update_correspondences + evaluate */
 /* evaluate(delta_eval) on the correspondences and Mahalanobis matrices of pose_lin.  The correspondences of the last linearise (or error
@@ -399,47 +408,67 @@ int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_de
 int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
                        int* num_subtrees, int* top_columns);
 
-/* kernel selection (not part of the reference API): 0 = reference-shaped kernel (reference bucket table, 92 explicit sums: also
- * the path of non-orthonormal poses and the in-library cross-check), 1 / 2 = pipeline kernel over the hashed line table in f64 /
- * with f32 outer products, 3 / 4 = pipeline kernel over the occupancy-block grid in f64 / with f32 outer products, 5 / 6 / 7 = A/B
- * forms of 4 (no lean start; 512- / 256-point tiles), 8 = 4 with the look-ahead lookup (bit-identical results), 9 / 10 / 11 = the
- * second-generation kernel (csrc/gp_vgicp_tile2.hpp) with the default / the non-temporal / the per-batch policy on the source
- * stream; maps without a block grid and factors with surface validation run as 8 under 9-11.  Default 11:
- * M = (C_B + R C_A R^T)^-1, the transform and the residual are f64 in every variant; "f32 outer products" computes what follows
- * the inverse in f32 (measured parity vs the CPU factor <= 1e-7 relative, gate 1e-5).  See gp_vgicp.hip and DESIGN.md sections 4.1, 8.
+/* ---- per-handle tuning (not part of the reference API) --------------------------------------------------------------------------
+ * Every knob below belongs to ONE batch / factor / map / search structure; the library keeps no process-global switches, so two
+ * handles driven from two threads never see each other's settings (thread-compatible per handle, re-entrant across
+ * handles; tests/test_vgicp_gpu.py::test_two_threads_two_batches).
+ *
+ * GP_TUNE_KERNEL selects the tile-kernel family of a VGICP batch.  M = (C_B + R C_A R^T)^-1, the transform and the residual are f64
+ * in every family; "f32 outer products" computes what follows the inverse in f32 (measured parity vs the CPU factor <= 1e-7
+ * relative, gate 1e-5).  A family that does not apply to a batch falls back (GP_TUNE_EFFECTIVE_KERNEL reads what a built table runs):
+ *   GP_KERNEL_REFERENCE  reference-shaped kernel (reference bucket table, 92 explicit sums for non-orthonormal poses): cross-check
+ *   GP_KERNEL_HASHED     pipeline kernel over the hashed line table, f32 outer products: maps without a block grid
+ *   GP_KERNEL_GRID_F64   pipeline kernel over the occupancy-block grid, f64 throughout
+ *   GP_KERNEL_LOOKAHEAD  round-2 pipeline kernel (block grid, f32 outer products, look-ahead lookup): maps with >= 2^26 voxels
+ *   GP_KERNEL_GEN2       second generation (csrc/gp_vgicp_tile2.hpp), fixed 1024 / 512 / 256-point tiles
+ *   GP_KERNEL_STREAM     third generation (csrc/gp_vgicp_stream.hpp): per-wave chunk streams, balanced single-factor launches,
+ *                        surface validation inside the ring.  Default.
  * Environment switches read once at first use (A/B only): GP_POSES_ZERO_COPY=0 (synchronous batched calls upload poses with
  * hipMemcpyAsync instead of letting the kernels read the pinned staging buffer), GP_FINALIZE_PARTS=n (workgroups sharing the finalize
- * of a synchronous single-factor call, default 8), GP_FINALIZE_NARROW=0 (those workgroups with 1024 instead of 256 threads), GP_FINALIZE_HOST_EXPAND=0 (they expand the 6x6 blocks themselves
- * instead of handing their sums to the host), GP_GICP_SPLIT=0 (GICP factor: fused search + algebra kernel instead of the
- * correspondence kernel + algebra kernel). */
-int gp_debug_set_variant(int variant);
+ * of a synchronous single-factor call, default 8), GP_FINALIZE_NARROW=0 (those workgroups with 1024 instead of 256 threads),
+ * GP_FINALIZE_HOST_EXPAND=0 (they expand the 6x6 blocks themselves instead of handing their sums to the host), GP_GICP_SPLIT=0 (GICP
+ * factor: fused search + algebra kernel instead of the correspondence kernel + algebra kernel). */
+enum {
+  GP_KERNEL_REFERENCE = 0,
+  GP_KERNEL_HASHED = 2,
+  GP_KERNEL_GRID_F64 = 3,
+  GP_KERNEL_LOOKAHEAD = 8,
+  GP_KERNEL_GEN2 = 11,
+  GP_KERNEL_STREAM = 12
+};
+enum {
+  GP_TUNE_KERNEL = 0,           /* GP_KERNEL_* */
+  GP_TUNE_SOURCE_POLICY = 1,    /* cache policy of the source stream: 0 per batch (non-temporal iff no two factors share a source cloud), 1 default, 2 non-temporal */
+  GP_TUNE_XCD_CHUNK = 2,        /* workgroup -> tile map: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles dealt round robin */
+  GP_TUNE_STAGGER = 3,          /* round-2 kernels: the odd wave slots of every SIMD start `value` x 512 clocks late (0 = off) */
+  GP_TUNE_TILE_INTERLEAVE = 4,  /* 1 = consecutive factors that share a source cloud take turns tile by tile, 0 (default) = factor-major */
+  GP_TUNE_BALANCE = 5,          /* stream kernel, single factor: 1 (default) = the last round of workgroups takes the lighter share, 0 = flat split */
+  GP_TUNE_EFFECTIVE_KERNEL = 6, /* read-only: the family the batch's current table runs (-1 before the first pass) */
+  GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
+  GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
+                                   bounding box is too large for the block grid), 0 = binned deterministic build (default) */
+  GP_TUNE_KNN_STRUCTURE = 32    /* search structures (gp_point_grid, gp_estimate_covariances_ex, gp_gicp_factor): 0 = binned structure, per-lane search
+                                   (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding box is too large for the block
+                                   grid); 3 = as 0 with the row-tiled covariance pass in front of the per-lane search (exact, measured slower:
+                                   DESIGN.md section 4.8); 4 = as 0 with a second binned level between the cells and the superblocks */
+};
+int gp_vgicp_batch_set_tuning(gp_vgicp_batch_t* batch, int key, int value);
+int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* batch, int key, int* value);
+/* with GP_TUNE_TIMING = 1: the durations of the tile kernel and of the finalize kernel of the last synchronous gp_vgicp_batch_linearize[_view],
+ * i.e. of the kernels as they run INSIDE a step (behind the idle queue the host leaves between two passes), HIP events on the batch's stream */
+int gp_vgicp_batch_last_kernel_ms(const gp_vgicp_batch_t* batch, float* tile_ms, float* finalize_ms);
+/* the per-factor entry points (gp_vgicp_factor_linearize, ..._issue_*) run a batch of one: this is its tuning */
+int gp_vgicp_factor_set_tuning(gp_vgicp_factor_t* factor, int key, int value);
+int gp_voxelmap_set_tuning(gp_voxelmap_t* map, int key, int value);
 /* host-side check hook (runs without a device): the 29 target-side sums of a rigid pass (ACC layout of csrc/gp_device.hpp: count, error,
  * M[6], K[9], TL[6], q x Mr [3], Mr [3]) and the pose delta (column-major 4x4) -> the complete record, i.e. H_t from the sums and
  * H_s = Ad^T H_t Ad, H_ts = -H_t Ad, b_s = -Ad^T b_t (integrated_vgicp_factor_gpu.cpp:199-213 consumes them).  This is the expansion the
  * synchronous single-factor call runs on the host on the added sums of its finalize parts. */
 int gp_debug_expand_rigid(const double sums[32], const double pose[16], gp_linearized6* out);
-/* workgroup -> tile map of the pipeline kernel: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles are
- * dealt to the XCDs round robin */
-int gp_debug_set_xcd_chunk(int tiles);
-/* execution order of a batch's tiles: 1 = consecutive factors that share a source cloud take turns tile by tile, 0 (default) = factor-major */
-int gp_debug_set_tile_interleave(int on);
-/* A/B hook: 1 = build voxel maps with the reference-shaped hashed scheme (atomicCAS claims + atomic sums; also the fallback of clouds
- * whose bounding box is too large for the block grid), 0 = binned deterministic build (default) */
-int gp_debug_set_map_build(int hashed);
-/* A/B hook: 0 = binned structure, per-lane search (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding
- * box is too large for the block grid); 3 = as 0 with the row-tiled covariance pass (one wave per occupied cell row, candidates staged
- * through LDS) in front of the per-lane search -- exact, measured slower; 4 = as 0 with a second binned level
- * (cell size x4) between the cells and the superblocks */
-int gp_debug_set_knn_structure(int mode);
-/* measurement hook: enable != 0 zeroes and starts the work counters of the binned search; enable == 0 stops and reads them:
- * out[0..5] = {shell walks (a query counts once per stage it walks), f32 distance evaluations, f64 distance evaluations, block entries
- * read, occupied cells visited, octant stages (first stage of a 1-NN search)} */
-int gp_debug_knn_counters(int enable, unsigned long long* out);
-/* tuning knob: the odd wave slots of every SIMD start `units` x 512 clocks late (0 = off, default) */
-int gp_debug_set_stagger(int units);
-/* timeline hook: per-workgroup phase timestamps (s_memtime) of the default pipeline kernel into dev_buffer ([num_tiles][16] uint64:
- * slots 0-7 phases, 8 HW_ID, 9 XCC_ID); NULL disables */
-int gp_debug_set_trace_buffer(void* dev_buffer);
+/* timeline hook (measurement): per-workgroup phase timestamps (s_memtime) of THIS batch's single-factor linearise into dev_buffer
+ * ([2048][16] uint64: slots 0-7 phases, 8 HW_ID, 9 XCC_ID, 10 / 11 start / end on the device-wide clock; row 2047: the finalize kernel of the
+ * synchronous call); NULL disables */
+int gp_vgicp_batch_set_trace_buffer(gp_vgicp_batch_t* batch, void* dev_buffer);
 #ifdef __cplusplus
 }
 #endif

@@ -35,8 +35,8 @@ write, _ = per_kernel(write_csv, "WRITE_SIZE")
 for k in sorted(fetch, key=lambda k: -fetch[k]):
     print(f"FETCH_SIZE[KiB] mean={fetch[k]:12.1f} launches={nf[k]:4d} WRITE_SIZE[KiB] mean={write.get(k, float('nan')):10.1f}  {k[:100]}")
 calib = find(fetch, "calibration_stream_kernel")
-tile_f = find(fetch, "vgicp_pipeline")
-tile_w = find(write, "vgicp_pipeline") or 0.0
+tile_f = find(fetch, "vgicp_stream") or find(fetch, "vgicp_pipeline")
+tile_w = find(write, "vgicp_stream") or find(write, "vgicp_pipeline") or 0.0
 res = {"fetch_size_kib": tile_f, "write_size_kib": tile_w, "calibration_fetch_kib": calib, "known_calibration_bytes": 48 * n_src}
 if calib and tile_f:
     k = 48.0 * n_src / (calib * 1024.0)

@@ -276,22 +276,17 @@ def test_unsymmetrised_covariances(gpu, kitti00):
     om = oracle.OracleVoxelMap(0.5)
     om.insert(kitti00["target_points"], tc)
     Lo = oracle.OracleVGICPFactor(om, kitti00["source_points"], sc, 2).linearize(delta)
-    lib = gpu.load()
-    try:
-        for variant in [0, 1, 4, 11]:  # reference-shaped kernel, hashed f64 pipeline, the round-2 grid kernel, default
-            gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
-            vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
-            vm.insert(tgt)
-            L = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, src), delta)
-            assert L.num_inliers == Lo.num_inliers
-            for k in ["H_target", "H_source"]:
-                h = getattr(Lo, k)
-                assert rel_err(getattr(L, k), 0.5 * (h + h.T)) <= PARITY_TOL, (variant, k)
-            for k in ["H_target_source", "b_target", "b_source"]:
-                assert rel_err(getattr(L, k), getattr(Lo, k)) <= PARITY_TOL, (variant, k)
-            assert abs(L.error - Lo.error) <= PARITY_TOL * Lo.error
-    finally:
-        lib.gp_debug_set_variant(11)
+    for variant in [0, 2, 8, 11, 12]:  # GP_KERNEL_*: reference-shaped kernel, hashed pipeline, the round-2 grid kernel, second generation, stream (default)
+        vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+        vm.insert(tgt)
+        L = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, src).set_tuning(0, variant), delta)
+        assert L.num_inliers == Lo.num_inliers
+        for k in ["H_target", "H_source"]:
+            h = getattr(Lo, k)
+            assert rel_err(getattr(L, k), 0.5 * (h + h.T)) <= PARITY_TOL, (variant, k)
+        for k in ["H_target_source", "b_target", "b_source"]:
+            assert rel_err(getattr(L, k), getattr(Lo, k)) <= PARITY_TOL, (variant, k)
+        assert abs(L.error - Lo.error) <= PARITY_TOL * Lo.error
     # GICP reads both clouds' covariances the same way
     fg = gpu.IntegratedGICPFactorGPU(0, 1, tgt, src)
     Lg = fg.linearize_delta(delta)

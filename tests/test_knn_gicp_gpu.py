@@ -98,14 +98,10 @@ def test_binned_and_hashed_structures_agree(gpu, kitti00):
     p = kitti00["target_points"]
     q = kitti00["source_points"][:4000]
     res = []
-    try:
-        for hashed in (0, 1):
-            gpu._capi.check(lib.gp_debug_set_knn_structure(hashed), "structure")
-            tree = gpu.KdTreeGPU(gpu.PointCloudGPU(p), cell_size=0.5)
-            res.append(tree.knn_search(q, 10))
-            res.append(tree.knn_search(q, 1, max_sq_dist=0.04))
-    finally:
-        lib.gp_debug_set_knn_structure(0)
+    for hashed in (0, 1):  # GP_TUNE_KNN_STRUCTURE of THIS structure (gp_point_grid_create_ex)
+        tree = gpu.KdTreeGPU(gpu.PointCloudGPU(p), cell_size=0.5, structure=hashed)
+        res.append(tree.knn_search(q, 10))
+        res.append(tree.knn_search(q, 1, max_sq_dist=0.04))
     assert np.abs(res[0][1] - res[2][1]).max() == 0.0 and (res[0][0] == res[2][0]).mean() > 0.999
     np.testing.assert_array_equal(res[1][2], res[3][2])
     assert np.array_equal(res[1][1][res[1][2] == 1], res[3][1][res[3][2] == 1])
@@ -122,14 +118,10 @@ def test_binned_and_hashed_structures_agree(gpu, kitti00):
     # covariance estimation: the per-lane search on the binned structure (default), the row-tiled pass, two binned levels and the hashed grid agree
     # (same exact neighbour sets; ties may be ordered differently, which the sample covariance does not see)
     covs = []
-    try:
-        for mode in (0, 3, 4, 1):
-            gpu._capi.check(lib.gp_debug_set_knn_structure(mode), "structure")
-            fr0 = gpu.PointCloudGPU(p)
-            assert gpu.estimate_covariances_gpu(fr0, 10) == 0
-            covs.append(fr0.download("covs").astype(np.float64))
-    finally:
-        lib.gp_debug_set_knn_structure(0)
+    for mode in (0, 3, 4, 1):
+        fr0 = gpu.PointCloudGPU(p)
+        assert gpu.estimate_covariances_gpu(fr0, 10, structure=mode) == 0
+        covs.append(fr0.download("covs").astype(np.float64))
     for other in covs[1:]:
         rel = np.linalg.norm((covs[0] - other).reshape(len(p), -1), axis=1) / np.linalg.norm(other.reshape(len(p), -1), axis=1)
         assert (rel < 1e-5).mean() > 0.999, (rel < 1e-5).mean()  # all but the neighbourhoods with exact distance ties at rank k

@@ -1,9 +1,10 @@
 """GPU parity tests of the VGICP hot path: HIP (through the C-ABI) vs the CPU oracle on the same seeded inputs.
 
-Tolerance: the north-star gate is <= 1e-5 relative on H and b.  The default kernel (variant 11, gp_vgicp_tile2.hpp; variant 8 = 4 + look-ahead lookup for what it does not cover) computes the transform, the
-fused covariance, its inverse and the residual in f64 and the outer products that follow in f32: measured <= 1e-7, held
-here to PARITY_TOL = 1e-6 -- ten times tighter than required.  The all-f64 variants (0, 1, 3) are held to F64_TOL = 1e-7
-(the only f32 quantity left is the stored voxel mean offset)."""
+Tolerance: the north-star gate is <= 1e-5 relative on H and b.  The default kernel (GP_KERNEL_STREAM, gp_vgicp_stream.hpp; GP_KERNEL_LOOKAHEAD / _HASHED for
+what it does not cover) computes the transform, the fused covariance, its inverse and the residual in f64 and the outer products that follow in
+f32: measured <= 1e-7, held here to PARITY_TOL = 1e-6 -- ten times tighter than required.  The all-f64 families (GP_KERNEL_REFERENCE, _GRID_F64) are
+held to F64_TOL = 1e-7 (the only f32 quantity left is the stored voxel mean offset).  Kernel families are selected PER FACTOR / PER BATCH
+(gp_vgicp_factor_set_tuning / gp_vgicp_batch_set_tuning): the library has no process-global switches."""
 import ctypes as C
 
 import numpy as np
@@ -76,31 +77,42 @@ def test_rigid_and_general_pose_paths(gpu, kitti00):
         assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), PARITY_TOL, name)
 
 
-DEFAULT_VARIANT = 11
-MIXED_TOL = 1e-6  # variants with f32 outer products (2, 4): measured <= 1e-7, gate 1e-5
+DEFAULT_VARIANT = 12  # GP_KERNEL_STREAM
+MIXED_TOL = 1e-6  # families with f32 outer products: measured <= 1e-7, gate 1e-5
+KERNEL, SOURCE_POLICY = 0, 1  # GP_TUNE_KERNEL, GP_TUNE_SOURCE_POLICY
 
 
-@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (1, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (4, MIXED_TOL), (5, MIXED_TOL), (6, MIXED_TOL), (7, MIXED_TOL), (8, MIXED_TOL), (9, MIXED_TOL), (10, MIXED_TOL), (11, MIXED_TOL)])
+def _factor(gpu, vm, src, variant=None, policy=None):
+    """a factor whose own batch runs kernel family `variant` (GP_KERNEL_*: 0 reference-shaped, 2 hashed line table, 3 block grid f64, 8 look-ahead,
+    11 second generation, 12 stream) with source-stream policy `policy` (0 per batch, 1 default, 2 non-temporal)"""
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    if variant is not None:
+        f.set_tuning(KERNEL, variant)
+    if policy is not None:
+        f.set_tuning(SOURCE_POLICY, policy)
+    return f
+
+
+@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (8, MIXED_TOL), (11, MIXED_TOL), (12, MIXED_TOL)])
 def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
-    """gp_debug_set_variant: 0 reference-shaped kernel, 1 / 2 pipeline kernel over the hashed line table (f64 / f32 outer products),
-    3 / 4 pipeline kernel over the occupancy-block grid (f64 / f32 outer products; 4 is the default) -- linearise and error
-    evaluation, full tiles, a partial tile and the per-lane fallback all go through the selected kernel"""
-    lib = gpu.load()
-    try:
-        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
-        _, src, vm = _build(gpu, kitti00, 0.5)
-        f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
-        _, fo = _oracle(kitti00, 0.5)
-        delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
-        assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), tol, f"variant {variant}")
-        de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
-        err = C.c_double()
-        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
-        fo.linearize(delta)
-        eo = fo.error(de)
-        assert abs(err.value - eo) <= tol * abs(eo)
-    finally:
-        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    """GP_TUNE_KERNEL per factor: 0 reference-shaped kernel, 2 pipeline kernel over the hashed line table, 3 / 8 round-2 pipeline kernel over the
+    occupancy-block grid (f64 / f32 outer products + look-ahead), 11 second generation, 12 stream kernel (default) -- linearise and error
+    evaluation, full tiles, a partial tile and the per-lane tail all go through the selected kernel"""
+    _, src, vm = _build(gpu, kitti00, 0.5)
+    f = _factor(gpu, vm, src, variant)
+    _, fo = _oracle(kitti00, 0.5)
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), tol, f"variant {variant}")
+    de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
+    err = C.c_double()
+    gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+    fo.linearize(delta)
+    eo = fo.error(de)
+    assert abs(err.value - eo) <= tol * abs(eo)
+    # an invalid family is refused, and the refusal leaves the factor as it was
+    with pytest.raises(gpu.GPError):
+        f.set_tuning(KERNEL, 5)
+    assert_linearized_close(_sync_linearize(gpu, f, delta), fo.linearize(delta), tol, f"variant {variant} again")
 
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1023, 1024, 1025, 4097])
@@ -161,9 +173,9 @@ def _coord_hash32(x, y, z):
     return h
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [2, 8, 12])
 def test_line_table_overflow_walks_on(gpu, variant):
-    """(variants 1 / 2: the hashed line table, the fallback of maps too large for the block grid; variant 4: the same voxels
+    """(family 2: the hashed line table, the fallback of maps too large for the block grid; 8 / 12: the same voxels
     through the occupancy-block grid, where nothing collides)
     the pipeline kernel's line table holds 4 keys per home line; seven voxels built to share one home line force the
     walk-on path (full line, no match -> next line) for hits, and a probe of the same full line for a voxel that does not
@@ -190,19 +202,14 @@ def test_line_table_overflow_walks_on(gpu, variant):
         return (a @ a.transpose(0, 2, 1) * 0.01 + 1e-3 * np.eye(3)).astype(np.float32)
 
     d = dict(target_points=tgt_pts, target_covs=covs(len(tgt_pts)), source_points=src_pts, source_covs=covs(len(src_pts)))
-    lib = gpu.load()
-    try:
-        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
-        _, src, vm = _build(gpu, d, res)
-        assert vm.voxelmap_info.num_voxels == 8
-        f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
-        _, fo = _oracle(d, res, 1)
-        Lo = fo.linearize(np.eye(4))
-        L = _sync_linearize(gpu, f, np.eye(4))
-        assert Lo.num_inliers == 7 * 96 and L.num_inliers == Lo.num_inliers  # every present voxel found, the absent ones missed
-        assert_linearized_close(L, Lo, PARITY_TOL, "colliding voxels")
-    finally:
-        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    _, src, vm = _build(gpu, d, res)
+    assert vm.voxelmap_info.num_voxels == 8
+    f = _factor(gpu, vm, src, variant)
+    _, fo = _oracle(d, res, 1)
+    Lo = fo.linearize(np.eye(4))
+    L = _sync_linearize(gpu, f, np.eye(4))
+    assert Lo.num_inliers == 7 * 96 and L.num_inliers == Lo.num_inliers  # every present voxel found, the absent ones missed
+    assert_linearized_close(L, Lo, PARITY_TOL, "colliding voxels")
 
 
 def test_block_grid_fallback_for_huge_boxes(gpu, kitti00):
@@ -365,32 +372,179 @@ def test_unary_factor_and_caching_protocol(gpu, kitti00, capsys):
     assert c.keys() == [7] and not c.is_binary
 
 
-def test_surface_validation(gpu):
+def _surface_keep(points, normals, delta):
+    """lookup_voxels.cuh:41-50 restated in numpy: a point is rejected when normalized(T p) . (R n) > 0.174 = cos(80 deg)"""
+    p, n = points.astype(np.float64), normals.astype(np.float64)
+    q = p @ delta[:3, :3].T + delta[:3, 3]
+    tn = n @ delta[:3, :3].T
+    return ~(((q / np.linalg.norm(q, axis=1, keepdims=True)) * tn).sum(1) > 0.174)
+
+
+@pytest.mark.parametrize("variant", [0, 8, 12])
+def test_surface_validation(gpu, variant):
     from gtsam_points_amd import synthetic
 
     d = synthetic.make_pair(20000, 40000, seed=5)
+    d["source_normals"] = d["source_normals"].copy()
+    d["source_normals"][::3] *= -1.0  # (the cast normals all face the sensor and pass the gate: turn every third one away)
     _, src, vm = _build(gpu, d, 0.5)
-    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    f = _factor(gpu, vm, src, variant)
     delta = d["T_true"]
     L0 = _sync_linearize(gpu, f, delta)
     f.set_enable_surface_validation(True)
     L1 = _sync_linearize(gpu, f, delta)
-    # restate lookup_voxels.cuh:41-50 in numpy and linearise the surviving subset with the oracle
-    p = d["source_points"].astype(np.float64)
-    n = d["source_normals"].astype(np.float64)
-    q = p @ delta[:3, :3].T + delta[:3, 3]
-    tn = n @ delta[:3, :3].T
-    keep = ~(((q / np.linalg.norm(q, axis=1, keepdims=True)) * tn).sum(1) > 0.174)
+    # linearise the surviving subset with the oracle
+    keep = _surface_keep(d["source_points"], d["source_normals"], delta)
+    assert 0.02 < 1.0 - keep.mean() < 0.98  # the gate really splits this cloud
     omap = oracle.OracleVoxelMap(0.5)
     omap.insert(d["target_points"], d["target_covs"])
-    Lo = oracle.OracleVGICPFactor(omap, d["source_points"][keep], d["source_covs"][keep], 2).linearize(delta)
+    fo = oracle.OracleVGICPFactor(omap, d["source_points"][keep], d["source_covs"][keep], 2)
+    Lo = fo.linearize(delta)
     assert_linearized_close(L1, Lo, PARITY_TOL, "surface validation")
-    assert L1.num_inliers <= L0.num_inliers
+    assert L1.num_inliers < L0.num_inliers
+    # the error evaluation keeps the validated correspondences of the linearisation pose (vgicp_derivatives.cuh:85-139)
+    de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
+    err = C.c_double()
+    gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+    eo = fo.error(de)
+    assert abs(err.value - eo) <= PARITY_TOL * abs(eo)
     # a cloud without normals refuses the switch (integrated_vgicp_factor_gpu.hpp:84-86)
     src2 = gpu.PointCloudGPU(d["source_points"], d["source_covs"])
     f2 = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src2)
     with pytest.raises(gpu.GPError):
         f2.set_enable_surface_validation(True)
+
+
+def test_surface_validation_rides_in_the_ring_at_size(gpu):
+    """900 k source points with normals through the DEFAULT kernel: the normals are the fourth 12-B LDS-DMA row of the stream kernel's ring
+    (3-4 chunks per wave, so the steady-state step with five requests per chunk runs), not a reason to fall back to the round-2 kernel
+    (VERDICT r02 #7).  Against the oracle on the surviving subset, against the round-2 kernel, and bit-reproducible."""
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_c2_workload(900_013, 500_000, seed=9)
+    delta = d["T_true"] @ expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    _, src, vm = _build(gpu, d, 0.5)
+    recs = {}
+    for variant in (12, 8):
+        f = _factor(gpu, vm, src, variant)
+        f.set_enable_surface_validation(True)
+        recs[variant] = (_sync_linearize(gpu, f, delta), _sync_linearize(gpu, f, delta))
+    keep = _surface_keep(d["source_points"], d["source_normals"], delta)
+    assert 0.02 < 1.0 - keep.mean() < 0.98
+    omap = oracle.OracleVoxelMap(0.5)
+    omap.insert(d["target_points"], d["target_covs"])
+    Lo = oracle.OracleVGICPFactor(omap, d["source_points"][keep], d["source_covs"][keep], oracle.max_threads()).linearize(delta)
+    for variant, (L, L2) in recs.items():
+        assert_linearized_close(L, Lo, MIXED_TOL, f"surface validation at size, family {variant}")
+        for k in BLOCKS:
+            assert np.array_equal(getattr(L, k), getattr(L2, k))
+    for k in BLOCKS:
+        assert rel_err(getattr(recs[12][0], k), getattr(recs[8][0], k)) < 1e-9
+
+
+def test_one_validating_factor_does_not_demote_its_batch(gpu, kitti07):
+    """a batch in which ONE factor has set_enable_surface_validation(true): the whole batch still runs the stream kernel (its normals-row
+    instantiation; the other factors' descriptors carry surface_validation = 0 and skip the gate) -- round 2 sent such a batch to the round-2
+    kernel wholesale.  Every factor against the oracle: the validating one on its surviving subset."""
+    lib = gpu.load()
+    normals = {}
+    for i in range(3):
+        w, v = np.linalg.eigh(kitti07[f"covs_{i}"].astype(np.float64))
+        n = v[:, :, 0]  # eigenvector of the smallest eigenvalue: the surface normal the regularised covariance encodes
+        n *= -np.sign((n * kitti07[f"points_{i}"]).sum(1, keepdims=True) + 1e-30)  # towards the sensor ...
+        n[::4] *= -1.0  # ... except every fourth one, so that the gate has something to reject
+        normals[i] = n.astype(np.float32)
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"], normals=normals[i]) for i in range(3)]
+    maps = []
+    for c in clouds:
+        m = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(c)
+        maps.append(m)
+    pairs = [(0, 1), (1, 2), (0, 2)]
+    factors = [gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
+    factors[1].set_enable_surface_validation(True)
+    deltas = [np.linalg.inv(kitti07["poses"][i]) @ kitti07["poses"][j] for i, j in pairs]
+    F = len(factors)
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch, s = C.c_void_p(), C.c_void_p()
+    gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+    gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+    poses = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in deltas]).copy()
+    out = np.zeros((F, 122))
+    gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, out.ctypes.data), "linearize")
+    eff = C.c_int(-2)
+    gpu._capi.check(lib.gp_vgicp_batch_get_tuning(batch, 6, C.byref(eff)), "get_tuning")  # GP_TUNE_EFFECTIVE_KERNEL
+    assert eff.value == 12
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+    for k, ((i, j), delta) in enumerate(zip(pairs, deltas)):
+        om = oracle.OracleVoxelMap(1.0)
+        om.insert(kitti07[f"points_{i}"], kitti07[f"covs_{i}"])
+        keep = _surface_keep(kitti07[f"points_{j}"], normals[j], delta) if k == 1 else np.ones(len(normals[j]), bool)
+        if k == 1:
+            assert 0.01 < 1.0 - keep.mean() < 0.99
+        Lo = oracle.OracleVGICPFactor(om, kitti07[f"points_{j}"][keep], kitti07[f"covs_{j}"][keep], 2).linearize(delta)
+        assert_linearized_close(gpu.LinearizedSystem6.from_doubles(out[k]), Lo, PARITY_TOL, f"factor {k}")
+
+
+def test_two_threads_two_batches(gpu, kitti07):
+    """"C-ABI calls are thread-compatible per handle, re-entrant across handles".  Two host threads drive two batches (own
+    streams, DIFFERENT kernel families selected per batch) at the same time, 300 synchronous linearise + error passes each; every result must
+    equal, bit for bit, what the same batch returns when it runs alone.  (ctypes releases the GIL around the calls, so they really overlap.)"""
+    import threading
+
+    lib = gpu.load()
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(4)]
+    maps = []
+    for c in clouds:
+        m = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(c)
+        maps.append(m)
+    sets = [([(0, 1), (1, 2), (0, 2)], 12), ([(2, 3), (1, 3)], 8)]
+    work = []
+    for pairs, family in sets:
+        factors = [gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
+        F = len(factors)
+        arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+        batch, s = C.c_void_p(), C.c_void_p()
+        gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+        gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+        gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, KERNEL, family), "tuning")
+        poses = np.stack([np.ascontiguousarray((np.linalg.inv(kitti07["poses"][i]) @ kitti07["poses"][j]).T).reshape(16) for i, j in pairs]).copy()
+        poses_e = np.stack([np.ascontiguousarray((np.linalg.inv(kitti07["poses"][i]) @ kitti07["poses"][j] @ expmap([0.001, 0.002, -0.001, 0.01, -0.02, 0.01])).T).reshape(16)
+                            for i, j in pairs]).copy()
+        ref, ref_e = np.zeros((F, 122)), np.zeros(F)
+        gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, poses.ctypes.data, ref.ctypes.data), "linearize")
+        gpu._capi.check(lib.gp_vgicp_batch_compute_error(batch, poses.ctypes.data, poses_e.ctypes.data, ref_e.ctypes.data), "error")
+        eff = C.c_int(-2)
+        gpu._capi.check(lib.gp_vgicp_batch_get_tuning(batch, 6, C.byref(eff)), "get_tuning")
+        assert eff.value == family and ref[:, 0].min() > 1000
+        work.append(dict(factors=factors, batch=batch, stream=s, poses=poses, poses_e=poses_e, ref=ref, ref_e=ref_e, F=F, bad=0, rc=0))
+    assert not np.array_equal(work[0]["ref"][0], work[1]["ref"][0])
+    start = threading.Barrier(2)
+
+    def run(w):
+        out, err = np.zeros((w["F"], 122)), np.zeros(w["F"])
+        start.wait()
+        for _ in range(300):
+            w["rc"] |= lib.gp_vgicp_batch_linearize(w["batch"], w["poses"].ctypes.data, out.ctypes.data)
+            w["rc"] |= lib.gp_vgicp_batch_compute_error(w["batch"], w["poses"].ctypes.data, w["poses_e"].ctypes.data, err.ctypes.data)
+            if not (np.array_equal(out, w["ref"]) and np.array_equal(err, w["ref_e"])):
+                w["bad"] += 1
+
+    threads = [threading.Thread(target=run, args=(w,)) for w in work]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for w in work:
+        assert w["rc"] == 0 and w["bad"] == 0, (w["rc"], w["bad"])
+        # the other thread's family did not leak into this batch
+        eff = C.c_int(-2)
+        gpu._capi.check(lib.gp_vgicp_batch_get_tuning(w["batch"], 6, C.byref(eff)), "get_tuning")
+        lib.gp_vgicp_batch_destroy(w["batch"])
+        lib.gp_stream_destroy(w["stream"])
+    assert [w["ref"].shape[0] for w in work] == [3, 2]
 
 
 def test_linearity_and_determinism_at_1m(gpu):
@@ -423,28 +577,23 @@ def test_linearity_and_determinism_at_1m(gpu):
     assert L.num_inliers > 0.5 * len(d["source_points"])
 
 
-@pytest.mark.parametrize("variant", [9, 10, 11])
+@pytest.mark.parametrize("variant,policy", [(11, 1), (11, 2), (11, 0), (12, 1), (12, 2), (12, 0)])
 @pytest.mark.parametrize("n_src", [400_000, 1_000_077])
-def test_second_generation_kernel_at_size(gpu, variant, n_src):
-    """vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp; variants 9 / 10 / 11 = default / non-temporal / per-batch policy on the source stream) only takes over when the batch has >= 768 tiles of
-    512 or 1024 points, which no fixture reaches: 400 k points -> 782 tiles of 512 (two chunks per wave), 1,000,077 points -> 977 tiles
-    of 1024 with a partial last tile (a full wave, a partial wave through the per-lane path, an empty wave).  Against the oracle, plus
-    bit-reproducibility and agreement with the round-2 kernel far below the parity tolerance."""
+def test_second_and_third_generation_kernels_at_size(gpu, variant, policy, n_src):
+    """vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp, family 11) and vgicp_stream_kernel (gp_vgicp_stream.hpp, family 12, default) with the default /
+    the non-temporal / the per-batch policy on the source stream, at sizes no fixture reaches.  Family 11: 400 k points -> 782 tiles of 512
+    (two chunks per wave), 1,000,077 points -> 977 tiles of 1024 with a partial last tile.  Family 12: one resident round of 1024 workgroups
+    with 6-7 / 13-16 chunks each (one or two per wave; three or four) and 13 points behind the last full chunk for the per-lane tail.
+    Against the oracle, plus bit-reproducibility and agreement with the round-2 kernel far below the parity tolerance."""
     from gtsam_points_amd import synthetic
 
     d = synthetic.make_c2_workload(n_src, 500_000, seed=7)
-    lib = gpu.load()
     delta = d["T_true"] @ expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
     _, src, vm = _build(gpu, d, 0.5)
-    try:
-        gpu._capi.check(lib.gp_debug_set_variant(8), "variant")
-        L8 = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, src), delta)
-        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
-        f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
-        L = _sync_linearize(gpu, f, delta)
-        L2 = _sync_linearize(gpu, f, delta)
-    finally:
-        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    L8 = _sync_linearize(gpu, _factor(gpu, vm, src, 8), delta)
+    f = _factor(gpu, vm, src, variant, policy)
+    L = _sync_linearize(gpu, f, delta)
+    L2 = _sync_linearize(gpu, f, delta)
     for k in BLOCKS:
         assert np.array_equal(getattr(L, k), getattr(L2, k))
         assert rel_err(getattr(L, k), getattr(L8, k)) < 1e-9, k  # same algorithm, arithmetic differs at the 1e-16 level per point
@@ -453,31 +602,62 @@ def test_second_generation_kernel_at_size(gpu, variant, n_src):
     assert_linearized_close(L, fo.linearize(delta), MIXED_TOL, f"variant {variant}, {n_src} points")
     # the error evaluation runs through the same kernel family: correspondences and M at `delta`, residual at `de`
     de = delta @ expmap([0.002, -0.001, 0.003, 0.01, 0.02, -0.01])
-    try:
-        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
-        err, err2 = C.c_double(), C.c_double()
-        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
-        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err2)), "compute_error")
-        e_lin = C.c_double()
-        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(delta), C.byref(e_lin)), "compute_error")
-    finally:
-        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    err, err2 = C.c_double(), C.c_double()
+    gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+    gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err2)), "compute_error")
+    e_lin = C.c_double()
+    gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(delta), C.byref(e_lin)), "compute_error")
     eo = fo.error(de)
     assert err.value == err2.value
-    if variant == DEFAULT_VARIANT:
-        # a view that starts 12 / 36 bytes into an allocation: the 12-B DMA rows of this kernel take any 4-B aligned array, and the
+    if policy == 0:
+        # a view that starts 12 / 36 bytes into an allocation: the 12-B DMA rows of these kernels take any 4-B aligned array, and the
         # same points must give the same record bit for bit
         whole = gpu.PointCloudGPU(np.concatenate([d["source_points"][:1], d["source_points"]]), np.concatenate([d["source_covs"][:1], d["source_covs"]]))
         view = gpu.PointCloudGPU.from_device(whole.points_gpu[1:], whole.covs_gpu[1:])
         assert view.points_gpu.data_ptr() % 16 != 0
-        Lv = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, view), delta)
+        Lv = _sync_linearize(gpu, _factor(gpu, vm, view, variant, policy), delta)
         for k in BLOCKS:
             assert np.array_equal(getattr(Lv, k), getattr(L, k)), k
+        # a device-resident pose (issue_linearize without a host copy) cannot be checked for orthonormality on the host, so it takes the 92-sum
+        # reference-shaped kernel over the batch's TILE TABLE -- for the stream family that table is the balanced plan itself (tiles of
+        # different sizes, XCD-major): same correspondences, explicit J_s instead of the adjoint identity
+        import torch
+
+        pose_dev = torch.tensor(np.ascontiguousarray(delta.T).reshape(16), dtype=torch.float64, device="cuda")
+        out_dev = torch.zeros(122, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        gpu._capi.check(f._lib.gp_vgicp_factor_issue_linearize(f._h, None, C.c_void_p(pose_dev.data_ptr()), C.c_void_p(out_dev.data_ptr())), "issue_linearize")
+        gpu._capi.check(f._lib.gp_vgicp_factor_sync(f._h), "sync")
+        Ld = gpu.LinearizedSystem6.from_doubles(out_dev.cpu().numpy())
+        assert Ld.num_inliers == L.num_inliers
+        for k in BLOCKS:
+            assert rel_err(getattr(Ld, k), getattr(L, k)) < 1e-7, k
     assert abs(err.value - eo) <= MIXED_TOL * abs(eo), (err.value, eo)
     assert abs(e_lin.value - L.error) <= 1e-7 * abs(L.error)  # evaluated at the linearisation pose it is the linearise's own error
 
 
-@pytest.mark.parametrize("variant", [0, 4, 8, 11])
+@pytest.mark.parametrize("n_src", [64 * 4096 * 5 + 37])
+def test_stream_kernel_beyond_one_round_of_four_chunk_waves(gpu, n_src):
+    """1.3 M points: more than 4096 waves x 4 chunks, so the stream kernel keeps ONE resident round (1024 workgroups) and its waves stream 5-6
+    chunks each through the ring (the steady-state step repeated; both ring parities at the end of a stream), where family 11 launches 1281
+    tiles in two rounds.  Both against the oracle and against each other."""
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_c2_workload(n_src, 500_000, seed=11)
+    delta = d["T_true"] @ expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
+    _, src, vm = _build(gpu, d, 0.5)
+    L12 = _sync_linearize(gpu, _factor(gpu, vm, src, 12), delta)
+    L12f = _sync_linearize(gpu, _factor(gpu, vm, src, 12).set_tuning(5, 0), delta)  # GP_TUNE_BALANCE = 0: flat split
+    L11 = _sync_linearize(gpu, _factor(gpu, vm, src, 11), delta)
+    _, fo = _oracle(d, 0.5, oracle.max_threads())
+    Lo = fo.linearize(delta)
+    for L, what in [(L12, "stream"), (L12f, "stream, flat split"), (L11, "second generation")]:
+        assert_linearized_close(L, Lo, MIXED_TOL, what)
+    for k in BLOCKS:
+        assert rel_err(getattr(L12, k), getattr(L11, k)) < 1e-9 and rel_err(getattr(L12, k), getattr(L12f, k)) < 1e-9
+
+
+@pytest.mark.parametrize("variant", [0, 8, 11, 12])
 def test_non_finite_source_points_are_skipped(gpu, kitti00, variant):
     """LiDAR clouds carry NaN / inf returns.  A non-finite source point has no voxel: the reference floors it into an undefined integer
     coordinate that no table holds; on the device the conversion of a NaN is 0, i.e. voxel (0, 0, 0) -- which this map contains -- so
@@ -504,18 +684,14 @@ def test_non_finite_source_points_are_skipped(gpu, kitti00, variant):
     tgt = gpu.PointCloudGPU(tp, tc)
     vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
     vm.insert(tgt)
-    try:
-        gpu._capi.check(lib.gp_debug_set_variant(variant), "variant")
-        out = {}
-        for name, (pp, cc) in dict(dirty=(p, c), clean=(p[keep], c[keep])).items():
-            src = gpu.PointCloudGPU(pp, cc)
-            f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
-            L = _sync_linearize(gpu, f, delta)
-            err = C.c_double()
-            gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
-            out[name] = (L, err.value, gpu.overlap_gpu(vm, src, delta))
-    finally:
-        lib.gp_debug_set_variant(DEFAULT_VARIANT)
+    out = {}
+    for name, (pp, cc) in dict(dirty=(p, c), clean=(p[keep], c[keep])).items():
+        src = gpu.PointCloudGPU(pp, cc)
+        f = _factor(gpu, vm, src, variant)
+        L = _sync_linearize(gpu, f, delta)
+        err = C.c_double()
+        gpu._capi.check(f._lib.gp_vgicp_factor_compute_error(f._h, gpu.types._pose16(delta), gpu.types._pose16(de), C.byref(err)), "compute_error")
+        out[name] = (L, err.value, gpu.overlap_gpu(vm, src, delta))
     (Ld, ed, od), (Lc, ec, oc) = out["dirty"], out["clean"]
     assert Ld.num_inliers == Lc.num_inliers
     for k in BLOCKS:

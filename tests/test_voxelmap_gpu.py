@@ -239,8 +239,10 @@ def test_binned_build_is_bit_reproducible_and_matches_the_hashed_build(gpu, kitt
     intens = np.abs(kitti00["target_points"][:, 0]).astype(np.float32)
     cloud = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"], intensities=intens)
 
-    def build():
+    def build(hashed=False):
         vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+        if hashed:
+            gpu._capi.check(lib.gp_voxelmap_set_tuning(vm._h, gpu._capi.GP_TUNE_MAP_BUILD, 1), "gp_voxelmap_set_tuning")
         vm.insert(cloud)
         return vm
 
@@ -252,11 +254,7 @@ def test_binned_build_is_bit_reproducible_and_matches_the_hashed_build(gpu, kitt
     for k in ["num_points", "means", "covs", "intensities"]:
         assert np.array_equal(da[k], db[k]), k
     assert lib.gp_voxelmap_has_block_grid(a._h) == 1
-    try:
-        gpu._capi.check(lib.gp_debug_set_map_build(1), "map build")
-        h = build()
-    finally:
-        lib.gp_debug_set_map_build(0)
+    h = build(hashed=True)  # gp_voxelmap_set_tuning(GP_TUNE_MAP_BUILD, 1) on THIS map
     ch, nh, mh, vh = h.download_f64()
     assert len(ch) == len(ca)
     order = {tuple(c): i for i, c in enumerate(ch.tolist())}
