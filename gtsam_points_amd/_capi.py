@@ -188,6 +188,7 @@ _SIGNATURES = {
     "gp_voxelmap_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gp_vgicp_batch_set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_debug_expand_rigid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_debug_stream_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "gp_trim_device_cache": (C.c_int, []),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
@@ -196,6 +197,8 @@ _SIGNATURES = {
 GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM = 0, 2, 3, 8, 11, 12
 GP_TUNE_KERNEL, GP_TUNE_SOURCE_POLICY, GP_TUNE_XCD_CHUNK, GP_TUNE_STAGGER, GP_TUNE_TILE_INTERLEAVE, GP_TUNE_BALANCE, GP_TUNE_EFFECTIVE_KERNEL = 0, 1, 2, 3, 4, 5, 6
 GP_TUNE_TIMING = 7
+GP_TUNE_XCD_WEIGHT_0 = 8
+GP_TUNE_OVERLAP_FINALIZE = 17
 GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32
 KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM]
 

@@ -1,29 +1,77 @@
-"""Build-time check of the hand-placed vmcnt arithmetic (called by the Makefile on the device assembly of gp_vgicp.hip).
+"""Build-time checks of the hand-placed vmcnt arithmetic (called by the Makefile on the device assembly of gp_vgicp.hip).
 
-vgicp_pipeline2_kernel issues every vector-memory instruction from inline asm and counts the requests in flight itself.  A load that
-hipcc tracks on its own would make it insert `s_waitcnt vmcnt(N)` instructions of its own -- normally vmcnt(0) in front of an LDS read
-or of a register the tracked load writes -- which drain the source requests in flight and silently serialise the pipeline (it happened
-three times while the kernel was written: the LDS-DMA builtin, the surface-validation normals, the per-lane loads of the partial-wave
-path).  This script lists, per instantiation, the vmcnt waits that are NOT inside an inline-asm block; tests/test_build_cpu.py wants 0."""
+vgicp_pipeline2_kernel and vgicp_stream_kernel issue every vector-memory instruction from inline asm and count the requests in flight
+themselves.  Two things can silently break that, and both are checked here per instantiation:
+
+  compiler_vmcnt_waits   a load that hipcc tracks on its own makes it insert `s_waitcnt vmcnt(N)` instructions of its own -- normally vmcnt(0)
+                         in front of an LDS read or of a register the tracked load writes -- which drain the source requests in flight and
+                         serialise the pipeline (it happened three times while the second generation was written).  Counted: vmcnt waits
+                         that are NOT inside an inline-asm block.
+  inflight_reg_touches   the destination registers of an asm-issued load hold nothing until the matching wait, but the compiler believes
+                         they are defined at the issue: a copy it places in between (a phi at a loop back-edge, the operand copy in front of
+                         one of two alternative wait statements) reads them before the data lands (round 3: wild record offsets, a memory
+                         fault on the GPU box).  Counted, walking the text in layout order: instructions outside asm blocks that read or
+                         write a register of a load still in flight (in-order retirement: an asm `s_waitcnt vmcnt(N)` retires all but the
+                         N youngest requests; LDS-DMA requests have no destination registers but take part in the count).
+tests/test_build_cpu.py wants 0 for both."""
 import re
 import sys
 
-name, inside, counts = None, False, {}
+KERNEL = re.compile(r"^(_ZN2gp(?:22vgicp_pipeline2_kernel|19vgicp_stream_kernel)\w+):")
+VREG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs_of(text):
+    out = set()
+    for m in VREG.finditer(text):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+name, inside = None, False
+waits, touches, examples = {}, {}, {}
+inflight = []  # one entry per asm-issued vector-memory request, oldest first: set of destination registers (empty for LDS-DMA)
 for line in open(sys.argv[1]):
-    m = re.match(r"^(_ZN2gp(?:22vgicp_pipeline2_kernel|19vgicp_stream_kernel)\w+):", line)
+    m = KERNEL.match(line)
     if m:
         name = m.group(1)
-        counts[name] = 0
+        waits[name], touches[name], examples[name] = 0, 0, []
+        inflight = []
         continue
     if name is None:
         continue
-    if "s_endpgm" in line:
+    code = line.split(";")[0].strip()
+    if "s_endpgm" in code:
         name = None
-    elif "#ASMSTART" in line:
+        continue
+    if "#ASMSTART" in line:
         inside = True
-    elif "#ASMEND" in line:
+        continue
+    if "#ASMEND" in line:
         inside = False
-    elif "s_waitcnt" in line and "vmcnt" in line and not inside:
-        counts[name] += 1
-for k, v in sorted(counts.items()):
-    print(f"{k} compiler_vmcnt_waits {v}")
+        continue
+    if not code or code.endswith(":") or code.startswith("."):
+        continue
+    if inside:
+        if code.startswith("global_load_lds"):
+            inflight.append(set())
+        elif code.startswith("global_load"):
+            inflight.append(regs_of(code.split(",")[0]))
+        else:
+            w = re.match(r"s_waitcnt\s+vmcnt\((\d+)\)", code)
+            if w:
+                keep = int(w.group(1))
+                inflight = inflight[len(inflight) - keep:] if keep else []
+        continue
+    if "s_waitcnt" in code and "vmcnt" in code:
+        waits[name] += 1
+    pending = set().union(*inflight) if inflight else set()
+    if pending and not code.startswith("s_") and (regs_of(code) & pending):
+        touches[name] += 1
+        if len(examples[name]) < 3:
+            examples[name].append(code)
+for k in sorted(waits):
+    print(f"{k} compiler_vmcnt_waits {waits[k]} inflight_reg_touches {touches[k]}" + ("   e.g. " + " | ".join(examples[k]) if examples[k] else ""))

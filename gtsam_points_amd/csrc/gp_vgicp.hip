@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_tile_kernel(const FactorD
       tile.begin = tile_idx * inl.tile_points;
       tile.count = min(inl.tile_points, inl.factor.n - tile.begin);
     } else {  // the table of a single-factor stream batch is its plan (gp_vgicp_stream.hpp): tiles of different sizes, XCD-major
-      plan_tile(inl.plan, tile_idx / inl.plan.wgs_per_xcd, tile_idx % inl.plan.wgs_per_xcd, &tile.begin, &tile.count);
+      const int px = tile_idx / inl.plan.wgs_per_xcd, pq = tile_idx % inl.plan.wgs_per_xcd;
+      plan_tile(plan_fields(inl.plan, px, pq), px, pq, &tile.begin, &tile.count);
     }
     tile.row = tile_idx;
   } else {
@@ -482,6 +483,79 @@ __global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const Fac
   }
 }
 
+// Overlapped finalize of a synchronous single-factor linearise (round 3).  `nparts` workgroups of 256 threads, launched on a SECOND stream right
+// behind the tile kernel: part g waits until arrive[g] has reached `target[g]` -- every tile workgroup of its share has published its partial
+// row write-through and added 1 (vgicp_stream_kernel) -- then sums its rows in the fixed order of vgicp_finalize_rigid_kernel's split form
+// and hands its 32 SUMS to the host (host-mapped record slot + completion word).  What this removes from the step: the kernel boundary behind
+// the tile kernel (end-of-kernel cache flush + dependent dispatch, 1.7-2 us) and the finalize's own start-up; the parts are resident and have
+// their pointers when the last row arrives.  No workgroup of the tile kernel ever waits for this kernel, and the host launches the tile kernel
+// FIRST, so whatever queue the two streams map to there is no deadlock: at worst this kernel starts when the tile kernel has finished.
+// A wait that exceeds ~30 ms (a tile kernel that never ran) stores the failure word kFinalizeTimedOut instead of the sequence number.
+constexpr unsigned long long kFinalizeTimedOut = ~0ull;
+struct ArriveTargets {
+  unsigned long long v[16];
+};
+__global__ void __launch_bounds__(256) vgicp_finalize_overlapped_kernel(const double* __restrict__ partials, const int num_rows, const int rows_per_part,
+                                                                         const unsigned long long* __restrict__ arrive, const ArriveTargets targets,
+                                                                         gp_linearized6* __restrict__ out, const DoneFlags done) {
+  constexpr int kSlices = 8, kWaves = 4;
+  const int part = blockIdx.x;
+  const int row_begin = part * rows_per_part, row_count = min(rows_per_part, num_rows - row_begin);
+  __shared__ double wsum[kWaves][32];
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    const unsigned long long want = targets.v[part];
+    int good = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(arrive + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > 40000000u / 16u) {  // ~30 ms of polling: the tile kernel is not coming
+        good = 0;
+        break;
+      }
+    }
+    ok = good;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!ok) {
+    if (threadIdx.x == 0 && done.flags) __hip_atomic_store(done.flags + part, kFinalizeTimedOut, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  {
+    // the rows were stored write-through: read them past this CU's L1 (sc1), all of a lane's rows requested in one batch, fixed summation order
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(partials + (size_t)row_begin * ACC_STRIDE + comp);
+    double total = 0.0;
+    for (int t0 = slice; t0 < row_count; t0 += 32 * kSlices) {
+      double v[32];
+#pragma unroll
+      for (int k = 0; k < 32; k++) {
+        const int t = t0 + k * kSlices;
+        v[k] = t < row_count ? __builtin_bit_cast(double, __hip_atomic_load(base + (size_t)t * ACC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+      }
+#pragma unroll
+      for (int w = 16; w > 0; w >>= 1) {
+#pragma unroll
+        for (int k = 0; k < w; k++) v[k] += v[k + w];
+      }
+      total += v[0];
+    }
+    total += __shfl_xor(total, 32, 64);  // the wave's two slices
+    if (lane < 32) wsum[wave][lane] = total;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  if (lane < 32) {
+    const double s = (wsum[0][lane] + wsum[2][lane]) + (wsum[1][lane] + wsum[3][lane]);  // the order of vgicp_finalize_rigid_kernel<256>: bit-identical records
+    reinterpret_cast<double*>(out + part)[lane] = s;
+  }
+  if (done.flags) {
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(done.flags + part, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
                                                                              double* __restrict__ out, int single_tile_count, const DoneFlags done) {
   const int fi = blockIdx.x;
@@ -552,13 +626,18 @@ struct gp_vgicp_batch;
 
 // Per-batch tuning (gp_vgicp_batch_set_tuning / gp_vgicp_factor_set_tuning; keys GP_TUNE_* of gtsam_points_hip.h).  Nothing here is process-global:
 // two batches on two threads may run different kernels side by side (re-entrant across handles).
+constexpr int kDefaultSkewPermille = 100;
 struct gp_vgicp_tuning {
   int kernel = GP_KERNEL_STREAM;  // GP_KERNEL_*: which tile kernel family the batch prefers (it falls back where that family does not apply)
   int source_policy = 0;          // cache policy of the source stream: 0 = per batch (non-temporal iff no two factors share a source cloud), 1 = default, 2 = non-temporal
   int xcd_chunk = 0;              // workgroup -> tile map: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles dealt round robin
   int stagger = 0;                // round-2 kernels: odd wave slots start `stagger` x 512 clocks late
   int tile_interleave = 0;        // consecutive factors that share a source cloud take turns tile by tile
-  int balance = 1;                // stream kernel, single factor: 1 = the last round of workgroups takes the lighter share, 0 = flat floor split
+  int xcd_weights[8] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // GP_TUNE_XCD_WEIGHT_0 + x: share of XCD x in 1/1000 of the mean (unset: the library's table)
+  bool xcd_weights_set = false;
+  int overlap_finalize = 0;       // synchronous single-factor linearise of the stream family: finalize workgroups on a second stream wait for arrival counters
+                                  // (measured: the second stream costs ~10 us per step on this stack, profiles/r03_overlap_finalize.jsonl: off by default)
+  int balance = kDefaultSkewPermille;  // stream kernel, one large factor: how much more a dispatch round takes than the next, in 1/1000 of the mean share (0 = flat)
 };
 
 struct gp_vgicp_factor {
@@ -588,8 +667,13 @@ struct gp_vgicp_batch {
   int family = 0;         // GP_KERNEL_* the tile table was built for (tuning.kernel after the fallbacks)
   bool nt = false;        // source stream non-temporal (tuning.source_policy resolved)
   bool any_sv = false;    // some factor validates surfaces
-  gp::StreamPlan plan{};  // stream kernel, single factor: how the chunks are dealt (also written into the tile table)
+  bool planned = false;   // stream kernel, one large factor: the tile list is a balanced StreamPlan (else fixed tiles of tile_points)
+  gp::StreamPlan plan{};  // ... how the chunks are dealt (also written into the tile table)
   unsigned long long* trace = nullptr;  // timeline build of the tile kernel: [2048][16] uint64 device buffer (gp_vgicp_batch_set_trace_buffer)
+  // overlapped finalize (GP_TUNE_OVERLAP_FINALIZE; synchronous single-factor calls of the stream family)
+  hipStream_t fin_stream = nullptr;       // the finalize workgroups' own stream (created on first use)
+  gp::DeviceArray d_arrive;               // 16 monotonic arrival counters
+  unsigned long long arrived[16] = {0};   // what the counters read once every launch issued so far has finished
   bool timing = false;                  // GP_TUNE_TIMING: the synchronous linearise brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_tile_ms = 0.f, last_finalize_ms = 0.f;
@@ -651,37 +735,88 @@ struct PoseSource {
   const double* d_lin = nullptr;
   const double* d_eval = nullptr;
   gp::InlinePoses inl{};
+  unsigned long long* arrive = nullptr;  // overlapped finalize: the tile workgroups announce their rows here (stream kernel only)
+  int rows_per_part = 1;
 };
 
-// Stream kernel, ONE factor of n points: the launch geometry (number of workgroups, a multiple of 8) and how the chunks are dealt.
-// At most one resident round of workgroups whatever n is; below that, four chunks per workgroup (one per wave).
-int make_stream_plan(int n, bool late_light, gp::StreamPlan* p) {
+// Stream kernel, ONE large factor of n points: the launch geometry (number of workgroups, a multiple of 8) and how the chunks are dealt
+// (StreamPlan, gp_vgicp_shared.hpp).  At most one resident round of workgroups whatever n is.
+//   skew_permille   how much more a dispatch round takes than the next one, in 1/1000 of the mean share (0 = flat split)
+//   xcd_weights     per-XCD share in 1/1000 of the mean share (1000 = equal), or null = kXcdWeightPermille
+// Measured on MI355X (round 3, per-workgroup timelines of the 1 M-point headline): the workgroups of XCDs 4-7 START 0.3-0.7 us behind those of
+// XCD 0 (the dispatcher reaches them later) and end as much later -- the "XCD spread" round 2 saw.  Giving them 3-8 % smaller shares did NOT
+// move the kernel's duration beyond noise (11.54 / 11.56 / 11.64 / 11.41 us for four tables, profiles/r03_sweep_xcd_weights.jsonl): the
+// shares stay equal, the knob stays (GP_TUNE_XCD_WEIGHT_0 + x).
+constexpr int kXcdWeightPermille[gp::kNumXCD] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};
+int make_stream_plan(int n, int skew_permille, const int* xcd_weights, gp::StreamPlan* p) {
   const int C = n / gp::kChunkPoints;
-  int G = std::min(kResidentWorkgroups, (std::max((C + 3) / 4, 1) + gp::kNumXCD - 1) / gp::kNumXCD * gp::kNumXCD);
+  const int G = std::min(kResidentWorkgroups, (std::max((C + 3) / 4, 1) + gp::kNumXCD - 1) / gp::kNumXCD * gp::kNumXCD);
   const int gx = G / gp::kNumXCD;
+  *p = gp::StreamPlan{};
   p->tail = n % gp::kChunkPoints;
-  p->cx = C / gp::kNumXCD;
-  p->cr = C % gp::kNumXCD;
   p->wgs_per_xcd = gx;
-  const int cmax = p->cx + (p->cr ? 1 : 0);
-  // the last round: the workgroups the dispatcher places when every compute unit of the XCD (32) already holds the earlier ones
-  const int cus_per_xcd = kResidentWorkgroups / 4 / gp::kNumXCD;
-  int late = std::min(gx, cus_per_xcd), early = gx - late;
-  int hi = (cmax + gx - 1) / gx;
-  if (!late_light || early == 0 || p->cx - early * hi < late * (hi - 1)) {  // the late share would fall below hi - 1 per workgroup: flat split instead
-    early = 0;
-    late = gx;
-    hi = 0;
+  // shares of the XCDs: proportional to their weights, whole chunks, summing to C (largest remainders first; equal weights = cx or cx + 1)
+  const int* w = xcd_weights ? xcd_weights : kXcdWeightPermille;
+  int share[gp::kNumXCD];
+  {
+    int64_t wsum = 0;
+    for (int x = 0; x < gp::kNumXCD; x++) wsum += std::max(w[x], 1);
+    int given = 0;
+    int64_t frac[gp::kNumXCD];
+    for (int x = 0; x < gp::kNumXCD; x++) {
+      const int64_t num = (int64_t)C * std::max(w[x], 1);
+      share[x] = (int)(num / wsum);
+      frac[x] = num % wsum;
+      given += share[x];
+    }
+    for (int left = C - given; left > 0; left--) {
+      int best = 0;
+      for (int x = 1; x < gp::kNumXCD; x++)
+        if (frac[x] > frac[best]) best = x;
+      share[best]++;
+      frac[best] = -1;
+    }
   }
-  p->early_wgs = early;
-  p->hi = hi;
-  const int rem0 = p->cx - early * hi, rem1 = rem0 + 1;
-  p->lo0 = rem0 / late;
-  p->extra0 = rem0 % late;
-  p->lo1 = rem1 / late;
-  p->extra1 = rem1 % late;
+  for (int x = 0, at = 0; x < gp::kNumXCD; x++) {
+    p->xbegin[x] = at;
+    at += share[x];
+  }
+  const int rounds = (gx + gp::kStreamRound - 1) / gp::kStreamRound;  // <= 4
+  const int late = gx - gp::kStreamRound * (rounds - 1);
+  auto fill = [&](int x, double skew) {  // shares of the rounds of XCD x in front of its last one; returns what the last round's workgroups share
+    const double mean = (double)share[x] / gx;
+    int used = 0;
+    for (int r = 0; r < 3; r++) p->n[x][r] = p->pre[x][r] = 0;
+    for (int r = 0; r + 1 < rounds; r++) {
+      p->n[x][r] = std::max(0, (int)std::ceil(mean * (1.0 + skew * (0.5 * (rounds - 1) - r)) - 1e-9));  // (rounded up: the last round never ends up above the one before it)
+      p->pre[x][r] = used;
+      used += gp::kStreamRound * p->n[x][r];
+    }
+    p->before_last[x] = used;
+    return share[x] - used;
+  };
+  // the last round must get something sensible on every XCD: at least a third of the mean share per workgroup, never a negative rest; else
+  // (and for skew 0) ONE flat round per XCD: every workgroup floor(share / gx) chunks, the first share % gx one more
+  bool skewed = skew_permille > 0 && rounds > 1;
+  for (int x = 0; x < gp::kNumXCD && skewed; x++) {
+    const int rem = fill(x, skew_permille / 1000.0);
+    if (rem < 0 || (int64_t)rem * 3 * gx < (int64_t)share[x] * late) skewed = false;
+  }
+  p->last_begin = skewed ? gp::kStreamRound * (rounds - 1) : 0;
+  if (!skewed)
+    for (int x = 0; x < gp::kNumXCD; x++) {
+      for (int r = 0; r < 3; r++) p->n[x][r] = p->pre[x][r] = 0;
+      p->before_last[x] = 0;
+    }
+  const int late_wgs = gx - p->last_begin;
+  for (int x = 0; x < gp::kNumXCD; x++) {
+    const int left = share[x] - p->before_last[x];
+    p->lo[x] = left / late_wgs;
+    p->extra[x] = left % late_wgs;
+  }
   return G;
 }
+constexpr int kPlanMinPoints = 65536;  // single factors below this keep the fixed tiles of a batch (their records then do not depend on how they are batched)
 
 int build_table(gp_vgicp_batch* b) {
   const int F = (int)b->factors.size();
@@ -714,16 +849,17 @@ int build_table(gp_vgicp_batch* b) {
   b->family = fam;
   b->gen2_ok = fam == GP_KERNEL_GEN2 || fam == GP_KERNEL_STREAM;
   // tiles
-  if (fam == GP_KERNEL_STREAM && F == 1) {
-    // one factor: the balanced plan; the table holds the same tiles the in-argument launch derives from the plan (plan_tile)
-    const int G = make_stream_plan(descs[0].n, b->tuning.balance != 0, &b->plan);
+  b->planned = fam == GP_KERNEL_STREAM && F == 1 && descs[0].n >= kPlanMinPoints;
+  if (b->planned) {
+    // one large factor: the balanced plan; the table holds the same tiles the in-argument launch derives from the plan (plan_tile)
+    const int G = make_stream_plan(descs[0].n, b->tuning.balance, b->tuning.xcd_weights_set ? b->tuning.xcd_weights : nullptr, &b->plan);
     b->ppt = 4;
     b->tile_points = 0;
     descs[0].tile_begin = 0;
     for (int x = 0; x < gp::kNumXCD; x++)
       for (int q = 0; q < b->plan.wgs_per_xcd; q++) {
         int begin = 0, count = 0;
-        gp::plan_tile(b->plan, x, q, &begin, &count);
+        gp::plan_tile(gp::plan_fields(b->plan, x, q), x, q, &begin, &count);
         tiles.push_back(gp::TileDesc{0, begin, count, (int)tiles.size()});
       }
     descs[0].tile_count = G;
@@ -758,7 +894,7 @@ int build_table(gp_vgicp_batch* b) {
     b->stream_once = b->shares_device_ok && std::adjacent_find(srcs.begin(), srcs.end()) == srcs.end();
     b->nt = b->tuning.source_policy == 2 || (b->tuning.source_policy == 0 && b->stream_once);
   }
-  if (b->tuning.tile_interleave && !(fam == GP_KERNEL_STREAM && F == 1)) {
+  if (b->tuning.tile_interleave && !b->planned) {
     // execution order: consecutive factors that read the SAME source cloud (a submap matched against several targets, BASELINE
     // configs[3]) take turns tile by tile, so the workgroups that run side by side on an XCD read the same source bytes at the same
     // time -- one of them misses L2, the others hit.  Partial rows stay factor-major (TileDesc::row).
@@ -837,7 +973,7 @@ template <int MODE>
 int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   if (b->num_tiles <= 0) return GP_OK;
   const int fam = MODE == gp::MODE_LIN_GENERAL ? GP_KERNEL_REFERENCE : b->family;
-  const bool single_plan = fam == GP_KERNEL_STREAM && b->factors.size() == 1;  // the tile list IS the plan: the contiguous map, whatever xcd_chunk says
+  const bool single_plan = b->planned;  // the tile list IS the plan: the contiguous map, whatever xcd_chunk says
   // the reference-shaped kernels (the 92-sum path included) keep the contiguous map
   const int chunk = (fam == GP_KERNEL_REFERENCE || single_plan) ? 0 : b->tuning.xcd_chunk;
   const dim3 grid_dim(grid_tiles(b->num_tiles, chunk)), block(gp::kBlockThreads);
@@ -849,6 +985,8 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   inl.tile_points = b->tile_points;
   inl.plan = b->plan;
   inl.trace = b->trace;
+  inl.arrive = ps.arrive;
+  inl.rows_per_part = ps.rows_per_part;
   const bool traced = b->trace != nullptr && inl.use && MODE == gp::MODE_LIN;  // the timeline builds exist for single-factor linearise launches
 #define GP_ARGS grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials
   if constexpr (MODE == gp::MODE_LIN_GENERAL) {
@@ -1065,10 +1203,20 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
     case GP_TUNE_TILE_INTERLEAVE:
       t->tile_interleave = value ? 1 : 0;
       return GP_OK;
+    case GP_TUNE_OVERLAP_FINALIZE:
+      t->overlap_finalize = value ? 1 : 0;
+      return GP_OK;
     case GP_TUNE_BALANCE:
-      t->balance = value ? 1 : 0;
+      if (value < 0 || value > 600) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_BALANCE: 0 (flat) .. 600 (per mille of the mean share per dispatch round)");
+      t->balance = value;
       return GP_OK;
     default:
+      if (key >= GP_TUNE_XCD_WEIGHT_0 && key < GP_TUNE_XCD_WEIGHT_0 + 8) {
+        if (value < 500 || value > 1500) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_XCD_WEIGHT_x: 500..1500 (per mille of the mean share)");
+        t->xcd_weights[key - GP_TUNE_XCD_WEIGHT_0] = value;
+        t->xcd_weights_set = true;
+        return GP_OK;
+      }
       return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
   }
 }
@@ -1093,6 +1241,7 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
     case GP_TUNE_STAGGER: *value = b->tuning.stagger; return GP_OK;
     case GP_TUNE_TILE_INTERLEAVE: *value = b->tuning.tile_interleave; return GP_OK;
     case GP_TUNE_BALANCE: *value = b->tuning.balance; return GP_OK;
+    case GP_TUNE_OVERLAP_FINALIZE: *value = b->tuning.overlap_finalize; return GP_OK;
     case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
     default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
   }
@@ -1310,6 +1459,10 @@ int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch) {
   if (!batch) return GP_OK;
   for (auto& e : batch->ev)
     if (e) (void)hipEventDestroy(e);
+  if (batch->fin_stream) {
+    (void)hipStreamSynchronize(batch->fin_stream);
+    (void)hipStreamDestroy(batch->fin_stream);
+  }
   // the staging buffers are about to be freed: the last H2D copy must have finished.  The stream itself is the caller's and may
   // already be gone (the reference's clone() drops it, integrated_vgicp_factor_gpu.cpp:122-134), so it is not synchronised here.
   if (batch->h2d_done) {
@@ -1428,8 +1581,39 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
   const bool sums_only = parts > 1 && host_expand;
   if (b->timing && !b->ev[0])
     for (auto& e : b->ev) GP_HIP(hipEventCreate(&e));
-  GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));
-  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+  const bool overlapped = sums_only && b->family == GP_KERNEL_STREAM && b->tuning.overlap_finalize && !b->timing && !b->trace && parts <= 16;
+  if (overlapped) {
+    // tile kernel on the batch's stream, the finalize parts on a second stream, waiting for the arrival counters (vgicp_finalize_overlapped_kernel)
+    if (!b->fin_stream) {
+      GP_HIP(hipStreamCreateWithFlags(&b->fin_stream, hipStreamNonBlocking));
+      GP_TRY(b->d_arrive.alloc(sizeof(unsigned long long) * 16));
+      GP_HIP(hipMemset(b->d_arrive.ptr, 0, sizeof(unsigned long long) * 16));
+      memset(b->arrived, 0, sizeof(b->arrived));
+    }
+    double* partials = nullptr;
+    GP_TRY(partials_ptr(b, &partials));
+    const int per = (b->num_tiles + parts - 1) / parts;
+    ps.arrive = b->d_arrive.as<unsigned long long>();
+    ps.rows_per_part = per;
+    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));  // FIRST: nothing of it ever waits for the finalize parts
+    gp::ArriveTargets targets{};
+    for (int g = 0; g < parts; g++) {
+      b->arrived[g] += (unsigned long long)std::max(0, std::min(per, b->num_tiles - g * per));
+      targets.v[g] = b->arrived[g];
+    }
+    hipLaunchKernelGGL(gp::vgicp_finalize_overlapped_kernel, dim3(parts), dim3(256), 0, b->fin_stream, (const double*)partials, b->num_tiles, per,
+                       (const unsigned long long*)b->d_arrive.as<unsigned long long>(), targets, reinterpret_cast<gp_linearized6*>(b->h_out_dev), done);
+    GP_HIP(hipGetLastError());
+    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->fin_stream, spin_budget_us(b)));
+    for (int g = 0; g < parts; g++)
+      if (static_cast<const volatile unsigned long long*>(b->h_done.ptr)[g] != done.seq) {
+        (void)hipStreamSynchronize(b->stream);
+        return gp::fail(GP_ERROR_HIP, "VGICP linearise: the finalize parts gave up waiting for the tile kernel (it did not run to completion)");
+      }
+  } else {
+    GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));
+    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+  }
   if (b->timing) {  // measurement: the two kernels of THIS synchronous pass, i.e. behind the idle queue the host left between two passes
     GP_HIP(hipEventSynchronize(b->ev[2]));
     GP_HIP(hipEventElapsedTime(&b->last_tile_ms, b->ev[0], b->ev[1]));
@@ -1460,6 +1644,22 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
         o[k] = a;
       }
     }
+  }
+  return GP_OK;
+}
+
+// host-side check hook (no device needed): the tiles a planned single-factor launch of n points deals to its workgroups, in tile-list order
+// (XCD-major).  begin / count: arrays of `capacity` ints; *num_tiles = workgroups of the launch (<= 1024).
+int gp_debug_stream_plan(int n, int skew_permille, const int* xcd_weights_permille, int capacity, int* begin, int* count, int* num_tiles) {
+  if (n < 0 || skew_permille < 0 || !num_tiles) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_stream_plan: bad arguments");
+  gp::StreamPlan plan;
+  const int G = make_stream_plan(n, skew_permille, xcd_weights_permille, &plan);
+  *num_tiles = G;
+  if (begin && count) {
+    if (capacity < G) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_stream_plan: capacity too small");
+    int t = 0;
+    for (int x = 0; x < gp::kNumXCD; x++)
+      for (int q = 0; q < plan.wgs_per_xcd; q++, t++) gp::plan_tile(gp::plan_fields(plan, x, q), x, q, &begin[t], &count[t]);
   }
   return GP_OK;
 }

@@ -22,16 +22,23 @@ struct FactorDesc {
 };
 
 
-// How the stream kernel (gp_vgicp_stream.hpp) deals the 64-point chunks of ONE factor to the workgroups of a launch.  The chunk list is cut
-// into eight contiguous shares, one per XCD (workgroup b runs on XCD b % 8); inside a share the first `early_wgs` workgroups take `hi` chunks
-// each, the remaining ones -- the last round the dispatcher places, one workgroup per compute unit -- split what is left evenly (`lo`, the
-// first `extra` of them one more).  cx / cr: chunks per share (the first `cr` shares own cx + 1); lo0 / extra0 belong to a share of cx
-// chunks, lo1 / extra1 to one of cx + 1.  tail: points behind the last full chunk (the last workgroup reads them with per-lane loads).
+// How the stream kernel (gp_vgicp_stream.hpp) deals the 64-point chunks of ONE large factor to the workgroups of a launch.  The chunk list is
+// cut into eight contiguous shares, one per XCD (workgroup b runs on XCD b % 8, position q = b / 8 in the share).  The dispatcher places a
+// share's workgroups in rounds of 32 (one per compute unit of the XCD), and a compute unit issues from its OLDEST waves first: with equal
+// shares the workgroups of a CU end in the order they were placed, ~1 us apart, and the tail of the launch runs on a quarter of the waves
+// (per-workgroup timeline of round 3, profiles/r03_sweep.jsonl).  So the rounds get DIFFERENT shares: workgroups of round r < last take n[r]
+// chunks each (more for the early rounds), the workgroups from `last_begin` on split what is left evenly (`lo`, the first `extra` one more).
+constexpr int kStreamRound = 32;  // workgroups per dispatch round of an XCD = its compute units
 struct StreamPlan {
-  int cx, cr;
-  int wgs_per_xcd, early_wgs, hi;
-  int lo0, extra0, lo1, extra1;
-  int tail;
+  int wgs_per_xcd, last_begin;  // workgroups per XCD share; first workgroup of the share's last round (a multiple of 32)
+  int tail;                     // points behind the last full chunk (the very last workgroup reads them with per-lane loads)
+  int pad_;
+  // per XCD: the XCDs do not run the same kernel equally fast (XCDs 4-7 end 0.5-0.9 us behind 0-3 on equal shares, whatever data they are
+  // given: profiles/r03_sweep.jsonl), so their shares differ (host: kXcdWeightPermille in gp_vgicp.hip)
+  int xbegin[kNumXCD];               // first chunk of the XCD's share
+  int n[kNumXCD][3], pre[kNumXCD][3];  // rounds in front of the last one: chunks per workgroup, and chunks of the share in front of the round
+  int before_last[kNumXCD];          // chunks of the share in front of its last round
+  int lo[kNumXCD], extra[kNumXCD];   // the last round: `lo` chunks per workgroup, the first `extra` workgroups one more
 };
 
 // a single-factor launch carries its poses AND its factor descriptor in the kernel arguments: no H2D copy and no
@@ -47,6 +54,11 @@ struct InlinePoses {
                   // tile list is dealt to the XCDs in runs of c tiles (round robin), which evens out what the XCDs have to do
   StreamPlan plan;            // stream kernel, single-factor launches
   unsigned long long* trace;  // timeline build of the tile kernels (per batch: gp_vgicp_batch_set_trace_buffer); null = off
+  // overlapped finalize (synchronous single-factor calls): a workgroup publishes its partial row write-through and adds 1 to
+  // arrive[row / rows_per_part]; the finalize workgroups, launched on a second stream, wait for their counter instead of for the kernel boundary
+  unsigned long long* arrive;  // null = off
+  int rows_per_part;
+  int pad2_;
 };
 
 struct TileDesc {

@@ -7,10 +7,10 @@
 // 977 workgroups on 256 compute units -- 209 CUs carry four tiles and end at 12.2 us, 47 carry three and end at 10.5 us -- and every launch
 // larger than one round of workgroups pays the cold start of the pipeline (first points 0.8 us, first hop 1.0 us, a 2.3 us first step) once per
 // tile.  Here
-//   * a single-factor launch deals CHUNKS, not fixed tiles: at most 1024 workgroups = one resident round whatever the size of the cloud; every
-//     XCD owns a contiguous eighth of the chunk list, its early workgroups take `hi` chunks each and its last round of workgroups (the ones the
-//     dispatcher places last, one per compute unit) share what is left evenly -- every compute unit of the headline carries 61 or 62 chunks
-//     (StreamPlan, filled by the host; a workgroup's chunks are dealt to its four waves as evenly as they go);
+//   * a large single-factor launch deals CHUNKS, not fixed tiles: at most 1024 workgroups = one resident round whatever the size of the cloud;
+//     every XCD owns a contiguous eighth of the chunk list and its four dispatch rounds of 32 workgroups take DIFFERENT shares (StreamPlan,
+//     gp_vgicp_shared.hpp): a compute unit issues from its oldest waves first, so equal shares end ~1 us apart in dispatch order and the
+//     launch's tail runs on a quarter of the waves; a workgroup's chunks are dealt to its four waves as evenly as they go;
 //   * clouds beyond one round of 4-chunk waves stay in ONE round: the waves simply stream more chunks through the same ring (an 8 M-point
 //     source is 30 chunks per wave), so the cold start is paid once per wave, not once per 1024 points;
 //   * surface validation (SV) rides in the same ring: the normals are a fourth 12-B LDS-DMA row per chunk, issued from inline asm like the rest,
@@ -58,23 +58,22 @@ __device__ __forceinline__ WaveWork split_tile(int begin, int count, int wave) {
   return ww;
 }
 
-// INL: the points workgroup (x = XCD, q = position in the XCD's share) of a single-factor launch owns -- the same tile the host writes into the
-// tile table for the launches that cannot carry the descriptor in their arguments (make_stream_plan / plan_tile_host in gp_vgicp.hip)
-__host__ __device__ __forceinline__ void plan_tile(const StreamPlan& p, int x, int q, int* begin, int* count) {
-  const int big = x < p.cr ? 1 : 0;  // this XCD owns cx + 1 chunks
-  const int xbegin = x * p.cx + (x < p.cr ? x : p.cr);
-  int n, c0;
-  if (q < p.early_wgs) {
-    n = p.hi;
-    c0 = q * p.hi;
-  } else {
-    const int k = q - p.early_wgs;
-    const int lo = big ? p.lo1 : p.lo0, extra = big ? p.extra1 : p.extra0;
-    n = lo + (k < extra ? 1 : 0);
-    c0 = p.early_wgs * p.hi + k * lo + (k < extra ? k : extra);
-  }
-  *begin = (xbegin + c0) * kChunkPoints;
-  *count = n * kChunkPoints + ((x == kNumXCD - 1 && q == p.wgs_per_xcd - 1) ? p.tail : 0);  // the very last workgroup also takes the points behind the last full chunk
+// the points workgroup (x = XCD, q = position in the XCD's share) of a planned single-factor launch owns -- also what the host writes into the
+// tile table for the launches that cannot carry the descriptor in their arguments (make_stream_plan in gp_vgicp.hip)
+struct PlanFields {  // the fields of the plan workgroup (x, q) needs
+  int nr, pre, lo, extra, xbegin, L, before_last, gx, tail;
+};
+__host__ __device__ __forceinline__ PlanFields plan_fields(const StreamPlan& p, int x, int q) {
+  const int r = q / kStreamRound < 2 ? q / kStreamRound : 2;  // (workgroups of the last round do not use nr / pre)
+  return PlanFields{p.n[x][r], p.pre[x][r], p.lo[x], p.extra[x], p.xbegin[x], p.last_begin, p.before_last[x], p.wgs_per_xcd, p.tail};
+}
+__host__ __device__ __forceinline__ void plan_tile(const PlanFields& f, int x, int q, int* begin, int* count) {
+  const int i = q % kStreamRound, k = q - f.L;
+  const bool late = q >= f.L;
+  const int n = late ? f.lo + (k < f.extra ? 1 : 0) : f.nr;
+  const int c0 = late ? f.before_last + k * f.lo + (k < f.extra ? k : f.extra) : f.pre + i * f.nr;
+  *begin = (f.xbegin + c0) * kChunkPoints;
+  *count = n * kChunkPoints + ((x == kNumXCD - 1 && q == f.gx - 1) ? f.tail : 0);  // the very last workgroup also takes the points behind the last full chunk
 }
 
 template <int MODE, bool NT, bool INL, bool SV, bool TRACE = false>
@@ -88,18 +87,55 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   constexpr int kWaveBytes = SV ? 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + 2 * kCovSlotBytes : kWaveLdsBytes;  // 10 KB with normals, else 8.5 KB
   static_assert(kWaveBytes >= kWaveLdsBytes, "the reduction needs 8.5 KB of the wave's region");
   __shared__ __attribute__((aligned(16))) char smem[4 * kWaveBytes];
+  // ---- what the first source request needs, in as few dependent scalar-load round trips as possible.  The in-argument form reads every field
+  // it may need -- the plan's entries for this workgroup included -- up front and pins them with an empty asm: left alone, hipcc sinks those loads
+  // into the branches of the tile arithmetic (five dependent s_load / s_waitcnt rounds in front of the first DMA, 1.26 us from workgroup start
+  // to the first points instead of 0.83: per-workgroup timeline of round 3) ----
+  const int bx = blockIdx.x % kNumXCD, bq = blockIdx.x / kNumXCD;
   int tile_idx;  // index into the tile list: XCD x walks a contiguous eighth of it
+  FactorDesc f;
+  WaveWork ww;
+  int factor_idx = 0, row;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (INL) {
-    tile_idx = (blockIdx.x % kNumXCD) * inl.plan.wgs_per_xcd + blockIdx.x / kNumXCD;
+    PlanFields pf = plan_fields(inl.plan, bx, bq);
+    int tile_points = inl.tile_points, fn = inl.factor.n;
+    const float* fpts = inl.factor.points;
+    const float* fcov = inl.factor.covs;
+    const float* fnrm = inl.factor.normals;
+    asm volatile("" : "+s"(pf.nr), "+s"(pf.pre), "+s"(pf.lo), "+s"(pf.extra), "+s"(pf.xbegin), "+s"(pf.L), "+s"(pf.before_last), "+s"(pf.gx), "+s"(pf.tail), "+s"(tile_points),
+                 "+s"(fn), "+s"(fpts), "+s"(fcov), "+s"(fnrm));
+    int begin, count;
+    if (tile_points == 0) {  // one large factor: the tile list is the StreamPlan
+      tile_idx = bx * pf.gx + bq;
+      plan_tile(pf, bx, bq, &begin, &count);
+    } else {  // fixed tiles of tile_points
+      const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
+      tile_idx = bx * per + bq;
+      if (tile_idx >= num_tiles) return;
+      begin = tile_idx * tile_points;
+      count = min(tile_points, fn - begin);
+    }
+    f = inl.factor;
+    f.points = fpts;
+    f.covs = fcov;
+    f.normals = fnrm;
+    row = tile_idx;
+    ww = split_tile(begin, count, wave);
   } else {
     if (inl.xcd_chunk > 0) {
-      const int c = inl.xcd_chunk, x = blockIdx.x % kNumXCD, q = blockIdx.x / kNumXCD;
-      tile_idx = ((q / c) * kNumXCD + x) * c + (q % c);
+      const int c = inl.xcd_chunk;
+      tile_idx = ((bq / c) * kNumXCD + bx) * c + (bq % c);
     } else {
       const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
-      tile_idx = (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
+      tile_idx = bx * per + bq;
     }
     if (tile_idx >= num_tiles) return;
+    const TileDesc tile = tiles[tile_idx];
+    f = factors[tile.factor];
+    factor_idx = tile.factor;
+    row = tile.row;
+    ww = split_tile(__builtin_amdgcn_readfirstlane(tile.begin), __builtin_amdgcn_readfirstlane(tile.count), wave);
   }
   unsigned long long* trace = TRACE ? inl.trace : nullptr;
   GP_TRACE(0);
@@ -111,22 +147,6 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     }
   }
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  FactorDesc f;
-  WaveWork ww;
-  int factor_idx = 0, row = tile_idx;
-  if constexpr (INL) {
-    f = inl.factor;
-    int begin, count;
-    plan_tile(inl.plan, blockIdx.x % kNumXCD, blockIdx.x / kNumXCD, &begin, &count);
-    ww = split_tile(begin, count, wave);
-  } else {
-    const TileDesc tile = tiles[tile_idx];
-    f = factors[tile.factor];
-    factor_idx = tile.factor;
-    row = tile.row;
-    ww = split_tile(__builtin_amdgcn_readfirstlane(tile.begin), __builtin_amdgcn_readfirstlane(tile.count), wave);
-  }
   const int n = __builtin_amdgcn_readfirstlane(ww.n);
   const int tail = __builtin_amdgcn_readfirstlane(ww.tail);
   const size_t first = ww.first;
@@ -233,67 +253,66 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     load_cov6(c9, a);
   };
 
-  Ahead P0, P1;
+  Ahead Pc;  // the chunk whose record has landed (front half and lookup done)
   v4f head;
   v2d c01, c23, c45;
   double a[6];
-  // one step of the steady state: chunk j (ring half PAR, front half done, hop 1 in flight in `cur`); behind hop 1 only the K requests of
-  // chunk j+1 may be in flight.  Order: wait hop 1 -> hop 2 -> wait (everything) -> front half of chunk j+1 (its hop 1 travels under the
-  // algebra below) -> covariance out of LDS -> chunk j+2 requested into the places of chunk j -> algebra.
-  auto step = [&](auto par_c, int j, Ahead& cur, Ahead& nxt) {
-    constexpr int PAR = decltype(par_c)::value;
-    const bool has1 = j + 1 < n, has2 = j + 2 < n;  // wave-uniform
-    if (has1) vm_wait_blk_n<K>(cur.blk);            // [H(j), chunk j+1 x K]
-    else vm_wait_blk_n<0>(cur.blk);
-    if constexpr (TRACE) {
-      if (j == 1) GP_TRACE(4);
-    }
-    const bool hit = back_issue(cur, head, c01, c23, c45);
-    vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+1 (requested a step ago), which the front half below reads
-    if (has1) front_ring(PAR ^ 1, nxt);
-    cov_ring(PAR, a);
-    if (has2) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dma_head(j + 2, PAR);
-      dma_cov(j + 2, PAR);
-    }
-    if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, cur.ex + head.x, cur.ey + head.y, cur.ez + head.z, cur.qx, cur.qy, cur.qz, acc);
-    if constexpr (TRACE) {
-      if (j == 1) GP_TRACE(5);
-    }
-  };
-
+  // HAZARD the schedule below is built around: the destination registers of an asm-issued load hold nothing until the matching s_waitcnt, but
+  // the compiler believes they are defined at the issue.  Any copy it places between the two -- a phi at a loop back-edge, or the operand copy in
+  // front of one of TWO alternative wait statements -- reads the registers before the data lands (round 3: exactly that, wild record offsets,
+  // a memory fault).  Therefore (i) the loop is rotated so that NOTHING asm-issued is in flight at its back-edge (the body ends with the
+  // vmcnt(0) behind hop 2), and (ii) every register-tied wait is ONE unconditional statement; run-time alternatives only add an untied
+  // `s_waitcnt` in front of it.
   if (n > 0) {
     // points first: only chunk 0's points (and normals) are in flight, so the first transform and hop 1 do not queue behind everybody's
     // covariances; those follow hop 1 (they are needed behind hop 2), the head of chunk 1 goes out before hop 2 and its covariances behind it
     vm_wait<0>();
     GP_TRACE(1);
-    front_ring(0, P0);  // in flight: H0
+    front_ring(0, Pc);  // in flight: H0
     dma_cov(0, 0);
-    const bool has1 = n > 1, has2 = n > 2;
+    const bool has1 = n > 1;
     if (has1) dma_head(1, 1);  // in flight: H0, C0 x3, head of chunk 1 (K - 3 requests)
-    if (has1) vm_wait_blk_n<K>(P0.blk);
-    else vm_wait_blk_n<3>(P0.blk);
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    vm_wait_blk_n<K>(Pc.blk);
     GP_TRACE(2);
-    const bool hit = back_issue(P0, head, c01, c23, c45);
-    if (has1) {
-      dma_cov(1, 1);                        // [C0 x3, head 1, R0 x4, C1 x3]
-      vm_wait_rec<3>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the head of chunk 1
-      front_ring(1, P1);
-    } else {
-      vm_wait_rec<0>(head, c01, c23, c45);
-    }
-    cov_ring(0, a);
-    if (has2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dma_head(2, 0);
-      dma_cov(2, 0);
-    }
-    if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, P0.ex + head.x, P0.ey + head.y, P0.ez + head.z, P0.qx, P0.qy, P0.qz, acc);
-    GP_TRACE(3);
-    for (int j = 1; j < n; j += 2) {
-      step(std::integral_constant<int, 1>{}, j, P1, P0);
-      if (j + 1 < n) step(std::integral_constant<int, 0>{}, j + 1, P0, P1);
+    bool hit = back_issue(Pc, head, c01, c23, c45);
+    if (has1) dma_cov(1, 1);  // [C0 x3, head 1, R0 x4, C1 x3]
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vm_wait_rec<3>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the head of chunk 1 (C1 may still travel: it is older than
+                                          // the next hop 1, whose wait below retires it)
+    // steady state, rotated: the body starts where the record of chunk j has landed and ends where the record of chunk j+1 has.
+    //   front half of chunk j+1 (its hop 1 travels under the algebra below) -> covariance of chunk j out of LDS -> chunk j+2 requested into the
+    //   places of chunk j -> algebra of chunk j -> wait hop 1 of chunk j+1 -> its hop 2 -> wait (everything)
+    for (int j = 0;; j++) {
+      const int par = j & 1;
+      const bool more = j + 1 < n, more2 = j + 2 < n;  // wave-uniform
+      Ahead Pn;
+      if (more) front_ring(par ^ 1, Pn);
+      cov_ring(par, a);
+      if (more2) {  // chunk j+2 takes the places of chunk j, whose points and covariance have just been read
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_head(j + 2, par);
+        dma_cov(j + 2, par);
+      }
+      if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, Pc.ex + head.x, Pc.ey + head.y, Pc.ez + head.z, Pc.qx, Pc.qy, Pc.qz, acc);
+      if constexpr (TRACE) {
+        if (j == 0) GP_TRACE(3);
+        if (j == 1) GP_TRACE(5);
+      }
+      if (!more) break;
+      if (!more2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      vm_wait_blk_n<K>(Pn.blk);  // [H(j+1), chunk j+2 x K]
+      if constexpr (TRACE) {
+        if (j == 0) GP_TRACE(4);
+      }
+      hit = back_issue(Pn, head, c01, c23, c45);
+      vm_wait_rec<0>(head, c01, c23, c45);  // the record, and chunk j+2, which the next front half reads: nothing is in flight at the back-edge
+      Pc.ex = Pn.ex;
+      Pc.ey = Pn.ey;
+      Pc.ez = Pn.ez;
+      Pc.qx = Pn.qx;
+      Pc.qy = Pn.qy;
+      Pc.qz = Pn.qz;
     }
     vm_wait<0>();
   }
@@ -377,7 +396,16 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
       const double* w3 = reinterpret_cast<const double*>(smem + 4 * kWaveBytes - 32 * 8);
       sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
     }
-    ((GP_GLOBAL double*)partials)[(size_t)row * ACC_STRIDE + threadIdx.x] = sum;
+    GP_GLOBAL double* dst = (GP_GLOBAL double*)partials + (size_t)row * ACC_STRIDE + threadIdx.x;
+    if (inl.arrive) {
+      // overlapped finalize: the row goes out write-through (sc0 sc1: visible to every XCD once the store is acknowledged, no release fence --
+      // MI355X_MICROARCH.md, inter-workgroup visibility), then ONE relaxed agent-scope add announces it.  Nothing waits here: the finalize
+      // workgroups on the other stream poll the counter; this kernel's duration gains the store acknowledgement of 256 bytes
+      asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : : "v"(dst), "v"(sum) : "memory");
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(inl.arrive + row / inl.rows_per_part, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      *dst = sum;
+    }
   }
   GP_TRACE(7);
   if constexpr (TRACE) {

@@ -442,8 +442,14 @@ enum {
   GP_TUNE_XCD_CHUNK = 2,        /* workgroup -> tile map: 0 = every XCD walks a contiguous eighth of the tile list, c > 0 = runs of c tiles dealt round robin */
   GP_TUNE_STAGGER = 3,          /* round-2 kernels: the odd wave slots of every SIMD start `value` x 512 clocks late (0 = off) */
   GP_TUNE_TILE_INTERLEAVE = 4,  /* 1 = consecutive factors that share a source cloud take turns tile by tile, 0 (default) = factor-major */
-  GP_TUNE_BALANCE = 5,          /* stream kernel, single factor: 1 (default) = the last round of workgroups takes the lighter share, 0 = flat split */
+  GP_TUNE_BALANCE = 5,          /* stream kernel, one large factor: how much more a dispatch round of workgroups takes than the next one, in 1/1000 of
+                                   the mean share (0 = flat split; a compute unit issues from its oldest waves first, csrc/gp_vgicp_shared.hpp) */
   GP_TUNE_EFFECTIVE_KERNEL = 6, /* read-only: the family the batch's current table runs (-1 before the first pass) */
+  GP_TUNE_XCD_WEIGHT_0 = 8,     /* .. + 7: stream kernel, one large factor: share of XCD x in 1/1000 of the mean share (500..1500); setting any of the eight
+                                   replaces the library's measured table (the others then count as 1000) */
+  GP_TUNE_OVERLAP_FINALIZE = 17, /* synchronous single-factor linearise of the stream family: 1 = the finalize workgroups run on a second stream and wait for the
+                                   tile workgroups' arrival counters instead of for the kernel boundary (bit-identical records; measured SLOWER on ROCm 7.2 --
+                                   launching on a second stream costs ~10 us per step -- so the default is 0 = tile kernel, then finalize kernel) */
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */
@@ -465,6 +471,10 @@ int gp_voxelmap_set_tuning(gp_voxelmap_t* map, int key, int value);
  * H_s = Ad^T H_t Ad, H_ts = -H_t Ad, b_s = -Ad^T b_t (integrated_vgicp_factor_gpu.cpp:199-213 consumes them).  This is the expansion the
  * synchronous single-factor call runs on the host on the added sums of its finalize parts. */
 int gp_debug_expand_rigid(const double sums[32], const double pose[16], gp_linearized6* out);
+/* host-side check hook (runs without a device): the tiles (first point, number of points) a planned single-factor launch of the stream kernel deals
+ * to its workgroups for a factor of n points and a GP_TUNE_BALANCE value, in tile-list order (XCD-major); *num_tiles = workgroups of the launch */
+int gp_debug_stream_plan(int n, int skew_permille, const int* xcd_weights_permille /* [8] or NULL = the library's table */, int capacity, int* begin, int* count,
+                         int* num_tiles);
 /* timeline hook (measurement): per-workgroup phase timestamps (s_memtime) of THIS batch's single-factor linearise into dev_buffer
  * ([2048][16] uint64: slots 0-7 phases, 8 HW_ID, 9 XCC_ID, 10 / 11 start / end on the device-wide clock; row 2047: the finalize kernel of the
  * synchronous call); NULL disables */

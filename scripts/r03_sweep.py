@@ -23,10 +23,11 @@ from gtsam_points_amd import _capi, synthetic  # noqa: E402
 
 lib = gpa.load()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-cases = [tuple(int(x) for x in c.split(":")) for c in (args[0] if len(args) > 0 else "8:0:1,11:0:1,12:0:1,12:0:0,12:1:1").split(",")]
+cases = [tuple(int(x) for x in c.split(":")) for c in (args[0] if len(args) > 0 else "8:0:0,11:0:0,12:0:0,12:0:100,12:0:200").split(",")]
 BIG = "--big" in sys.argv
 TRACE = "--no-trace" not in sys.argv
 KERNEL, POLICY, BALANCE = 0, 1, 5  # GP_TUNE_*
+XCD_WEIGHTS = {0: [1000] * 8, 2: [1045, 1045, 1045, 1045, 940, 925, 975, 980], 3: [1015, 1015, 1015, 1015, 980, 975, 990, 995]}
 BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
 
 
@@ -35,10 +36,16 @@ def make_batch(f, case):
     batch, s = C.c_void_p(), C.c_void_p()
     lib.gp_stream_create(C.byref(s))
     _capi.check(lib.gp_vgicp_batch_create(arr, 1, s, C.byref(batch)), "batch")
-    fam, pol, bal = case
+    fam, pol, bal = case[:3]
     _capi.check(lib.gp_vgicp_batch_set_tuning(batch, KERNEL, fam), "kernel")
     _capi.check(lib.gp_vgicp_batch_set_tuning(batch, POLICY, pol), "policy")
     _capi.check(lib.gp_vgicp_batch_set_tuning(batch, BALANCE, bal), "balance")
+    if len(case) > 4:
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, case[4]), "overlap")  # GP_TUNE_OVERLAP_FINALIZE
+    wsel = case[3] if len(case) > 3 else 1  # XCD weights: 0 equal shares, 1 the library's table (default), 2.. alternatives
+    if wsel != 1:
+        for x, w in enumerate(XCD_WEIGHTS[wsel]):
+            _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 8 + x, w), "xcd weight")
     return batch, s
 
 
@@ -79,7 +86,7 @@ def run_case(name, d, res, delta, Lo, iters=50):
         alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
         eff = C.c_int(-2)
         lib.gp_vgicp_batch_get_tuning(batch, 6, C.byref(eff))
-        print(json.dumps(dict(case=name, family=case[0], policy=case[1], balance=case[2], effective_family=eff.value, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5),
+        print(json.dumps(dict(case=name, family=case[0], policy=case[1], balance=case[2], xcd_weights=(case[3] if len(case) > 3 else 1), overlap=(case[4] if len(case) > 4 else 1), effective_family=eff.value, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5),
                               fin_ms=round(best[2], 5), sync_call_ms=round(wall, 5), error_sync_call_ms=round(err_wall, 5),
                               frac=round(alg / (best[0] * 1e-3) / 8e12, 4), alg_bytes=alg, max_rel_err=max(errs.values()) if errs else None,
                               inliers_ok=(L.num_inliers == Lo.num_inliers) if Lo is not None else None, has_grid=int(lib.gp_voxelmap_has_block_grid(vm._h)),
@@ -145,6 +152,7 @@ def trace_case(f, delta, label, case):
     for k_, e_ in cu_end.items():
         by_xcc.setdefault(k_ // 4096, []).append(e_)
     device_axis["cu_last_end_by_xcc"] = {str(x): dict(p50=round(float(np.median(v)), 2), max=round(float(max(v)), 2)) for x, v in sorted(by_xcc.items())}
+    device_axis["wg_start_p50_by_xcc"] = {str(int(x)): round(float(np.median(rs[xcc[ok] == x])), 2) for x in sorted(set(xcc[ok].tolist()))}
     tile_ids = np.nonzero(trace.cpu().numpy()[:2047, 0] > 0)[0]
     same_cu = {}
     for k_, tid in zip(keys.tolist(), tile_ids.tolist()):
@@ -176,7 +184,7 @@ Lo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], oracle.m
 f, vm, src, tgt = run_case("c2_1M", d, 0.5, delta, Lo)
 if TRACE:
     for case in [c for c in cases if c[0] in (11, 12)]:
-        trace_case(f, delta, f"c2_1M family {case[0]} policy {case[1]} balance {case[2]}", case)
+        trace_case(f, delta, f"c2_1M family {case[0]} policy {case[1]} balance {case[2]} weights {case[3] if len(case) > 3 else 1}", case)
 
 k = np.load(os.path.join(ROOT, "tests/golden/kitti00_dec8.npz"))
 dk = {n: k[n] for n in k.files}

@@ -126,3 +126,45 @@ def test_host_side_expansion_of_the_rigid_sums():
     assert rel(out[38:74].reshape(6, 6).T, Hs) < 1e-12
     assert rel(out[74:110].reshape(6, 6).T, Hts) < 1e-12
     assert rel(out[110:116], bt) < 1e-13 and rel(out[116:122], bs) < 1e-12
+
+
+def test_stream_plan_partitions_every_point_once():
+    """gp_debug_stream_plan (host code, no device): the tiles the stream kernel deals to the workgroups of a planned single-factor launch cover
+    [0, n) exactly once, in order, in whole 64-point chunks except for the very last tile; at most 1024 workgroups; the early dispatch rounds
+    of an XCD never take less than the later ones; with equal XCD weights a flat plan differs by at most one chunk between workgroups, and the
+    XCD shares follow the weights."""
+    import ctypes as C
+
+    import numpy as np
+
+    from gtsam_points_amd import _capi
+
+    lib = _capi.load()
+    equal = (C.c_int * 8)(*([1000] * 8))
+    skewed = (C.c_int * 8)(1100, 1000, 1000, 1000, 900, 900, 1000, 1100)
+    for n in [0, 1, 63, 64, 65, 4097, 65536, 124605, 400000, 999999, 1000000, 1000077, 1310757, 8000000, 33554432 + 17]:
+        for skew in [0, 50, 100, 200, 350, 600]:
+            for weights in (equal, None, skewed):
+                G = C.c_int()
+                assert lib.gp_debug_stream_plan(n, skew, weights, 0, None, None, C.byref(G)) == 0
+                assert 8 <= G.value <= 1024 and G.value % 8 == 0
+                b, c = np.zeros(G.value, np.int32), np.zeros(G.value, np.int32)
+                assert lib.gp_debug_stream_plan(n, skew, weights, G.value, b.ctypes.data, c.ctypes.data, C.byref(G)) == 0
+                assert (c >= 0).all() and int(c.astype(np.int64).sum()) == n, (n, skew)
+                pos = 0
+                for t in range(G.value):
+                    if c[t]:
+                        assert b[t] == pos, (n, skew, t)
+                        pos += int(c[t])
+                assert (c[:-1] % 64 == 0).all() and c[-1] % 64 == n % 64
+                per = G.value // 8
+                chunks = (c // 64).reshape(8, per)
+                if skew == 0 and weights is equal:
+                    assert chunks.max() - chunks.min() <= 1 or n < 64 * G.value
+                if weights is skewed and n >= 1000000:
+                    tot = chunks.sum(1).astype(np.float64)
+                    assert np.abs(tot / tot.mean() - np.array(list(skewed)) / 1000.0).max() < 0.01
+                for x in range(8):  # rounds of 32 workgroups: shares do not grow with the round
+                    rounds = [chunks[x, r : r + 32] for r in range(0, per, 32)]
+                    for a_, bb in zip(rounds, rounds[1:]):
+                        assert a_.min() >= bb.max() - 1, (n, skew, x)

@@ -636,6 +636,46 @@ def test_second_and_third_generation_kernels_at_size(gpu, variant, policy, n_src
     assert abs(e_lin.value - L.error) <= 1e-7 * abs(L.error)  # evaluated at the linearisation pose it is the linearise's own error
 
 
+def test_overlapped_finalize_equals_the_two_kernel_form(gpu):
+    """GP_TUNE_OVERLAP_FINALIZE (opt-in): the finalize parts of a synchronous single-factor linearise run on a second stream and wait for the
+    tile workgroups' arrival counters instead of for the kernel boundary.  Same rows, same summation order: the record must equal the two-kernel
+    form bit for bit, call after call (the counters are monotonic), also when the two forms alternate and when the table is rebuilt in between."""
+    from gtsam_points_amd import synthetic
+
+    d = synthetic.make_c2_workload(700_000, 500_000, seed=13)
+    _, src, vm = _build(gpu, d, 0.5)
+    lib = gpu.load()
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    arr = (C.c_void_p * 1)(f._h.value)
+    batch, s = C.c_void_p(), C.c_void_p()
+    gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+    gpu._capi.check(lib.gp_vgicp_batch_create(arr, 1, s, C.byref(batch)), "batch")
+    rng = np.random.default_rng(3)
+    out = np.zeros((1, 122))
+    recs = {0: [], 1: []}
+    poses = [np.ascontiguousarray((d["T_true"] @ expmap(rng.uniform(-1e-3, 1e-3, 6))).T).reshape(1, 16).copy() for _ in range(6)]
+    for rep in range(3):
+        for mode in (1, 0, 1):
+            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, mode), "overlap")  # GP_TUNE_OVERLAP_FINALIZE
+            for k, pose in enumerate(poses):
+                gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data), "linearize")
+                recs[mode].append((k, out.copy()))
+        gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 5, 100 + 50 * rep), "balance")  # rebuilds the table (another plan)
+        recs = {0: [], 1: []} if rep < 2 else recs
+        if rep < 2:
+            continue
+    by_pose = {}
+    for mode in (0, 1):
+        for k, r in recs[mode]:
+            by_pose.setdefault(k, []).append(r)
+    for k, rs in by_pose.items():
+        assert len(rs) == 3 and all(np.array_equal(rs[0], r) for r in rs[1:]), k
+    _, fo = _oracle(d, 0.5, oracle.max_threads())
+    assert_linearized_close(gpu.LinearizedSystem6.from_doubles(by_pose[0][0][0]), fo.linearize(np.ascontiguousarray(poses[0].reshape(4, 4).T)), MIXED_TOL, "overlapped finalize")
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+
+
 @pytest.mark.parametrize("n_src", [64 * 4096 * 5 + 37])
 def test_stream_kernel_beyond_one_round_of_four_chunk_waves(gpu, n_src):
     """1.3 M points: more than 4096 waves x 4 chunks, so the stream kernel keeps ONE resident round (1024 workgroups) and its waves stream 5-6
