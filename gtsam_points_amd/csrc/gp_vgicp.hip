@@ -635,6 +635,7 @@ struct gp_vgicp_tuning {
   int tile_interleave = 0;        // consecutive factors that share a source cloud take turns tile by tile
   int xcd_weights[8] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // GP_TUNE_XCD_WEIGHT_0 + x: share of XCD x in 1/1000 of the mean (unset: the library's table)
   bool xcd_weights_set = false;
+  int tile_chunks = 0;            // stream family, batches: 64-point chunks per wave of a tile (tile = 256 x this many points); 0 = the largest of 4 / 2 / 1 that fills 3/4 of the chip
   int overlap_finalize = 0;       // synchronous single-factor linearise of the stream family: finalize workgroups on a second stream wait for arrival counters
                                   // (measured: the second stream costs ~10 us per step on this stack, profiles/r03_overlap_finalize.jsonl: off by default)
   int balance = kDefaultSkewPermille;  // stream kernel, one large factor: how much more a dispatch round takes than the next, in 1/1000 of the mean share (0 = flat)
@@ -877,6 +878,7 @@ int build_table(gp_vgicp_batch* b) {
         }
       }
     }
+    if (fam == GP_KERNEL_STREAM && b->tuning.tile_chunks > 0) ppt = b->tuning.tile_chunks;  // (the stream kernel takes tiles of any whole number of chunks)
     b->ppt = ppt;
     b->tile_points = 64 * 4 * ppt;
     for (int i = 0; i < F; i++) {
@@ -1206,6 +1208,10 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
     case GP_TUNE_OVERLAP_FINALIZE:
       t->overlap_finalize = value ? 1 : 0;
       return GP_OK;
+    case GP_TUNE_TILE_CHUNKS:
+      if (value < 0 || value > 64) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_TILE_CHUNKS: 0 (automatic) .. 64 chunks per wave");
+      t->tile_chunks = value;
+      return GP_OK;
     case GP_TUNE_BALANCE:
       if (value < 0 || value > 600) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_BALANCE: 0 (flat) .. 600 (per mille of the mean share per dispatch round)");
       t->balance = value;
@@ -1242,6 +1248,7 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
     case GP_TUNE_TILE_INTERLEAVE: *value = b->tuning.tile_interleave; return GP_OK;
     case GP_TUNE_BALANCE: *value = b->tuning.balance; return GP_OK;
     case GP_TUNE_OVERLAP_FINALIZE: *value = b->tuning.overlap_finalize; return GP_OK;
+    case GP_TUNE_TILE_CHUNKS: *value = b->tuning.tile_chunks; return GP_OK;
     case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
     default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
   }

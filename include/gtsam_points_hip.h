@@ -450,6 +450,8 @@ enum {
   GP_TUNE_OVERLAP_FINALIZE = 17, /* synchronous single-factor linearise of the stream family: 1 = the finalize workgroups run on a second stream and wait for the
                                    tile workgroups' arrival counters instead of for the kernel boundary (bit-identical records; measured SLOWER on ROCm 7.2 --
                                    launching on a second stream costs ~10 us per step -- so the default is 0 = tile kernel, then finalize kernel) */
+  GP_TUNE_TILE_CHUNKS = 18,     /* stream family, fixed-tile launches (batches, small single factors): 64-point chunks per wave of a tile (a tile = 256 x value points);
+                                   0 (default) = the largest of 4 / 2 / 1 that still gives >= 768 tiles */
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */
