@@ -122,6 +122,7 @@ _SIGNATURES = {
     "gp_sparse_system_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_symbolic": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gp_sparse_symbolic_schedule": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gp_cloud_upload_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gp_cloud_upload_mat3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     # factor

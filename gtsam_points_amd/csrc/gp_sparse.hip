@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <numeric>
 #include <queue>
@@ -42,7 +43,8 @@ struct SparseSymbolic {
   std::vector<int> upd_a, upd_b;
   std::vector<int> row_ptr;        // [P + 1] -> row_blk / row_col: the blocks L_kj (j < k) of row k and their columns, ascending j
   std::vector<int> row_blk, row_col;
-  std::vector<int> work_ptr, work_cols;  // work lists: [num_subtrees] subtrees, then ONE list with the top columns (may be empty)
+  std::vector<int> work_ptr, work_cols;  // work lists: [num_subtrees] subtrees, then the CHAINS of the top part (separator columns), grouped by level
+  std::vector<int> level_ptr;            // [num_levels + 1] -> work lists: level 0 = the subtrees, level l >= 1 = the top chains whose children are all in lower levels
   int num_subtrees = 0;
   long long nnzA = 0;
 };
@@ -138,7 +140,50 @@ static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vec
   rec(all);
 }
 
-static int sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, SparseSymbolic* out) {
+// minimum degree by multiple elimination (ordering = 2): every round eliminates an independent set of the nodes whose degree in the current
+// elimination graph is within `slack` of the minimum -- the fill-reducing heuristic of GTSAM's default COLAMD-class orderings (which is what
+// the reference's solves run with, optimizers/levenberg_marquardt_ext.cpp:200-220), in its multiple-elimination form because independent nodes
+// of one round are siblings in the elimination tree: the rounds are what the device schedule runs side by side.  slack = 0 is the classical
+// MMD; slack = 1 lets e.g. the interior nodes of a chain (degree 2, against 1 at the two ends) go in the first round, which makes a chain's
+// tree logarithmic instead of one path.  Deterministic: ties by node index.  The graph is explicit (sorted neighbour lists incl. fill), fine
+// for pose graphs of 10^4 nodes.
+static void minimum_degree(const std::vector<std::vector<int>>& adj0, int slack, std::vector<int>* order) {
+  const int P = (int)adj0.size();
+  std::vector<std::vector<int>> adj = adj0;
+  std::vector<char> gone((size_t)P, 0), blocked((size_t)P, 0);
+  order->clear();
+  order->reserve(P);
+  std::vector<int> cand, merged;
+  int left = P;
+  while (left > 0) {
+    int dmin = P + 1;
+    for (int v = 0; v < P; v++)
+      if (!gone[v]) dmin = std::min(dmin, (int)adj[v].size());
+    cand.clear();
+    for (int v = 0; v < P; v++)
+      if (!gone[v] && (int)adj[v].size() <= dmin + slack) cand.push_back(v);
+    std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+    std::fill(blocked.begin(), blocked.end(), 0);
+    for (int v : cand) {
+      if (blocked[v]) continue;
+      // eliminate v: its neighbours become a clique
+      const std::vector<int> nb = adj[v];
+      for (int a : nb) {
+        blocked[a] = 1;  // not in this round: its degree has just changed
+        merged.clear();
+        std::set_union(adj[a].begin(), adj[a].end(), nb.begin(), nb.end(), std::back_inserter(merged));
+        merged.erase(std::remove_if(merged.begin(), merged.end(), [&](int w) { return w == a || w == v; }), merged.end());
+        adj[a].swap(merged);
+      }
+      adj[v].clear();
+      gone[v] = 1;
+      left--;
+      order->push_back(v);
+    }
+  }
+}
+
+static int sparse_symbolic_with(int num_slots, const int* factor_slots, int num_factors, int ordering, SparseSymbolic* out) {
   SparseSymbolic& S = *out;
   const int P = num_slots;
   S.P = P;
@@ -160,6 +205,8 @@ static int sparse_symbolic(int num_slots, const int* factor_slots, int num_facto
   S.perm.resize(P);
   if (ordering == 1) {
     nested_dissection(adj, &S.perm);
+  } else if (ordering == 2 || ordering == 3) {
+    minimum_degree(adj, ordering == 2 ? 0 : 1, &S.perm);
   } else {
     std::iota(S.perm.begin(), S.perm.end(), 0);
   }
@@ -273,14 +320,83 @@ static int sparse_symbolic(int num_slots, const int* factor_slots, int num_facto
   for (int r : roots) owner[r] = S.num_subtrees++;
   for (int j = P - 1; j >= 0; j--)
     if (!in_top[j] && owner[j] < 0) owner[j] = owner[S.parent[j]];  // parent index > child index: the parent is done
-  S.work_ptr.assign(S.num_subtrees + 2, 0);
-  for (int j = 0; j < P; j++) S.work_ptr[(in_top[j] ? S.num_subtrees : owner[j]) + 1]++;
-  for (int w = 0; w <= S.num_subtrees; w++) S.work_ptr[w + 1] += S.work_ptr[w];
-  S.work_cols.resize(P);
-  {
-    std::vector<int> cur(S.work_ptr.begin(), S.work_ptr.end() - 1);
-    for (int j = 0; j < P; j++) S.work_cols[cur[in_top[j] ? S.num_subtrees : owner[j]]++] = j;  // ascending inside every list
+  // the top part, level-scheduled: its columns are cut into CHAINS (a column with exactly one child in the top continues that child's chain)
+  // and a chain's level is one above the highest level among the chains below it (subtrees: level 0).  One launch per level, one workgroup
+  // per chain: the separators of a dissection's level l run side by side instead of behind each other on one workgroup (round 2: band graphs
+  // spent 4-5 ms there).
+  std::vector<int> chain_of((size_t)P, -1), chain_level;
+  std::vector<std::vector<int>> chain_cols;
+  for (int j = 0; j < P; j++) {  // children precede parents
+    if (!in_top[j]) continue;
+    int top_children = 0, only = -1, lvl = 1;
+    for (int c : children[j]) {
+      if (in_top[c]) {
+        top_children++;
+        only = c;
+        lvl = std::max(lvl, chain_level[(size_t)chain_of[c]] + 1);
+      }
+    }
+    if (top_children == 1) {
+      chain_of[j] = chain_of[only];
+      chain_cols[(size_t)chain_of[j]].push_back(j);
+    } else {
+      chain_of[j] = (int)chain_cols.size();
+      chain_cols.push_back({j});
+      chain_level.push_back(lvl);
+    }
   }
+  int num_levels = 1;
+  for (int l : chain_level) num_levels = std::max(num_levels, l + 1);
+  std::vector<std::vector<int>> by_level((size_t)num_levels);
+  for (size_t c = 0; c < chain_cols.size(); c++) by_level[(size_t)chain_level[c]].push_back((int)c);
+  const int num_lists = S.num_subtrees + (int)chain_cols.size();
+  S.work_ptr.assign(num_lists + 1, 0);
+  S.work_cols.clear();
+  S.work_cols.reserve(P);
+  S.level_ptr.assign(1, 0);
+  {
+    std::vector<std::vector<int>> sub((size_t)S.num_subtrees);
+    for (int j = 0; j < P; j++)
+      if (!in_top[j]) sub[(size_t)owner[j]].push_back(j);  // ascending inside every list
+    int list = 0;
+    for (auto& cols : sub) {
+      S.work_cols.insert(S.work_cols.end(), cols.begin(), cols.end());
+      S.work_ptr[++list] = (int)S.work_cols.size();
+    }
+    S.level_ptr.push_back(list);
+    for (int l = 1; l < num_levels; l++) {
+      for (int c : by_level[(size_t)l]) {
+        S.work_cols.insert(S.work_cols.end(), chain_cols[(size_t)c].begin(), chain_cols[(size_t)c].end());
+        S.work_ptr[++list] = (int)S.work_cols.size();
+      }
+      S.level_ptr.push_back(list);
+    }
+  }
+  return GP_OK;
+}
+
+// what one solve walks sequentially: the sum over the levels of the longest work list of the level
+static int critical_columns(const SparseSymbolic& S) {
+  int crit = 0;
+  for (size_t l = 0; l + 1 < S.level_ptr.size(); l++) {
+    int longest = 0;
+    for (int w = S.level_ptr[l]; w < S.level_ptr[l + 1]; w++) longest = std::max(longest, S.work_ptr[w + 1] - S.work_ptr[w]);
+    crit += longest;
+  }
+  return crit;
+}
+
+// ordering = 4 (automatic): nested dissection and minimum degree with slack are both tried and the schedule with the shorter critical path
+// (then the smaller factor) is kept -- band-like graphs want the dissection (separators side by side), graphs with random loop closures and
+// grids the minimum degree (less fill AND a shorter path); the symbolic phase is host code run once per graph
+static int sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, SparseSymbolic* out) {
+  if (ordering != 4) return sparse_symbolic_with(num_slots, factor_slots, num_factors, ordering, out);
+  SparseSymbolic a, b;
+  GP_TRY(sparse_symbolic_with(num_slots, factor_slots, num_factors, 1, &a));
+  GP_TRY(sparse_symbolic_with(num_slots, factor_slots, num_factors, 3, &b));
+  const int ca = critical_columns(a), cb = critical_columns(b);
+  const bool take_b = cb < ca || (cb == ca && b.colptr[num_slots] < a.colptr[num_slots]);
+  *out = take_b ? std::move(b) : std::move(a);
   return GP_OK;
 }
 
@@ -538,8 +654,8 @@ extern "C" {
 
 int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
                        int* num_subtrees, int* top_columns) {
-  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 1)
-    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_symbolic: bad arguments (ordering: 0 = natural, 1 = nested dissection)");
+  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 4)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_symbolic: bad arguments (ordering: 0 = natural, 1 = nested dissection, 2 = minimum degree, 3 = minimum degree with slack, 4 = automatic)");
   gp::SparseSymbolic S;
   GP_TRY(gp::sparse_symbolic(num_slots, factor_slots, num_factors, ordering, &S));
   if (perm_out) memcpy(perm_out, S.perm.data(), sizeof(int) * (size_t)num_slots);
@@ -547,15 +663,29 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
   if (nnz_a_blocks) *nnz_a_blocks = S.nnzA;
   if (nnz_l_blocks) *nnz_l_blocks = S.colptr[num_slots];
   if (num_subtrees) *num_subtrees = S.num_subtrees;
-  if (top_columns) *top_columns = S.work_ptr[S.num_subtrees + 1] - S.work_ptr[S.num_subtrees];
+  if (top_columns) *top_columns = num_slots - S.work_ptr[S.num_subtrees];
+  return GP_OK;
+}
+
+// the schedule of the numeric phase (pure host code): number of launch levels (level 0 = the subtrees) and the critical path in columns, i.e. the
+// sum over the levels of the longest work list of the level -- what one solve walks sequentially
+int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_factors, int ordering, int* num_levels, int* critical_columns, int* num_lists) {
+  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 4)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_symbolic_schedule: bad arguments");
+  gp::SparseSymbolic S;
+  GP_TRY(gp::sparse_symbolic(num_slots, factor_slots, num_factors, ordering, &S));
+  const int levels = (int)S.level_ptr.size() - 1;
+  if (num_levels) *num_levels = levels;
+  if (critical_columns) *critical_columns = gp::critical_columns(S);
+  if (num_lists) *num_lists = S.level_ptr[levels];
   return GP_OK;
 }
 
 int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_factors, int ordering, gp_stream_t stream, gp_sparse_system_t** out) {
   if (!out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: null out");
   *out = nullptr;
-  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 1)
-    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: factor_slots = [num_factors][2] (target, source; < 0 = fixed), ordering 0 | 1");
+  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 4)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: factor_slots = [num_factors][2] (target, source; < 0 = fixed), ordering 0 .. 4");
   auto s = std::make_unique<gp_sparse_system>();
   GP_TRY(gp::sparse_symbolic(num_slots, factor_slots, num_factors, ordering, &s->sym));
   const gp::SparseSymbolic& S = s->sym;
@@ -653,7 +783,7 @@ int gp_sparse_system_info(const gp_sparse_system_t* s, int64_t* nnz_a_blocks, in
   if (nnz_l_blocks) *nnz_l_blocks = S.colptr[S.P];
   if (block_products) *block_products = (int64_t)S.upd_a.size();
   if (num_subtrees) *num_subtrees = S.num_subtrees;
-  if (top_columns) *top_columns = S.work_ptr[S.num_subtrees + 1] - S.work_ptr[S.num_subtrees];
+  if (top_columns) *top_columns = S.P - S.work_ptr[S.num_subtrees];
   return GP_OK;
 }
 
@@ -722,13 +852,18 @@ int gp_sparse_system_download(const gp_sparse_system_t* s, double* A_host, doubl
 int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_out) {
   if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_solve: build the system first");
   const gp::SparseSymbolic& S = s->sym;
-  const int nsub = S.num_subtrees;
-  const bool has_top = S.work_ptr[nsub + 1] > S.work_ptr[nsub];
   GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
-  if (nsub > 0) hipLaunchKernelGGL(gp::sparse_factor_kernel, dim3(nsub), dim3(gp::kSparseThreads), 0, s->stream, s->view, 0);
-  if (has_top) hipLaunchKernelGGL(gp::sparse_factor_kernel, dim3(1), dim3(gp::kSparseThreads), 0, s->stream, s->view, nsub);
-  if (has_top) hipLaunchKernelGGL(gp::sparse_backsolve_kernel, dim3(1), dim3(64), 0, s->stream, s->view, nsub);
-  if (nsub > 0) hipLaunchKernelGGL(gp::sparse_backsolve_kernel, dim3(nsub), dim3(64), 0, s->stream, s->view, 0);
+  // one launch per level of the schedule (level 0: the subtrees; then the chains of separator columns, level by level), the backward
+  // substitution the same levels in reverse
+  const int levels = (int)S.level_ptr.size() - 1;
+  for (int l = 0; l < levels; l++) {
+    const int first = S.level_ptr[l], count = S.level_ptr[l + 1] - first;
+    if (count > 0) hipLaunchKernelGGL(gp::sparse_factor_kernel, dim3(count), dim3(gp::kSparseThreads), 0, s->stream, s->view, first);
+  }
+  for (int l = levels - 1; l >= 0; l--) {
+    const int first = S.level_ptr[l], count = S.level_ptr[l + 1] - first;
+    if (count > 0) hipLaunchKernelGGL(gp::sparse_backsolve_kernel, dim3(count), dim3(64), 0, s->stream, s->view, first);
+  }
   hipLaunchKernelGGL(gp::sparse_unpermute_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), s->d_perm, S.P, s->x_slots.as<double>());
   GP_HIP(hipGetLastError());
   s->built = false;

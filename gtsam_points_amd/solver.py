@@ -102,17 +102,22 @@ def sparse_symbolic(num_slots, factor_slots, ordering=0):
     na, nl, ns, nt = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
     _capi.check(lib.gp_sparse_symbolic(int(num_slots), fs.ctypes.data, len(fs), int(ordering), perm.ctypes.data, parent.ctypes.data, C.byref(na), C.byref(nl), C.byref(ns),
                                        C.byref(nt)), "gp_sparse_symbolic")
-    return dict(perm=perm, parent=parent, nnz_a_blocks=na.value, nnz_l_blocks=nl.value, num_subtrees=ns.value, top_columns=nt.value)
+    lv, cc, wl = C.c_int(), C.c_int(), C.c_int()
+    _capi.check(lib.gp_sparse_symbolic_schedule(int(num_slots), fs.ctypes.data, len(fs), int(ordering), C.byref(lv), C.byref(cc), C.byref(wl)), "gp_sparse_symbolic_schedule")
+    return dict(perm=perm, parent=parent, nnz_a_blocks=na.value, nnz_l_blocks=nl.value, num_subtrees=ns.value, top_columns=nt.value, num_levels=lv.value,
+                critical_columns=cc.value, num_lists=wl.value)
 
 
 class SparseLinearSystemGPU:
     """A x = b over 6-dof pose slots as a block-sparse lower triangle, solved by a block-sparse LL^T on the device.
 
-    factor_slots as for DenseLinearSystemGPU; ordering: "natural" (slot order = elimination order) or "nd" (nested dissection)."""
+    factor_slots as for DenseLinearSystemGPU; ordering: "natural" (slot order = elimination order), "nd" (nested dissection), "amd" (minimum degree by
+    multiple elimination: the fill of the COLAMD-class orderings GTSAM gives the reference), "amd1" (the same with a slack of one on the degree) or
+    "auto" (default: "nd" and "amd1" are both tried, the schedule with the shorter critical path is kept)."""
 
-    ORDERINGS = {"natural": 0, "nd": 1}
+    ORDERINGS = {"natural": 0, "nd": 1, "amd": 2, "amd1": 3, "auto": 4}
 
-    def __init__(self, num_slots, factor_slots, ordering="nd", stream=None):
+    def __init__(self, num_slots, factor_slots, ordering="auto", stream=None):
         self._lib = _capi.load()
         self.num_slots = int(num_slots)
         self.factor_slots = np.ascontiguousarray(np.asarray(factor_slots, dtype=np.int32).reshape(-1, 2))

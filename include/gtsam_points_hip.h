@@ -388,7 +388,11 @@ int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev)
  *   left-looking block LL^T in f64 scheduled over the elimination tree (independent subtrees = one workgroup each, then the
  *   separator columns), forward substitution fused, four launches per solve; every block is a gather in a fixed order (deterministic).
  * ordering: 0 = natural (the slot order is the elimination order: "the ordering from the factor key list"),
- *           1 = nested dissection by BFS bisection of the pose graph (shallow elimination tree: chains become ~log2(P) levels).
+ *           1 = nested dissection by BFS bisection of the pose graph (shallow elimination tree: chains become ~log2(P) levels),
+ *           2 = minimum degree by multiple elimination (the fill of a COLAMD-class ordering, which is what GTSAM gives the reference's solves:
+ *               optimizers/levenberg_marquardt_ext.cpp:200-220); 3 = the same with a slack of one on the degree (more nodes per round: a bushier tree),
+ *           4 = automatic: 1 and 3 are both tried, the schedule with the shorter critical path (then the smaller factor) is kept.
+ * The numeric phase runs one launch per LEVEL of the schedule: the independent subtrees, then the chains of separator columns level by level.
  * Same slot / record conventions as gp_dense_system_*; no limit on num_slots. */
 typedef struct gp_sparse_system gp_sparse_system_t;
 int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_factors, int ordering, gp_stream_t stream, gp_sparse_system_t** out);
@@ -407,6 +411,9 @@ int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_de
  * parent[k] (-1 = root), block counts and the schedule; any output pointer may be NULL */
 int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
                        int* num_subtrees, int* top_columns);
+/* the schedule of the numeric phase (pure host code): launch levels (level 0 = the independent subtrees, then the chains of separator columns level by
+ * level, one workgroup per chain), the critical path in columns (sum over the levels of the longest work list) and the number of work lists */
+int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_factors, int ordering, int* num_levels, int* critical_columns, int* num_lists);
 
 /* ---- per-handle tuning (not part of the reference API) --------------------------------------------------------------------------
  * Every knob below belongs to ONE batch / factor / map / search structure; the library keeps no process-global switches, so two

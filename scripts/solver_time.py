@@ -52,7 +52,7 @@ for kind in ("chain", "loops"):
         if P <= 512:
             xd, b, s = time_system(gpa.DenseLinearSystemGPU(P, pairs), rec_dev, 3)
             row.update(dense_build_ms=round(b, 3), dense_solve_ms=round(s, 3))
-        for name in ("natural", "nd"):
+        for name in ("natural", "nd", "amd", "amd1", "auto"):
             sp = gpa.SparseLinearSystemGPU(P, pairs, ordering=name)
             x, b, s = time_system(sp, rec_dev)
             info = sp.info()

@@ -31,22 +31,41 @@ def _boolean_fill(n, slots, perm):
     return nnz_a, int(np.tril(M).sum()), parent
 
 
-@pytest.mark.parametrize("ordering", [0, 1])
-@pytest.mark.parametrize("case", ["chain", "loops", "disconnected", "grid"])
-def test_symbolic_matches_boolean_elimination(case, ordering):
+def _graph(case):
     rng = np.random.default_rng(5)
     if case == "chain":
-        n, slots = 512, _chain_graph(512, fixed_first=True)
-    elif case == "loops":
+        return 512, _chain_graph(512, fixed_first=True)
+    if case == "loops":
         n = 300
-        slots = _chain_graph(n, closures=[(int(a), int(b)) for a, b in rng.integers(0, n, (40, 2)) if a != b])
-    elif case == "disconnected":
-        n = 40
-        slots = [(i, i + 1) for i in range(0, 15)] + [(i, i + 1) for i in range(20, 39)]  # poses 16..19 isolated
-    else:
-        w = 12
-        n = w * w
-        slots = [(r * w + c, r * w + c + 1) for r in range(w) for c in range(w - 1)] + [(r * w + c, (r + 1) * w + c) for r in range(w - 1) for c in range(w)]
+        return n, _chain_graph(n, closures=[(int(a), int(b)) for a, b in rng.integers(0, n, (40, 2)) if a != b])
+    if case == "disconnected":
+        return 40, [(i, i + 1) for i in range(0, 15)] + [(i, i + 1) for i in range(20, 39)]  # poses 16..19 isolated
+    if case == "band":
+        return 512, [(i, i + d) for i in range(512) for d in (1, 2, 7) if i + d < 512]
+    w = 12
+    return w * w, [(r * w + c, r * w + c + 1) for r in range(w) for c in range(w - 1)] + [(r * w + c, (r + 1) * w + c) for r in range(w - 1) for c in range(w)]
+
+
+@pytest.mark.parametrize("case", ["chain", "loops", "disconnected", "grid", "band"])
+def test_minimum_degree_never_fills_more_than_the_dissection(case):
+    """ordering 2 (minimum degree by multiple elimination -- the fill-reducing class of ordering GTSAM hands the reference's solver) against
+    ordering 1 (BFS nested dissection): its factor is never larger; ordering 4 (automatic) keeps whichever of 1 / 3 has the shorter critical
+    path; the level schedule covers every column exactly once and walks far fewer columns sequentially than there are."""
+    n, slots = _graph(case)
+    nd, md, md1, auto = (gpa.sparse_symbolic(n, slots, o) for o in (1, 2, 3, 4))
+    assert md["nnz_l_blocks"] <= nd["nnz_l_blocks"], (md["nnz_l_blocks"], nd["nnz_l_blocks"])
+    assert auto["critical_columns"] == min(nd["critical_columns"], md1["critical_columns"])
+    for s in (nd, md, md1, auto):
+        assert sorted(s["perm"].tolist()) == list(range(n))
+        assert 1 <= s["num_levels"] <= 64 and s["critical_columns"] <= n
+    if case in ("chain", "band"):
+        assert auto["critical_columns"] <= 64 + n // 8  # separators / rounds side by side: nowhere near one path of n columns
+
+
+@pytest.mark.parametrize("ordering", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("case", ["chain", "loops", "disconnected", "grid", "band"])
+def test_symbolic_matches_boolean_elimination(case, ordering):
+    n, slots = _graph(case)
     s = gpa.sparse_symbolic(n, slots, ordering)
     perm = s["perm"]
     assert sorted(perm.tolist()) == list(range(n))
