@@ -478,7 +478,6 @@ struct SparseView {
   int* status;    // != 0: a pivot was not positive
 };
 
-constexpr int kSparseThreads = 256;
 
 // visibility of LDS writes between the lanes of ONE wave (its LDS operations execute in program order; this keeps the compiler from
 // moving them and makes it wait for the writes): what __syncthreads() is for a workgroup, without the s_barrier
@@ -490,7 +489,8 @@ constexpr int kSparseThreads = 256;
   } while (0)
 
 // left-looking block Cholesky of the columns of work list (first_list + blockIdx.x), in elimination order
-__global__ void __launch_bounds__(kSparseThreads) sparse_factor_kernel(SparseView S, int first_list) {
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) sparse_factor_kernel(SparseView S, int first_list) {
   __shared__ double D[6][7];   // diagonal block (row stride 7: the column sweeps below are conflict-free), becomes L_kk
   __shared__ double rhs[6];
   __shared__ int bad;
@@ -501,14 +501,40 @@ __global__ void __launch_bounds__(kSparseThreads) sparse_factor_kernel(SparseVie
     const int k = S.work_cols[w];
     const int base = S.colptr[k], nb = S.colptr[k + 1] - base;
     // 1. gather: every entry of every block of the column collects its updates (ascending source column)
-    for (int e = t; e < 36 * nb; e += kSparseThreads) {
+    for (int e = t; e < 36 * nb; e += THREADS) {
       const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
       double acc = S.L[36 * (size_t)d + (e % 36)];
-      for (int u = S.upd_ptr[d]; u < S.upd_ptr[d + 1]; u++) {
-        const double* A = S.L + 36 * (size_t)S.upd_a[u];
-        const double* B = S.L + 36 * (size_t)S.upd_b[u];
+      // the products of an entry are a chain of dependent round trips (index -> block -> value) when taken one at a time: the separator columns of a
+      // band graph carry ~100 products per block and took ~27 us apiece.  Four products' indices, then their 48 operands, are requested together;
+      // the subtractions keep the order of the list (ascending source column), so the factor is bit for bit what the one-at-a-time loop gives
+      int u = S.upd_ptr[d];
+      const int ue = S.upd_ptr[d + 1];
+      constexpr int kBatch = 4;
+      for (; u < ue; u += kBatch) {
+        int ia[kBatch], ib[kBatch];
 #pragma unroll
-        for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * B[c + 6 * q];
+        for (int w = 0; w < kBatch; w++) {
+          const int uu = u + w < ue ? u + w : ue - 1;  // (a short tail repeats the last product's operands and skips its subtraction)
+          ia[w] = S.upd_a[uu];
+          ib[w] = S.upd_b[uu];
+        }
+        double av[kBatch][6], bv[kBatch][6];
+#pragma unroll
+        for (int w = 0; w < kBatch; w++) {
+          const double* A = S.L + 36 * (size_t)ia[w];
+          const double* B = S.L + 36 * (size_t)ib[w];
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            av[w][q] = A[r + 6 * q];
+            bv[w][q] = B[c + 6 * q];
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < kBatch; w++)
+          if (u + w < ue) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc -= av[w][q] * bv[w][q];
+          }
       }
       if (d == base) {
         D[r][c] = acc;
@@ -520,7 +546,29 @@ __global__ void __launch_bounds__(kSparseThreads) sparse_factor_kernel(SparseVie
     if (t >= 64 && t < 70) {
       const int r = t - 64;
       double acc = S.y[6 * (size_t)k + r];
-      for (int u = S.row_ptr[k]; u < S.row_ptr[k + 1]; u++) {
+      int u = S.row_ptr[k];
+      const int ue = S.row_ptr[k + 1];
+      for (; u + 4 <= ue; u += 4) {  // four blocks of the row requested together, subtracted in list order (see the gather above)
+        int ib[4], ic[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          ib[w] = S.row_blk[u + w];
+          ic[w] = S.row_col[u + w];
+        }
+        double av[4][6], yv[4][6];
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            av[w][q] = S.L[36 * (size_t)ib[w] + r + 6 * q];
+            yv[w][q] = S.y[6 * (size_t)ic[w] + q];
+          }
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+          for (int q = 0; q < 6; q++) acc -= av[w][q] * yv[w][q];
+      }
+      for (; u < ue; u++) {
         const double* A = S.L + 36 * (size_t)S.row_blk[u];
         const double* yj = S.y + 6 * (size_t)S.row_col[u];
 #pragma unroll
@@ -557,7 +605,7 @@ __global__ void __launch_bounds__(kSparseThreads) sparse_factor_kernel(SparseVie
     if (t < 36) S.L[36 * (size_t)base + t] = (t % 6) >= (t / 6) ? D[t % 6][t / 6] : 0.0;
     if (t >= 64 && t < 70) S.y[6 * (size_t)k + (t - 64)] = rhs[t - 64];
     // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row): forward substitution along the row
-    for (int e = t; e < 6 * (nb - 1); e += kSparseThreads) {
+    for (int e = t; e < 6 * (nb - 1); e += THREADS) {
       double* Bk = S.L + 36 * (size_t)(base + 1 + e / 6);
       const int r = e % 6;
       double o[6];
@@ -858,7 +906,11 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
   const int levels = (int)S.level_ptr.size() - 1;
   for (int l = 0; l < levels; l++) {
     const int first = S.level_ptr[l], count = S.level_ptr[l + 1] - first;
-    if (count > 0) hipLaunchKernelGGL(gp::sparse_factor_kernel, dim3(count), dim3(gp::kSparseThreads), 0, s->stream, s->view, first);
+    // 256 threads for the subtrees (columns of a few blocks), 1024 for the chains of separator columns (a dozen blocks each).  Measured on the 512-pose
+    // band graph (profiles/r03_solver_time.txt): this form 1.34 ms; 512 threads + batches of eight products 1.45-1.48 ms with or without the next
+    // batch's indices prefetched; 1024 threads + batches of eight 2.8 ms (the 128-register cap spills the batch)
+    if (count > 0 && l == 0) hipLaunchKernelGGL(gp::sparse_factor_kernel<256>, dim3(count), dim3(256), 0, s->stream, s->view, first);
+    if (count > 0 && l > 0) hipLaunchKernelGGL(gp::sparse_factor_kernel<1024>, dim3(count), dim3(1024), 0, s->stream, s->view, first);
   }
   for (int l = levels - 1; l >= 0; l--) {
     const int first = S.level_ptr[l], count = S.level_ptr[l + 1] - first;
