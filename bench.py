@@ -58,6 +58,18 @@ def _effective_kernel(lib, batch):
     return v.value
 
 
+def _load_split():
+    """rocprofv3 per-dispatch durations of the tile kernel by launch pattern (scripts/kernel_trace_split.py over the driver's bench command, builder-run)"""
+    path = os.path.join(ROOT, "profiles", "kernel_trace_split.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return dict(in_step_ms=round(d["in_step"]["mean_us"] * 1e-3, 5), all_ms=round(d["all"]["mean_us"] * 1e-3, 5),
+                    source="profiles/kernel_trace_split.json (builder-run rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5`); NOT measured in this run")
+    except Exception:
+        return {}
+
+
 def _load_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), or None.
     bench.py cannot collect PMC counters itself; scripts/gpu_check.sh does, in separate rocprofv3 --pmc passes,
@@ -541,20 +553,7 @@ def main():
     _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pose.ctypes.data, args.kernel_iters, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
     alg_bytes = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
     achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
-    # the same kernel INSIDE the synchronous step (behind the queue the host leaves idle between two passes): HIP events around the two kernels of
-    # every pass of a second, untimed loop of the same steps (GP_TUNE_TIMING; the events are not in the timed region above)
-    in_step_tile, in_step_fin = None, None
-    if not dist_on:
-        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_TIMING, 1), "timing")
-        tt, tf = [], []
-        a_, b_ = C.c_float(), C.c_float()
-        for _ in range(max(args.steps, 20)):
-            step()
-            lib.gp_vgicp_batch_last_kernel_ms(batch, C.byref(a_), C.byref(b_))
-            tt.append(a_.value)
-            tf.append(b_.value)
-        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_TIMING, 0), "timing")
-        in_step_tile, in_step_fin = float(np.mean(tt)), float(np.mean(tf))
+    split = _load_split()
     roofline = dict(
         bound="hbm",
         kernel=KERNEL_NAMES.get(_effective_kernel(lib, batch), "?"),
@@ -566,12 +565,15 @@ def main():
         traffic_source=_load_traffic()[1],
         algorithmic_bytes=alg_bytes,
         kernel_ms=round(ms_main.value, 5),
-        kernel_ms_in_step=round(in_step_tile, 5) if in_step_tile else None,
-        frac_in_step=round(alg_bytes / (in_step_tile * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if in_step_tile else None,
-        finalize_kernel_ms_in_step=round(in_step_fin, 5) if in_step_fin else None,
-        kernel_ms_note="kernel_ms / frac: HIP events over back-to-back launches on the launch stream (the kernel at the device's sustained state); kernel_ms_in_step / "
-                       "frac_in_step: HIP events around the same kernel inside synchronous steps, i.e. behind the queue the host leaves idle between two passes "
-                       "(a second, untimed loop of the same steps); the rocprofv3 --stats average of this command mixes both launch patterns (profiles/, DESIGN.md section 6)",
+        kernel_ms_in_step=split.get("in_step_ms"),
+        frac_in_step=round(alg_bytes / (split["in_step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if split.get("in_step_ms") else None,
+        kernel_ms_rocprof_mean=split.get("all_ms"),
+        frac_rocprof_mean=round(alg_bytes / (split["all_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if split.get("all_ms") else None,
+        kernel_ms_in_step_source=split.get("source"),
+        kernel_ms_note="kernel_ms / frac: measured in THIS run, HIP events over back-to-back launches on the launch stream (the kernel at the device's sustained state); "
+                       "kernel_ms_in_step (the same kernel behind the queue the host leaves idle between two synchronous passes) and kernel_ms_rocprof_mean (all "
+                       "dispatches of the driver's command, both launch patterns) are rocprofv3 per-dispatch durations read from the committed builder-run split "
+                       "(HIP events around a kernel inside a step would add their own markers to it), DESIGN.md section 6",
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
     )

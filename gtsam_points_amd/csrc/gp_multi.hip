@@ -21,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <numeric>
+#include <string>
 
 #include "gp_host.hpp"
 
@@ -240,7 +241,29 @@ void destroy_multi(gp_vgicp_multi_batch* mb) {
 
 // one pass over all shards: WIDTH doubles per factor (122: linearise, 1: error)
 template <typename Issue>
+int run_pass_impl(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issue, double* out_host, bool* group_open);
+
+// A failure in the middle of a pass must not leave an RCCL group open or work in flight on the other devices' streams (the next collective of
+// this thread would hang or misbehave): the group is closed and every shard's stream drained before the error is handed up.
+template <typename Issue>
 int run_pass(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issue, double* out_host) {
+  bool group_open = false;
+  const int rc = run_pass_impl(mb, width, err_pass, issue, out_host, &group_open);
+  if (rc != GP_OK) {
+    const std::string keep = gp_last_error() ? gp_last_error() : "";
+    if (group_open) (void)rccl().GroupEnd();
+    for (auto& s : mb->shards) {
+      (void)hipSetDevice(s.device);
+      if (s.stream) (void)hipStreamSynchronize(s.stream);
+    }
+    (void)hipGetLastError();
+    gp::fail(rc, keep.c_str());  // (the clean-up calls may have replaced the message)
+  }
+  return rc;
+}
+
+template <typename Issue>
+int run_pass_impl(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issue, double* out_host, bool* group_open) {
   DeviceGuard guard;
   const size_t F = (size_t)mb->num_factors;
   // ---- compute: every shard issues its batched kernels into its rows ----
@@ -274,10 +297,12 @@ int run_pass(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issue, do
   if (mb->use_rccl) {
     Rccl& r = rccl();
     GP_NCCL(r.GroupStart());
+    *group_open = true;
     for (auto& s : mb->shards) {
       gp::DeviceArray& dst = err_pass ? s.d_err : s.d_stack;
       GP_NCCL(r.AllReduce(dst.ptr, dst.ptr, (size_t)width * F, ncclDouble, ncclSum, s.comm, s.stream));
     }
+    *group_open = false;
     GP_NCCL(r.GroupEnd());
     Shard& s0 = mb->shards[0];
     GP_HIP(hipSetDevice(s0.device));
