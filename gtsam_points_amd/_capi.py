@@ -201,6 +201,7 @@ GP_TUNE_TIMING = 7
 GP_TUNE_XCD_WEIGHT_0 = 8
 GP_TUNE_OVERLAP_FINALIZE = 17
 GP_TUNE_TILE_CHUNKS = 18
+GP_TUNE_MAX_WORKGROUPS = 19
 GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32
 KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM]
 

@@ -1,5 +1,6 @@
 // gp_host.hpp -- host-side internals shared by the translation units of libgtsam_points_hip.so
 #pragma once
+#include <algorithm>
 
 #include <hip/hip_runtime.h>
 
@@ -81,8 +82,20 @@ struct BlockCache {
   }
   void trim() {
     if (entries.empty()) return;
-    (void)hipDeviceSynchronize();  // the tagged streams may be gone by now: everything is returned on the NULL stream
-    for (const Entry& e : entries) (void)hipFreeAsync(e.ptr, nullptr);
+    // the tagged streams may be gone by now: every block is returned on the NULL stream of ITS device, behind a synchronisation of that device
+    // (a single-process multi-GPU batch parks blocks of several devices in one thread's cache)
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    std::vector<int> devices;
+    for (const Entry& e : entries)
+      if (std::find(devices.begin(), devices.end(), e.device) == devices.end()) devices.push_back(e.device);
+    for (int dev : devices) {
+      if (hipSetDevice(dev) != hipSuccess) continue;
+      (void)hipDeviceSynchronize();
+      for (const Entry& e : entries)
+        if (e.device == dev) (void)hipFreeAsync(e.ptr, nullptr);
+    }
+    (void)hipSetDevice(cur);
     entries.clear();
     total = 0;
   }
@@ -130,6 +143,11 @@ struct DeviceArray {
       bytes = got;
     } else {
       hipError_t e = hipMallocAsync(&ptr, n, stream);
+      if (e != hipSuccess) {  // out of memory while up to 4 GiB sit parked in this thread's cache: give them back and try once more
+        (void)hipGetLastError();
+        BlockCache::get().trim();
+        e = hipMallocAsync(&ptr, n, stream);
+      }
       if (e != hipSuccess) {
         ptr = nullptr;
         return hip_fail(e, "hipMallocAsync", __FILE__, __LINE__);

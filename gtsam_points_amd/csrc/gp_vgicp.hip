@@ -626,7 +626,7 @@ struct gp_vgicp_batch;
 
 // Per-batch tuning (gp_vgicp_batch_set_tuning / gp_vgicp_factor_set_tuning; keys GP_TUNE_* of gtsam_points_hip.h).  Nothing here is process-global:
 // two batches on two threads may run different kernels side by side (re-entrant across handles).
-constexpr int kDefaultSkewPermille = 100;
+constexpr int kDefaultSkewPermille = -1;  // automatic: by the mean share (make_stream_plan)
 struct gp_vgicp_tuning {
   int kernel = GP_KERNEL_STREAM;  // GP_KERNEL_*: which tile kernel family the batch prefers (it falls back where that family does not apply)
   int source_policy = 0;          // cache policy of the source stream: 0 = per batch (non-temporal iff no two factors share a source cloud), 1 = default, 2 = non-temporal
@@ -635,6 +635,7 @@ struct gp_vgicp_tuning {
   int tile_interleave = 0;        // consecutive factors that share a source cloud take turns tile by tile
   int xcd_weights[8] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // GP_TUNE_XCD_WEIGHT_0 + x: share of XCD x in 1/1000 of the mean (unset: the library's table)
   bool xcd_weights_set = false;
+  int max_wgs = 1024;             // stream family, one large factor: workgroups of the planned launch (<= one resident round of 1024)
   int tile_chunks = 0;            // stream family, batches: 64-point chunks per wave of a tile (tile = 256 x this many points); 0 = the largest of 4 / 2 / 1 that fills 3/4 of the chip
   int overlap_finalize = 0;       // synchronous single-factor linearise of the stream family: finalize workgroups on a second stream wait for arrival counters
                                   // (measured: the second stream costs ~10 us per step on this stack, profiles/r03_overlap_finalize.jsonl: off by default)
@@ -749,13 +750,20 @@ struct PoseSource {
 // move the kernel's duration beyond noise (11.54 / 11.56 / 11.64 / 11.41 us for four tables, profiles/r03_sweep_xcd_weights.jsonl): the
 // shares stay equal, the knob stays (GP_TUNE_XCD_WEIGHT_0 + x).
 constexpr int kXcdWeightPermille[gp::kNumXCD] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};
-int make_stream_plan(int n, int skew_permille, const int* xcd_weights, gp::StreamPlan* p) {
+int make_stream_plan(int n, int skew_permille, const int* xcd_weights, gp::StreamPlan* p, int max_wgs = kResidentWorkgroups) {
   const int C = n / gp::kChunkPoints;
-  const int G = std::min(kResidentWorkgroups, (std::max((C + 3) / 4, 1) + gp::kNumXCD - 1) / gp::kNumXCD * gp::kNumXCD);
+  const int G = std::min(std::max(gp::kNumXCD, max_wgs / gp::kNumXCD * gp::kNumXCD), (std::max((C + 3) / 4, 1) + gp::kNumXCD - 1) / gp::kNumXCD * gp::kNumXCD);
   const int gx = G / gp::kNumXCD;
   *p = gp::StreamPlan{};
   p->tail = n % gp::kChunkPoints;
   p->wgs_per_xcd = gx;
+  if (skew_permille < 0) {
+    // automatic: what a later dispatch round loses against an earlier one is mostly an ABSOLUTE delay (dispatch order, oldest-first issue), so the
+    // relative skew shrinks with the work per workgroup.  Measured best values (profiles/r03_sweep_skew.jsonl, r03_sweep_xcd_weights.jsonl): ~300
+    // at 15 chunks per workgroup (the 1 M-point headline), ~100 at 122 (an 8 M-point source); linear in between
+    const double mean = (double)C / G;
+    skew_permille = mean <= 24.0 ? 250 : (mean >= 96.0 ? 100 : (int)(250.0 - 150.0 * (mean - 24.0) / 72.0));
+  }
   // shares of the XCDs: proportional to their weights, whole chunks, summing to C (largest remainders first; equal weights = cx or cx + 1)
   const int* w = xcd_weights ? xcd_weights : kXcdWeightPermille;
   int share[gp::kNumXCD];
@@ -853,7 +861,7 @@ int build_table(gp_vgicp_batch* b) {
   b->planned = fam == GP_KERNEL_STREAM && F == 1 && descs[0].n >= kPlanMinPoints;
   if (b->planned) {
     // one large factor: the balanced plan; the table holds the same tiles the in-argument launch derives from the plan (plan_tile)
-    const int G = make_stream_plan(descs[0].n, b->tuning.balance, b->tuning.xcd_weights_set ? b->tuning.xcd_weights : nullptr, &b->plan);
+    const int G = make_stream_plan(descs[0].n, b->tuning.balance, b->tuning.xcd_weights_set ? b->tuning.xcd_weights : nullptr, &b->plan, b->tuning.max_wgs);
     b->ppt = 4;
     b->tile_points = 0;
     descs[0].tile_begin = 0;
@@ -1208,12 +1216,16 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
     case GP_TUNE_OVERLAP_FINALIZE:
       t->overlap_finalize = value ? 1 : 0;
       return GP_OK;
+    case GP_TUNE_MAX_WORKGROUPS:
+      if (value < 8 || value > 1024) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_MAX_WORKGROUPS: 8 .. 1024");
+      t->max_wgs = value;
+      return GP_OK;
     case GP_TUNE_TILE_CHUNKS:
       if (value < 0 || value > 64) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_TILE_CHUNKS: 0 (automatic) .. 64 chunks per wave");
       t->tile_chunks = value;
       return GP_OK;
     case GP_TUNE_BALANCE:
-      if (value < 0 || value > 600) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_BALANCE: 0 (flat) .. 600 (per mille of the mean share per dispatch round)");
+      if (value < -1 || value > 600) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_BALANCE: -1 (automatic), 0 (flat) .. 600 (per mille of the mean share per dispatch round)");
       t->balance = value;
       return GP_OK;
     default:
@@ -1658,7 +1670,7 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
 // host-side check hook (no device needed): the tiles a planned single-factor launch of n points deals to its workgroups, in tile-list order
 // (XCD-major).  begin / count: arrays of `capacity` ints; *num_tiles = workgroups of the launch (<= 1024).
 int gp_debug_stream_plan(int n, int skew_permille, const int* xcd_weights_permille, int capacity, int* begin, int* count, int* num_tiles) {
-  if (n < 0 || skew_permille < 0 || !num_tiles) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_stream_plan: bad arguments");
+  if (n < 0 || skew_permille < -1 || !num_tiles) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_stream_plan: bad arguments");
   gp::StreamPlan plan;
   const int G = make_stream_plan(n, skew_permille, xcd_weights_permille, &plan);
   *num_tiles = G;

@@ -572,6 +572,9 @@ int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float*
   auto* m = ext(map);
   hipStream_t s = m->stream;
   const double inv_leaf = 1.0 / m->resolution;
+  // re-inserting into a map that already holds arrays releases them to the block cache ("any stream may take them"): kernels of other streams
+  // that still read the old map must have finished.  A fresh map has nothing to wait for.
+  if (m->buckets.ptr) GP_HIP(hipDeviceSynchronize());
   m->offloaded = false;
   m->generation++;
   if (n > 0 && !m->force_hashed_build) {
@@ -1004,7 +1007,10 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   GP_TRY(to_host(m->h_coords, m->voxel_coords, sizeof(int) * 3 * V, s));
   const size_t G = m->has_grid ? (size_t)m->gdim[0] * m->gdim[1] * m->gdim[2] : 0;
   GP_TRY(to_host(m->h_gblocks, m->gblocks, sizeof(gp::GridBlock) * G, s));
-  GP_HIP(hipStreamSynchronize(s));
+  // the arrays go back to the per-thread block cache tagged "any stream may take them": a factor kernel on ANOTHER stream may still be reading
+  // the map (the caller offloads while a linearise is in flight on the factor's stream), so every stream of the device is drained first -- what
+  // hipFree used to imply; an offload is a rare, millisecond-scale operation
+  GP_HIP(hipDeviceSynchronize());
   m->buckets.release();
   m->records.release();
   m->num_points.release();

@@ -450,7 +450,8 @@ enum {
   GP_TUNE_STAGGER = 3,          /* round-2 kernels: the odd wave slots of every SIMD start `value` x 512 clocks late (0 = off) */
   GP_TUNE_TILE_INTERLEAVE = 4,  /* 1 = consecutive factors that share a source cloud take turns tile by tile, 0 (default) = factor-major */
   GP_TUNE_BALANCE = 5,          /* stream kernel, one large factor: how much more a dispatch round of workgroups takes than the next one, in 1/1000 of
-                                   the mean share (0 = flat split; a compute unit issues from its oldest waves first, csrc/gp_vgicp_shared.hpp) */
+                                   the mean share (0 = flat split; -1 = automatic, the default: 250 for small shares down to 100 for large ones; a compute unit issues from
+                                   its oldest waves first, csrc/gp_vgicp_shared.hpp) */
   GP_TUNE_EFFECTIVE_KERNEL = 6, /* read-only: the family the batch's current table runs (-1 before the first pass) */
   GP_TUNE_XCD_WEIGHT_0 = 8,     /* .. + 7: stream kernel, one large factor: share of XCD x in 1/1000 of the mean share (500..1500); setting any of the eight
                                    replaces the library's measured table (the others then count as 1000) */
@@ -459,6 +460,7 @@ enum {
                                    launching on a second stream costs ~10 us per step -- so the default is 0 = tile kernel, then finalize kernel) */
   GP_TUNE_TILE_CHUNKS = 18,     /* stream family, fixed-tile launches (batches, small single factors): 64-point chunks per wave of a tile (a tile = 256 x value points);
                                    0 (default) = the largest of 4 / 2 / 1 that still gives >= 768 tiles */
+  GP_TUNE_MAX_WORKGROUPS = 19,  /* stream family, one large factor: workgroups of the planned launch, 8 .. 1024 (default 1024 = one resident round) */
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */

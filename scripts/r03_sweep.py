@@ -42,6 +42,8 @@ def make_batch(f, case):
     _capi.check(lib.gp_vgicp_batch_set_tuning(batch, BALANCE, bal), "balance")
     if len(case) > 4:
         _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, case[4]), "overlap")  # GP_TUNE_OVERLAP_FINALIZE
+    if len(case) > 5:
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 19, case[5]), "max workgroups")  # GP_TUNE_MAX_WORKGROUPS
     wsel = case[3] if len(case) > 3 else 1  # XCD weights: 0 equal shares, 1 the library's table (default), 2.. alternatives
     if wsel != 1:
         for x, w in enumerate(XCD_WEIGHTS[wsel]):
@@ -86,7 +88,7 @@ def run_case(name, d, res, delta, Lo, iters=50):
         alg = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
         eff = C.c_int(-2)
         lib.gp_vgicp_batch_get_tuning(batch, 6, C.byref(eff))
-        print(json.dumps(dict(case=name, family=case[0], policy=case[1], balance=case[2], xcd_weights=(case[3] if len(case) > 3 else 1), overlap=(case[4] if len(case) > 4 else 1), effective_family=eff.value, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5),
+        print(json.dumps(dict(case=name, family=case[0], policy=case[1], balance=case[2], xcd_weights=(case[3] if len(case) > 3 else 1), overlap=(case[4] if len(case) > 4 else 0), max_wgs=(case[5] if len(case) > 5 else 1024), effective_family=eff.value, tile_ms=round(best[0], 5), pass_ms=round(best[1], 5),
                               fin_ms=round(best[2], 5), sync_call_ms=round(wall, 5), error_sync_call_ms=round(err_wall, 5),
                               frac=round(alg / (best[0] * 1e-3) / 8e12, 4), alg_bytes=alg, max_rel_err=max(errs.values()) if errs else None,
                               inliers_ok=(L.num_inliers == Lo.num_inliers) if Lo is not None else None, has_grid=int(lib.gp_voxelmap_has_block_grid(vm._h)),

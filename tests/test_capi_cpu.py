@@ -143,7 +143,7 @@ def test_stream_plan_partitions_every_point_once():
     equal = (C.c_int * 8)(*([1000] * 8))
     skewed = (C.c_int * 8)(1100, 1000, 1000, 1000, 900, 900, 1000, 1100)
     for n in [0, 1, 63, 64, 65, 4097, 65536, 124605, 400000, 999999, 1000000, 1000077, 1310757, 8000000, 33554432 + 17]:
-        for skew in [0, 50, 100, 200, 350, 600]:
+        for skew in [-1, 0, 50, 100, 200, 350, 600]:
             for weights in (equal, None, skewed):
                 G = C.c_int()
                 assert lib.gp_debug_stream_plan(n, skew, weights, 0, None, None, C.byref(G)) == 0
