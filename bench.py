@@ -12,7 +12,7 @@ Inputs (source cloud, voxel map) are resident in HBM before the timed region.  v
 Weak scaling: per-GPU work is fixed as N grows.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (vgicp_pipeline2_kernel): algorithmic bytes (SURVEY.md 8(d):
+  roofline     -- dominant kernel (vgicp_stream_kernel): algorithmic bytes (SURVEY.md 8(d):
                   48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration measured with HIP events on the
                   stream it is launched on; peak 8 TB/s HBM3E.
   cpu_baseline -- the reference's own CPU factor (oracle/_ref/libref.so, kind "reference"; the C restatement, kind "port", when
@@ -46,7 +46,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6
 
 KERNEL_NAMES = {
     12: "vgicp_stream_kernel<linearise, non-temporal source stream, in-argument descriptor> (gp_vgicp_stream.hpp): 1024 workgroups, balanced chunk plan",
-    11: "vgicp_pipeline2_kernel<4 chunks/wave, non-temporal source stream, in-argument descriptor> (gp_vgicp_tile2.hpp)",
     8: "vgicp_pipeline_kernel<look-ahead> (gp_vgicp_tile.hpp)",
     2: "vgicp_pipeline_kernel<hashed line table> (gp_vgicp_tile.hpp)",
 }

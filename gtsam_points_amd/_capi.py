@@ -195,7 +195,7 @@ _SIGNATURES = {
 }
 
 # tuning keys / kernel families of include/gtsam_points_hip.h
-GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM = 0, 2, 3, 8, 11, 12
+GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_STREAM = 0, 2, 3, 8, 12
 GP_TUNE_KERNEL, GP_TUNE_SOURCE_POLICY, GP_TUNE_XCD_CHUNK, GP_TUNE_STAGGER, GP_TUNE_TILE_INTERLEAVE, GP_TUNE_BALANCE, GP_TUNE_EFFECTIVE_KERNEL = 0, 1, 2, 3, 4, 5, 6
 GP_TUNE_TIMING = 7
 GP_TUNE_XCD_WEIGHT_0 = 8
@@ -203,7 +203,7 @@ GP_TUNE_OVERLAP_FINALIZE = 17
 GP_TUNE_TILE_CHUNKS = 18
 GP_TUNE_MAX_WORKGROUPS = 19
 GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32
-KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_GEN2, GP_KERNEL_STREAM]
+KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_STREAM]
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES.keys()) + ["gp_linearized6_to_f32"])
 

@@ -683,7 +683,6 @@ struct gp_vgicp_batch {
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
   bool use_grid = false;  // every factor's map carries an occupancy-block grid (else the hashed line table is used)
-  bool gen2_ok = false;   // ... every map's records fit 32-bit byte offsets and no factor validates surfaces (vgicp_pipeline2_kernel)
   bool stream_once = false;  // no two factors of the batch read the same source cloud (and no sibling batch on this device does: gp_multi.hip
                              // clears shares_device_ok): the source stream may use the non-temporal policy
   bool shares_device_ok = true;
@@ -709,10 +708,9 @@ namespace {
 //   GP_KERNEL_HASHED (2)      round-1/2 pipeline kernel over the hashed line table, f32 outer products: what a map without a block grid runs
 //   GP_KERNEL_GRID_F64 (3)    round-2 pipeline kernel over the block grid, f64 throughout (parity 4e-10 / 1e-15 instead of 6e-9)
 //   GP_KERNEL_LOOKAHEAD (8)   round-2 pipeline kernel, block grid, f32 outer products, look-ahead lookup: what maps with >= 2^26 voxels run
-//   GP_KERNEL_GEN2 (11)       second generation (gp_vgicp_tile2.hpp): fixed tiles of 1024 / 512 / 256 points -- kept for the A/B of round 3
 //   GP_KERNEL_STREAM (12)     third generation (gp_vgicp_stream.hpp): per-wave chunk streams, balanced single-factor launches, surface validation
 //                             in the ring.  Default.
-// A family that does not apply to a batch (no block grid, records beyond 32-bit offsets, surface validation on GEN2) falls back to LOOKAHEAD, and
+// A family that does not apply to a batch (no block grid, records beyond 32-bit offsets) falls back to LOOKAHEAD, and
 // that to HASHED.  Measured and removed (numbers: DESIGN.md section 8 of rounds 1-3): the f64 hashed kernel, the non-lean start, forced 512- / 256-point
 // tiles, the deep pipeline, the source-frame formulation.
 const bool g_zero_copy_poses = [] {  // A/B switch of the pose hand-over of the synchronous batched calls (stage_poses)
@@ -852,11 +850,9 @@ int build_table(gp_vgicp_batch* b) {
   }
   // the family this batch really runs
   int fam = b->tuning.kernel;
-  if ((fam == GP_KERNEL_STREAM || fam == GP_KERNEL_GEN2) && (!b->use_grid || !offsets32)) fam = GP_KERNEL_LOOKAHEAD;
-  if (fam == GP_KERNEL_GEN2 && b->any_sv) fam = GP_KERNEL_LOOKAHEAD;  // (the second generation has no normals row)
+  if (fam == GP_KERNEL_STREAM && (!b->use_grid || !offsets32)) fam = GP_KERNEL_LOOKAHEAD;
   if ((fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_GRID_F64) && !b->use_grid) fam = GP_KERNEL_HASHED;
   b->family = fam;
-  b->gen2_ok = fam == GP_KERNEL_GEN2 || fam == GP_KERNEL_STREAM;
   // tiles
   b->planned = fam == GP_KERNEL_STREAM && F == 1 && descs[0].n >= kPlanMinPoints;
   if (b->planned) {
@@ -874,7 +870,7 @@ int build_table(gp_vgicp_batch* b) {
     descs[0].tile_count = G;
   } else {
     int ppt = kPipelineChunks;  // the hashed-line-table, reference-shaped and f64 kernels exist for 1024-point tiles only
-    if (fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_GEN2 || fam == GP_KERNEL_STREAM) {
+    if (fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_STREAM) {
       // per batch: the largest tile that still fills 3/4 of the chip's resident workgroups, so that a 15 k-point scan is not left to 15 workgroups
       ppt = 1;
       for (int cand : {4, 2}) {
@@ -886,7 +882,15 @@ int build_table(gp_vgicp_batch* b) {
         }
       }
     }
-    if (fam == GP_KERNEL_STREAM && b->tuning.tile_chunks > 0) ppt = b->tuning.tile_chunks;  // (the stream kernel takes tiles of any whole number of chunks)
+    if (fam == GP_KERNEL_STREAM) {
+      // the stream kernel takes tiles of any whole number of chunks: 2048-point tiles (eight chunks per wave: the cold start of the pipeline is paid
+      // half as often) where that still leaves two rounds of workgroups -- C3 56.7 -> 51.3 us, C4 shard 135 -> 115 us, whole C4 1.08 -> 1.00 ms
+      // (profiles/r03_tile_chunks.jsonl; 4096-point tiles: C3 54.7, C4 shard 114)
+      int64_t count8 = 0;
+      for (const auto* f : b->factors) count8 += (f->n + 2047) / 2048;
+      if (count8 >= 2 * kResidentWorkgroups) ppt = 8;
+      if (b->tuning.tile_chunks > 0) ppt = b->tuning.tile_chunks;
+    }
     b->ppt = ppt;
     b->tile_points = 64 * 4 * ppt;
     for (int i = 0; i < F; i++) {
@@ -1024,30 +1028,6 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
     }
 #undef GP_LAUNCH_STREAM_S
 #undef GP_LAUNCH_STREAM
-  } else if (fam == GP_KERNEL_GEN2) {
-#define GP_LAUNCH_PIPE2(PPT, NT, INL, TRACE) hipLaunchKernelGGL((gp::vgicp_pipeline2_kernel<MODE, PPT, NT, INL, TRACE>), GP_ARGS)
-#define GP_LAUNCH_PIPE2_S(PPT, INL)                     \
-  do {                                                  \
-    if (b->nt) GP_LAUNCH_PIPE2(PPT, true, INL, false);  \
-    else GP_LAUNCH_PIPE2(PPT, false, INL, false);       \
-  } while (0)
-    if (b->ppt == 4 && traced) {
-      if constexpr (MODE == gp::MODE_LIN) {
-        if (b->nt) GP_LAUNCH_PIPE2(4, true, true, true);
-        else GP_LAUNCH_PIPE2(4, false, true, true);
-      }
-    } else if (b->ppt == 4) {
-      if (inl.use) GP_LAUNCH_PIPE2_S(4, true);
-      else GP_LAUNCH_PIPE2_S(4, false);
-    } else if (b->ppt == 2) {
-      if (inl.use) GP_LAUNCH_PIPE2_S(2, true);
-      else GP_LAUNCH_PIPE2_S(2, false);
-    } else {
-      if (inl.use) GP_LAUNCH_PIPE2_S(1, true);
-      else GP_LAUNCH_PIPE2_S(1, false);
-    }
-#undef GP_LAUNCH_PIPE2_S
-#undef GP_LAUNCH_PIPE2
   } else {
     // the round-2 family: <MODE, f32 outer products, chunks per wave, block grid, TRACE, lean start, look-ahead lookup>
 #define GP_LAUNCH_PIPE(F32, PPT, GRID, LEAN, AHEAD) hipLaunchKernelGGL((gp::vgicp_pipeline_kernel<MODE, F32, PPT, GRID, false, LEAN, AHEAD>), GP_ARGS)
@@ -1193,9 +1173,8 @@ extern "C" {
 static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
   switch (key) {
     case GP_TUNE_KERNEL:
-      if (value != GP_KERNEL_REFERENCE && value != GP_KERNEL_HASHED && value != GP_KERNEL_GRID_F64 && value != GP_KERNEL_LOOKAHEAD && value != GP_KERNEL_GEN2 &&
-          value != GP_KERNEL_STREAM)
-        return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_KERNEL: one of GP_KERNEL_REFERENCE (0), _HASHED (2), _GRID_F64 (3), _LOOKAHEAD (8), _GEN2 (11), _STREAM (12)");
+      if (value != GP_KERNEL_REFERENCE && value != GP_KERNEL_HASHED && value != GP_KERNEL_GRID_F64 && value != GP_KERNEL_LOOKAHEAD && value != GP_KERNEL_STREAM)
+        return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_KERNEL: one of GP_KERNEL_REFERENCE (0), _HASHED (2), _GRID_F64 (3), _LOOKAHEAD (8), _STREAM (12)");
       t->kernel = value;
       return GP_OK;
     case GP_TUNE_SOURCE_POLICY:

@@ -128,7 +128,7 @@ typedef struct gp_voxelmap gp_voxelmap_t;
  * (fast_floor(x * (1.0/leaf)), gaussian_voxelmap_cpu.cpp:59-61).
  * Deviation: the default (binned) build keeps EVERY voxel -- like the CPU map -- and sizes the reference-visible bucket table by
  * doubling from init_num_buckets until every voxel is inserted within max_bucket_scan_count probes; target_points_drop_rate is
- * honoured only by the reference-shaped hashed build (gp_debug_set_map_build(1) and the fallback for huge bounding boxes), whose
+ * honoured only by the reference-shaped hashed build (gp_voxelmap_set_tuning(GP_TUNE_MAP_BUILD, 1) and the fallback for huge bounding boxes), whose
  * doubling sequence starts at the first size >= N/16, so with a drop rate > 0 num_buckets and the set of dropped points can
  * differ from the reference's. */
 int gp_voxelmap_create(double resolution, int init_num_buckets, int max_bucket_scan_count, double target_points_drop_rate, gp_stream_t stream, gp_voxelmap_t** out);
@@ -427,7 +427,6 @@ int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_
  *   GP_KERNEL_HASHED     pipeline kernel over the hashed line table, f32 outer products: maps without a block grid
  *   GP_KERNEL_GRID_F64   pipeline kernel over the occupancy-block grid, f64 throughout
  *   GP_KERNEL_LOOKAHEAD  round-2 pipeline kernel (block grid, f32 outer products, look-ahead lookup): maps with >= 2^26 voxels
- *   GP_KERNEL_GEN2       second generation (csrc/gp_vgicp_tile2.hpp), fixed 1024 / 512 / 256-point tiles
  *   GP_KERNEL_STREAM     third generation (csrc/gp_vgicp_stream.hpp): per-wave chunk streams, balanced single-factor launches,
  *                        surface validation inside the ring.  Default.
  * Environment switches read once at first use (A/B only): GP_POSES_ZERO_COPY=0 (synchronous batched calls upload poses with
@@ -440,7 +439,6 @@ enum {
   GP_KERNEL_HASHED = 2,
   GP_KERNEL_GRID_F64 = 3,
   GP_KERNEL_LOOKAHEAD = 8,
-  GP_KERNEL_GEN2 = 11,
   GP_KERNEL_STREAM = 12
 };
 enum {

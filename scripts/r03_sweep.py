@@ -4,7 +4,7 @@
     on the C2 workload: tile-kernel time (HIP events, best of 3 x 50 launches), whole device pass, synchronous call, parity vs the oracle
   * per-workgroup timeline of the traced build incl. the hardware placement (HW_ID) of every workgroup and the chunks every CU carried
   * the real kernel on an 8 M-point source (working set > the 256 MiB Infinity Cache)
-Usage: python scripts/r03_sweep.py [cases, e.g. 11:0:1,12:0:1,12:0:0] [--big] [--no-trace]"""
+Usage: python scripts/r03_sweep.py [cases, e.g. 8:0:0,12:0:1,12:0:0] [--big] [--no-trace]"""
 import ctypes as C
 import json
 import os
@@ -23,7 +23,7 @@ from gtsam_points_amd import _capi, synthetic  # noqa: E402
 
 lib = gpa.load()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-cases = [tuple(int(x) for x in c.split(":")) for c in (args[0] if len(args) > 0 else "8:0:0,11:0:0,12:0:0,12:0:100,12:0:200").split(",")]
+cases = [tuple(int(x) for x in c.split(":")) for c in (args[0] if len(args) > 0 else "8:0:0,12:0:0,12:0:100,12:0:200").split(",")]
 BIG = "--big" in sys.argv
 TRACE = "--no-trace" not in sys.argv
 KERNEL, POLICY, BALANCE = 0, 1, 5  # GP_TUNE_*
@@ -185,7 +185,7 @@ om.insert(d["target_points"], d["target_covs"])
 Lo = oracle.OracleVGICPFactor(om, d["source_points"], d["source_covs"], oracle.max_threads()).linearize(delta)
 f, vm, src, tgt = run_case("c2_1M", d, 0.5, delta, Lo)
 if TRACE:
-    for case in [c for c in cases if c[0] in (11, 12)]:
+    for case in [c for c in cases if c[0] == 12]:
         trace_case(f, delta, f"c2_1M family {case[0]} policy {case[1]} balance {case[2]} weights {case[3] if len(case) > 3 else 1}", case)
 
 k = np.load(os.path.join(ROOT, "tests/golden/kitti00_dec8.npz"))

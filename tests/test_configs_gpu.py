@@ -276,7 +276,7 @@ def test_unsymmetrised_covariances(gpu, kitti00):
     om = oracle.OracleVoxelMap(0.5)
     om.insert(kitti00["target_points"], tc)
     Lo = oracle.OracleVGICPFactor(om, kitti00["source_points"], sc, 2).linearize(delta)
-    for variant in [0, 2, 8, 11, 12]:  # GP_KERNEL_*: reference-shaped kernel, hashed pipeline, the round-2 grid kernel, second generation, stream (default)
+    for variant in [0, 2, 8, 12]:  # GP_KERNEL_*: reference-shaped kernel, hashed pipeline, the round-2 grid kernel, stream (default)
         vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
         vm.insert(tgt)
         L = _sync_linearize(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, src).set_tuning(0, variant), delta)

@@ -84,7 +84,7 @@ KERNEL, SOURCE_POLICY = 0, 1  # GP_TUNE_KERNEL, GP_TUNE_SOURCE_POLICY
 
 def _factor(gpu, vm, src, variant=None, policy=None):
     """a factor whose own batch runs kernel family `variant` (GP_KERNEL_*: 0 reference-shaped, 2 hashed line table, 3 block grid f64, 8 look-ahead,
-    11 second generation, 12 stream) with source-stream policy `policy` (0 per batch, 1 default, 2 non-temporal)"""
+    12 stream) with source-stream policy `policy` (0 per batch, 1 default, 2 non-temporal)"""
     f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
     if variant is not None:
         f.set_tuning(KERNEL, variant)
@@ -93,10 +93,10 @@ def _factor(gpu, vm, src, variant=None, policy=None):
     return f
 
 
-@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (8, MIXED_TOL), (11, MIXED_TOL), (12, MIXED_TOL)])
+@pytest.mark.parametrize("variant,tol", [(0, F64_TOL), (2, MIXED_TOL), (3, F64_TOL), (8, MIXED_TOL), (12, MIXED_TOL)])
 def test_every_kernel_variant_matches_the_oracle(gpu, kitti00, variant, tol):
     """GP_TUNE_KERNEL per factor: 0 reference-shaped kernel, 2 pipeline kernel over the hashed line table, 3 / 8 round-2 pipeline kernel over the
-    occupancy-block grid (f64 / f32 outer products + look-ahead), 11 second generation, 12 stream kernel (default) -- linearise and error
+    occupancy-block grid (f64 / f32 outer products + look-ahead), 12 stream kernel (default) -- linearise and error
     evaluation, full tiles, a partial tile and the per-lane tail all go through the selected kernel"""
     _, src, vm = _build(gpu, kitti00, 0.5)
     f = _factor(gpu, vm, src, variant)
@@ -577,13 +577,12 @@ def test_linearity_and_determinism_at_1m(gpu):
     assert L.num_inliers > 0.5 * len(d["source_points"])
 
 
-@pytest.mark.parametrize("variant,policy", [(11, 1), (11, 2), (11, 0), (12, 1), (12, 2), (12, 0)])
+@pytest.mark.parametrize("variant,policy", [(12, 1), (12, 2), (12, 0)])
 @pytest.mark.parametrize("n_src", [400_000, 1_000_077])
-def test_second_and_third_generation_kernels_at_size(gpu, variant, policy, n_src):
-    """vgicp_pipeline2_kernel (gp_vgicp_tile2.hpp, family 11) and vgicp_stream_kernel (gp_vgicp_stream.hpp, family 12, default) with the default /
-    the non-temporal / the per-batch policy on the source stream, at sizes no fixture reaches.  Family 11: 400 k points -> 782 tiles of 512
-    (two chunks per wave), 1,000,077 points -> 977 tiles of 1024 with a partial last tile.  Family 12: one resident round of 1024 workgroups
-    with 6-7 / 13-16 chunks each (one or two per wave; three or four) and 13 points behind the last full chunk for the per-lane tail.
+def test_stream_kernel_at_size(gpu, variant, policy, n_src):
+    """vgicp_stream_kernel (gp_vgicp_stream.hpp, family 12, default) with the default / the non-temporal / the per-batch policy on the source
+    stream, at sizes no fixture reaches: one resident round of 1024 workgroups with 6-7 / 13-16 chunks each (one or two per wave; three or
+    four) and 13 points behind the last full chunk for the per-lane tail.
     Against the oracle, plus bit-reproducibility and agreement with the round-2 kernel far below the parity tolerance."""
     from gtsam_points_amd import synthetic
 
@@ -679,8 +678,8 @@ def test_overlapped_finalize_equals_the_two_kernel_form(gpu):
 @pytest.mark.parametrize("n_src", [64 * 4096 * 5 + 37])
 def test_stream_kernel_beyond_one_round_of_four_chunk_waves(gpu, n_src):
     """1.3 M points: more than 4096 waves x 4 chunks, so the stream kernel keeps ONE resident round (1024 workgroups) and its waves stream 5-6
-    chunks each through the ring (the steady-state step repeated; both ring parities at the end of a stream), where family 11 launches 1281
-    tiles in two rounds.  Both against the oracle and against each other."""
+    chunks each through the ring (the steady-state step repeated; both ring parities at the end of a stream).  The skewed plan, the flat
+    split and the round-2 look-ahead kernel (1281 fixed tiles in two rounds) against the oracle and against each other."""
     from gtsam_points_amd import synthetic
 
     d = synthetic.make_c2_workload(n_src, 500_000, seed=11)
@@ -688,16 +687,16 @@ def test_stream_kernel_beyond_one_round_of_four_chunk_waves(gpu, n_src):
     _, src, vm = _build(gpu, d, 0.5)
     L12 = _sync_linearize(gpu, _factor(gpu, vm, src, 12), delta)
     L12f = _sync_linearize(gpu, _factor(gpu, vm, src, 12).set_tuning(5, 0), delta)  # GP_TUNE_BALANCE = 0: flat split
-    L11 = _sync_linearize(gpu, _factor(gpu, vm, src, 11), delta)
+    L8 = _sync_linearize(gpu, _factor(gpu, vm, src, 8), delta)
     _, fo = _oracle(d, 0.5, oracle.max_threads())
     Lo = fo.linearize(delta)
-    for L, what in [(L12, "stream"), (L12f, "stream, flat split"), (L11, "second generation")]:
+    for L, what in [(L12, "stream"), (L12f, "stream, flat split"), (L8, "look-ahead")]:
         assert_linearized_close(L, Lo, MIXED_TOL, what)
     for k in BLOCKS:
-        assert rel_err(getattr(L12, k), getattr(L11, k)) < 1e-9 and rel_err(getattr(L12, k), getattr(L12f, k)) < 1e-9
+        assert rel_err(getattr(L12, k), getattr(L8, k)) < 1e-9 and rel_err(getattr(L12, k), getattr(L12f, k)) < 1e-9
 
 
-@pytest.mark.parametrize("variant", [0, 8, 11, 12])
+@pytest.mark.parametrize("variant", [0, 8, 12])
 def test_non_finite_source_points_are_skipped(gpu, kitti00, variant):
     """LiDAR clouds carry NaN / inf returns.  A non-finite source point has no voxel: the reference floors it into an undefined integer
     coordinate that no table holds; on the device the conversion of a NaN is 0, i.e. voxel (0, 0, 0) -- which this map contains -- so
