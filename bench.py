@@ -64,6 +64,7 @@ def _load_split():
         with open(path) as f:
             d = json.load(f)
         return dict(in_step_ms=round(d["in_step"]["mean_us"] * 1e-3, 5), all_ms=round(d["all"]["mean_us"] * 1e-3, 5),
+                    fused_in_step_ms=round(d["fused_in_step"]["mean_us"] * 1e-3, 5) if "fused_in_step" in d else None,
                     source="profiles/kernel_trace_split.json (builder-run rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5`); NOT measured in this run")
     except Exception:
         return {}
@@ -445,6 +446,8 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the sharded 4096-factor configuration (BASELINE configs[3])")
     ap.add_argument("--c4-steps", type=int, default=30)
     ap.add_argument("--no-c4-inlib", action="store_true", help="skip the single-process multi-device leg of c4 (run by rank 0 when it sees > 1 device)")
+    ap.add_argument("--finalize", choices=["fused", "two-kernel"], default="fused",
+                    help="synchronous step: fused = the library default (the last tile workgroups finalize, one launch); two-kernel = GP_TUNE_FUSED_FINALIZE 0")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C5 objects (BASELINE configs[0], [2], [4])")
     args = ap.parse_args()
 
@@ -498,6 +501,8 @@ def main():
     arr = (C.c_void_p * 1)(factor._h.value)
     batch = C.c_void_p()
     _capi.check(lib.gp_vgicp_batch_create(arr, 1, C.c_void_p(stream.cuda_stream), C.byref(batch)), "gp_vgicp_batch_create")
+    if args.finalize == "two-kernel":
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_FUSED_FINALIZE, 0), "finalize form")
     delta = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
 
@@ -569,10 +574,13 @@ def main():
         kernel_ms_rocprof_mean=split.get("all_ms"),
         frac_rocprof_mean=round(alg_bytes / (split["all_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if split.get("all_ms") else None,
         kernel_ms_in_step_source=split.get("source"),
-        kernel_ms_note="kernel_ms / frac: measured in THIS run, HIP events over back-to-back launches on the launch stream (the kernel at the device's sustained state); "
-                       "kernel_ms_in_step (the same kernel behind the queue the host leaves idle between two synchronous passes) and kernel_ms_rocprof_mean (all "
-                       "dispatches of the driver's command, both launch patterns) are rocprofv3 per-dispatch durations read from the committed builder-run split "
-                       "(HIP events around a kernel inside a step would add their own markers to it), DESIGN.md section 6",
+        step_finalize=args.finalize if not dist_on else "device-resident records (two kernels)",
+        kernel_ms_note="kernel_ms / frac: measured in THIS run, HIP events over back-to-back launches of the tile kernel on the launch stream (the kernel at the device's "
+                       "sustained state, two-kernel form: the streaming part alone).  kernel_ms_in_step and kernel_ms_rocprof_mean are rocprofv3 per-dispatch durations read "
+                       "from the committed builder-run split of the driver's command with `--finalize two-kernel` (the same kernel behind the queue the host leaves idle "
+                       "between two synchronous passes; all dispatches, both launch patterns).  The default step runs the FUSED form: the same kernel plus the finalize of "
+                       "the last eight workgroups (+2.7 us of kernel, no finalize launch; fused_kernel_ms_in_step), DESIGN.md sections 4.2 and 6",
+        fused_kernel_ms_in_step=split.get("fused_in_step_ms"),
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
     )

@@ -199,7 +199,7 @@ GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, 
 GP_TUNE_KERNEL, GP_TUNE_SOURCE_POLICY, GP_TUNE_XCD_CHUNK, GP_TUNE_STAGGER, GP_TUNE_TILE_INTERLEAVE, GP_TUNE_BALANCE, GP_TUNE_EFFECTIVE_KERNEL = 0, 1, 2, 3, 4, 5, 6
 GP_TUNE_TIMING = 7
 GP_TUNE_XCD_WEIGHT_0 = 8
-GP_TUNE_OVERLAP_FINALIZE = 17
+GP_TUNE_FUSED_FINALIZE = 17
 GP_TUNE_TILE_CHUNKS = 18
 GP_TUNE_MAX_WORKGROUPS = 19
 GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32

@@ -483,79 +483,6 @@ __global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const Fac
   }
 }
 
-// Overlapped finalize of a synchronous single-factor linearise (round 3).  `nparts` workgroups of 256 threads, launched on a SECOND stream right
-// behind the tile kernel: part g waits until arrive[g] has reached `target[g]` -- every tile workgroup of its share has published its partial
-// row write-through and added 1 (vgicp_stream_kernel) -- then sums its rows in the fixed order of vgicp_finalize_rigid_kernel's split form
-// and hands its 32 SUMS to the host (host-mapped record slot + completion word).  What this removes from the step: the kernel boundary behind
-// the tile kernel (end-of-kernel cache flush + dependent dispatch, 1.7-2 us) and the finalize's own start-up; the parts are resident and have
-// their pointers when the last row arrives.  No workgroup of the tile kernel ever waits for this kernel, and the host launches the tile kernel
-// FIRST, so whatever queue the two streams map to there is no deadlock: at worst this kernel starts when the tile kernel has finished.
-// A wait that exceeds ~30 ms (a tile kernel that never ran) stores the failure word kFinalizeTimedOut instead of the sequence number.
-constexpr unsigned long long kFinalizeTimedOut = ~0ull;
-struct ArriveTargets {
-  unsigned long long v[16];
-};
-__global__ void __launch_bounds__(256) vgicp_finalize_overlapped_kernel(const double* __restrict__ partials, const int num_rows, const int rows_per_part,
-                                                                         const unsigned long long* __restrict__ arrive, const ArriveTargets targets,
-                                                                         gp_linearized6* __restrict__ out, const DoneFlags done) {
-  constexpr int kSlices = 8, kWaves = 4;
-  const int part = blockIdx.x;
-  const int row_begin = part * rows_per_part, row_count = min(rows_per_part, num_rows - row_begin);
-  __shared__ double wsum[kWaves][32];
-  __shared__ int ok;
-  if (threadIdx.x == 0) {
-    const unsigned long long want = targets.v[part];
-    int good = 1;
-    unsigned spins = 0;
-    while (__hip_atomic_load(arrive + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > 40000000u / 16u) {  // ~30 ms of polling: the tile kernel is not coming
-        good = 0;
-        break;
-      }
-    }
-    ok = good;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (!ok) {
-    if (threadIdx.x == 0 && done.flags) __hip_atomic_store(done.flags + part, kFinalizeTimedOut, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
-  const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  {
-    // the rows were stored write-through: read them past this CU's L1 (sc1), all of a lane's rows requested in one batch, fixed summation order
-    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(partials + (size_t)row_begin * ACC_STRIDE + comp);
-    double total = 0.0;
-    for (int t0 = slice; t0 < row_count; t0 += 32 * kSlices) {
-      double v[32];
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        const int t = t0 + k * kSlices;
-        v[k] = t < row_count ? __builtin_bit_cast(double, __hip_atomic_load(base + (size_t)t * ACC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-      }
-#pragma unroll
-      for (int w = 16; w > 0; w >>= 1) {
-#pragma unroll
-        for (int k = 0; k < w; k++) v[k] += v[k + w];
-      }
-      total += v[0];
-    }
-    total += __shfl_xor(total, 32, 64);  // the wave's two slices
-    if (lane < 32) wsum[wave][lane] = total;
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  if (lane < 32) {
-    const double s = (wsum[0][lane] + wsum[2][lane]) + (wsum[1][lane] + wsum[3][lane]);  // the order of vgicp_finalize_rigid_kernel<256>: bit-identical records
-    reinterpret_cast<double*>(out + part)[lane] = s;
-  }
-  if (done.flags) {
-    __threadfence_system();
-    if (lane == 0) __hip_atomic_store(done.flags + part, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(const FactorDesc* __restrict__ factors, const double* __restrict__ partials,
                                                                              double* __restrict__ out, int single_tile_count, const DoneFlags done) {
   const int fi = blockIdx.x;
@@ -637,8 +564,9 @@ struct gp_vgicp_tuning {
   bool xcd_weights_set = false;
   int max_wgs = 1024;             // stream family, one large factor: workgroups of the planned launch (<= one resident round of 1024)
   int tile_chunks = 0;            // stream family, batches: 64-point chunks per wave of a tile (tile = 256 x this many points); 0 = the largest of 4 / 2 / 1 that fills 3/4 of the chip
-  int overlap_finalize = 0;       // synchronous single-factor linearise of the stream family: finalize workgroups on a second stream wait for arrival counters
-                                  // (measured: the second stream costs ~10 us per step on this stack, profiles/r03_overlap_finalize.jsonl: off by default)
+  int fused_finalize = 1;       // synchronous single-factor linearise of the stream family: the last tile workgroup of each part sums the part's rows
+                                  // and hands them to the host (InlinePoses: fused finalize) -- no finalize launch.  (The first form of this knob, finalize
+                                  // workgroups on a second stream waiting for the counters, cost +10 us per step: profiles/r03_overlap_finalize.jsonl)
   int balance = kDefaultSkewPermille;  // stream kernel, one large factor: how much more a dispatch round takes than the next, in 1/1000 of the mean share (0 = flat)
 };
 
@@ -672,9 +600,8 @@ struct gp_vgicp_batch {
   bool planned = false;   // stream kernel, one large factor: the tile list is a balanced StreamPlan (else fixed tiles of tile_points)
   gp::StreamPlan plan{};  // ... how the chunks are dealt (also written into the tile table)
   unsigned long long* trace = nullptr;  // timeline build of the tile kernel: [2048][16] uint64 device buffer (gp_vgicp_batch_set_trace_buffer)
-  // overlapped finalize (GP_TUNE_OVERLAP_FINALIZE; synchronous single-factor calls of the stream family)
-  hipStream_t fin_stream = nullptr;       // the finalize workgroups' own stream (created on first use)
-  gp::DeviceArray d_arrive;               // 16 monotonic arrival counters
+  // fused finalize (GP_TUNE_FUSED_FINALIZE; synchronous single-factor calls of the stream family)
+  gp::DeviceArray d_arrive;               // 16 monotonic arrival counters, kArriveStride words apart
   unsigned long long arrived[16] = {0};   // what the counters read once every launch issued so far has finished
   bool timing = false;                  // GP_TUNE_TIMING: the synchronous linearise brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -735,8 +662,6 @@ struct PoseSource {
   const double* d_lin = nullptr;
   const double* d_eval = nullptr;
   gp::InlinePoses inl{};
-  unsigned long long* arrive = nullptr;  // overlapped finalize: the tile workgroups announce their rows here (stream kernel only)
-  int rows_per_part = 1;
 };
 
 // Stream kernel, ONE large factor of n points: the launch geometry (number of workgroups, a multiple of 8) and how the chunks are dealt
@@ -999,8 +924,6 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   inl.tile_points = b->tile_points;
   inl.plan = b->plan;
   inl.trace = b->trace;
-  inl.arrive = ps.arrive;
-  inl.rows_per_part = ps.rows_per_part;
   const bool traced = b->trace != nullptr && inl.use && MODE == gp::MODE_LIN;  // the timeline builds exist for single-factor linearise launches
 #define GP_ARGS grid_dim, block, 0, b->stream, fd, td, b->num_tiles, ps.d_lin, ps.d_eval, inl, partials
   if constexpr (MODE == gp::MODE_LIN_GENERAL) {
@@ -1192,8 +1115,8 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
     case GP_TUNE_TILE_INTERLEAVE:
       t->tile_interleave = value ? 1 : 0;
       return GP_OK;
-    case GP_TUNE_OVERLAP_FINALIZE:
-      t->overlap_finalize = value ? 1 : 0;
+    case GP_TUNE_FUSED_FINALIZE:
+      t->fused_finalize = value ? 1 : 0;
       return GP_OK;
     case GP_TUNE_MAX_WORKGROUPS:
       if (value < 8 || value > 1024) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_MAX_WORKGROUPS: 8 .. 1024");
@@ -1238,7 +1161,7 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
     case GP_TUNE_STAGGER: *value = b->tuning.stagger; return GP_OK;
     case GP_TUNE_TILE_INTERLEAVE: *value = b->tuning.tile_interleave; return GP_OK;
     case GP_TUNE_BALANCE: *value = b->tuning.balance; return GP_OK;
-    case GP_TUNE_OVERLAP_FINALIZE: *value = b->tuning.overlap_finalize; return GP_OK;
+    case GP_TUNE_FUSED_FINALIZE: *value = b->tuning.fused_finalize; return GP_OK;
     case GP_TUNE_TILE_CHUNKS: *value = b->tuning.tile_chunks; return GP_OK;
     case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
     default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
@@ -1457,10 +1380,6 @@ int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch) {
   if (!batch) return GP_OK;
   for (auto& e : batch->ev)
     if (e) (void)hipEventDestroy(e);
-  if (batch->fin_stream) {
-    (void)hipStreamSynchronize(batch->fin_stream);
-    (void)hipStreamDestroy(batch->fin_stream);
-  }
   // the staging buffers are about to be freed: the last H2D copy must have finished.  The stream itself is the caller's and may
   // already be gone (the reference's clone() drops it, integrated_vgicp_factor_gpu.cpp:122-134), so it is not synchronised here.
   if (batch->h2d_done) {
@@ -1579,35 +1498,30 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
   const bool sums_only = parts > 1 && host_expand;
   if (b->timing && !b->ev[0])
     for (auto& e : b->ev) GP_HIP(hipEventCreate(&e));
-  const bool overlapped = sums_only && b->family == GP_KERNEL_STREAM && b->tuning.overlap_finalize && !b->timing && !b->trace && parts <= 16;
-  if (overlapped) {
-    // tile kernel on the batch's stream, the finalize parts on a second stream, waiting for the arrival counters (vgicp_finalize_overlapped_kernel)
-    if (!b->fin_stream) {
-      GP_HIP(hipStreamCreateWithFlags(&b->fin_stream, hipStreamNonBlocking));
-      GP_TRY(b->d_arrive.alloc(sizeof(unsigned long long) * 16));
-      GP_HIP(hipMemset(b->d_arrive.ptr, 0, sizeof(unsigned long long) * 16));
+  const bool fused = sums_only && b->family == GP_KERNEL_STREAM && ps.inl.use && b->tuning.fused_finalize && !b->timing && parts <= 16;
+  if (fused) {
+    // ONE launch: the last workgroup of each part of the tile list finalizes the part (gp_vgicp_stream.hpp: finalize_part_rows)
+    if (!b->d_arrive.ptr) {
+      GP_TRY(b->d_arrive.alloc(sizeof(unsigned long long) * 16 * gp::kArriveStride));
+      GP_HIP(hipMemset(b->d_arrive.ptr, 0, sizeof(unsigned long long) * 16 * gp::kArriveStride));
       memset(b->arrived, 0, sizeof(b->arrived));
     }
     double* partials = nullptr;
     GP_TRY(partials_ptr(b, &partials));
     const int per = (b->num_tiles + parts - 1) / parts;
-    ps.arrive = b->d_arrive.as<unsigned long long>();
-    ps.rows_per_part = per;
-    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));  // FIRST: nothing of it ever waits for the finalize parts
-    gp::ArriveTargets targets{};
+    ps.inl.arrive = b->d_arrive.as<unsigned long long>();
+    ps.inl.rows_per_part = per;
+    ps.inl.num_rows = b->num_tiles;
     for (int g = 0; g < parts; g++) {
       b->arrived[g] += (unsigned long long)std::max(0, std::min(per, b->num_tiles - g * per));
-      targets.v[g] = b->arrived[g];
+      ps.inl.arrive_target[g] = b->arrived[g];
     }
-    hipLaunchKernelGGL(gp::vgicp_finalize_overlapped_kernel, dim3(parts), dim3(256), 0, b->fin_stream, (const double*)partials, b->num_tiles, per,
-                       (const unsigned long long*)b->d_arrive.as<unsigned long long>(), targets, reinterpret_cast<gp_linearized6*>(b->h_out_dev), done);
-    GP_HIP(hipGetLastError());
-    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->fin_stream, spin_budget_us(b)));
-    for (int g = 0; g < parts; g++)
-      if (static_cast<const volatile unsigned long long*>(b->h_done.ptr)[g] != done.seq) {
-        (void)hipStreamSynchronize(b->stream);
-        return gp::fail(GP_ERROR_HIP, "VGICP linearise: the finalize parts gave up waiting for the tile kernel (it did not run to completion)");
-      }
+    ps.inl.fin_out = static_cast<double*>(b->h_out_dev);
+    ps.inl.fin_stride = (int)(sizeof(gp_linearized6) / sizeof(double));
+    ps.inl.fin_flags = done.flags;
+    ps.inl.fin_seq = done.seq;
+    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
   } else {
     GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));

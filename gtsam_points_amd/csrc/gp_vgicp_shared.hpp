@@ -28,6 +28,7 @@ struct FactorDesc {
 // shares the workgroups of a CU end in the order they were placed, ~1 us apart, and the tail of the launch runs on a quarter of the waves
 // (per-workgroup timeline of round 3, profiles/r03_sweep.jsonl).  So the rounds get DIFFERENT shares: workgroups of round r < last take n[r]
 // chunks each (more for the early rounds), the workgroups from `last_begin` on split what is left evenly (`lo`, the first `extra` one more).
+constexpr int kArriveStride = 512;  // 64-bit words between the arrival counters of two parts (fused finalize): 4 KB, another memory channel
 constexpr int kStreamRound = 32;  // workgroups per dispatch round of an XCD = its compute units
 struct StreamPlan {
   int wgs_per_xcd, last_begin;  // workgroups per XCD share; first workgroup of the share's last round (a multiple of 32)
@@ -54,10 +55,17 @@ struct InlinePoses {
                   // tile list is dealt to the XCDs in runs of c tiles (round robin), which evens out what the XCDs have to do
   StreamPlan plan;            // stream kernel, single-factor launches
   unsigned long long* trace;  // timeline build of the tile kernels (per batch: gp_vgicp_batch_set_trace_buffer); null = off
-  // overlapped finalize (synchronous single-factor calls): a workgroup publishes its partial row write-through and adds 1 to
-  // arrive[row / rows_per_part]; the finalize workgroups, launched on a second stream, wait for their counter instead of for the kernel boundary
+  // fused finalize (synchronous single-factor calls; GP_TUNE_FUSED_FINALIZE, on by default): a workgroup publishes its partial row write-through and
+  // adds 1 to arrive[row / rows_per_part]; the workgroup whose add completes a part (arrive_target) sums the part's rows in the fixed order of
+  // the split finalize kernel and hands the 32 sums to the host (fin_out slot + completion word): no second kernel, no kernel boundary
   unsigned long long* arrive;  // null = off
   int rows_per_part;
+  int num_rows;
+  unsigned long long arrive_target[16];  // the counters are monotonic: what arrive[g] reads when this launch's part g is complete
+  double* fin_out;                       // host-mapped records, part g -> fin_out + g * fin_stride
+  unsigned long long* fin_flags;         // host-mapped completion words
+  unsigned long long fin_seq;
+  int fin_stride;                        // doubles between the slots of two parts
   int pad2_;
 };
 

@@ -76,6 +76,46 @@ __host__ __device__ __forceinline__ void plan_tile(const PlanFields& f, int x, i
   *count = n * kChunkPoints + ((x == kNumXCD - 1 && q == f.gx - 1) ? f.tail : 0);  // the very last workgroup also takes the points behind the last full chunk
 }
 
+// The last workgroup of a part (fused finalize, see InlinePoses): all 256 threads sum the part's rows -- every one stored write-through by its
+// workgroup before that workgroup's add to the arrival counter -- in exactly the order of the split form of vgicp_finalize_rigid_kernel<256>
+// (8 slices of rows, pairwise tree over a slice's 32 rows per batch, the wave's two slices, then (w0 + w2) + (w1 + w3)): the records are bit-identical to the two-kernel form
+// (tests/test_vgicp_gpu.py::test_fused_finalize_equals_the_two_kernel_form).  wsum: 4 x 32 doubles of LDS nobody else uses any more.
+__device__ __forceinline__ void finalize_part_rows(const double* __restrict__ partials, const int row_begin, const int row_count, double* wsum, double* out,
+                                                   unsigned long long* flag, const unsigned long long seq, unsigned long long* tr) {
+  constexpr int kSlices = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  // read past this CU's L1 and the XCD's L2 view of other XCDs' lines (sc1), all of a lane's rows requested in one batch
+  const unsigned long long* base = reinterpret_cast<const unsigned long long*>(partials + (size_t)row_begin * ACC_STRIDE + comp);
+  double total = 0.0;
+  for (int t0 = slice; t0 < row_count; t0 += 32 * kSlices) {
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      const int t = t0 + k * kSlices;
+      v[k] = t < row_count ? __builtin_bit_cast(double, __hip_atomic_load(base + (size_t)t * ACC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+    }
+#pragma unroll
+    for (int w = 16; w > 0; w >>= 1) {
+#pragma unroll
+      for (int k = 0; k < w; k++) v[k] += v[k + w];
+    }
+    total += v[0];
+  }
+  total += __shfl_xor(total, 32, 64);  // the wave's two slices
+  if (tr && threadIdx.x == 0) tr[14] = __builtin_amdgcn_s_memrealtime();
+  if (lane < 32) wsum[wave * 32 + lane] = total;
+  __syncthreads();
+  if (wave != 0) return;
+  // the record slot and the completion word are host-mapped (uncached on this side): the sums go out as system-scope stores, the word follows
+  // their acknowledgement -- no cache write-back (`__threadfence_system()` = buffer_wbl2 + buffer_inv costs 3.5 us here and has nothing to write back)
+  const double s = lane < 32 ? (wsum[lane] + wsum[64 + lane]) + (wsum[32 + lane] + wsum[96 + lane]) : 0.0;
+  if (lane < 32) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(out + lane), "v"(s) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(flag), "v"(seq) : "memory");
+  if (tr && lane == 0) tr[15] = __builtin_amdgcn_s_memrealtime();
+}
+
 template <int MODE, bool NT, bool INL, bool SV, bool TRACE = false>
 __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
@@ -398,13 +438,29 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     }
     GP_GLOBAL double* dst = (GP_GLOBAL double*)partials + (size_t)row * ACC_STRIDE + threadIdx.x;
     if (inl.arrive) {
-      // overlapped finalize: the row goes out write-through (sc0 sc1: visible to every XCD once the store is acknowledged, no release fence --
-      // MI355X_MICROARCH.md, inter-workgroup visibility), then ONE relaxed agent-scope add announces it.  Nothing waits here: the finalize
-      // workgroups on the other stream poll the counter; this kernel's duration gains the store acknowledgement of 256 bytes
+      // fused finalize: the row goes out write-through (sc0 sc1: visible to every XCD once the store is acknowledged, no release fence --
+      // MI355X_MICROARCH.md, inter-workgroup visibility), then ONE relaxed agent-scope add announces it
       asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : : "v"(dst), "v"(sum) : "memory");
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(inl.arrive + row / inl.rows_per_part, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       *dst = sum;
+    }
+  }
+  if constexpr (MODE == MODE_LIN && INL) {
+    if (inl.arrive) {  // (kernel argument: uniform over the launch)
+      unsigned long long* tr = nullptr;
+      if constexpr (TRACE) tr = trace ? trace + (size_t)tile_idx * 16 : nullptr;
+      const int part = row / inl.rows_per_part;
+      int* const last = reinterpret_cast<int*>(smem + 4 * kWaveBytes - 32 * 8 - 16);  // below wave 3's sums: nothing lives there any more
+      if (threadIdx.x == 0) {
+        if (tr) tr[12] = __builtin_amdgcn_s_memrealtime();
+        // one counter per part, 4 KB apart: device-scope atomics on ONE line retire at ~12 ns apiece (MI355X_MICROARCH.md, fanin), 1024 of them would be 12 us
+        const unsigned long long seen = __hip_atomic_fetch_add(inl.arrive + (size_t)part * kArriveStride, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last = seen + 1 == inl.arrive_target[part];
+        if (tr) tr[13] = __builtin_amdgcn_s_memrealtime();
+      }
+      __syncthreads();
+      if (*last) finalize_part_rows(partials, part * inl.rows_per_part, min(inl.rows_per_part, inl.num_rows - part * inl.rows_per_part), reinterpret_cast<double*>(smem),
+                                    inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq, tr);
     }
   }
   GP_TRACE(7);

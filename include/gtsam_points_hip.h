@@ -453,9 +453,11 @@ enum {
   GP_TUNE_EFFECTIVE_KERNEL = 6, /* read-only: the family the batch's current table runs (-1 before the first pass) */
   GP_TUNE_XCD_WEIGHT_0 = 8,     /* .. + 7: stream kernel, one large factor: share of XCD x in 1/1000 of the mean share (500..1500); setting any of the eight
                                    replaces the library's measured table (the others then count as 1000) */
-  GP_TUNE_OVERLAP_FINALIZE = 17, /* synchronous single-factor linearise of the stream family: 1 = the finalize workgroups run on a second stream and wait for the
-                                   tile workgroups' arrival counters instead of for the kernel boundary (bit-identical records; measured SLOWER on ROCm 7.2 --
-                                   launching on a second stream costs ~10 us per step -- so the default is 0 = tile kernel, then finalize kernel) */
+  GP_TUNE_FUSED_FINALIZE = 17,  /* synchronous single-factor linearise of the stream family (rigid pose, >= 256 tiles): 1 (default) = fused finalize -- the tile
+                                   workgroup whose arrival completes an eighth of the tile list sums that eighth's rows and hands the sums to the host: one launch,
+                                   no finalize kernel, 1.5-1.8 us off the step (profiles/r03_fused_finalize.jsonl); 0 = tile kernel, then finalize kernel.  The
+                                   records of the two forms are bit-identical.  (Round 3's first form, finalize workgroups on a second stream, cost +10 us per
+                                   step -- the arrival counters shared one line -- and was removed: profiles/r03_overlap_finalize.jsonl) */
   GP_TUNE_TILE_CHUNKS = 18,     /* stream family, fixed-tile launches (batches, small single factors): 64-point chunks per wave of a tile (a tile = 256 x value points);
                                    0 (default) = the largest of 4 / 2 / 1 that still gives >= 768 tiles */
   GP_TUNE_MAX_WORKGROUPS = 19,  /* stream family, one large factor: workgroups of the planned launch, 8 .. 1024 (default 1024 = one resident round) */

@@ -6,10 +6,14 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=$GRAFT_REPO_ROOT/gpurun_out/r03; rm -rf $O; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > $O/device.txt; nproc >> $O/device.txt
-# 1. per-kernel times of the bench command (driver's form: --steps 20 --warmup 5), with the per-dispatch trace for the launch-pattern split
+# 1. per-kernel times of the bench command (driver's form: --steps 20 --warmup 5; the step runs the fused finalize), with the per-dispatch trace for the
+#    launch-pattern split; the same with --finalize two-kernel (the tile kernel alone inside a step)
 rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-configs > $O/rocprof_bench.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv && head -5 $f | cut -c1-200
-t=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python scripts/kernel_trace_split.py "$t" $O/kernel_trace_split.json | tee $O/kernel_trace_split.txt
+tf=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
+rm -rf /tmp/prof2 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-configs --finalize two-kernel > $O/rocprof_bench_two_kernel.log 2>&1
+f=$(find /tmp/prof2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats_two_kernel.csv && head -5 $f | cut -c1-200
+t=$(find /tmp/prof2 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python scripts/kernel_trace_split.py "$t" $O/kernel_trace_split.json "$tf" | tee $O/kernel_trace_split.txt
 # 2. HBM traffic of the tile kernel: FETCH_SIZE / WRITE_SIZE in separate passes, read side calibrated on a known stream
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr

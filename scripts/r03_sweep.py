@@ -41,7 +41,7 @@ def make_batch(f, case):
     _capi.check(lib.gp_vgicp_batch_set_tuning(batch, POLICY, pol), "policy")
     _capi.check(lib.gp_vgicp_batch_set_tuning(batch, BALANCE, bal), "balance")
     if len(case) > 4:
-        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, case[4]), "overlap")  # GP_TUNE_OVERLAP_FINALIZE
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, case[4]), "overlap")  # GP_TUNE_FUSED_FINALIZE
     if len(case) > 5:
         _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 19, case[5]), "max workgroups")  # GP_TUNE_MAX_WORKGROUPS
     wsel = case[3] if len(case) > 3 else 1  # XCD weights: 0 equal shares, 1 the library's table (default), 2.. alternatives

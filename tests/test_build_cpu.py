@@ -50,7 +50,7 @@ def test_stream_kernel_has_no_compiler_vmcnt_waits():
     assert all("vgicp_stream_kernel" in r[0] for r in rows)
     for row in rows:
         name, n, touches = row[0], row[2], row[4]
-        assert int(n) == 0, name
+        assert int(n) == 0, name  # (compiler waits with none of the asm's requests in flight -- the fused finalize tail -- are listed as idle_vmcnt_waits)
         # no instruction outside the asm blocks may read or write the destination registers of an asm-issued load that is still in flight
         # (csrc/count_waits.py): the round-3 memory fault was a phi copy of such registers at a loop back-edge
         assert row[3] == "inflight_reg_touches" and int(touches) == 0, row

@@ -595,7 +595,7 @@ def test_stream_kernel_at_size(gpu, variant, policy, n_src):
     L2 = _sync_linearize(gpu, f, delta)
     for k in BLOCKS:
         assert np.array_equal(getattr(L, k), getattr(L2, k))
-        assert rel_err(getattr(L, k), getattr(L8, k)) < 1e-9, k  # same algorithm, arithmetic differs at the 1e-16 level per point
+        assert rel_err(getattr(L, k), getattr(L8, k)) < 1e-8, k  # same algorithm; the f32 partial sums of a wave are cut differently (plan vs fixed tiles)
     assert L.num_inliers == L8.num_inliers
     _, fo = _oracle(d, 0.5, oracle.max_threads())
     assert_linearized_close(L, fo.linearize(delta), MIXED_TOL, f"variant {variant}, {n_src} points")
@@ -635,10 +635,10 @@ def test_stream_kernel_at_size(gpu, variant, policy, n_src):
     assert abs(e_lin.value - L.error) <= 1e-7 * abs(L.error)  # evaluated at the linearisation pose it is the linearise's own error
 
 
-def test_overlapped_finalize_equals_the_two_kernel_form(gpu):
-    """GP_TUNE_OVERLAP_FINALIZE (opt-in): the finalize parts of a synchronous single-factor linearise run on a second stream and wait for the
-    tile workgroups' arrival counters instead of for the kernel boundary.  Same rows, same summation order: the record must equal the two-kernel
-    form bit for bit, call after call (the counters are monotonic), also when the two forms alternate and when the table is rebuilt in between."""
+def test_fused_finalize_equals_the_two_kernel_form(gpu):
+    """GP_TUNE_FUSED_FINALIZE: the tile workgroup whose arrival completes a part of the tile list sums that part's rows and hands the sums to the
+    host -- one launch, no finalize kernel.  Same rows, same summation order: the record must equal the two-kernel form bit for bit, call after
+    call (the counters are monotonic), also when the two forms alternate and when the table is rebuilt in between."""
     from gtsam_points_amd import synthetic
 
     d = synthetic.make_c2_workload(700_000, 500_000, seed=13)
@@ -655,7 +655,7 @@ def test_overlapped_finalize_equals_the_two_kernel_form(gpu):
     poses = [np.ascontiguousarray((d["T_true"] @ expmap(rng.uniform(-1e-3, 1e-3, 6))).T).reshape(1, 16).copy() for _ in range(6)]
     for rep in range(3):
         for mode in (1, 0, 1):
-            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, mode), "overlap")  # GP_TUNE_OVERLAP_FINALIZE
+            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, mode), "overlap")  # GP_TUNE_FUSED_FINALIZE
             for k, pose in enumerate(poses):
                 gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data), "linearize")
                 recs[mode].append((k, out.copy()))
@@ -670,7 +670,7 @@ def test_overlapped_finalize_equals_the_two_kernel_form(gpu):
     for k, rs in by_pose.items():
         assert len(rs) == 3 and all(np.array_equal(rs[0], r) for r in rs[1:]), k
     _, fo = _oracle(d, 0.5, oracle.max_threads())
-    assert_linearized_close(gpu.LinearizedSystem6.from_doubles(by_pose[0][0][0]), fo.linearize(np.ascontiguousarray(poses[0].reshape(4, 4).T)), MIXED_TOL, "overlapped finalize")
+    assert_linearized_close(gpu.LinearizedSystem6.from_doubles(by_pose[0][0][0]), fo.linearize(np.ascontiguousarray(poses[0].reshape(4, 4).T)), MIXED_TOL, "fused finalize")
     lib.gp_vgicp_batch_destroy(batch)
     lib.gp_stream_destroy(s)
 
