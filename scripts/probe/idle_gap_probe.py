@@ -1,6 +1,6 @@
 """Does the tile kernel run slower when it is launched after an idle gap?  Launches the C2 pass (tile + finalize kernel, asynchronous
 issue + stream sync) with a host-side busy wait of G microseconds between passes; run under rocprofv3 --kernel-trace and feed the CSV to
-the analysis at the bottom of scripts/r02_idle_gap.sh."""
+the analysis at the bottom of scripts/r02/r02_idle_gap.sh."""
 import ctypes as C, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
