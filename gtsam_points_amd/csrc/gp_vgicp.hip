@@ -502,6 +502,15 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(con
   signal_done(done, fi, threadIdx.x == 0);
 }
 
+// split form of the error finalize for a synchronous single-factor evaluation with >= kFinalizeSplitTiles rows: part g sums rows [g * per, ...) and hands its
+// sum to the host, which adds the parts in slot order.  Same code as the fused form runs in the part's last tile workgroup (finalize_part_error).
+__global__ void __launch_bounds__(256) vgicp_finalize_error_parts_kernel(const double* __restrict__ partials, const int num_rows, const int rows_per_part, double* __restrict__ out,
+                                                                         const int out_stride, const DoneFlags done) {
+  __shared__ double wsum[4];
+  const int part = blockIdx.x, row_begin = part * rows_per_part;
+  finalize_part_error(partials, row_begin, min(rows_per_part, num_rows - row_begin), wsum, out + (size_t)part * out_stride, done.flags + part, done.seq);
+}
+
 int wait_done(const unsigned long long* flags_host, size_t count, unsigned long long seq, hipStream_t stream, long spin_us) {
   const volatile unsigned long long* fl = flags_host;
   const auto t0 = std::chrono::steady_clock::now();
@@ -1479,6 +1488,27 @@ static void expand_rigid_host(const double* sum, const double* pose /*col-major 
     }
 }
 
+// fused finalize: arrival counters (monotonic, one per part, kArriveStride words apart) and where the parts' last workgroups deliver
+static int arm_arrival(gp_vgicp_batch_t* b, PoseSource* ps, int parts, int per, const gp::DoneFlags& done) {
+  if (!b->d_arrive.ptr) {
+    GP_TRY(b->d_arrive.alloc(sizeof(unsigned long long) * 16 * gp::kArriveStride));
+    GP_HIP(hipMemset(b->d_arrive.ptr, 0, sizeof(unsigned long long) * 16 * gp::kArriveStride));
+    memset(b->arrived, 0, sizeof(b->arrived));
+  }
+  ps->inl.arrive = b->d_arrive.as<unsigned long long>();
+  ps->inl.rows_per_part = per;
+  ps->inl.num_rows = b->num_tiles;
+  for (int g = 0; g < parts; g++) {
+    b->arrived[g] += (unsigned long long)std::max(0, std::min(per, b->num_tiles - g * per));
+    ps->inl.arrive_target[g] = b->arrived[g];
+  }
+  ps->inl.fin_out = static_cast<double*>(b->h_out_dev);
+  ps->inl.fin_stride = (int)(sizeof(gp_linearized6) / sizeof(double));
+  ps->inl.fin_flags = done.flags;
+  ps->inl.fin_seq = done.seq;
+  return GP_OK;
+}
+
 // synchronous: the finalize kernel stores the records straight into host-mapped pinned memory (no D2H copy op).
 // out_host != nullptr: the records are copied there; view != nullptr: *view points at them where they lie (the batch's own pinned
 // buffer, or `view_store` for the single large factor whose parts the host combines) until the next call on the batch.
@@ -1501,25 +1531,9 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
   const bool fused = sums_only && b->family == GP_KERNEL_STREAM && ps.inl.use && b->tuning.fused_finalize && !b->timing && parts <= 16;
   if (fused) {
     // ONE launch: the last workgroup of each part of the tile list finalizes the part (gp_vgicp_stream.hpp: finalize_part_rows)
-    if (!b->d_arrive.ptr) {
-      GP_TRY(b->d_arrive.alloc(sizeof(unsigned long long) * 16 * gp::kArriveStride));
-      GP_HIP(hipMemset(b->d_arrive.ptr, 0, sizeof(unsigned long long) * 16 * gp::kArriveStride));
-      memset(b->arrived, 0, sizeof(b->arrived));
-    }
     double* partials = nullptr;
     GP_TRY(partials_ptr(b, &partials));
-    const int per = (b->num_tiles + parts - 1) / parts;
-    ps.inl.arrive = b->d_arrive.as<unsigned long long>();
-    ps.inl.rows_per_part = per;
-    ps.inl.num_rows = b->num_tiles;
-    for (int g = 0; g < parts; g++) {
-      b->arrived[g] += (unsigned long long)std::max(0, std::min(per, b->num_tiles - g * per));
-      ps.inl.arrive_target[g] = b->arrived[g];
-    }
-    ps.inl.fin_out = static_cast<double*>(b->h_out_dev);
-    ps.inl.fin_stride = (int)(sizeof(gp_linearized6) / sizeof(double));
-    ps.inl.fin_flags = done.flags;
-    ps.inl.fin_seq = done.seq;
+    GP_TRY(arm_arrival(b, &ps, parts, (b->num_tiles + parts - 1) / parts, done));
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
   } else {
@@ -1601,6 +1615,29 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
   PoseSource ps;
   GP_TRY(stage_poses(b, poses_lin_host, poses_eval_host, &ps, true));
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+  const int parts = (F == 1 && ps.inl.use && b->family == GP_KERNEL_STREAM && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
+  if (parts > 1 && parts <= 16) {
+    // one large factor: eight part sums, added here in slot order -- by the part's last tile workgroup (fused, one launch) or by a second kernel
+    double* partials = nullptr;
+    GP_TRY(partials_ptr(b, &partials));
+    const int per = (b->num_tiles + parts - 1) / parts;
+    constexpr int kSlot = (int)(sizeof(gp_linearized6) / sizeof(double));
+    if (b->tuning.fused_finalize) {
+      GP_TRY(arm_arrival(b, &ps, parts, per, done));
+      GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
+    } else {
+      GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
+      hipLaunchKernelGGL(gp::vgicp_finalize_error_parts_kernel, dim3(parts), dim3(256), 0, b->stream, (const double*)partials, b->num_tiles, per,
+                         static_cast<double*>(b->h_out_dev), kSlot, done);
+      GP_HIP(hipGetLastError());
+    }
+    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+    const double* p = static_cast<const double*>(b->h_out.ptr);
+    double a = p[0];
+    for (int q = 1; q < parts; q++) a += p[(size_t)q * kSlot];
+    out_host[0] = a;
+    return GP_OK;
+  }
   GP_TRY(launch_error(b, ps, reinterpret_cast<double*>(b->h_out_dev), done));
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream, spin_budget_us(b)));
   memcpy(out_host, b->h_out.ptr, sizeof(double) * F);

@@ -116,6 +116,25 @@ __device__ __forceinline__ void finalize_part_rows(const double* __restrict__ pa
   if (tr && lane == 0) tr[15] = __builtin_amdgcn_s_memrealtime();
 }
 
+// The same for an error evaluation: the part's sum of r^T M r (row entry ACC_ERR) in the fixed order thread -> wave tree -> (w0 + w1) + (w2 + w3).
+// Shared by the fused form (the part's last tile workgroup) and by vgicp_finalize_error_parts_kernel (two-kernel form): identical bits.
+__device__ __forceinline__ void finalize_part_error(const double* __restrict__ partials, const int row_begin, const int row_count, double* wsum, double* out,
+                                                    unsigned long long* flag, const unsigned long long seq) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long* base = reinterpret_cast<const unsigned long long*>(partials + (size_t)row_begin * ACC_STRIDE + ACC_ERR);
+  double s = 0.0;
+  for (int t = threadIdx.x; t < row_count; t += 256)
+    s += __builtin_bit_cast(double, __hip_atomic_load(base + (size_t)t * ACC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) wsum[wave] = s;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double total = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : : "v"(out), "v"(total) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(flag), "v"(seq) : "memory");
+}
+
 template <int MODE, bool NT, bool INL, bool SV, bool TRACE = false>
 __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
@@ -445,7 +464,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
       *dst = sum;
     }
   }
-  if constexpr (MODE == MODE_LIN && INL) {
+  if constexpr (INL) {
     if (inl.arrive) {  // (kernel argument: uniform over the launch)
       unsigned long long* tr = nullptr;
       if constexpr (TRACE) tr = trace ? trace + (size_t)tile_idx * 16 : nullptr;
@@ -459,8 +478,13 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
         if (tr) tr[13] = __builtin_amdgcn_s_memrealtime();
       }
       __syncthreads();
-      if (*last) finalize_part_rows(partials, part * inl.rows_per_part, min(inl.rows_per_part, inl.num_rows - part * inl.rows_per_part), reinterpret_cast<double*>(smem),
-                                    inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq, tr);
+      if (*last) {
+        const int row_begin = part * inl.rows_per_part, row_count = min(inl.rows_per_part, inl.num_rows - row_begin);
+        if constexpr (MODE == MODE_ERR)
+          finalize_part_error(partials, row_begin, row_count, reinterpret_cast<double*>(smem), inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq);
+        else
+          finalize_part_rows(partials, row_begin, row_count, reinterpret_cast<double*>(smem), inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq, tr);
+      }
     }
   }
   GP_TRACE(7);

@@ -44,10 +44,17 @@ for name, n_src in [("c2_1M", 1_000_000), ("c2_300k", 300_000), ("c2_4M", 4_000_
             t0 = time.perf_counter_ns()
             lib.gp_vgicp_batch_linearize(batch, pose.ctypes.data, out.ctypes.data)
             ts[i] = time.perf_counter_ns() - t0
+        te = np.empty(steps)
+        e = C.c_double()
+        for i in range(steps):
+            t0 = time.perf_counter_ns()
+            lib.gp_vgicp_batch_compute_error(batch, pose.ctypes.data, pose.ctypes.data, C.byref(e))
+            te[i] = time.perf_counter_ns() - t0
         records.setdefault(mode, out.copy())
         same = bool(np.array_equal(records[mode], out) and np.array_equal(records[0], out))
         print(json.dumps(dict(case=name, fused=mode, steps=steps, call_us_median=round(float(np.median(ts)) / 1e3, 2), call_us_mean=round(float(ts.mean()) / 1e3, 2),
-                              call_us_p90=round(float(np.percentile(ts, 90)) / 1e3, 2), record_equals_two_kernel_form=same)), flush=True)
+                              call_us_p90=round(float(np.percentile(ts, 90)) / 1e3, 2), error_call_us_median=round(float(np.median(te)) / 1e3, 2), error=e.value,
+                              record_equals_two_kernel_form=same)), flush=True)
     lib.gp_vgicp_batch_destroy(batch)
     lib.gp_stream_destroy(s)
 

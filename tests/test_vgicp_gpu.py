@@ -671,6 +671,19 @@ def test_fused_finalize_equals_the_two_kernel_form(gpu):
         assert len(rs) == 3 and all(np.array_equal(rs[0], r) for r in rs[1:]), k
     _, fo = _oracle(d, 0.5, oracle.max_threads())
     assert_linearized_close(gpu.LinearizedSystem6.from_doubles(by_pose[0][0][0]), fo.linearize(np.ascontiguousarray(poses[0].reshape(4, 4).T)), MIXED_TOL, "fused finalize")
+    # the error evaluation has the same two forms (eight part sums, by the parts' last tile workgroups or by a second kernel): same bits, call after call
+    errs = {0: [], 1: []}
+    e = C.c_double()
+    for mode in (1, 0, 1, 0):
+        gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, mode), "fused")
+        for k in range(1, 4):
+            gpu._capi.check(lib.gp_vgicp_batch_compute_error(batch, poses[0].ctypes.data, poses[k].ctypes.data, C.byref(e)), "compute_error")
+            errs[mode].append(e.value)
+    assert errs[0] == errs[1] and errs[0][:3] == errs[0][3:]
+    fo.linearize(np.ascontiguousarray(poses[0].reshape(4, 4).T))
+    for k in range(1, 4):
+        eo = fo.error(np.ascontiguousarray(poses[k].reshape(4, 4).T))
+        assert abs(errs[1][k - 1] - eo) <= MIXED_TOL * abs(eo)
     lib.gp_vgicp_batch_destroy(batch)
     lib.gp_stream_destroy(s)
 
