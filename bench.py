@@ -6,15 +6,19 @@
 
 Workload (config.workload): BASELINE.json configs[1] -- ONE VGICP factor per GPU, 1 M synthetic source points vs a
 2 M-point GaussianVoxelMap at 0.5 m (gtsam_points_amd.synthetic.make_c2_workload; rank r uses seed 42 + r).
-A "step" is one linearize() pass as the optimizer sees it: pose upload (128 B) -> tiled HIP kernel -> finalize kernel
--> [N > 1: RCCL all-reduce of the stacked [N x 122] f64 record buffer over xGMI] -> D2H of the stacked records -> sync.
+A "step" is one linearize() pass as the optimizer sees it.  N = 1: gp_vgicp_batch_linearize -- the pose rides in the kernel arguments, ONE launch (the
+tile kernel's last workgroups finalize, --finalize two-kernel for tile kernel + finalize kernel), records into host memory, the host polls completion
+words.  N > 1: pose -> tile kernel -> finalize kernel -> RCCL all-reduce of the stacked [N x 122] f64 record buffer over xGMI -> D2H -> sync.
 Inputs (source cloud, voxel map) are resident in HBM before the timed region.  value = N * 1e6 * K / elapsed.
 Weak scaling: per-GPU work is fixed as N grows.
 
 Extra objects on the JSON line:
   roofline     -- dominant kernel (vgicp_stream_kernel): algorithmic bytes (SURVEY.md 8(d):
-                  48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration measured with HIP events on the
-                  stream it is launched on; peak 8 TB/s HBM3E.
+                  48 N_src + 16 N_buckets + 52 N_voxels + 560) / its mean duration AS THE TIMED STEPS RAN IT: the fused kernel stamps
+                  its own start, last partial row and hand-over on the device's 100 MHz clock (kernel_ms = streaming part, fused_kernel_ms =
+                  with the finalize tail).  Beside it: the same kernel back to back under HIP events on its launch stream
+                  (kernel_ms_back_to_back: the device's sustained state) and the committed rocprofv3 per-dispatch figures of the driver's
+                  command (rocprof_*).  Peak 8 TB/s HBM3E.
   cpu_baseline -- the reference's own CPU factor (oracle/_ref/libref.so, kind "reference"; the C restatement, kind "port", when
                   that library is absent) timed on this box's cores on the same workload, rank 0 / N=1 only.
   c4           -- BASELINE configs[3] next to the headline: the 4096-factor graph (512 submaps x 32768 points, 8 factors per
@@ -65,7 +69,8 @@ def _load_split():
             d = json.load(f)
         return dict(in_step_ms=round(d["in_step"]["mean_us"] * 1e-3, 5), all_ms=round(d["all"]["mean_us"] * 1e-3, 5),
                     fused_in_step_ms=round(d["fused_in_step"]["mean_us"] * 1e-3, 5) if "fused_in_step" in d else None,
-                    source="profiles/kernel_trace_split.json (builder-run rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5`); NOT measured in this run")
+                    source="profiles/kernel_trace_split.json: builder-run rocprofv3 --kernel-trace per-dispatch durations of `bench.py --steps 20 --warmup 5` (fused) and of the same "
+                           "with --finalize two-kernel (in step / mean); NOT measured in this run -- the cross-check of kernel_ms")
     except Exception:
         return {}
 
@@ -540,11 +545,14 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    dev_steps, dev_stream_us, dev_kernel_us = C.c_double(), C.c_double(), C.c_double()
+    lib.gp_vgicp_batch_device_times(batch, 1, None, None, None)  # reset: the kernel's own time stamps of the timed steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    lib.gp_vgicp_batch_device_times(batch, 0, C.byref(dev_steps), C.byref(dev_stream_us), C.byref(dev_kernel_us))
     if dist_on:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -552,12 +560,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.source_points * args.steps / elapsed
 
-    # ---- dominant-kernel roofline: HIP events on the launch stream ----
+    # ---- dominant-kernel roofline ----
+    # (1) as the timed steps ran it: the fused kernel stamps its own start / last row in / sums out on the device's 100 MHz clock (gp_vgicp_batch_device_times)
+    # (2) back to back: HIP events on the launch stream over a loop of tile-kernel launches (two-kernel form: the streaming part alone)
     ms_total, ms_main, ms_fin = C.c_float(), C.c_float(), C.c_float()
     _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pose.ctypes.data, args.kernel_iters, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
     alg_bytes = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
-    achieved = alg_bytes / (ms_main.value * 1e-3) / 1e9
+    in_step = dev_steps.value >= args.steps and dev_stream_us.value > 0
+    kernel_ms = dev_stream_us.value * 1e-3 if in_step else ms_main.value
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     split = _load_split()
+
+    def _frac(ms):
+        return round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms else None
+
     roofline = dict(
         bound="hbm",
         kernel=KERNEL_NAMES.get(_effective_kernel(lib, batch), "?"),
@@ -568,19 +584,22 @@ def main():
         traffic=_load_traffic()[0],
         traffic_source=_load_traffic()[1],
         algorithmic_bytes=alg_bytes,
-        kernel_ms=round(ms_main.value, 5),
-        kernel_ms_in_step=split.get("in_step_ms"),
-        frac_in_step=round(alg_bytes / (split["in_step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if split.get("in_step_ms") else None,
-        kernel_ms_rocprof_mean=split.get("all_ms"),
-        frac_rocprof_mean=round(alg_bytes / (split["all_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if split.get("all_ms") else None,
-        kernel_ms_in_step_source=split.get("source"),
+        kernel_ms=round(kernel_ms, 5),
+        kernel_ms_source=(f"measured in THIS run inside the {args.steps} timed steps: the streaming part of the fused kernel (first workgroup started .. last partial row in) on the "
+                          "device's 100 MHz constant clock, stamped by the kernel itself (gp_vgicp_batch_device_times); mean over the steps") if in_step
+        else "measured in THIS run: HIP events over back-to-back tile-kernel launches on the launch stream (no fused steps in this configuration)",
+        fused_kernel_ms=round(dev_kernel_us.value * 1e-3, 5) if in_step else None,
+        fused_kernel_note="first workgroup started .. last part's sums on their way to the host: the streaming part + the finalize tail of the last eight workgroups" if in_step else None,
+        kernel_ms_back_to_back=round(ms_main.value, 5),
+        frac_back_to_back=_frac(ms_main.value),
+        kernel_ms_back_to_back_source="HIP events on the launch stream over back-to-back launches of the tile kernel (two-kernel form), this run: the kernel at the device's sustained state",
+        rocprof_kernel_ms_in_step=split.get("in_step_ms"),
+        rocprof_frac_in_step=_frac(split.get("in_step_ms")),
+        rocprof_kernel_ms_mean=split.get("all_ms"),
+        rocprof_frac_mean=_frac(split.get("all_ms")),
+        rocprof_fused_kernel_ms_in_step=split.get("fused_in_step_ms"),
+        rocprof_source=split.get("source"),
         step_finalize=args.finalize if not dist_on else "device-resident records (two kernels)",
-        kernel_ms_note="kernel_ms / frac: measured in THIS run, HIP events over back-to-back launches of the tile kernel on the launch stream (the kernel at the device's "
-                       "sustained state, two-kernel form: the streaming part alone).  kernel_ms_in_step and kernel_ms_rocprof_mean are rocprofv3 per-dispatch durations read "
-                       "from the committed builder-run split of the driver's command with `--finalize two-kernel` (the same kernel behind the queue the host leaves idle "
-                       "between two synchronous passes; all dispatches, both launch patterns).  The default step runs the FUSED form: the same kernel plus the finalize of "
-                       "the last eight workgroups (+2.7 us of kernel, no finalize launch; fused_kernel_ms_in_step), DESIGN.md sections 4.2 and 6",
-        fused_kernel_ms_in_step=split.get("fused_in_step_ms"),
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
     )

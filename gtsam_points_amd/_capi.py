@@ -185,6 +185,7 @@ _SIGNATURES = {
     "gp_vgicp_batch_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gp_vgicp_batch_get_tuning": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gp_vgicp_batch_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gp_vgicp_batch_device_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gp_vgicp_factor_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gp_voxelmap_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gp_vgicp_batch_set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -615,6 +615,8 @@ struct gp_vgicp_batch {
   bool timing = false;                  // GP_TUNE_TIMING: the synchronous linearise brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_tile_ms = 0.f, last_finalize_ms = 0.f;
+  // fused steps: the kernel's own 100 MHz time stamps (gp_vgicp_batch_device_times)
+  double dev_steps = 0.0, dev_stream_ticks = 0.0, dev_kernel_ticks = 0.0;
   int tile_points = 0;
   int64_t total_points = 0;
   gp::DeviceArray d_factors, d_tiles, d_partials, d_poses;  // d_poses: [2][F][16] (lin, eval)
@@ -1378,6 +1380,15 @@ void batch_set_sources_shared(gp_vgicp_batch* batch, bool shared) {
 }
 
 // measurement: durations of the tile kernel and the finalize kernel of the last synchronous linearise (GP_TUNE_TIMING = 1), HIP events on the batch's stream
+int gp_vgicp_batch_device_times(gp_vgicp_batch_t* batch, int reset, double* steps, double* stream_us_mean, double* kernel_us_mean) {
+  if (!batch) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_device_times: null batch");
+  if (steps) *steps = batch->dev_steps;
+  if (stream_us_mean) *stream_us_mean = batch->dev_steps > 0 ? batch->dev_stream_ticks / batch->dev_steps / 100.0 : 0.0;
+  if (kernel_us_mean) *kernel_us_mean = batch->dev_steps > 0 ? batch->dev_kernel_ticks / batch->dev_steps / 100.0 : 0.0;
+  if (reset) batch->dev_steps = batch->dev_stream_ticks = batch->dev_kernel_ticks = 0.0;
+  return GP_OK;
+}
+
 int gp_vgicp_batch_last_kernel_ms(const gp_vgicp_batch_t* batch, float* tile_ms, float* finalize_ms) {
   if (!batch) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_last_kernel_ms: null batch");
   if (tile_ms) *tile_ms = batch->last_tile_ms;
@@ -1536,6 +1547,22 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
     GP_TRY(arm_arrival(b, &ps, parts, (b->num_tiles + parts - 1) / parts, done));
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+    {
+      // the step as the device saw it: first workgroup started .. last row in .. last sums out (words 34 / 32 / 33 of the parts' slots)
+      const unsigned long long* w = static_cast<const unsigned long long*>(b->h_out.ptr);
+      constexpr size_t N = sizeof(gp_linearized6) / sizeof(double);
+      unsigned long long t0 = ~0ull, t_rows = 0, t_out = 0;
+      for (int g = 0; g < parts; g++) {
+        if (g < gp::kNumXCD) t0 = std::min(t0, w[g * N + 34]);
+        t_rows = std::max(t_rows, w[g * N + 32]);
+        t_out = std::max(t_out, w[g * N + 33]);
+      }
+      if (t0 <= t_rows && t_rows <= t_out && t_out - t0 < 100000000ull) {
+        b->dev_steps += 1.0;
+        b->dev_stream_ticks += (double)(t_rows - t0);
+        b->dev_kernel_ticks += (double)(t_out - t0);
+      }
+    }
   } else {
     GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));

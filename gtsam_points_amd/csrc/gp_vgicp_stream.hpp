@@ -81,7 +81,7 @@ __host__ __device__ __forceinline__ void plan_tile(const PlanFields& f, int x, i
 // (8 slices of rows, pairwise tree over a slice's 32 rows per batch, the wave's two slices, then (w0 + w2) + (w1 + w3)): the records are bit-identical to the two-kernel form
 // (tests/test_vgicp_gpu.py::test_fused_finalize_equals_the_two_kernel_form).  wsum: 4 x 32 doubles of LDS nobody else uses any more.
 __device__ __forceinline__ void finalize_part_rows(const double* __restrict__ partials, const int row_begin, const int row_count, double* wsum, double* out,
-                                                   unsigned long long* flag, const unsigned long long seq, unsigned long long* tr) {
+                                                   unsigned long long* flag, const unsigned long long seq, unsigned long long* tr, const unsigned long long t_rows) {
   constexpr int kSlices = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -109,8 +109,10 @@ __device__ __forceinline__ void finalize_part_rows(const double* __restrict__ pa
   if (wave != 0) return;
   // the record slot and the completion word are host-mapped (uncached on this side): the sums go out as system-scope stores, the word follows
   // their acknowledgement -- no cache write-back (`__threadfence_system()` = buffer_wbl2 + buffer_inv costs 3.5 us here and has nothing to write back)
-  const double s = lane < 32 ? (wsum[lane] + wsum[64 + lane]) + (wsum[32 + lane] + wsum[96 + lane]) : 0.0;
-  if (lane < 32) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(out + lane), "v"(s) : "memory");
+  double s = lane < 32 ? (wsum[lane] + wsum[64 + lane]) + (wsum[32 + lane] + wsum[96 + lane]) : 0.0;
+  if (lane == 32) s = __builtin_bit_cast(double, t_rows);                           // time stamps ride in the same store: when the part's last row was in,
+  if (lane == 33) s = __builtin_bit_cast(double, __builtin_amdgcn_s_memrealtime());  // and when its sums leave
+  if (lane < 34) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(out + lane), "v"(s) : "memory");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(flag), "v"(seq) : "memory");
   if (tr && lane == 0) tr[15] = __builtin_amdgcn_s_memrealtime();
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   constexpr int kWaveBytes = SV ? 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + 2 * kCovSlotBytes : kWaveLdsBytes;  // 10 KB with normals, else 8.5 KB
   static_assert(kWaveBytes >= kWaveLdsBytes, "the reduction needs 8.5 KB of the wave's region");
   __shared__ __attribute__((aligned(16))) char smem[4 * kWaveBytes];
+  const unsigned long long t_begin = INL ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz constant clock; used by the fused form's own time stamps (below)
   // ---- what the first source request needs, in as few dependent scalar-load round trips as possible.  The in-argument form reads every field
   // it may need -- the plan's entries for this workgroup included -- up front and pins them with an empty asm: left alone, hipcc sinks those loads
   // into the branches of the tile arithmetic (five dependent s_load / s_waitcnt rounds in front of the first DMA, 1.26 us from workgroup start
@@ -198,6 +201,13 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   }
   unsigned long long* trace = TRACE ? inl.trace : nullptr;
   GP_TRACE(0);
+  if constexpr (INL && MODE == MODE_LIN) {
+    // fused form: the first workgroup of every XCD leaves its start time in the part's host slot (word 34), fire and forget; the parts' finalizers add when
+    // their last row was in (32) and when their sums left (33).  The host turns the three into the duration of the streaming part and of the
+    // whole kernel as THIS step ran it (gp_vgicp_batch_device_times): the step's own clock, no events, no profiler
+    if (inl.arrive && blockIdx.x < kNumXCD && threadIdx.x == 0)
+      asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(inl.fin_out + (size_t)blockIdx.x * inl.fin_stride + 34), "v"(t_begin) : "memory");
+  }
   if constexpr (TRACE) {
     if (trace && threadIdx.x == 0) {
       trace[(size_t)tile_idx * 16 + 10] = __builtin_amdgcn_s_memrealtime();
@@ -476,6 +486,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
         const unsigned long long seen = __hip_atomic_fetch_add(inl.arrive + (size_t)part * kArriveStride, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *last = seen + 1 == inl.arrive_target[part];
         if (tr) tr[13] = __builtin_amdgcn_s_memrealtime();
+        if (*last) *reinterpret_cast<unsigned long long*>(last + 2) = __builtin_amdgcn_s_memrealtime();
       }
       __syncthreads();
       if (*last) {
@@ -483,7 +494,8 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
         if constexpr (MODE == MODE_ERR)
           finalize_part_error(partials, row_begin, row_count, reinterpret_cast<double*>(smem), inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq);
         else
-          finalize_part_rows(partials, row_begin, row_count, reinterpret_cast<double*>(smem), inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq, tr);
+          finalize_part_rows(partials, row_begin, row_count, reinterpret_cast<double*>(smem), inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq, tr,
+                             *reinterpret_cast<const unsigned long long*>(last + 2));
       }
     }
   }

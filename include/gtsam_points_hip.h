@@ -474,6 +474,11 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* batch, int key, int* value
 /* with GP_TUNE_TIMING = 1: the durations of the tile kernel and of the finalize kernel of the last synchronous gp_vgicp_batch_linearize[_view],
  * i.e. of the kernels as they run INSIDE a step (behind the idle queue the host leaves between two passes), HIP events on the batch's stream */
 int gp_vgicp_batch_last_kernel_ms(const gp_vgicp_batch_t* batch, float* tile_ms, float* finalize_ms);
+/* fused synchronous single-factor linearise steps (GP_TUNE_FUSED_FINALIZE = 1) time themselves on the device's 100 MHz constant clock: the first workgroup of
+ * every XCD stores its start, every part's finalizer when the part's last partial row was in and when its sums left for the host.  Since the last reset:
+ * number of such steps, mean duration of the streaming part (first start .. last row in: what the roofline fraction is quoted on, as the step ran it) and
+ * of the whole kernel's work (.. last sums out), in microseconds.  No events, no profiler, nothing added to the step but three 8-byte stores per part. */
+int gp_vgicp_batch_device_times(gp_vgicp_batch_t* batch, int reset, double* steps, double* stream_us_mean, double* kernel_us_mean);
 /* the per-factor entry points (gp_vgicp_factor_linearize, ..._issue_*) run a batch of one: this is its tuning */
 int gp_vgicp_factor_set_tuning(gp_vgicp_factor_t* factor, int key, int value);
 int gp_voxelmap_set_tuning(gp_voxelmap_t* map, int key, int value);

@@ -671,6 +671,12 @@ def test_fused_finalize_equals_the_two_kernel_form(gpu):
         assert len(rs) == 3 and all(np.array_equal(rs[0], r) for r in rs[1:]), k
     _, fo = _oracle(d, 0.5, oracle.max_threads())
     assert_linearized_close(gpu.LinearizedSystem6.from_doubles(by_pose[0][0][0]), fo.linearize(np.ascontiguousarray(poses[0].reshape(4, 4).T)), MIXED_TOL, "fused finalize")
+    # the fused steps time themselves on the device clock: 3 reps x 2 fused blocks x 6 poses since the batch was created
+    n, stream_us, kernel_us = C.c_double(), C.c_double(), C.c_double()
+    gpu._capi.check(lib.gp_vgicp_batch_device_times(batch, 1, C.byref(n), C.byref(stream_us), C.byref(kernel_us)), "device_times")
+    assert n.value == 36 and 3.0 < stream_us.value < 200.0 and stream_us.value < kernel_us.value < stream_us.value + 20.0, (n.value, stream_us.value, kernel_us.value)
+    gpu._capi.check(lib.gp_vgicp_batch_device_times(batch, 0, C.byref(n), None, None), "device_times")
+    assert n.value == 0
     # the error evaluation has the same two forms (eight part sums, by the parts' last tile workgroups or by a second kernel): same bits, call after call
     errs = {0: [], 1: []}
     e = C.c_double()
