@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) grid_scatter_kernel(const float* __restri
 }
 
 // ---- exact k-NN -------------------------------------------------------------------------------------------------
-template <int KMAX>
+template <int KMAX, bool FULL = false>  // FULL: the list always holds exactly KMAX neighbours (k == KMAX): straight-line insertion only
 struct TopK {
   // d / idx are only ever indexed with compile-time constants (unrolled loops + predicates): a run-time index such as d[k - 1]
   // would send both arrays to scratch memory (160 B per lane for KMAX = 10) and turn every comparison into a memory access
@@ -210,6 +210,38 @@ struct TopK {
   // KnnResult::push (ann/knn_result.hpp:89-109): strict '<', earlier-visited ties win
   __device__ void push(int index, double dist) {
     if (!(dist < bound)) return;
+    if constexpr (FULL) {
+      // full list (the common case: covariance estimation asks for exactly KMAX): straight-line code.  c[j] = dist < d[j] is monotone in j (the list is
+      // sorted), the new entry j is d[j-1] where c[j-1], the candidate where c[j] alone, d[j] otherwise -- for the distances that is
+      // max(d[j-1], min(dist, d[j])), for the indices two selects on the same masks: 10 compares + 20 min/max + 20 selects, no exec-mask regions
+      // (the position-by-position form below compiles to ten of them plus a scalar branch tree for the bound: ~70 vector and ~80 scalar / branch
+      // instructions per insertion, executed by the whole wave whenever one lane inserts)
+      bool c[KMAX];
+#pragma unroll
+      for (int j = 0; j < KMAX; j++) c[j] = dist < d[j];
+      // (v_min_f64 / v_max_f64 through asm: fmin / fmax make hipcc quiet every operand first -- `v_max_f64 x, x, x`, eleven more f64 instructions per
+      // insertion -- and no operand here is a NaN: squared distances of finite points and the finite sentinel of init())
+      auto min64 = [](double a, double b) {
+        double r;
+        asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+      };
+      auto max64 = [](double a, double b) {
+        double r;
+        asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+      };
+#pragma unroll
+      for (int j = KMAX - 1; j >= 1; j--) {
+        idx[j] = c[j - 1] ? idx[j - 1] : (c[j] ? index : idx[j]);
+        d[j] = max64(d[j - 1], min64(dist, d[j]));
+      }
+      idx[0] = c[0] ? index : idx[0];
+      d[0] = min64(dist, d[0]);
+      bound = d[KMAX - 1];
+      found = found + 1 < KMAX ? found + 1 : KMAX;
+      return;
+    }
     bool placed = false;
 #pragma unroll
     for (int j = KMAX - 1; j >= 0; j--) {
@@ -231,6 +263,11 @@ struct TopK {
   }
 };
 
+// f32 filter bound for "exact squared distance < worst": the f32 differences are off by <= m per axis, so the f32 squared distance is at most
+// worst (1 + 1e-6) + 4 sqrt(worst) m + 4 m^2, and 4 sqrt(w) m <= w / 1024 + 4096 m^2 (AM-GM) spares the square root -- it sat behind every insertion
+// with its IEEE refinement, ~20 instructions; the filter admits candidates within 0.1 % of the bound instead, the f64 comparison decides as before
+__device__ __forceinline__ float loosened_bound(double worst, float m2x4100) { return (float)worst * 1.000978f + m2x4100; }
+
 // LiDAR density varies by three orders of magnitude between the near and the far field, so one cell size cannot be right
 // everywhere: the structure keeps up to kMaxLevels grids (cell size x4 per level) and every query runs the same exact
 // search on the finest level whose 3x3x3 neighbourhood already holds enough points.  Exactness does not depend on the choice.
@@ -240,8 +277,8 @@ struct MultiGridView {
   int num_levels;
 };
 
-template <int KMAX>
-__device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top);
+template <int KMAX, bool FULL>
+__device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top);
 
 __device__ __forceinline__ int count27(const GridView& g, double qx, double qy, double qz) {
   const int cx = hashed_cell(qx * g.inv_h), cy = hashed_cell(qy * g.inv_h), cz = hashed_cell(qz * g.inv_h);
@@ -255,8 +292,8 @@ __device__ __forceinline__ int count27(const GridView& g, double qx, double qy, 
   return c;
 }
 
-template <int KMAX>
-__device__ __forceinline__ void knn_query_multi(const MultiGridView& mg, double qx, double qy, double qz, int want, TopK<KMAX>& top) {
+template <int KMAX, bool FULL>
+__device__ __forceinline__ void knn_query_multi(const MultiGridView& mg, double qx, double qy, double qz, int want, TopK<KMAX, FULL>& top) {
   int level = mg.num_levels - 1;
   for (int l = 0; l + 1 < mg.num_levels; l++) {
     if (count27(mg.lv[l], qx, qy, qz) >= want) {
@@ -264,11 +301,11 @@ __device__ __forceinline__ void knn_query_multi(const MultiGridView& mg, double 
       break;
     }
   }
-  knn_query<KMAX>(mg.lv[level], qx, qy, qz, top);
+  knn_query<KMAX, FULL>(mg.lv[level], qx, qy, qz, top);
 }
 
-template <int KMAX>
-__device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
+template <int KMAX, bool FULL>
+__device__ __forceinline__ void knn_query(const GridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top) {
   if (!(fabs(qx) < 1.0e300 && fabs(qy) < 1.0e300 && fabs(qz) < 1.0e300)) return;  // non-finite query: no neighbours
   const int cx = hashed_cell(qx * g.inv_h), cy = hashed_cell(qy * g.inv_h), cz = hashed_cell(qz * g.inv_h);
   // distance from the query to the nearest face of its own cell
@@ -333,8 +370,8 @@ __device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my
 
 // max_shells: how many shells beyond the first one that reaches the box this call may walk before it gives up (returns false: the
 // caller retries on a coarser level); returns true when the search is complete (bound met, or every point seen)
-template <int KMAX>
-__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top, int max_shells) {
+template <int KMAX, bool FULL>
+__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top, int max_shells) {
   const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
   if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;  // non-finite query: no neighbours
   const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
@@ -351,10 +388,8 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
   const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
   // |f32 difference - exact difference| <= margin per axis (rounding of q to float + the subtraction), generously
   const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;
-  auto loosened = [&](double worst) {
-    const float w = (float)worst;  // +inf while fewer than k neighbours are held and no distance bound was given
-    return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
-  };
+  const float m2x4100 = 4100.0f * margin * margin;
+  auto loosened = [&](double worst) { return loosened_bound(worst, m2x4100); };  // (+inf while fewer than k neighbours are held and no distance bound was given)
   float accept = loosened(top.worst());
   unsigned n_f32 = 0, n_f64 = 0, n_blk = 0, n_cell = 0;  // work counters: only read when g.counters is set (measurement runs)
   // candidates of one cell: the loads of four consecutive points are issued together (a lane's loads miss L1 more often than not, and
@@ -450,8 +485,8 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
 // 27 of shells 0 + 1.  The 8 block entries are requested together, then the 8 cell ranges, then the points four at a time: three
 // dependent round trips in front of the point scan instead of one per block, cell and point.  Returns true when the bound is met;
 // otherwise the caller walks the shells with the list as it stands (a point pushed twice cannot displace itself in a 1-NN list).
-template <int KMAX>
-__device__ __forceinline__ bool knn_query_octant(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top) {
+template <int KMAX, bool FULL>
+__device__ __forceinline__ bool knn_query_octant(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top) {
   static_assert(KMAX == 1, "duplicates are harmless only in a 1-NN list");
   const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
   if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;  // non-finite query: no neighbours
@@ -466,10 +501,8 @@ __device__ __forceinline__ bool knn_query_octant(const BinGridView& g, double qx
   }
   const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
   const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;  // as in knn_query_bins
-  auto loosened = [&](double worst) {
-    const float w = (float)worst;
-    return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
-  };
+  const float m2x4100 = 4100.0f * margin * margin;
+  auto loosened = [&](double worst) { return loosened_bound(worst, m2x4100); };
   float accept = loosened(top.worst());
   unsigned n_f32 = 0, n_f64 = 0, n_cell = 0;
   int4 e[8];
@@ -534,8 +567,8 @@ __device__ __forceinline__ bool knn_query_octant(const BinGridView& g, double qx
 // of shells' worth of empty space in a few dozen 8-byte loads this way.  Entries of an x-row are contiguous in memory and are
 // requested four at a time: one round trip per (mostly empty) entry was what these walks cost.
 // Returns true when the search is complete (bound met, every point seen, or the box exhausted), false after max_shells + 1 shells.
-template <int KMAX, bool SUPER>
-__device__ __forceinline__ bool knn_query_coarse(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX>& top, int max_shells) {
+template <int KMAX, bool SUPER, bool FULL>
+__device__ __forceinline__ bool knn_query_coarse(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top, int max_shells) {
   const double unit = (SUPER ? 16.0 : 4.0) * g.h, inv_unit = (SUPER ? 0.0625 : 0.25) * g.inv_h;
   // SUPER coordinates are relative to the grid's first block (the grid origin is not a multiple of four blocks)
   const double ux = qx * inv_unit - (SUPER ? 0.25 * (double)g.geom.lo[0] : 0.0), uy = qy * inv_unit - (SUPER ? 0.25 * (double)g.geom.lo[1] : 0.0),
@@ -555,10 +588,8 @@ __device__ __forceinline__ bool knn_query_coarse(const BinGridView& g, double qx
   const int dimx = SUPER ? g.sdim[0] : g.geom.dim[0], dimy = SUPER ? g.sdim[1] : g.geom.dim[1];
   const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
   const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;  // as in knn_query_bins
-  auto loosened = [&](double worst) {
-    const float w = (float)worst;
-    return w * 1.000001f + 4.0f * sqrtf(w) * margin + 4.0f * margin * margin;
-  };
+  const float m2x4100 = 4100.0f * margin * margin;
+  auto loosened = [&](double worst) { return loosened_bound(worst, m2x4100); };
   float accept = loosened(top.worst());
   unsigned n_f32 = 0, n_f64 = 0, n_blk = 0;
   auto test_point = [&](const float4 v) {
@@ -668,24 +699,24 @@ struct SearchView {
 
 // stage 0: cell shells 0 .. 4 (occupied cells only: work-efficient while the neighbourhood is a few cells wide); stage 1: superblock
 // shells -- blocks as cells, those beyond the current k-th distance skipped -- until the bound is met or the box is exhausted
-template <int KMAX>
-__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX>& top, bool skip_fine = false) {
+template <int KMAX, bool FULL = false>
+__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX, FULL>& top, bool skip_fine = false) {
   if (g.binned) {
     const int k = top.k;
     const double bound = top.worst();  // the caller's max_sq_dist (nothing has been pushed yet)
     // (skip_fine: the row-tiled pass has scanned the shells 0 and 1 of the finest level, which therefore cannot settle the query; the
     // walk still starts there -- the list is not carried over -- but goes on to shell 4 at once)
     if constexpr (KMAX == 1) {
-      if (knn_query_octant<KMAX>(g.bins[0], qx, qy, qz, top)) return;
+      if (knn_query_octant<KMAX, FULL>(g.bins[0], qx, qy, qz, top)) return;
     }
     for (int l = 0; l < g.binned; l++) {
       if (l > 0) top.init(k, bound);
-      if (knn_query_bins<KMAX>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : 4)) return;
+      if (knn_query_bins<KMAX, FULL>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : 4)) return;
     }
     top.init(k, bound);
-    knn_query_coarse<KMAX, true>(g.bins[g.binned - 1], qx, qy, qz, top, 0x3fffffff);
+    knn_query_coarse<KMAX, true, FULL>(g.bins[g.binned - 1], qx, qy, qz, top, 0x3fffffff);
   } else {
-    knn_query_multi<KMAX>(g.hashed, qx, qy, qz, want, top);
+    knn_query_multi<KMAX, FULL>(g.hashed, qx, qy, qz, want, top);
   }
 }
 
@@ -845,8 +876,8 @@ __device__ __forceinline__ void inverse3_general(const double* a /*col-major*/, 
 // estimate_covariances (features/covariance_estimation.cpp:18-77): k-NN (query included) -> sample covariance ->
 // V diag(1e-3, 1, 1) V^-1.  Fewer than k neighbours -> identity (:27-31).
 // sample covariance of the k neighbours -> V diag(1e-3, 1, 1) V^-1 (features/covariance_estimation.cpp:33-53)
-template <int KMAX>
-__device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX>& top, const float* __restrict__ points, int k, float* __restrict__ out) {
+template <int KMAX, bool FULL>
+__device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX, FULL>& top, const float* __restrict__ points, int k, float* __restrict__ out) {
   double sp[3] = {0, 0, 0}, spp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < KMAX; j++)
@@ -874,7 +905,9 @@ __device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX>& top
 
 // estimate_covariances, per-lane search (every query walks its own shells; see knn_query_bins / knn_query): the general path, and
 // the second pass of the tiled kernel below for the queries it left over (todo_list != nullptr: the *todo_count positions listed)
-template <int KMAX, int MIN_WAVES = 1>  // MIN_WAVES = 4 (k <= 10): registers capped at 128 (7 of 137 spilled) for four waves per SIMD instead of three: 1.41 -> 1.28 ms per 1 M points
+// MIN_WAVES = 4 (k <= 10): registers capped at 128 for four waves per SIMD instead of three: 1.41 -> 1.28 ms per 1 M points (round 2).
+// FULL: k == KMAX, the list is always full: straight-line insertion (TopK<KMAX, true>)
+template <int KMAX, int MIN_WAVES = 1, bool FULL = false>
 __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
                                                          int* __restrict__ num_short, const int* __restrict__ todo_list, const int* __restrict__ todo_count) {
   int t = blockIdx.x * 128 + threadIdx.x;
@@ -888,16 +921,16 @@ __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g
   const float4 self = g.binned ? g.bins[0].sorted[t] : g.hashed.lv[0].sorted[t];
   const int i = __float_as_int(self.w);
   const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
-  TopK<KMAX> top;
+  TopK<KMAX, FULL> top;
   top.init(k, 1.7976931348623157e308);
-  knn_query_any<KMAX>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr);
+  knn_query_any<KMAX, FULL>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr);
   float* out = covs + 9 * (size_t)i;
   if (top.found < k) {
     atomicAdd(num_short, 1);
     for (int j = 0; j < 9; j++) out[j] = (j % 4 == 0) ? 1.0f : 0.0f;
     return;
   }
-  covariance_from_neighbours<KMAX>(top, points, k, out);
+  covariance_from_neighbours<KMAX, FULL>(top, points, k, out);
 }
 
 // estimate_covariances, tiled: ONE WAVE PER OCCUPIED CELL ROW (the <= 4 x-adjacent cells of one (y, z) row of a block).  The queries
@@ -1625,7 +1658,10 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
     }
     if (nq > 0 && rc == GP_OK) {
       static const int cov_waves = [] { const char* e = getenv("GP_COV_WAVES"); return e ? atoi(e) : 4; }();  // A/B: 3 = uncapped registers
-      if (k <= 10 && cov_waves == 4)
+      static const bool cov_full = [] { const char* e = getenv("GP_COV_FULL"); return !e || atoi(e) != 0; }();  // A/B: 0 = the position-by-position insertion for k = 10 as well
+      if (k == 10 && cov_waves == 4 && cov_full)
+        hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
+      else if (k <= 10 && cov_waves == 4)
         hipLaunchKernelGGL((gp::covariance_kernel<10, 4>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
       else if (k <= 10)
         hipLaunchKernelGGL((gp::covariance_kernel<10, 1>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
