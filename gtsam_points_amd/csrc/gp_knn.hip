@@ -1659,7 +1659,7 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
     if (nq > 0 && rc == GP_OK) {
       static const int cov_waves = [] { const char* e = getenv("GP_COV_WAVES"); return e ? atoi(e) : 4; }();  // A/B: 3 = uncapped registers
       static const bool cov_full = [] { const char* e = getenv("GP_COV_FULL"); return !e || atoi(e) != 0; }();  // A/B: 0 = the position-by-position insertion for k = 10 as well
-      if (k == 10 && cov_waves == 4 && cov_full)
+      if (k == 10 && cov_waves == 4 && cov_full)  // (capped at 96 registers for five waves per SIMD: 41 spilled, 1.08 vs 1.07 ms -- no gain)
         hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
       else if (k <= 10 && cov_waves == 4)
         hipLaunchKernelGGL((gp::covariance_kernel<10, 4>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
