@@ -41,6 +41,7 @@ struct SparseSymbolic {
   std::vector<int> rowidx;         // [nnzL] row (elimination index) of every block
   std::vector<int> upd_ptr;        // [nnzL + 1] -> upd_a / upd_b: block (i, k) -= L[upd_a] * L[upd_b]^T, in ascending source column
   std::vector<int> upd_a, upd_b;
+  std::vector<int> upd_bpos;       // position of block upd_b[u] in the row list of its row k (row_ptr[k] + upd_bpos[u] -> row_blk): the separator kernel stages row k in LDS
   std::vector<int> row_ptr;        // [P + 1] -> row_blk / row_col: the blocks L_kj (j < k) of row k and their columns, ascending j
   std::vector<int> row_blk, row_col;
   std::vector<int> work_ptr, work_cols;  // work lists: [num_subtrees] subtrees, then the CHAINS of the top part (separator columns), grouped by level
@@ -264,6 +265,7 @@ static int sparse_symbolic_with(int num_slots, const int* factor_slots, int num_
   for (int k = 0; k < P; k++) S.row_ptr[k + 1] += S.row_ptr[k];
   S.upd_a.resize(S.upd_ptr[nnzL]);
   S.upd_b.resize(S.upd_ptr[nnzL]);
+  S.upd_bpos.resize(S.upd_ptr[nnzL]);
   S.row_blk.resize(S.row_ptr[P]);
   S.row_col.resize(S.row_ptr[P]);
   {
@@ -276,6 +278,7 @@ static int sparse_symbolic_with(int num_slots, const int* factor_slots, int num_
         for (size_t p = q; p < col[j].size(); p++) {
           const int d = find_block(col[j][p], k);
           S.upd_a[ucur[d]] = S.colptr[j] + 1 + (int)p;
+          S.upd_bpos[ucur[d]] = rcur[k] - 1 - S.row_ptr[k];
           S.upd_b[ucur[d]++] = bkj;
         }
       }
@@ -467,6 +470,7 @@ struct SparseView {
   const int* upd_ptr;
   const int* upd_a;
   const int* upd_b;
+  const int* upd_bpos;
   const int* row_ptr;
   const int* row_blk;
   const int* row_col;
@@ -605,6 +609,198 @@ __global__ void __launch_bounds__(THREADS) sparse_factor_kernel(SparseView S, in
     if (t < 36) S.L[36 * (size_t)base + t] = (t % 6) >= (t / 6) ? D[t % 6][t / 6] : 0.0;
     if (t >= 64 && t < 70) S.y[6 * (size_t)k + (t - 64)] = rhs[t - 64];
     // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row): forward substitution along the row
+    for (int e = t; e < 6 * (nb - 1); e += THREADS) {
+      double* Bk = S.L + 36 * (size_t)(base + 1 + e / 6);
+      const int r = e % 6;
+      double o[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = Bk[r + 6 * c];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+          if (q < c) s -= o[q] * D[c][q];
+        o[c] = s / D[c][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
+    }
+    __syncthreads();  // the next column of this list reads these blocks (same compute unit: global writes are visible after the barrier)
+  }
+  if (t == 0 && bad) atomicOr(S.status, 1);
+}
+
+// The same for the chains of SEPARATOR columns (levels > 0): columns of 40-70 blocks whose entries each collect ~100 block products.  In the kernel above
+// every entry of a block walks its product list by itself -- 12 loads per product and entry (a 6-row of A, a 6-row of B), four products per dependent round
+// trip -- and a 512-pose band graph spent ~20 us per such column, 60 columns one after the other (profiles/r03_solver_time.txt).  Here:
+//   * the B operands of a column k are the blocks L_kj of ROW k, the same for every block of the column: they are staged once in LDS (with y_j for the forward
+//     substitution), and a product names its B by position in that row (upd_bpos);
+//   * one thread owns a ROW of a block (six entries): 6 global loads per product instead of 72 per block-entry set, 36 fma against LDS operands;
+//   * the product list of a block row is cut into G contiguous slices (G = what fits the workgroup, <= 8), whose partial sums meet in LDS in slice order:
+//     a row's chain of dependent round trips is 1 / G as long.  Fixed order => bit-reproducible; the rounding differs from the one-at-a-time order of the kernel
+//     above at the 1e-16 level.
+// Columns whose row list exceeds kStageBlocks take the per-entry gather of the kernel above (same results as there).
+constexpr int kStageBlocks = 128;
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) sparse_factor_staged_kernel(SparseView S, int first_list) {
+  __shared__ double Bs[kStageBlocks][36];  // L_kj, j = row list of the column being factored
+  __shared__ double ys[kStageBlocks][6];   // y_j
+  __shared__ double part[THREADS][6];      // slice partials: [row item * G + slice][c]
+  __shared__ double rpart[16][6];
+  __shared__ double D[6][7];
+  __shared__ double rhs[6];
+  __shared__ int bad;
+  const int list = first_list + blockIdx.x;
+  const int t = threadIdx.x;
+  if (t == 0) bad = 0;
+  for (int w = S.work_ptr[list]; w < S.work_ptr[list + 1]; w++) {
+    const int k = S.work_cols[w];
+    const int base = S.colptr[k], nb = S.colptr[k + 1] - base;
+    const int rb = S.row_ptr[k], nrow = S.row_ptr[k + 1] - rb;
+    const bool staged = nrow <= kStageBlocks;
+    if (staged) {
+      for (int e = t; e < 36 * nrow; e += THREADS) Bs[e / 36][e % 36] = S.L[36 * (size_t)S.row_blk[rb + e / 36] + (e % 36)];
+      for (int e = t; e < 6 * nrow; e += THREADS) ys[e / 6][e % 6] = S.y[6 * (size_t)S.row_col[rb + e / 6] + (e % 6)];
+      __syncthreads();
+      // 1. gather, one thread per (block row, slice)
+      const int R = 6 * nb;
+      int G = THREADS / R;
+      G = G < 1 ? 1 : (G > 8 ? 8 : G);
+      for (int item = t; item < R * G; item += THREADS) {  // (one pass unless the column has more than THREADS / 6 blocks)
+        const int ri = item / G, g = item % G;
+        const int d = base + ri / 6, r = ri % 6;
+        const int ub = S.upd_ptr[d], len = S.upd_ptr[d + 1] - ub;
+        const int per = (len + G - 1) / G;
+        int u = ub + g * per;
+        const int ue = min(ub + len, u + per);
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        constexpr int kBatch = 4;
+        for (; u < ue; u += kBatch) {
+          int ia[kBatch], bp[kBatch];
+#pragma unroll
+          for (int q = 0; q < kBatch; q++) {
+            const int uu = u + q < ue ? u + q : ue - 1;
+            ia[q] = S.upd_a[uu];
+            bp[q] = S.upd_bpos[uu];
+          }
+          double av[kBatch][6];
+#pragma unroll
+          for (int q = 0; q < kBatch; q++) {
+            const double* A = S.L + 36 * (size_t)ia[q] + r;
+#pragma unroll
+            for (int m = 0; m < 6; m++) av[q][m] = A[6 * m];
+          }
+#pragma unroll
+          for (int q = 0; q < kBatch; q++)
+            if (u + q < ue) {
+              const double* B = Bs[bp[q]];
+#pragma unroll
+              for (int m = 0; m < 6; m++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[c] -= av[q][m] * B[c + 6 * m];
+            }
+        }
+        if (G == 1 && R <= THREADS) {
+          // no slices to meet: the row goes to its place at once
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            const double v = S.L[36 * (size_t)d + r + 6 * c] + acc[c];
+            if (d == base) D[r][c] = v;
+            else S.L[36 * (size_t)d + r + 6 * c] = v;
+          }
+        } else if (R * G <= THREADS) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) part[item][c] = acc[c];
+        } else {
+          // more rows than threads (G == 1, several passes): straight to memory as well
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            const double v = S.L[36 * (size_t)d + r + 6 * c] + acc[c];
+            if (d == base) D[r][c] = v;
+            else S.L[36 * (size_t)d + r + 6 * c] = v;
+          }
+        }
+      }
+      // right-hand side of the forward substitution: b_k - sum_j L_kj y_j, sixteen slices of the row list
+      if (t < 96) {
+        const int r = t % 6, g = t / 6;
+        const int per = (nrow + 15) / 16;
+        double a = 0.0;
+        for (int j = g * per; j < min(nrow, (g + 1) * per); j++)
+#pragma unroll
+          for (int m = 0; m < 6; m++) a -= Bs[j][r + 6 * m] * ys[j][m];
+        rpart[g][r] = a;
+      }
+      __syncthreads();
+      if (G > 1 && R * G <= THREADS) {
+        for (int e = t; e < 6 * R; e += THREADS) {
+          const int ri = e / 6, c = e % 6;
+          const int d = base + ri / 6, r = ri % 6;
+          double v = S.L[36 * (size_t)d + r + 6 * c];
+          for (int g = 0; g < G; g++) v += part[ri * G + g][c];
+          if (d == base) D[r][c] = v;
+          else S.L[36 * (size_t)d + r + 6 * c] = v;
+        }
+      }
+      if (t < 6) {
+        double a = S.y[6 * (size_t)k + t];
+        for (int g = 0; g < 16; g++) a += rpart[g][t];
+        rhs[t] = a;
+      }
+    } else {
+      // row list too long for the stage: per-entry gather, as in sparse_factor_kernel
+      for (int e = t; e < 36 * nb; e += THREADS) {
+        const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
+        double acc = S.L[36 * (size_t)d + (e % 36)];
+        for (int u = S.upd_ptr[d]; u < S.upd_ptr[d + 1]; u++) {
+          const double* A = S.L + 36 * (size_t)S.upd_a[u];
+          const double* B = S.L + 36 * (size_t)S.upd_b[u];
+#pragma unroll
+          for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * B[c + 6 * q];
+        }
+        if (d == base) D[r][c] = acc;
+        else S.L[36 * (size_t)d + (e % 36)] = acc;
+      }
+      if (t >= 64 && t < 70) {
+        const int r = t - 64;
+        double acc = S.y[6 * (size_t)k + r];
+        for (int u = rb; u < rb + nrow; u++) {
+          const double* A = S.L + 36 * (size_t)S.row_blk[u];
+          const double* yj = S.y + 6 * (size_t)S.row_col[u];
+#pragma unroll
+          for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * yj[q];
+        }
+        rhs[r] = acc;
+      }
+    }
+    __syncthreads();
+    // 2. the diagonal block: 6x6 Cholesky by the first wave (lane = (row, column)), then y_k = L_kk^-1 rhs
+    if (t < 64) {
+      const int r = t % 6, c = t / 6;
+      for (int j = 0; j < 6; j++) {
+        double piv = D[j][j];
+        if (!(piv > 0.0)) {
+          if (t == 0) bad = 1;
+          piv = 1.0;
+        }
+        const double l = sqrt(piv);
+        GP_WAVE_SYNC_LDS();
+        if (t < 36 && c == j && r >= j) D[r][j] = r == j ? l : D[r][j] / l;
+        GP_WAVE_SYNC_LDS();
+        if (t < 36 && c > j && r >= c) D[r][c] -= D[r][j] * D[c][j];
+        GP_WAVE_SYNC_LDS();
+      }
+      if (t == 0) {
+        for (int i = 0; i < 6; i++) {
+          double s = rhs[i];
+          for (int q = 0; q < i; q++) s -= D[i][q] * rhs[q];
+          rhs[i] = s / D[i][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (t < 36) S.L[36 * (size_t)base + t] = (t % 6) >= (t / 6) ? D[t % 6][t / 6] : 0.0;
+    if (t >= 64 && t < 70) S.y[6 * (size_t)k + (t - 64)] = rhs[t - 64];
+    // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row)
     for (int e = t; e < 6 * (nb - 1); e += THREADS) {
       double* Bk = S.L + 36 * (size_t)(base + 1 + e / 6);
       const int r = e % 6;
@@ -775,13 +971,13 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     s->dests.push_back(d);
   }
   // one device arena for all index arrays
-  const std::vector<int>* arrs[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols, &S.perm};
+  const std::vector<int>* arrs[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols, &S.perm, &S.upd_bpos};
   size_t total = 0;
   for (const auto* a : arrs) total += a->size() + 1;
   std::vector<int> packed;
   packed.reserve(total);
-  size_t offs[11];
-  for (int i = 0; i < 11; i++) {
+  size_t offs[12];
+  for (int i = 0; i < 12; i++) {
     offs[i] = packed.size();
     packed.insert(packed.end(), arrs[i]->begin(), arrs[i]->end());
     packed.push_back(0);
@@ -807,6 +1003,7 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
   s->view.work_ptr = base + offs[8];
   s->view.work_cols = base + offs[9];
   s->d_perm = base + offs[10];
+  s->view.upd_bpos = base + offs[11];
   s->view.L = s->L.as<double>();
   s->view.y = s->y.as<double>();
   s->view.x = s->x.as<double>();
@@ -910,7 +1107,11 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
     // band graph (profiles/r03_solver_time.txt): this form 1.34 ms; 512 threads + batches of eight products 1.45-1.48 ms with or without the next
     // batch's indices prefetched; 1024 threads + batches of eight 2.8 ms (the 128-register cap spills the batch)
     if (count > 0 && l == 0) hipLaunchKernelGGL(gp::sparse_factor_kernel<256>, dim3(count), dim3(256), 0, s->stream, s->view, first);
-    if (count > 0 && l > 0) hipLaunchKernelGGL(gp::sparse_factor_kernel<1024>, dim3(count), dim3(1024), 0, s->stream, s->view, first);
+    if (count > 0 && l > 0) {
+      static const bool staged = [] { const char* e = getenv("GP_SPARSE_STAGED"); return !e || atoi(e) != 0; }();  // A/B: 0 = the per-entry gather for the chains as well
+      if (staged) hipLaunchKernelGGL(gp::sparse_factor_staged_kernel<1024>, dim3(count), dim3(1024), 0, s->stream, s->view, first);
+      else hipLaunchKernelGGL(gp::sparse_factor_kernel<1024>, dim3(count), dim3(1024), 0, s->stream, s->view, first);
+    }
   }
   for (int l = levels - 1; l >= 0; l--) {
     const int first = S.level_ptr[l], count = S.level_ptr[l + 1] - first;
