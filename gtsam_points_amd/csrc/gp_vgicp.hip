@@ -1158,6 +1158,10 @@ int gp_vgicp_batch_set_tuning(gp_vgicp_batch_t* b, int key, int value) {
     b->timing = value != 0;
     return GP_OK;
   }
+  if (key == GP_TUNE_TEST_ARRIVAL_SKEW) {  // test hook: the host's idea of arrival counter 0 runs `value` ahead of the device's, as after a launch that was lost
+    b->arrived[0] += (unsigned long long)(value > 0 ? value : 0);
+    return GP_OK;
+  }
   GP_TRY(apply_tuning(&b->tuning, key, value));
   b->table_dirty = true;
   return GP_OK;
@@ -1509,14 +1513,31 @@ static int arm_arrival(gp_vgicp_batch_t* b, PoseSource* ps, int parts, int per, 
   ps->inl.arrive = b->d_arrive.as<unsigned long long>();
   ps->inl.rows_per_part = per;
   ps->inl.num_rows = b->num_tiles;
-  for (int g = 0; g < parts; g++) {
-    b->arrived[g] += (unsigned long long)std::max(0, std::min(per, b->num_tiles - g * per));
-    ps->inl.arrive_target[g] = b->arrived[g];
-  }
+  for (int g = 0; g < parts; g++)  // (committed to b->arrived by fused_launched() once the launch has gone out)
+    ps->inl.arrive_target[g] = b->arrived[g] + (unsigned long long)std::max(0, std::min(per, b->num_tiles - g * per));
   ps->inl.fin_out = static_cast<double*>(b->h_out_dev);
   ps->inl.fin_stride = (int)(sizeof(gp_linearized6) / sizeof(double));
   ps->inl.fin_flags = done.flags;
   ps->inl.fin_seq = done.seq;
+  return GP_OK;
+}
+
+static void fused_launched(gp_vgicp_batch_t* b, const PoseSource& ps, int parts) {
+  for (int g = 0; g < parts; g++) b->arrived[g] = ps.inl.arrive_target[g];
+}
+// did every part's completion word arrive?  (after wait_done, which hands over to hipStreamSynchronize when its spin budget is used up: in the two-kernel
+// form a finished stream means finished records, in the fused form the records exist only if the parts' last workgroups saw their counters complete)
+static bool words_arrived(const gp_vgicp_batch_t* b, int count, unsigned long long seq) {
+  const volatile unsigned long long* fl = static_cast<const volatile unsigned long long*>(b->h_done.ptr);
+  for (int g = 0; g < count; g++)
+    if (fl[g] != seq) return false;
+  return true;
+}
+// the arrival counters and the host's idea of them have come apart (a launch that failed half way, a kernel that was torn down): start over from zero
+static int reset_arrival(gp_vgicp_batch_t* b) {
+  GP_HIP(hipStreamSynchronize(b->stream));
+  if (b->d_arrive.ptr) GP_HIP(hipMemset(b->d_arrive.ptr, 0, sizeof(unsigned long long) * 16 * gp::kArriveStride));
+  memset(b->arrived, 0, sizeof(b->arrived));
   return GP_OK;
 }
 
@@ -1546,8 +1567,16 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
     GP_TRY(partials_ptr(b, &partials));
     GP_TRY(arm_arrival(b, &ps, parts, (b->num_tiles + parts - 1) / parts, done));
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+    fused_launched(b, ps, parts);
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
-    {
+    if (!words_arrived(b, parts, done.seq)) {
+      // the stream is idle and the words are not there: the counters were out of step.  The rows are complete (the kernel has finished): reset the
+      // counters and let the finalize kernel do this call's sums
+      GP_TRY(reset_arrival(b));
+      const gp::DoneFlags again{done.flags, ++b->seq, nullptr};
+      GP_TRY(launch_finalize<false>(b, ps, partials, reinterpret_cast<gp_linearized6*>(b->h_out_dev), again, -parts));
+      GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, again.seq, b->stream, spin_budget_us(b)));
+    } else {
       // the step as the device saw it: first workgroup started .. last row in .. last sums out (words 34 / 32 / 33 of the parts' slots)
       const unsigned long long* w = static_cast<const unsigned long long*>(b->h_out.ptr);
       constexpr size_t N = sizeof(gp_linearized6) / sizeof(double);
@@ -1649,16 +1678,25 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
     GP_TRY(partials_ptr(b, &partials));
     const int per = (b->num_tiles + parts - 1) / parts;
     constexpr int kSlot = (int)(sizeof(gp_linearized6) / sizeof(double));
-    if (b->tuning.fused_finalize) {
+    bool fused = b->tuning.fused_finalize != 0;
+    if (fused) {
       GP_TRY(arm_arrival(b, &ps, parts, per, done));
       GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
-    } else {
-      GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
-      hipLaunchKernelGGL(gp::vgicp_finalize_error_parts_kernel, dim3(parts), dim3(256), 0, b->stream, (const double*)partials, b->num_tiles, per,
-                         static_cast<double*>(b->h_out_dev), kSlot, done);
-      GP_HIP(hipGetLastError());
+      fused_launched(b, ps, parts);
+      GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+      if (!words_arrived(b, parts, done.seq)) {  // (see batch_linearize_sync)
+        GP_TRY(reset_arrival(b));
+        fused = false;
+      }
     }
-    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
+    if (!fused) {
+      const gp::DoneFlags again{done.flags, b->tuning.fused_finalize ? ++b->seq : done.seq};
+      if (!b->tuning.fused_finalize) GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
+      hipLaunchKernelGGL(gp::vgicp_finalize_error_parts_kernel, dim3(parts), dim3(256), 0, b->stream, (const double*)partials, b->num_tiles, per,
+                         static_cast<double*>(b->h_out_dev), kSlot, again);
+      GP_HIP(hipGetLastError());
+      GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), (size_t)parts, again.seq, b->stream, spin_budget_us(b)));
+    }
     const double* p = static_cast<const double*>(b->h_out.ptr);
     double a = p[0];
     for (int q = 1; q < parts; q++) a += p[(size_t)q * kSlot];

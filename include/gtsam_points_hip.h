@@ -460,6 +460,8 @@ enum {
                                    step -- the arrival counters shared one line -- and was removed: profiles/r03_overlap_finalize.jsonl) */
   GP_TUNE_TILE_CHUNKS = 18,     /* stream family, fixed-tile launches (batches, small single factors): 64-point chunks per wave of a tile (a tile = 256 x value points);
                                    0 (default) = the largest of 4 / 2 / 1 that still gives >= 768 tiles */
+  GP_TUNE_TEST_ARRIVAL_SKEW = 20, /* test hook (batches only): puts the host's count of arrival counter 0 `value` ahead of the device's, as a lost launch would; the next fused
+                                   step must notice that its completion words do not arrive, reset the counters and finish through the finalize kernel */
   GP_TUNE_MAX_WORKGROUPS = 19,  /* stream family, one large factor: workgroups of the planned launch, 8 .. 1024 (default 1024 = one resident round) */
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose

@@ -677,6 +677,22 @@ def test_fused_finalize_equals_the_two_kernel_form(gpu):
     assert n.value == 36 and 3.0 < stream_us.value < 200.0 and stream_us.value < kernel_us.value < stream_us.value + 20.0, (n.value, stream_us.value, kernel_us.value)
     gpu._capi.check(lib.gp_vgicp_batch_device_times(batch, 0, C.byref(n), None, None), "device_times")
     assert n.value == 0
+    # a fused step whose completion words cannot arrive (the host's count of an arrival counter is ahead of the device's, as after a lost launch): the
+    # call notices once the stream is idle, resets the counters and finishes through the finalize kernel -- same record; the steps after it are fused again
+    gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, 1), "fused")
+    gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, poses[0].ctypes.data, out.ctypes.data), "linearize")
+    good = out.copy()
+    gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 20, 5), "arrival skew")  # GP_TUNE_TEST_ARRIVAL_SKEW
+    for _ in range(3):
+        out[:] = 0
+        gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, poses[0].ctypes.data, out.ctypes.data), "linearize")
+        assert np.array_equal(out, good)
+    gpu._capi.check(lib.gp_vgicp_batch_device_times(batch, 1, C.byref(n), None, None), "device_times")
+    assert n.value == 3  # the reference step and two of the three: the first after the skew went through the finalize kernel
+    gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 20, 3), "arrival skew")
+    gpu._capi.check(lib.gp_vgicp_batch_compute_error(batch, poses[0].ctypes.data, poses[1].ctypes.data, C.byref(e0 := C.c_double())), "compute_error")
+    gpu._capi.check(lib.gp_vgicp_batch_compute_error(batch, poses[0].ctypes.data, poses[1].ctypes.data, C.byref(e1 := C.c_double())), "compute_error")
+    assert e0.value == e1.value
     # the error evaluation has the same two forms (eight part sums, by the parts' last tile workgroups or by a second kernel): same bits, call after call
     errs = {0: [], 1: []}
     e = C.c_double()
