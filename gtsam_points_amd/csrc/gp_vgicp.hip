@@ -24,6 +24,7 @@
 #include "gp_host.hpp"
 #include "gp_vgicp_tile.hpp"
 #include "gp_vgicp_tile2.hpp"
+#include "gp_vgicp_finalize.hpp"
 #include "gp_vgicp_stream.hpp"
 
 namespace gp {
@@ -288,28 +289,6 @@ __global__ void __launch_bounds__(kFinalizeThreads) vgicp_finalize_kernel(const 
   signal_done(done, fi, t < 122);
 }
 
-// visibility of LDS writes between the lanes of ONE wave (its LDS operations execute in program order; this only keeps the compiler
-// from moving them and makes it wait for the writes): what __syncthreads() is for a workgroup, without the s_barrier
-#define GP_WAVE_SYNC()                                       \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
-    __builtin_amdgcn_wave_barrier();                         \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
-  } while (0)
-
-__device__ __forceinline__ double pick9(int i, double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7, double a8) {
-  double v = a0;
-  v = i == 1 ? a1 : v;
-  v = i == 2 ? a2 : v;
-  v = i == 3 ? a3 : v;
-  v = i == 4 ? a4 : v;
-  v = i == 5 ? a5 : v;
-  v = i == 6 ? a6 : v;
-  v = i == 7 ? a7 : v;
-  v = i == 8 ? a8 : v;
-  return v;
-}
-
 // finalize of the 29-sum (rigid pose) pass, round 2.  The timeline of the generic kernel above (scripts/trace_finalize.py) showed
 // 2.7 us for the partials (250 KB through ONE compute unit's L1: bandwidth, not latency), and then 2.1 + 2.4 us for what should be
 // nothing: sixteen waves meeting at four barriers, 6x6 tables indexed at run time (= scratch memory round trips) and a pose fetched
@@ -342,58 +321,26 @@ __global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const Fac
     tile_count = hi - lo;
   }
   __shared__ double wsum[kWaves][32];
-  __shared__ double sum[32];
-  __shared__ double Rl[9], Xl[9];  // R and [t]x, row-major
-  __shared__ double Ht[6][6], Ad[6][6], HtA[6][6], bt[6];
-  __shared__ double dst[122];
+  __shared__ RigidScratch S;
   GP_FIN_TRACE(0);
   if (done.trace && threadIdx.x == 0 && blockIdx.x == 0) done.trace[9] = __builtin_amdgcn_s_getreg(GP_GETREG_XCC_ID);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
   {
     // fixed summation order (deterministic).  All of a lane's rows are requested in ONE batch of up to 32 independent loads
-    const double* base = partials + (size_t)tile_begin * ACC_STRIDE + comp;
-    double total = 0.0;
-    for (int t0 = slice; t0 < tile_count; t0 += 32 * kSlices) {
-      double v[32];
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        const int t = t0 + k * kSlices;
-        v[k] = t < tile_count ? base[(size_t)t * ACC_STRIDE] : 0.0;
-      }
-#pragma unroll
-      for (int w = 16; w > 0; w >>= 1) {
-#pragma unroll
-        for (int k = 0; k < w; k++) v[k] += v[k + w];
-      }
-      total += v[0];
-    }
+    double total = rigid_slice_total<kSlices, false>(partials + (size_t)tile_begin * ACC_STRIDE + comp, tile_count, slice);
     total += __shfl_xor(total, 32, 64);  // the wave's two slices
     if (lane < 32) wsum[wave][lane] = total;
   }
   GP_FIN_TRACE(1);
   __syncthreads();
   if (wave != 0) return;  // (a finished wave no longer takes part in barriers; none follow anyway)
-  if (lane < 32) {
-    double v[kWaves];
-#pragma unroll
-    for (int k = 0; k < kWaves; k++) v[k] = wsum[k][lane];
-#pragma unroll
-    for (int w = kWaves / 2; w > 0; w >>= 1) {
-#pragma unroll
-      for (int k = 0; k < w; k++) v[k] += v[k + w];
-    }
-    sum[lane] = v[0];
-  } else if (lane < 41) {
-    const int i = lane - 32;
-    Rl[i] = pick9(i, T.r00, T.r01, T.r02, T.r10, T.r11, T.r12, T.r20, T.r21, T.r22);
-    Xl[i] = pick9(i, 0.0, -T.tz, T.ty, T.tz, 0.0, -T.tx, -T.ty, T.tx, 0.0);
-  }
+  if (lane < 32) S.sum[lane] = rigid_wave_tree<kWaves>(&wsum[0][0], lane);
   GP_WAVE_SYNC();
   GP_FIN_TRACE(2);
   if (sums_only) {
     double* out_rec = reinterpret_cast<double*>(out + blockIdx.x);
-    if (lane < 32) out_rec[lane] = sum[lane];
+    if (lane < 32) out_rec[lane] = S.sum[lane];
     GP_FIN_TRACE(3);
     if (done.flags) {
       GP_FIN_TRACE(4);
@@ -404,70 +351,9 @@ __global__ void __launch_bounds__(THREADS) vgicp_finalize_rigid_kernel(const Fac
     }
     return;
   }
+  rigid_expand_wave(S, T, lane);
   const int t = lane;
-  const int r = t / 6, c = t % 6;  // t < 36: one 6x6 entry per lane
-  constexpr int OFF_HT = 2, OFF_HS = 38, OFF_HTS = 74, OFF_BT = 110, OFF_BS = 116;
-  auto sym3 = [](int a, int b) {  // packed index of a symmetric 3x3 (00 01 02 11 12 22)
-    const int i = a < b ? a : b, j = a < b ? b : a;
-    return (i * (5 - i)) / 2 + j;
-  };
-  if (t < 36) {
-    // H_t = [[TL, -K^T], [-K, M]]
-    double h;
-    if (r < 3 && c < 3) {
-      h = sum[ACC_TL + sym3(r, c)];
-    } else if (r >= 3 && c < 3) {
-      h = -sum[ACC_K + (r - 3) * 3 + c];
-    } else if (r < 3) {
-      h = -sum[ACC_K + (c - 3) * 3 + r];
-    } else {
-      h = sum[ACC_M + sym3(r - 3, c - 3)];
-    }
-    Ht[r][c] = h;
-    dst[OFF_HT + c * 6 + r] = h;
-    // Ad(delta) = [[R, 0], [[t]x R, R]]   ([omega, v] ordering, GTSAM Pose3::AdjointMap)
-    double a;
-    if (r < 3 && c < 3) {
-      a = Rl[r * 3 + c];
-    } else if (r < 3) {
-      a = 0.0;
-    } else if (c >= 3) {
-      a = Rl[(r - 3) * 3 + (c - 3)];
-    } else {
-      a = Xl[(r - 3) * 3] * Rl[c] + Xl[(r - 3) * 3 + 1] * Rl[3 + c] + Xl[(r - 3) * 3 + 2] * Rl[6 + c];
-    }
-    Ad[r][c] = a;
-  } else if (t < 42) {
-    const int k = t - 36;
-    const double b = k < 3 ? sum[ACC_QXMR + k] : sum[ACC_MR + k - 3];
-    bt[k] = b;
-    dst[OFF_BT + k] = b;
-  } else if (t == 42) {
-    dst[0] = sum[ACC_COUNT];
-    dst[1] = sum[ACC_ERR];
-  }
-  GP_WAVE_SYNC();
-  if (t < 36) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) a += Ht[r][k] * Ad[k][c];
-    HtA[r][c] = a;
-    dst[OFF_HTS + c * 6 + r] = -a;  // H_ts = -H_t Ad
-  } else if (t < 42) {
-    const int k6 = t - 36;
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) a += Ad[k][k6] * bt[k];
-    dst[OFF_BS + k6] = -a;  // b_s = -Ad^T b_t
-  }
-  GP_WAVE_SYNC();
-  if (t < 36) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) a += Ad[k][r] * HtA[k][c];
-    dst[OFF_HS + c * 6 + r] = a;  // H_s = Ad^T H_t Ad
-  }
-  GP_WAVE_SYNC();
+  const double* dst = S.dst;
   GP_FIN_TRACE(3);
   // the record leaves in two coalesced sweeps of 8-byte stores (it may be only 8-byte aligned, integrated_vgicp_factor_gpu.cpp:219-220;
   // when `out` is host-mapped memory, scattered stores would each be their own PCIe write)
@@ -611,6 +497,8 @@ struct gp_vgicp_batch {
   unsigned long long* trace = nullptr;  // timeline build of the tile kernel: [2048][16] uint64 device buffer (gp_vgicp_batch_set_trace_buffer)
   // fused finalize (GP_TUNE_FUSED_FINALIZE; synchronous single-factor calls of the stream family)
   gp::DeviceArray d_arrive;               // 16 monotonic arrival counters, kArriveStride words apart
+  gp::DeviceArray d_factor_arrive;        // fused finalize by factor: one counter per factor, kFactorArriveStride words apart, zero between launches
+  size_t factor_arrive_count = 0;
   unsigned long long arrived[16] = {0};   // what the counters read once every launch issued so far has finished
   bool timing = false;                  // GP_TUNE_TIMING: the synchronous linearise brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -1160,6 +1048,11 @@ int gp_vgicp_batch_set_tuning(gp_vgicp_batch_t* b, int key, int value) {
   }
   if (key == GP_TUNE_TEST_ARRIVAL_SKEW) {  // test hook: the host's idea of arrival counter 0 runs `value` ahead of the device's, as after a launch that was lost
     b->arrived[0] += (unsigned long long)(value > 0 ? value : 0);
+    if (b->d_factor_arrive.ptr && value > 0) {  // ... and factor counter 0 is far out of range: that factor's record cannot complete
+      const unsigned long long v = 1ull << 40;
+      GP_HIP(hipStreamSynchronize(b->stream));
+      GP_HIP(hipMemcpy(b->d_factor_arrive.ptr, &v, sizeof(v), hipMemcpyHostToDevice));
+    }
     return GP_OK;
   }
   GP_TRY(apply_tuning(&b->tuning, key, value));
@@ -1591,6 +1484,35 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
         b->dev_stream_ticks += (double)(t_rows - t0);
         b->dev_kernel_ticks += (double)(t_out - t0);
       }
+    }
+  } else if (parts == 1 && rigid && b->family == GP_KERNEL_STREAM && b->tuning.fused_finalize && !b->timing && !b->trace) {
+    // ONE launch for a batch (or a small single factor): the workgroup that stores a factor's last row finalizes the factor (gp_vgicp_stream.hpp), so
+    // the records leave for the host while the other factors' tiles are still running
+    if (b->factor_arrive_count < F) {
+      const size_t bytes = sizeof(unsigned long long) * gp::kFactorArriveStride * F;
+      GP_TRY(b->d_factor_arrive.alloc(bytes));
+      GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, bytes));
+      b->factor_arrive_count = F;
+    }
+    double* partials = nullptr;
+    GP_TRY(partials_ptr(b, &partials));
+    ps.inl.arrive = b->d_factor_arrive.as<unsigned long long>();
+    ps.inl.rows_per_part = 0;
+    ps.inl.num_rows = b->num_tiles;
+    ps.inl.fin_out = static_cast<double*>(b->h_out_dev);
+    ps.inl.fin_stride = (int)(sizeof(gp_linearized6) / sizeof(double));
+    ps.inl.fin_flags = done.flags;
+    ps.inl.fin_seq = done.seq;
+    GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream, spin_budget_us(b)));
+    if (!words_arrived(b, (int)F, done.seq)) {
+      // (the stream is idle and a record is missing: a counter was left dirty by a launch that did not run to its end.  The rows are complete: clean the
+      // counters and let the finalize kernel do this call's records)
+      GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, sizeof(unsigned long long) * gp::kFactorArriveStride * F));
+      const gp::DoneFlags again{done.flags, ++b->seq, nullptr};
+      ps.inl.arrive = nullptr;
+      GP_TRY(launch_finalize<false>(b, ps, partials, reinterpret_cast<gp_linearized6*>(b->h_out_dev), again, 1));
+      GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, again.seq, b->stream, spin_budget_us(b)));
     }
   } else {
     GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));

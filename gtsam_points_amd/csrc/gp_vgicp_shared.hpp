@@ -29,6 +29,7 @@ struct FactorDesc {
 // (per-workgroup timeline of round 3, profiles/r03_sweep.jsonl).  So the rounds get DIFFERENT shares: workgroups of round r < last take n[r]
 // chunks each (more for the early rounds), the workgroups from `last_begin` on split what is left evenly (`lo`, the first `extra` one more).
 constexpr int kArriveStride = 512;  // 64-bit words between the arrival counters of two parts (fused finalize): 4 KB, another memory channel
+constexpr int kFactorArriveStride = 16;  // 64-bit words between the arrival counters of two FACTORS (fused finalize of a batch): one 128-byte line each
 constexpr int kStreamRound = 32;  // workgroups per dispatch round of an XCD = its compute units
 struct StreamPlan {
   int wgs_per_xcd, last_begin;  // workgroups per XCD share; first workgroup of the share's last round (a multiple of 32)
@@ -59,7 +60,8 @@ struct InlinePoses {
   // adds 1 to arrive[row / rows_per_part]; the workgroup whose add completes a part (arrive_target) sums the part's rows in the fixed order of
   // the split finalize kernel and hands the 32 sums to the host (fin_out slot + completion word): no second kernel, no kernel boundary
   unsigned long long* arrive;  // null = off
-  int rows_per_part;
+  int rows_per_part;  // > 0: fused finalize by parts of ONE factor's row list (counter g for rows [g * rows_per_part, ...)); 0 with `arrive` set: by FACTOR
+                      // (counter factor_idx * kFactorArriveStride, reset by the last arriver; fin_out / fin_flags indexed by factor)
   int num_rows;
   unsigned long long arrive_target[16];  // the counters are monotonic: what arrive[g] reads when this launch's part g is complete
   double* fin_out;                       // host-mapped records, part g -> fin_out + g * fin_stride

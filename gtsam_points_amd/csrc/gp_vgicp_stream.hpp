@@ -21,6 +21,7 @@
 // wave adds up, so records differ from the second generation at the 1e-16 level (fixed order per launch geometry: still bit-reproducible).
 #pragma once
 
+#include "gp_vgicp_finalize.hpp"
 #include "gp_vgicp_tile2.hpp"
 
 namespace gp {
@@ -474,8 +475,8 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
       *dst = sum;
     }
   }
-  if constexpr (INL) {
-    if (inl.arrive) {  // (kernel argument: uniform over the launch)
+  if (inl.arrive && inl.rows_per_part > 0) {  // (kernel arguments: uniform over the launch) fused finalize by PARTS of one large factor's row list
+    if constexpr (INL) {
       unsigned long long* tr = nullptr;
       if constexpr (TRACE) tr = trace ? trace + (size_t)tile_idx * 16 : nullptr;
       const int part = row / inl.rows_per_part;
@@ -496,6 +497,46 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
         else
           finalize_part_rows(partials, row_begin, row_count, reinterpret_cast<double*>(smem), inl.fin_out + (size_t)part * inl.fin_stride, inl.fin_flags + part, inl.fin_seq, tr,
                              *reinterpret_cast<const unsigned long long*>(last + 2));
+      }
+    }
+  } else if (inl.arrive) {
+    // fused finalize by FACTOR (synchronous batched calls, small single factors): the workgroup that stores a factor's last row sums the factor's rows and
+    // expands them into the record -- rigid_slice_total / rigid_wave_tree / rigid_expand_wave in the order of vgicp_finalize_rigid_kernel<1024>, whose 32
+    // slices of rows are taken four to a thread here -- and hands record and completion word to the host while the other factors' tiles are still running:
+    // no finalize launch, and the records' way over PCIe (a third of a 512-factor call) is hidden behind the tile kernel
+    if constexpr (MODE == MODE_LIN) {
+      int* const last = reinterpret_cast<int*>(smem + 4 * kWaveBytes - 32 * 8 - 16);
+      if (threadIdx.x == 0) {
+        unsigned long long* ctr = inl.arrive + (size_t)factor_idx * kFactorArriveStride;
+        const unsigned long long seen = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool l = seen + 1 == (unsigned long long)f.tile_count;
+        if (l) __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every arrival of this launch is in: ready for the next one
+        *last = l;
+      }
+      __syncthreads();
+      if (*last) {
+        double* wsum16 = reinterpret_cast<double*>(smem);                  // [16][32]: what the sixteen waves of the finalize kernel would have left
+        RigidScratch& S = *reinterpret_cast<RigidScratch*>(smem + 4096);   // (both below the waves' own sums, which nobody reads any more)
+        static_assert(4096 + sizeof(RigidScratch) <= kWaveBytes - 32 * 8, "scratch of the fused finalize must fit in front of wave 0's sums");
+        const int comp = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const double* base = partials + (size_t)f.tile_begin * ACC_STRIDE + comp;
+        const double s0 = rigid_slice_total<32, true>(base, f.tile_count, 4 * sl), s1 = rigid_slice_total<32, true>(base, f.tile_count, 4 * sl + 1);
+        const double s2 = rigid_slice_total<32, true>(base, f.tile_count, 4 * sl + 2), s3 = rigid_slice_total<32, true>(base, f.tile_count, 4 * sl + 3);
+        wsum16[(2 * sl) * 32 + comp] = s0 + s1;
+        wsum16[(2 * sl + 1) * 32 + comp] = s2 + s3;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+          const int l64 = threadIdx.x;
+          if (l64 < 32) S.sum[l64] = rigid_wave_tree<16>(wsum16, l64);
+          GP_WAVE_SYNC();
+          rigid_expand_wave(S, Tl, l64);
+          double* out_rec = inl.fin_out + (size_t)factor_idx * inl.fin_stride;
+          const double d0 = S.dst[l64], d1 = l64 + 64 < 122 ? S.dst[l64 + 64] : 0.0;
+          asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(out_rec + l64), "v"(d0) : "memory");
+          if (l64 + 64 < 122) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(out_rec + l64 + 64), "v"(d1) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (l64 == 0) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(inl.fin_flags + factor_idx), "v"(inl.fin_seq) : "memory");
+        }
       }
     }
   }

@@ -442,6 +442,60 @@ def test_surface_validation_rides_in_the_ring_at_size(gpu):
         assert rel_err(getattr(recs[12][0], k), getattr(recs[8][0], k)) < 1e-9
 
 
+def test_fused_finalize_by_factor_equals_the_two_kernel_batch(gpu, kitti07):
+    """synchronous batched call, default: the workgroup that stores a factor's last partial row finalizes the factor inside the tile kernel (one launch, the
+    records stream to the host while other factors' tiles run).  Every record must equal, bit for bit, the one the finalize kernel writes -- the two-kernel
+    form of the same call (GP_TUNE_FUSED_FINALIZE 0) and the device-resident form (issue_linearize) that the multi-GPU path uses -- call after call, with
+    poses changing; a factor whose arrival counter is unusable is noticed (its word does not arrive) and the call finishes through the finalize kernel."""
+    poses = kitti07["poses"]
+    rng = np.random.default_rng(77)
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(5)]
+    maps = []
+    for c in clouds:
+        vm = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        vm.insert(c)
+        maps.append(vm)
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4), (0, 3), (1, 4), (0, 4), (1, 0), (4, 3)]
+    factors = [gpu.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j]) for i, j in pairs]
+    lib = gpu.load()
+    F = len(factors)
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch, s = C.c_void_p(), C.c_void_p()
+    gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+    gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+    import torch
+
+    out = np.zeros((F, 122))
+    dev = torch.zeros((F, 122), dtype=torch.float64, device="cuda")
+    for rep in range(4):
+        deltas = [oracle.calc_delta(poses[i] @ expmap(rng.uniform(-0.03, 0.03, 6)), poses[j] @ expmap(rng.uniform(-0.03, 0.03, 6))) for i, j in pairs]
+        P = np.ascontiguousarray(np.stack([d.T.reshape(16) for d in deltas]))
+        recs = {}
+        for mode in (1, 0, 1):
+            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, mode), "fused")
+            out[:] = 0
+            gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, P.ctypes.data, out.ctypes.data), "linearize")
+            recs.setdefault(mode, []).append(out.copy())
+        gpu._capi.check(lib.gp_vgicp_batch_issue_linearize(batch, P.ctypes.data, C.c_void_p(dev.data_ptr())), "issue")
+        gpu._capi.check(lib.gp_stream_synchronize(s), "sync")
+        assert np.array_equal(recs[1][0], recs[0][0]) and np.array_equal(recs[1][1], recs[0][0]) and np.array_equal(dev.cpu().numpy(), recs[0][0])
+        if rep == 2:  # factor 0's counter becomes unusable: the call must still deliver every record
+            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, 1), "fused")
+            gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, P.ctypes.data, out.ctypes.data), "linearize")
+            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 20, 1), "arrival skew")
+            for _ in range(2):
+                out[:] = 0
+                gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, P.ctypes.data, out.ctypes.data), "linearize")
+                assert np.array_equal(out, recs[0][0])
+    for k, ((i, j), d) in enumerate(zip(pairs, deltas)):
+        omap = oracle.OracleVoxelMap(1.0)
+        omap.insert(kitti07[f"points_{i}"], kitti07[f"covs_{i}"])
+        Lo = oracle.OracleVGICPFactor(omap, kitti07[f"points_{j}"], kitti07[f"covs_{j}"], 2).linearize(d)
+        assert_linearized_close(gpu.LinearizedSystem6.from_doubles(recs[1][0][k]), Lo, MIXED_TOL, f"factor {k}")
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+
+
 def test_one_validating_factor_does_not_demote_its_batch(gpu, kitti07):
     """a batch in which ONE factor has set_enable_surface_validation(true): the whole batch still runs the stream kernel (its normals-row
     instantiation; the other factors' descriptors carry surface_validation = 0 and skip the gate) -- round 2 sent such a batch to the round-2
