@@ -47,6 +47,21 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_R
   [ -n "$f" ] && python scripts/r03_c4_traffic_parse.py "$f" $CFG 4 >> $O/c4_traffic.txt 2>> $O/c4_traffic.err
 done
 cat $O/c4_traffic.txt; tail -3 $O/c4_traffic.err 2>/dev/null
+# 4b. fused finalize A/B and tail timeline, surface validation at size, block-sparse solver, C5 kernel stats, synchronous batched calls under rocprofv3
+timeout 300 python scripts/r03_fused.py 1500 4 > $O/fused_finalize.jsonl 2>/dev/null; cut -c1-260 $O/fused_finalize.jsonl | head -6
+timeout 200 python scripts/r03_sv_time.py 2>/dev/null | grep "^{" > $O/surface_validation_time.jsonl; cat $O/surface_validation_time.jsonl
+timeout 600 python scripts/solver_time.py > $O/solver_time.jsonl 2>/dev/null; python - <<'PY'
+import json, os
+for l in open(os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r03/solver_time.jsonl"):
+    d = json.loads(l)
+    print(d["graph"], d["poses"], {k.replace("sparse_", "").replace("_solve_ms", ""): v for k, v in d.items() if k.endswith("_solve_ms") and k.startswith("sparse")})
+PY
+rm -rf /tmp/pk && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o c5 -- python scripts/r03_c5.py > $O/c5.log 2>&1
+f=$(find /tmp/pk -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c5_kernel_stats.csv && head -3 $f | cut -c1-200; grep "^{" $O/c5.log
+for wl in c4 c3; do
+  rm -rf /tmp/pb && PMC=1 C4_CONFIGS=0:0:0 WORKLOAD=$wl timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o p -- python scripts/r03_c4_traffic.py > /tmp/pb.log 2>&1
+  f=$(find /tmp/pb -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "vgicp_stream_kernel|finalize" $f | cut -c1-60,170-260 | tee -a $O/sync_kernels_$wl.txt
+done
 # 5. the whole default bench (driver's clock) and the GPU test-suite, smoke
 timeout 900 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log > $O/bench_n1.json; cut -c1-400 $O/bench_n1.json
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke exit $?" >> $O/smoke.txt; tail -2 $O/smoke.txt
