@@ -386,6 +386,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
     rmax = max(rmax, max(abs(c[a] - lo[a]), abs(c[a] - hi[a])));  // shell that covers it
   }
   const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+  const float fxf = (float)fx, fyf = (float)fy, fzf = (float)fz, h2f = (float)(g.h * g.h);  // (cell-box pruning below)
   // |f32 difference - exact difference| <= margin per axis (rounding of q to float + the subtraction), generously
   const float margin = (fabsf(qxf) + fabsf(qyf) + fabsf(qzf) + 1.0f) * 2.4e-7f;
   const float m2x4100 = 4100.0f * margin * margin;
@@ -452,6 +453,15 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
             while (m) {
               const int bit = __ffsll((long long)m) - 1;
               m &= m - 1ull;
+              if (r > 0) {
+                // a cell whose box is farther from the query than the current k-th neighbour holds nothing of interest (the corners of a shell's cube
+                // usually are): box distance in cell units, f32 with slack -- the test only ever SKIPS, and only cells every point of which fails the
+                // list's own strict comparison
+                // (relative to the query's own cell: small integers and the query's position inside its cell, exact to 1e-7 whatever the coordinates)
+                const float rx = (float)(4 * bx + (bit & 3) - c[0]) - fxf, ry = (float)(4 * by + ((bit >> 2) & 3) - c[1]) - fyf, rz = (float)(4 * bz + (bit >> 4) - c[2]) - fzf;
+                const float ex = fmaxf(fmaxf(rx, -rx - 1.0f), 0.0f), ey = fmaxf(fmaxf(ry, -ry - 1.0f), 0.0f), ez = fmaxf(fmaxf(rz, -rz - 1.0f), 0.0f);
+                if ((ex * ex + ey * ey + ez * ez) * h2f * 0.9999f > accept) continue;
+              }
               const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
               const int pb = g.cell_start[ord], pe = g.cell_start[ord + 1];
               n_cell++;
