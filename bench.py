@@ -581,6 +581,8 @@ def main():
         peak=HBM_PEAK_GBS,
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 5),
+        frac_note=("frac is quoted on the kernel as the timed steps ran it (VERDICT r02: not the best launch pattern).  Round 2's line quoted the back-to-back figure: like for like, "
+                   "in step 0.51 (r02) -> this frac, back to back 0.57 (r02) -> frac_back_to_back") if in_step else None,
         traffic=_load_traffic()[0],
         traffic_source=_load_traffic()[1],
         algorithmic_bytes=alg_bytes,
