@@ -1504,6 +1504,12 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
     ps.inl.fin_flags = done.flags;
     ps.inl.fin_seq = done.seq;
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
+    for (size_t i = 0; i < F; i++)
+      if (b->h_descs[i].tile_count == 0) {  // a factor without points has no workgroup to finalize it: its (empty) record is written here
+        const double zeros[32] = {0.0};
+        expand_rigid_host(zeros, poses_host + 16 * i, reinterpret_cast<double*>(static_cast<gp_linearized6*>(b->h_out.ptr) + i));
+        static_cast<volatile unsigned long long*>(b->h_done.ptr)[i] = done.seq;
+      }
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream, spin_budget_us(b)));
     if (!words_arrived(b, (int)F, done.seq)) {
       // (the stream is idle and a record is missing: a counter was left dirty by a launch that did not run to its end.  The rows are complete: clean the

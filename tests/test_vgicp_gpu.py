@@ -496,6 +496,43 @@ def test_fused_finalize_by_factor_equals_the_two_kernel_batch(gpu, kitti07):
     lib.gp_stream_destroy(s)
 
 
+def test_batch_with_an_empty_factor(gpu, kitti07):
+    """a factor without source points has no tile and therefore no workgroup that could finalize it inside the tile kernel: the fused batched call writes its
+    (all-zero) record itself -- same bits as the finalize kernel of the two-kernel form, and without waiting out the spin budget for a word nobody sends"""
+    import time
+
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(3)]
+    empty = gpu.PointCloudGPU(np.zeros((1, 3), np.float32), np.zeros((1, 3, 3), np.float32))
+    empty.num_points = 0
+    maps = []
+    for c in clouds:
+        vm = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        vm.insert(c)
+        maps.append(vm)
+    factors = [gpu.IntegratedVGICPFactorGPU(0, 1, maps[0], clouds[1]), gpu.IntegratedVGICPFactorGPU(0, 2, maps[0], empty), gpu.IntegratedVGICPFactorGPU(1, 2, maps[1], clouds[2])]
+    lib = gpu.load()
+    F = len(factors)
+    arr = (C.c_void_p * F)(*[f._h.value for f in factors])
+    batch, s = C.c_void_p(), C.c_void_p()
+    gpu._capi.check(lib.gp_stream_create(C.byref(s)), "stream")
+    gpu._capi.check(lib.gp_vgicp_batch_create(arr, F, s, C.byref(batch)), "batch")
+    P = np.ascontiguousarray(np.stack([expmap([0.01, -0.02, 0.015, 0.1, -0.05, 0.03]).T.reshape(16)] * F))
+    out = np.ones((F, 122))
+    recs = {}
+    for mode in (1, 0):
+        gpu._capi.check(lib.gp_vgicp_batch_set_tuning(batch, 17, mode), "fused")
+        for _ in range(3):
+            out[:] = 1
+            t0 = time.perf_counter()
+            gpu._capi.check(lib.gp_vgicp_batch_linearize(batch, P.ctypes.data, out.ctypes.data), "linearize")
+            dt = time.perf_counter() - t0
+        recs[mode] = (out.copy(), dt)
+    assert np.array_equal(recs[0][0], recs[1][0]) and np.all(recs[1][0][1] == 0.0) and recs[1][0][0, 0] > 100
+    assert recs[1][1] < 80e-6, recs[1][1]  # (the spin budget alone is 100 us)
+    lib.gp_vgicp_batch_destroy(batch)
+    lib.gp_stream_destroy(s)
+
+
 def test_one_validating_factor_does_not_demote_its_batch(gpu, kitti07):
     """a batch in which ONE factor has set_enable_surface_validation(true): the whole batch still runs the stream kernel (its normals-row
     instantiation; the other factors' descriptors carry surface_validation = 0 and skip the gate) -- round 2 sent such a batch to the round-2
