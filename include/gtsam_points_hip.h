@@ -261,8 +261,9 @@ int gp_vgicp_factor_compute_error(gp_vgicp_factor_t* f, const double pose_lin[16
 
 /* ---- NonlinearFactorSetGPU fast path: one batched launch over a factor table ----
  * replaces the per-factor loop of cuda/nonlinear_factor_set_gpu.cpp:64-218 (F x {reduce, select} launches,
- * 2F stream syncs) by: one H2D of all poses, one tiled kernel over all factors' points, one finalize kernel,
- * one D2H. */
+ * 2F stream syncs) by ONE tiled launch over all factors' points for a synchronous rigid-pose call (poses read where the caller left them, the workgroup that
+ * stores a factor's last partial row finalizes the factor, records and completion words go straight into host-mapped memory), and by a tiled launch + a finalize
+ * launch for the asynchronous entry points (device-resident records). */
 
 typedef struct gp_vgicp_batch gp_vgicp_batch_t;
 
@@ -277,7 +278,7 @@ int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* batch, const double* po
 int gp_vgicp_batch_sync(gp_vgicp_batch_t* batch);
 /* synchronous: upload poses, compute, download F records into out_host */
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_host);
-/* the same pass without the copy into a caller array: *out_view points at the F records where the finalize kernel stored them (the
+/* the same pass without the copy into a caller array: *out_view points at the F records where the kernels stored them (the
  * batch's pinned, host-mapped result buffer), valid until the next call on this batch.  The 976 bytes per factor are then read once,
  * by their consumer (NonlinearFactorSetGPU's store_linearized loop), instead of copied first: 6 us of a 98 us 256-factor pass,
  * 12 us of a 289 us 512-factor pass (profiles/r02_sync_batch_overheads.txt) */
@@ -453,13 +454,13 @@ enum {
   GP_TUNE_EFFECTIVE_KERNEL = 6, /* read-only: the family the batch's current table runs (-1 before the first pass) */
   GP_TUNE_XCD_WEIGHT_0 = 8,     /* .. + 7: stream kernel, one large factor: share of XCD x in 1/1000 of the mean share (500..1500); setting any of the eight
                                    replaces the library's measured table (the others then count as 1000) */
-  GP_TUNE_FUSED_FINALIZE = 17,  /* synchronous single-factor linearise of the stream family (rigid pose, >= 256 tiles): 1 (default) = fused finalize -- the tile
-                                   workgroup whose arrival completes an eighth of the tile list sums that eighth's rows and hands the sums to the host: one launch,
-                                   no finalize kernel, 1.5-1.8 us off the step (profiles/r03_fused_finalize.jsonl); 0 = tile kernel, then finalize kernel.  The
-                                   records of the two forms are bit-identical.  (Round 3's first form, finalize workgroups on a second stream, cost +10 us per
-                                   step -- the arrival counters shared one line -- and was removed: profiles/r03_overlap_finalize.jsonl) */
+  GP_TUNE_FUSED_FINALIZE = 17,  /* synchronous rigid-pose linearise / error evaluation of the stream family: 1 (default) = ONE launch -- a large single factor: the tile
+                                   workgroup whose arrival completes an eighth of the row list sums that eighth and hands the sums to the host; a batch or a small
+                                   factor: the workgroup that stores a factor's last row sums, expands and delivers the factor's record.  0 = tile kernel, then finalize
+                                   kernel.  The records of the two forms are bit-identical (the same functions in the same order, csrc/gp_vgicp_finalize.hpp).
+                                   1.5-1.8 us off a 1 M-point step, 10-20 % off a 256- / 512-factor call (profiles/r03_fused_finalize.jsonl, r03_fused_by_factor.txt) */
   GP_TUNE_TILE_CHUNKS = 18,     /* stream family, fixed-tile launches (batches, small single factors): 64-point chunks per wave of a tile (a tile = 256 x value points);
-                                   0 (default) = the largest of 4 / 2 / 1 that still gives >= 768 tiles */
+                                   0 (default) = 8 when the batch has >= 2048 tiles of 2048 points, else the largest of 4 / 2 / 1 that still gives >= 768 tiles */
   GP_TUNE_TEST_ARRIVAL_SKEW = 20, /* test hook (batches only): puts the host's count of arrival counter 0 `value` ahead of the device's, as a lost launch would; the next fused
                                    step must notice that its completion words do not arrive, reset the counters and finish through the finalize kernel */
   GP_TUNE_MAX_WORKGROUPS = 19,  /* stream family, one large factor: workgroups of the planned launch, 8 .. 1024 (default 1024 = one resident round) */
