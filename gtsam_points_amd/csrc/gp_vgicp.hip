@@ -713,6 +713,11 @@ int build_table(gp_vgicp_batch* b) {
       int64_t count8 = 0;
       for (const auto* f : b->factors) count8 += (f->n + 2047) / 2048;
       if (count8 >= 2 * kResidentWorkgroups) ppt = 8;
+      // ... and 4096-point tiles from 4096 such tiles up (a C4 shard: 512 factors x 8): with the factors finalized inside the tile kernel every tile ends with a
+      // write-through row and an arrival, so fewer, larger tiles win while there are still four rounds of them (C4 shard 0.171 -> 0.163 ms; C3, 1536 such tiles: no)
+      int64_t count16 = 0;
+      for (const auto* f : b->factors) count16 += (f->n + 4095) / 4096;
+      if (count16 >= 4 * kResidentWorkgroups) ppt = 16;
       if (b->tuning.tile_chunks > 0) ppt = b->tuning.tile_chunks;
     }
     b->ppt = ppt;
