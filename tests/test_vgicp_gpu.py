@@ -6,6 +6,7 @@ f32: measured <= 1e-7, held here to PARITY_TOL = 1e-6 -- ten times tighter than 
 held to F64_TOL = 1e-7 (the only f32 quantity left is the stored voxel mean offset).  Kernel families are selected PER FACTOR / PER BATCH
 (gp_vgicp_factor_set_tuning / gp_vgicp_batch_set_tuning): the library has no process-global switches."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -940,3 +941,14 @@ def test_alignment_gate_gpu(gpu, kitti07):
         ang, trans = pose_error(np.linalg.inv(est[0]) @ est[k], np.linalg.inv(poses[0]) @ poses[k])
         assert ang < 0.015 and trans < 0.15, (k, ang, trans)
     assert hook.linearization_count() > 0 and hook.evaluation_count() > 0
+
+
+def test_randomised_soak_of_the_fused_paths(gpu):
+    """scripts/r03_fuzz.py for a few seconds: three threads drive a large single factor, a small one and a 12-factor batch with random poses while the knobs change
+    under them (table rebuilds, timing mode, injected arrival-counter desyncs); every fused record / error equals the two-kernel form's, bit for bit"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r03_fuzz.py"), "4", "11"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FUZZ_OK" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
