@@ -207,6 +207,17 @@ struct TopK {
     }
   }
   __device__ double worst() const { return bound; }
+  // neighbours held.  FULL lists do not count their insertions (two instructions in the hottest block of the search): an entry is held iff its index is valid
+  __device__ int count() const {
+    if constexpr (FULL) {
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX; j++) c += idx[j] >= 0 ? 1 : 0;
+      return c;
+    } else {
+      return found;
+    }
+  }
   // KnnResult::push (ann/knn_result.hpp:89-109): strict '<', earlier-visited ties win
   __device__ void push(int index, double dist) {
     if (!(dist < bound)) return;
@@ -239,8 +250,7 @@ struct TopK {
       idx[0] = c[0] ? index : idx[0];
       d[0] = min64(dist, d[0]);
       bound = d[KMAX - 1];
-      found = found + 1 < KMAX ? found + 1 : KMAX;
-      return;
+      return;  // (`found` is not kept up in this form: count() reads it off the list)
     }
     bool placed = false;
 #pragma unroll
@@ -331,7 +341,7 @@ __device__ __forceinline__ void knn_query(const GridView& g, double qx, double q
       }
     const double safe = (double)r * g.h + face;
     if (top.worst() <= safe * safe) return;  // every unvisited point is farther than the current k-th (or than max_sq_dist)
-    if (top.found >= g.n) return;            // the whole cloud has been seen (clouds smaller than k)
+    if (top.count() >= g.n) return;            // the whole cloud has been seen (clouds smaller than k)
   }
 }
 
@@ -474,7 +484,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
     }
     const double safe = (double)r * g.h + face;
     const bool done = top.worst() <= safe * safe   // every unvisited point is farther than the current k-th (or than max_sq_dist)
-                      || top.found >= g.n;         // the whole cloud has been seen (clouds smaller than k)
+                      || top.count() >= g.n;         // the whole cloud has been seen (clouds smaller than k)
     if (done || r == rlast) {
       if (g.counters) {
         atomicAdd(g.counters + 0, 1ull);
@@ -684,7 +694,7 @@ __device__ __forceinline__ bool knn_query_coarse(const BinGridView& g, double qx
       }
     }
     const double safe = (double)r * unit + face;
-    done = top.worst() <= safe * safe || top.found >= g.n;
+    done = top.worst() <= safe * safe || top.count() >= g.n;
   }
   if (g.counters) {
     atomicAdd(g.counters + 0, 1ull);
@@ -935,7 +945,7 @@ __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g
   top.init(k, 1.7976931348623157e308);
   knn_query_any<KMAX, FULL>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr);
   float* out = covs + 9 * (size_t)i;
-  if (top.found < k) {
+  if (top.count() < k) {
     atomicAdd(num_short, 1);
     for (int j = 0; j < 9; j++) out[j] = (j % 4 == 0) ? 1.0f : 0.0f;
     return;
