@@ -527,8 +527,15 @@ def main():
     else:
         from gtsam_points_amd.distributed import ShardedLinearizer
 
-        def issue(poses_local, view):
-            _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses_local.ctypes.data, C.c_void_p(view.data_ptr())), "gp_vgicp_batch_issue_linearize")
+        issue_linearize = lib.gp_vgicp_batch_issue_linearize
+        pose_ptr = C.c_void_p(pose.ctypes.data)
+        row_ptr = {}
+
+        def issue(poses_local, view):  # (pose array and row view are the same objects every step: their addresses are taken once)
+            if not row_ptr:
+                row_ptr[0] = C.c_void_p(view.data_ptr())
+            if issue_linearize(batch, pose_ptr, row_ptr[0]) != 0:
+                _capi.check(1, "gp_vgicp_batch_issue_linearize")
 
         sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue, always_exchange=True)
 

@@ -138,17 +138,21 @@ class ShardedLinearizer:
         self.stream = stream
         self.always_exchange = bool(always_exchange)  # run the zeroing + all-reduce with ONE rank as well (a 1-rank communicator is valid: RCCL smoke on a 1-GPU box)
         self.stacked = torch.zeros((self.total, RECORD_DOUBLES), dtype=torch.float64, device=device)
+        # (a step is tens of microseconds: what does not change from call to call is looked up once)
+        self.own_rows = self.stacked[self.begin : self.end] if self.end > self.begin else None
+        self._exchange = None
 
     def _run(self, poses_local):
         import torch.distributed as dist
 
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        exchange = world > 1 or (self.always_exchange and dist.is_initialized())
-        if exchange:
+        if self._exchange is None:
+            world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+            self._exchange = world > 1 or (self.always_exchange and dist.is_initialized())
+        if self._exchange:
             self.stacked.zero_()
-        if self.end > self.begin:
-            self.issue(poses_local, self.stacked[self.begin : self.end])
-        if exchange:
+        if self.own_rows is not None:
+            self.issue(poses_local, self.own_rows)
+        if self._exchange:
             dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked
 
