@@ -380,8 +380,11 @@ __device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my
 
 // max_shells: how many shells beyond the first one that reaches the box this call may walk before it gives up (returns false: the
 // caller retries on a coarser level); returns true when the search is complete (bound met, or every point seen)
-template <int KMAX, bool FULL>
-__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top, int max_shells) {
+constexpr int kRangeCap = 16;       // candidate ranges a lane collects before it scans them (flat scan of knn_query_bins)
+constexpr int kRangeStride = 128;   // int2 entries between two slots of one lane's list = threads of the workgroups that use it
+
+template <int KMAX, bool FULL, bool FLAT = false>
+__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top, int max_shells, int2* rl = nullptr) {
   const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
   if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;  // non-finite query: no neighbours
   const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
@@ -431,6 +434,58 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
       if (p + 2 < pe) test_point(v2);
     }
   };
+  // FLAT scan (rl != nullptr: a per-lane list of candidate ranges in LDS, kRangeCap entries, lane stride kRangeStride).  Scanning a cell the moment the walk
+  // finds it keeps the lanes of a wave out of step -- they find their cells at different points of the nested block / cell loops, and the wave runs the point
+  // loop once per (lane group, cell): ~590 executions of the candidate test per wave for ~185 candidates per lane.  With the list, a shell's cells are only
+  // COLLECTED by the walk; then every lane streams through its ranges in one loop, four candidates per trip, all lanes busy until their own list ends.  A
+  // lane's candidates keep their order, so the result is the same list, bit for bit.
+  int rl_count = 0;
+  auto flush_ranges = [&]() {
+    int ri = 0, p = 0, pe = 0;
+    auto next_range = [&]() {
+      if (ri < rl_count) {
+        const int2 rg = rl[ri * kRangeStride];
+        ri++;
+        p = rg.x;
+        pe = rg.y;
+      } else {
+        p = 0;
+        pe = 0;
+      }
+    };
+    next_range();
+    while (p < pe) {
+      int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      bool k0 = false, k1 = false, k2 = false, k3 = false;
+      auto take = [&](int& a, bool& k) {
+        k = p < pe;
+        if (k) {
+          a = p;
+          p++;
+          if (p == pe) next_range();
+        }
+      };
+      take(a0, k0);
+      take(a1, k1);
+      take(a2, k2);
+      take(a3, k3);
+      const float4 v0 = g.sorted[a0], v1 = g.sorted[a1], v2 = g.sorted[a2], v3 = g.sorted[a3];
+      if (k0) test_point(v0);
+      if (k1) test_point(v1);
+      if (k2) test_point(v2);
+      if (k3) test_point(v3);
+    }
+    rl_count = 0;
+  };
+  auto visit_range = [&](int pb, int pe) {
+    if constexpr (!FLAT) {
+      scan_range(pb, pe);
+    } else if (pe > pb) {
+      rl[rl_count * kRangeStride] = make_int2(pb, pe);
+      rl_count++;
+      if (__builtin_amdgcn_ballot_w64(rl_count >= kRangeCap) != 0ull) flush_ranges();  // (some lane's list is full: the lanes that are here scan what they hold)
+    }
+  };
   const int rlast = (max_shells < rmax - r0) ? r0 + max_shells : rmax;
   for (int r = r0; r <= rlast; r++) {
     int b0[3], b1[3];
@@ -476,12 +531,13 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
               const int pb = g.cell_start[ord], pe = g.cell_start[ord + 1];
               n_cell++;
               n_f32 += (unsigned)(pe - pb);
-              scan_range(pb, pe);
+              visit_range(pb, pe);
             }
           }
         }
       }
     }
+    if constexpr (FLAT) flush_ranges();
     const double safe = (double)r * g.h + face;
     const bool done = top.worst() <= safe * safe   // every unvisited point is farther than the current k-th (or than max_sq_dist)
                       || top.count() >= g.n;         // the whole cloud has been seen (clouds smaller than k)
@@ -719,8 +775,8 @@ struct SearchView {
 
 // stage 0: cell shells 0 .. 4 (occupied cells only: work-efficient while the neighbourhood is a few cells wide); stage 1: superblock
 // shells -- blocks as cells, those beyond the current k-th distance skipped -- until the bound is met or the box is exhausted
-template <int KMAX, bool FULL = false>
-__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX, FULL>& top, bool skip_fine = false) {
+template <int KMAX, bool FULL = false, bool FLAT = false>
+__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX, FULL>& top, bool skip_fine = false, int2* rl = nullptr) {
   if (g.binned) {
     const int k = top.k;
     const double bound = top.worst();  // the caller's max_sq_dist (nothing has been pushed yet)
@@ -731,7 +787,7 @@ __device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, do
     }
     for (int l = 0; l < g.binned; l++) {
       if (l > 0) top.init(k, bound);
-      if (knn_query_bins<KMAX, FULL>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : 4)) return;
+      if (knn_query_bins<KMAX, FULL, FLAT>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : 4, rl)) return;
     }
     top.init(k, bound);
     knn_query_coarse<KMAX, true, FULL>(g.bins[g.binned - 1], qx, qy, qz, top, 0x3fffffff);
@@ -943,7 +999,13 @@ __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g
   const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
   TopK<KMAX, FULL> top;
   top.init(k, 1.7976931348623157e308);
-  knn_query_any<KMAX, FULL>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr);
+  int2* rl = nullptr;
+  if constexpr (FULL) {  // (the k = KMAX build of estimate_covariances: flat scan, see knn_query_bins)
+    __shared__ int2 range_lists[kRangeCap * kRangeStride];
+    static_assert(kRangeStride == 128, "one list per thread of this kernel's workgroups");
+    rl = range_lists + threadIdx.x;
+  }
+  knn_query_any<KMAX, FULL, FULL>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr, rl);
   float* out = covs + 9 * (size_t)i;
   if (top.count() < k) {
     atomicAdd(num_short, 1);

@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03o; rm -rf $O; mkdir -p $O
+O=gpurun_out/r03q; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests/test_knn_gicp_gpu.py -m gpu -q -x > $O/pytest.txt 2>&1; echo "pytest exit $?" >> $O/pytest.txt; tail -4 $O/pytest.txt | cut -c1-300
 timeout 300 python scripts/r03_c5.py 2>&1 | grep "^{" | tee -a $O/c5.jsonl
 GP_COV_FULL=0 timeout 300 python scripts/r03_c5.py 2>&1 | grep "^{" | tee -a $O/c5.jsonl
