@@ -514,6 +514,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
             const int4 raw = *reinterpret_cast<const int4*>(g.blocks + bi);
             n_blk++;
             const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
+            if (bits == 0ull) continue;  // an empty block (most of what a far-field query walks): nothing to mask
             unsigned long long m = bits & cube_mask(mx, my, mz) & ~cube_mask(mx1, my1, mz1);  // occupied cells of this shell
             while (m) {
               const int bit = __ffsll((long long)m) - 1;
