@@ -454,6 +454,7 @@ def main():
     ap.add_argument("--finalize", choices=["fused", "two-kernel"], default="fused",
                     help="synchronous step: fused = the library default (the last tile workgroups finalize, one launch); two-kernel = GP_TUNE_FUSED_FINALIZE 0")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C5 objects (BASELINE configs[0], [2], [4])")
+    ap.add_argument("--no-mirror", action="store_true", help="A/B: stream the caller's 12 + 36 B per point instead of the packed 36-B mirror (GP_TUNE_SOURCE_MIRROR 0)")
     args = ap.parse_args()
 
     import torch
@@ -508,6 +509,8 @@ def main():
     _capi.check(lib.gp_vgicp_batch_create(arr, 1, C.c_void_p(stream.cuda_stream), C.byref(batch)), "gp_vgicp_batch_create")
     if args.finalize == "two-kernel":
         _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_FUSED_FINALIZE, 0), "finalize form")
+    if args.no_mirror:
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_SOURCE_MIRROR, 0), "source mirror")
     delta = d["T_true"] @ synthetic.expmap([2e-4, -1e-4, 1.5e-4, 0.02, -0.01, 0.015])
     pose = np.ascontiguousarray(delta.T).reshape(1, 16).copy()
 
@@ -573,6 +576,9 @@ def main():
     ms_total, ms_main, ms_fin = C.c_float(), C.c_float(), C.c_float()
     _capi.check(lib.gp_vgicp_batch_time_linearize(batch, pose.ctypes.data, args.kernel_iters, C.byref(ms_total), C.byref(ms_main), C.byref(ms_fin)), "time_linearize")
     alg_bytes = int(lib.gp_vgicp_batch_algorithmic_bytes(batch))
+    actual_bytes = int(lib.gp_vgicp_batch_actual_bytes(batch))
+    mirrored = C.c_int(-1)
+    lib.gp_vgicp_batch_get_tuning(batch, _capi.GP_TUNE_EFFECTIVE_MIRROR, C.byref(mirrored))
     in_step = dev_steps.value >= args.steps and dev_stream_us.value > 0
     kernel_ms = dev_stream_us.value * 1e-3 if in_step else ms_main.value
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -593,6 +599,13 @@ def main():
         traffic=_load_traffic()[0],
         traffic_source=_load_traffic()[1],
         algorithmic_bytes=alg_bytes,
+        algorithmic_bytes_note="SURVEY.md 8(d), reference-layout accounting (48 B per source point + the reference's bucket table and voxel arrays): internal repacking does not change it",
+        source_stream=("packed private mirror: 36 B per point (12 B point + the 6 floats of the symmetric covariance), three 12-B LDS-DMA rows per 64-point chunk" if mirrored.value == 1
+                       else "the caller's arrays: 12 + 36 B per point, four 12-B LDS-DMA rows per chunk"),
+        actual_bytes=actual_bytes,
+        actual_bytes_note="what the launch requests with perfect reuse of the lookup structures: the source stream as read + 16 B per 4x4x4-voxel block of the map's box + 64-B records + pose and record",
+        frac_actual=round(actual_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        frac_fused_kernel=(round(alg_bytes / (dev_kernel_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if in_step and dev_kernel_us.value > 0 else None),
         kernel_ms=round(kernel_ms, 5),
         kernel_ms_source=(f"measured in THIS run inside the {args.steps} timed steps: the streaming part of the fused kernel (first workgroup started .. last partial row in) on the "
                           "device's 100 MHz constant clock, stamped by the kernel itself (gp_vgicp_batch_device_times); mean over the steps") if in_step

@@ -164,6 +164,9 @@ _SIGNATURES = {
     "gp_vgicp_batch_size": (C.c_int, [C.c_void_p]),
     "gp_vgicp_batch_total_points": (C.c_int64, [C.c_void_p]),
     "gp_vgicp_batch_algorithmic_bytes": (C.c_int64, [C.c_void_p]),
+    "gp_vgicp_batch_actual_bytes": (C.c_int64, [C.c_void_p]),
+    "gp_source_mirror_invalidate": (C.c_int, [C.c_void_p]),
+    "gp_source_mirror_bytes": (C.c_int64, []),
     "gp_vgicp_batch_issue_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_issue_compute_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_sync": (C.c_int, [C.c_void_p]),
@@ -203,6 +206,8 @@ GP_TUNE_XCD_WEIGHT_0 = 8
 GP_TUNE_FUSED_FINALIZE = 17
 GP_TUNE_TILE_CHUNKS = 18
 GP_TUNE_MAX_WORKGROUPS = 19
+GP_TUNE_TEST_ARRIVAL_SKEW = 20
+GP_TUNE_SOURCE_MIRROR, GP_TUNE_EFFECTIVE_MIRROR = 21, 22
 GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32
 KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_STREAM]
 

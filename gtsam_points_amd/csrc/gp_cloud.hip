@@ -14,6 +14,9 @@
 //       float[N][3] / float[N][9] device layout.
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "gp_host.hpp"
@@ -117,6 +120,95 @@ __global__ void __launch_bounds__(256) pack_mat3_kernel(const T* __restrict__ sr
   for (int col = 0; col < 3; col++)
 #pragma unroll
     for (int r = 0; r < 3; r++) dst[9 * i + col * 3 + r] = (float)s[col * src_dim + r];
+}
+
+// the packed mirror of a source cloud (SourceMirror, gp_host.hpp): thread = point; a workgroup writes four 2304-byte chunks.  flag |= 1 when some
+// covariance is not symmetric to the last bit (NaN entries compare unequal and land here as well): such a cloud keeps the API layout.
+__global__ void __launch_bounds__(256) pack_source_mirror_kernel(const float* __restrict__ points, const float* __restrict__ covs, int n, char* __restrict__ dst,
+                                                                 int* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float p[3] = {0.f, 0.f, 0.f}, c[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < (size_t)n) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = points[3 * i + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) c[k] = covs[9 * i + k];
+  }
+  // column-major 3x3: (r, c) = c9[3 c + r]; the kernels read c00, c01 = c9[3], c02 = c9[6], c11 = c9[4], c12 = c9[7], c22 = c9[8] (load_cov6)
+  const bool asym = c[3] != c[1] || c[6] != c[2] || c[7] != c[5];
+  if (__builtin_amdgcn_ballot_w64(asym) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+  float* chunk = reinterpret_cast<float*>(dst + (i >> 6) * (size_t)kMirrorChunkBytes);  // (the last chunk is padded with zeros; the kernels never stream it)
+  const int l = (int)(i & 63);
+  chunk[3 * l + 0] = p[0], chunk[3 * l + 1] = p[1], chunk[3 * l + 2] = p[2];
+  chunk[192 + 3 * l + 0] = c[0], chunk[192 + 3 * l + 1] = c[3], chunk[192 + 3 * l + 2] = c[6];
+  chunk[384 + 3 * l + 0] = c[4], chunk[384 + 3 * l + 1] = c[7], chunk[384 + 3 * l + 2] = c[8];
+}
+
+namespace {
+using MirrorKey = std::tuple<int, const float*, const float*, int>;
+std::recursive_mutex g_mirror_mutex;  // (recursive: a mirror that fails to pack is destroyed under the lock, and its destructor takes it)
+std::map<MirrorKey, std::weak_ptr<SourceMirror>>& mirror_registry() {
+  static auto* m = new std::map<MirrorKey, std::weak_ptr<SourceMirror>>;  // never destroyed: factors may outlive static destruction order
+  return *m;
+}
+std::atomic<long long> g_mirror_bytes{0};
+}  // namespace
+
+SourceMirror::~SourceMirror() {
+  g_mirror_bytes -= (long long)data.bytes;
+  std::lock_guard<std::recursive_mutex> lock(g_mirror_mutex);
+  auto& reg = mirror_registry();
+  auto it = reg.find(MirrorKey{device, points, covs, n});
+  if (it != reg.end() && it->second.expired()) reg.erase(it);
+}
+
+int acquire_source_mirror(const float* points, const float* covs, int n, int device, hipStream_t stream, std::shared_ptr<SourceMirror>* out) {
+  out->reset();
+  if (!points || !covs || n < 64) return GP_OK;
+  std::lock_guard<std::recursive_mutex> lock(g_mirror_mutex);  // (held through the pack: two threads asking for the same cloud get one mirror)
+  auto& reg = mirror_registry();
+  const MirrorKey key{device, points, covs, n};
+  auto it = reg.find(key);
+  if (it != reg.end()) {
+    if (auto live = it->second.lock()) {
+      *out = live;
+      return GP_OK;
+    }
+  }
+  int cur = 0;
+  GP_HIP(hipGetDevice(&cur));
+  if (cur != device) GP_HIP(hipSetDevice(device));
+  auto m = std::make_shared<SourceMirror>();
+  m->points = points, m->covs = covs, m->n = n, m->device = device;
+  const size_t chunks = ((size_t)n + 63) / 64;
+  DeviceArray flag;
+  int rc = m->data.alloc(chunks * (size_t)kMirrorChunkBytes);
+  if (rc == GP_OK) {
+    g_mirror_bytes += (long long)m->data.bytes;
+    rc = flag.alloc_async(sizeof(int), stream);
+  }
+  int h_flag = 1;
+  if (rc == GP_OK) {
+    hipError_t e = hipMemsetAsync(flag.ptr, 0, sizeof(int), stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(pack_source_mirror_kernel, dim3((unsigned)((chunks * 64 + 255) / 256)), dim3(256), 0, stream, points, covs, n, m->data.as<char>(), flag.as<int>());
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flag.ptr, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) rc = hip_fail(e, "pack_source_mirror_kernel", __FILE__, __LINE__);
+  }
+  flag.release_on(stream);
+  if (cur != device) (void)hipSetDevice(cur);
+  if (rc != GP_OK) return rc;
+  m->usable = h_flag == 0;
+  if (!m->usable) {  // nothing will stream it: give the memory back, keep the verdict
+    g_mirror_bytes -= (long long)m->data.bytes;
+    m->data.release();
+  }
+  reg[key] = m;
+  *out = m;
+  return GP_OK;
 }
 
 }  // namespace gp
@@ -272,6 +364,23 @@ int gp_merge_frames(const double* poses, const float* const* points_dev, const f
   *out_map = map;
   return GP_OK;
 }
+
+// an owner is about to rewrite or free device arrays that factors may have mirrored (PointCloudGPU::add_*_gpu on a live cloud, offload_gpu,
+// the destructor): forget every mirror built from `dev_ptr` (as points or covariances), so that a later factor on the same address packs afresh.
+// Factors that still hold such a mirror keep streaming it until gp_vgicp_factor_set_source hands them the new arrays (they borrow the old ones).
+int gp_source_mirror_invalidate(const void* dev_ptr) {
+  if (!dev_ptr) return GP_OK;
+  std::lock_guard<std::recursive_mutex> lock(gp::g_mirror_mutex);
+  auto& reg = gp::mirror_registry();
+  for (auto it = reg.begin(); it != reg.end();) {
+    if (std::get<1>(it->first) == dev_ptr || std::get<2>(it->first) == dev_ptr) it = reg.erase(it);
+    else ++it;
+  }
+  return GP_OK;
+}
+
+// device bytes held by live packed mirrors (all devices): what the factors' memory_usage_gpu() adds on top of the caller's arrays
+int64_t gp_source_mirror_bytes(void) { return (int64_t)gp::g_mirror_bytes.load(); }
 
 int gp_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, gp_stream_t stream) {
   if (bytes == 0) return GP_OK;

@@ -237,6 +237,28 @@ struct PinnedArray {
   }
 };
 
+// Packed private mirror of a source cloud (round 4; gp_cloud.hip).  The VGICP stream kernel uses only the symmetric part of a source covariance, so
+// the API layout's 12 + 36 B per point (types/point_cloud.hpp:114-118, read by include/gtsam_points/cuda/kernels/vgicp_derivatives.cuh:36-50) is
+// repacked once per cloud into 36 B per point, chunk-major: per 64 points 2304 contiguous bytes = 64 x (x, y, z) | 64 x (c00, c01, c02) | 64 x (c11, c12, c22)
+// -- three 768-byte rows, each ONE 12-B-per-lane LDS-DMA instruction.  A mirror is built only when every covariance is symmetric to the last bit
+// (estimate_covariances' output is), so the six floats are the caller's own and records are bit-identical to the unpacked stream; otherwise
+// `usable` is false and the kernels keep the caller's arrays (which carry the (a_ij + a_ji) / 2 symmetrisation in f64).
+// Shared by every factor that reads the same (points, covs, n) -- a submap that is the source of eight factors has ONE mirror, and its re-reads hit L2 --
+// through a registry of weak references: the mirror lives as long as some factor holds it.  The caller's arrays are immutable while a factor borrows
+// them (the reference holds them through PointCloud::ConstPtr); an owner that rewrites or frees them calls gp_source_mirror_invalidate.
+struct SourceMirror {
+  DeviceArray data;
+  const float* points = nullptr;
+  const float* covs = nullptr;
+  int n = 0;
+  int device = 0;
+  bool usable = false;  // false: some covariance is not bit-symmetric (or non-finite): the kernels stream the caller's arrays
+  ~SourceMirror();
+};
+constexpr int kMirrorChunkBytes = 2304;
+// *out: the shared mirror of (points, covs, n) on `device`, packed on `stream` (synchronised before return) when it does not exist yet; null when n < 64
+int acquire_source_mirror(const float* points, const float* covs, int n, int device, hipStream_t stream, std::shared_ptr<SourceMirror>* out);
+
 }  // namespace gp
 
 // TempBufferManager (cuda/stream_temp_buffer_roundrobin.cu:11-47)

@@ -101,6 +101,7 @@ int gp_malloc(void** ptr, size_t bytes) {
 }
 
 int gp_free(void* ptr) {
+  if (ptr) (void)gp_source_mirror_invalidate(ptr);  // the address may be handed out again: no later factor may join a packed mirror built from what lay here
   if (ptr) GP_HIP(hipFree(ptr));
   return GP_OK;
 }

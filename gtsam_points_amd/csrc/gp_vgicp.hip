@@ -463,6 +463,7 @@ struct gp_vgicp_tuning {
                                   // and hands them to the host (InlinePoses: fused finalize) -- no finalize launch.  (The first form of this knob, finalize
                                   // workgroups on a second stream waiting for the counters, cost +10 us per step: profiles/r03_overlap_finalize.jsonl)
   int balance = kDefaultSkewPermille;  // stream kernel, one large factor: how much more a dispatch round takes than the next, in 1/1000 of the mean share (0 = flat)
+  int source_mirror = 1;          // stream family: stream the sources' packed mirrors (36 B per point, gp::SourceMirror) when every factor of the batch has one; 0 = the caller's arrays
 };
 
 struct gp_vgicp_factor {
@@ -479,6 +480,8 @@ struct gp_vgicp_factor {
   bool owns_stream = false;
   gp_temp_buffer* temp_buffer = nullptr;
   bool owns_temp_buffer = false;
+  std::shared_ptr<gp::SourceMirror> mirror;  // packed mirror of (points, covs, n), shared with the other factors on this cloud; acquired by the first table build that wants it
+  bool mirror_tried = false;                 // ... which happened (a cloud of < 64 points has none)
   gp_vgicp_batch* self_batch = nullptr;  // lazily built batch of one, used by the per-factor entry points
   gp_vgicp_tuning tuning;                // what the self batch is created with (gp_vgicp_factor_set_tuning)
 };
@@ -492,6 +495,7 @@ struct gp_vgicp_batch {
   int family = 0;         // GP_KERNEL_* the tile table was built for (tuning.kernel after the fallbacks)
   bool nt = false;        // source stream non-temporal (tuning.source_policy resolved)
   bool any_sv = false;    // some factor validates surfaces
+  bool packed = false;    // every factor streams its packed mirror (vgicp_stream_kernel<PK>)
   bool planned = false;   // stream kernel, one large factor: the tile list is a balanced StreamPlan (else fixed tiles of tile_points)
   gp::StreamPlan plan{};  // ... how the chunks are dealt (also written into the tile table)
   unsigned long long* trace = nullptr;  // timeline build of the tile kernel: [2048][16] uint64 device buffer (gp_vgicp_batch_set_trace_buffer)
@@ -677,6 +681,24 @@ int build_table(gp_vgicp_batch* b) {
   if (fam == GP_KERNEL_STREAM && (!b->use_grid || !offsets32)) fam = GP_KERNEL_LOOKAHEAD;
   if ((fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_GRID_F64) && !b->use_grid) fam = GP_KERNEL_HASHED;
   b->family = fam;
+  // the packed source mirrors (gp::SourceMirror): built once per cloud, here, where a table upload synchronises anyway.  The batch streams them when
+  // EVERY factor with a full chunk has a usable one (a cloud with an unsymmetric covariance has none and keeps the whole batch on the caller's arrays)
+  b->packed = false;
+  if (fam == GP_KERNEL_STREAM && b->tuning.source_mirror) {
+    bool all = F > 0;
+    for (int i = 0; i < F; i++) {
+      gp_vgicp_factor* f = b->factors[i];
+      if (!f->mirror_tried) {
+        GP_TRY(gp::acquire_source_mirror(f->points, f->covs, f->n, f->device, b->stream, &f->mirror));
+        f->mirror_tried = true;
+      }
+      if (f->mirror && f->mirror->usable) descs[i].packed = f->mirror->data.as<char>();
+      else if (f->n >= gp::kChunkPoints) all = false;
+    }
+    b->packed = all;
+  }
+  if (!b->packed)
+    for (auto& d : descs) d.packed = nullptr;
   // tiles
   b->planned = fam == GP_KERNEL_STREAM && F == 1 && descs[0].n >= kPlanMinPoints;
   if (b->planned) {
@@ -818,7 +840,8 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   const int fam = MODE == gp::MODE_LIN_GENERAL ? GP_KERNEL_REFERENCE : b->family;
   const bool single_plan = b->planned;  // the tile list IS the plan: the contiguous map, whatever xcd_chunk says
   // the reference-shaped kernels (the 92-sum path included) keep the contiguous map
-  const int chunk = (fam == GP_KERNEL_REFERENCE || single_plan) ? 0 : b->tuning.xcd_chunk;
+  // ... and so does every in-argument launch of the stream kernel (its fixed-tile branch knows no other map)
+  const int chunk = (fam == GP_KERNEL_REFERENCE || single_plan || (fam == GP_KERNEL_STREAM && ps.inl.use)) ? 0 : b->tuning.xcd_chunk;
   const dim3 grid_dim(grid_tiles(b->num_tiles, chunk)), block(gp::kBlockThreads);
   const gp::FactorDesc* fd = b->d_factors.as<gp::FactorDesc>();
   const gp::TileDesc* td = b->d_tiles.as<gp::TileDesc>();
@@ -835,16 +858,26 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   } else if (fam == GP_KERNEL_REFERENCE) {
     hipLaunchKernelGGL(gp::vgicp_tile_kernel<MODE>, GP_ARGS);
   } else if (fam == GP_KERNEL_STREAM) {
-#define GP_LAUNCH_STREAM(NT, INL, SV, TRACE) hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, NT, INL, SV, TRACE>), GP_ARGS)
-#define GP_LAUNCH_STREAM_S(INL, SV)              \
-  do {                                           \
-    if (b->nt) GP_LAUNCH_STREAM(true, INL, SV, false); \
-    else GP_LAUNCH_STREAM(false, INL, SV, false);      \
+#define GP_LAUNCH_STREAM(NT, INL, SV, PK, TRACE) hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, NT, INL, SV, PK, TRACE>), GP_ARGS)
+#define GP_LAUNCH_STREAM_S(INL, SV)                                  \
+  do {                                                               \
+    if (b->packed) {                                                 \
+      if (b->nt) GP_LAUNCH_STREAM(true, INL, SV, true, false);       \
+      else GP_LAUNCH_STREAM(false, INL, SV, true, false);            \
+    } else {                                                         \
+      if (b->nt) GP_LAUNCH_STREAM(true, INL, SV, false, false);      \
+      else GP_LAUNCH_STREAM(false, INL, SV, false, false);           \
+    }                                                                \
   } while (0)
     if (traced && !b->any_sv) {
       if constexpr (MODE == gp::MODE_LIN) {
-        if (b->nt) GP_LAUNCH_STREAM(true, true, false, true);
-        else GP_LAUNCH_STREAM(false, true, false, true);
+        if (b->packed) {
+          if (b->nt) GP_LAUNCH_STREAM(true, true, false, true, true);
+          else GP_LAUNCH_STREAM(false, true, false, true, true);
+        } else {
+          if (b->nt) GP_LAUNCH_STREAM(true, true, false, false, true);
+          else GP_LAUNCH_STREAM(false, true, false, false, true);
+        }
       }
     } else if (inl.use) {
       if (b->any_sv) GP_LAUNCH_STREAM_S(true, true);
@@ -1030,6 +1063,9 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
       if (value < 0 || value > 64) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_TILE_CHUNKS: 0 (automatic) .. 64 chunks per wave");
       t->tile_chunks = value;
       return GP_OK;
+    case GP_TUNE_SOURCE_MIRROR:
+      t->source_mirror = value ? 1 : 0;
+      return GP_OK;
     case GP_TUNE_BALANCE:
       if (value < -1 || value > 600) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_BALANCE: -1 (automatic), 0 (flat) .. 600 (per mille of the mean share per dispatch round)");
       t->balance = value;
@@ -1077,6 +1113,8 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
     case GP_TUNE_FUSED_FINALIZE: *value = b->tuning.fused_finalize; return GP_OK;
     case GP_TUNE_TILE_CHUNKS: *value = b->tuning.tile_chunks; return GP_OK;
     case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
+    case GP_TUNE_SOURCE_MIRROR: *value = b->tuning.source_mirror; return GP_OK;
+    case GP_TUNE_EFFECTIVE_MIRROR: *value = b->table_dirty ? -1 : (b->packed ? 1 : 0); return GP_OK;  // does the built table stream the packed mirrors?
     default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
   }
 }
@@ -1179,6 +1217,8 @@ int gp_vgicp_factor_set_source(gp_vgicp_factor_t* f, const float* points_dev, co
   f->points = points_dev;
   f->covs = covs_dev;
   f->normals = normals_dev;
+  f->mirror.reset();  // (also the way to say "the arrays were rewritten in place": the next table build packs afresh, or joins the mirror of the new arrays)
+  f->mirror_tried = false;
   f->generation++;
   return GP_OK;
 }
@@ -1320,6 +1360,25 @@ int64_t gp_vgicp_batch_algorithmic_bytes(const gp_vgicp_batch_t* batch) {
   int64_t bytes = 0;
   for (const auto* f : batch->factors)
     bytes += 48ll * f->n + 16ll * f->target->info.num_buckets + 52ll * f->target->info.num_voxels + 560ll + (f->surface_validation ? 12ll * f->n : 0ll);
+  return bytes;
+}
+
+// what one pass of the batch's built table really requests from memory with perfect reuse of the lookup structures: the source stream as the kernel reads it
+// (36 B per point through the packed mirrors, else 48; + 12 with surface validation), every DISTINCT map's block grid (16 B per 4x4x4 voxels of its box) or
+// bucket table and its 64-B records once, pose in and record out.  Beside gp_vgicp_batch_algorithmic_bytes (the reference-layout accounting,
+// which repacking does not change) in bench.py's roofline object.
+int64_t gp_vgicp_batch_actual_bytes(gp_vgicp_batch_t* batch) {
+  if (!batch) return 0;
+  if (table_is_stale(batch) && build_table(batch) != GP_OK) return 0;
+  int64_t bytes = 0;
+  std::vector<const gp_voxelmap*> maps;
+  for (const auto* f : batch->factors) {
+    const int full = batch->packed ? f->n / gp::kChunkPoints * gp::kChunkPoints : 0;  // (the points behind the last full chunk come from the caller's arrays)
+    bytes += 36ll * full + 48ll * (f->n - full) + 560ll + (f->surface_validation && f->normals ? 12ll * f->n : 0ll);
+    if (std::find(maps.begin(), maps.end(), f->target) == maps.end()) maps.push_back(f->target);
+  }
+  for (const auto* m : maps)
+    bytes += 64ll * m->info.num_voxels + (m->has_grid && batch->use_grid ? 16ll * m->gdim[0] * m->gdim[1] * m->gdim[2] : 16ll * m->info.num_buckets);
   return bytes;
 }
 

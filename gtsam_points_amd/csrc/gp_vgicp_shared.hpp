@@ -14,6 +14,7 @@ struct FactorDesc {
   const float* points;   // [n][3]
   const float* covs;     // [n][9]
   const float* normals;  // [n][3] or null
+  const char* packed;    // the source's packed mirror (gp::SourceMirror: 2304 B per 64-point chunk) or null: what vgicp_stream_kernel<PK> streams instead of points / covs
   VoxelMapView map;
   int n;
   int surface_validation;

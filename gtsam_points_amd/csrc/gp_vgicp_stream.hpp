@@ -138,15 +138,22 @@ __device__ __forceinline__ void finalize_part_error(const double* __restrict__ p
   asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(flag), "v"(seq) : "memory");
 }
 
-template <int MODE, bool NT, bool INL, bool SV, bool TRACE = false>
+template <int MODE, bool NT, bool INL, bool SV, bool PK, bool TRACE = false>
 __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                                double* __restrict__ partials) {
   static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "rigid linearise and error evaluation");
   constexpr int NACC = MODE == MODE_ERR ? 2 : 32;
-  constexpr int K = 4 + (SV ? 1 : 0);  // vector-memory requests per chunk: points (+ normals) + 3 covariance rows
+  // PK: the source stream is the factor's PACKED MIRROR (SourceMirror, gp_host.hpp): per 64-point chunk 2304 contiguous bytes = 64 points (12 B) | 64 x
+  // (c00, c01, c02) | 64 x (c11, c12, c22) -- the symmetric covariance the algebra uses, 36 B per point instead of the API layout's 48: three 12-B DMA rows
+  // per chunk instead of four, and no symmetry test.  Built only from covariances that are symmetric to the last bit, so the six floats ARE the
+  // caller's: records are bit-identical to the unpacked stream (tests/test_vgicp_gpu.py::test_packed_mirror_is_bit_identical).
+  constexpr int KC = PK ? 2 : 3;                // covariance rows per chunk
+  constexpr int K = 1 + KC + (SV ? 1 : 0);      // vector-memory requests per chunk: points (+ normals) + covariance rows
   constexpr int kNrmSlotBytes = SV ? kPtsSlotBytes : 0;
-  constexpr int kWaveBytes = SV ? 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + 2 * kCovSlotBytes : kWaveLdsBytes;  // 10 KB with normals, else 8.5 KB
+  constexpr int kChunkSlotBytes = PK ? kCovSlotBytes : kPtsSlotBytes + kCovSlotBytes;  // one chunk of the ring: 3 KB packed (points in its first KB), else 1 + 3 KB
+  constexpr int kRingBytes = 2 * kChunkSlotBytes + 2 * kNrmSlotBytes;
+  constexpr int kWaveBytes = kRingBytes > kWaveLdsBytes ? kRingBytes : kWaveLdsBytes;  // 10 KB for the unpacked stream with normals, else 8.5 KB (the reduction's)
   static_assert(kWaveBytes >= kWaveLdsBytes, "the reduction needs 8.5 KB of the wave's region");
   __shared__ __attribute__((aligned(16))) char smem[4 * kWaveBytes];
   const unsigned long long t_begin = INL ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz constant clock; used by the fused form's own time stamps (below)
@@ -166,16 +173,19 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     const float* fpts = inl.factor.points;
     const float* fcov = inl.factor.covs;
     const float* fnrm = inl.factor.normals;
+    const char* fpk = inl.factor.packed;
     asm volatile("" : "+s"(pf.nr), "+s"(pf.pre), "+s"(pf.lo), "+s"(pf.extra), "+s"(pf.xbegin), "+s"(pf.L), "+s"(pf.before_last), "+s"(pf.gx), "+s"(pf.tail), "+s"(tile_points),
-                 "+s"(fn), "+s"(fpts), "+s"(fcov), "+s"(fnrm));
+                 "+s"(fn), "+s"(fpts), "+s"(fcov), "+s"(fnrm), "+s"(fpk));
     int begin, count;
     if (tile_points == 0) {  // one large factor: the tile list is the StreamPlan
       tile_idx = bx * pf.gx + bq;
       plan_tile(pf, bx, bq, &begin, &count);
     } else {  // fixed tiles of tile_points
+      // (the in-argument launch always uses the contiguous map, whatever xcd_chunk says; a grid rounded up for another map must not run a tile twice:
+      // the fused finalize counts arrivals -- ADVICE r03)
       const int per = (num_tiles + kNumXCD - 1) / kNumXCD;
       tile_idx = bx * per + bq;
-      if (tile_idx >= num_tiles) return;
+      if (bq >= per || tile_idx >= num_tiles) return;
       begin = tile_idx * tile_points;
       count = min(tile_points, fn - begin);
     }
@@ -183,6 +193,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     f.points = fpts;
     f.covs = fcov;
     f.normals = fnrm;
+    f.packed = fpk;
     row = tile_idx;
     ww = split_tile(begin, count, wave);
   } else {
@@ -206,7 +217,8 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     // fused form: the first workgroup of every XCD leaves its start time in the part's host slot (word 34), fire and forget; the parts' finalizers add when
     // their last row was in (32) and when their sums left (33).  The host turns the three into the duration of the streaming part and of the
     // whole kernel as THIS step ran it (gp_vgicp_batch_device_times): the step's own clock, no events, no profiler
-    if (inl.arrive && blockIdx.x < kNumXCD && threadIdx.x == 0)
+    // (parts form only: in the by-factor form fin_out slot i is factor i's record, not a part's scratch slot)
+    if (inl.arrive && inl.rows_per_part > 0 && blockIdx.x < kNumXCD && threadIdx.x == 0)
       asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(inl.fin_out + (size_t)blockIdx.x * inl.fin_stride + 34), "v"(t_begin) : "memory");
   }
   if constexpr (TRACE) {
@@ -221,19 +233,26 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   const int tail = __builtin_amdgcn_readfirstlane(ww.tail);
   const size_t first = ww.first;
   char* wbase = smem + wave * kWaveBytes;
-  auto pslot = [&](int par) { return wbase + par * kPtsSlotBytes; };
-  auto nslot = [&](int par) { return wbase + 2 * kPtsSlotBytes + par * kNrmSlotBytes; };
-  auto cslot = [&](int par) { return wbase + 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + par * kCovSlotBytes; };
-  const GP_GLOBAL char* upts = uniform_ptr((const GP_GLOBAL char*)as_global(f.points) + 12 * first);
-  const GP_GLOBAL char* ucov = uniform_ptr((const GP_GLOBAL char*)as_global(f.covs) + 36 * first);
+  // ring layout of a wave.  Unpacked: [points 0 | points 1 | normals 0 | normals 1 | covariances 0 | covariances 1]; packed: [chunk 0 | chunk 1 | normals 0 |
+  // normals 1] with a chunk = [points | (c00, c01, c02) | (c11, c12, c22)], 1 KB each
+  auto pslot = [&](int par) { return PK ? wbase + par * kCovSlotBytes : wbase + par * kPtsSlotBytes; };
+  auto nslot = [&](int par) { return PK ? wbase + 2 * kCovSlotBytes + par * kNrmSlotBytes : wbase + 2 * kPtsSlotBytes + par * kNrmSlotBytes; };
+  auto cslot = [&](int par) { return PK ? wbase + par * kCovSlotBytes : wbase + 2 * kPtsSlotBytes + 2 * kNrmSlotBytes + par * kCovSlotBytes; };
+  // (a wave's first point is a multiple of 64 in every tile list: plan shares, fixed tiles and split_tile all deal whole chunks)
+  const GP_GLOBAL char* upts = PK ? uniform_ptr((const GP_GLOBAL char*)f.packed + (first >> 6) * (size_t)kPackedChunkBytes) : uniform_ptr((const GP_GLOBAL char*)as_global(f.points) + 12 * first);
+  const GP_GLOBAL char* ucov = PK ? upts : uniform_ptr((const GP_GLOBAL char*)as_global(f.covs) + 36 * first);
   const GP_GLOBAL char* unrm = SV ? uniform_ptr((const GP_GLOBAL char*)as_global(f.normals) + 12 * first) : nullptr;
   const unsigned voff = (unsigned)lane * 12u;
+  constexpr size_t kSrcChunkStride = PK ? (size_t)kPackedChunkBytes : (size_t)kChunkPoints * 12, kCovChunkStride = PK ? (size_t)kPackedChunkBytes : (size_t)kChunkPoints * 36;
   // requests of chunk j (its rows start j * 64 points behind the wave's first point); par = j & 1 = which half of the ring
   auto dma_head = [&](int j, int par) {  // what the front half of a chunk reads: its points (and normals)
-    chunk_dma12_pts<NT>(upts + (size_t)j * (kChunkPoints * 12), voff, pslot(par));
+    chunk_dma12_pts<NT>(upts + (size_t)j * kSrcChunkStride, voff, pslot(par));
     if constexpr (SV) chunk_dma12_row<NT>(unrm + (size_t)j * (kChunkPoints * 12), voff, nslot(par));
   };
-  auto dma_cov = [&](int j, int par) { chunk_dma12_cov<NT>(ucov + (size_t)j * (kChunkPoints * 36), voff, cslot(par)); };
+  auto dma_cov = [&](int j, int par) {
+    if constexpr (PK) chunk_dma12_cov_packed<NT>(ucov + (size_t)j * kCovChunkStride, voff, cslot(par));
+    else chunk_dma12_cov<NT>(ucov + (size_t)j * kCovChunkStride, voff, cslot(par));
+  };
 
   if (n > 0) dma_head(0, 0);
 
@@ -317,10 +336,16 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   };
   // the covariance of this lane's point out of the ring (three 12-B columns), symmetrised like load_cov6 does
   auto cov_ring = [&](int par, double* a) {
-    const char* c = cslot(par) + 48 * lane;
-    const v3f c0 = *reinterpret_cast<const v3f*>(c), c1 = *reinterpret_cast<const v3f*>(c + 16), c2 = *reinterpret_cast<const v3f*>(c + 32);
-    const float c9[9] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z};
-    load_cov6(c9, a);
+    if constexpr (PK) {  // the six floats of the symmetric matrix: rows 1 and 2 of the chunk, one conflict-free ds_read_b96 each
+      const char* c = cslot(par) + 16 * lane;
+      const v3f ca = *reinterpret_cast<const v3f*>(c + kPtsSlotBytes), cb = *reinterpret_cast<const v3f*>(c + 2 * kPtsSlotBytes);
+      a[0] = (double)ca.x, a[1] = (double)ca.y, a[2] = (double)ca.z, a[3] = (double)cb.x, a[4] = (double)cb.y, a[5] = (double)cb.z;
+    } else {
+      const char* c = cslot(par) + 48 * lane;
+      const v3f c0 = *reinterpret_cast<const v3f*>(c), c1 = *reinterpret_cast<const v3f*>(c + 16), c2 = *reinterpret_cast<const v3f*>(c + 32);
+      const float c9[9] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z};
+      load_cov6(c9, a);
+    }
   };
 
   Ahead Pc;  // the chunk whose record has landed (front half and lookup done)
@@ -341,14 +366,14 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     front_ring(0, Pc);  // in flight: H0
     dma_cov(0, 0);
     const bool has1 = n > 1;
-    if (has1) dma_head(1, 1);  // in flight: H0, C0 x3, head of chunk 1 (K - 3 requests)
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (has1) dma_head(1, 1);  // in flight: H0, C0 x KC, head of chunk 1 (K - KC requests)
+    else vm_wait<KC>();
     vm_wait_blk_n<K>(Pc.blk);
     GP_TRACE(2);
     bool hit = back_issue(Pc, head, c01, c23, c45);
-    if (has1) dma_cov(1, 1);  // [C0 x3, head 1, R0 x4, C1 x3]
+    if (has1) dma_cov(1, 1);  // [C0 x KC, head 1, R0 x4, C1 x KC]
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    vm_wait_rec<3>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the head of chunk 1 (C1 may still travel: it is older than
+    vm_wait_rec<KC>(head, c01, c23, c45);  // the record, the covariances of chunk 0 and the head of chunk 1 (C1 may still travel: it is older than
                                           // the next hop 1, whose wait below retires it)
     // steady state, rotated: the body starts where the record of chunk j has landed and ends where the record of chunk j+1 has.
     //   front half of chunk j+1 (its hop 1 travels under the algebra below) -> covariance of chunk j out of LDS -> chunk j+2 requested into the

@@ -121,6 +121,38 @@ __device__ __forceinline__ void chunk_dma12_cov(const GP_GLOBAL char* ucov, unsi
   }
 }
 
+// the covariance rows of a PACKED chunk (SourceMirror: [64 points | 64 x (c00, c01, c02) | 64 x (c11, c12, c22)], 768 B each): rows 1 and 2 of the
+// chunk at `uchunk` into the second and third KB of the chunk's 3 KB slot (M0 = slot + 256 k for the row at instruction offset 768 k, as above)
+constexpr int kPackedChunkBytes = 2304;
+template <bool NT>
+__device__ __forceinline__ void chunk_dma12_cov_packed(const GP_GLOBAL char* uchunk, unsigned voff, char* slot) {
+  const unsigned lds_c1 = (unsigned)(size_t)(GP_LDS char*)slot + 256u, lds_c2 = lds_c1 + 256u;
+  unsigned saved;
+  if constexpr (NT) {
+    asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:768 nt\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:1536 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(voff), "s"(uchunk), "s"(lds_c1), "s"(lds_c2)
+      : "memory");
+  } else {
+    asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:768\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "global_load_lds_dwordx3 %1, %2 offset:1536\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(saved)
+      : "v"(voff), "s"(uchunk), "s"(lds_c1), "s"(lds_c2)
+      : "memory");
+  }
+}
+
 // 24-bit multiply-add (the block grid has < 2^24 blocks): hipcc turned __umul24(a, b) + c into a v_mad_u64_u32
 __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
   unsigned r;
@@ -147,10 +179,11 @@ __device__ __forceinline__ void vm_wait() {
   static_assert(N >= 0 && N <= 8, "counts used by the schedules below");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  static_assert(N == 0 || N == 1 || N == 3 || N == 4 || N == 7, "add the count");
+  static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 7, "add the count");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait_blk(v4i& blk) {
@@ -163,9 +196,10 @@ __device__ __forceinline__ void vm_wait_blk(v4i& blk) {
 template <int N>
 __device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& c45) {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
   if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(head), "+v"(c01), "+v"(c23), "+v"(c45) : : "memory");
-  static_assert(N == 0 || N == 3 || N == 4, "add the count");
+  static_assert(N == 0 || N == 2 || N == 3 || N == 4, "add the count");
 }
 
 // M = (C_B + R C_A R^T)^-1 in f64 and the 29 sums in f32: accumulate_core of gp_vgicp_tile.hpp with one Newton step behind the

@@ -75,6 +75,20 @@ class PointCloudGPU(OffloadableGPU):
         if intensities is not None:
             self.add_intensities(intensities)
 
+    def _forget_mirrors(self, attr):
+        """The device tensor of `attr` is about to be replaced or dropped and torch may hand its address out again: the library must not let a later
+        factor join a packed source mirror built from the old contents (gp_source_mirror_invalidate, include/gtsam_points_hip.h)."""
+        t = getattr(self, attr + "_gpu", None)
+        if t is not None and attr in ("points", "covs"):
+            try:
+                self._lib().gp_source_mirror_invalidate(C.c_void_p(t.data_ptr()))
+            except Exception:  # interpreter shutdown
+                pass
+
+    def __del__(self):
+        for a in ("points", "covs"):
+            self._forget_mirrors(a)
+
     def _upload(self, a, width):
         import torch
 
@@ -120,6 +134,7 @@ class PointCloudGPU(OffloadableGPU):
         return isinstance(a, torch.Tensor)  # (numpy >= 2 arrays also carry a .device attribute)
 
     def add_points(self, points):  # add_points_gpu, types/point_cloud_gpu.cu:110-140 (D in {3,4})
+        self._forget_mirrors("points")
         if self._is_tensor(points):
             self.points_gpu = self._upload(points[:, :3], 3)
         else:
@@ -129,8 +144,10 @@ class PointCloudGPU(OffloadableGPU):
         self.generation += 1
 
     def add_covs(self, covs):  # add_covs_gpu: (N,3,3) or (N,4,4); (N,9) = already column-major rows
+        self._forget_mirrors("covs")
         if self._is_tensor(covs):
             self.covs_gpu = self._upload(covs, 9)
+            self.generation += 1
             return
         c = np.asarray(covs)
         self.covs_gpu = self._upload(c, 9) if c.ndim == 2 else self._pack_upload(c, matrix=True)
@@ -208,6 +225,7 @@ class PointCloudGPU(OffloadableGPU):
             if getattr(self, a + "_gpu") is not None:
                 if self._host.get(a) is None:
                     self._host[a] = self.download(a)
+                self._forget_mirrors(a)
                 setattr(self, a + "_gpu", None)
         self.generation += 1
         return True

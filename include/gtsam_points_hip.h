@@ -237,6 +237,14 @@ int gp_vgicp_factor_set_surface_validation(gp_vgicp_factor_t* f, int enable); /*
 /* the source cloud's device arrays moved (PointCloudGPU::offload_gpu + reload_gpu, types/point_cloud_gpu.cu:304-370):
  * hand the factor the new pointers; every batch holding the factor rebuilds its table on the next issue */
 int gp_vgicp_factor_set_source(gp_vgicp_factor_t* f, const float* points_dev, const float* covs_dev, const float* normals_dev);
+/* Packed source mirrors.  The stream kernels read a private 36-B-per-point repack of (points_dev, covs_dev) -- replaces the per-point reads of
+ * include/gtsam_points/cuda/kernels/vgicp_derivatives.cuh:36-50 -- built once per cloud at a factor's first table build and shared by every factor
+ * on the same (points_dev, covs_dev, num_points).  The borrowed arrays are therefore IMMUTABLE while a factor holds them (the reference holds them through
+ * PointCloud::ConstPtr).  An owner that rewrites them in place, or frees them while the address may be handed out again, calls
+ * gp_source_mirror_invalidate(ptr) (forget mirrors built from ptr, so that later factors pack afresh) and gp_vgicp_factor_set_source on the factors
+ * that keep using the cloud (same or new pointers: the factor drops its mirror and packs again).  gp_source_mirror_bytes: device bytes of all live mirrors. */
+int gp_source_mirror_invalidate(const void* dev_ptr);
+int64_t gp_source_mirror_bytes(void);
 int gp_vgicp_factor_set_inlier_update_thresh(gp_vgicp_factor_t* f, double trans, double angle); /* kept for API parity; every linearise rescans all points */
 int gp_vgicp_factor_num_points(const gp_vgicp_factor_t* f);
 int gp_vgicp_factor_device(const gp_vgicp_factor_t* f); /* the device the source arrays live on */
@@ -272,6 +280,10 @@ int gp_vgicp_batch_destroy(gp_vgicp_batch_t* batch);
 int gp_vgicp_batch_size(const gp_vgicp_batch_t* batch);
 int64_t gp_vgicp_batch_total_points(const gp_vgicp_batch_t* batch);
 int64_t gp_vgicp_batch_algorithmic_bytes(const gp_vgicp_batch_t* batch); /* sum 48 N + 16 buckets + 52 voxels + 560 */
+/* what a pass of the batch's built table really requests with perfect reuse of the lookup structures: the source stream as the kernel reads it (36 B per point
+ * through the packed mirrors, GP_TUNE_SOURCE_MIRROR, else 48; + 12 with surface validation), each distinct map's block grid (or bucket table) and 64-B records once,
+ * pose in, record out.  Reported beside the algorithmic figure, which internal repacking does not change. */
+int64_t gp_vgicp_batch_actual_bytes(gp_vgicp_batch_t* batch);
 /* asynchronous on the batch stream; poses_host = double[F][16]; out_dev = gp_linearized6[F] in device memory */
 int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_dev);
 int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* batch, const double* poses_lin_host, const double* poses_eval_host, double* out_dev);
@@ -464,6 +476,10 @@ enum {
   GP_TUNE_TEST_ARRIVAL_SKEW = 20, /* test hook (batches only): puts the host's count of arrival counter 0 `value` ahead of the device's, as a lost launch would; the next fused
                                    step must notice that its completion words do not arrive, reset the counters and finish through the finalize kernel */
   GP_TUNE_MAX_WORKGROUPS = 19,  /* stream family, one large factor: workgroups of the planned launch, 8 .. 1024 (default 1024 = one resident round) */
+  GP_TUNE_SOURCE_MIRROR = 21,   /* stream family: 1 (default) = the kernels stream the sources' packed private mirrors (36 B per point: 12 B point + the six floats of the
+                                   symmetric covariance, chunk-major; built once per cloud at the first table build, shared by all factors on the cloud, only from
+                                   covariances that are symmetric to the last bit -- records are bit-identical to 0 = the caller's arrays (12 + 36 B per point) */
+  GP_TUNE_EFFECTIVE_MIRROR = 22,/* read-only: 1 when the batch's current table streams the packed mirrors (-1 before the first pass) */
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */
