@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(256) pack_mat3_kernel(const T* __restrict__ sr
 __global__ void __launch_bounds__(256) pack_source_mirror_kernel(const float* __restrict__ points, const float* __restrict__ covs, int n, char* __restrict__ dst,
                                                                  int* __restrict__ flag) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if ((i >> 6) >= ((size_t)n + 63) / 64) return;  // whole waves behind the last chunk (the grid is rounded up to four chunks per workgroup)
   float p[3] = {0.f, 0.f, 0.f}, c[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < (size_t)n) {
 #pragma unroll

@@ -571,11 +571,14 @@ struct PoseSource {
 // (StreamPlan, gp_vgicp_shared.hpp).  At most one resident round of workgroups whatever n is.
 //   skew_permille   how much more a dispatch round takes than the next one, in 1/1000 of the mean share (0 = flat split)
 //   xcd_weights     per-XCD share in 1/1000 of the mean share (1000 = equal), or null = kXcdWeightPermille
-// Measured on MI355X (round 3, per-workgroup timelines of the 1 M-point headline): the workgroups of XCDs 4-7 START 0.3-0.7 us behind those of
-// XCD 0 (the dispatcher reaches them later) and end as much later -- the "XCD spread" round 2 saw.  Giving them 3-8 % smaller shares did NOT
-// move the kernel's duration beyond noise (11.54 / 11.56 / 11.64 / 11.41 us for four tables, profiles/r03_sweep_xcd_weights.jsonl): the
-// shares stay equal, the knob stays (GP_TUNE_XCD_WEIGHT_0 + x).
-constexpr int kXcdWeightPermille[gp::kNumXCD] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};
+// Measured on MI355X (round 4, scripts/r04_instep_xcd.py: per-workgroup start / end stamps of the 1 M-point headline INSIDE synchronous steps, i.e. behind
+// an idle queue -- the pattern every synchronous call runs in): the command processor hands the dispatch to the XCDs one after the other, in the order
+// 0, 1, 2, 3, 7, 6, 5, 4: XCD 1 starts 0.17 us behind XCD 0, XCD 3 0.5 us, XCD 7 0.6-0.9, XCD 4 1.1-1.5 us (two boxes) -- and with equal shares they END
+// as much later: XCDs 0-3 at 10.4-11.3 us, XCD 4 at 12.8.  (Back to back the offsets are 0.3-0.7 us, which is why round 3's weights, measured back
+// to back, moved nothing.)  A workgroup's life is ~3.7 us of fill and drain + ~6 us that scale with its share, so the shares that equalise the ends are
+// 1 + (mean offset - offset) / 6 us: the table below (mean of the two boxes' offsets).  Last end 12.8 -> 11.8-11.9 us in the traced build.
+// GP_TUNE_XCD_WEIGHT_0 + x overrides.
+constexpr int kXcdWeightPermille[gp::kNumXCD] = {1090, 1070, 1045, 1025, 905, 935, 950, 980};
 int make_stream_plan(int n, int skew_permille, const int* xcd_weights, gp::StreamPlan* p, int max_wgs = kResidentWorkgroups) {
   const int C = n / gp::kChunkPoints;
   const int G = std::min(std::max(gp::kNumXCD, max_wgs / gp::kNumXCD * gp::kNumXCD), (std::max((C + 3) / 4, 1) + gp::kNumXCD - 1) / gp::kNumXCD * gp::kNumXCD);

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   const Pose Te = MODE == MODE_ERR ? (INL ? load_pose(inl.eval) : load_pose(poses_eval + 16 * (size_t)factor_idx)) : Tl;
   const double leaf = uniform_f64(f.map.leaf), inv_leaf = uniform_f64(f.map.inv_leaf), half_leaf = uniform_f64(0.5 * f.map.leaf);
   const int glo0 = f.map.glo[0], glo1 = f.map.glo[1], glo2 = f.map.glo[2];
-  const unsigned gd0 = (unsigned)f.map.gdim[0], gd1 = (unsigned)f.map.gdim[1], gd2 = (unsigned)f.map.gdim[2];
+  const unsigned gd0 = __builtin_amdgcn_readfirstlane((unsigned)f.map.gdim[0]), gd1 = __builtin_amdgcn_readfirstlane((unsigned)f.map.gdim[1]), gd2 = (unsigned)f.map.gdim[2];
   const GP_GLOBAL char* gblocks = uniform_ptr((const GP_GLOBAL char*)f.map.gblocks);
   const GP_GLOBAL char* records = uniform_ptr((const GP_GLOBAL char*)f.map.records);
 
@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   };
   // front half: transform, (surface validation,) voxel coordinate, hop 1 issued
   auto front = [&](float pxf, float pyf, float pzf, float nxf, float nyf, float nzf, bool active, Ahead& P) {
+#pragma clang fp contract(off)  // (every instantiation computes the same bits: the fused multiply-adds are the ones written out)
     const double dx = (double)pxf, dy = (double)pyf, dz = (double)pzf;
     const double lx = __builtin_fma(Tl.r00, dx, __builtin_fma(Tl.r01, dy, __builtin_fma(Tl.r02, dz, tvx)));
     const double ly = __builtin_fma(Tl.r10, dx, __builtin_fma(Tl.r11, dy, __builtin_fma(Tl.r12, dz, tvy)));
@@ -290,7 +291,9 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     const double ux = lx * inv_leaf, uy = ly * inv_leaf, uz = lz * inv_leaf;
     const int cx = (int)__builtin_floor(ux), cy = (int)__builtin_floor(uy), cz = (int)__builtin_floor(uz);
     if constexpr (MODE == MODE_ERR) {
-      const double ex_ = Te.r00 * dx + Te.r01 * dy + Te.r02 * dz + Te.tx, ey_ = Te.r10 * dx + Te.r11 * dy + Te.r12 * dz + Te.ty, ez_ = Te.r20 * dx + Te.r21 * dy + Te.r22 * dz + Te.tz;
+      const double ex_ = __builtin_fma(Te.r00, dx, __builtin_fma(Te.r01, dy, __builtin_fma(Te.r02, dz, Te.tx)));
+      const double ey_ = __builtin_fma(Te.r10, dx, __builtin_fma(Te.r11, dy, __builtin_fma(Te.r12, dz, Te.ty)));
+      const double ez_ = __builtin_fma(Te.r20, dx, __builtin_fma(Te.r21, dy, __builtin_fma(Te.r22, dz, Te.tz)));
       P.ex = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(ux), half_leaf) + (lx - ex_));
       P.ey = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(uy), half_leaf) + (ly - ey_));
       P.ez = (float)(__builtin_fma(-leaf, __builtin_amdgcn_fract(uz), half_leaf) + (lz - ez_));
@@ -308,14 +311,15 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
       // lookup_voxels.cuh:41-50: reject when normalized(q) . (R n) > cos(80 deg), at the LINEARISATION pose (the error evaluation keeps the
       // correspondences of the linearise, vgicp_derivatives.cuh:85-139).  s / |q| > c  <=>  s > 0 and s^2 > c^2 |q|^2: no square root, no division
       const double nx = (double)nxf, ny = (double)nyf, nz = (double)nzf;
-      const double tnx = Tl.r00 * nx + Tl.r01 * ny + Tl.r02 * nz, tny = Tl.r10 * nx + Tl.r11 * ny + Tl.r12 * nz, tnz = Tl.r20 * nx + Tl.r21 * ny + Tl.r22 * nz;
-      const double s = lx * tnx + ly * tny + lz * tnz;
-      const double qq = lx * lx + ly * ly + lz * lz;
+      const double tnx = __builtin_fma(Tl.r02, nz, __builtin_fma(Tl.r01, ny, Tl.r00 * nx)), tny = __builtin_fma(Tl.r12, nz, __builtin_fma(Tl.r11, ny, Tl.r10 * nx));
+      const double tnz = __builtin_fma(Tl.r22, nz, __builtin_fma(Tl.r21, ny, Tl.r20 * nx));
+      const double s = __builtin_fma(lz, tnz, __builtin_fma(ly, tny, lx * tnx));
+      const double qq = __builtin_fma(lz, lz, __builtin_fma(ly, ly, lx * lx));
       if (s > 0.0 && s * s > (0.174 * 0.174) * qq) live = false;
     }
     const unsigned bx = (unsigned)((cx >> 2) - glo0), by = (unsigned)((cy >> 2) - glo1), bz = (unsigned)((cz >> 2) - glo2);
     const bool inbox = (bx < gd0) & (by < gd1) & (bz < gd2);
-    const unsigned lin = inbox ? mad24(mad24(bz, gd1, by), gd0, bx) : 0u;  // < 2^24 blocks
+    const unsigned lin = inbox ? mad24s(mad24s(bz, gd1, by), gd0, bx) : 0u;  // < 2^24 blocks
     P.pos = (inbox && live) ? (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3)) : -1;
     grid_issue_s(gblocks, lin * 16u, P.blk);
   };

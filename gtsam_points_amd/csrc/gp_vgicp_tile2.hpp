@@ -160,6 +160,13 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
   return r;
 }
 
+// ... with a wave-uniform multiplier straight out of an SGPR (a VOP3 instruction reads one scalar operand; the "v" form cost a v_mov per use)
+__device__ __forceinline__ unsigned mad24s(unsigned a, unsigned b_uniform, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+
 // saddr-form lookups: wave-uniform base in an SGPR pair, 32-bit byte offset per lane
 __device__ __forceinline__ void grid_issue_s(const GP_GLOBAL char* base, unsigned off, v4i& blk) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(blk) : "v"(off), "s"(base) : "memory");
@@ -203,36 +210,46 @@ __device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& 
 }
 
 // M = (C_B + R C_A R^T)^-1 in f64 and the 29 sums in f32: accumulate_core of gp_vgicp_tile.hpp with one Newton step behind the
-// hardware reciprocal (v_rcp_f64 is good to ~2^-23, one step gives 2^-46)
+// hardware reciprocal (v_rcp_f64 is good to ~2^-23, one step gives 2^-46).
+// Round 4: the steady state of the stream kernel is VALU-bound (240 vector instructions per 64-point chunk; f64 instructions issue in 4 cycles, f32 in 2 --
+// profiles/r01_microbench.txt -- ~750 cycles per chunk and SIMD, 7 of the launch's 10.5 us), and every instantiation must compute the same bits (the packed
+// and the unpacked stream, with and without surface validation: tests/test_mirror_gpu.py), so the arithmetic is spelled out instruction by instruction:
+// `#pragma clang fp contract(off)` + explicit fused multiply-adds in exactly the places hipcc's contraction had put them.  Two cheaper forms were measured and
+// dropped: cofactors x (1 / det) in f32 (-1 % cycles; the record moved 6e-8 against the round-2 kernel), and the sums' products added straight into the
+// accumulators (see below).
 template <int MODE>
 __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a, const v2d& c01, const v2d& c23, const v2d& c45, float RX, float RY, float RZ, float QX,
                                                  float QY, float QZ, float* acc) {
+#pragma clang fp contract(off)
   float M0, M1, M2, M3, M4, M5;
   {
     const double a00 = a[0], a01 = a[1], a02 = a[2], a11 = a[3], a12 = a[4], a22 = a[5];
-    const double rc00 = Tl.r00 * a00 + Tl.r01 * a01 + Tl.r02 * a02, rc01 = Tl.r00 * a01 + Tl.r01 * a11 + Tl.r02 * a12, rc02 = Tl.r00 * a02 + Tl.r01 * a12 + Tl.r02 * a22;
-    const double rc10 = Tl.r10 * a00 + Tl.r11 * a01 + Tl.r12 * a02, rc11 = Tl.r10 * a01 + Tl.r11 * a11 + Tl.r12 * a12, rc12 = Tl.r10 * a02 + Tl.r11 * a12 + Tl.r12 * a22;
-    const double rc20 = Tl.r20 * a00 + Tl.r21 * a01 + Tl.r22 * a02, rc21 = Tl.r20 * a01 + Tl.r21 * a11 + Tl.r22 * a12, rc22 = Tl.r20 * a02 + Tl.r21 * a12 + Tl.r22 * a22;
-    const double s00 = c01.x + rc00 * Tl.r00 + rc01 * Tl.r01 + rc02 * Tl.r02;
-    const double s01 = c01.y + rc00 * Tl.r10 + rc01 * Tl.r11 + rc02 * Tl.r12;
-    const double s02 = c23.x + rc00 * Tl.r20 + rc01 * Tl.r21 + rc02 * Tl.r22;
-    const double s11 = c23.y + rc10 * Tl.r10 + rc11 * Tl.r11 + rc12 * Tl.r12;
-    const double s12 = c45.x + rc10 * Tl.r20 + rc11 * Tl.r21 + rc12 * Tl.r22;
-    const double s22 = c45.y + rc20 * Tl.r20 + rc21 * Tl.r21 + rc22 * Tl.r22;
-    const double i00 = s11 * s22 - s12 * s12, i01 = s02 * s12 - s01 * s22, i02 = s01 * s12 - s02 * s11;
-    const double det = s00 * i00 + s01 * i01 + s02 * i02;
+    const auto dot3 = [](double x0, double y0, double x1, double y1, double x2, double y2) { return __builtin_fma(x2, y2, __builtin_fma(x1, y1, x0 * y0)); };
+    const auto dot3p = [](double c, double x0, double y0, double x1, double y1, double x2, double y2) { return __builtin_fma(x2, y2, __builtin_fma(x1, y1, __builtin_fma(x0, y0, c))); };
+    const double rc00 = dot3(Tl.r00, a00, Tl.r01, a01, Tl.r02, a02), rc01 = dot3(Tl.r00, a01, Tl.r01, a11, Tl.r02, a12), rc02 = dot3(Tl.r00, a02, Tl.r01, a12, Tl.r02, a22);
+    const double rc10 = dot3(Tl.r10, a00, Tl.r11, a01, Tl.r12, a02), rc11 = dot3(Tl.r10, a01, Tl.r11, a11, Tl.r12, a12), rc12 = dot3(Tl.r10, a02, Tl.r11, a12, Tl.r12, a22);
+    const double rc20 = dot3(Tl.r20, a00, Tl.r21, a01, Tl.r22, a02), rc21 = dot3(Tl.r20, a01, Tl.r21, a11, Tl.r22, a12), rc22 = dot3(Tl.r20, a02, Tl.r21, a12, Tl.r22, a22);
+    const double s00 = dot3p(c01.x, rc00, Tl.r00, rc01, Tl.r01, rc02, Tl.r02);
+    const double s01 = dot3p(c01.y, rc00, Tl.r10, rc01, Tl.r11, rc02, Tl.r12);
+    const double s02 = dot3p(c23.x, rc00, Tl.r20, rc01, Tl.r21, rc02, Tl.r22);
+    const double s11 = dot3p(c23.y, rc10, Tl.r10, rc11, Tl.r11, rc12, Tl.r12);
+    const double s12 = dot3p(c45.x, rc10, Tl.r20, rc11, Tl.r21, rc12, Tl.r22);
+    const double s22 = dot3p(c45.y, rc20, Tl.r20, rc21, Tl.r21, rc22, Tl.r22);
+    const double i00 = __builtin_fma(s11, s22, -(s12 * s12)), i01 = __builtin_fma(s02, s12, -(s01 * s22)), i02 = __builtin_fma(s01, s12, -(s02 * s11));
+    const double det = __builtin_fma(s02, i02, __builtin_fma(s01, i01, s00 * i00));
     double x = __builtin_amdgcn_rcp(det);
-    x = x * (2.0 - det * x);
+    x = x * __builtin_fma(-det, x, 2.0);
     M0 = (float)(i00 * x);
     M1 = (float)(i01 * x);
     M2 = (float)(i02 * x);
-    M3 = (float)((s00 * s22 - s02 * s02) * x);
-    M4 = (float)((s01 * s02 - s00 * s12) * x);
-    M5 = (float)((s00 * s11 - s01 * s01) * x);
+    M3 = (float)(__builtin_fma(s00, s22, -(s02 * s02)) * x);
+    M4 = (float)(__builtin_fma(s01, s02, -(s00 * s12)) * x);
+    M5 = (float)(__builtin_fma(s00, s11, -(s01 * s01)) * x);
   }
-  const float mrx = M0 * RX + M1 * RY + M2 * RZ, mry = M1 * RX + M3 * RY + M4 * RZ, mrz = M2 * RX + M4 * RY + M5 * RZ;
+  const auto fm = [](float x, float y, float c) { return __builtin_fmaf(x, y, c); };
+  const float mrx = fm(M2, RZ, fm(M1, RY, M0 * RX)), mry = fm(M4, RZ, fm(M3, RY, M1 * RX)), mrz = fm(M5, RZ, fm(M4, RY, M2 * RX));
   acc[ACC_COUNT] += 1.0f;
-  acc[ACC_ERR] += RX * mrx + RY * mry + RZ * mrz;
+  acc[ACC_ERR] += fm(RZ, mrz, fm(RY, mry, RX * mrx));
   if constexpr (MODE == MODE_ERR) return;
   acc[ACC_M + 0] += M0;
   acc[ACC_M + 1] += M1;
@@ -240,9 +257,10 @@ __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a
   acc[ACC_M + 3] += M3;
   acc[ACC_M + 4] += M4;
   acc[ACC_M + 5] += M5;
-  const float k00 = M1 * QZ - M2 * QY, k01 = M2 * QX - M0 * QZ, k02 = M0 * QY - M1 * QX;
-  const float k10 = M3 * QZ - M4 * QY, k11 = M4 * QX - M1 * QZ, k12 = M1 * QY - M3 * QX;
-  const float k20 = M4 * QZ - M5 * QY, k21 = M5 * QX - M2 * QZ, k22 = M2 * QY - M4 * QX;
+  // K = M S, S = [q]x
+  const float k00 = fm(M1, QZ, -(M2 * QY)), k01 = fm(M2, QX, -(M0 * QZ)), k02 = fm(M0, QY, -(M1 * QX));
+  const float k10 = fm(M3, QZ, -(M4 * QY)), k11 = fm(M4, QX, -(M1 * QZ)), k12 = fm(M1, QY, -(M3 * QX));
+  const float k20 = fm(M4, QZ, -(M5 * QY)), k21 = fm(M5, QX, -(M2 * QZ)), k22 = fm(M2, QY, -(M4 * QX));
   acc[ACC_K + 0] += k00;
   acc[ACC_K + 1] += k01;
   acc[ACC_K + 2] += k02;
@@ -252,15 +270,18 @@ __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a
   acc[ACC_K + 6] += k20;
   acc[ACC_K + 7] += k21;
   acc[ACC_K + 8] += k22;
-  acc[ACC_TL + 0] += QZ * k10 - QY * k20;
-  acc[ACC_TL + 1] += QZ * k11 - QY * k21;
-  acc[ACC_TL + 2] += QZ * k12 - QY * k22;
-  acc[ACC_TL + 3] += QX * k21 - QZ * k01;
-  acc[ACC_TL + 4] += QX * k22 - QZ * k02;
-  acc[ACC_TL + 5] += QY * k02 - QX * k12;
-  acc[ACC_QXMR + 0] += QY * mrz - QZ * mry;
-  acc[ACC_QXMR + 1] += QZ * mrx - QX * mrz;
-  acc[ACC_QXMR + 2] += QX * mry - QY * mrx;
+  // TL = -S K (upper triangle), b_t = [q x (M r); M r]: every term is formed first and added once (adding the products straight into the accumulators -- two fused
+  // multiply-adds per sum, 13 instructions fewer -- rounds twice at the magnitude of the PRODUCTS, which cancel: measured 2e-8 instead of 6e-9 against the oracle
+  // and as much between two partitions of the same cloud.  Not kept.)
+  acc[ACC_TL + 0] += fm(QZ, k10, -(QY * k20));
+  acc[ACC_TL + 1] += fm(QZ, k11, -(QY * k21));
+  acc[ACC_TL + 2] += fm(QZ, k12, -(QY * k22));
+  acc[ACC_TL + 3] += fm(QX, k21, -(QZ * k01));
+  acc[ACC_TL + 4] += fm(QX, k22, -(QZ * k02));
+  acc[ACC_TL + 5] += fm(QY, k02, -(QX * k12));
+  acc[ACC_QXMR + 0] += fm(QY, mrz, -(QZ * mry));
+  acc[ACC_QXMR + 1] += fm(QZ, mrx, -(QX * mrz));
+  acc[ACC_QXMR + 2] += fm(QX, mry, -(QY * mrx));
   acc[ACC_MR + 0] += mrx;
   acc[ACC_MR + 1] += mry;
   acc[ACC_MR + 2] += mrz;

@@ -821,7 +821,7 @@ def test_stream_kernel_beyond_one_round_of_four_chunk_waves(gpu, n_src):
     for L, what in [(L12, "stream"), (L12f, "stream, flat split"), (L8, "look-ahead")]:
         assert_linearized_close(L, Lo, MIXED_TOL, what)
     for k in BLOCKS:
-        assert rel_err(getattr(L12, k), getattr(L8, k)) < 1e-9 and rel_err(getattr(L12, k), getattr(L12f, k)) < 1e-9
+        assert rel_err(getattr(L12, k), getattr(L8, k)) < 1e-9 and rel_err(getattr(L12, k), getattr(L12f, k)) < 5e-9  # (two partitions of the same f32 per-lane sums: 2e-10 .. 2e-9)
 
 
 @pytest.mark.parametrize("variant", [0, 8, 12])
