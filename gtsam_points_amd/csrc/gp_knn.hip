@@ -544,11 +544,17 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
                       || top.count() >= g.n;         // the whole cloud has been seen (clouds smaller than k)
     if (done || r == rlast) {
       if (g.counters) {
+#ifdef GP_KNN_WAVELOG  // per-wave rows instead of the global counters (which serialise the launch): sum and maximum over the lanes of the candidates, the last shell
+        unsigned long long* wl = g.counters + 8 + 8 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+        atomicAdd(wl + 3, (unsigned long long)n_f32 | ((unsigned long long)n_f64 << 32));
+        atomicMax(wl + 2, (unsigned long long)n_f32 | ((unsigned long long)r << 32));
+#else
         atomicAdd(g.counters + 0, 1ull);
         atomicAdd(g.counters + 1, (unsigned long long)n_f32);
         atomicAdd(g.counters + 2, (unsigned long long)n_f64);
         atomicAdd(g.counters + 3, (unsigned long long)n_blk);
         atomicAdd(g.counters + 4, (unsigned long long)n_cell);
+#endif
       }
       return done || rlast >= rmax;
     }
@@ -770,6 +776,8 @@ __device__ __forceinline__ bool knn_query_coarse(const BinGridView& g, double qx
 // staging affects speed only.
 struct SearchView {
   int binned;      // number of binned levels (0: hashed fallback)
+  int fine_shells; // shells beyond the first one that a query walks on the finest cells before it starts over on a coarser level (4 in rounds 2-3)
+  int block_stage; // shells of BLOCKS (cells four times the size) a query walks between the fine shells and the superblocks; 0 = round 3's staging (none)
   BinGridView bins[kMaxLevels];
   MultiGridView hashed;
 };
@@ -781,15 +789,37 @@ __device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, do
   if (g.binned) {
     const int k = top.k;
     const double bound = top.worst();  // the caller's max_sq_dist (nothing has been pushed yet)
+#ifdef GP_KNN_WAVELOG  // measurement build (scripts/r04_c5_wavelog.py): per-wave stamps of the stages, rows of 8 uint64 behind the 8 work counters
+    unsigned long long* wl = g.bins[0].counters ? g.bins[0].counters + 8 + 8 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) : nullptr;
+    const bool wlane = (threadIdx.x & 63) == 0;
+#define GP_WL(slot, value) do { if (wl && wlane) wl[slot] = (value); } while (0)
+#define GP_WL_ALL(slot, value) do { const unsigned long long v_ = (value); if (wl && wlane) wl[slot] = v_; } while (0)
+#else
+#define GP_WL(slot, value) do { } while (0)
+#define GP_WL_ALL(slot, value) do { } while (0)
+#endif
+    GP_WL(0, __builtin_amdgcn_s_memrealtime());
     // (skip_fine: the row-tiled pass has scanned the shells 0 and 1 of the finest level, which therefore cannot settle the query; the
     // walk still starts there -- the list is not carried over -- but goes on to shell 4 at once)
     if constexpr (KMAX == 1) {
       if (knn_query_octant<KMAX, FULL>(g.bins[0], qx, qy, qz, top)) return;
     }
-    for (int l = 0; l < g.binned; l++) {
+    bool settled = false;
+    for (int l = 0; l < g.binned && !settled; l++) {
       if (l > 0) top.init(k, bound);
-      if (knn_query_bins<KMAX, FULL, FLAT>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : 4, rl)) return;
+      settled = knn_query_bins<KMAX, FULL, FLAT>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : g.fine_shells, rl);
     }
+    GP_WL_ALL(5, (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(!settled)));
+    GP_WL(1, __builtin_amdgcn_s_memrealtime());
+    if (settled) return;
+    // round 4: sparse neighbourhoods (the far field of a LiDAR scan: one point per cell) first try the BLOCKS as cells -- shells 0 .. block_stage of a grid four
+    // times as coarse, 27 entries for the first two, a few points each -- before they start over on the superblocks, whose first shell alone scans every point
+    // within 4-12 m of the query: those queries were the launch's tail (a hundred 64-query chunks of 350-460 us in a launch whose balanced length was 334 us)
+    if (g.block_stage > 0) {
+      top.init(k, bound);
+      settled = knn_query_coarse<KMAX, false, FULL>(g.bins[g.binned - 1], qx, qy, qz, top, g.block_stage);
+    }
+    if (settled) return;
     top.init(k, bound);
     knn_query_coarse<KMAX, true, FULL>(g.bins[g.binned - 1], qx, qy, qz, top, 0x3fffffff);
   } else {
@@ -1014,6 +1044,30 @@ __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g
     return;
   }
   covariance_from_neighbours<KMAX, FULL>(top, points, k, out);
+#ifdef GP_KNN_WAVELOG
+  if (g.binned && g.bins[0].counters && (threadIdx.x & 63) == 0) {
+    unsigned long long* wl = g.bins[0].counters + 8 + 8 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    wl[4] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (g.binned && g.bins[0].counters) {  // cells the wave's 64 queries span (ordinal of the last lane's cell - ordinal of the first one's + 1), and the own cell's population
+    const BinGridView& b = g.bins[0];
+    const int cx = fast_floor(qx * b.inv_h), cy = fast_floor(qy * b.inv_h), cz = fast_floor(qz * b.inv_h);
+    const size_t bi = ((size_t)((cz >> 2) - b.geom.lo[2]) * (size_t)b.geom.dim[1] + (size_t)((cy >> 2) - b.geom.lo[1])) * (size_t)b.geom.dim[0] + (size_t)((cx >> 2) - b.geom.lo[0]);
+    const int4 raw = *reinterpret_cast<const int4*>(b.blocks + bi);
+    const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
+    const int bit = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+    const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
+    const int pop = b.cell_start[ord + 1] - b.cell_start[ord];
+    const int o0 = __builtin_amdgcn_readlane(ord, 0), o63 = __builtin_amdgcn_readlane(ord, 63), p0 = __builtin_amdgcn_readlane(pop, 0);
+    const int blkpop = b.cell_start[raw.z + __popcll(bits)] - b.cell_start[raw.z];
+    const int bp0 = __builtin_amdgcn_readlane(blkpop, 0);
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long* wl = g.bins[0].counters + 8 + 8 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+      wl[7] = (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) | ((unsigned long long)(o63 - o0 + 1) << 32);
+      wl[6] = (unsigned long long)p0 | ((unsigned long long)bp0 << 32);
+    }
+  }
+#endif
 }
 
 // estimate_covariances, tiled: ONE WAVE PER OCCUPIED CELL ROW (the <= 4 x-adjacent cells of one (y, z) row of a block).  The queries
@@ -1421,6 +1475,15 @@ struct gp_point_grid {
   gp::SearchView view() const {
     gp::SearchView v{};
     v.binned = binned ? (int)bin_levels.size() : 0;
+    // round 4 measured both knobs on the 1 M-point cloud (scripts/r04_c5.py, profiles/r04_c5_staging.jsonl): fine shells 0 .. 4 with and without two or three shells
+    // of blocks in front of the superblocks -- 1.02-1.05 ms per call whatever the staging: 1434 of 10^6 queries get past the fine shells at all
+    // (profiles/r04_c5_wavelog.txt).  The defaults stay round 3's.
+    v.block_stage = 0;
+    v.fine_shells = 4;
+    if (structure >= 16) {  // experiment encoding (scripts/r04_c5.py): 16 | fine shells << 4 | block shells << 8
+      v.fine_shells = (structure >> 4) & 7;
+      v.block_stage = (structure >> 8) & 7;
+    }
     if (binned) {
       for (size_t l = 0; l < bin_levels.size(); l++) {
         const BinLevel& b = *bin_levels[l];
@@ -1561,7 +1624,7 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
 int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
-  if (structure != 0 && structure != 1 && structure != 3 && structure != 4) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4}");
+  if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4} (>= 16: staging experiment)");
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
   g->structure = structure;

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -586,15 +587,22 @@ int make_stream_plan(int n, int skew_permille, const int* xcd_weights, gp::Strea
   *p = gp::StreamPlan{};
   p->tail = n % gp::kChunkPoints;
   p->wgs_per_xcd = gx;
+  const double mean_chunks = (double)C / G;
   if (skew_permille < 0) {
-    // automatic: what a later dispatch round loses against an earlier one is mostly an ABSOLUTE delay (dispatch order, oldest-first issue), so the
-    // relative skew shrinks with the work per workgroup.  Measured best values (profiles/r03_sweep_skew.jsonl, r03_sweep_xcd_weights.jsonl): ~300
-    // at 15 chunks per workgroup (the 1 M-point headline), ~100 at 122 (an 8 M-point source); linear in between
-    const double mean = (double)C / G;
-    skew_permille = mean <= 24.0 ? 250 : (mean >= 96.0 ? 100 : (int)(250.0 - 150.0 * (mean - 24.0) / 72.0));
+    // automatic.  Round 3 needed ~250 at 15 chunks per workgroup because the rounds also had to absorb the XCDs' start offsets; with those in the XCD shares
+    // (below) the in-step sweeps of round 4 (scripts/r04_sweep.py, 1 M / 3 M / 8 M points) put the best value at 100-150 for every size: 250 costs 0.3-0.5 us at
+    // 1 M and 3 us at 8 M, 50 as much
+    skew_permille = 150;
   }
-  // shares of the XCDs: proportional to their weights, whole chunks, summing to C (largest remainders first; equal weights = cx or cx + 1)
-  const int* w = xcd_weights ? xcd_weights : kXcdWeightPermille;
+  // shares of the XCDs: proportional to their weights, whole chunks, summing to C (largest remainders first; equal weights = cx or cx + 1).
+  // The library's table compensates a FIXED delay (the XCD's dispatch offset), measured at the headline's 15.26 chunks per workgroup: its deviations from 1000
+  // scale with 15.26 / (chunks per workgroup) -- an 8 M-point source gets an eighth of them (the unscaled table cost it 1.5 us of 60), a 100 k-point one twice.
+  int scaled[gp::kNumXCD];
+  if (!xcd_weights) {
+    const double k = std::min(2.0, 15.26 / std::max(mean_chunks, 1.0));
+    for (int x = 0; x < gp::kNumXCD; x++) scaled[x] = 1000 + (int)std::lround((kXcdWeightPermille[x] - 1000) * k);
+  }
+  const int* w = xcd_weights ? xcd_weights : scaled;
   int share[gp::kNumXCD];
   {
     int64_t wsum = 0;
