@@ -117,25 +117,33 @@ def run_c4_inlib(lib, gpa, _capi, synthetic, torch, home_device, steps):
             keep.append((clouds, maps))
         torch.cuda.set_device(home_device)
         _capi.check(lib.gp_set_device(home_device.index), "gp_set_device")
-        mb = MultiDeviceBatch(factors, use_rccl=1)
         poses = np.stack([np.ascontiguousarray(synthetic.c4_delta(sub, t, s).T).reshape(16) for t, s in pairs]).copy()
         out = np.zeros((F, 122))
         t_setup = time.time() - t_setup
-        for _ in range(3):
-            mb.linearize_flat(poses, out)
-        comp, exch = [], []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            mb.linearize_flat(poses, out)
-            tm = mb.last_timing()
-            comp.append(tm["ms_compute"])
-            exch.append(tm["ms_exchange"])
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        res = dict(devices=ndev, shards=mb.num_shards, uses_rccl=bool(mb.uses_rccl), inlib_ms=round(ms, 4), inlib_compute_ms=round(float(np.median(comp)), 4),
-                   inlib_allreduce_ms=round(float(np.median(exch)), 4), value=round(F * synthetic.C4_POINTS / (ms * 1e-3), 1), unit="point-correspondences/s",
-                   inlier_fraction=round(float(out[:, 0].sum()) / (F * synthetic.C4_POINTS), 4), setup_s=round(t_setup, 1),
-                   note="host wall per gp_vgicp_multi_batch_linearize (poses in host memory -> all 4096 records in host memory); compute / exchange from the library's own HIP events")
-        del mb, factors, keep
+        res = dict(devices=ndev, unit="point-correspondences/s", setup_s=round(t_setup, 1),
+                   note="host wall per gp_vgicp_multi_batch_linearize (poses in host memory -> all 4096 records in host memory); compute / exchange from the library's own HIP events; "
+                        "one leg per exchange: in-place ncclAllGather of the equal contiguous shards, ncclAllReduce of the zeroed stack, and no collective (every shard's finalize "
+                        "kernel stores its records straight into the one host-pinned stack)")
+        ref = None
+        for use_rccl, leg in [(2, "all_gather"), (1, "all_reduce"), (0, "no_collective")]:
+            mb = MultiDeviceBatch(factors, use_rccl=use_rccl)
+            for _ in range(3):
+                mb.linearize_flat(poses, out)
+            comp, exch = [], []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                mb.linearize_flat(poses, out)
+                tm = mb.last_timing()
+                comp.append(tm["ms_compute"])
+                exch.append(tm["ms_exchange"])
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            if ref is None:
+                ref = out.copy()
+            res[leg] = dict(exchange=mb.exchange, shards=mb.num_shards, ms=round(ms, 4), compute_ms=round(float(np.median(comp)), 4), exchange_ms=round(float(np.median(exch)), 4),
+                            value=round(F * synthetic.C4_POINTS / (ms * 1e-3), 1), records_equal_first_leg=bool(np.array_equal(ref, out)))
+            del mb
+        res["inlier_fraction"] = round(float(ref[:, 0].sum()) / (F * synthetic.C4_POINTS), 4)
+        del factors, keep
         return res
     except Exception as exc:  # the headline must survive a failure of this optional leg
         try:
@@ -178,7 +186,7 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
     def issue(poses_local, view):
         _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, poses_local.ctypes.data, C.c_void_p(view.data_ptr())), "gp_vgicp_batch_issue_linearize")
 
-    sharded = ShardedLinearizer(F, (begin, end), device, issue, always_exchange=dist_on)
+    sharded = ShardedLinearizer(F, (begin, end), device, issue, always_exchange=dist_on, exchange=args.c4_exchange)
     host_out = torch.zeros((F, RECORD_DOUBLES), dtype=torch.float64).pin_memory()
 
     def step():
@@ -199,8 +207,8 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # the exchange alone: all-reduce of the stacked records (+ zeroing), HIP events on the stream it is issued on
-    ar_ms = 0.0
+    # the exchange alone, both forms: zeroing + all-reduce of the stacked records, and the in-place all-gather (when the plan qualifies); HIP events on the stream they are issued on
+    ar_ms, ag_ms = 0.0, None
     if dist_on:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
@@ -211,6 +219,14 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         e1.record(stream)
         e1.synchronize()
         ar_ms = e0.elapsed_time(e1) / 10
+        if sharded.exchange == "all_gather":
+            barrier()
+            e0.record(stream)
+            for _ in range(10):
+                dist.all_gather_into_tensor(sharded.stacked, sharded.own_rows)
+            e1.record(stream)
+            e1.synchronize()
+            ag_ms = e0.elapsed_time(e1) / 10
     ms_total, ms_main, ms_fin = C.c_float(), C.c_float(), C.c_float()
     alg = 0
     if n_local:
@@ -241,14 +257,15 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         workload="BASELINE configs[3]: 4096 pairwise VGICP factors (512 submaps x 32768 pts, 1.0 m voxels), sharded by source submap over the ranks",
         factors=F, points_per_linearize=points, n_gpus=world, scaling="strong", steps=args.c4_steps,
         ms_per_linearize=round(ms, 4), value=round(points / (ms * 1e-3), 1), unit="point-correspondences/s",
-        allreduce_ms=round(ar_ms, 4), stack_bytes=F * RECORD_DOUBLES * 8,
+        exchange=sharded.exchange, allreduce_ms=round(ar_ms, 4), allgather_ms=round(ag_ms, 4) if ag_ms is not None else None, stack_bytes=F * RECORD_DOUBLES * 8,
         tile_kernel_ms_slowest_rank=round(tile_ms_max, 5), algorithmic_bytes_total=int(alg_sum),
         algorithmic_frac_per_gpu=round(alg_sum / world / (tile_ms_max * 1e-3) / 8e12, 4) if tile_ms_max > 0 else None,
         algorithmic_frac_note="algorithmic bytes (SURVEY.md 8(d)) charge every factor its own 48 B/pt source stream although each source cloud serves 8 factors "
                               "(unique data ~0.9 GB of 7.9 GB) and ~half of the points miss: NOT an HBM fraction, no roofline credit claimed",
         inlib=inlib,
         factors_rank0=n_local, inlier_fraction=round(inliers / points, 4), setup_s=round(t_setup, 1),
-        step="per rank: zero [4096 x 122] f64 stack -> batched tile + finalize kernels into own rows -> ONE all-reduce (RCCL) -> D2H -> sync",
+        step="per rank: batched tile + finalize kernels into own rows of the [4096 x 122] f64 stack -> ONE collective (RCCL; `exchange`: in-place all-gather of the equal "
+             "contiguous shards, or zeroed stack + all-reduce) -> D2H -> sync",
     )
 
 
@@ -450,6 +467,8 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=50)
     ap.add_argument("--no-c4", action="store_true", help="skip the sharded 4096-factor configuration (BASELINE configs[3])")
     ap.add_argument("--c4-steps", type=int, default=30)
+    ap.add_argument("--c4-exchange", choices=["all_gather", "all_reduce"], default="all_gather",
+                    help="the c4 step's collective: all_gather = in place, half the bytes, no zeroing (falls back to the all-reduce when the shards are not equal contiguous ranges)")
     ap.add_argument("--no-c4-inlib", action="store_true", help="skip the single-process multi-device leg of c4 (run by rank 0 when it sees > 1 device)")
     ap.add_argument("--finalize", choices=["fused", "two-kernel"], default="fused",
                     help="synchronous step: fused = the library default (the last tile workgroups finalize, one launch); two-kernel = GP_TUNE_FUSED_FINALIZE 0")

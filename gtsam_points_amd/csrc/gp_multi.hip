@@ -9,13 +9,17 @@
 //     ONE ncclAllReduce(sum) per device over that stack (RCCL over xGMI; every row has exactly one writer, so the sum is exact)
 //     ONE D2H of the complete stack from the first shard's device
 //
-// RCCL is loaded with dlopen when a multi-batch really spans several devices (single-GPU users never load it).  Where it is
-// not used -- all shards on one device (the single-GPU rehearsal of an N-shard plan), a missing library, or use_rccl == 0 --
-// every shard copies its own rows to the host instead (functionally equivalent: the consumer is host-side).
+// Round 4: the stack has one writer per row and gp_shard_plan deals contiguous ranges, so when the shards are EQUAL contiguous ranges in rank order (C4: 8 x 512
+// factors) the same exchange is an in-place ncclAllGather -- (N-1)/N of the stack per device instead of 2 (N-1)/N, and no zeroing ("the equivalent
+// cheaper form").  use_rccl = 2 asks for it (falls back to the all-reduce when the plan does not qualify); gp_vgicp_multi_batch_uses_rccl tells which runs.
+//
+// RCCL is loaded with dlopen when a multi-batch really spans several devices (single-GPU users never load it; its six entry points are declared below, the
+// library is not needed to build).  Where it is not used -- all shards on one device (the single-GPU rehearsal of an N-shard plan), a missing library, or
+// use_rccl == 0 -- NO collective and no copy runs at all: every shard's finalize kernel stores its records straight into its rows of ONE host-pinned, portable
+// stack (the consumer is host-side), and the pass ends with the shards' streams' synchronisation.
 //
 // Everything here is built on the public per-device entry points (gp_vgicp_batch_*), one host thread issuing to all devices.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstring>
@@ -133,6 +137,12 @@ int gp_shard_plan_destroy(gp_shard_plan_t* plan) {
 }  // extern "C"
 
 // ---- RCCL, loaded on demand ---------------------------------------------------------------------------------------------------
+// the part of rccl.h this file uses (nccl.h's public ABI: opaque communicator, result / type / op enumerations), so that building the library does not need RCCL's headers
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;  // ncclFloat64
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+
 namespace {
 
 struct Rccl {
@@ -140,6 +150,7 @@ struct Rccl {
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -160,10 +171,11 @@ Rccl& rccl() {
   r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
   r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
   r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-  r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd && r.GetErrorString;
+  r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.AllGather && r.GroupStart && r.GroupEnd && r.GetErrorString;
   return r;
 }
 
@@ -213,7 +225,10 @@ struct gp_vgicp_multi_batch {
   std::deque<Shard> shards;  // (a Shard owns device arrays: it never moves)
   int num_factors = 0;
   bool use_rccl = false;
-  gp::PinnedArray h_stack;  // [F_total x 122] f64: results land here
+  bool gather = false;      // the exchange is an in-place ncclAllGather (equal contiguous shards in rank order) instead of the all-reduce
+  size_t gather_rows = 0;   // ... rows per shard
+  void* h_stack = nullptr;  // [F_total x 122] f64, pinned + portable: results land here (written by the finalize kernels themselves when no collective runs)
+  void* h_err = nullptr;    // [F_total] f64, likewise
   float last_ms_compute = 0.f, last_ms_exchange = 0.f;
 };
 
@@ -236,6 +251,8 @@ void destroy_multi(gp_vgicp_multi_batch* mb) {
     if (s.e_done) (void)hipEventDestroy(s.e_done);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
+  if (mb->h_stack) (void)hipHostFree(mb->h_stack);
+  if (mb->h_err) (void)hipHostFree(mb->h_err);
   delete mb;
 }
 
@@ -267,17 +284,19 @@ int run_pass_impl(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issu
   DeviceGuard guard;
   const size_t F = (size_t)mb->num_factors;
   // ---- compute: every shard issues its batched kernels into its rows ----
+  double* h = static_cast<double*>(err_pass ? mb->h_err : mb->h_stack);
   for (auto& s : mb->shards) {
     GP_HIP(hipSetDevice(s.device));
     gp::DeviceArray& dst = err_pass ? s.d_err : s.d_stack;
     GP_HIP(hipEventRecord(s.e_begin, s.stream));
+    const bool zero = mb->use_rccl && !mb->gather;  // (the all-gather overwrites every row; the all-reduce adds zeros to all rows but the writer's)
     if (s.index.empty()) {
-      if (mb->use_rccl) GP_HIP(hipMemsetAsync(dst.ptr, 0, sizeof(double) * width * F, s.stream));
+      if (zero) GP_HIP(hipMemsetAsync(dst.ptr, 0, sizeof(double) * width * F, s.stream));
       GP_HIP(hipEventRecord(s.e_compute, s.stream));
       continue;
     }
     if (mb->use_rccl) {
-      GP_HIP(hipMemsetAsync(dst.ptr, 0, sizeof(double) * width * F, s.stream));
+      if (zero) GP_HIP(hipMemsetAsync(dst.ptr, 0, sizeof(double) * width * F, s.stream));
       if (s.contiguous) {
         GP_TRY(issue(s, dst.as<double>() + (size_t)s.index[0] * width));
       } else {
@@ -287,20 +306,31 @@ int run_pass_impl(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issu
                            (const int*)s.d_index.as<int>(), dst.as<double>(), n, width);
         GP_HIP(hipGetLastError());
       }
+    } else if (s.contiguous) {
+      // no collective: the finalize kernel's record stores go straight into the shard's rows of the host stack (pinned, portable: every device sees it at the
+      // same address): no device-side stack, no copy operation, nothing left to do but wait for the streams
+      void* hd = nullptr;
+      GP_HIP(hipHostGetDevicePointer(&hd, h + (size_t)s.index[0] * width, 0));
+      GP_TRY(issue(s, static_cast<double*>(hd)));
     } else {
-      GP_TRY(issue(s, dst.as<double>()));  // local rows only
+      GP_TRY(issue(s, dst.as<double>()));  // local rows, copied out one by one below
     }
     GP_HIP(hipEventRecord(s.e_compute, s.stream));
   }
   // ---- exchange ----
-  double* h = mb->h_stack.as<double>();
   if (mb->use_rccl) {
     Rccl& r = rccl();
     GP_NCCL(r.GroupStart());
     *group_open = true;
     for (auto& s : mb->shards) {
       gp::DeviceArray& dst = err_pass ? s.d_err : s.d_stack;
-      GP_NCCL(r.AllReduce(dst.ptr, dst.ptr, (size_t)width * F, ncclDouble, ncclSum, s.comm, s.stream));
+      if (mb->gather) {
+        const size_t count = mb->gather_rows * (size_t)width;  // in place: rank k's send buffer is its own slot of the receive buffer
+        const size_t rank = (size_t)(&s - &mb->shards[0]);
+        GP_NCCL(r.AllGather(dst.as<double>() + rank * count, dst.ptr, count, ncclDouble, s.comm, s.stream));
+      } else {
+        GP_NCCL(r.AllReduce(dst.ptr, dst.ptr, (size_t)width * F, ncclDouble, ncclSum, s.comm, s.stream));
+      }
     }
     *group_open = false;
     GP_NCCL(r.GroupEnd());
@@ -314,14 +344,10 @@ int run_pass_impl(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issu
   } else {
     for (auto& s : mb->shards) {
       GP_HIP(hipSetDevice(s.device));
-      const double* src = (err_pass ? s.d_err : s.d_stack).as<double>();
-      if (!s.index.empty()) {
-        if (s.contiguous) {
-          GP_HIP(hipMemcpyAsync(h + (size_t)s.index[0] * width, src, sizeof(double) * width * s.index.size(), hipMemcpyDeviceToHost, s.stream));
-        } else {
-          for (size_t k = 0; k < s.index.size(); k++)
-            GP_HIP(hipMemcpyAsync(h + (size_t)s.index[k] * width, src + k * width, sizeof(double) * width, hipMemcpyDeviceToHost, s.stream));
-        }
+      if (!s.index.empty() && !s.contiguous) {
+        const double* src = (err_pass ? s.d_err : s.d_stack).as<double>();
+        for (size_t k = 0; k < s.index.size(); k++)
+          GP_HIP(hipMemcpyAsync(h + (size_t)s.index[k] * width, src + k * width, sizeof(double) * width, hipMemcpyDeviceToHost, s.stream));
       }
       GP_HIP(hipEventRecord(s.e_done, s.stream));
     }
@@ -402,7 +428,10 @@ int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_facto
   std::vector<int> uniq = devlist;
   std::sort(uniq.begin(), uniq.end());
   const bool distinct = std::unique(uniq.begin(), uniq.end()) == uniq.end();
+  // use_rccl: 0 = no collective (records straight into the host stack), 1 = ncclAllReduce of the zeroed stack, 2 = in-place ncclAllGather when the shards are equal
+  // contiguous ranges in rank order (else the all-reduce), < 0 = automatic (2 when the batch spans several devices)
   bool want_rccl = use_rccl > 0 || (use_rccl < 0 && num_shards > 1);
+  const bool want_gather = use_rccl == 2 || use_rccl < 0;
   if (want_rccl && (!distinct || !rccl().ok)) {
     if (use_rccl > 0) {
       destroy_multi(mb);
@@ -442,7 +471,23 @@ int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_facto
       break;
     }
   }
-  if (rc == GP_OK) rc = mb->h_stack.ensure(sizeof(double) * kRecordDoubles * std::max<size_t>(F, 1));
+  if (rc == GP_OK) {
+    // portable: one address every device can store to (the no-collective pass) and the copy engine can write (the collective passes)
+    if (hipHostMalloc(&mb->h_stack, sizeof(double) * kRecordDoubles * std::max<size_t>(F, 1), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(&mb->h_err, sizeof(double) * std::max<size_t>(F, 1), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
+      rc = gp::fail(GP_ERROR_HIP, "gp_vgicp_multi_batch_create: hipHostMalloc (portable) failed");
+  }
+  if (rc == GP_OK && mb->use_rccl && want_gather && num_shards > 0 && F % (size_t)num_shards == 0) {
+    // all-gather: shard k must be exactly rows [k * F / N, (k + 1) * F / N)
+    const size_t rows = F / (size_t)num_shards;
+    bool ok = rows > 0;
+    for (int k = 0; k < num_shards && ok; k++) {
+      const Shard& s = mb->shards[(size_t)k];
+      ok = s.contiguous && s.index.size() == rows && (size_t)s.index[0] == (size_t)k * rows;
+    }
+    mb->gather = ok;
+    mb->gather_rows = ok ? rows : 0;
+  }
   if (rc == GP_OK && mb->use_rccl) {
     std::vector<ncclComm_t> comms((size_t)num_shards, nullptr);
     const ncclResult_t e = rccl().CommInitAll(comms.data(), num_shards, devlist.data());
@@ -467,7 +512,7 @@ int gp_vgicp_multi_batch_destroy(gp_vgicp_multi_batch_t* mb) {
 
 int gp_vgicp_multi_batch_size(const gp_vgicp_multi_batch_t* mb) { return mb ? mb->num_factors : 0; }
 int gp_vgicp_multi_batch_num_shards(const gp_vgicp_multi_batch_t* mb) { return mb ? (int)mb->shards.size() : 0; }
-int gp_vgicp_multi_batch_uses_rccl(const gp_vgicp_multi_batch_t* mb) { return mb && mb->use_rccl ? 1 : 0; }
+int gp_vgicp_multi_batch_uses_rccl(const gp_vgicp_multi_batch_t* mb) { return mb && mb->use_rccl ? (mb->gather ? 2 : 1) : 0; }  // 0 no collective, 1 all-reduce, 2 all-gather
 
 int gp_vgicp_multi_batch_shard_info(const gp_vgicp_multi_batch_t* mb, int shard, int* device, int* num_factors, int64_t* num_points) {
   if (!mb || shard < 0 || shard >= (int)mb->shards.size()) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_multi_batch_shard_info: bad arguments");

@@ -43,7 +43,8 @@ class MultiDeviceBatch:
     process uses; `ShardedLinearizer` below is the one-process-per-GPU form bench.py is launched in).
       factors        IntegratedVGICPFactorGPU objects, each created from arrays / a map on the device of its shard
       shard_of       None = one shard per device; or a list of shard indices (several shards may share a device)
-      use_rccl       -1 auto, 0 never (host gather), 1 required"""
+      use_rccl       0 no collective (every shard's finalize kernel stores its records into its rows of one host-pinned stack), 1 ncclAllReduce of the zeroed
+                     stack (required), 2 in-place ncclAllGather when the shards are equal contiguous ranges in rank order (else the all-reduce), -1 automatic"""
 
     def __init__(self, factors, shard_of=None, num_shards=0, use_rccl=-1):
         import ctypes as C
@@ -75,6 +76,11 @@ class MultiDeviceBatch:
     @property
     def uses_rccl(self):
         return bool(self._lib.gp_vgicp_multi_batch_uses_rccl(self._h))
+
+    @property
+    def exchange(self):
+        """which exchange a pass runs: "none" (records straight into the host stack), "all_reduce", "all_gather" """
+        return ("none", "all_reduce", "all_gather")[int(self._lib.gp_vgicp_multi_batch_uses_rccl(self._h))]
 
     def shard_info(self, shard):
         import ctypes as C
@@ -125,10 +131,12 @@ class ShardedLinearizer:
                                        stacked buffer (on GPUs: gp_vgicp_batch_issue_linearize with out_dev = view pointer)
     """
 
-    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False):
+    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False, exchange="all_reduce"):
         """stream: the torch.cuda.Stream the `issue` callback launches its kernels on (a torch.cuda.ExternalStream around the
-        batch's hipStream_t when the batch owns its stream).  The zeroing of the stack, the kernels and the all-reduce are then
-        all ordered on that one stream; None = torch's current stream (CPU / gloo, or a batch created on torch's stream)."""
+        batch's hipStream_t when the batch owns its stream).  The zeroing of the stack, the kernels and the collective are then
+        all ordered on that one stream; None = torch's current stream (CPU / gloo, or a batch created on torch's stream).
+        exchange: "all_reduce" (the north star's: sum over the zeroed stack, any partition) or "all_gather" (in place, no zeroing, half the bytes: needs EQUAL
+        contiguous shards in rank order -- every rank passes the same total and its own [rank * n, (rank + 1) * n) -- and falls back to the all-reduce otherwise)."""
         import torch
 
         self.total = int(total_factors)
@@ -136,24 +144,47 @@ class ShardedLinearizer:
         self.issue = issue
         self.group = group
         self.stream = stream
-        self.always_exchange = bool(always_exchange)  # run the zeroing + all-reduce with ONE rank as well (a 1-rank communicator is valid: RCCL smoke on a 1-GPU box)
+        self.always_exchange = bool(always_exchange)  # run the collective with ONE rank as well (a 1-rank communicator is valid: RCCL smoke on a 1-GPU box)
         self.stacked = torch.zeros((self.total, RECORD_DOUBLES), dtype=torch.float64, device=device)
         # (a step is tens of microseconds: what does not change from call to call is looked up once)
         self.own_rows = self.stacked[self.begin : self.end] if self.end > self.begin else None
-        self._exchange = None
+        self._want = exchange
+        self._exchange = None  # None = not decided yet: torch.distributed may be initialised after this object; decided by the first pass that finds it up
+        self.exchange = "none"
+
+    def _decide(self):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            return False  # (not cached: asked again by the next pass)
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        self._exchange = world > 1 or self.always_exchange
+        rows = self.end - self.begin
+        gather_ok = self._want == "all_gather" and rows * world == self.total and self.begin == rank * rows
+        if self._exchange and self._want == "all_gather":
+            # every rank must take the same branch: agree on the plan (one tiny all-reduce, once)
+            import torch
+
+            flag = torch.tensor([1 if gather_ok else 0], dtype=torch.int32, device=self.stacked.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            gather_ok = bool(flag.item())
+        self.exchange = ("all_gather" if gather_ok else "all_reduce") if self._exchange else "none"
+        return self._exchange
 
     def _run(self, poses_local):
         import torch.distributed as dist
 
-        if self._exchange is None:
-            world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-            self._exchange = world > 1 or (self.always_exchange and dist.is_initialized())
-        if self._exchange:
+        exchange = self._exchange if self._exchange is not None else self._decide()
+        if exchange and self.exchange == "all_reduce":
             self.stacked.zero_()
         if self.own_rows is not None:
             self.issue(poses_local, self.own_rows)
-        if self._exchange:
-            dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
+        if exchange:
+            if self.exchange == "all_gather":
+                dist.all_gather_into_tensor(self.stacked, self.own_rows, group=self.group)  # in place: the input is this rank's slot of the output
+            else:
+                dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked
 
     def linearize(self, poses_local):

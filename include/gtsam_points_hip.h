@@ -323,8 +323,11 @@ typedef struct gp_vgicp_multi_batch gp_vgicp_multi_batch_t;
 /* factors[i] must have been created from arrays / a map resident on the device of its shard.
  * shard_of_factor == NULL: one shard per device the factors live on (num_shards ignored).  Otherwise shard_of_factor[i] in
  * [0, num_shards): several shards may share a device (the single-GPU rehearsal of an N-GPU plan).
- * use_rccl: -1 = RCCL all-reduce when the shards sit on distinct devices and librccl.so loads, else every shard copies its own rows
- * to the host; 0 = never; 1 = required (error otherwise; one shard on one device is a valid 1-rank communicator). */
+ * use_rccl: 0 = no collective: every shard's finalize kernel stores its records straight into its rows of one host-pinned, portable stack; 1 = ncclAllReduce(sum)
+ * of the zeroed [F x 122] f64 stack (required: error when the shards share a device or librccl.so does not load; one shard on one device is a valid 1-rank
+ * communicator); 2 = in-place ncclAllGather when the shards are equal contiguous ranges in rank order (what gp_shard_plan deals for equal weights: half the bytes of
+ * the all-reduce, no zeroing), else the all-reduce; -1 = automatic: 2 when the shards sit on distinct devices and librccl.so loads, else 0.
+ * gp_vgicp_multi_batch_uses_rccl: 0 no collective, 1 all-reduce, 2 all-gather. */
 int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_factors, const int* shard_of_factor, int num_shards, int use_rccl,
                                 gp_vgicp_multi_batch_t** out);
 int gp_vgicp_multi_batch_destroy(gp_vgicp_multi_batch_t* mb);

@@ -77,6 +77,43 @@ def test_sharded_linearize_gloo_world2():
         assert np.array_equal(ret[r], ref), f"rank {r}: stacked records differ from the single-process result"
 
 
+def _worker_gather(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    n = 6  # equal weights: gp_shard_plan deals 3 + 3 -- equal contiguous shards in rank order, the case the in-place all-gather serves
+    begin, end = partition_factors([1000] * n, world)[rank]
+
+    def issue(_poses, view):
+        view.copy_(torch.from_numpy(_records_for(PAIRS, list(range(begin, end)))))
+
+    # created BEFORE the process group exists (the decision must not be cached as "no exchange")
+    lin = ShardedLinearizer(n, (begin, end), "cpu", issue, exchange="all_gather")
+    ragged = ShardedLinearizer(len(PAIRS), partition_factors(WEIGHTS, world)[rank], "cpu", lambda _p, v: v.copy_(torch.from_numpy(_records_for(PAIRS, list(range(*partition_factors(WEIGHTS, world)[rank]))))),
+                               exchange="all_gather")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = lin.linearize(None).clone()
+    b = lin.linearize(None)
+    assert torch.equal(a, b) and lin.exchange == "all_gather"
+    c = ragged.linearize(None)
+    assert ragged.exchange == "all_reduce"  # 4 + 3 factors: the plan does not qualify, every rank falls back together
+    ret[rank] = (a.numpy(), c.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_linearize_all_gather_gloo_world2():
+    """the exchange as an in-place all-gather (equal contiguous shards: half the bytes of the all-reduce, no zeroing), and its fall-back"""
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_gather, args=(world, port, ret), nprocs=world, join=True)
+    ref6 = _records_for(PAIRS, list(range(6)))
+    ref7 = _records_for(PAIRS, list(range(len(PAIRS))))
+    for r in range(world):
+        assert np.array_equal(ret[r][0], ref6) and np.array_equal(ret[r][1], ref7), r
+
+
 def test_shard_plan_is_optimal_and_leaves_no_shard_empty():
     """gp_shard_plan_create (pure host code of the C-ABI): contiguous, complete, minimises the largest shard (checked against
     brute force over all boundary placements on small lists), and never leaves a shard empty while another holds two factors"""

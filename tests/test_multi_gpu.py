@@ -81,8 +81,12 @@ def test_rccl_allreduce_path(gpu, kitti07):
     clouds, maps, factors, deltas, deltas2 = _graph(gpu, kitti07)
     ref, ref_err = _plain_batch(gpu, factors, deltas, deltas2)
     one = MultiDeviceBatch(factors, use_rccl=1)
-    assert one.num_shards == 1 and one.uses_rccl
+    assert one.num_shards == 1 and one.uses_rccl and one.exchange == "all_reduce"
     assert np.array_equal(one.linearize(deltas), ref) and np.array_equal(one.compute_error(deltas, deltas2), ref_err)
+    gather = MultiDeviceBatch(factors, use_rccl=2)  # one shard holding everything = one equal contiguous range: the in-place ncclAllGather with one rank
+    assert gather.num_shards == 1 and gather.exchange == "all_gather"
+    assert np.array_equal(gather.linearize(deltas), ref) and np.array_equal(gather.compute_error(deltas, deltas2), ref_err)
+    del gather
     ndev = torch.cuda.device_count()
     if ndev < 2:
         return
@@ -105,9 +109,11 @@ def test_rccl_allreduce_path(gpu, kitti07):
         keep.append((local_clouds, local_maps))
     torch.cuda.set_device(0)
     lib.gp_set_device(0)
-    multi = MultiDeviceBatch(sharded, use_rccl=1)
-    assert multi.num_shards == len({p for p in range(ndev) if parts[p][1] > parts[p][0]}) and multi.uses_rccl
-    assert np.array_equal(multi.linearize(deltas), ref) and np.array_equal(multi.compute_error(deltas, deltas2), ref_err)
+    for use_rccl in (1, 2, 0):  # all-reduce, all-gather where the plan is equal ranges (else the all-reduce again), no collective
+        multi = MultiDeviceBatch(sharded, use_rccl=use_rccl)
+        assert multi.num_shards == len({p for p in range(ndev) if parts[p][1] > parts[p][0]}) and multi.uses_rccl == (use_rccl > 0)
+        assert np.array_equal(multi.linearize(deltas), ref) and np.array_equal(multi.compute_error(deltas, deltas2), ref_err)
+        del multi
 
 
 def test_voxelmap_clone(gpu, kitti00):
@@ -162,3 +168,51 @@ def test_bench_step_through_rccl_with_one_rank(gpu):
     par = r["parity_vs_oracle"]
     assert par["num_inliers_equal"] and max(par[k] for k in ["H_target", "H_source", "H_target_source", "b_target", "b_source", "error"]) < 1e-6
     assert r["c4"]["factors"] == 4096 and r["c4"]["allreduce_ms"] > 0 and 0.3 < r["c4"]["inlier_fraction"] < 0.9
+    assert r["c4"]["exchange"] == "all_gather" and r["c4"]["allgather_ms"] > 0  # one rank holding all 4096 rows = one equal contiguous shard
+
+
+def test_c4_plan_over_all_visible_devices(gpu):
+    """BASELINE configs[3] through the in-library path on REAL devices: the 8-shard plan of a C4 slice (64 submaps' worth would be 512 factors per shard; here 8 factors per
+    shard keep the test short) with one shard per visible device, every exchange form -- in-place ncclAllGather, ncclAllReduce, no collective -- against the plain batch on
+    device 0, bit for bit.  Skips below two devices (the driver's 8-GPU node runs it; the loop being sharded is cuda/nonlinear_factor_set_gpu.cpp:64-139)."""
+    import torch
+
+    from gtsam_points_amd import synthetic
+    from gtsam_points_amd.distributed import MultiDeviceBatch, partition_factors
+
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two devices")
+    lib = gpu.load()
+    pairs = synthetic.c4_factor_pairs()[: 8 * ndev]  # equal shards: the all-gather plan
+    need = sorted({i for p in pairs for i in p})
+    sub = synthetic.make_c4_submaps(need)
+    deltas = [synthetic.c4_delta(sub, t, s) for t, s in pairs]
+
+    def build(dev, mine):
+        torch.cuda.set_device(dev)
+        gpu._capi.check(lib.gp_set_device(dev), "gp_set_device")
+        clouds = {i: gpu.PointCloudGPU(sub[i][0], sub[i][1], device=f"cuda:{dev}") for i in sorted({i for p in mine for i in p})}
+        maps = {}
+        for t in sorted({t for t, _ in mine}):
+            maps[t] = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+            maps[t].insert(clouds[t])
+        return [gpu.IntegratedVGICPFactorGPU(t, s, maps[t], clouds[s]) for t, s in mine], (clouds, maps)
+
+    plain, keep0 = build(0, pairs)
+    ref = MultiDeviceBatch(plain, use_rccl=0).linearize(deltas)
+    parts = partition_factors([synthetic.C4_POINTS] * len(pairs), ndev)
+    assert [e - b for b, e in parts] == [8] * ndev
+    sharded, keep = [], []
+    for dev, (b, e) in enumerate(parts):
+        fs, k = build(dev, pairs[b:e])
+        sharded += fs
+        keep.append(k)
+    torch.cuda.set_device(0)
+    lib.gp_set_device(0)
+    for use_rccl, want in [(2, "all_gather"), (1, "all_reduce"), (0, "none"), (-1, "all_gather")]:
+        mb = MultiDeviceBatch(sharded, use_rccl=use_rccl)
+        assert mb.num_shards == ndev and mb.exchange == want, (mb.exchange, want)
+        assert np.array_equal(mb.linearize(deltas), ref), want
+        assert np.array_equal(mb.compute_error(deltas, deltas), ref[:, 1]) or np.allclose(mb.compute_error(deltas, deltas), ref[:, 1], rtol=1e-7)
+        del mb
