@@ -374,18 +374,10 @@ __global__ void __launch_bounds__(kBlockThreads) vgicp_finalize_error_kernel(con
                                                                              double* __restrict__ out, int single_tile_count, const DoneFlags done) {
   const int fi = blockIdx.x;
   const int tile_begin = single_tile_count >= 0 ? 0 : factors[fi].tile_begin, tile_count = single_tile_count >= 0 ? single_tile_count : factors[fi].tile_count;
+  static_assert(kBlockThreads == 256, "error_factor_total is written for 256 threads");
   __shared__ double lds[kBlockThreads / 64];
-  double s = 0.0;
-  for (int t = threadIdx.x; t < tile_count; t += kBlockThreads) s += partials[(size_t)(tile_begin + t) * ACC_STRIDE + ACC_ERR];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0;
-    for (int w = 0; w < kBlockThreads / 64; w++) a += lds[w];
-    out[fi] = a;
-  }
+  const double a = error_factor_total<false>(partials, tile_begin, tile_count, lds);  // (shared with the tile kernel's fused tail: same order, same bits)
+  if (threadIdx.x == 0) out[fi] = a;
   signal_done(done, fi, threadIdx.x == 0);
 }
 
@@ -1704,6 +1696,42 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
     double a = p[0];
     for (int q = 1; q < parts; q++) a += p[(size_t)q * kSlot];
     out_host[0] = a;
+    return GP_OK;
+  }
+  if (b->family == GP_KERNEL_STREAM && b->tuning.fused_finalize && !b->trace) {
+    // ONE launch (round 4): the workgroup that stores a factor's last row adds the factor's rows up -- in the order of vgicp_finalize_error_kernel -- and hands the sum and
+    // the completion word to the host (the by-factor form of the linearise, gp_vgicp_stream.hpp); small single factors and batches alike
+    if (b->factor_arrive_count < F) {
+      const size_t bytes = sizeof(unsigned long long) * gp::kFactorArriveStride * F;
+      GP_TRY(b->d_factor_arrive.alloc(bytes));
+      GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, bytes));
+      b->factor_arrive_count = F;
+    }
+    double* partials = nullptr;
+    GP_TRY(partials_ptr(b, &partials));
+    ps.inl.arrive = b->d_factor_arrive.as<unsigned long long>();
+    ps.inl.rows_per_part = 0;
+    ps.inl.num_rows = b->num_tiles;
+    ps.inl.fin_out = static_cast<double*>(b->h_out_dev);
+    ps.inl.fin_stride = 1;  // one double per factor
+    ps.inl.fin_flags = done.flags;
+    ps.inl.fin_seq = done.seq;
+    GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
+    for (size_t i = 0; i < F; i++)
+      if (b->h_descs[i].tile_count == 0) {  // no points, no workgroup: the empty sum is written here
+        static_cast<volatile double*>(b->h_out.ptr)[i] = 0.0;
+        static_cast<volatile unsigned long long*>(b->h_done.ptr)[i] = done.seq;
+      }
+    GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, done.seq, b->stream, spin_budget_us(b)));
+    if (!words_arrived(b, (int)F, done.seq)) {  // a counter left dirty by a launch that did not run to its end: clean them, the finalize kernel does this call's sums
+      GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, sizeof(unsigned long long) * gp::kFactorArriveStride * F));
+      const gp::DoneFlags again{done.flags, ++b->seq};
+      hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), (const double*)partials,
+                         static_cast<double*>(b->h_out_dev), -1, again);
+      GP_HIP(hipGetLastError());
+      GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, again.seq, b->stream, spin_budget_us(b)));
+    }
+    memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
     return GP_OK;
   }
   GP_TRY(launch_error(b, ps, reinterpret_cast<double*>(b->h_out_dev), done));

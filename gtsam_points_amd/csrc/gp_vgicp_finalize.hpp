@@ -16,6 +16,26 @@ namespace gp {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
   } while (0)
 
+// sum of r^T M r over a factor's partial rows in the order of vgicp_finalize_error_kernel: thread t of 256 adds rows t, t + 256, ...; the wave's 64 values meet in a
+// shuffle-down tree; the four waves' sums are added in wave order.  All 256 threads of the workgroup call it; the total is returned on thread 0.  SC1: the rows were
+// stored write-through by other workgroups of this launch (the fused finalize of the tile kernel): read past this XCD's L2 view.  wsum: 4 doubles of LDS.
+template <bool SC1>
+__device__ __forceinline__ double error_factor_total(const double* __restrict__ partials, int tile_begin, int tile_count, double* wsum) {
+  double s = 0.0;
+  for (int t = threadIdx.x; t < tile_count; t += 256) {
+    const double* p = partials + (size_t)(tile_begin + t) * ACC_STRIDE + ACC_ERR;
+    s += SC1 ? __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *p;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double a = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < 4; w++) a += wsum[w];
+  return a;
+}
+
 __device__ __forceinline__ double pick9(int i, double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7, double a8) {
   double v = a0;
   v = i == 1 ? a1 : v;

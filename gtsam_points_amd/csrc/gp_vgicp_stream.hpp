@@ -533,6 +533,25 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     // expands them into the record -- rigid_slice_total / rigid_wave_tree / rigid_expand_wave in the order of vgicp_finalize_rigid_kernel<1024>, whose 32
     // slices of rows are taken four to a thread here -- and hands record and completion word to the host while the other factors' tiles are still running:
     // no finalize launch, and the records' way over PCIe (a third of a 512-factor call) is hidden behind the tile kernel
+    if constexpr (MODE == MODE_ERR) {
+      // the error evaluation's by-factor form (round 4): the last arriver adds the factor's rows up in the order of vgicp_finalize_error_kernel (error_factor_total)
+      int* const last = reinterpret_cast<int*>(smem + 4 * kWaveBytes - 32 * 8 - 16);
+      if (threadIdx.x == 0) {
+        unsigned long long* ctr = inl.arrive + (size_t)factor_idx * kFactorArriveStride;
+        const unsigned long long seen = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool l = seen + 1 == (unsigned long long)f.tile_count;
+        if (l) __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last = l;
+      }
+      __syncthreads();
+      if (*last) {
+        const double total = error_factor_total<true>(partials, f.tile_begin, f.tile_count, reinterpret_cast<double*>(smem));
+        if (threadIdx.x == 0) {
+          asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : : "v"(inl.fin_out + (size_t)factor_idx * inl.fin_stride), "v"(total) : "memory");
+          asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(inl.fin_flags + factor_idx), "v"(inl.fin_seq) : "memory");
+        }
+      }
+    }
     if constexpr (MODE == MODE_LIN) {
       int* const last = reinterpret_cast<int*>(smem + 4 * kWaveBytes - 32 * 8 - 16);
       if (threadIdx.x == 0) {

@@ -953,3 +953,45 @@ def test_randomised_soak_of_the_fused_paths(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r03_fuzz.py"), "4", "11"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "FUZZ_OK" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
+
+
+def test_fused_error_finalize_by_factor(gpu, kitti07):
+    """round 4: a synchronous error evaluation of a batch (or of a small single factor) is ONE launch too -- the workgroup that stores a factor's last partial row adds the
+    factor's rows up in the order of vgicp_finalize_error_kernel and hands the sum to the host.  Same bits as the two-kernel form (GP_TUNE_FUSED_FINALIZE 0), call after call,
+    with an empty factor in the batch, and against the oracle."""
+    lib = gpu.load()
+    clouds = [gpu.PointCloudGPU(kitti07[f"points_{i}"], kitti07[f"covs_{i}"]) for i in range(5)]
+    clouds.append(gpu.PointCloudGPU(kitti07["points_0"][:0], kitti07["covs_0"][:0]) if False else clouds[0])
+    maps = []
+    for c in clouds[:5]:
+        m = gpu.GaussianVoxelMapGPU(1.0, target_points_drop_rate=0.0)
+        m.insert(c)
+        maps.append(m)
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 2), (1, 3), (2, 4), (0, 3), (1, 4), (0, 4)]
+    rng = np.random.default_rng(8)
+    dl = [expmap(rng.uniform(-0.05, 0.05, 6)) for _ in pairs]
+    de = [d @ expmap(rng.uniform(-0.01, 0.01, 6)) for d in dl]
+    pl = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in dl]).copy()
+    pe = np.stack([np.ascontiguousarray(d.T).reshape(16) for d in de]).copy()
+    for sel in (slice(0, 10), slice(3, 4)):  # a batch of ten, a batch of one (a small single factor: < 256 partial rows)
+        factors = [gpu.IntegratedVGICPFactorGPU(t, s, maps[t], clouds[s]) for t, s in pairs[sel]]
+        arr = (C.c_void_p * len(factors))(*[f._h.value for f in factors])
+        b = C.c_void_p()
+        gpu._capi.check(lib.gp_vgicp_batch_create(arr, len(factors), None, C.byref(b)), "batch")
+        a, c = np.ascontiguousarray(pl[sel]), np.ascontiguousarray(pe[sel])
+        got = {}
+        for fused in (1, 0, 1):
+            gpu._capi.check(lib.gp_vgicp_batch_set_tuning(b, 17, fused), "fused")
+            for rep in range(3):
+                e = np.zeros(len(factors))
+                gpu._capi.check(lib.gp_vgicp_batch_compute_error(b, a.ctypes.data, c.ctypes.data, e.ctypes.data), "compute_error")
+                got.setdefault(fused, []).append(e)
+        assert all(np.array_equal(got[1][0], x) for x in got[1] + got[0]), sel
+        for k, (t, s) in enumerate(pairs[sel]):
+            om = oracle.OracleVoxelMap(1.0)
+            om.insert(kitti07[f"points_{t}"], kitti07[f"covs_{t}"])
+            fo = oracle.OracleVGICPFactor(om, kitti07[f"points_{s}"], kitti07[f"covs_{s}"], 2)
+            fo.linearize(dl[sel][k])
+            eo = fo.error(de[sel][k])
+            assert abs(got[1][0][k] - eo) <= PARITY_TOL * abs(eo), (sel, k)
+        lib.gp_vgicp_batch_destroy(b)
