@@ -102,16 +102,22 @@ __global__ void __launch_bounds__(256) bins_flag_kernel(const unsigned* __restri
 // start, its occupancy bit, and -- at the first cell of a block -- the block's base.  total[0] = number of cells.
 __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __restrict__ sorted_keys, const int* __restrict__ flags, const int* __restrict__ scanned, int n,
                                                           const int* __restrict__ total, GridBlock* __restrict__ blocks, int* __restrict__ cell_start,
-                                                          unsigned* __restrict__ cell_of, int* __restrict__ cell_block, int* __restrict__ num_binned) {
+                                                          unsigned* __restrict__ cell_of, int* __restrict__ cell_block, int* __restrict__ num_binned,
+                                                          int* __restrict__ host_counts /* host-mapped: [8] binned points, [9] cells */) {
   const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= (size_t)n) return;
   const unsigned k = sorted_keys[j];
   const int num_cells = *total;
+  if (j == 0) {
+    num_binned[1] = num_cells;  // (kept for the kernels behind: the scan's slot is re-used)
+    host_counts[9] = num_cells;
+  }
   if (k == kInvalidKey) {
     cell_of[j] = kInvalidKey;
     if (j == 0 || sorted_keys[j - 1] != kInvalidKey) {
       cell_start[num_cells] = (int)j;
       *num_binned = (int)j;
+      host_counts[8] = (int)j;
     }
     return;
   }
@@ -127,18 +133,23 @@ __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __rest
   if (j == (size_t)n - 1) {
     cell_start[num_cells] = n;
     *num_binned = n;
+    host_counts[8] = n;
   }
 }
 
 // occupied blocks as a compact ascending list: cell c opens a block when it is the block's first cell
-__global__ void __launch_bounds__(256) bins_block_flag_kernel(int num_cells, const int* __restrict__ cell_block, const GridBlock* __restrict__ blocks, int* __restrict__ flags) {
+// (launched over all n positions: the cell count is still on the device -- entries behind the last cell are flagged 0)
+__global__ void __launch_bounds__(256) bins_block_flag_kernel(int n, const int* __restrict__ num_cells, const int* __restrict__ cell_block, const GridBlock* __restrict__ blocks,
+                                                              int* __restrict__ flags) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < num_cells) flags[c] = blocks[cell_block[c]].base == c ? 1 : 0;
+  if (c < n) flags[c] = (c < *num_cells && blocks[cell_block[c]].base == c) ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) bins_block_list_kernel(int num_cells, const int* __restrict__ cell_block, const int* __restrict__ flags, const int* __restrict__ scanned,
-                                                              int* __restrict__ occ_blocks) {
+__global__ void __launch_bounds__(256) bins_block_list_kernel(const int* __restrict__ num_cells, const int* __restrict__ cell_block, const int* __restrict__ flags,
+                                                              const int* __restrict__ scanned, int* __restrict__ occ_blocks, const int* __restrict__ scan_total,
+                                                              int* __restrict__ num_occ_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < num_cells && flags[c]) occ_blocks[scanned[c]] = cell_block[c];
+  if (c == 0) *num_occ_out = *scan_total;
+  if (c < *num_cells && flags[c]) occ_blocks[scanned[c]] = cell_block[c];
 }
 
 }  // namespace
@@ -158,15 +169,17 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   // ---- bounding box ----
-  DeviceArray boxes, d_small;
+  DeviceArray boxes, d_small;  // d_small (device): [8] binned points, [9] cells -- what the kernels behind read (a host-mapped word would be a PCIe read per wave)
+  HostWords hw;  // host-mapped: [0..5] bounding box, [8] binned points, [9] cells, [10] occupied blocks -- written by the kernels, read behind the synchronisations
+  GP_TRY(HostWords::get(&hw));
   GP_TRY(boxes.alloc_async(sizeof(int) * 6 * (size_t)wgs, s));
   GP_TRY(d_small.alloc_async(sizeof(int) * 16, s));
   hipLaunchKernelGGL(bins_bbox_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, boxes.as<int>());
-  hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), wgs, d_small.as<int>());
+  hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), wgs, hw.dev);
   GP_HIP(hipGetLastError());
-  int h_bbox[6];
-  GP_HIP(hipMemcpyAsync(h_bbox, d_small.ptr, sizeof(h_bbox), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));
+  int h_bbox[6];
+  for (int a = 0; a < 6; a++) h_bbox[a] = reinterpret_cast<volatile int*>(hw.host)[a];
   const double t1 = now();
   if (h_bbox[0] > h_bbox[3]) {  // no finite point at all
     GP_TRY(bins->cell_start.alloc_pooled(sizeof(int), s));
@@ -186,7 +199,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   }
   bins->num_blocks = (long long)bins->geom.dim[0] * bins->geom.dim[1] * bins->geom.dim[2];
   // ---- keys = (block, bit), stable sort, cells = runs of equal keys ----
-  DeviceArray keys_b, vals_b, sort_scratch, flags, scanned, scan_scratch;
+  DeviceArray keys_b, vals_b, sort_scratch, flags, scanned, scan_scratch, states;
   GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_HIP(hipMemsetAsync(bins->blocks.ptr, 0, sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
@@ -196,15 +209,20 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(sort_scratch.alloc_async(sizeof(int) * radix_sort_scratch_ints(n), s));
   GP_TRY(flags.alloc_async(sizeof(int) * (size_t)n, s));
   GP_TRY(scanned.alloc_async(sizeof(int) * (size_t)n, s));
-  GP_TRY(scan_scratch.alloc_async(sizeof(int) * ((size_t)n / kScanThreads + 8), s));
+  GP_TRY(scan_scratch.alloc_async(sizeof(int) * scan_scratch_ints(n), s));
   hipLaunchKernelGGL(bins_key_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>());
   GP_HIP(hipGetLastError());
   int bits = 6;
   while ((1ll << bits) < bins->num_blocks * 64) bits++;
   // skipped points carry kInvalidKey = 0x7fffffff: every pass sees all-ones digits, so they land behind every cell
   bool in_b = false;
-  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, std::min(bits + 1, 31), true,
-                          sort_scratch.as<int>(), s, &in_b));
+  // the look-back states of every scan of this build (one per sort pass, two over the sorted points): ONE fill
+  const int key_bits = std::min(bits + 1, 31);
+  const size_t sort_words = radix_sort_state_words(n, key_bits), scan_words = onepass_state_words(n);
+  GP_TRY(states.alloc_async(sizeof(unsigned long long) * (sort_words + 2 * scan_words), s));
+  GP_HIP(hipMemsetAsync(states.ptr, 0, sizeof(unsigned long long) * (sort_words + 2 * scan_words), s));
+  unsigned long long* st = states.as<unsigned long long>();
+  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_scratch.as<int>(), s, &in_b, st));
   if (in_b) {
     bins->cell_of.swap(keys_b);
     bins->order.swap(vals_b);
@@ -212,40 +230,35 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   // keys_b is free now: it receives the sorted keys' cell ordinals while cell_of still holds the sorted keys
   hipLaunchKernelGGL(bins_flag_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, flags.as<int>());
   GP_HIP(hipGetLastError());
-  GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, n, scan_scratch.as<int>(), s));
+  GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, n, scan_scratch.as<int>(), s, st + sort_words));
   const int scan_blocks = (int)(((long long)n + kScanThreads - 1) / kScanThreads);
   const int* d_total = scan_scratch.as<int>() + scan_blocks;  // the scan's grand total = number of cells
-  int h_cells = 0;
-  GP_HIP(hipMemcpyAsync(&h_cells, d_total, sizeof(int), hipMemcpyDeviceToHost, s));
+  // (round 4: no host round trip in the middle -- the arrays the cell count would size are allocated for the worst case, one cell per point, and the kernels behind
+  // read the count where the scan left it; the host learns cells, occupied blocks and binned points together at the end)
   const double t2 = now();
-  GP_HIP(hipStreamSynchronize(s));  // the cell count sizes cell_start
-  const double t3 = now();
-  bins->num_cells = h_cells;
-  GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)h_cells + 1), s));
-  GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)std::max(h_cells, 1), s));
-  GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)std::max(h_cells, 1), s));  // at most one block per cell
+  const double t3 = t2;
+  GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)n + 1), s));
+  GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
+  GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
   hipLaunchKernelGGL(bins_finish_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), (const int*)flags.as<int>(),
                      (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(),
-                     d_small.as<int>() + 8);
+                     d_small.as<int>() + 8, hw.dev);
   GP_HIP(hipGetLastError());
   bins->cell_of.swap(keys_b);  // cell_of = ordinals of the sorted points
-  // the compact list of occupied blocks (flags / scanned are re-used: num_cells <= n)
-  int h_occ = 0;
-  if (h_cells > 0) {
-    const int cw = (h_cells + 255) / 256;
-    hipLaunchKernelGGL(bins_block_flag_kernel, dim3(cw), dim3(256), 0, s, h_cells, (const int*)bins->cell_block.as<int>(), (const GridBlock*)bins->blocks.as<GridBlock>(), flags.as<int>());
-    GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, h_cells, scan_scratch.as<int>(), s));
-    hipLaunchKernelGGL(bins_block_list_kernel, dim3(cw), dim3(256), 0, s, h_cells, (const int*)bins->cell_block.as<int>(), (const int*)flags.as<int>(),
-                       (const int*)scanned.as<int>(), bins->occ_blocks.as<int>());
-    GP_HIP(hipGetLastError());
-    const int cell_scan_blocks = (h_cells + kScanThreads - 1) / kScanThreads;
-    GP_HIP(hipMemcpyAsync(&h_occ, scan_scratch.as<int>() + cell_scan_blocks, sizeof(int), hipMemcpyDeviceToHost, s));
-  }
-  int h_binned = 0;
-  GP_HIP(hipMemcpyAsync(&h_binned, d_small.as<int>() + 8, sizeof(int), hipMemcpyDeviceToHost, s));
+  // the compact list of occupied blocks (flags / scanned are re-used: num_cells <= n; entries behind the last cell are flagged 0)
+  // (bins_finish_kernel left the cell count in d_small[9]: the second scan re-uses the first one's slot)
+  const int* d_cells = d_small.as<int>() + 9;
+  hipLaunchKernelGGL(bins_block_flag_kernel, dim3(wgs), dim3(256), 0, s, n, d_cells, (const int*)bins->cell_block.as<int>(), (const GridBlock*)bins->blocks.as<GridBlock>(), flags.as<int>());
+  GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, n, scan_scratch.as<int>(), s, st + sort_words + scan_words));
+  hipLaunchKernelGGL(bins_block_list_kernel, dim3(wgs), dim3(256), 0, s, d_cells, (const int*)bins->cell_block.as<int>(), (const int*)flags.as<int>(),
+                     (const int*)scanned.as<int>(), bins->occ_blocks.as<int>(), d_total, hw.dev + 10);
+  GP_HIP(hipGetLastError());
+  // the occupied-block count = the second scan's total: bins_block_list_kernel copies it next to the others
   GP_HIP(hipStreamSynchronize(s));
-  bins->num_occ_blocks = h_occ;
-  bins->num_binned = h_binned;
+  const int h_counts[3] = {reinterpret_cast<volatile int*>(hw.host)[9], reinterpret_cast<volatile int*>(hw.host)[10], reinterpret_cast<volatile int*>(hw.host)[8]};  // cells, occupied blocks, binned points
+  bins->num_cells = h_counts[0];
+  bins->num_occ_blocks = h_counts[0] > 0 ? h_counts[1] : 0;
+  bins->num_binned = h_counts[2];
   if (dbg) fprintf(stderr, "bin_points: bbox %.0f us, sort issue %.0f us, wait %.0f us, finish %.0f us\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
   return GP_OK;
 }

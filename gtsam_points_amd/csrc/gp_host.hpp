@@ -259,6 +259,32 @@ constexpr int kMirrorChunkBytes = 2304;
 // *out: the shared mirror of (points, covs, n) on `device`, packed on `stream` (synchronised before return) when it does not exist yet; null when n < 64
 int acquire_source_mirror(const float* points, const float* covs, int n, int device, hipStream_t stream, std::shared_ptr<SourceMirror>* out);
 
+// A few words of host-mapped pinned memory per host thread and device: where a structure build's kernels leave the counts the host sizes the next step by (bounding
+// box, number of cells, failed insertions).  Reading them is a load behind the stream's synchronisation -- a D2H copy of device words is a copy KERNEL plus its launch
+// (~7 us apiece, six per map build: profiles/r04_map_build_stats.txt).  Never freed (the runtime may be gone when a thread ends).
+struct HostWords {
+  int* host = nullptr;
+  int* dev = nullptr;
+  static constexpr int kWords = 64;
+  static int get(HostWords* out) {
+    static thread_local HostWords w[16];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return fail(GP_ERROR_HIP, "HostWords: no current device");
+    if (!w[d].host) {
+      void* p = nullptr;
+      hipError_t e = hipHostMalloc(&p, sizeof(int) * kWords, hipHostMallocMapped);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+      void* dp = nullptr;
+      e = hipHostGetDevicePointer(&dp, p, 0);
+      if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer", __FILE__, __LINE__);
+      w[d].host = static_cast<int*>(p);
+      w[d].dev = static_cast<int*>(dp);
+    }
+    *out = w[d];
+    return GP_OK;
+  }
+};
+
 }  // namespace gp
 
 // TempBufferManager (cuda/stream_temp_buffer_roundrobin.cu:11-47)

@@ -93,14 +93,19 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const unsigned* __re
 // scratch ints needed by radix_sort_pairs for n elements
 inline size_t radix_sort_scratch_ints(int n) {
   const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
-  return 256 * tiles + (256 * tiles) / kScanThreads + 8;
+  return 256 * tiles + scan_scratch_ints(256ll * (long long)tiles);
 }
 
 // Sorts n pairs by the low `key_bits` bits of the key, stable.  (keys_a, vals_a) hold the input -- with vals_iota the values are
 // taken to be 0..n-1 and vals_a is only storage; the passes ping-pong between the a and b buffers; *result_in_b tells where the
 // sorted pairs ended up.  n <= 2^30.
+// zeroed_states: radix_sort_state_words(n, key_bits) words the caller has zeroed on `s` (one look-back state per pass), or null
+inline size_t radix_sort_state_words(int n, int key_bits) {
+  const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
+  return (size_t)((key_bits + 7) / 8) * onepass_state_words(256ll * (long long)tiles);
+}
 inline int radix_sort_pairs(unsigned* keys_a, int* vals_a, unsigned* keys_b, int* vals_b, int n, int key_bits, bool vals_iota, int* scratch, hipStream_t s,
-                            bool* result_in_b) {
+                            bool* result_in_b, unsigned long long* zeroed_states = nullptr) {
   *result_in_b = false;
   if (n <= 0) return GP_OK;
   const int tiles = (n + kSortTile - 1) / kSortTile;
@@ -114,7 +119,7 @@ inline int radix_sort_pairs(unsigned* keys_a, int* vals_a, unsigned* keys_b, int
     int* vout = in_a ? vals_b : vals_a;
     hipLaunchKernelGGL(radix_hist_kernel<0>, dim3(tiles), dim3(256), 0, s, kin, n, shift, hist, tiles);
     GP_HIP(hipGetLastError());
-    GP_TRY(exclusive_scan_strided(hist, 1, hist, 1, 256ll * tiles, scan_scratch, s));
+    GP_TRY(exclusive_scan_strided(hist, 1, hist, 1, 256ll * tiles, scan_scratch, s, zeroed_states ? zeroed_states + (size_t)(shift / 8) * onepass_state_words(256ll * tiles) : nullptr));
     hipLaunchKernelGGL(radix_scatter_kernel<0>, dim3(tiles), dim3(256), 0, s, kin, vin, n, shift, (const int*)hist, tiles, kout, vout);
     GP_HIP(hipGetLastError());
     in_a = !in_a;

@@ -208,15 +208,17 @@ __global__ void __launch_bounds__(256) buckets_renumber_kernel(uint32_t num_buck
 }
 
 // ---- binned build (gp_binning.hpp): per-voxel statistics as an ORDERED segmented sum ----------------------------------------
-// One wave per voxel.  The voxel's points come in ascending index order (stable sort); every chunk of 64 is reduced with a fixed
-// butterfly and the chunk sums are added in order: the statistics are bit-identical from run to run (no atomics).
+// Sixteen lanes per voxel (round 4; rounds 2-3: one wave per voxel -- the median voxel of a scan holds three points, the mean 10-30, so three quarters of a wave's
+// lanes idled through nine six-step butterflies: 114 us per 2 M points, the largest kernel of the map build).  The voxel's points come in ascending index order
+// (stable sort); every chunk of 16 is reduced with a fixed butterfly and the chunk sums are added in order: the statistics are bit-identical from run to run (no atomics).
 // sums relative to the voxel centre in f64, like accumulate_kernel; outputs as finalize_kernel.
 __global__ void __launch_bounds__(256) segmented_stats_kernel(const float* __restrict__ points, const float* __restrict__ covs, const float* __restrict__ intensities,
                                                               int num_voxels, const int* __restrict__ cell_start, const int* __restrict__ order, double inv_leaf, double leaf,
                                                               VoxelRecord* __restrict__ records, int* __restrict__ num_points, float* __restrict__ voxel_means,
                                                               float* __restrict__ voxel_covs, float* __restrict__ voxel_intensities, int* __restrict__ voxel_coords) {
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int kGroup = 16;
+  const int lane = threadIdx.x & (kGroup - 1);
+  const int v = blockIdx.x * (256 / kGroup) + (threadIdx.x / kGroup);
   if (v >= num_voxels) return;
   const int b = cell_start[v], e = cell_start[v + 1];
   const size_t i0 = (size_t)order[b];
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(256) segmented_stats_kernel(const float* __res
   const double ox = ((double)cx + 0.5) * leaf, oy = ((double)cy + 0.5) * leaf, oz = ((double)cz + 0.5) * leaf;
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   float imax = 0.0f;  // max intensity (:138-139): intensities are non-negative upstream (atomicMax on the float bits), 0 when absent
-  for (int chunk = b; chunk < e; chunk += 64) {
+  for (int chunk = b; chunk < e; chunk += kGroup) {
     const int j = chunk + lane;
     double val[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float it = 0.0f;
@@ -246,11 +248,11 @@ __global__ void __launch_bounds__(256) segmented_stats_kernel(const float* __res
     for (int k = 0; k < 9; k++) {
       double x = val[k];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      for (int off = kGroup / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kGroup);
       acc[k] += x;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) it = fmaxf(it, __shfl_xor(it, off, 64));
+    for (int off = kGroup / 2; off > 0; off >>= 1) it = fmaxf(it, __shfl_xor(it, off, kGroup));
     imax = fmaxf(imax, it);
   }
   if (lane != 0) return;
@@ -299,7 +301,7 @@ __global__ void __launch_bounds__(256) insert_voxels_kernel(int num_voxels, cons
       return;
     }
   }
-  atomicAdd(failed, num_points[v]);
+  *failed = 1;  // (a flag, not a count: the caller doubles the table until nothing fails; host-mapped on the binned build's path)
 }
 
 // lookup_voxels_kernel (cuda/kernels/lookup_voxels.cuh:34-60): voxel index of delta * p, or -1
@@ -435,7 +437,7 @@ static int build_grid_device(gp_voxelmap* m, hipStream_t s) {
   hipLaunchKernelGGL(gp::grid_count_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, nb, blocks);
   GP_HIP(hipGetLastError());
   gp::DeviceArray scratch, perm, coords_new;
-  GP_TRY(scratch.alloc(sizeof(int) * (size_t)(nb / gp::kScanThreads + 4)));
+  GP_TRY(scratch.alloc(sizeof(int) * gp::scan_scratch_ints(nb)));
   GP_TRY(perm.alloc(sizeof(int) * (size_t)V));
   GP_TRY(coords_new.alloc(sizeof(int) * 3 * (size_t)V));
   int* base0 = &blocks[0].base;
@@ -527,7 +529,7 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   m->info.num_voxels = V;
   GP_TRY(alloc_voxel_arrays(m, V));
   GP_TRY(m->voxel_coords.alloc_pooled(sizeof(int) * 3 * (size_t)std::max(V, 1), s));
-  hipLaunchKernelGGL(gp::segmented_stats_kernel, dim3((V + 3) / 4), dim3(256), 0, s, points_dev, covs_dev, intensities_dev, V, (const int*)bins.cell_start.as<int>(),
+  hipLaunchKernelGGL(gp::segmented_stats_kernel, dim3((V + 15) / 16), dim3(256), 0, s, points_dev, covs_dev, intensities_dev, V, (const int*)bins.cell_start.as<int>(),
                      (const int*)bins.order.as<int>(), 1.0 / m->resolution, m->resolution, m->records.as<gp::VoxelRecord>(), m->num_points.as<int>(), m->voxel_means.as<float>(),
                      m->voxel_covs.as<float>(), m->voxel_intensities.as<float>(), m->voxel_coords.as<int>());
   GP_HIP(hipGetLastError());
@@ -541,27 +543,30 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   // reference-visible bucket table (create_bucket_table, :253-307): the reference doubles the table until the fraction of points
   // whose probe chain is exhausted is <= target_points_drop_rate and then drops those points; here the table is doubled along the
   // same sequence until every voxel is placed, so no point is ever dropped (the CPU map, the parity target, drops none either)
-  gp::DeviceArray failed;
-  GP_TRY(failed.alloc_async(sizeof(int) * 4, s));
+  // (round 4: the "a voxel found no bucket" flag is a host-mapped word the kernel stores to -- no fill, no copy kernel -- and the private line table is issued behind
+  // the insertion before the one synchronisation that ends the build; a table that turns out too small is the rare path and starts over)
+  gp::HostWords hw;
+  GP_TRY(gp::HostWords::get(&hw));
   int64_t num_buckets = m->init_num_buckets;
   while (num_buckets < (int64_t)V + V / 2) num_buckets *= 2;  // the sequence is entered where the voxels fit at a load factor <= 2/3
+  bool private_built = false;
   for (;; num_buckets *= 2) {
     if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
     GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
     GP_HIP(hipMemsetAsync(m->buckets.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
-    GP_HIP(hipMemsetAsync(failed.ptr, 0, sizeof(int), s));
+    reinterpret_cast<volatile int*>(hw.host)[12] = 0;
     const uint32_t mask = ((num_buckets & (num_buckets - 1)) == 0) ? (uint32_t)(num_buckets - 1) : 0u;
     hipLaunchKernelGGL(gp::insert_voxels_kernel, dim3(grid_for((size_t)V)), dim3(kBlock), 0, s, V, (const int*)m->voxel_coords.as<int>(), (const int*)m->num_points.as<int>(),
-                       m->buckets.as<gp_voxel_bucket>(), (uint32_t)num_buckets, mask, m->info.max_bucket_scan_count, failed.as<int>());
+                       m->buckets.as<gp_voxel_bucket>(), (uint32_t)num_buckets, mask, m->info.max_bucket_scan_count, hw.dev + 12);
     GP_HIP(hipGetLastError());
-    int h_failed = 0;
-    GP_HIP(hipMemcpyAsync(&h_failed, failed.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
-    GP_HIP(hipStreamSynchronize(s));
-    if (h_failed == 0) break;
+    m->info.num_buckets = (int)num_buckets;
+    if (!private_built) {  // (does not depend on the bucket table: issued once, behind the first attempt, in front of the synchronisation)
+      GP_TRY(build_private_table(m, s));
+      private_built = true;
+    }
+    GP_HIP(hipStreamSynchronize(s));  // :250
+    if (reinterpret_cast<volatile int*>(hw.host)[12] == 0) break;
   }
-  m->info.num_buckets = (int)num_buckets;
-  GP_TRY(build_private_table(m, s));
-  GP_HIP(hipStreamSynchronize(s));  // :250
   return GP_OK;
 }
 
