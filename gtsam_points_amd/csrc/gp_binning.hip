@@ -90,17 +90,26 @@ __global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__
   keys[i] = key;
 }
 
-// sorted keys -> 1 at the first point of every cell (0 elsewhere and on the skipped points behind the cells)
-__global__ void __launch_bounds__(256) bins_flag_kernel(const unsigned* __restrict__ sorted_keys, int n, int* __restrict__ flags) {
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= (size_t)n) return;
-  const unsigned k = sorted_keys[j];
-  flags[j] = (k != kInvalidKey && (j == 0 || sorted_keys[j - 1] != k)) ? 1 : 0;
-}
+// sorted keys -> 1 at the first point of every cell (0 elsewhere and on the skipped points behind the cells).  Round 4: the flags are not stored -- the scan and the
+// kernels behind it evaluate them where they need them (one kernel, one 8 MB array and its read-back less per build)
+struct CellStartFlag {
+  const unsigned* sorted_keys;
+  __device__ __forceinline__ int operator()(long long j) const {
+    const unsigned k = sorted_keys[j];
+    return (k != kInvalidKey && (j == 0 || sorted_keys[j - 1] != k)) ? 1 : 0;
+  }
+};
+// cell c opens a block when it is the block's first cell (entries behind the last cell: 0)
+struct BlockStartFlag {
+  const int* num_cells;
+  const int* cell_block;
+  const GridBlock* blocks;
+  __device__ __forceinline__ int operator()(long long c) const { return (c < *num_cells && blocks[cell_block[c]].base == (int)c) ? 1 : 0; }
+};
 
 // ordinal of every sorted point's cell (exclusive scan of the flags, + its own flag, - 1); at the first point of a cell: the cell's
 // start, its occupancy bit, and -- at the first cell of a block -- the block's base.  total[0] = number of cells.
-__global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __restrict__ sorted_keys, const int* __restrict__ flags, const int* __restrict__ scanned, int n,
+__global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __restrict__ sorted_keys, const int* __restrict__ scanned, int n,
                                                           const int* __restrict__ total, GridBlock* __restrict__ blocks, int* __restrict__ cell_start,
                                                           unsigned* __restrict__ cell_of, int* __restrict__ cell_block, int* __restrict__ num_binned,
                                                           int* __restrict__ host_counts /* host-mapped: [8] binned points, [9] cells */) {
@@ -121,9 +130,10 @@ __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __rest
     }
     return;
   }
-  const int ord = scanned[j] + flags[j] - 1;
+  const int flag = (j == 0 || sorted_keys[j - 1] != k) ? 1 : 0;  // (CellStartFlag)
+  const int ord = scanned[j] + flag - 1;
   cell_of[j] = (unsigned)ord;
-  if (flags[j]) {
+  if (flag) {
     cell_start[ord] = (int)j;
     cell_block[ord] = (int)(k >> 6);
     GridBlock* blk = blocks + (k >> 6);
@@ -138,18 +148,13 @@ __global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __rest
 }
 
 // occupied blocks as a compact ascending list: cell c opens a block when it is the block's first cell
-// (launched over all n positions: the cell count is still on the device -- entries behind the last cell are flagged 0)
-__global__ void __launch_bounds__(256) bins_block_flag_kernel(int n, const int* __restrict__ num_cells, const int* __restrict__ cell_block, const GridBlock* __restrict__ blocks,
-                                                              int* __restrict__ flags) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < n) flags[c] = (c < *num_cells && blocks[cell_block[c]].base == c) ? 1 : 0;
-}
-__global__ void __launch_bounds__(256) bins_block_list_kernel(const int* __restrict__ num_cells, const int* __restrict__ cell_block, const int* __restrict__ flags,
+// occupied blocks as a compact ascending list (launched over all n positions: the cell count is still on the device)
+__global__ void __launch_bounds__(256) bins_block_list_kernel(const int* __restrict__ num_cells, const int* __restrict__ cell_block, const GridBlock* __restrict__ blocks,
                                                               const int* __restrict__ scanned, int* __restrict__ occ_blocks, const int* __restrict__ scan_total,
                                                               int* __restrict__ num_occ_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c == 0) *num_occ_out = *scan_total;
-  if (c < *num_cells && flags[c]) occ_blocks[scanned[c]] = cell_block[c];
+  if (c < *num_cells && blocks[cell_block[c]].base == c) occ_blocks[scanned[c]] = cell_block[c];
 }
 
 }  // namespace
@@ -199,7 +204,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   }
   bins->num_blocks = (long long)bins->geom.dim[0] * bins->geom.dim[1] * bins->geom.dim[2];
   // ---- keys = (block, bit), stable sort, cells = runs of equal keys ----
-  DeviceArray keys_b, vals_b, sort_scratch, flags, scanned, scan_scratch, states;
+  DeviceArray keys_b, vals_b, sort_scratch, scanned, scan_scratch, states;
   GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_HIP(hipMemsetAsync(bins->blocks.ptr, 0, sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
@@ -207,7 +212,6 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
   GP_TRY(vals_b.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(sort_scratch.alloc_async(sizeof(int) * radix_sort_scratch_ints(n), s));
-  GP_TRY(flags.alloc_async(sizeof(int) * (size_t)n, s));
   GP_TRY(scanned.alloc_async(sizeof(int) * (size_t)n, s));
   GP_TRY(scan_scratch.alloc_async(sizeof(int) * scan_scratch_ints(n), s));
   hipLaunchKernelGGL(bins_key_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>());
@@ -228,9 +232,8 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
     bins->order.swap(vals_b);
   }
   // keys_b is free now: it receives the sorted keys' cell ordinals while cell_of still holds the sorted keys
-  hipLaunchKernelGGL(bins_flag_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, flags.as<int>());
-  GP_HIP(hipGetLastError());
-  GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, n, scan_scratch.as<int>(), s, st + sort_words));
+  GP_TRY(exclusive_scan_of(CellStartFlag{bins->cell_of.as<unsigned>()}, scanned.as<int>(), n, scan_scratch.as<int>() + (int)(((long long)n + kScanThreads - 1) / kScanThreads), s,
+                           st + sort_words));
   const int scan_blocks = (int)(((long long)n + kScanThreads - 1) / kScanThreads);
   const int* d_total = scan_scratch.as<int>() + scan_blocks;  // the scan's grand total = number of cells
   // (round 4: no host round trip in the middle -- the arrays the cell count would size are allocated for the worst case, one cell per point, and the kernels behind
@@ -240,17 +243,16 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)n + 1), s));
   GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
-  hipLaunchKernelGGL(bins_finish_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), (const int*)flags.as<int>(),
-                     (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(),
+  hipLaunchKernelGGL(bins_finish_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(),
                      d_small.as<int>() + 8, hw.dev);
   GP_HIP(hipGetLastError());
   bins->cell_of.swap(keys_b);  // cell_of = ordinals of the sorted points
   // the compact list of occupied blocks (flags / scanned are re-used: num_cells <= n; entries behind the last cell are flagged 0)
   // (bins_finish_kernel left the cell count in d_small[9]: the second scan re-uses the first one's slot)
   const int* d_cells = d_small.as<int>() + 9;
-  hipLaunchKernelGGL(bins_block_flag_kernel, dim3(wgs), dim3(256), 0, s, n, d_cells, (const int*)bins->cell_block.as<int>(), (const GridBlock*)bins->blocks.as<GridBlock>(), flags.as<int>());
-  GP_TRY(exclusive_scan_strided(flags.as<int>(), 1, scanned.as<int>(), 1, n, scan_scratch.as<int>(), s, st + sort_words + scan_words));
-  hipLaunchKernelGGL(bins_block_list_kernel, dim3(wgs), dim3(256), 0, s, d_cells, (const int*)bins->cell_block.as<int>(), (const int*)flags.as<int>(),
+  GP_TRY(exclusive_scan_of(BlockStartFlag{d_cells, bins->cell_block.as<int>(), bins->blocks.as<GridBlock>()}, scanned.as<int>(), n, const_cast<int*>(d_total), s,
+                           st + sort_words + scan_words));
+  hipLaunchKernelGGL(bins_block_list_kernel, dim3(wgs), dim3(256), 0, s, d_cells, (const int*)bins->cell_block.as<int>(), (const GridBlock*)bins->blocks.as<GridBlock>(),
                      (const int*)scanned.as<int>(), bins->occ_blocks.as<int>(), d_total, hw.dev + 10);
   GP_HIP(hipGetLastError());
   // the occupied-block count = the second scan's total: bins_block_list_kernel copies it next to the others

@@ -1528,7 +1528,7 @@ struct gp_gicp_factor {
 // the default update tolerances being zero); an error evaluation re-uses the stored correspondences when they belong to its
 // linearisation pose -- the reference's error() evaluates on the correspondences of the last linearise (impl.hpp:183-185).
 static int gicp_correspond(gp_gicp_factor* f, const gp::GicpPoses& P, bool reuse) {
-  static const bool split = [] { const char* e = getenv("GP_GICP_SPLIT"); return !e || atoi(e) != 0; }();
+  constexpr bool split = true;  // the correspondence pass is its own kernel (the fused kernel: 0.233 vs 0.160 ms per linearise, profiles/r02_gicp_split_ab.jsonl)
   if (!split || f->desc.n <= 0) return 0;
   if (!f->corr.ptr) {
     if (f->corr.alloc(sizeof(int) * (size_t)f->desc.n) != GP_OK) return 0;  // no memory for the index array: the fused kernel still works
@@ -1791,7 +1791,7 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
         const gp::RowScanOut scan{scan_buf.as<int>(), reinterpret_cast<float*>(scan_buf.as<int>() + (size_t)gp::kTileKeep * nq),
                                   reinterpret_cast<float*>(scan_buf.as<int>() + (size_t)(gp::kTileKeep + 1) * nq), nq};
         hipLaunchKernelGGL(gp::covariance_rows_kernel, dim3(16u * (unsigned)g->bin_levels[0]->bins.num_occ_blocks), dim3(gp::kRowThreads), 0, s, v.bins[0],
-                           (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), scan, getenv("GP_KNN_KNOCK") ? atoi(getenv("GP_KNN_KNOCK")) : 0);
+                           (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), scan, 0);
         hipLaunchKernelGGL(gp::covariance_settle_kernel<10>, grid, block, 0, s, v.bins[0].sorted, scan, points_dev, k, covs_dev, todo.as<int>(), todo.as<int>() + nq);
         d_todo = todo.as<int>();
         if (getenv("GP_KNN_DEBUG")) {  // how much the tiled pass left over
@@ -1803,8 +1803,8 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
       }
     }
     if (nq > 0 && rc == GP_OK) {
-      static const int cov_waves = [] { const char* e = getenv("GP_COV_WAVES"); return e ? atoi(e) : 4; }();  // A/B: 3 = uncapped registers
-      static const bool cov_full = [] { const char* e = getenv("GP_COV_FULL"); return !e || atoi(e) != 0; }();  // A/B: 0 = the position-by-position insertion for k = 10 as well
+      constexpr int cov_waves = 4;      // registers capped at 128 for four waves per SIMD (uncapped, three waves: 1.41 vs 1.28 ms, round 2)
+      constexpr bool cov_full = true;   // k = 10: the straight-line insertion of full lists (profiles/r03_c5_straightline.txt)
       if (k == 10 && cov_waves == 4 && cov_full)  // (capped at 96 registers for five waves per SIMD: 41 spilled, 1.08 vs 1.07 ms -- no gain)
         hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
       else if (k <= 10 && cov_waves == 4)

@@ -69,8 +69,14 @@ constexpr int kOnePassTile = 16384;  // 1024 threads x 16: a 2 M-entry scan is 1
 constexpr int kOnePassPerThread = kOnePassTile / 1024;
 inline size_t onepass_state_words(long long m) { return 2 + (size_t)((m + kOnePassTile - 1) / kOnePassTile); }
 
-template <int UNUSED = 0>
-__global__ void __launch_bounds__(1024) scan_onepass_kernel(const int* __restrict__ in, int in_stride, int* __restrict__ out, int out_stride, long long m,
+// the scan's input as a function of the position (a flag computed from other arrays need not be stored first), or an array
+struct ScanArrayInput {
+  const int* in;
+  int stride;
+  __device__ __forceinline__ int operator()(long long i) const { return in[i * stride]; }
+};
+template <typename Input>
+__global__ void __launch_bounds__(1024) scan_onepass_kernel(const Input input, const int* __restrict__ in, int in_stride, int* __restrict__ out, int out_stride, long long m,
                                                             unsigned long long* __restrict__ state, int* __restrict__ total) {
   __shared__ int wave_sum[16];
   __shared__ int tile_id, tile_prefix;
@@ -83,7 +89,8 @@ __global__ void __launch_bounds__(1024) scan_onepass_kernel(const int* __restric
   int mine = 0;
   // a thread owns 16 consecutive elements (64 B): as four 16-byte accesses when the array is dense -- sixteen 4-byte accesses at a 64-byte lane stride cost a
   // cache-line operation per lane and instruction, 19 us for a 2 M-entry scan
-  const bool vec = in_stride == 1 && out_stride == 1 && base + kOnePassPerThread <= m && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const bool vec_out = out_stride == 1 && base + kOnePassPerThread <= m && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const bool vec = in != nullptr && in_stride == 1 && vec_out && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
   if (vec) {
     const int4* p = reinterpret_cast<const int4*>(in + base);
 #pragma unroll
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(1024) scan_onepass_kernel(const int* __restric
   } else {
 #pragma unroll
     for (int k = 0; k < kOnePassPerThread; k++) {
-      v[k] = base + k < m ? in[(base + k) * in_stride] : 0;
+      v[k] = base + k < m ? input(base + k) : 0;
       mine += v[k];
     }
   }
@@ -143,7 +150,7 @@ __global__ void __launch_bounds__(1024) scan_onepass_kernel(const int* __restric
   }
   __syncthreads();
   int run = tile_prefix + wave_excl + incl - mine;
-  if (vec) {
+  if (vec_out) {
     int4* p = reinterpret_cast<int4*>(out + base);
 #pragma unroll
     for (int q = 0; q < kOnePassPerThread / 4; q++) {
@@ -167,6 +174,15 @@ __global__ void __launch_bounds__(1024) scan_onepass_kernel(const int* __restric
 // stride.  The grand total is left at scratch[ceil(m / 1024)] (both forms).
 inline size_t scan_scratch_ints(long long m) { return (size_t)(m / kScanThreads) + 8 + 2 * onepass_state_words(m) + 2; }
 
+// exclusive scan of input(0 .. m - 1) into out[] (dense), the grand total into *total: one launch.  zeroed_state as below (required).  m <= 2^31 - 16384.
+template <typename Input>
+inline int exclusive_scan_of(const Input& input, int* out, long long m, int* total, hipStream_t s, unsigned long long* zeroed_state) {
+  if (m <= 0) return GP_OK;
+  hipLaunchKernelGGL(scan_onepass_kernel<Input>, dim3((unsigned)((m + kOnePassTile - 1) / kOnePassTile)), dim3(1024), 0, s, input, (const int*)nullptr, 1, out, 1, m, zeroed_state, total);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
 // zeroed_state: onepass_state_words(m) words the CALLER has zeroed on `s` (a build that runs several scans zeroes all their states with one fill), or null
 inline int exclusive_scan_strided(const int* in, int in_stride, int* out, int out_stride, long long m, int* scratch, hipStream_t s, unsigned long long* zeroed_state = nullptr) {
   if (m <= 0) return GP_OK;
@@ -175,7 +191,8 @@ inline int exclusive_scan_strided(const int* in, int in_stride, int* out, int ou
     // the state words live behind the total's slot, 8-byte aligned
     unsigned long long* state = zeroed_state ? zeroed_state : reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(scratch + nb + 2 + 1) & ~uintptr_t(7));
     if (!zeroed_state) GP_HIP(hipMemsetAsync(state, 0, sizeof(unsigned long long) * onepass_state_words(m), s));
-    hipLaunchKernelGGL(scan_onepass_kernel<0>, dim3((unsigned)((m + kOnePassTile - 1) / kOnePassTile)), dim3(1024), 0, s, in, in_stride, out, out_stride, m, state, scratch + nb);
+    hipLaunchKernelGGL(scan_onepass_kernel<ScanArrayInput>, dim3((unsigned)((m + kOnePassTile - 1) / kOnePassTile)), dim3(1024), 0, s, ScanArrayInput{in, in_stride}, in,
+                       in_stride, out, out_stride, m, state, scratch + nb);
     GP_HIP(hipGetLastError());
     return GP_OK;
   }

@@ -1108,7 +1108,7 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
     // batch's indices prefetched; 1024 threads + batches of eight 2.8 ms (the 128-register cap spills the batch)
     if (count > 0 && l == 0) hipLaunchKernelGGL(gp::sparse_factor_kernel<256>, dim3(count), dim3(256), 0, s->stream, s->view, first);
     if (count > 0 && l > 0) {
-      static const bool staged = [] { const char* e = getenv("GP_SPARSE_STAGED"); return !e || atoi(e) != 0; }();  // A/B: 0 = the per-entry gather for the chains as well
+      constexpr bool staged = true;  // separator chains through the LDS-staged kernel (the per-entry gather for them as well: 1.45 vs 0.93 ms, profiles/r03_solver_time.txt)
       if (staged) hipLaunchKernelGGL(gp::sparse_factor_staged_kernel<1024>, dim3(count), dim3(1024), 0, s->stream, s->view, first);
       else hipLaunchKernelGGL(gp::sparse_factor_kernel<1024>, dim3(count), dim3(1024), 0, s->stream, s->view, first);
     }

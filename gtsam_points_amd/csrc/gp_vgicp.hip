@@ -536,20 +536,14 @@ namespace {
 // A family that does not apply to a batch (no block grid, records beyond 32-bit offsets) falls back to LOOKAHEAD, and
 // that to HASHED.  Measured and removed (numbers: DESIGN.md section 8 of rounds 1-3): the f64 hashed kernel, the non-lean start, forced 512- / 256-point
 // tiles, the deep pipeline, the source-frame formulation.
-const bool g_zero_copy_poses = [] {  // A/B switch of the pose hand-over of the synchronous batched calls (stage_poses)
-  const char* e = getenv("GP_POSES_ZERO_COPY");
-  return !e || atoi(e) != 0;
-}();
+// (the A/B switches of rounds 2-3 -- GP_POSES_ZERO_COPY, GP_FINALIZE_PARTS, GP_FINALIZE_NARROW, GP_FINALIZE_HOST_EXPAND: environment variables read once per
+// process -- are gone: their measurements are in profiles/r02_*, r03_* and DESIGN.md; the winners are constants.  The library reads no environment variable that
+// changes what it computes or launches.)
+constexpr bool g_zero_copy_poses = true;  // synchronous batched calls: the kernels read the poses where the host staged them (stage_poses)
 constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
 constexpr int kFinalizePartsMax = 16;
-static int finalize_parts() {  // workgroups sharing the finalize of a synchronous single-factor call (vgicp_finalize_rigid_kernel)
-  static const int v = [] {
-    const char* e = getenv("GP_FINALIZE_PARTS");
-    const int p = e ? atoi(e) : 8;  // A/B on C2 (scripts/r02_finalize_parts.sh): 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 (and the host step suffers)
-    return p < 1 ? 1 : (p > kFinalizePartsMax ? kFinalizePartsMax : p);
-  }();
-  return v;
-}
+// workgroups sharing the finalize of a synchronous single-factor call (A/B on C2, scripts/r02/r02_finalize_parts.sh: 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 and the host step suffers)
+static constexpr int finalize_parts() { return 8; }
 constexpr int kFinalizeSplitTiles = 256;  // ... when the factor has at least this many tiles
 constexpr int kResidentWorkgroups = 1024;  // 256 compute units x 4 workgroups of the tile kernels (34-40 KB of LDS, <= 128 VGPRs)
 
@@ -923,7 +917,7 @@ int launch_finalize(gp_vgicp_batch* b, const PoseSource& ps, const double* parti
     hipLaunchKernelGGL(gp::vgicp_finalize_kernel<true>, dim3((int)b->factors.size()), dim3(gp::kFinalizeThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(),
                        ps.d_lin, ps.inl, partials, out_dev, done);
   } else {
-    static const bool narrow = [] { const char* e = getenv("GP_FINALIZE_NARROW"); return !e || atoi(e) != 0; }();  // A/B: 0 = 1024-thread parts
+    constexpr bool narrow = true;  // 256-thread parts (1024-thread ones measured slower, round 2)
     const int nparts = parts < 0 ? -parts : parts;  // (parts < 0: the parts deliver their sums, the host expands)
     if (nparts > 1 && narrow)
       hipLaunchKernelGGL(gp::vgicp_finalize_rigid_kernel<256>, dim3((int)b->factors.size() * nparts), dim3(256), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), ps.d_lin,
@@ -1516,7 +1510,7 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq, b->trace ? b->trace + 2047 * 16 : nullptr};
   const bool rigid = poses_are_rigid(poses_host, F);
   const int parts = (F == 1 && rigid && b->num_tiles >= kFinalizeSplitTiles) ? finalize_parts() : 1;
-  static const bool host_expand = [] { const char* e = getenv("GP_FINALIZE_HOST_EXPAND"); return !e || atoi(e) != 0; }();  // A/B: 0 = the parts expand
+  constexpr bool host_expand = true;  // the parts deliver their 32 sums, the host expands once (the parts expanding: measured slower, round 2)
   const bool sums_only = parts > 1 && host_expand;
   if (b->timing && !b->ev[0])
     for (auto& e : b->ev) GP_HIP(hipEventCreate(&e));

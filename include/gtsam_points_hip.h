@@ -434,7 +434,8 @@ int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_
 /* ---- per-handle tuning (not part of the reference API) --------------------------------------------------------------------------
  * Every knob below belongs to ONE batch / factor / map / search structure; the library keeps no process-global switches, so two
  * handles driven from two threads never see each other's settings (thread-compatible per handle, re-entrant across
- * handles; tests/test_vgicp_gpu.py::test_two_threads_two_batches).
+ * handles; tests/test_vgicp_gpu.py::test_two_threads_two_batches).  The library reads ONE environment variable, GP_KNN_DEBUG: when set, the structure builds print
+ * their host-side timing split to stderr; nothing that is computed or launched depends on the environment (the A/B variables of rounds 2-3 are gone).
  *
  * GP_TUNE_KERNEL selects the tile-kernel family of a VGICP batch.  M = (C_B + R C_A R^T)^-1, the transform and the residual are f64
  * in every family; "f32 outer products" computes what follows the inverse in f32 (measured parity vs the CPU factor <= 1e-7
