@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "gp_binning.hpp"
+#include "gp_scan.hpp"
 #include "gp_host.hpp"
 #include "gp_vgicp_tile.hpp"
 
@@ -443,14 +444,18 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
   auto flush_ranges = [&]() {
     int ri = 0, p = 0, pe = 0;
     auto next_range = [&]() {
-      if (ri < rl_count) {
+      p = 0;
+      pe = 0;
+      while (ri < rl_count) {
         const int2 rg = rl[ri * kRangeStride];
         ri++;
+        // round 4: a cell collected while the list was not full yet (or the bound still loose) is looked at again when its turn comes: by then a dense cell in front of
+        // it has usually brought the k-th distance down to centimetres, and a cell whose box is farther than that holds nothing of interest -- the queries that needed
+        // shell 1 because their own cell held fewer than k points used to scan all 26 neighbours in full (up to 465 candidates on a lane, the launch's longest waves)
+        if (__int_as_float(rg.y & (int)0xffff0000) > accept) continue;
         p = rg.x;
-        pe = rg.y;
-      } else {
-        p = 0;
-        pe = 0;
+        pe = rg.x + (rg.y & 0xffff);
+        break;
       }
     };
     next_range();
@@ -477,13 +482,19 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
     }
     rl_count = 0;
   };
-  auto visit_range = [&](int pb, int pe) {
+  // box2: squared distance of the cell's box from the query (0 for the own cell), already scaled down by the slack of the collection-time test; kept with the range as
+  // the upper 16 bits of a float -- truncated, i.e. rounded DOWN: the re-test at scan time can only keep more than the exact value would -- beside a 16-bit count
+  auto visit_range = [&](int pb, int pe, float box2) {
     if constexpr (!FLAT) {
       scan_range(pb, pe);
-    } else if (pe > pb) {
-      rl[rl_count * kRangeStride] = make_int2(pb, pe);
-      rl_count++;
-      if (__builtin_amdgcn_ballot_w64(rl_count >= kRangeCap) != 0ull) flush_ranges();  // (some lane's list is full: the lanes that are here scan what they hold)
+    } else {
+      while (pe > pb) {
+        const int cnt = min(pe - pb, 0xffff);
+        rl[rl_count * kRangeStride] = make_int2(pb, cnt | (__float_as_int(box2) & (int)0xffff0000));
+        rl_count++;
+        pb += cnt;
+        if (__builtin_amdgcn_ballot_w64(rl_count >= kRangeCap) != 0ull) flush_ranges();  // (some lane's list is full: the lanes that are here scan what they hold)
+      }
     }
   };
   const int rlast = (max_shells < rmax - r0) ? r0 + max_shells : rmax;
@@ -519,6 +530,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
             while (m) {
               const int bit = __ffsll((long long)m) - 1;
               m &= m - 1ull;
+              float box2 = 0.0f;
               if (r > 0) {
                 // a cell whose box is farther from the query than the current k-th neighbour holds nothing of interest (the corners of a shell's cube
                 // usually are): box distance in cell units, f32 with slack -- the test only ever SKIPS, and only cells every point of which fails the
@@ -526,13 +538,14 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
                 // (relative to the query's own cell: small integers and the query's position inside its cell, exact to 1e-7 whatever the coordinates)
                 const float rx = (float)(4 * bx + (bit & 3) - c[0]) - fxf, ry = (float)(4 * by + ((bit >> 2) & 3) - c[1]) - fyf, rz = (float)(4 * bz + (bit >> 4) - c[2]) - fzf;
                 const float ex = fmaxf(fmaxf(rx, -rx - 1.0f), 0.0f), ey = fmaxf(fmaxf(ry, -ry - 1.0f), 0.0f), ez = fmaxf(fmaxf(rz, -rz - 1.0f), 0.0f);
-                if ((ex * ex + ey * ey + ez * ez) * h2f * 0.9999f > accept) continue;
+                box2 = (ex * ex + ey * ey + ez * ez) * h2f * 0.9999f;
+                if (box2 > accept) continue;
               }
               const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
               const int pb = g.cell_start[ord], pe = g.cell_start[ord + 1];
               n_cell++;
               n_f32 += (unsigned)(pe - pb);
-              visit_range(pb, pe);
+              visit_range(pb, pe, box2);
             }
           }
         }
@@ -1008,6 +1021,35 @@ __device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX, FULL
       for (int kk = 0; kk < 3; kk++) s += V[kk * 3 + r] * lam[kk] * Vinv[c * 3 + kk];
       out[c * 3 + r] = (float)s;
     }
+}
+
+// Heavy queries first (round 4).  A query whose own cell holds fewer than k points cannot settle in shell 0: it walks shell 1 at least -- 26 more cells, dense ones
+// scanned in full until its list is full, or shell after shell of empty space in the far field -- and a wave of such queries runs 300-500 us against a mean of ~90
+// (profiles/r04_c5_wavelog.txt).  In cell-sorted order those waves are scattered over the launch, and the ones that start late ARE its tail (99 % of the waves done
+// at 420 us, the last at 710).  The launch therefore takes its queries through an order array: the positions of the queries with own-cell population < k first
+// (ascending, so that neighbours in the list are still neighbours in space), all others behind them -- longest-processing-time-first with a per-query predictor,
+// and waves whose lanes have alike work.  Same queries, same per-query search: identical results.
+struct HeavyQueryFlag {
+  BinGridView g;  // (the cell ordinals of the sorted positions are not kept with the structure: the query's cell is looked up like the search does)
+  int k;
+  __device__ __forceinline__ int operator()(long long t) const {
+    const float4 q = g.sorted[t];
+    const int cx = fast_floor((double)q.x * g.inv_h), cy = fast_floor((double)q.y * g.inv_h), cz = fast_floor((double)q.z * g.inv_h);
+    const size_t bi = ((size_t)((cz >> 2) - g.geom.lo[2]) * (size_t)g.geom.dim[1] + (size_t)((cy >> 2) - g.geom.lo[1])) * (size_t)g.geom.dim[0] + (size_t)((cx >> 2) - g.geom.lo[0]);
+    const int4 raw = *reinterpret_cast<const int4*>(g.blocks + bi);
+    const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
+    const int bit = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+    const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
+    return (g.cell_start[ord + 1] - g.cell_start[ord] < k) ? 1 : 0;
+  }
+};
+__global__ void __launch_bounds__(256) heavy_first_order_kernel(HeavyQueryFlag flag, const int* __restrict__ heavy_before, const int* __restrict__ num_heavy, int nq,
+                                                                int* __restrict__ order) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nq) return;
+  if (t == 0) order[nq] = nq;  // (the list's length, where covariance_kernel's todo protocol reads it)
+  const int hb = heavy_before[t];
+  order[flag(t) ? hb : *num_heavy + (t - hb)] = t;
 }
 
 // estimate_covariances, per-lane search (every query walks its own shells; see knn_query_bins / knn_query): the general path, and
@@ -1624,7 +1666,7 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
 int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
-  if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4} (>= 16: staging experiment)");
+  if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure != 6 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4, 6} (>= 16: staging experiment)");
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
   g->structure = structure;
@@ -1799,6 +1841,23 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
           (void)hipMemcpyAsync(&left, todo.as<int>() + nq, sizeof(int), hipMemcpyDeviceToHost, s);
           (void)hipStreamSynchronize(s);
           fprintf(stderr, "gp_estimate_covariances: tiled pass over %d blocks settled %d of %d queries\n", g->bin_levels[0]->bins.num_occ_blocks, nq - left, nq);
+        }
+      }
+    }
+    gp::DeviceArray heavy_before, order_state;
+    if (nq > 0 && rc == GP_OK && g->binned && !d_todo && g->structure != 6) {
+      // heavy queries first (HeavyQueryFlag above): order[] = positions with own-cell population < k, then the rest; one scan + one scatter (~15 us per 1 M points)
+      const gp::HeavyQueryFlag flag{v.bins[0], k};
+      rc = todo.alloc_async(sizeof(int) * ((size_t)nq + 2), s);
+      if (rc == GP_OK) rc = heavy_before.alloc_async(sizeof(int) * (size_t)nq, s);
+      if (rc == GP_OK) rc = order_state.alloc_async(sizeof(unsigned long long) * gp::onepass_state_words(nq), s);
+      if (rc == GP_OK) {
+        (void)hipMemsetAsync(order_state.ptr, 0, sizeof(unsigned long long) * gp::onepass_state_words(nq), s);
+        int* d_heavy = todo.as<int>() + nq + 1;
+        rc = gp::exclusive_scan_of(flag, heavy_before.as<int>(), nq, d_heavy, s, order_state.as<unsigned long long>());
+        if (rc == GP_OK) {
+          hipLaunchKernelGGL(gp::heavy_first_order_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, flag, (const int*)heavy_before.as<int>(), (const int*)d_heavy, nq, todo.as<int>());
+          d_todo = todo.as<int>();
         }
       }
     }
