@@ -24,16 +24,29 @@ __device__ __forceinline__ bool point_cell(const float* __restrict__ points, siz
   return ok;
 }
 
-// per-workgroup bounding box (block units) of the finite points: boxes[wg][6] = {min xyz, max xyz}; a workgroup without a finite
-// point writes the neutral box
+// bounding box (block units) of the finite points: a workgroup reduces 4096 points (the sixteen loads of a thread in flight together) into boxes[wg][6] = {min xyz,
+// max xyz}; a workgroup without a finite point writes the neutral box.  (Round 4 tried one launch -- the boxes folded into six words with atomicMax, the last
+// workgroup by ticket writing the result: 488 atomics on one address are served one after the other, 16 us; this pair is 8.)
+constexpr int kBboxTile = 4096;
 __global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict__ points, int n, double inv_cell, int* __restrict__ boxes) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  if (i < (size_t)n) {
-    int c[3];
-    if (point_cell(points, i, inv_cell, c[0], c[1], c[2])) {
+  const size_t base = (size_t)blockIdx.x * kBboxTile;
+  float p[kBboxTile / 256][3];
 #pragma unroll
-      for (int a = 0; a < 3; a++) lo[a] = hi[a] = c[a] >> 2;
+  for (int r = 0; r < kBboxTile / 256; r++) {
+    const size_t i = min(base + (size_t)r * 256 + threadIdx.x, (size_t)n - 1);  // (a point seen twice does not change the box)
+#pragma unroll
+    for (int a = 0; a < 3; a++) p[r][a] = points[3 * i + a];
+  }
+#pragma unroll
+  for (int r = 0; r < kBboxTile / 256; r++) {
+    const double ux = (double)p[r][0] * inv_cell, uy = (double)p[r][1] * inv_cell, uz = (double)p[r][2] * inv_cell;
+    const bool ok = fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9;  // (point_cell's rule)
+    const int c[3] = {fast_floor(ux) >> 2, fast_floor(uy) >> 2, fast_floor(uz) >> 2};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = ok ? min(lo[a], c[a]) : lo[a];
+      hi[a] = ok ? max(hi[a], c[a]) : hi[a];
     }
   }
 #pragma unroll
@@ -59,7 +72,7 @@ __global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __restrict__ boxes, int nb, int* __restrict__ bbox) {
+__global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __restrict__ boxes, int nb, int* __restrict__ bbox /* host-mapped */, int seq) {
   __shared__ int part[256][6];
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   for (int b = threadIdx.x; b < nb; b += 256)
@@ -77,84 +90,217 @@ __global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __rest
       for (int a = 0; a < 6; a++) part[threadIdx.x][a] = a < 3 ? min(part[threadIdx.x][a], part[threadIdx.x + w][a]) : max(part[threadIdx.x][a], part[threadIdx.x + w][a]);
     __syncthreads();
   }
-  if (threadIdx.x < 6) bbox[threadIdx.x] = part[0][threadIdx.x];
+  if (threadIdx.x < 6) {
+    bbox[threadIdx.x] = part[0][threadIdx.x];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the box is in host memory before the flag is stored (HostWords::wait_flag)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) bbox[HostWords::kFlag] = seq;
 }
 
-// sort key of a point: (block index, bit inside the block) -- the order the cells are numbered in.  < 2^24 * 64 = 2^30
-__global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)n) return;
-  int cx, cy, cz;
-  unsigned key = kInvalidKey;
-  if (point_cell(points, i, inv_cell, cx, cy, cz)) key = (unsigned)(grid_block_index(g, cx, cy, cz) * 64 + grid_bit(cx, cy, cz));
-  keys[i] = key;
-}
-
-// sorted keys -> 1 at the first point of every cell (0 elsewhere and on the skipped points behind the cells).  Round 4: the flags are not stored -- the scan and the
-// kernels behind it evaluate them where they need them (one kernel, one 8 MB array and its read-back less per build)
-struct CellStartFlag {
-  const unsigned* sorted_keys;
-  __device__ __forceinline__ int operator()(long long j) const {
-    const unsigned k = sorted_keys[j];
-    return (k != kInvalidKey && (j == 0 || sorted_keys[j - 1] != k)) ? 1 : 0;
-  }
-};
-// cell c opens a block when it is the block's first cell (entries behind the last cell: 0)
-struct BlockStartFlag {
-  const int* num_cells;
-  const int* cell_block;
-  const GridBlock* blocks;
-  __device__ __forceinline__ int operator()(long long c) const { return (c < *num_cells && blocks[cell_block[c]].base == (int)c) ? 1 : 0; }
-};
-
-// ordinal of every sorted point's cell (exclusive scan of the flags, + its own flag, - 1); at the first point of a cell: the cell's
-// start, its occupancy bit, and -- at the first cell of a block -- the block's base.  total[0] = number of cells.
-__global__ void __launch_bounds__(256) bins_finish_kernel(const unsigned* __restrict__ sorted_keys, const int* __restrict__ scanned, int n,
-                                                          const int* __restrict__ total, GridBlock* __restrict__ blocks, int* __restrict__ cell_start,
-                                                          unsigned* __restrict__ cell_of, int* __restrict__ cell_block, int* __restrict__ num_binned,
-                                                          int* __restrict__ host_counts /* host-mapped: [8] binned points, [9] cells */) {
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= (size_t)n) return;
-  const unsigned k = sorted_keys[j];
-  const int num_cells = *total;
-  if (j == 0) {
-    num_binned[1] = num_cells;  // (kept for the kernels behind: the scan's slot is re-used)
-    host_counts[9] = num_cells;
-  }
-  if (k == kInvalidKey) {
-    cell_of[j] = kInvalidKey;
-    if (j == 0 || sorted_keys[j - 1] != kInvalidKey) {
-      cell_start[num_cells] = (int)j;
-      *num_binned = (int)j;
-      host_counts[8] = (int)j;
+// sort key of a point: (block index, bit inside the block) -- the order the cells are numbered in.  < 2^24 * 64 = 2^30.  The kernel also counts the keys' digits for
+// every pass of the sort behind it (gp_sort.hpp: the sort needs no pass over the keys for that).
+constexpr int kKeyTile = 4096;
+__global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys, int passes,
+                                                       unsigned* __restrict__ hist) {
+  __shared__ SortHistLds l;
+  sort_hist_clear(l);
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * kKeyTile;
+  // two halves of eight points: the loads of a half are in flight together
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    float p[8][3];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const size_t i = min(base + (size_t)(half * 8 + r) * 256 + threadIdx.x, (size_t)n - 1);
+#pragma unroll
+      for (int a = 0; a < 3; a++) p[r][a] = points[3 * i + a];
     }
-    return;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const size_t i = base + (size_t)(half * 8 + r) * 256 + threadIdx.x;
+      const double ux = (double)p[r][0] * inv_cell, uy = (double)p[r][1] * inv_cell, uz = (double)p[r][2] * inv_cell;
+      const bool ok = fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9;  // (point_cell's rule)
+      const int cx = fast_floor(ux), cy = fast_floor(uy), cz = fast_floor(uz);
+      const unsigned key = ok ? (unsigned)(grid_block_index(g, cx, cy, cz) * 64 + grid_bit(cx, cy, cz)) : kInvalidKey;
+      if (i < (size_t)n) {
+        keys[i] = key;
+        sort_hist_count(l, key, passes);
+      }
+    }
   }
-  const int flag = (j == 0 || sorted_keys[j - 1] != k) ? 1 : 0;  // (CellStartFlag)
-  const int ord = scanned[j] + flag - 1;
-  cell_of[j] = (unsigned)ord;
-  if (flag) {
-    cell_start[ord] = (int)j;
-    cell_block[ord] = (int)(k >> 6);
-    GridBlock* blk = blocks + (k >> 6);
-    atomicOr(&blk->bits, 1ull << (k & 63u));  // one atomic per CELL (not per point); the bits of a block come from <= 64 cells
-    if (j == 0 || (sorted_keys[j - 1] >> 6) != (k >> 6)) blk->base = ord;
+  __syncthreads();
+  sort_hist_flush(l, passes, hist);
+}
+
+// Cells = runs of equal keys in the sorted order.  TWO kernels (round 4; was: scan of the cell-start flags, a kernel writing the cells, scan of the block-start
+// flags, a kernel writing the block list -- 61 us per 2 M points, with an 8 MB array of scanned flags written and read twice between them).  A workgroup takes a tile
+// of 4096 sorted keys; bins_count_kernel counts the cells AND the blocks that start in it (one packed sum: cells in the low 31 bits, blocks above), stores the
+// tile's word and adds it to its group's word (32 tiles per group).  bins_cells_kernel forms the flags again, takes its prefix = the groups in front + the tiles in
+// front inside its own group (one entry per lane of the first wave), and writes, per point, the ordinal of its cell; at the first point of a cell: the cell's
+// start, its block and its occupancy bit; at the first cell of a block: the block's base and its entry in the compact list of occupied blocks.
+// The thread that sees the end of the binned points (the first skipped point, or the last point) knows all three counts -- binned points, cells, blocks -- and stores
+// them for the host (host_counts[8..10], host-mapped words).
+// (One kernel with the tiles waiting for their predecessors' words was tried first: the wait directly follows the publication, so every tile waits for the slowest
+// tile in front of it -- 16 us median for the 488 tiles of 2 M points, of a 33 us kernel: scripts/probe/bins_probe.hip.  The sort's passes hide the same wait behind
+// their ranking; here there is nothing to hide it behind, and the second read of the keys comes from the cache.)
+// state (64-bit words, zeroed): group words [groups], behind them tile words [tiles].
+constexpr int kCellsTile = 4096, kCellsPerThread = 16, kCellsGroup = 32;
+inline size_t cells_tiles(long long n) { return (size_t)((n + kCellsTile - 1) / kCellsTile); }
+inline size_t cells_groups(long long n) { return (cells_tiles(n) + kCellsGroup - 1) / kCellsGroup; }
+inline size_t cells_state_words(long long n) { return cells_groups(n) + cells_tiles(n); }
+
+// a thread's 16 consecutive sorted keys and their flags: bit k of cflag = a cell starts at element k, of bflag = a block starts there
+struct CellKeys {
+  unsigned key[kCellsPerThread];
+  unsigned prev0, cflag, bflag;
+  bool full, any, has_prev;
+};
+__device__ __forceinline__ void load_cell_keys(const unsigned* __restrict__ sorted_keys, int n, long long base, CellKeys& c) {
+  c.full = base + kCellsPerThread <= (long long)n;
+  if (c.full && (reinterpret_cast<uintptr_t>(sorted_keys) & 15) == 0) {
+    const uint4* p = reinterpret_cast<const uint4*>(sorted_keys + base);
+#pragma unroll
+    for (int q = 0; q < kCellsPerThread / 4; q++) {
+      const uint4 x = p[q];
+      c.key[4 * q] = x.x, c.key[4 * q + 1] = x.y, c.key[4 * q + 2] = x.z, c.key[4 * q + 3] = x.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kCellsPerThread; k++) c.key[k] = base + k < (long long)n ? sorted_keys[base + k] : kInvalidKey;
   }
-  if (j == (size_t)n - 1) {
-    cell_start[num_cells] = n;
-    *num_binned = n;
-    host_counts[8] = n;
+  c.any = base < (long long)n;
+  c.has_prev = c.any && base > 0;
+  c.prev0 = c.has_prev ? sorted_keys[base - 1] : 0u;
+  c.cflag = 0, c.bflag = 0;
+  unsigned prev = c.prev0;
+  bool have = c.has_prev;
+#pragma unroll
+  for (int k = 0; k < kCellsPerThread; k++) {
+    const bool in = base + k < (long long)n && c.key[k] != kInvalidKey;
+    if (in && (!have || prev != c.key[k])) c.cflag |= 1u << k;
+    if (in && (!have || (prev >> 6) != (c.key[k] >> 6))) c.bflag |= 1u << k;
+    prev = c.key[k];
+    have = true;
   }
 }
 
-// occupied blocks as a compact ascending list: cell c opens a block when it is the block's first cell
-// occupied blocks as a compact ascending list (launched over all n positions: the cell count is still on the device)
-__global__ void __launch_bounds__(256) bins_block_list_kernel(const int* __restrict__ num_cells, const int* __restrict__ cell_block, const GridBlock* __restrict__ blocks,
-                                                              const int* __restrict__ scanned, int* __restrict__ occ_blocks, const int* __restrict__ scan_total,
-                                                              int* __restrict__ num_occ_out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0) *num_occ_out = *scan_total;
-  if (c < *num_cells && blocks[cell_block[c]].base == c) occ_blocks[scanned[c]] = cell_block[c];
+__global__ void __launch_bounds__(256) bins_count_kernel(const unsigned* __restrict__ sorted_keys, int n, unsigned long long* __restrict__ state, int num_groups) {
+  __shared__ unsigned long long wave_sum[4];
+  const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  CellKeys c;
+  load_cell_keys(sorted_keys, n, (long long)tile * kCellsTile + (long long)threadIdx.x * kCellsPerThread, c);
+  unsigned long long sum = (unsigned long long)__popc(c.cflag) | ((unsigned long long)__popc(c.bflag) << 31);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) wave_sum[wave] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    state[num_groups + tile] = total;
+    if (total) atomicAdd(state + tile / kCellsGroup, total);  // (integer sum of <= 32 tiles: the order does not matter)
+  }
+}
+
+__global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restrict__ sorted_keys, int n, const unsigned long long* __restrict__ state, int num_groups,
+                                                         GridBlock* __restrict__ blocks, int* __restrict__ cell_start, unsigned* __restrict__ cell_of, int* __restrict__ cell_block,
+                                                         int* __restrict__ occ_blocks, int* __restrict__ host_counts /* host-mapped */, int seq) {
+  __shared__ unsigned long long wave_sum[4];
+  __shared__ unsigned long long tile_prefix;
+  const int tile = blockIdx.x;
+  GP_SORT_STAMP(tile, 0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)tile * kCellsTile + (long long)threadIdx.x * kCellsPerThread;
+  // the tile's prefix: the groups in front, then the tiles in front inside the own group (asked for first: the answer arrives with the keys)
+  unsigned long long prefix = 0;
+  if (wave == 0) {
+    const int group = tile / kCellsGroup, in_group = tile % kCellsGroup;
+    const int entries = group + in_group;
+    for (int e0 = 0; e0 < entries; e0 += 64) {
+      const int e = e0 + lane;
+      unsigned long long w = 0;
+      if (e < entries) w = e < group ? state[e] : state[num_groups + (size_t)group * kCellsGroup + (e - group)];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+      prefix += w;
+    }
+  }
+  CellKeys ck;
+  load_cell_keys(sorted_keys, n, base, ck);
+  unsigned (&key)[kCellsPerThread] = ck.key;
+  const unsigned cflag = ck.cflag, bflag = ck.bflag, prev0 = ck.prev0;
+  const bool full = ck.full, any = ck.any, has_prev = ck.has_prev;
+  const unsigned long long mine = (unsigned long long)__popc(cflag) | ((unsigned long long)__popc(bflag) << 31);
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  if (threadIdx.x == 0) tile_prefix = prefix;
+  __syncthreads();
+  GP_SORT_STAMP(tile, 1);  // keys loaded, flags counted, prefix known
+  unsigned long long wave_excl = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    if (w < wave) wave_excl += wave_sum[w];
+  GP_SORT_STAMP(tile, 2);
+  if (!any) return;
+  const unsigned long long excl = tile_prefix + wave_excl + incl - mine;
+  const int cells0 = (int)(excl & 0x7fffffffull), blocks0 = (int)(excl >> 31);  // cells / blocks that start in front of this thread's first element
+  // the ordinal of every element's cell: cells that start at or before it, minus one (straight-line: no branch per element)
+  unsigned ord_out[kCellsPerThread];
+#pragma unroll
+  for (int k = 0; k < kCellsPerThread; k++) ord_out[k] = key[k] == kInvalidKey ? kInvalidKey : (unsigned)(cells0 + __popc(cflag & ((2u << k) - 1u)) - 1);
+  if (full && (reinterpret_cast<uintptr_t>(cell_of) & 15) == 0) {
+    uint4* p = reinterpret_cast<uint4*>(cell_of + base);
+#pragma unroll
+    for (int q = 0; q < kCellsPerThread / 4; q++) p[q] = make_uint4(ord_out[4 * q], ord_out[4 * q + 1], ord_out[4 * q + 2], ord_out[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kCellsPerThread; k++)
+      if (base + k < (long long)n) cell_of[base + k] = ord_out[k];
+  }
+  GP_SORT_STAMP(tile, 3);  // ordinals stored
+  // the cells that start here: one trip per set flag (a voxel map has a cell start every ~27 points, a search grid every ~4), not one per element
+  for (unsigned rest = cflag; rest;) {
+    const int k = __ffs(rest) - 1;
+    rest &= rest - 1u;
+    unsigned kk = key[0];
+#pragma unroll
+    for (int q = 1; q < kCellsPerThread; q++) kk = k == q ? key[q] : kk;  // (register array: select, no indexing)
+    const int ord = cells0 + __popc(cflag & ((1u << k) - 1u));
+    cell_start[ord] = (int)(base + k);
+    cell_block[ord] = (int)(kk >> 6);
+    atomicOr(&blocks[kk >> 6].bits, 1ull << (kk & 63u));  // one atomic per CELL (integer: the result does not depend on the order)
+    if ((bflag >> k) & 1u) {
+      const int bo = blocks0 + __popc(bflag & ((1u << k) - 1u));
+      blocks[kk >> 6].base = ord;
+      occ_blocks[bo] = (int)(kk >> 6);
+    }
+  }
+  GP_SORT_STAMP(tile, 4);  // cells written
+  // the end of the binned points: the first skipped point (they sort behind every cell), or the last point
+  const int cells_end = cells0 + __popc(cflag), blocks_end = blocks0 + __popc(bflag);
+  int end_at = -1;
+  {
+    bool prev_binned = has_prev ? prev0 != kInvalidKey : true;  // (element 0 of a cloud without a single binned point closes it at 0)
+#pragma unroll
+    for (int k = 0; k < kCellsPerThread; k++) {
+      const bool in_range = base + k < (long long)n;
+      if (in_range && key[k] == kInvalidKey && prev_binned && end_at < 0) end_at = (int)(base + k);
+      if (in_range && base + k == (long long)n - 1 && key[k] != kInvalidKey) end_at = n;
+      prev_binned = key[k] != kInvalidKey;
+    }
+  }
+  if (end_at >= 0) {
+    cell_start[cells_end] = end_at;
+    host_counts[8] = end_at, host_counts[9] = cells_end, host_counts[10] = blocks_end;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counts are in host memory before the flag is stored (HostWords::wait_flag)
+    host_counts[HostWords::kFlag] = seq;
+  }
 }
 
 }  // namespace
@@ -169,20 +315,28 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
     GP_HIP(hipMemsetAsync(bins->cell_start.ptr, 0, sizeof(int), s));
     return GP_OK;
   }
-  const int wgs = (n + 255) / 256;
+  if (n >= (1 << 30)) return fail(GP_ERROR_INVALID_ARGUMENT, "bin_points: at most 2^30 - 1 points");
   const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  // ---- bounding box ----
-  DeviceArray boxes, d_small;  // d_small (device): [8] binned points, [9] cells -- what the kernels behind read (a host-mapped word would be a PCIe read per wave)
+  // ---- the state words of every kernel of this build (per sort pass -- sized for the widest key --, the histograms, the cells kernel's): ONE fill ----
+  DeviceArray states;
   HostWords hw;  // host-mapped: [0..5] bounding box, [8] binned points, [9] cells, [10] occupied blocks -- written by the kernels, read behind the synchronisations
   GP_TRY(HostWords::get(&hw));
-  GP_TRY(boxes.alloc_async(sizeof(int) * 6 * (size_t)wgs, s));
-  GP_TRY(d_small.alloc_async(sizeof(int) * 16, s));
-  hipLaunchKernelGGL(bins_bbox_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, boxes.as<int>());
-  hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), wgs, hw.dev);
+  const size_t sort_words = radix_sort_state_words32(n, 32) /* 32-bit */, cells_words = cells_state_words(n) /* 64-bit */;
+  const size_t sort_off = 0, cells_off = (sort_off + sort_words * 4 + 7) & ~size_t(7), state_bytes = cells_off + cells_words * 8;
+  GP_TRY(states.alloc_async(state_bytes, s));
+  GP_HIP(hipMemsetAsync(states.ptr, 0, state_bytes, s));
+  char* st = states.as<char>();
+  // ---- bounding box ----
+  DeviceArray boxes;
+  const int box_wgs = (n + kBboxTile - 1) / kBboxTile;
+  GP_TRY(boxes.alloc_async(sizeof(int) * 6 * (size_t)box_wgs, s));
+  hipLaunchKernelGGL(bins_bbox_kernel, dim3(box_wgs), dim3(256), 0, s, points_dev, n, inv_cell, boxes.as<int>());
+  const int seq_box = hw.next_seq();
+  hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), box_wgs, hw.dev, seq_box);
   GP_HIP(hipGetLastError());
-  GP_HIP(hipStreamSynchronize(s));
+  GP_TRY(hw.wait_flag(seq_box, s));
   int h_bbox[6];
   for (int a = 0; a < 6; a++) h_bbox[a] = reinterpret_cast<volatile int*>(hw.host)[a];
   const double t1 = now();
@@ -204,64 +358,53 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   }
   bins->num_blocks = (long long)bins->geom.dim[0] * bins->geom.dim[1] * bins->geom.dim[2];
   // ---- keys = (block, bit), stable sort, cells = runs of equal keys ----
-  DeviceArray keys_b, vals_b, sort_scratch, scanned, scan_scratch, states;
+  DeviceArray keys_b, vals_b;
   GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_HIP(hipMemsetAsync(bins->blocks.ptr, 0, sizeof(GridBlock) * (size_t)bins->num_blocks, s));
   GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
   GP_TRY(bins->order.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
   GP_TRY(vals_b.alloc_pooled(sizeof(int) * (size_t)n, s));
-  GP_TRY(sort_scratch.alloc_async(sizeof(int) * radix_sort_scratch_ints(n), s));
-  GP_TRY(scanned.alloc_async(sizeof(int) * (size_t)n, s));
-  GP_TRY(scan_scratch.alloc_async(sizeof(int) * scan_scratch_ints(n), s));
-  hipLaunchKernelGGL(bins_key_kernel, dim3(wgs), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>());
-  GP_HIP(hipGetLastError());
   int bits = 6;
   while ((1ll << bits) < bins->num_blocks * 64) bits++;
   // skipped points carry kInvalidKey = 0x7fffffff: every pass sees all-ones digits, so they land behind every cell
   bool in_b = false;
-  // the look-back states of every scan of this build (one per sort pass, two over the sorted points): ONE fill
   const int key_bits = std::min(bits + 1, 31);
-  const size_t sort_words = radix_sort_state_words(n, key_bits), scan_words = onepass_state_words(n);
-  GP_TRY(states.alloc_async(sizeof(unsigned long long) * (sort_words + 2 * scan_words), s));
-  GP_HIP(hipMemsetAsync(states.ptr, 0, sizeof(unsigned long long) * (sort_words + 2 * scan_words), s));
-  unsigned long long* st = states.as<unsigned long long>();
-  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_scratch.as<int>(), s, &in_b, st));
+  unsigned* sort_state = reinterpret_cast<unsigned*>(st + sort_off);
+  hipLaunchKernelGGL(bins_key_kernel, dim3((n + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), (key_bits + 7) / 8,
+                     radix_sort_hist(sort_state, n, key_bits));
+  GP_HIP(hipGetLastError());
+  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_state, true, true, s, &in_b));
   if (in_b) {
     bins->cell_of.swap(keys_b);
     bins->order.swap(vals_b);
   }
-  // keys_b is free now: it receives the sorted keys' cell ordinals while cell_of still holds the sorted keys
-  GP_TRY(exclusive_scan_of(CellStartFlag{bins->cell_of.as<unsigned>()}, scanned.as<int>(), n, scan_scratch.as<int>() + (int)(((long long)n + kScanThreads - 1) / kScanThreads), s,
-                           st + sort_words));
-  const int scan_blocks = (int)(((long long)n + kScanThreads - 1) / kScanThreads);
-  const int* d_total = scan_scratch.as<int>() + scan_blocks;  // the scan's grand total = number of cells
-  // (round 4: no host round trip in the middle -- the arrays the cell count would size are allocated for the worst case, one cell per point, and the kernels behind
-  // read the count where the scan left it; the host learns cells, occupied blocks and binned points together at the end)
+  // keys_b is free now: it receives the sorted points' cell ordinals while cell_of still holds the sorted keys
+  // (no host round trip in the middle: the arrays the cell count would size are allocated for the worst case, one cell per point; the host learns cells, occupied
+  // blocks and binned points together at the end)
   const double t2 = now();
-  const double t3 = t2;
   GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)n + 1), s));
   GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
-  hipLaunchKernelGGL(bins_finish_kernel, dim3(wgs), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), (const int*)scanned.as<int>(), n, d_total, bins->blocks.as<GridBlock>(), bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(),
-                     d_small.as<int>() + 8, hw.dev);
+  const int seq_cells = hw.next_seq();
+  hipLaunchKernelGGL(bins_count_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n,
+                     reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n));
+  hipLaunchKernelGGL(bins_cells_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n,
+                     (const unsigned long long*)reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n), bins->blocks.as<GridBlock>(),
+                     bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(), bins->occ_blocks.as<int>(), hw.dev, seq_cells);
   GP_HIP(hipGetLastError());
   bins->cell_of.swap(keys_b);  // cell_of = ordinals of the sorted points
-  // the compact list of occupied blocks (flags / scanned are re-used: num_cells <= n; entries behind the last cell are flagged 0)
-  // (bins_finish_kernel left the cell count in d_small[9]: the second scan re-uses the first one's slot)
-  const int* d_cells = d_small.as<int>() + 9;
-  GP_TRY(exclusive_scan_of(BlockStartFlag{d_cells, bins->cell_block.as<int>(), bins->blocks.as<GridBlock>()}, scanned.as<int>(), n, const_cast<int*>(d_total), s,
-                           st + sort_words + scan_words));
-  hipLaunchKernelGGL(bins_block_list_kernel, dim3(wgs), dim3(256), 0, s, d_cells, (const int*)bins->cell_block.as<int>(), (const GridBlock*)bins->blocks.as<GridBlock>(),
-                     (const int*)scanned.as<int>(), bins->occ_blocks.as<int>(), d_total, hw.dev + 10);
-  GP_HIP(hipGetLastError());
-  // the occupied-block count = the second scan's total: bins_block_list_kernel copies it next to the others
-  GP_HIP(hipStreamSynchronize(s));
+  // the counts are awaited, not the kernels: what the caller issues behind this is ordered by the stream, and the scratch arrays go back to the pool in ITS order
+  GP_TRY(hw.wait_flag(seq_cells, s));
+  keys_b.release_on(s);
+  vals_b.release_on(s);
+  states.release_on(s);
+  boxes.release_on(s);
   const int h_counts[3] = {reinterpret_cast<volatile int*>(hw.host)[9], reinterpret_cast<volatile int*>(hw.host)[10], reinterpret_cast<volatile int*>(hw.host)[8]};  // cells, occupied blocks, binned points
   bins->num_cells = h_counts[0];
   bins->num_occ_blocks = h_counts[0] > 0 ? h_counts[1] : 0;
   bins->num_binned = h_counts[2];
-  if (dbg) fprintf(stderr, "bin_points: bbox %.0f us, sort issue %.0f us, wait %.0f us, finish %.0f us\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  if (dbg) fprintf(stderr, "bin_points: bbox %.0f us, sort issue %.0f us, finish %.0f us\n", t1 - t0, t2 - t1, now() - t2);
   return GP_OK;
 }
 

@@ -6,6 +6,8 @@
 
 #include <atomic>
 #include <memory>
+#include <chrono>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -265,7 +267,26 @@ int acquire_source_mirror(const float* points, const float* covs, int n, int dev
 struct HostWords {
   int* host = nullptr;
   int* dev = nullptr;
+  int* seq = nullptr;  // this thread's sequence counter for word kFlag (below)
   static constexpr int kWords = 64;
+  // Word kFlag is a completion flag: the host draws a fresh sequence number (next_seq), hands it to the LAST kernel of a step, and that kernel stores it behind its
+  // result words (stores to host memory, `s_waitcnt vmcnt(0)` between the results and the flag).  wait_flag polls the word -- the host sees it ~1 us behind the store,
+  // where hipStreamSynchronize adds the runtime's wake-up (5-10 us) -- and falls back to the synchronisation after 500 us (a failed kernel never stores).
+  // The flag says "the results are there", NOT "the kernel is finished": only results may be read behind it; everything else stays ordered by the stream.
+  static constexpr int kFlag = 15;
+  int next_seq() const { return ++*seq; }
+  int wait_flag(int expect, hipStream_t s) const {
+    const volatile int* f = host + kFlag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0; *f != expect; spins++) {
+      if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+        break;
+      }
+    }
+    return GP_OK;
+  }
   static int get(HostWords* out) {
     static thread_local HostWords w[16];
     int d = 0;
@@ -279,6 +300,9 @@ struct HostWords {
       if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer", __FILE__, __LINE__);
       w[d].host = static_cast<int*>(p);
       w[d].dev = static_cast<int*>(dp);
+      static thread_local int seqs[16];
+      w[d].seq = &seqs[d];
+      for (int i = 0; i < kWords; i++) w[d].host[i] = 0;
     }
     *out = w[d];
     return GP_OK;
@@ -311,8 +335,12 @@ struct gp_voxelmap {
   gp::DeviceArray voxel_covs;   // float[num_voxels][9]
   gp::DeviceArray voxel_intensities;  // float[num_voxels]
   gp::DeviceArray voxel_coords; // int[num_voxels][3] voxel coordinate of each voxel index
-  gp::DeviceArray plines;  // line table of the VGICP pipeline kernel (gp::VoxelMapView::plines)
+  gp::DeviceArray plines;  // line table of the hashed VGICP kernel family (gp::VoxelMapView::plines): built on first use when the map has its block grid (round 4: its
+                           // 16 MB fill and its kernel were 12 us of every map build, for a table no kernel of the default path reads)
   uint32_t plmask = 0;
+  bool private_built = false;
+  std::mutex private_mutex;    // (batches of several threads may ask at once)
+  int ensure_private_table();  // (gp_voxelmap.hip) builds plines on the map's stream and synchronises it; no-op when built
   gp::DeviceArray gblocks;  // occupancy-block grid (gp::GridBlock[gdim0 * gdim1 * gdim2]); empty when the box is too large
   int glo[3] = {0, 0, 0}, gdim[3] = {0, 0, 0};
   bool has_grid = false;

@@ -1029,27 +1029,24 @@ __device__ __forceinline__ void covariance_from_neighbours(const TopK<KMAX, FULL
 // at 420 us, the last at 710).  The launch therefore takes its queries through an order array: the positions of the queries with own-cell population < k first
 // (ascending, so that neighbours in the list are still neighbours in space), all others behind them -- longest-processing-time-first with a per-query predictor,
 // and waves whose lanes have alike work.  Same queries, same per-query search: identical results.
-struct HeavyQueryFlag {
-  BinGridView g;  // (the cell ordinals of the sorted positions are not kept with the structure: the query's cell is looked up like the search does)
+// (the predictor depends on the query's CELL only, so the prefix sums run over the cells -- a few 10^5 entries -- not over the points: per cell the number of its
+// points when that is below k, else 0; the points of a heavy cell c go to heavy_before[c] + their rank inside the cell, the others behind all heavy ones in order)
+struct HeavyCellCount {
+  const int* cell_start;
   int k;
-  __device__ __forceinline__ int operator()(long long t) const {
-    const float4 q = g.sorted[t];
-    const int cx = fast_floor((double)q.x * g.inv_h), cy = fast_floor((double)q.y * g.inv_h), cz = fast_floor((double)q.z * g.inv_h);
-    const size_t bi = ((size_t)((cz >> 2) - g.geom.lo[2]) * (size_t)g.geom.dim[1] + (size_t)((cy >> 2) - g.geom.lo[1])) * (size_t)g.geom.dim[0] + (size_t)((cx >> 2) - g.geom.lo[0]);
-    const int4 raw = *reinterpret_cast<const int4*>(g.blocks + bi);
-    const unsigned long long bits = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned long long)(unsigned)raw.x;
-    const int bit = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
-    const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
-    return (g.cell_start[ord + 1] - g.cell_start[ord] < k) ? 1 : 0;
+  __device__ __forceinline__ int operator()(long long c) const {
+    const int size = cell_start[c + 1] - cell_start[c];
+    return size < k ? size : 0;
   }
 };
-__global__ void __launch_bounds__(256) heavy_first_order_kernel(HeavyQueryFlag flag, const int* __restrict__ heavy_before, const int* __restrict__ num_heavy, int nq,
-                                                                int* __restrict__ order) {
+__global__ void __launch_bounds__(256) heavy_first_order_kernel(const int* __restrict__ cell_start, const unsigned* __restrict__ cell_of, const int* __restrict__ heavy_before,
+                                                                const int* __restrict__ num_heavy, int k, int nq, int* __restrict__ order) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nq) return;
   if (t == 0) order[nq] = nq;  // (the list's length, where covariance_kernel's todo protocol reads it)
-  const int hb = heavy_before[t];
-  order[flag(t) ? hb : *num_heavy + (t - hb)] = t;
+  const int c = (int)cell_of[t];
+  const int b = cell_start[c], size = cell_start[c + 1] - b, hb = heavy_before[c];
+  order[size < k ? hb + (t - b) : *num_heavy + (t - hb)] = t;
 }
 
 // estimate_covariances, per-lane search (every query walks its own shells; see knn_query_bins / knn_query): the general path, and
@@ -1664,7 +1661,14 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 
 // structure: GP_TUNE_KNN_STRUCTURE value (0 binned + per-lane search, 1 hashed multi-level grid, 3 row-tiled covariance pass first, 4 two binned
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
+static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
+                                  gp_point_grid_t** out);
 int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
+  return point_grid_create_impl(points_dev, n, cell_size, structure, counters_dev, stream, false, out);
+}
+// keep_cell_of: the cell ordinals of the sorted positions stay with the first level (gp_estimate_covariances orders its queries by them)
+static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
+                                  gp_point_grid_t** out) {
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
   if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure != 6 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4, 6} (>= 16: staging experiment)");
   auto* g = new gp_point_grid;
@@ -1704,12 +1708,16 @@ int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, in
       if (lv->bins.num_occ_blocks > 0)
         hipLaunchKernelGGL(gp::super_mark_kernel, dim3((lv->bins.num_occ_blocks + 255) / 256), dim3(256), 0, g->stream, (const int*)lv->bins.occ_blocks.as<int>(),
                            lv->bins.num_occ_blocks, lv->bins.geom, lv->sdim[0], lv->sdim[1], lv->super.as<unsigned long long>());
-      const hipError_t e = hipStreamSynchronize(g->stream);
-      if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
+      {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
+      }
+      // (no synchronisation here: the arrays below go back to the pool in stream order, and whoever searches the structure does so on this stream or
+      // synchronises -- gp_point_grid_create's contract is "built on `stream`")
       lv->h = h;
-      lv->bins.order.release();  // only the sorted copy is searched
-      lv->bins.cell_of.release();
-      lv->bins.cell_block.release();
+      lv->bins.order.release_on(g->stream);  // only the sorted copy is searched
+      if (!(keep_cell_of && l == 0)) lv->bins.cell_of.release_on(g->stream);
+      lv->bins.cell_block.release_on(g->stream);
       g->bin_levels.push_back(std::move(lv));
     }
     if (rc != GP_OK) {
@@ -1811,7 +1819,7 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
   const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  GP_TRY(gp_point_grid_create_ex(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, &g));
+  GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, &g));
   const double t1 = now();
   gp::DeviceArray d_short;
   int rc = d_short.alloc_async(sizeof(int), s);
@@ -1845,18 +1853,20 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
       }
     }
     gp::DeviceArray heavy_before, order_state;
-    if (nq > 0 && rc == GP_OK && g->binned && !d_todo && g->structure != 6) {
-      // heavy queries first (HeavyQueryFlag above): order[] = positions with own-cell population < k, then the rest; one scan + one scatter (~15 us per 1 M points)
-      const gp::HeavyQueryFlag flag{v.bins[0], k};
+    if (nq > 0 && rc == GP_OK && g->binned && !d_todo && g->structure != 6 && g->bin_levels[0]->bins.cell_of.ptr) {
+      // heavy queries first (HeavyCellCount above): order[] = positions with own-cell population < k, then the rest; one scan over the cells + one scatter
+      const gp::PointBins& bins = g->bin_levels[0]->bins;
+      const int nc = bins.num_cells;
       rc = todo.alloc_async(sizeof(int) * ((size_t)nq + 2), s);
-      if (rc == GP_OK) rc = heavy_before.alloc_async(sizeof(int) * (size_t)nq, s);
-      if (rc == GP_OK) rc = order_state.alloc_async(sizeof(unsigned long long) * gp::onepass_state_words(nq), s);
+      if (rc == GP_OK) rc = heavy_before.alloc_async(sizeof(int) * (size_t)nc, s);
+      if (rc == GP_OK) rc = order_state.alloc_async(sizeof(unsigned long long) * gp::onepass_state_words(nc), s);
       if (rc == GP_OK) {
-        (void)hipMemsetAsync(order_state.ptr, 0, sizeof(unsigned long long) * gp::onepass_state_words(nq), s);
+        (void)hipMemsetAsync(order_state.ptr, 0, sizeof(unsigned long long) * gp::onepass_state_words(nc), s);
         int* d_heavy = todo.as<int>() + nq + 1;
-        rc = gp::exclusive_scan_of(flag, heavy_before.as<int>(), nq, d_heavy, s, order_state.as<unsigned long long>());
+        rc = gp::exclusive_scan_of(gp::HeavyCellCount{bins.cell_start.as<int>(), k}, heavy_before.as<int>(), nc, d_heavy, s, order_state.as<unsigned long long>());
         if (rc == GP_OK) {
-          hipLaunchKernelGGL(gp::heavy_first_order_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, flag, (const int*)heavy_before.as<int>(), (const int*)d_heavy, nq, todo.as<int>());
+          hipLaunchKernelGGL(gp::heavy_first_order_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const int*)bins.cell_start.as<int>(), (const unsigned*)bins.cell_of.as<unsigned>(),
+                             (const int*)heavy_before.as<int>(), (const int*)d_heavy, k, nq, todo.as<int>());
           d_todo = todo.as<int>();
         }
       }

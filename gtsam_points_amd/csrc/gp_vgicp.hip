@@ -496,6 +496,7 @@ struct gp_vgicp_batch {
   gp::DeviceArray d_arrive;               // 16 monotonic arrival counters, kArriveStride words apart
   gp::DeviceArray d_factor_arrive;        // fused finalize by factor: one counter per factor, kFactorArriveStride words apart, zero between launches
   size_t factor_arrive_count = 0;
+  bool factor_arrive_dirty = false;       // a by-factor fused launch went out and has not been seen to complete: the zero-reset counters may be anywhere
   unsigned long long arrived[16] = {0};   // what the counters read once every launch issued so far has finished
   bool timing = false;                  // GP_TUNE_TIMING: the synchronous linearise brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -658,6 +659,16 @@ int build_table(gp_vgicp_batch* b) {
   b->use_grid = true;
   bool offsets32 = true;
   b->any_sv = false;
+  {
+    // the hashed family reads the maps' private line tables, which a map with a block grid builds only now (gp_voxelmap::ensure_private_table)
+    bool all_grid = true;
+    for (int i = 0; i < F; i++) {
+      if (!b->factors[i]->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
+      if (!b->factors[i]->target->has_grid) all_grid = false;
+    }
+    if (!all_grid || b->tuning.kernel == GP_KERNEL_HASHED)
+      for (int i = 0; i < F; i++) GP_TRY(const_cast<gp_voxelmap*>(b->factors[i]->target)->ensure_private_table());  // (a cache of the map, not its state)
+  }
   for (int i = 0; i < F; i++) {
     const gp_vgicp_factor* f = b->factors[i];
     if (!f->target->loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "VGICP factor: target voxel map is not loaded on the GPU");
@@ -1495,6 +1506,17 @@ static int reset_arrival(gp_vgicp_batch_t* b) {
   return GP_OK;
 }
 
+// The by-factor fused finalize counts arrivals in zero-reset counters (the last arriver of a factor stores 0): a launch that went out and was never seen to complete
+// (an error return between launch and the last completion word, a torn-down kernel) may have left small positive values behind, which would let the NEXT launch's
+// factors finalize early on stale rows without anybody noticing.  Such a batch cleans its counters, behind the stream, before it counts again.
+static int clean_factor_arrivals(gp_vgicp_batch_t* b) {
+  if (!b->factor_arrive_dirty || !b->d_factor_arrive.ptr) return GP_OK;
+  GP_HIP(hipStreamSynchronize(b->stream));
+  GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, sizeof(unsigned long long) * gp::kFactorArriveStride * b->factor_arrive_count));
+  b->factor_arrive_dirty = false;
+  return GP_OK;
+}
+
 // synchronous: the finalize kernel stores the records straight into host-mapped pinned memory (no D2H copy op).
 // out_host != nullptr: the records are copied there; view != nullptr: *view points at them where they lie (the batch's own pinned
 // buffer, or `view_store` for the single large factor whose parts the host combines) until the next call on the batch.
@@ -1557,6 +1579,7 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
     }
     double* partials = nullptr;
     GP_TRY(partials_ptr(b, &partials));
+    GP_TRY(clean_factor_arrivals(b));
     ps.inl.arrive = b->d_factor_arrive.as<unsigned long long>();
     ps.inl.rows_per_part = 0;
     ps.inl.num_rows = b->num_tiles;
@@ -1564,6 +1587,7 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
     ps.inl.fin_stride = (int)(sizeof(gp_linearized6) / sizeof(double));
     ps.inl.fin_flags = done.flags;
     ps.inl.fin_seq = done.seq;
+    b->factor_arrive_dirty = true;  // (cleared below once every completion word of THIS launch has been seen: an error return in between leaves it set)
     GP_TRY(launch_tiles<gp::MODE_LIN>(b, ps, partials));
     for (size_t i = 0; i < F; i++)
       if (b->h_descs[i].tile_count == 0) {  // a factor without points has no workgroup to finalize it: its (empty) record is written here
@@ -1581,6 +1605,7 @@ static int batch_linearize_sync(gp_vgicp_batch_t* b, const double* poses_host, g
       GP_TRY(launch_finalize<false>(b, ps, partials, reinterpret_cast<gp_linearized6*>(b->h_out_dev), again, 1));
       GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, again.seq, b->stream, spin_budget_us(b)));
     }
+    b->factor_arrive_dirty = false;  // every factor's last arriver reset its counter (or the fallback cleaned them)
   } else {
     GP_TRY(launch_linearize(b, ps, reinterpret_cast<gp_linearized6*>(b->h_out_dev), rigid, done, sums_only ? -parts : parts, b->timing));
     GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F * (size_t)parts, done.seq, b->stream, spin_budget_us(b)));
@@ -1703,6 +1728,7 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
     }
     double* partials = nullptr;
     GP_TRY(partials_ptr(b, &partials));
+    GP_TRY(clean_factor_arrivals(b));
     ps.inl.arrive = b->d_factor_arrive.as<unsigned long long>();
     ps.inl.rows_per_part = 0;
     ps.inl.num_rows = b->num_tiles;
@@ -1710,6 +1736,7 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
     ps.inl.fin_stride = 1;  // one double per factor
     ps.inl.fin_flags = done.flags;
     ps.inl.fin_seq = done.seq;
+    b->factor_arrive_dirty = true;
     GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
     for (size_t i = 0; i < F; i++)
       if (b->h_descs[i].tile_count == 0) {  // no points, no workgroup: the empty sum is written here
@@ -1725,6 +1752,7 @@ int gp_vgicp_batch_compute_error(gp_vgicp_batch_t* b, const double* poses_lin_ho
       GP_HIP(hipGetLastError());
       GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, again.seq, b->stream, spin_budget_us(b)));
     }
+    b->factor_arrive_dirty = false;
     memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
     return GP_OK;
   }

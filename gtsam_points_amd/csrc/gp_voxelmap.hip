@@ -208,53 +208,89 @@ __global__ void __launch_bounds__(256) buckets_renumber_kernel(uint32_t num_buck
 }
 
 // ---- binned build (gp_binning.hpp): per-voxel statistics as an ORDERED segmented sum ----------------------------------------
-// Sixteen lanes per voxel (round 4; rounds 2-3: one wave per voxel -- the median voxel of a scan holds three points, the mean 10-30, so three quarters of a wave's
-// lanes idled through nine six-step butterflies: 114 us per 2 M points, the largest kernel of the map build).  The voxel's points come in ascending index order
-// (stable sort); every chunk of 16 is reduced with a fixed butterfly and the chunk sums are added in order: the statistics are bit-identical from run to run (no atomics).
+// Sixteen lanes per voxel, sixteen voxels per workgroup (rounds 2-3: one wave per voxel -- the median voxel of a scan holds three points, the mean 10-30, so three
+// quarters of a wave's lanes idled through nine six-step butterflies: 114 us per 2 M points, the largest kernel of the map build).  The rows of a voxel's points are
+// a random gather through the sort order (12 + 36 B from wherever the point lies in the caller's arrays); when the lanes of a voxel fetched their own rows, the wave
+// waited for its longest voxel with most lanes idle (68 us per 2 M points at 2.3 TB/s of fabric traffic: latency-bound).  Now the WHOLE workgroup gathers the rows of
+// its sixteen voxels -- one contiguous range of the sort order, every lane busy, two rows per lane in flight -- into LDS, 512 rows at a time, and the voxels' lanes
+// sum from LDS.  Lane l of a voxel adds the voxel's points l, l + 16, ... in ascending order (stable sort: ascending point index), one fixed butterfly joins the
+// sixteen lanes at the end: the statistics are bit-identical from run to run (no atomics) and do not depend on where the 512-row batches fall.
 // sums relative to the voxel centre in f64, like accumulate_kernel; outputs as finalize_kernel.
+constexpr int kStatsBatch = 512;
 __global__ void __launch_bounds__(256) segmented_stats_kernel(const float* __restrict__ points, const float* __restrict__ covs, const float* __restrict__ intensities,
                                                               int num_voxels, const int* __restrict__ cell_start, const int* __restrict__ order, double inv_leaf, double leaf,
                                                               VoxelRecord* __restrict__ records, int* __restrict__ num_points, float* __restrict__ voxel_means,
                                                               float* __restrict__ voxel_covs, float* __restrict__ voxel_intensities, int* __restrict__ voxel_coords) {
   constexpr int kGroup = 16;
+  __shared__ float rows[kStatsBatch][12];  // x y z, then the covariance's nine entries
+  __shared__ float inten[kStatsBatch];
   const int lane = threadIdx.x & (kGroup - 1);
-  const int v = blockIdx.x * (256 / kGroup) + (threadIdx.x / kGroup);
-  if (v >= num_voxels) return;
-  const int b = cell_start[v], e = cell_start[v + 1];
-  const size_t i0 = (size_t)order[b];
-  const int cx = fast_floor((double)points[3 * i0] * inv_leaf), cy = fast_floor((double)points[3 * i0 + 1] * inv_leaf), cz = fast_floor((double)points[3 * i0 + 2] * inv_leaf);
-  const double ox = ((double)cx + 0.5) * leaf, oy = ((double)cy + 0.5) * leaf, oz = ((double)cz + 0.5) * leaf;
+  const int v0 = blockIdx.x * (256 / kGroup);
+  const int v1 = min(v0 + 256 / kGroup, num_voxels);
+  const int v = v0 + (threadIdx.x / kGroup);
+  const bool live = v < num_voxels;
+  const int p0 = cell_start[v0], p1 = cell_start[v1];
+  const int b = live ? cell_start[v] : p1, e = live ? cell_start[v + 1] : p1;
+  int cx = 0, cy = 0, cz = 0;
+  double ox = 0.0, oy = 0.0, oz = 0.0;  // the voxel's centre, from its first point -- taken from the batch that holds it (two dependent loads less in front of the gather)
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   float imax = 0.0f;  // max intensity (:138-139): intensities are non-negative upstream (atomicMax on the float bits), 0 when absent
-  for (int chunk = b; chunk < e; chunk += kGroup) {
-    const int j = chunk + lane;
-    double val[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float it = 0.0f;
-    if (j < e) {
-      const size_t i = (size_t)order[j];
-      const float* c = covs + 9 * i;
-      val[0] = (double)points[3 * i] - ox;
-      val[1] = (double)points[3 * i + 1] - oy;
-      val[2] = (double)points[3 * i + 2] - oz;
-      val[3] = (double)c[0];
-      val[4] = 0.5 * ((double)c[3] + (double)c[1]);  // symmetric part of the column-major 3x3 (the input itself when symmetric)
-      val[5] = 0.5 * ((double)c[6] + (double)c[2]);
-      val[6] = (double)c[4];
-      val[7] = 0.5 * ((double)c[7] + (double)c[5]);
-      val[8] = (double)c[8];
-      if (intensities) it = intensities[i];
+  for (int batch = p0; batch < p1; batch += kStatsBatch) {
+    const int cnt = min(kStatsBatch, p1 - batch);
+    float row[kStatsBatch / 256][12];
+    float rit[kStatsBatch / 256];
+#pragma unroll
+    for (int q = 0; q < kStatsBatch / 256; q++) {
+      const int r = q * 256 + (int)threadIdx.x;
+      rit[q] = 0.0f;
+      if (r < cnt) {
+        const size_t i = (size_t)order[batch + r];
+#pragma unroll
+        for (int k = 0; k < 3; k++) row[q][k] = points[3 * i + k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) row[q][3 + k] = covs[9 * i + k];
+        if (intensities) rit[q] = intensities[i];
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-      double x = val[k];
+    for (int q = 0; q < kStatsBatch / 256; q++) {
+      const int r = q * 256 + (int)threadIdx.x;
+      if (r < cnt) {
 #pragma unroll
-      for (int off = kGroup / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kGroup);
-      acc[k] += x;
+        for (int k = 0; k < 12; k++) rows[r][k] = row[q][k];
+        inten[r] = rit[q];
+      }
     }
-#pragma unroll
-    for (int off = kGroup / 2; off > 0; off >>= 1) it = fmaxf(it, __shfl_xor(it, off, kGroup));
-    imax = fmaxf(imax, it);
+    __syncthreads();
+    const int lo = max(b, batch), hi = min(e, batch + cnt);
+    if (live && b >= batch && b < batch + cnt) {
+      const float* f = rows[b - batch];
+      cx = fast_floor((double)f[0] * inv_leaf), cy = fast_floor((double)f[1] * inv_leaf), cz = fast_floor((double)f[2] * inv_leaf);
+      ox = ((double)cx + 0.5) * leaf, oy = ((double)cy + 0.5) * leaf, oz = ((double)cz + 0.5) * leaf;
+    }
+    for (int j = lo + ((lane - (lo - b)) & (kGroup - 1)); j < hi; j += kGroup) {
+      const float* c = rows[j - batch];
+      acc[0] += (double)c[0] - ox;
+      acc[1] += (double)c[1] - oy;
+      acc[2] += (double)c[2] - oz;
+      acc[3] += (double)c[3];
+      acc[4] += 0.5 * ((double)c[6] + (double)c[4]);  // symmetric part of the column-major 3x3 (the input itself when symmetric)
+      acc[5] += 0.5 * ((double)c[9] + (double)c[5]);
+      acc[6] += (double)c[7];
+      acc[7] += 0.5 * ((double)c[10] + (double)c[8]);
+      acc[8] += (double)c[11];
+      imax = fmaxf(imax, inten[j - batch]);
+    }
+    __syncthreads();
   }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int off = kGroup / 2; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, kGroup);
+  }
+#pragma unroll
+  for (int off = kGroup / 2; off > 0; off >>= 1) imax = fmaxf(imax, __shfl_xor(imax, off, kGroup));
+  if (!live) return;
   if (lane != 0) return;
   const int n = e - b;
   const double inv_n = 1.0 / (double)n;
@@ -389,6 +425,16 @@ static int build_private_table(gp_voxelmap* m, hipStream_t s) {
     hipLaunchKernelGGL(gp::line_claim_kernel, dim3((V + 255) / 256), dim3(256), 0, s, V, m->voxel_coords.as<int>(), m->plines.as<gp_voxel_bucket>(), m->plmask);
     GP_HIP(hipGetLastError());
   }
+  m->private_built = true;
+  return GP_OK;
+}
+
+int gp_voxelmap::ensure_private_table() {
+  std::lock_guard<std::mutex> lock(private_mutex);
+  if (private_built) return GP_OK;
+  if (!loaded()) return gp::fail(GP_ERROR_NOT_LOADED, "voxel map is not loaded on the GPU");
+  GP_TRY(build_private_table(this, stream));
+  GP_HIP(hipStreamSynchronize(stream));
   return GP_OK;
 }
 
@@ -543,13 +589,16 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   // reference-visible bucket table (create_bucket_table, :253-307): the reference doubles the table until the fraction of points
   // whose probe chain is exhausted is <= target_points_drop_rate and then drops those points; here the table is doubled along the
   // same sequence until every voxel is placed, so no point is ever dropped (the CPU map, the parity target, drops none either)
-  // (round 4: the "a voxel found no bucket" flag is a host-mapped word the kernel stores to -- no fill, no copy kernel -- and the private line table is issued behind
-  // the insertion before the one synchronisation that ends the build; a table that turns out too small is the rare path and starts over)
+  // (round 4: the "a voxel found no bucket" flag is a host-mapped word the kernel stores to -- no fill, no copy kernel; a table that turns out too small is the rare
+  // path and starts over)
   gp::HostWords hw;
   GP_TRY(gp::HostWords::get(&hw));
   int64_t num_buckets = m->init_num_buckets;
-  while (num_buckets < (int64_t)V + V / 2) num_buckets *= 2;  // the sequence is entered where the voxels fit at a load factor <= 2/3
-  bool private_built = false;
+  // the sequence is entered where the voxels fit at a load factor <= 1/3: at 1/2 .. 2/3 some probe chain among 10^5 voxels exceeds max_bucket_scan_count almost surely,
+  // and the failed attempt (fill + insertion + a synchronisation) was 45 us of the 2 M-point build (profiles/r04_build_timeline.txt)
+  while (num_buckets < 3 * (int64_t)V) num_buckets *= 2;
+  m->private_built = false;  // (the hashed kernel family's line table is built when a batch first asks for it: gp_voxelmap::ensure_private_table)
+  m->plines.release();
   for (;; num_buckets *= 2) {
     if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
     GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
@@ -560,10 +609,6 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
                        m->buckets.as<gp_voxel_bucket>(), (uint32_t)num_buckets, mask, m->info.max_bucket_scan_count, hw.dev + 12);
     GP_HIP(hipGetLastError());
     m->info.num_buckets = (int)num_buckets;
-    if (!private_built) {  // (does not depend on the bucket table: issued once, behind the first attempt, in front of the synchronisation)
-      GP_TRY(build_private_table(m, s));
-      private_built = true;
-    }
     GP_HIP(hipStreamSynchronize(s));  // :250
     if (reinterpret_cast<volatile int*>(hw.host)[12] == 0) break;
   }
@@ -823,8 +868,11 @@ int gp_voxelmap_assign(gp_voxelmap_t* map, int num_voxels, const int* coords, co
     m->has_grid = true;
   }
   GP_HIP(hipStreamSynchronize(s));  // the staging vectors die with this scope
-  GP_TRY(build_private_table(m, s));
-  GP_HIP(hipStreamSynchronize(s));
+  m->private_built = false;
+  if (!m->has_grid) {
+    GP_TRY(build_private_table(m, s));
+    GP_HIP(hipStreamSynchronize(s));
+  }
   return GP_OK;
 }
 
@@ -951,7 +999,8 @@ int gp_voxelmap_clone_to_device(const gp_voxelmap_t* map, int device, gp_stream_
   copy(m->voxel_covs, map->voxel_covs, sizeof(float) * 9 * V);
   copy(m->voxel_intensities, map->voxel_intensities, sizeof(float) * V);
   copy(m->voxel_coords, map->voxel_coords, sizeof(int) * 3 * V);
-  copy(m->plines, map->plines, 64 * ((size_t)map->plmask + 1));
+  if (map->private_built) copy(m->plines, map->plines, 64 * ((size_t)map->plmask + 1));
+  m->private_built = map->private_built;
   if (map->has_grid) copy(m->gblocks, map->gblocks, sizeof(gp::GridBlock) * (size_t)map->gdim[0] * map->gdim[1] * map->gdim[2]);
   if (rc == GP_OK) {
     const hipError_t e = hipStreamSynchronize(s);
@@ -971,7 +1020,7 @@ size_t gp_voxelmap_memory_usage_gpu(const gp_voxelmap_t* map) {
   if (!map) return 0;
   // reference formula (gaussian_voxelmap_gpu.cu:469-472) + the gather records, coordinates and line table this implementation adds
   return (size_t)map->info.num_voxels * (sizeof(int) + sizeof(float) * 3 + sizeof(float) * 9 + sizeof(gp::VoxelRecord) + sizeof(int) * 3) +
-         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + ((size_t)map->plmask + 1) * 4 * sizeof(gp_voxel_bucket) +
+         (size_t)map->info.num_buckets * sizeof(gp_voxel_bucket) + (map->private_built ? ((size_t)map->plmask + 1) * 4 * sizeof(gp_voxel_bucket) : 0) +
          (map->has_grid ? (size_t)map->gdim[0] * map->gdim[1] * map->gdim[2] * sizeof(gp::GridBlock) : 0);
 }
 
@@ -1024,6 +1073,7 @@ int gp_voxelmap_offload(gp_voxelmap_t* map, gp_stream_t stream) {
   m->voxel_intensities.release();
   m->voxel_coords.release();
   m->plines.release();
+  m->private_built = false;
   m->gblocks.release();
   m->offloaded = true;
   m->generation++;
@@ -1043,7 +1093,8 @@ int gp_voxelmap_reload(gp_voxelmap_t* map, gp_stream_t stream) {
   GP_TRY(to_device(m->voxel_intensities, m->h_intensities, s));
   GP_TRY(to_device(m->voxel_coords, m->h_coords, s));
   if (m->has_grid) GP_TRY(to_device(m->gblocks, m->h_gblocks, s));
-  GP_TRY(build_private_table(m, s));
+  m->private_built = false;
+  if (!m->has_grid) GP_TRY(build_private_table(m, s));
   GP_HIP(hipStreamSynchronize(s));
   m->offloaded = false;
   m->generation++;
