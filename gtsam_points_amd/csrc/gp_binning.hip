@@ -11,7 +11,7 @@ namespace gp {
 
 namespace {
 
-constexpr unsigned kInvalidKey = 0x7fffffffu;
+constexpr unsigned kNoCell = 0x7fffffffu;  // cell_of[] of a skipped (non-finite) point
 
 __device__ __forceinline__ bool point_cell(const float* __restrict__ points, size_t i, double inv_cell, int& cx, int& cy, int& cz) {
   const float x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __rest
 // every pass of the sort behind it (gp_sort.hpp: the sort needs no pass over the keys for that).
 constexpr int kKeyTile = 4096;
 __global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys, int passes,
-                                                       unsigned* __restrict__ hist) {
+                                                       unsigned* __restrict__ hist, unsigned invalid_key) {
   __shared__ SortHistLds l;
   sort_hist_clear(l);
   __syncthreads();
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__
       const double ux = (double)p[r][0] * inv_cell, uy = (double)p[r][1] * inv_cell, uz = (double)p[r][2] * inv_cell;
       const bool ok = fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9;  // (point_cell's rule)
       const int cx = fast_floor(ux), cy = fast_floor(uy), cz = fast_floor(uz);
-      const unsigned key = ok ? (unsigned)(grid_block_index(g, cx, cy, cz) * 64 + grid_bit(cx, cy, cz)) : kInvalidKey;
+      const unsigned key = ok ? (unsigned)(grid_block_index(g, cx, cy, cz) * 64 + grid_bit(cx, cy, cz)) : invalid_key;
       if (i < (size_t)n) {
         keys[i] = key;
         sort_hist_count(l, key, passes);
@@ -157,7 +157,7 @@ struct CellKeys {
   unsigned prev0, cflag, bflag;
   bool full, any, has_prev;
 };
-__device__ __forceinline__ void load_cell_keys(const unsigned* __restrict__ sorted_keys, int n, long long base, CellKeys& c) {
+__device__ __forceinline__ void load_cell_keys(const unsigned* __restrict__ sorted_keys, int n, long long base, unsigned invalid_key, CellKeys& c) {
   c.full = base + kCellsPerThread <= (long long)n;
   if (c.full && (reinterpret_cast<uintptr_t>(sorted_keys) & 15) == 0) {
     const uint4* p = reinterpret_cast<const uint4*>(sorted_keys + base);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void load_cell_keys(const unsigned* __restrict__ sort
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < kCellsPerThread; k++) c.key[k] = base + k < (long long)n ? sorted_keys[base + k] : kInvalidKey;
+    for (int k = 0; k < kCellsPerThread; k++) c.key[k] = base + k < (long long)n ? sorted_keys[base + k] : invalid_key;
   }
   c.any = base < (long long)n;
   c.has_prev = c.any && base > 0;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void load_cell_keys(const unsigned* __restrict__ sort
   bool have = c.has_prev;
 #pragma unroll
   for (int k = 0; k < kCellsPerThread; k++) {
-    const bool in = base + k < (long long)n && c.key[k] != kInvalidKey;
+    const bool in = base + k < (long long)n && c.key[k] != invalid_key;
     if (in && (!have || prev != c.key[k])) c.cflag |= 1u << k;
     if (in && (!have || (prev >> 6) != (c.key[k] >> 6))) c.bflag |= 1u << k;
     prev = c.key[k];
@@ -186,11 +186,11 @@ __device__ __forceinline__ void load_cell_keys(const unsigned* __restrict__ sort
   }
 }
 
-__global__ void __launch_bounds__(256) bins_count_kernel(const unsigned* __restrict__ sorted_keys, int n, unsigned long long* __restrict__ state, int num_groups) {
+__global__ void __launch_bounds__(256) bins_count_kernel(const unsigned* __restrict__ sorted_keys, int n, unsigned invalid_key, unsigned long long* __restrict__ state, int num_groups) {
   __shared__ unsigned long long wave_sum[4];
   const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   CellKeys c;
-  load_cell_keys(sorted_keys, n, (long long)tile * kCellsTile + (long long)threadIdx.x * kCellsPerThread, c);
+  load_cell_keys(sorted_keys, n, (long long)tile * kCellsTile + (long long)threadIdx.x * kCellsPerThread, invalid_key, c);
   unsigned long long sum = (unsigned long long)__popc(c.cflag) | ((unsigned long long)__popc(c.bflag) << 31);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) bins_count_kernel(const unsigned* __restr
   }
 }
 
-__global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restrict__ sorted_keys, int n, const unsigned long long* __restrict__ state, int num_groups,
+__global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restrict__ sorted_keys, int n, unsigned invalid_key, const unsigned long long* __restrict__ state, int num_groups,
                                                          GridBlock* __restrict__ blocks, int* __restrict__ cell_start, unsigned* __restrict__ cell_of, int* __restrict__ cell_block,
                                                          int* __restrict__ occ_blocks, int* __restrict__ host_counts /* host-mapped */, int seq) {
   __shared__ unsigned long long wave_sum[4];
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
     }
   }
   CellKeys ck;
-  load_cell_keys(sorted_keys, n, base, ck);
+  load_cell_keys(sorted_keys, n, base, invalid_key, ck);
   unsigned (&key)[kCellsPerThread] = ck.key;
   const unsigned cflag = ck.cflag, bflag = ck.bflag, prev0 = ck.prev0;
   const bool full = ck.full, any = ck.any, has_prev = ck.has_prev;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
   // the ordinal of every element's cell: cells that start at or before it, minus one (straight-line: no branch per element)
   unsigned ord_out[kCellsPerThread];
 #pragma unroll
-  for (int k = 0; k < kCellsPerThread; k++) ord_out[k] = key[k] == kInvalidKey ? kInvalidKey : (unsigned)(cells0 + __popc(cflag & ((2u << k) - 1u)) - 1);
+  for (int k = 0; k < kCellsPerThread; k++) ord_out[k] = key[k] == invalid_key ? kNoCell : (unsigned)(cells0 + __popc(cflag & ((2u << k) - 1u)) - 1);
   if (full && (reinterpret_cast<uintptr_t>(cell_of) & 15) == 0) {
     uint4* p = reinterpret_cast<uint4*>(cell_of + base);
 #pragma unroll
@@ -286,13 +286,13 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
   const int cells_end = cells0 + __popc(cflag), blocks_end = blocks0 + __popc(bflag);
   int end_at = -1;
   {
-    bool prev_binned = has_prev ? prev0 != kInvalidKey : true;  // (element 0 of a cloud without a single binned point closes it at 0)
+    bool prev_binned = has_prev ? prev0 != invalid_key : true;  // (element 0 of a cloud without a single binned point closes it at 0)
 #pragma unroll
     for (int k = 0; k < kCellsPerThread; k++) {
       const bool in_range = base + k < (long long)n;
-      if (in_range && key[k] == kInvalidKey && prev_binned && end_at < 0) end_at = (int)(base + k);
-      if (in_range && base + k == (long long)n - 1 && key[k] != kInvalidKey) end_at = n;
-      prev_binned = key[k] != kInvalidKey;
+      if (in_range && key[k] == invalid_key && prev_binned && end_at < 0) end_at = (int)(base + k);
+      if (in_range && base + k == (long long)n - 1 && key[k] != invalid_key) end_at = n;
+      prev_binned = key[k] != invalid_key;
     }
   }
   if (end_at >= 0) {
@@ -324,7 +324,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   HostWords hw;  // host-mapped: [0..5] bounding box, [8] binned points, [9] cells, [10] occupied blocks -- written by the kernels, read behind the synchronisations
   GP_TRY(HostWords::get(&hw));
   const size_t sort_words = radix_sort_state_words32(n, 32) /* 32-bit */, cells_words = cells_state_words(n) /* 64-bit */;
-  const size_t sort_off = 0, cells_off = (sort_off + sort_words * 4 + 7) & ~size_t(7), state_bytes = cells_off + cells_words * 8;
+  const size_t sort_off = 0, cells_off = (sort_off + sort_words * 4 + 7) & ~size_t(7), state_bytes = (cells_off + cells_words * 8 + 255) & ~size_t(255);  // (a fill whose size is not a multiple of 16 B is two kernels)
   GP_TRY(states.alloc_async(state_bytes, s));
   GP_HIP(hipMemsetAsync(states.ptr, 0, state_bytes, s));
   char* st = states.as<char>();
@@ -365,14 +365,15 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(bins->order.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
   GP_TRY(vals_b.alloc_pooled(sizeof(int) * (size_t)n, s));
-  int bits = 6;
-  while ((1ll << bits) < bins->num_blocks * 64) bits++;
-  // skipped points carry kInvalidKey = 0x7fffffff: every pass sees all-ones digits, so they land behind every cell
+  // keys of the binned points are below K = blocks * 64; skipped points carry the all-ones key of the narrowest width that exceeds them -- 2^b - 1 >= K -- so they
+  // land behind every cell, and the sort runs over b bits (a search grid of 1 M points has K ~ 1.2e7: 24 bits, three passes; one bit more for the marker was a fourth)
+  int key_bits = 7;
+  while ((1ll << key_bits) - 1 < bins->num_blocks * 64) key_bits++;
+  const unsigned invalid_key = (unsigned)((1ll << key_bits) - 1);
   bool in_b = false;
-  const int key_bits = std::min(bits + 1, 31);
   unsigned* sort_state = reinterpret_cast<unsigned*>(st + sort_off);
   hipLaunchKernelGGL(bins_key_kernel, dim3((n + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), (key_bits + 7) / 8,
-                     radix_sort_hist(sort_state, n, key_bits));
+                     radix_sort_hist(sort_state, n, key_bits), invalid_key);
   GP_HIP(hipGetLastError());
   GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_state, true, true, s, &in_b));
   if (in_b) {
@@ -387,9 +388,9 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
   const int seq_cells = hw.next_seq();
-  hipLaunchKernelGGL(bins_count_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n,
+  hipLaunchKernelGGL(bins_count_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, invalid_key,
                      reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n));
-  hipLaunchKernelGGL(bins_cells_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n,
+  hipLaunchKernelGGL(bins_cells_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, invalid_key,
                      (const unsigned long long*)reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n), bins->blocks.as<GridBlock>(),
                      bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(), bins->occ_blocks.as<int>(), hw.dev, seq_cells);
   GP_HIP(hipGetLastError());

@@ -43,7 +43,7 @@ int hip_fail(hipError_t err, const char* expr, const char* file, int line);
 // calls were 1-2 ms of a 3 ms covariance estimation.  A released block is parked here, tagged with the stream in whose order it
 // was released (kSyncedRelease: the owner synchronised the work that used it first, so any stream may take it), and handed to the next
 // request of the same device and stream whose size it fits (<= 2x).  A block released in the order of the NULL stream is only handed
-// back to requests on the NULL stream: non-blocking streams are not ordered behind it.  Bounded: kMaxEntries blocks / kMaxBytes; beyond that blocks go back to
+// back to requests on the NULL stream: non-blocking streams are not ordered behind it.  Bounded: kMaxEntries blocks / kMaxBytes; beyond that the oldest blocks go back to
 // the pool.  gp_trim_device_cache() empties it.
 struct BlockCache {
   struct Entry {
@@ -51,7 +51,9 @@ struct BlockCache {
     size_t bytes;
     hipStream_t stream;
     int device;
+    unsigned long long age;  // value of `clock` when the block was parked
   };
+  unsigned long long clock = 0;
   static hipStream_t synced_release() { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(1)); }  // tag, never a real stream
   static constexpr size_t kMaxEntries = 96;
   static constexpr size_t kMaxBytes = size_t(4) << 30;
@@ -76,9 +78,23 @@ struct BlockCache {
     entries.pop_back();
     return p;
   }
+  // A full cache makes room by giving its OLDEST blocks of this device back to the pool (round 4: it used to refuse the new block instead -- after a phase that
+  // parked many blocks of other sizes, every later call paid hipFreeAsync + hipMallocAsync for all of its scratch arrays, up to milliseconds per call:
+  // bench.py's C5 behind C3's 64 map builds).  The one-off cost of the eviction is paid once, by the first calls of the new phase.
   bool put(void* p, size_t bytes, hipStream_t stream, int device) {
-    if (entries.size() >= kMaxEntries || total + bytes > kMaxBytes) return false;
-    entries.push_back({p, bytes, stream, device});
+    if (bytes > kMaxBytes / 2) return false;
+    while (entries.size() >= kMaxEntries || total + bytes > kMaxBytes) {
+      int oldest = -1;
+      for (int i = 0; i < (int)entries.size(); i++)
+        if (entries[i].device == device && (oldest < 0 || entries[i].age < entries[oldest].age)) oldest = i;
+      if (oldest < 0) return false;  // (full of other devices' blocks)
+      const Entry e = entries[oldest];
+      (void)hipFreeAsync(e.ptr, e.stream == synced_release() ? nullptr : e.stream);
+      total -= e.bytes;
+      entries[oldest] = entries.back();
+      entries.pop_back();
+    }
+    entries.push_back({p, bytes, stream, device, ++clock});
     total += bytes;
     return true;
   }

@@ -382,6 +382,7 @@ __device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my
 // max_shells: how many shells beyond the first one that reaches the box this call may walk before it gives up (returns false: the
 // caller retries on a coarser level); returns true when the search is complete (bound met, or every point seen)
 constexpr int kRangeCap = 16;       // candidate ranges a lane collects before it scans them (flat scan of knn_query_bins)
+constexpr int kFlatWidth = 4;       // candidates whose loads a lane has in flight per trip of the flat scan (8: 16 registers spilled, 0.748 vs 0.754 ms per call: no gain)
 constexpr int kRangeStride = 128;   // int2 entries between two slots of one lane's list = threads of the workgroups that use it
 
 template <int KMAX, bool FULL, bool FLAT = false>
@@ -460,25 +461,24 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
     };
     next_range();
     while (p < pe) {
-      int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-      bool k0 = false, k1 = false, k2 = false, k3 = false;
-      auto take = [&](int& a, bool& k) {
-        k = p < pe;
-        if (k) {
-          a = p;
+      int a[kFlatWidth];
+      bool k[kFlatWidth];
+#pragma unroll
+      for (int q = 0; q < kFlatWidth; q++) {
+        a[q] = 0;
+        k[q] = p < pe;
+        if (k[q]) {
+          a[q] = p;
           p++;
           if (p == pe) next_range();
         }
-      };
-      take(a0, k0);
-      take(a1, k1);
-      take(a2, k2);
-      take(a3, k3);
-      const float4 v0 = g.sorted[a0], v1 = g.sorted[a1], v2 = g.sorted[a2], v3 = g.sorted[a3];
-      if (k0) test_point(v0);
-      if (k1) test_point(v1);
-      if (k2) test_point(v2);
-      if (k3) test_point(v3);
+      }
+      float4 v[kFlatWidth];
+#pragma unroll
+      for (int q = 0; q < kFlatWidth; q++) v[q] = g.sorted[a[q]];
+#pragma unroll
+      for (int q = 0; q < kFlatWidth; q++)
+        if (k[q]) test_point(v[q]);
     }
     rl_count = 0;
   };
@@ -1662,13 +1662,15 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 // structure: GP_TUNE_KNN_STRUCTURE value (0 binned + per-lane search, 1 hashed multi-level grid, 3 row-tiled covariance pass first, 4 two binned
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
 static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
-                                  gp_point_grid_t** out);
+                                  bool synchronise, gp_point_grid_t** out);
 int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
-  return point_grid_create_impl(points_dev, n, cell_size, structure, counters_dev, stream, false, out);
+  // (synchronised: gp_knn_search takes a stream of its own, which need not be the one the structure was built on)
+  return point_grid_create_impl(points_dev, n, cell_size, structure, counters_dev, stream, false, true, out);
 }
-// keep_cell_of: the cell ordinals of the sorted positions stay with the first level (gp_estimate_covariances orders its queries by them)
+// keep_cell_of: the cell ordinals of the sorted positions stay with the first level (gp_estimate_covariances orders its queries by them);
+// synchronise = false: the caller searches on `stream` itself, the last kernels of the build need not be waited for
 static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
-                                  gp_point_grid_t** out) {
+                                  bool synchronise, gp_point_grid_t** out) {
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
   if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure != 6 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4, 6} (>= 16: staging experiment)");
   auto* g = new gp_point_grid;
@@ -1702,9 +1704,10 @@ static int point_grid_create_impl(const float* points_dev, int n, double cell_si
         lv->sdim[a] = (lv->bins.geom.dim[a] + 3) / 4;
         sn *= (size_t)lv->sdim[a];
       }
-      rc = lv->super.alloc_pooled(sizeof(unsigned long long) * sn, g->stream);
+      const size_t super_bytes = (sizeof(unsigned long long) * sn + 255) & ~size_t(255);  // (a fill whose size is not a multiple of 16 B is two kernels)
+      rc = lv->super.alloc_pooled(super_bytes, g->stream);
       if (rc != GP_OK) break;
-      (void)hipMemsetAsync(lv->super.ptr, 0, sizeof(unsigned long long) * sn, g->stream);
+      (void)hipMemsetAsync(lv->super.ptr, 0, super_bytes, g->stream);
       if (lv->bins.num_occ_blocks > 0)
         hipLaunchKernelGGL(gp::super_mark_kernel, dim3((lv->bins.num_occ_blocks + 255) / 256), dim3(256), 0, g->stream, (const int*)lv->bins.occ_blocks.as<int>(),
                            lv->bins.num_occ_blocks, lv->bins.geom, lv->sdim[0], lv->sdim[1], lv->super.as<unsigned long long>());
@@ -1712,8 +1715,11 @@ static int point_grid_create_impl(const float* points_dev, int n, double cell_si
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
       }
-      // (no synchronisation here: the arrays below go back to the pool in stream order, and whoever searches the structure does so on this stream or
-      // synchronises -- gp_point_grid_create's contract is "built on `stream`")
+      if (synchronise && rc == GP_OK) {
+        const hipError_t e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
+      }
+      // (the arrays below go back to the pool in stream order)
       lv->h = h;
       lv->bins.order.release_on(g->stream);  // only the sorted copy is searched
       if (!(keep_cell_of && l == 0)) lv->bins.cell_of.release_on(g->stream);
@@ -1819,12 +1825,15 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
   const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, &g));
+  GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, false, &g));
   const double t1 = now();
+  // one zeroed block: [0] the count of queries with fewer than k neighbours, [256 B ..) the look-back state of the heavy-first scan (one fill kernel, not two)
   gp::DeviceArray d_short;
-  int rc = d_short.alloc_async(sizeof(int), s);
+  const bool heavy_first = g->binned && g->structure != 6 && g->structure != 3 && !g->bin_levels.empty() && g->bin_levels[0]->bins.cell_of.ptr;
+  const size_t zero_bytes = 256 + (heavy_first ? ((sizeof(unsigned long long) * gp::onepass_state_words(g->bin_levels[0]->bins.num_cells) + 255) & ~size_t(255)) : 0);
+  int rc = d_short.alloc_async(zero_bytes, s);
   if (rc == GP_OK) {
-    (void)hipMemsetAsync(d_short.ptr, 0, sizeof(int), s);
+    (void)hipMemsetAsync(d_short.ptr, 0, zero_bytes, s);
     const gp::SearchView v = g->view();
     const int nq = g->binned ? g->num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
     if (nq < n) hipLaunchKernelGGL(gp::nonfinite_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, covs_dev, d_short.as<int>());
@@ -1852,18 +1861,17 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
         }
       }
     }
-    gp::DeviceArray heavy_before, order_state;
-    if (nq > 0 && rc == GP_OK && g->binned && !d_todo && g->structure != 6 && g->bin_levels[0]->bins.cell_of.ptr) {
+    gp::DeviceArray heavy_before;
+    if (nq > 0 && rc == GP_OK && heavy_first && !d_todo) {
       // heavy queries first (HeavyCellCount above): order[] = positions with own-cell population < k, then the rest; one scan over the cells + one scatter
       const gp::PointBins& bins = g->bin_levels[0]->bins;
       const int nc = bins.num_cells;
       rc = todo.alloc_async(sizeof(int) * ((size_t)nq + 2), s);
       if (rc == GP_OK) rc = heavy_before.alloc_async(sizeof(int) * (size_t)nc, s);
-      if (rc == GP_OK) rc = order_state.alloc_async(sizeof(unsigned long long) * gp::onepass_state_words(nc), s);
       if (rc == GP_OK) {
-        (void)hipMemsetAsync(order_state.ptr, 0, sizeof(unsigned long long) * gp::onepass_state_words(nc), s);
         int* d_heavy = todo.as<int>() + nq + 1;
-        rc = gp::exclusive_scan_of(gp::HeavyCellCount{bins.cell_start.as<int>(), k}, heavy_before.as<int>(), nc, d_heavy, s, order_state.as<unsigned long long>());
+        rc = gp::exclusive_scan_of(gp::HeavyCellCount{bins.cell_start.as<int>(), k}, heavy_before.as<int>(), nc, d_heavy, s,
+                                   reinterpret_cast<unsigned long long*>(d_short.as<char>() + 256));
         if (rc == GP_OK) {
           hipLaunchKernelGGL(gp::heavy_first_order_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const int*)bins.cell_start.as<int>(), (const unsigned*)bins.cell_of.as<unsigned>(),
                              (const int*)heavy_before.as<int>(), (const int*)d_heavy, k, nq, todo.as<int>());

@@ -17,6 +17,9 @@ f=$(find /tmp/prof2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $
 t=$(find /tmp/prof2 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python scripts/kernel_trace_split.py "$t" $O/kernel_trace_split.json "$tf" | tee $O/kernel_trace_split.txt
 rm -rf /tmp/prof3 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof3 -o bench -- python bench.py --steps 20 --warmup 5 $B --no-mirror > $O/rocprof_bench_no_mirror.log 2>&1
 f=$(find /tmp/prof3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats_no_mirror.csv && head -3 $f | cut -c1-200
+# (the mix of round 3's file: 25 fused steps + the back-to-back launches, without the untimed device wake-up's ~10^4 fused steps)
+rm -rf /tmp/prof4 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof4 -o bench -- python bench.py --steps 20 --warmup 5 $B --device-warmup-ms 0 > $O/rocprof_bench_no_warmup.log 2>&1
+f=$(find /tmp/prof4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats_no_warmup.csv && head -3 $f | cut -c1-200
 # 2. HBM traffic of the tile kernel: FETCH_SIZE / WRITE_SIZE in separate passes, read side calibrated on a known stream (48 B per point, the API layout's pattern)
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
@@ -48,10 +51,12 @@ timeout 200 python scripts/r04_instep_xcd.py 8=1000 9=1000 10=1000 11=1000 12=10
 timeout 100 python scripts/r04_warm.py 2>/dev/null | grep "^{" > $O/warm.jsonl; head -3 $O/warm.jsonl
 timeout 60 ./scripts/probe/dispatch_ramp_probe > $O/dispatch_ramp_probe.txt 2>&1; head -3 $O/dispatch_ramp_probe.txt
 # 5. C5 and the map build
-timeout 200 python scripts/r04_c5.py 0,80,560,544,800 2>/dev/null | grep "^{" > $O/c5_staging.jsonl; head -3 $O/c5_staging.jsonl
+timeout 200 python scripts/r04_c5.py 0,6 2>/dev/null | grep "^{" > $O/c5_staging.jsonl; head -4 $O/c5_staging.jsonl
 [ -f gtsam_points_amd/libgtsam_points_hip_wavelog.so ] && timeout 200 python scripts/r04_c5_wavelog.py 0 2>&1 | grep -v amdgpu > $O/c5_wavelog.txt
 rm -rf /tmp/pm && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -o mb -- python scripts/r04_map_build.py > $O/map_build.log 2>&1
 f=$(find /tmp/pm -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/map_build_kernel_stats.csv
+t=$(find /tmp/pm -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python scripts/r04_build_timeline.py $t > $O/build_timeline.txt
+timeout 60 ./scripts/probe/sort_probe > $O/sort_probe.txt 2>&1; timeout 60 ./scripts/probe/bins_probe > $O/bins_probe.txt 2>&1; tail -2 $O/sort_probe.txt | cut -c1-200
 timeout 100 python scripts/r04_map_build.py 2>/dev/null | grep "^{" > $O/map_build.json; cat $O/map_build.json
 # 6. the whole default bench (driver's clock), smoke and the GPU test-suite
 timeout 900 python bench.py > $O/bench.log 2>&1; grep "^{" $O/bench.log > $O/bench_n1.json; cut -c1-300 $O/bench_n1.json
