@@ -650,6 +650,8 @@ def main():
     while (time.perf_counter() - t_wake) * 1e3 < args.device_warmup_ms:
         step()
         wake_steps += 1
+        if wake_steps % 25 == 0 and not dist_on:
+            torch.cuda.synchronize()  # (the timed region is bracketed by device synchronisations: the wake-up runs the same pattern)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -816,7 +818,9 @@ def main():
                 step="poses (host) -> tile kernel -> finalize kernel -> [N>1: RCCL all-reduce of the stacked records] -> records in host memory, synchronised",
                 device_warmup=dict(ms=args.device_warmup_ms, steps=wake_steps,
                                    note="untimed, before the W warm-up steps: the same step run back to back until the device's power state has settled (the first ~10 ms of work "
-                                        "behind seconds of host-side set-up run 6-8 % slower: scripts/r04_warm.py, profiles/r04_warm.jsonl)"),
+                                        "behind seconds of host-side set-up run 6-8 % slower: scripts/r04_warm.py, profiles/r04_warm.jsonl), with a torch.cuda.synchronize() every 25 steps -- "
+                                        "the timed region ends with one, and a process's first device synchronisations take 50-200 us instead of ~17 (scripts/dbg/k20.py): with K = 20 "
+                                        "that alone was +3 us per step"),
             ),
             roofline=roofline,
             cpu_baseline=cpu_baseline,

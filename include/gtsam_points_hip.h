@@ -357,7 +357,7 @@ int gp_point_grid_destroy(gp_point_grid_t* grid);
 int gp_knn_search(const gp_point_grid_t* grid, const float* queries_dev, int num_queries, int k, double max_sq_dist, int* indices_dev, double* sq_dists_dev,
                   int* num_found_dev, gp_stream_t stream);
 /* estimate_covariances(points, n, k): k-NN incl. the query -> sample covariance -> V diag(1e-3,1,1) V^-1; fewer than k -> identity.
- * covs_dev float[n][9] column-major; cell_size <= 0 picks 0.5 m; *num_short = points with < k neighbours. Synchronous. */
+ * covs_dev float[n][9] column-major; cell_size <= 0 picks 0.25 m; *num_short = points with < k neighbours. Synchronous. */
 int gp_estimate_covariances(const float* points_dev, int num_points, int k, double cell_size, float* covs_dev, int* num_short, gp_stream_t stream);
 /* as above with a GP_TUNE_KNN_STRUCTURE value and (measurement) a device buffer of 8 work counters or NULL, see gp_point_grid_create_ex */
 int gp_estimate_covariances_ex(const float* points_dev, int num_points, int k, double cell_size, float* covs_dev, int* num_short, int structure,
