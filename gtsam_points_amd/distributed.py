@@ -182,7 +182,13 @@ class ShardedLinearizer:
             self.issue(poses_local, self.own_rows)
         if exchange:
             if self.exchange == "all_gather":
-                dist.all_gather_into_tensor(self.stacked, self.own_rows, group=self.group)  # in place: the input is this rank's slot of the output
+                try:
+                    dist.all_gather_into_tensor(self.stacked, self.own_rows, group=self.group)  # in place: the input is this rank's slot of the output
+                except (RuntimeError, ValueError, NotImplementedError):
+                    # a backend that refuses the in-place form (an argument check, raised on every rank alike before anything is issued): the all-reduce from now on;
+                    # this pass is repeated, since the stack was not zeroed for it
+                    self.exchange = "all_reduce"
+                    return self._run(poses_local)
             else:
                 dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked
