@@ -8,7 +8,8 @@ Workload (config.workload): BASELINE.json configs[1] -- ONE VGICP factor per GPU
 2 M-point GaussianVoxelMap at 0.5 m (gtsam_points_amd.synthetic.make_c2_workload; rank r uses seed 42 + r).
 A "step" is one linearize() pass as the optimizer sees it.  N = 1: gp_vgicp_batch_linearize -- the pose rides in the kernel arguments, ONE launch (the
 tile kernel's last workgroups finalize, --finalize two-kernel for tile kernel + finalize kernel), records into host memory, the host polls completion
-words.  N > 1: pose -> tile kernel -> finalize kernel -> RCCL all-reduce of the stacked [N x 122] f64 record buffer over xGMI -> D2H -> sync.
+words.  N > 1: pose -> tile kernel -> finalize kernel -> ONE RCCL collective over the stacked [N x 122] f64 record buffer over xGMI (in-place all-gather;
+--exchange all_reduce: zeroed stack + all-reduce) -> D2H -> sync.
 Inputs (source cloud, voxel map) are resident in HBM before the timed region.  value = N * 1e6 * K / elapsed.
 Weak scaling: per-GPU work is fixed as N grows.
 
@@ -551,6 +552,9 @@ def main():
     ap.add_argument("--c4-steps", type=int, default=30)
     ap.add_argument("--c4-exchange", choices=["all_gather", "all_reduce"], default="all_gather",
                     help="the c4 step's collective: all_gather = in place, half the bytes, no zeroing (falls back to the all-reduce when the shards are not equal contiguous ranges)")
+    ap.add_argument("--exchange", choices=["all_gather", "all_reduce"], default="all_gather",
+                    help="N > 1 headline step: the collective that exchanges the ranks' records (all_gather = in place, every row moved once, no zeroing of the stack: the default; "
+                         "all_reduce = the north star's wording: sum over the zeroed stack; falls back to it when the backend refuses the in-place gather)")
     ap.add_argument("--no-c4-inlib", action="store_true", help="skip the single-process multi-device leg of c4 (run in a subprocess by the N = 1 run when it sees > 1 device)")
     ap.add_argument("--c4-inlib-only", action="store_true", help="(internal) run only the single-process multi-device leg of c4 and print its JSON object")
     ap.add_argument("--finalize", choices=["fused", "two-kernel"], default="fused",
@@ -654,10 +658,10 @@ def main():
             if issue_linearize(batch, pose_ptr, row_ptr[0]) != 0:
                 _capi.check(1, "gp_vgicp_batch_issue_linearize")
 
-        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue, always_exchange=True)
+        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue, always_exchange=True, exchange=args.exchange)
 
         def step():
-            stacked = sharded.linearize(pose)  # zero, local kernels, RCCL all-reduce over xGMI
+            stacked = sharded.linearize(pose)  # local kernels into the rank's row, ONE RCCL collective over xGMI (in-place all-gather; --exchange all_reduce: zero + all-reduce)
             host_out.copy_(stacked, non_blocking=True)
             stream.synchronize()
 
@@ -844,9 +848,9 @@ def main():
                 num_voxels=info.num_voxels,
                 num_buckets=info.num_buckets,
                 inlier_fraction=round(rec.num_inliers / args.source_points, 4),
-                parallelism=f"{world} x 1 factor/GPU; RCCL all-reduce of stacked [N x 122] f64 records" if dist_on else "1 GPU",
-                exchange=(f"torch.distributed backend {dist.get_backend()}, world {world}" if dist_on else None),
-                step="poses (host) -> tile kernel -> finalize kernel -> [N>1: RCCL all-reduce of the stacked records] -> records in host memory, synchronised",
+                parallelism=f"{world} x 1 factor/GPU; RCCL {sharded.exchange} of stacked [N x 122] f64 records" if dist_on else "1 GPU",
+                exchange=(f"torch.distributed backend {dist.get_backend()}, world {world}, {sharded.exchange}" if dist_on else None),
+                step="poses (host) -> tile kernel -> finalize kernel -> [N>1: ONE RCCL collective over the stacked records: in-place all-gather, or --exchange all_reduce] -> records in host memory, synchronised",
                 device_warmup=dict(ms=args.device_warmup_ms, steps=wake_steps,
                                    note="untimed, before the W warm-up steps: the same step run back to back until the device's power state has settled (the first ~10 ms of work "
                                         "behind seconds of host-side set-up run 6-8 % slower: scripts/r04_warm.py, profiles/r04_warm.jsonl), with a torch.cuda.synchronize() every 25 steps -- "
