@@ -238,6 +238,7 @@ _TUNE_SIGNATURES = {
     "gp_debug_stream_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gp_debug_calibration_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gp_debug_spin": (C.c_int, [C.c_double, C.c_void_p]),
+    "gp_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 _TUNE = None
 

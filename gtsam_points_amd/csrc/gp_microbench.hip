@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "gp_host.hpp"
+#include "gp_sort.hpp"
 #include "gp_vgicp_tile.hpp"
 
 namespace gp {
@@ -314,6 +315,25 @@ int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n,
 }
 
 /* measurement hook: one wave spins for `microseconds` on `stream` (asynchronous) */
+// test hook for gp_sort.hpp (tests/test_sort_gpu.py): stable argsort of n keys by their low key_bits bits.  keys_dev is overwritten (ping-pong buffer);
+// sorted keys / original indices are copied into keys_out_dev / vals_out_dev.  Synchronous.
+int gp_debug_sort_pairs(unsigned* keys_dev, int n, int key_bits, unsigned* keys_out_dev, int* vals_out_dev, gp_stream_t stream) {
+  if (n < 0 || key_bits < 1 || key_bits > 32 || (n > 0 && (!keys_dev || !keys_out_dev || !vals_out_dev))) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_sort_pairs: bad arguments");
+  if (n == 0) return GP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gp::DeviceArray keys_b, vals_a, vals_b, state;
+  GP_TRY(keys_b.alloc(sizeof(unsigned) * (size_t)n));
+  GP_TRY(vals_a.alloc(sizeof(int) * (size_t)n));
+  GP_TRY(vals_b.alloc(sizeof(int) * (size_t)n));
+  GP_TRY(state.alloc(sizeof(unsigned) * gp::radix_sort_state_words32(n, key_bits)));
+  bool in_b = false;
+  GP_TRY(gp::radix_sort_pairs(keys_dev, vals_a.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, state.as<unsigned>(), false, false, s, &in_b));
+  GP_HIP(hipMemcpyAsync(keys_out_dev, in_b ? keys_b.ptr : (void*)keys_dev, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  GP_HIP(hipMemcpyAsync(vals_out_dev, in_b ? vals_b.ptr : vals_a.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  GP_HIP(hipStreamSynchronize(s));
+  return GP_OK;
+}
+
 int gp_debug_spin(double microseconds, gp_stream_t stream) {
   hipLaunchKernelGGL(gp::spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0), (unsigned long long*)nullptr);
   GP_HIP(hipGetLastError());

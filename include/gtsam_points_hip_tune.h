@@ -21,6 +21,9 @@ int gp_debug_stream_bench(const float* points_dev, const float* covs_dev, int n,
  * effect on the tile kernel's duration) */
 int gp_debug_spin(double microseconds, gp_stream_t stream);
 int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, int n, int iters, gp_stream_t stream);
+/* test hook for the stable radix sort behind the structure builds (gp_sort.hpp; tests/test_sort_gpu.py): argsort of n keys by their low key_bits bits.
+ * keys_dev is overwritten; sorted keys -> keys_out_dev, original indices -> vals_out_dev.  Synchronous. */
+int gp_debug_sort_pairs(unsigned* keys_dev, int n, int key_bits, unsigned* keys_out_dev, int* vals_out_dev, gp_stream_t stream);
 
 #ifdef __cplusplus
 }
