@@ -80,19 +80,32 @@ struct BlockCache {
   }
   // A full cache makes room by giving its OLDEST blocks of this device back to the pool (round 4: it used to refuse the new block instead -- after a phase that
   // parked many blocks of other sizes, every later call paid hipFreeAsync + hipMallocAsync for all of its scratch arrays, up to milliseconds per call:
-  // bench.py's C5 behind C3's 64 map builds).  The one-off cost of the eviction is paid once, by the first calls of the new phase.
+  // bench.py's C5 behind C3's 64 map builds).  The stream an old block is tagged with may have been destroyed since: the blocks are freed on the NULL stream
+  // behind ONE synchronisation of the device, a quarter of the cache at a time, so that a change of phase pays it once and not per block.
   bool put(void* p, size_t bytes, hipStream_t stream, int device) {
     if (bytes > kMaxBytes / 2) return false;
-    while (entries.size() >= kMaxEntries || total + bytes > kMaxBytes) {
-      int oldest = -1;
+    if (entries.size() >= kMaxEntries || total + bytes > kMaxBytes) {
+      int cur = -1;
+      if (hipGetDevice(&cur) != hipSuccess || cur != device) return false;  // (an array of another device is being released: it goes back to the pool directly)
+      std::vector<int> mine;
       for (int i = 0; i < (int)entries.size(); i++)
-        if (entries[i].device == device && (oldest < 0 || entries[i].age < entries[oldest].age)) oldest = i;
-      if (oldest < 0) return false;  // (full of other devices' blocks)
-      const Entry e = entries[oldest];
-      (void)hipFreeAsync(e.ptr, e.stream == synced_release() ? nullptr : e.stream);
-      total -= e.bytes;
-      entries[oldest] = entries.back();
-      entries.pop_back();
+        if (entries[i].device == device) mine.push_back(i);
+      if (mine.empty()) return false;  // (full of other devices' blocks)
+      std::sort(mine.begin(), mine.end(), [&](int a, int b) { return entries[a].age < entries[b].age; });
+      size_t evict = std::max<size_t>(kMaxEntries / 4, 1), freed = 0;
+      (void)hipDeviceSynchronize();
+      std::vector<bool> gone(entries.size(), false);
+      for (size_t j = 0; j < mine.size() && (j < evict || total - freed + bytes > kMaxBytes); j++) {
+        (void)hipFreeAsync(entries[mine[j]].ptr, nullptr);
+        freed += entries[mine[j]].bytes;
+        gone[mine[j]] = true;
+      }
+      std::vector<Entry> kept;
+      for (size_t i = 0; i < entries.size(); i++)
+        if (!gone[i]) kept.push_back(entries[i]);
+      entries.swap(kept);
+      total -= freed;
+      if (entries.size() >= kMaxEntries || total + bytes > kMaxBytes) return false;
     }
     entries.push_back({p, bytes, stream, device, ++clock});
     total += bytes;

@@ -283,3 +283,46 @@ def test_non_finite_points_are_skipped(gpu, kitti00):
     idx = np.array([order[tuple(x)] for x in coords.tolist()])
     np.testing.assert_array_equal(num_points, on[idx])
     assert np.abs(covs - ocov[idx]).max() < 1e-13 and num_points.sum() == keep.sum()
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 4095, 4096, 4097, 8193])
+def test_binned_build_at_sizes_around_the_tile_boundaries(gpu, kitti00, n):
+    """round 4: the build's kernels work on tiles of 4096 (keys, sort passes, cells) and batches of 512 rows (statistics): clouds of 1 point, one tile minus / plus one
+    point, two tiles plus one -- with a non-finite point at the very end and at the very start -- against the CPU map"""
+    p = kitti00["target_points"][:n].copy()
+    c = kitti00["target_covs"][:n]
+    for bad in ([], [n - 1], [0]):
+        q = p.copy()
+        keep = np.ones(n, bool)
+        for b in bad:
+            q[b, 0] = np.nan
+            keep[b] = False
+        if keep.sum() == 0:
+            continue
+        _, vm, _ = _maps(gpu, q, c, 0.5)
+        _, _, om = _maps(gpu, q[keep], c[keep], 0.5)
+        assert vm.voxelmap_info.num_voxels == om.num_voxels
+        coords, num_points, means, covs = vm.download_f64()
+        oc, on, omean, ocov, _ = om.export()
+        order = {tuple(x): i for i, x in enumerate(oc.tolist())}
+        idx = np.array([order[tuple(x)] for x in coords.tolist()])
+        np.testing.assert_array_equal(num_points, on[idx])
+        assert num_points.sum() == keep.sum()
+        assert np.abs(means - omean[idx]).max() < 1e-7 and np.abs(covs - ocov[idx]).max() < 1e-13
+
+
+def test_one_voxel_with_many_points_and_a_cloud_in_one_cell(gpu):
+    """statistics batches: a voxel far larger than the 512-row batch, next to tiny ones; and every point in ONE voxel"""
+    rng = np.random.default_rng(3)
+    big = rng.uniform(0.01, 0.49, size=(5000, 3)).astype(np.float32)  # one voxel at 0.5 m
+    small = (rng.uniform(0, 0.49, size=(40, 3)) + np.arange(40)[:, None] * 3.0 + 2.0).astype(np.float32)
+    for pts in (np.concatenate([small[:20], big, small[20:]]), big):
+        covs = np.tile(np.diag([1e-3, 1.0, 2.0]).astype(np.float32), (len(pts), 1, 1))
+        _, vm, om = _maps(gpu, pts, covs, 0.5)
+        assert vm.voxelmap_info.num_voxels == om.num_voxels
+        coords, num_points, means, covs64 = vm.download_f64()
+        oc, on, omean, ocov, _ = om.export()
+        order = {tuple(x): i for i, x in enumerate(oc.tolist())}
+        idx = np.array([order[tuple(x)] for x in coords.tolist()])
+        np.testing.assert_array_equal(num_points, on[idx])
+        assert np.abs(means - omean[idx]).max() < 1e-6 and np.abs(covs64 - ocov[idx]).max() < 1e-12
