@@ -543,7 +543,8 @@ namespace {
 constexpr bool g_zero_copy_poses = true;  // synchronous batched calls: the kernels read the poses where the host staged them (stage_poses)
 constexpr int kPipelineChunks = 4;  // 64-point chunks per wave: 1024-point tiles
 constexpr int kFinalizePartsMax = 16;
-// workgroups sharing the finalize of a synchronous single-factor call (A/B on C2, scripts/r02/r02_finalize_parts.sh: 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 and the host step suffers)
+// workgroups sharing the finalize of a synchronous single-factor call (A/B on C2, scripts/r02/r02_finalize_parts.sh: 1: 7.1 us, 2: 5.5, 4: 4.8, 8: 4.6, 16: 4.7 and the host step suffers;
+// round 4, fused form, 8 against 16: C2 fused kernel 12.2-12.8 vs 12.1-12.9 us, step 19.9-20.2 vs 20.0-20.6; 125 k points: kernel 6.4-6.5 vs 6.2, step 13.7-14.4 vs 14.2-14.7)
 static constexpr int finalize_parts() { return 8; }
 constexpr int kFinalizeSplitTiles = 256;  // ... when the factor has at least this many tiles
 constexpr int kResidentWorkgroups = 1024;  // 256 compute units x 4 workgroups of the tile kernels (34-40 KB of LDS, <= 128 VGPRs)

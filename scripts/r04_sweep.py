@@ -17,8 +17,10 @@ import torch  # noqa: E402,F401
 import gtsam_points_amd as gpa  # noqa: E402
 from gtsam_points_amd import _capi, synthetic  # noqa: E402
 
+if "--lib" in sys.argv:  # (A/B of a differently built library: the file name under gtsam_points_amd/)
+    _capi.LIB_PATH = os.path.join(ROOT, "gtsam_points_amd", sys.argv[sys.argv.index("--lib") + 1])
 lib = gpa.load()
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.endswith(".so")]
 
 
 def opt(name, default):
