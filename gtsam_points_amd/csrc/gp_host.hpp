@@ -293,6 +293,17 @@ int acquire_source_mirror(const float* points, const float* covs, int n, int dev
 // A few words of host-mapped pinned memory per host thread and device: where a structure build's kernels leave the counts the host sizes the next step by (bounding
 // box, number of cells, failed insertions).  Reading them is a load behind the stream's synchronisation -- a D2H copy of device words is a copy KERNEL plus its launch
 // (~7 us apiece, six per map build: profiles/r04_map_build_stats.txt).  Never freed (the runtime may be gone when a thread ends).
+// the last "kernel" of a step whose real last kernel has no single finishing thread: stores (optionally a device word into a host word, then) the sequence number into the
+// flag word.  In stream order behind the step's kernels, so the flag also means that they have finished.
+template <int UNUSED = 0>
+__global__ void host_flag_kernel(int* __restrict__ flag, int seq, const int* __restrict__ copy_src, int* __restrict__ copy_dst) {
+  if (copy_src) {
+    *copy_dst = *copy_src;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  *flag = seq;
+}
+
 struct HostWords {
   int* host = nullptr;
   int* dev = nullptr;
@@ -304,6 +315,15 @@ struct HostWords {
   // The flag says "the results are there", NOT "the kernel is finished": only results may be read behind it; everything else stays ordered by the stream.
   static constexpr int kFlag = 15;
   int next_seq() const { return ++*seq; }
+  // "everything issued on `s` so far has finished" without hipStreamSynchronize's wake-up: a one-thread kernel behind it stores the flag (and copies a device int into host word
+  // `copy_to_word` first, when asked to); the host polls
+  int finish(hipStream_t s, const int* copy_src_dev = nullptr, int copy_to_word = 0) const {
+    const int q = next_seq();
+    hipLaunchKernelGGL(host_flag_kernel<0>, dim3(1), dim3(1), 0, s, dev + kFlag, q, copy_src_dev, dev + copy_to_word);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "host_flag_kernel", __FILE__, __LINE__);
+    return wait_flag(q, s);
+  }
   int wait_flag(int expect, hipStream_t s) const {
     const volatile int* f = host + kFlag;
     const auto t0 = std::chrono::steady_clock::now();

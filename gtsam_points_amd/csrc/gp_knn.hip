@@ -1891,10 +1891,20 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
       else
         hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
     }
+    // the count of short queries comes back through a host-mapped word, behind a one-thread kernel whose flag the host polls (a D2H copy is a copy kernel + the
+    // stream synchronisation's wake-up: ~10 us more)
     int h_short = 0;
-    hipError_t e = hipMemcpyAsync(&h_short, d_short.ptr, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) rc = gp::hip_fail(e, "covariance_kernel", __FILE__, __LINE__);
+    {
+      gp::HostWords hw;
+      int frc = gp::HostWords::get(&hw);
+      if (frc == GP_OK) frc = hw.finish(s, d_short.as<int>(), 13);
+      if (frc == GP_OK) {
+        h_short = reinterpret_cast<volatile int*>(hw.host)[13];
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) frc = gp::hip_fail(e, "covariance_kernel", __FILE__, __LINE__);
+      }
+      if (frc != GP_OK && rc == GP_OK) rc = frc;
+    }
     if (num_short) *num_short = h_short;
     if (h_short > 0) fprintf(stderr, "warning: fewer than k neighbors found for %d points\n", h_short);  // covariance_estimation.cpp:28
   }

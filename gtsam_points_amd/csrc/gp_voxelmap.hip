@@ -609,7 +609,7 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
                        m->buckets.as<gp_voxel_bucket>(), (uint32_t)num_buckets, mask, m->info.max_bucket_scan_count, hw.dev + 12);
     GP_HIP(hipGetLastError());
     m->info.num_buckets = (int)num_buckets;
-    GP_HIP(hipStreamSynchronize(s));  // :250
+    GP_TRY(hw.finish(s));  // :250 (the build is complete: a flag kernel behind it, polled -- gp_host.hpp)
     if (reinterpret_cast<volatile int*>(hw.host)[12] == 0) break;
   }
   return GP_OK;
