@@ -47,6 +47,8 @@ struct SortHistLds {
 __device__ __forceinline__ void sort_hist_clear(SortHistLds& l) {  // 256-thread workgroups; barrier behind it is the caller's
   for (int p = 0; p < kSortMaxPasses; p++) l.h[p][threadIdx.x] = 0;
 }
+// (counting a wave's equal digits by their first lane alone -- ballot + readlane, up to three groups, the rest by atomics -- was measured against these plain LDS
+// atomics: a pass's load + count phase 1.0 -> 6.0 us, the key kernel 19 -> 26 us per 2 M points: the LDS unit serves same-address lanes faster than that loop)
 __device__ __forceinline__ void sort_hist_count(SortHistLds& l, unsigned key, int passes) {
   for (int p = 0; p < passes; p++) atomicAdd(&l.h[p][(key >> (8 * p)) & 255u], 1u);
 }
