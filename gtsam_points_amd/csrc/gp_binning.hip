@@ -101,9 +101,11 @@ __global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __rest
 // sort key of a point: (block index, bit inside the block) -- the order the cells are numbered in.  < 2^24 * 64 = 2^30.  The kernel also counts the keys' digits for
 // every pass of the sort behind it (gp_sort.hpp: the sort needs no pass over the keys for that).
 constexpr int kKeyTile = 4096;
-__global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys, int passes,
+template <int passes>  // (compile-time: with a run-time pass count the digit counts compile to a loop nest with a branch per count)
+__global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys,
                                                        unsigned* __restrict__ hist, unsigned invalid_key) {
   __shared__ SortHistLds l;
+  GP_SORT_STAMP(blockIdx.x, 8);
   sort_hist_clear(l);
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * kKeyTile;
@@ -130,8 +132,11 @@ __global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__
       }
     }
   }
+  GP_SORT_STAMP(blockIdx.x, 9);  // this wave's points done
   __syncthreads();
+  GP_SORT_STAMP(blockIdx.x, 10);
   sort_hist_flush(l, passes, hist);
+  GP_SORT_STAMP(blockIdx.x, 11);  // flush issued
 }
 
 // Cells = runs of equal keys in the sorted order.  TWO kernels (round 4; was: scan of the cell-start flags, a kernel writing the cells, scan of the block-start
@@ -372,8 +377,16 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   const unsigned invalid_key = (unsigned)((1ll << key_bits) - 1);
   bool in_b = false;
   unsigned* sort_state = reinterpret_cast<unsigned*>(st + sort_off);
-  hipLaunchKernelGGL(bins_key_kernel, dim3((n + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), (key_bits + 7) / 8,
-                     radix_sort_hist(sort_state, n, key_bits), invalid_key);
+  {
+    const dim3 kgrid((n + kKeyTile - 1) / kKeyTile), kblock(256);
+    unsigned* hist = radix_sort_hist(sort_state, n, key_bits);
+    switch ((key_bits + 7) / 8) {
+      case 1: hipLaunchKernelGGL(bins_key_kernel<1>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
+      case 2: hipLaunchKernelGGL(bins_key_kernel<2>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
+      case 3: hipLaunchKernelGGL(bins_key_kernel<3>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
+      default: hipLaunchKernelGGL(bins_key_kernel<4>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
+    }
+  }
   GP_HIP(hipGetLastError());
   GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_state, true, true, s, &in_b));
   if (in_b) {

@@ -50,12 +50,15 @@ __device__ __forceinline__ void sort_hist_clear(SortHistLds& l) {  // 256-thread
 // (counting a wave's equal digits by their first lane alone -- ballot + readlane, up to three groups, the rest by atomics -- was measured against these plain LDS
 // atomics: a pass's load + count phase 1.0 -> 6.0 us, the key kernel 19 -> 26 us per 2 M points: the LDS unit serves same-address lanes faster than that loop)
 __device__ __forceinline__ void sort_hist_count(SortHistLds& l, unsigned key, int passes) {
-  for (int p = 0; p < passes; p++) atomicAdd(&l.h[p][(key >> (8 * p)) & 255u], 1u);
+#pragma unroll
+  for (int p = 0; p < kSortMaxPasses; p++)
+    if (p < passes) atomicAdd(&l.h[p][(key >> (8 * p)) & 255u], 1u);
 }
 __device__ __forceinline__ void sort_hist_flush(SortHistLds& l, int passes, unsigned* __restrict__ hist /*[class][pass][256]*/) {  // behind a barrier
   unsigned* mine = hist + (size_t)(blockIdx.x % kSortHistClasses) * kSortMaxPasses * 256;
-  for (int p = 0; p < passes; p++)
-    if (l.h[p][threadIdx.x]) atomicAdd(mine + p * 256 + threadIdx.x, l.h[p][threadIdx.x]);
+#pragma unroll
+  for (int p = 0; p < kSortMaxPasses; p++)
+    if (p < passes && l.h[p][threadIdx.x]) atomicAdd(mine + p * 256 + threadIdx.x, l.h[p][threadIdx.x]);
 }
 // a tile index for this workgroup such that every smaller index has been drawn by a workgroup that is running (or done), without one hot counter: class c =
 // blockIdx % classes draws from its own counter, tile = ticket * classes + c (classes' shares of the grid are exactly the tiles of that form).  tickets: classes words, zeroed.

@@ -46,6 +46,21 @@ int run(int n, double cell) {
         for (int i = 0; i < tiles; i++) dd.push_back((double)(long long)(t[16 * (size_t)i + k + 1] - t[16 * (size_t)i + k]) / 100.0);
         printf(" %s %.2f / %.2f;", names[k], med(dd), *std::max_element(dd.begin(), dd.end()));
       }
+      {
+        // the key kernel's own stamps (slots 8 .. 11; its tiles are the same 4096 points)
+        unsigned long long kfirst = ~0ull, klast = 0;
+        for (int i = 0; i < tiles; i++) kfirst = std::min(kfirst, t[16 * (size_t)i + 8]), klast = std::max(klast, t[16 * (size_t)i + 11]);
+        printf(" | key kernel: first start -> last flush issued %.2f us; phases (median / max):", (klast - kfirst) / 100.0);
+        const char* kn[3] = {"load+key+count", "barrier", "flush issue"};
+        for (int k = 0; k < 3; k++) {
+          std::vector<double> dd;
+          for (int i = 0; i < tiles; i++) dd.push_back((double)(long long)(t[16 * (size_t)i + 9 + k] - t[16 * (size_t)i + 8 + k]) / 100.0);
+          printf(" %s %.2f / %.2f;", kn[k], med(dd), *std::max_element(dd.begin(), dd.end()));
+        }
+        std::vector<double> ks;
+        for (int i = 0; i < tiles; i++) ks.push_back((t[16 * (size_t)i + 8] - kfirst) / 100.0);
+        printf(" start median %.2f max %.2f |", med(ks), *std::max_element(ks.begin(), ks.end()));
+      }
       std::vector<double> st;
       for (int i = 0; i < tiles; i++) st.push_back((t[16 * (size_t)i] - first) / 100.0);
       printf(" ticket time median %.2f max %.2f\n", med(st), *std::max_element(st.begin(), st.end()));
