@@ -28,7 +28,8 @@ __device__ __forceinline__ bool point_cell(const float* __restrict__ points, siz
 // max xyz}; a workgroup without a finite point writes the neutral box.  (Round 4 tried one launch -- the boxes folded into six words with atomicMax, the last
 // workgroup by ticket writing the result: 488 atomics on one address are served one after the other, 16 us; this pair is 8.)
 constexpr int kBboxTile = 4096;
-__global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict__ points, int n, double inv_cell, int* __restrict__ boxes) {
+__global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict__ points, int n, double inv_cell, int* __restrict__ boxes, const FillJob zero_states) {
+  run_fill_job(zero_states);  // (the state words of the kernels behind: gp_host.hpp, FillJob)
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   const size_t base = (size_t)blockIdx.x * kBboxTile;
   float p[kBboxTile / 256][3];
@@ -103,7 +104,8 @@ __global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __rest
 constexpr int kKeyTile = 4096;
 template <int passes>  // (compile-time: with a run-time pass count the digit counts compile to a loop nest with a branch per count)
 __global__ void __launch_bounds__(256) bins_key_kernel(const float* __restrict__ points, int n, double inv_cell, GridGeom g, unsigned* __restrict__ keys,
-                                                       unsigned* __restrict__ hist, unsigned invalid_key) {
+                                                       unsigned* __restrict__ hist, unsigned invalid_key, const FillJob zero_blocks) {
+  run_fill_job(zero_blocks);  // (the block grid the cells kernel ORs its occupancy bits into)
   __shared__ SortHistLds l;
   GP_SORT_STAMP(blockIdx.x, 8);
   sort_hist_clear(l);
@@ -331,13 +333,12 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   const size_t sort_words = radix_sort_state_words32(n, 32) /* 32-bit */, cells_words = cells_state_words(n) /* 64-bit */;
   const size_t sort_off = 0, cells_off = (sort_off + sort_words * 4 + 7) & ~size_t(7), state_bytes = (cells_off + cells_words * 8 + 255) & ~size_t(255);  // (a fill whose size is not a multiple of 16 B is two kernels)
   GP_TRY(states.alloc_async(state_bytes, s));
-  GP_HIP(hipMemsetAsync(states.ptr, 0, state_bytes, s));
-  char* st = states.as<char>();
+  char* st = states.as<char>();  // (zeroed by the bounding-box kernel on its way)
   // ---- bounding box ----
   DeviceArray boxes;
   const int box_wgs = (n + kBboxTile - 1) / kBboxTile;
   GP_TRY(boxes.alloc_async(sizeof(int) * 6 * (size_t)box_wgs, s));
-  hipLaunchKernelGGL(bins_bbox_kernel, dim3(box_wgs), dim3(256), 0, s, points_dev, n, inv_cell, boxes.as<int>());
+  hipLaunchKernelGGL(bins_bbox_kernel, dim3(box_wgs), dim3(256), 0, s, points_dev, n, inv_cell, boxes.as<int>(), fill_job(states.ptr, state_bytes, 0u));
   const int seq_box = hw.next_seq();
   hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), box_wgs, hw.dev, seq_box);
   GP_HIP(hipGetLastError());
@@ -364,8 +365,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   bins->num_blocks = (long long)bins->geom.dim[0] * bins->geom.dim[1] * bins->geom.dim[2];
   // ---- keys = (block, bit), stable sort, cells = runs of equal keys ----
   DeviceArray keys_b, vals_b;
-  GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));
-  GP_HIP(hipMemsetAsync(bins->blocks.ptr, 0, sizeof(GridBlock) * (size_t)bins->num_blocks, s));
+  GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));  // (zeroed by the key kernel on its way)
   GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
   GP_TRY(bins->order.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
@@ -380,11 +380,12 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   {
     const dim3 kgrid((n + kKeyTile - 1) / kKeyTile), kblock(256);
     unsigned* hist = radix_sort_hist(sort_state, n, key_bits);
+    const FillJob zero_blocks = fill_job(bins->blocks.ptr, sizeof(GridBlock) * (size_t)bins->num_blocks, 0u);
     switch ((key_bits + 7) / 8) {
-      case 1: hipLaunchKernelGGL(bins_key_kernel<1>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
-      case 2: hipLaunchKernelGGL(bins_key_kernel<2>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
-      case 3: hipLaunchKernelGGL(bins_key_kernel<3>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
-      default: hipLaunchKernelGGL(bins_key_kernel<4>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key); break;
+      case 1: hipLaunchKernelGGL(bins_key_kernel<1>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key, zero_blocks); break;
+      case 2: hipLaunchKernelGGL(bins_key_kernel<2>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key, zero_blocks); break;
+      case 3: hipLaunchKernelGGL(bins_key_kernel<3>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key, zero_blocks); break;
+      default: hipLaunchKernelGGL(bins_key_kernel<4>, kgrid, kblock, 0, s, points_dev, n, inv_cell, bins->geom, bins->cell_of.as<unsigned>(), hist, invalid_key, zero_blocks); break;
     }
   }
   GP_HIP(hipGetLastError());

@@ -293,6 +293,27 @@ int acquire_source_mirror(const float* points, const float* covs, int n, int dev
 // A few words of host-mapped pinned memory per host thread and device: where a structure build's kernels leave the counts the host sizes the next step by (bounding
 // box, number of cells, failed insertions).  Reading them is a load behind the stream's synchronisation -- a D2H copy of device words is a copy KERNEL plus its launch
 // (~7 us apiece, six per map build: profiles/r04_map_build_stats.txt).  Never freed (the runtime may be gone when a thread ends).
+// A fill as a side job of a kernel that runs anyway (round 4): every kernel on this device costs ~8 us around its workgroups (dispatch to the first instruction, and
+// the write-back of its dirty L2 lines before the next kernel may start on another XCD), so a hipMemsetAsync in front of a kernel is that much for a few
+// microseconds of stores.  Called by every thread of a kernel whose successors -- not the kernel itself -- read the filled memory; 16-byte granules.
+struct FillJob {
+  uint4* ptr = nullptr;       // 16-byte aligned
+  unsigned long long count = 0;  // granules
+  unsigned value = 0;         // every 32-bit word
+};
+inline FillJob fill_job(void* p, size_t bytes, unsigned value) {  // bytes: a multiple of 16
+  FillJob f;
+  f.ptr = static_cast<uint4*>(p);
+  f.count = bytes / 16;
+  f.value = value;
+  return f;
+}
+__device__ __forceinline__ void run_fill_job(const FillJob& f) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const uint4 v = make_uint4(f.value, f.value, f.value, f.value);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < f.count; i += stride) f.ptr[i] = v;
+}
+
 // the last "kernel" of a step whose real last kernel has no single finishing thread: stores (optionally a device word into a host word, then) the sequence number into the
 // flag word.  In stream order behind the step's kernels, so the flag also means that they have finished.
 template <int UNUSED = 0>

@@ -851,7 +851,9 @@ __global__ void __launch_bounds__(256) nonfinite_identity_kernel(const float* __
 }
 
 // superblock occupancy: bit (bx & 3) + 4 (by & 3) + 16 (bz & 3) of entry (bx >> 2, by >> 2, bz >> 2), relative block coordinates
-__global__ void super_mark_kernel(const int* __restrict__ occ_blocks, int num, GridGeom geom, int sdim0, int sdim1, unsigned long long* __restrict__ super) {
+__global__ void super_mark_kernel(const int* __restrict__ occ_blocks, int num, GridGeom geom, int sdim0, int sdim1, unsigned long long* __restrict__ super,
+                                  const FillJob caller_zero) {
+  run_fill_job(caller_zero);  // (words the CALLER's kernels behind this one want zeroed: gp_estimate_covariances' counters)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= num) return;
   const long long b = occ_blocks[i];
@@ -859,7 +861,9 @@ __global__ void super_mark_kernel(const int* __restrict__ occ_blocks, int num, G
   atomicOr(super + ((size_t)(bz >> 2) * sdim1 + (by >> 2)) * sdim0 + (bx >> 2), 1ull << ((bx & 3) | ((by & 3) << 2) | ((bz & 3) << 4)));
 }
 
-__global__ void __launch_bounds__(256) gather_sorted_kernel(const float* __restrict__ points, const int* __restrict__ order, int n, float4* __restrict__ sorted) {
+__global__ void __launch_bounds__(256) gather_sorted_kernel(const float* __restrict__ points, const int* __restrict__ order, int n, float4* __restrict__ sorted,
+                                                           const FillJob zero_super) {
+  run_fill_job(zero_super);  // (the superblock masks the kernel behind this one ORs into: gp_host.hpp, FillJob)
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const size_t i = (size_t)order[j];
@@ -1662,15 +1666,24 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 // structure: GP_TUNE_KNN_STRUCTURE value (0 binned + per-lane search, 1 hashed multi-level grid, 3 row-tiled covariance pass first, 4 two binned
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
 static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
-                                  bool synchronise, gp_point_grid_t** out);
+                                  bool synchronise, gp_point_grid_t** out, const gp::FillJob caller_zero = gp::FillJob{}, bool* caller_zero_applied = nullptr);
 int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
   // (synchronised: gp_knn_search takes a stream of its own, which need not be the one the structure was built on)
   return point_grid_create_impl(points_dev, n, cell_size, structure, counters_dev, stream, false, true, out);
 }
 // keep_cell_of: the cell ordinals of the sorted positions stay with the first level (gp_estimate_covariances orders its queries by them);
 // synchronise = false: the caller searches on `stream` itself, the last kernels of the build need not be waited for
+// caller_zero: a fill the caller wants done on the stream before it searches; it rides in one of the build's kernels when the binned build runs (*caller_zero_applied)
 static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
-                                  bool synchronise, gp_point_grid_t** out) {
+                                  bool synchronise, gp_point_grid_t** out, const gp::FillJob caller_zero, bool* caller_zero_applied) {
+  bool caller_zero_done = false;
+  struct Report {
+    bool* out;
+    const bool* done;
+    ~Report() {
+      if (out) *out = *done;
+    }
+  } report{caller_zero_applied, &caller_zero_done};
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
   if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure != 6 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4, 6} (>= 16: staging experiment)");
   auto* g = new gp_point_grid;
@@ -1696,21 +1709,22 @@ static int point_grid_create_impl(const float* points_dev, int n, double cell_si
       }
       rc = lv->sorted.alloc_pooled(sizeof(float4) * (size_t)std::max(lv->bins.num_binned, 1), g->stream);
       if (rc != GP_OK) break;
-      hipLaunchKernelGGL(gp::gather_sorted_kernel, dim3((lv->bins.num_binned + 255) / 256), dim3(256), 0, g->stream, points_dev, (const int*)lv->bins.order.as<int>(),
-                         lv->bins.num_binned, lv->sorted.as<float4>());
-      // superblock occupancy (coarse stage of the search)
+      // superblock occupancy (coarse stage of the search): zeroed by the gather kernel on its way, marked by the kernel behind it
       size_t sn = 1;
       for (int a = 0; a < 3; a++) {
         lv->sdim[a] = (lv->bins.geom.dim[a] + 3) / 4;
         sn *= (size_t)lv->sdim[a];
       }
-      const size_t super_bytes = (sizeof(unsigned long long) * sn + 255) & ~size_t(255);  // (a fill whose size is not a multiple of 16 B is two kernels)
+      const size_t super_bytes = (sizeof(unsigned long long) * sn + 255) & ~size_t(255);
       rc = lv->super.alloc_pooled(super_bytes, g->stream);
       if (rc != GP_OK) break;
-      (void)hipMemsetAsync(lv->super.ptr, 0, super_bytes, g->stream);
-      if (lv->bins.num_occ_blocks > 0)
-        hipLaunchKernelGGL(gp::super_mark_kernel, dim3((lv->bins.num_occ_blocks + 255) / 256), dim3(256), 0, g->stream, (const int*)lv->bins.occ_blocks.as<int>(),
-                           lv->bins.num_occ_blocks, lv->bins.geom, lv->sdim[0], lv->sdim[1], lv->super.as<unsigned long long>());
+      hipLaunchKernelGGL(gp::gather_sorted_kernel, dim3((std::max(lv->bins.num_binned, 1) + 255) / 256), dim3(256), 0, g->stream, points_dev, (const int*)lv->bins.order.as<int>(),
+                         lv->bins.num_binned, lv->sorted.as<float4>(), gp::fill_job(lv->super.ptr, super_bytes, 0u));
+      // (launched also without occupied blocks when it carries the caller's fill)
+      if (lv->bins.num_occ_blocks > 0 || (l == 0 && caller_zero.count > 0))
+        hipLaunchKernelGGL(gp::super_mark_kernel, dim3((std::max(lv->bins.num_occ_blocks, 1) + 255) / 256), dim3(256), 0, g->stream, (const int*)lv->bins.occ_blocks.as<int>(),
+                           lv->bins.num_occ_blocks, lv->bins.geom, lv->sdim[0], lv->sdim[1], lv->super.as<unsigned long long>(), l == 0 ? caller_zero : gp::FillJob{});
+      if (l == 0) caller_zero_done = true;
       {
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = gp::hip_fail(e, "gather_sorted_kernel", __FILE__, __LINE__);
@@ -1825,15 +1839,18 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
   const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, false, &g));
-  const double t1 = now();
-  // one zeroed block: [0] the count of queries with fewer than k neighbours, [256 B ..) the look-back state of the heavy-first scan (one fill kernel, not two)
+  // one zeroed block: [0] the count of queries with fewer than k neighbours, [256 B ..) the look-back state of the heavy-first scan (sized for one cell per point).
+  // It is zeroed by one of the structure build's kernels on its way (gp_host.hpp, FillJob); only the hashed fallback build leaves it to a fill here.
   gp::DeviceArray d_short;
+  const size_t zero_bytes = 256 + ((sizeof(unsigned long long) * gp::onepass_state_words(n) + 255) & ~size_t(255));
+  GP_TRY(d_short.alloc_async(zero_bytes, s));
+  bool zeroed = false;
+  GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, false, &g, gp::fill_job(d_short.ptr, zero_bytes, 0u), &zeroed));
+  const double t1 = now();
   const bool heavy_first = g->binned && g->structure != 6 && g->structure != 3 && !g->bin_levels.empty() && g->bin_levels[0]->bins.cell_of.ptr;
-  const size_t zero_bytes = 256 + (heavy_first ? ((sizeof(unsigned long long) * gp::onepass_state_words(g->bin_levels[0]->bins.num_cells) + 255) & ~size_t(255)) : 0);
-  int rc = d_short.alloc_async(zero_bytes, s);
+  int rc = GP_OK;
   if (rc == GP_OK) {
-    (void)hipMemsetAsync(d_short.ptr, 0, zero_bytes, s);
+    if (!zeroed) (void)hipMemsetAsync(d_short.ptr, 0, zero_bytes, s);
     const gp::SearchView v = g->view();
     const int nq = g->binned ? g->num_binned : n;  // queries = the cell-sorted points; non-finite points are not among them
     if (nq < n) hipLaunchKernelGGL(gp::nonfinite_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points_dev, n, covs_dev, d_short.as<int>());

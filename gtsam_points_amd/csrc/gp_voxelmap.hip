@@ -220,7 +220,9 @@ constexpr int kStatsBatch = 512;
 __global__ void __launch_bounds__(256) segmented_stats_kernel(const float* __restrict__ points, const float* __restrict__ covs, const float* __restrict__ intensities,
                                                               int num_voxels, const int* __restrict__ cell_start, const int* __restrict__ order, double inv_leaf, double leaf,
                                                               VoxelRecord* __restrict__ records, int* __restrict__ num_points, float* __restrict__ voxel_means,
-                                                              float* __restrict__ voxel_covs, float* __restrict__ voxel_intensities, int* __restrict__ voxel_coords) {
+                                                              float* __restrict__ voxel_covs, float* __restrict__ voxel_intensities, int* __restrict__ voxel_coords,
+                                                              const gp::FillJob fill_buckets) {
+  gp::run_fill_job(fill_buckets);  // (the bucket table the insertion kernel behind this one claims its slots in: 0xff = empty)
   constexpr int kGroup = 16;
   __shared__ float rows[kStatsBatch][12];  // x y z, then the covariance's nine entries
   __shared__ float inten[kStatsBatch];
@@ -575,9 +577,18 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   m->info.num_voxels = V;
   GP_TRY(alloc_voxel_arrays(m, V));
   GP_TRY(m->voxel_coords.alloc_pooled(sizeof(int) * 3 * (size_t)std::max(V, 1), s));
+  // the bucket table of the first insertion attempt (below) is allocated here already: the statistics kernel fills it with "empty" on its way (gp_host.hpp, FillJob)
+  // the doubling sequence is entered where the voxels fit at a load factor <= 1/3: at 1/2 .. 2/3 some probe chain among 10^5 voxels exceeds max_bucket_scan_count almost
+  // surely, and the failed attempt (fill + insertion + a synchronisation) was 45 us of the 2 M-point build (profiles/r04_build_timeline.txt)
+  int64_t num_buckets = m->init_num_buckets;
+  while (num_buckets < 3 * (int64_t)V) num_buckets *= 2;
+  if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
+  GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
+  static_assert(sizeof(gp_voxel_bucket) == 16, "FillJob granules");
   hipLaunchKernelGGL(gp::segmented_stats_kernel, dim3((V + 15) / 16), dim3(256), 0, s, points_dev, covs_dev, intensities_dev, V, (const int*)bins.cell_start.as<int>(),
                      (const int*)bins.order.as<int>(), 1.0 / m->resolution, m->resolution, m->records.as<gp::VoxelRecord>(), m->num_points.as<int>(), m->voxel_means.as<float>(),
-                     m->voxel_covs.as<float>(), m->voxel_intensities.as<float>(), m->voxel_coords.as<int>());
+                     m->voxel_covs.as<float>(), m->voxel_intensities.as<float>(), m->voxel_coords.as<int>(),
+                     gp::fill_job(m->buckets.ptr, sizeof(gp_voxel_bucket) * (size_t)num_buckets, 0xffffffffu));
   GP_HIP(hipGetLastError());
   // occupancy-block grid: taken over from the bins
   m->gblocks.swap(bins.blocks);
@@ -593,16 +604,14 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   // path and starts over)
   gp::HostWords hw;
   GP_TRY(gp::HostWords::get(&hw));
-  int64_t num_buckets = m->init_num_buckets;
-  // the sequence is entered where the voxels fit at a load factor <= 1/3: at 1/2 .. 2/3 some probe chain among 10^5 voxels exceeds max_bucket_scan_count almost surely,
-  // and the failed attempt (fill + insertion + a synchronisation) was 45 us of the 2 M-point build (profiles/r04_build_timeline.txt)
-  while (num_buckets < 3 * (int64_t)V) num_buckets *= 2;
   m->private_built = false;  // (the hashed kernel family's line table is built when a batch first asks for it: gp_voxelmap::ensure_private_table)
   m->plines.release();
-  for (;; num_buckets *= 2) {
+  for (bool first = true;; num_buckets *= 2, first = false) {
     if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
-    GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
-    GP_HIP(hipMemsetAsync(m->buckets.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
+    if (!first) {  // (a table that turned out too small: the rare path)
+      GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
+      GP_HIP(hipMemsetAsync(m->buckets.ptr, 0xff, sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
+    }
     reinterpret_cast<volatile int*>(hw.host)[12] = 0;
     const uint32_t mask = ((num_buckets & (num_buckets - 1)) == 0) ? (uint32_t)(num_buckets - 1) : 0u;
     hipLaunchKernelGGL(gp::insert_voxels_kernel, dim3(grid_for((size_t)V)), dim3(kBlock), 0, s, V, (const int*)m->voxel_coords.as<int>(), (const int*)m->num_points.as<int>(),
