@@ -342,6 +342,15 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   const int seq_box = hw.next_seq();
   hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), box_wgs, hw.dev, seq_box);
   GP_HIP(hipGetLastError());
+  // (what does not depend on the box is allocated while the device works on it)
+  DeviceArray keys_b, vals_b;
+  GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
+  GP_TRY(bins->order.alloc_pooled(sizeof(int) * (size_t)n, s));
+  GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
+  GP_TRY(vals_b.alloc_pooled(sizeof(int) * (size_t)n, s));
+  GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)n + 1), s));
+  GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
+  GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
   GP_TRY(hw.wait_flag(seq_box, s));
   int h_bbox[6];
   for (int a = 0; a < 6; a++) h_bbox[a] = reinterpret_cast<volatile int*>(hw.host)[a];
@@ -364,12 +373,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   }
   bins->num_blocks = (long long)bins->geom.dim[0] * bins->geom.dim[1] * bins->geom.dim[2];
   // ---- keys = (block, bit), stable sort, cells = runs of equal keys ----
-  DeviceArray keys_b, vals_b;
   GP_TRY(bins->blocks.alloc_pooled(sizeof(GridBlock) * (size_t)bins->num_blocks, s));  // (zeroed by the key kernel on its way)
-  GP_TRY(bins->cell_of.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
-  GP_TRY(bins->order.alloc_pooled(sizeof(int) * (size_t)n, s));
-  GP_TRY(keys_b.alloc_pooled(sizeof(unsigned) * (size_t)n, s));
-  GP_TRY(vals_b.alloc_pooled(sizeof(int) * (size_t)n, s));
   // keys of the binned points are below K = blocks * 64; skipped points carry the all-ones key of the narrowest width that exceeds them -- 2^b - 1 >= K -- so they
   // land behind every cell, and the sort runs over b bits (a search grid of 1 M points has K ~ 1.2e7: 24 bits, three passes; one bit more for the marker was a fourth)
   int key_bits = 7;
@@ -398,9 +402,6 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   // (no host round trip in the middle: the arrays the cell count would size are allocated for the worst case, one cell per point; the host learns cells, occupied
   // blocks and binned points together at the end)
   const double t2 = now();
-  GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)n + 1), s));
-  GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
-  GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
   const int seq_cells = hw.next_seq();
   hipLaunchKernelGGL(bins_count_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, invalid_key,
                      reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n));
