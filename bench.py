@@ -490,7 +490,7 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
         points=nt, num_voxels=int(vmb.voxelmap_info.num_voxels), ms=round(mb_ms, 4), ms_min=round(float(np.min(ts[5:])) * 1e3, 4), points_per_s=round(nt / mb_ms * 1e3, 1),
         roofline=dict(bound="hbm", achieved=round(48.0 * nt / (mb_ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(48.0 * nt / (mb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       algorithmic_bytes=48 * nt, traffic=None,
-                      note="48 B per point read once (SURVEY.md 8(d), voxel-map build); host wall of the whole call (11 launches, three points where the host waits), not one kernel: the build is "
+                      note="48 B per point read once (SURVEY.md 8(d), voxel-map build); host wall of the whole call (10 launches, three points where the host waits), not one kernel: the build is "
                            "a chain of latency-bound kernels at this size (DESIGN.md section 4.4)"))
     return out
 

@@ -24,30 +24,36 @@ __device__ __forceinline__ bool point_cell(const float* __restrict__ points, siz
   return ok;
 }
 
-// bounding box (block units) of the finite points: a workgroup reduces 4096 points (the sixteen loads of a thread in flight together) into boxes[wg][6] = {min xyz,
-// max xyz}; a workgroup without a finite point writes the neutral box.  (Round 4 tried one launch -- the boxes folded into six words with atomicMax, the last
-// workgroup by ticket writing the result: 488 atomics on one address are served one after the other, 16 us; this pair is 8.)
+// bounding box (block units) of the finite points.  ONE kernel, reduced by the HOST: a workgroup reduces its tiles of 4096 points (the sixteen loads of a thread in
+// flight together; at most HostSlots::kSlots workgroups, which stride over the tiles) and leaves {min xyz, max xyz, -, seq} in its 32-byte slot of host-mapped memory,
+// the sequence number stored behind the box; the host combines the slots as they arrive.  A workgroup without a finite point leaves the neutral box.
+// (Tried before: the boxes folded into six device words with atomicMax and the last workgroup by ticket writing the result -- 488 atomics on one address are served one
+// after the other, 16 us; then per-workgroup boxes + a one-workgroup reduce kernel, 10 us of which ~6 are the second kernel's boundary.)
 constexpr int kBboxTile = 4096;
-__global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict__ points, int n, double inv_cell, int* __restrict__ boxes, const FillJob zero_states) {
+__global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict__ points, int n, double inv_cell, int* __restrict__ slots /* host-mapped */, int seq,
+                                                        const FillJob zero_states) {
   run_fill_job(zero_states);  // (the state words of the kernels behind: gp_host.hpp, FillJob)
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  const size_t base = (size_t)blockIdx.x * kBboxTile;
-  float p[kBboxTile / 256][3];
+  const size_t tiles = ((size_t)n + kBboxTile - 1) / kBboxTile;
+  for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const size_t base = tile * kBboxTile;
+    float p[kBboxTile / 256][3];
 #pragma unroll
-  for (int r = 0; r < kBboxTile / 256; r++) {
-    const size_t i = min(base + (size_t)r * 256 + threadIdx.x, (size_t)n - 1);  // (a point seen twice does not change the box)
+    for (int r = 0; r < kBboxTile / 256; r++) {
+      const size_t i = min(base + (size_t)r * 256 + threadIdx.x, (size_t)n - 1);  // (a point seen twice does not change the box)
 #pragma unroll
-    for (int a = 0; a < 3; a++) p[r][a] = points[3 * i + a];
-  }
+      for (int a = 0; a < 3; a++) p[r][a] = points[3 * i + a];
+    }
 #pragma unroll
-  for (int r = 0; r < kBboxTile / 256; r++) {
-    const double ux = (double)p[r][0] * inv_cell, uy = (double)p[r][1] * inv_cell, uz = (double)p[r][2] * inv_cell;
-    const bool ok = fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9;  // (point_cell's rule)
-    const int c[3] = {fast_floor(ux) >> 2, fast_floor(uy) >> 2, fast_floor(uz) >> 2};
+    for (int r = 0; r < kBboxTile / 256; r++) {
+      const double ux = (double)p[r][0] * inv_cell, uy = (double)p[r][1] * inv_cell, uz = (double)p[r][2] * inv_cell;
+      const bool ok = fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9;  // (point_cell's rule)
+      const int c[3] = {fast_floor(ux) >> 2, fast_floor(uy) >> 2, fast_floor(uz) >> 2};
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      lo[a] = ok ? min(lo[a], c[a]) : lo[a];
-      hi[a] = ok ? max(hi[a], c[a]) : hi[a];
+      for (int a = 0; a < 3; a++) {
+        lo[a] = ok ? min(lo[a], c[a]) : lo[a];
+        hi[a] = ok ? max(hi[a], c[a]) : hi[a];
+      }
     }
   }
 #pragma unroll
@@ -66,37 +72,19 @@ __global__ void __launch_bounds__(256) bins_bbox_kernel(const float* __restrict_
     }
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
-    int v = wave_box[0][threadIdx.x];
-    for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? min(v, wave_box[w][threadIdx.x]) : max(v, wave_box[w][threadIdx.x]);
-    boxes[6 * (size_t)blockIdx.x + threadIdx.x] = v;
-  }
-}
-
-__global__ void __launch_bounds__(256) bins_bbox_reduce_kernel(const int* __restrict__ boxes, int nb, int* __restrict__ bbox /* host-mapped */, int seq) {
-  __shared__ int part[256][6];
-  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  for (int b = threadIdx.x; b < nb; b += 256)
-    for (int a = 0; a < 3; a++) {
-      lo[a] = min(lo[a], boxes[6 * (size_t)b + a]);
-      hi[a] = max(hi[a], boxes[6 * (size_t)b + 3 + a]);
+  if (threadIdx.x == 0) {
+    int v[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      v[a] = wave_box[0][a];
+#pragma unroll
+      for (int w = 1; w < 4; w++) v[a] = a < 3 ? min(v[a], wave_box[w][a]) : max(v[a], wave_box[w][a]);
     }
-  for (int a = 0; a < 3; a++) {
-    part[threadIdx.x][a] = lo[a];
-    part[threadIdx.x][3 + a] = hi[a];
+    int4* slot = reinterpret_cast<int4*>(slots + 8 * (size_t)blockIdx.x);
+    slot[0] = make_int4(v[0], v[1], v[2], v[3]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first half is in host memory before the half that carries the sequence number
+    slot[1] = make_int4(v[4], v[5], 0, seq);
   }
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w)
-      for (int a = 0; a < 6; a++) part[threadIdx.x][a] = a < 3 ? min(part[threadIdx.x][a], part[threadIdx.x + w][a]) : max(part[threadIdx.x][a], part[threadIdx.x + w][a]);
-    __syncthreads();
-  }
-  if (threadIdx.x < 6) {
-    bbox[threadIdx.x] = part[0][threadIdx.x];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the box is in host memory before the flag is stored (HostWords::wait_flag)
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) bbox[HostWords::kFlag] = seq;
 }
 
 // sort key of a point: (block index, bit inside the block) -- the order the cells are numbered in.  < 2^24 * 64 = 2^30.  The kernel also counts the keys' digits for
@@ -335,12 +323,11 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(states.alloc_async(state_bytes, s));
   char* st = states.as<char>();  // (zeroed by the bounding-box kernel on its way)
   // ---- bounding box ----
-  DeviceArray boxes;
-  const int box_wgs = (n + kBboxTile - 1) / kBboxTile;
-  GP_TRY(boxes.alloc_async(sizeof(int) * 6 * (size_t)box_wgs, s));
-  hipLaunchKernelGGL(bins_bbox_kernel, dim3(box_wgs), dim3(256), 0, s, points_dev, n, inv_cell, boxes.as<int>(), fill_job(states.ptr, state_bytes, 0u));
+  HostSlots slots;
+  GP_TRY(HostSlots::get(&slots));
+  const int box_wgs = (int)std::min<size_t>(((size_t)n + kBboxTile - 1) / kBboxTile, (size_t)HostSlots::kSlots);
   const int seq_box = hw.next_seq();
-  hipLaunchKernelGGL(bins_bbox_reduce_kernel, dim3(1), dim3(256), 0, s, (const int*)boxes.as<int>(), box_wgs, hw.dev, seq_box);
+  hipLaunchKernelGGL(bins_bbox_kernel, dim3(box_wgs), dim3(256), 0, s, points_dev, n, inv_cell, slots.dev, seq_box, fill_job(states.ptr, state_bytes, 0u));
   GP_HIP(hipGetLastError());
   // (what does not depend on the box is allocated while the device works on it)
   DeviceArray keys_b, vals_b;
@@ -351,9 +338,27 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   GP_TRY(bins->cell_start.alloc_pooled(sizeof(int) * ((size_t)n + 1), s));
   GP_TRY(bins->cell_block.alloc_pooled(sizeof(int) * (size_t)n, s));
   GP_TRY(bins->occ_blocks.alloc_pooled(sizeof(int) * (size_t)n, s));  // at most one block per cell
-  GP_TRY(hw.wait_flag(seq_box, s));
-  int h_bbox[6];
-  for (int a = 0; a < 6; a++) h_bbox[a] = reinterpret_cast<volatile int*>(hw.host)[a];
+  // the host combines the workgroups' boxes as they arrive (bounded spin, then the stream -- which also surfaces a failed kernel)
+  int h_bbox[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  {
+    const volatile int* hs = slots.host;
+    const auto t_wait = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (int w = 0; w < box_wgs; w++) {
+      for (int spins = 0; hs[8 * w + 7] != seq_box; spins++) {
+        if ((spins & 63) == 63 && !synced && std::chrono::steady_clock::now() - t_wait > std::chrono::microseconds(500)) {
+          GP_HIP(hipStreamSynchronize(s));
+          synced = true;
+        } else if (synced && hs[8 * w + 7] != seq_box) {
+          return fail(GP_ERROR_HIP, "bin_points: the bounding-box kernel finished without leaving its boxes");
+        }
+      }
+      for (int a = 0; a < 3; a++) {
+        h_bbox[a] = std::min(h_bbox[a], (int)hs[8 * w + a]);
+        h_bbox[3 + a] = std::max(h_bbox[3 + a], (int)hs[8 * w + 3 + a]);
+      }
+    }
+  }
   const double t1 = now();
   if (h_bbox[0] > h_bbox[3]) {  // no finite point at all
     GP_TRY(bins->cell_start.alloc_pooled(sizeof(int), s));
@@ -415,7 +420,6 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   keys_b.release_on(s);
   vals_b.release_on(s);
   states.release_on(s);
-  boxes.release_on(s);
   const int h_counts[3] = {reinterpret_cast<volatile int*>(hw.host)[9], reinterpret_cast<volatile int*>(hw.host)[10], reinterpret_cast<volatile int*>(hw.host)[8]};  // cells, occupied blocks, binned points
   bins->num_cells = h_counts[0];
   bins->num_occ_blocks = h_counts[0] > 0 ? h_counts[1] : 0;

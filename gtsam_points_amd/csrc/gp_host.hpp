@@ -379,6 +379,33 @@ struct HostWords {
   }
 };
 
+// Per-thread, per-device host-mapped slots the workgroups of a kernel leave small records in for the HOST to combine (the bounding box of a structure build: one
+// 32-byte record per workgroup, the last word a sequence number stored behind the others) -- no reducing kernel, no ticket, no atomics, and the host has the result
+// ~1 us after the last record lands instead of a kernel boundary + a reduce kernel later.  kSlots records of eight ints; never freed.
+struct HostSlots {
+  int* host = nullptr;
+  int* dev = nullptr;
+  static constexpr int kSlots = 2048;
+  static int get(HostSlots* out) {
+    static thread_local HostSlots w[16];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return fail(GP_ERROR_HIP, "HostSlots: no current device");
+    if (!w[d].host) {
+      void* p = nullptr;
+      hipError_t e = hipHostMalloc(&p, sizeof(int) * 8 * kSlots, hipHostMallocMapped);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+      void* dp = nullptr;
+      e = hipHostGetDevicePointer(&dp, p, 0);
+      if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer", __FILE__, __LINE__);
+      w[d].host = static_cast<int*>(p);
+      w[d].dev = static_cast<int*>(dp);
+      for (int i = 0; i < 8 * kSlots; i++) w[d].host[i] = 0;
+    }
+    *out = w[d];
+    return GP_OK;
+  }
+};
+
 }  // namespace gp
 
 // TempBufferManager (cuda/stream_temp_buffer_roundrobin.cu:11-47)
