@@ -114,6 +114,48 @@ def test_sharded_linearize_all_gather_gloo_world2():
         assert np.array_equal(ret[r][0], ref6) and np.array_equal(ret[r][1], ref7), r
 
 
+def _worker_gather_refused(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    n = 6
+    begin, end = partition_factors([1000] * n, world)[rank]
+
+    def issue(_poses, view):
+        view.copy_(torch.from_numpy(_records_for(PAIRS, list(range(begin, end)))))
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lin = ShardedLinearizer(n, (begin, end), "cpu", issue, exchange="all_gather")
+    real = dist.all_gather_into_tensor
+
+    def refuse(*_a, **_k):  # a backend whose argument check rejects the in-place form: raised on every rank alike, before anything is issued
+        raise RuntimeError("all_gather_into_tensor: output and input tensors overlap")
+
+    dist.all_gather_into_tensor = refuse
+    try:
+        a = lin.linearize(None).clone()
+        assert lin.exchange == "all_reduce"  # decided once; the pass was repeated with the zeroed stack
+        b = lin.linearize(None)
+        assert torch.equal(a, b)
+    finally:
+        dist.all_gather_into_tensor = real
+    ret[rank] = a.numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_linearize_falls_back_when_the_backend_refuses_the_in_place_gather():
+    """round 4: the first multi-rank RCCL run has not happened yet -- if the backend rejects the in-place all-gather (an exception on every rank), the step becomes the
+    all-reduce of the zeroed stack and gives the same records"""
+    world = 2
+    port = 33500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_gather_refused, args=(world, port, ret), nprocs=world, join=True)
+    ref6 = _records_for(PAIRS, list(range(6)))
+    for r in range(world):
+        assert np.array_equal(ret[r], ref6), r
+
+
 def test_shard_plan_is_optimal_and_leaves_no_shard_empty():
     """gp_shard_plan_create (pure host code of the C-ABI): contiguous, complete, minimises the largest shard (checked against
     brute force over all boundary placements on small lists), and never leaves a shard empty while another holds two factors"""
