@@ -127,14 +127,16 @@ typedef struct gp_voxelmap gp_voxelmap_t;
  * resolution is double so that voxel coordinates are computed exactly as the CPU map does
  * (fast_floor(x * (1.0/leaf)), gaussian_voxelmap_cpu.cpp:59-61).
  * Deviation: the default (binned) build keeps EVERY voxel -- like the CPU map -- and sizes the reference-visible bucket table by
- * doubling from init_num_buckets until every voxel is inserted within max_bucket_scan_count probes; target_points_drop_rate is
+ * doubling from init_num_buckets until every voxel is inserted within max_bucket_scan_count probes (the sequence is entered at the first size >= 3 x the
+ * number of voxels: a fuller table almost surely fails an attempt); target_points_drop_rate is
  * honoured only by the reference-shaped hashed build (gp_voxelmap_set_tuning(GP_TUNE_MAP_BUILD, 1) and the fallback for huge bounding boxes), whose
  * doubling sequence starts at the first size >= N/16, so with a drop rate > 0 num_buckets and the set of dropped points can
  * differ from the reference's. */
 int gp_voxelmap_create(double resolution, int init_num_buckets, int max_bucket_scan_count, double target_points_drop_rate, gp_stream_t stream, gp_voxelmap_t** out);
 int gp_voxelmap_destroy(gp_voxelmap_t* map);
 /* insert(const PointCloud&): one-shot build from device arrays, gaussian_voxelmap_gpu.cu:211-307.
- * intensities_dev may be NULL (voxel intensities = 0, :232-240).  Synchronises the map's stream. */
+ * intensities_dev may be NULL (voxel intensities = 0, :232-240).  Returns when everything it issued on the map's stream has finished (a polled completion
+ * flag behind the last kernel; a stream synchronisation when that takes longer than 0.5 ms).  The hashed kernel family's private line table is built on first use. */
 int gp_voxelmap_insert(gp_voxelmap_t* map, const float* points_dev, const float* covs_dev, const float* intensities_dev, int num_points);
 int gp_voxelmap_info_get(const gp_voxelmap_t* map, gp_voxelmap_info* info);
 double gp_voxelmap_resolution(const gp_voxelmap_t* map);                       /* voxel_resolution() */
