@@ -256,11 +256,11 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
         import subprocess
 
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--c4-inlib-only", "--c4-steps", str(args.c4_steps)], capture_output=True, text=True, timeout=900)
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--c4-inlib-only", "--c4-steps", str(args.c4_steps)], capture_output=True, text=True, timeout=300)
             lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
             inlib = json.loads(lines[-1]) if lines else dict(error=f"no result (exit code {p.returncode}): {p.stderr[-400:]}")
         except subprocess.TimeoutExpired:
-            inlib = dict(error="the in-library multi-device leg did not finish within 900 s and was stopped")
+            inlib = dict(error="the in-library multi-device leg did not finish within 300 s and was stopped")
         except Exception as exc:
             inlib = dict(error=f"{type(exc).__name__}: {exc}")
     if rank != 0:
