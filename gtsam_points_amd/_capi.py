@@ -194,6 +194,9 @@ _SIGNATURES = {
     "gp_vgicp_batch_set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_debug_expand_rigid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_debug_stream_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "gp_debug_multi_gather_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
+    "gp_debug_inject_sort_fault": (C.c_int, [C.c_int]),
+    "gp_debug_sort_fallbacks": (C.c_int, []),
     "gp_trim_device_cache": (C.c_int, []),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
@@ -239,6 +242,8 @@ _TUNE_SIGNATURES = {
     "gp_debug_calibration_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gp_debug_spin": (C.c_int, [C.c_double, C.c_void_p]),
     "gp_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_debug_sort_pairs_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "gp_debug_occupy": (C.c_int, [C.c_double, C.c_int, C.c_void_p]),
 }
 _TUNE = None
 

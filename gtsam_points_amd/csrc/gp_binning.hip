@@ -200,10 +200,13 @@ __global__ void __launch_bounds__(256) bins_count_kernel(const unsigned* __restr
 
 __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restrict__ sorted_keys, int n, unsigned invalid_key, const unsigned long long* __restrict__ state, int num_groups,
                                                          GridBlock* __restrict__ blocks, int* __restrict__ cell_start, unsigned* __restrict__ cell_of, int* __restrict__ cell_block,
-                                                         int* __restrict__ occ_blocks, int* __restrict__ host_counts /* host-mapped */, int seq) {
+                                                         int* __restrict__ occ_blocks, int* __restrict__ host_counts /* host-mapped */, int seq,
+                                                         const unsigned* __restrict__ sort_state, unsigned sort_pass_words, int sort_passes) {
   __shared__ unsigned long long wave_sum[4];
   __shared__ unsigned long long tile_prefix;
   const int tile = blockIdx.x;
+  // a sort pass that gave up a wait (gp_sort.hpp, draw_tile) voids this build: the host must learn it even if the garbage keys leave no thread to report the counts
+  if (tile == 0 && threadIdx.x == 0 && radix_sort_faults(sort_state, sort_pass_words, sort_passes)) host_counts[11] = 1;
   GP_SORT_STAMP(tile, 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)tile * kCellsTile + (long long)threadIdx.x * kCellsPerThread;
@@ -293,6 +296,7 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
   if (end_at >= 0) {
     cell_start[cells_end] = end_at;
     host_counts[8] = end_at, host_counts[9] = cells_end, host_counts[10] = blocks_end;
+    if (radix_sort_faults(sort_state, sort_pass_words, sort_passes)) host_counts[11] = 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counts are in host memory before the flag is stored (HostWords::wait_flag)
     host_counts[HostWords::kFlag] = seq;
   }
@@ -300,7 +304,36 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
 
 }  // namespace
 
+namespace {
+thread_local int g_inject_sort_faults = 0;  // test hook: the next so many builds of this thread see a faulted sort (gp_debug_inject_sort_fault)
+thread_local int g_sort_fallbacks = 0;      // builds of this thread that went through the one-class sort
+int bin_points_once(const float* points_dev, int n, double inv_cell, hipStream_t s, PointBins* bins, bool* too_large, int ticket_classes, bool* sort_fault);
+}  // namespace
+
+void inject_sort_faults(int count) { g_inject_sort_faults = count; }
+int sort_fallbacks() { return g_sort_fallbacks; }
+
 int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, PointBins* bins, bool* too_large) {
+  bool fault = false;
+  int classes = kSortTicketClasses;
+  if (g_inject_sort_faults > 0) {
+    g_inject_sort_faults--;
+    classes = -kSortTicketClasses;
+  }
+  GP_TRY(bin_points_once(points_dev, n, inv_cell, s, bins, too_large, classes, &fault));
+  if (!fault) return GP_OK;
+  // A tile of the sort waited for a predecessor that had not even been started (the device did not start workgroups in blockIdx order: gp_sort.hpp). Everything the
+  // build derived from the keys is void; build again with the single ticket counter, which needs no such order.
+  g_sort_fallbacks++;
+  GP_HIP(hipStreamSynchronize(s));
+  GP_TRY(bin_points_once(points_dev, n, inv_cell, s, bins, too_large, 1, &fault));
+  if (fault) return fail(GP_ERROR_HIP, "bin_points: the radix sort made no progress (one-class form)");
+  return GP_OK;
+}
+
+namespace {
+int bin_points_once(const float* points_dev, int n, double inv_cell, hipStream_t s, PointBins* bins, bool* too_large, int ticket_classes, bool* sort_fault) {
+  *sort_fault = false;
   *too_large = false;
   bins->num_cells = 0;
   bins->num_binned = 0;
@@ -311,9 +344,6 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
     return GP_OK;
   }
   if (n >= (1 << 30)) return fail(GP_ERROR_INVALID_ARGUMENT, "bin_points: at most 2^30 - 1 points");
-  const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
   // ---- the state words of every kernel of this build (per sort pass -- sized for the widest key --, the histograms, the cells kernel's): ONE fill ----
   DeviceArray states;
   HostWords hw;  // host-mapped: [0..5] bounding box, [8] binned points, [9] cells, [10] occupied blocks -- written by the kernels, read behind the synchronisations
@@ -359,7 +389,6 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
       }
     }
   }
-  const double t1 = now();
   if (h_bbox[0] > h_bbox[3]) {  // no finite point at all
     GP_TRY(bins->cell_start.alloc_pooled(sizeof(int), s));
     GP_HIP(hipMemsetAsync(bins->cell_start.ptr, 0, sizeof(int), s));
@@ -398,7 +427,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
     }
   }
   GP_HIP(hipGetLastError());
-  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_state, true, true, s, &in_b));
+  GP_TRY(radix_sort_pairs(bins->cell_of.as<unsigned>(), bins->order.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, sort_state, true, true, s, &in_b, ticket_classes));
   if (in_b) {
     bins->cell_of.swap(keys_b);
     bins->order.swap(vals_b);
@@ -406,13 +435,14 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   // keys_b is free now: it receives the sorted points' cell ordinals while cell_of still holds the sorted keys
   // (no host round trip in the middle: the arrays the cell count would size are allocated for the worst case, one cell per point; the host learns cells, occupied
   // blocks and binned points together at the end)
-  const double t2 = now();
   const int seq_cells = hw.next_seq();
+  reinterpret_cast<volatile int*>(hw.host)[11] = 0;  // (the kernel only ever stores a 1 there)
   hipLaunchKernelGGL(bins_count_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, invalid_key,
                      reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n));
   hipLaunchKernelGGL(bins_cells_kernel, dim3((unsigned)cells_tiles(n)), dim3(256), 0, s, (const unsigned*)bins->cell_of.as<unsigned>(), n, invalid_key,
                      (const unsigned long long*)reinterpret_cast<unsigned long long*>(st + cells_off), (int)cells_groups(n), bins->blocks.as<GridBlock>(),
-                     bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(), bins->occ_blocks.as<int>(), hw.dev, seq_cells);
+                     bins->cell_start.as<int>(), keys_b.as<unsigned>(), bins->cell_block.as<int>(), bins->occ_blocks.as<int>(), hw.dev, seq_cells,
+                     (const unsigned*)sort_state, (unsigned)radix_sort_pass_words(n), (key_bits + 7) / 8);
   GP_HIP(hipGetLastError());
   bins->cell_of.swap(keys_b);  // cell_of = ordinals of the sorted points
   // the counts are awaited, not the kernels: what the caller issues behind this is ordered by the stream, and the scratch arrays go back to the pool in ITS order
@@ -420,12 +450,24 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   keys_b.release_on(s);
   vals_b.release_on(s);
   states.release_on(s);
+  if (reinterpret_cast<volatile int*>(hw.host)[11]) {
+    *sort_fault = true;
+    return GP_OK;
+  }
   const int h_counts[3] = {reinterpret_cast<volatile int*>(hw.host)[9], reinterpret_cast<volatile int*>(hw.host)[10], reinterpret_cast<volatile int*>(hw.host)[8]};  // cells, occupied blocks, binned points
   bins->num_cells = h_counts[0];
   bins->num_occ_blocks = h_counts[0] > 0 ? h_counts[1] : 0;
   bins->num_binned = h_counts[2];
-  if (dbg) fprintf(stderr, "bin_points: bbox %.0f us, sort issue %.0f us, finish %.0f us\n", t1 - t0, t2 - t1, now() - t2);
   return GP_OK;
 }
+}  // namespace
 
 }  // namespace gp
+
+extern "C" {
+int gp_debug_inject_sort_fault(int count) {
+  gp::inject_sort_faults(count < 0 ? 0 : count);
+  return GP_OK;
+}
+int gp_debug_sort_fallbacks(void) { return gp::sort_fallbacks(); }
+}

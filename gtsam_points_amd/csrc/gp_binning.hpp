@@ -52,6 +52,10 @@ struct PointBins {
 // Returns GP_OK with bins->num_cells >= 0, or GP_ERROR_INVALID_ARGUMENT with *too_large = true when the bounding box of the
 // occupied cells needs more than kMaxGridBlocks blocks (nothing is built then; the caller falls back to its hashed structure).
 // Synchronises the stream (twice: bounding box, cell count).
+// The build's radix sort hands tiles out through 32 ticket classes, which is fast and rests on the device starting workgroups in blockIdx order (gp_sort.hpp); a
+// sort that finds that order violated gives up instead of spinning, and the build runs again with the single ticket counter that needs no such order.
 int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, PointBins* bins, bool* too_large);
+void inject_sort_faults(int count);  // test hook (thread-local): the next `count` builds see a faulted first sort
+int sort_fallbacks();                // builds of this thread that went through the one-class sort
 
 }  // namespace gp

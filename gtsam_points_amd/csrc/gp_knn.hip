@@ -1836,9 +1836,6 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
   if (n == 0) return GP_OK;
   hipStream_t s = (hipStream_t)stream;
   gp_point_grid_t* g = nullptr;
-  const bool dbg = getenv("GP_KNN_DEBUG") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
   // one zeroed block: [0] the count of queries with fewer than k neighbours, [256 B ..) the look-back state of the heavy-first scan (sized for one cell per point).
   // It is zeroed by one of the structure build's kernels on its way (gp_host.hpp, FillJob); only the hashed fallback build leaves it to a fill here.
   gp::DeviceArray d_short;
@@ -1846,7 +1843,6 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
   GP_TRY(d_short.alloc_async(zero_bytes, s));
   bool zeroed = false;
   GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, false, &g, gp::fill_job(d_short.ptr, zero_bytes, 0u), &zeroed));
-  const double t1 = now();
   const bool heavy_first = g->binned && g->structure != 6 && g->structure != 3 && !g->bin_levels.empty() && g->bin_levels[0]->bins.cell_of.ptr;
   int rc = GP_OK;
   if (rc == GP_OK) {
@@ -1870,12 +1866,6 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
                            (const int*)g->bin_levels[0]->bins.occ_blocks.as<int>(), scan, 0);
         hipLaunchKernelGGL(gp::covariance_settle_kernel<10>, grid, block, 0, s, v.bins[0].sorted, scan, points_dev, k, covs_dev, todo.as<int>(), todo.as<int>() + nq);
         d_todo = todo.as<int>();
-        if (getenv("GP_KNN_DEBUG")) {  // how much the tiled pass left over
-          int left = 0;
-          (void)hipMemcpyAsync(&left, todo.as<int>() + nq, sizeof(int), hipMemcpyDeviceToHost, s);
-          (void)hipStreamSynchronize(s);
-          fprintf(stderr, "gp_estimate_covariances: tiled pass over %d blocks settled %d of %d queries\n", g->bin_levels[0]->bins.num_occ_blocks, nq - left, nq);
-        }
       }
     }
     gp::DeviceArray heavy_before;
@@ -1925,7 +1915,6 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
     if (num_short) *num_short = h_short;
     if (h_short > 0) fprintf(stderr, "warning: fewer than k neighbors found for %d points\n", h_short);  // covariance_estimation.cpp:28
   }
-  const double t2 = now();
   // the structure was built and searched on `s` only, and `s` has been synchronised: its arrays go back to the pool in stream order
   // (gp_point_grid_destroy has to assume searches on other streams and synchronises the device: 1.4 ms in a process with many streams)
   for (auto& lv : g->bin_levels) {
@@ -1933,7 +1922,6 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
       a->release_on(s);
   }
   delete g;
-  if (dbg) fprintf(stderr, "gp_estimate_covariances: structure %.0f us, search %.0f us, destroy %.0f us\n", t1 - t0, t2 - t1, now() - t2);
   return rc;
 }
 

@@ -334,6 +334,37 @@ int gp_debug_sort_pairs(unsigned* keys_dev, int n, int key_bits, unsigned* keys_
   return GP_OK;
 }
 
+// the sort with a chosen number of ticket classes (gp_sort.hpp: 32 = the builds' fast path, 1 = the deadlock-free form, negative = tile 0 raises the fault word);
+// *fault = some pass gave up a wait (the output is void then)
+int gp_debug_sort_pairs_ex(unsigned* keys_dev, int n, int key_bits, unsigned* keys_out_dev, int* vals_out_dev, int ticket_classes, int* fault, gp_stream_t stream) {
+  if (n < 0 || key_bits < 1 || key_bits > 32 || ticket_classes == 0 || !fault || (n > 0 && (!keys_dev || !keys_out_dev || !vals_out_dev)))
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_sort_pairs_ex: bad arguments");
+  *fault = 0;
+  if (n == 0) return GP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gp::DeviceArray keys_b, vals_a, vals_b, state;
+  GP_TRY(keys_b.alloc(sizeof(unsigned) * (size_t)n));
+  GP_TRY(vals_a.alloc(sizeof(int) * (size_t)n));
+  GP_TRY(vals_b.alloc(sizeof(int) * (size_t)n));
+  GP_TRY(state.alloc(sizeof(unsigned) * gp::radix_sort_state_words32(n, key_bits)));
+  bool in_b = false, f = false;
+  GP_TRY(gp::radix_sort_pairs(keys_dev, vals_a.as<int>(), keys_b.as<unsigned>(), vals_b.as<int>(), n, key_bits, true, state.as<unsigned>(), false, false, s, &in_b, ticket_classes));
+  GP_TRY(gp::radix_sort_fault(state.as<unsigned>(), n, key_bits, s, &f));
+  *fault = f ? 1 : 0;
+  GP_HIP(hipMemcpyAsync(keys_out_dev, in_b ? keys_b.ptr : (void*)keys_dev, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  GP_HIP(hipMemcpyAsync(vals_out_dev, in_b ? vals_b.ptr : vals_a.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  GP_HIP(hipStreamSynchronize(s));
+  return GP_OK;
+}
+
+// `workgroups` x 256 threads that each spin for `microseconds` (asynchronous): fills the CUs from another stream (the sort's forward-progress test)
+int gp_debug_occupy(double microseconds, int workgroups, gp_stream_t stream) {
+  if (workgroups <= 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_occupy: bad arguments");
+  hipLaunchKernelGGL(gp::spin_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0), (unsigned long long*)nullptr);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
 int gp_debug_spin(double microseconds, gp_stream_t stream) {
   hipLaunchKernelGGL(gp::spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0), (unsigned long long*)nullptr);
   GP_HIP(hipGetLastError());

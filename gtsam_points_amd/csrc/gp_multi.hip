@@ -213,6 +213,32 @@ struct Shard {
   ncclComm_t comm = nullptr;
 };
 
+// In-place all-gather: a shard's send buffer is where its own rows already lie in the stack, i.e. at its first global factor index (the gather plan makes shard k
+// exactly rows [k * rows, (k + 1) * rows)). Derived from the plan, never from where the Shard object lives (the shards sit in a std::deque, whose
+// elements are not contiguous -- `&s - &shards[0]` is undefined for every shard but the first).
+inline size_t gather_send_offset(const std::vector<int>& index, int width) { return index.empty() ? 0 : (size_t)index[0] * (size_t)width; }
+
+// the shards' factor lists from an explicit assignment (ascending global index inside a shard)
+inline std::vector<std::vector<int>> shard_index_lists(const int* shard_of, int num_factors, int num_shards) {
+  std::vector<std::vector<int>> lists((size_t)num_shards);
+  for (int i = 0; i < num_factors; i++) lists[(size_t)shard_of[i]].push_back(i);
+  return lists;
+}
+
+// all-gather applies iff shard k is exactly rows [k * F / N, (k + 1) * F / N); returns rows per shard or 0
+inline size_t gather_rows_of(const std::vector<std::vector<int>>& lists, size_t F) {
+  const size_t N = lists.size();
+  if (N == 0 || F == 0 || F % N != 0) return 0;
+  const size_t rows = F / N;
+  for (size_t k = 0; k < N; k++) {
+    const auto& ix = lists[k];
+    if (ix.size() != rows || (size_t)ix[0] != k * rows) return 0;
+    for (size_t j = 1; j < ix.size(); j++)
+      if (ix[j] != ix[j - 1] + 1) return 0;
+  }
+  return rows;
+}
+
 struct DeviceGuard {
   int saved = 0;
   DeviceGuard() { (void)hipGetDevice(&saved); }
@@ -326,8 +352,7 @@ int run_pass_impl(gp_vgicp_multi_batch* mb, int width, bool err_pass, Issue issu
       gp::DeviceArray& dst = err_pass ? s.d_err : s.d_stack;
       if (mb->gather) {
         const size_t count = mb->gather_rows * (size_t)width;  // in place: rank k's send buffer is its own slot of the receive buffer
-        const size_t rank = (size_t)(&s - &mb->shards[0]);
-        GP_NCCL(r.AllGather(dst.as<double>() + rank * count, dst.ptr, count, ncclDouble, s.comm, s.stream));
+        GP_NCCL(r.AllGather(dst.as<double>() + gather_send_offset(s.index, width), dst.ptr, count, ncclDouble, s.comm, s.stream));
       } else {
         GP_NCCL(r.AllReduce(dst.ptr, dst.ptr, (size_t)width * F, ncclDouble, ncclSum, s.comm, s.stream));
       }
@@ -477,16 +502,11 @@ int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_facto
         hipHostMalloc(&mb->h_err, sizeof(double) * std::max<size_t>(F, 1), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
       rc = gp::fail(GP_ERROR_HIP, "gp_vgicp_multi_batch_create: hipHostMalloc (portable) failed");
   }
-  if (rc == GP_OK && mb->use_rccl && want_gather && num_shards > 0 && F % (size_t)num_shards == 0) {
-    // all-gather: shard k must be exactly rows [k * F / N, (k + 1) * F / N)
-    const size_t rows = F / (size_t)num_shards;
-    bool ok = rows > 0;
-    for (int k = 0; k < num_shards && ok; k++) {
-      const Shard& s = mb->shards[(size_t)k];
-      ok = s.contiguous && s.index.size() == rows && (size_t)s.index[0] == (size_t)k * rows;
-    }
-    mb->gather = ok;
-    mb->gather_rows = ok ? rows : 0;
+  if (rc == GP_OK && mb->use_rccl && want_gather) {
+    std::vector<std::vector<int>> lists;
+    for (auto& s : mb->shards) lists.push_back(s.index);
+    mb->gather_rows = gather_rows_of(lists, F);
+    mb->gather = mb->gather_rows > 0;
   }
   if (rc == GP_OK && mb->use_rccl) {
     std::vector<ncclComm_t> comms((size_t)num_shards, nullptr);
@@ -502,6 +522,22 @@ int gp_vgicp_multi_batch_create(gp_vgicp_factor_t* const* factors, int num_facto
     return rc;
   }
   *out = mb;
+  return GP_OK;
+}
+
+// Host only (no device is touched): what the in-place all-gather of a pass would send from, per shard, for this assignment -- the functions the pass itself
+// uses. rows_per_shard = 0: the plan does not allow the all-gather (the pass would all-reduce).
+int gp_debug_multi_gather_plan(const int* shard_of_factor, int num_factors, int num_shards, int width, int64_t* rows_per_shard, int64_t* send_offset_doubles) {
+  if (!shard_of_factor || num_factors < 0 || num_shards <= 0 || width <= 0 || !rows_per_shard || !send_offset_doubles)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_multi_gather_plan: bad arguments");
+  for (int i = 0; i < num_factors; i++)
+    if (shard_of_factor[i] < 0 || shard_of_factor[i] >= num_shards) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_multi_gather_plan: shard index out of range");
+  std::deque<Shard> shards((size_t)num_shards);  // the container the batch keeps its shards in
+  const auto lists = shard_index_lists(shard_of_factor, num_factors, num_shards);
+  for (int k = 0; k < num_shards; k++) shards[(size_t)k].index = lists[(size_t)k];
+  *rows_per_shard = (int64_t)gather_rows_of(lists, (size_t)num_factors);
+  int k = 0;
+  for (auto& s : shards) send_offset_doubles[k++] = (int64_t)gather_send_offset(s.index, width);
   return GP_OK;
 }
 

@@ -38,6 +38,10 @@ constexpr int kSortGroup = 32;  // tiles per group of the two-level offsets (bel
 // 488 workgroups, or 488 histogram flushes into the same 256 words, stretch a 3 us kernel to 16-18 us (profiles/r04_build_pmc.txt: wave lifetimes of 3.6 us in
 // kernels 16 us long).  So the counters come in classes -- a workgroup uses the words of class blockIdx % classes -- and whoever needs the sum adds the classes up.
 constexpr int kSortTicketClasses = 32;
+constexpr int kSortFaultWord = 64;      // word of a pass's ticket line ([0 .. 31] tickets) that a tile whose wait expired sets to 1
+constexpr int kSortSpinBound = 200000;  // polls (>= ~1 us each: a sleep + a round trip to the coherence point) before a tile gives up: ~0.2 - 0.5 s
+// radix_onesweep_kernel's `ticket_classes` argument: kSortTicketClasses (fast path), 1 (deadlock-free), or a NEGATIVE class count = test hook: tile 0 raises the
+// fault word as if its wait had expired (tests/test_sort_gpu.py drives the fallback with it)
 constexpr int kSortHistClasses = 16;
 
 // LDS histograms of all passes' digits for a key the caller has in a register (the kernel that PRODUCES the keys counts them: no pass over the keys for it)
@@ -67,6 +71,10 @@ __device__ __forceinline__ void sort_hist_flush(SortHistLds& l, int passes, unsi
 // blockIdx order (as it does): the workgroups started so far then are a prefix of the grid, every class has handed out the same number of tickets (+- 1), and the
 // drawn tiles are a prefix too -- also when the grid exceeds what is resident at once (tests/test_sort_gpu.py sorts 1026 tiles against ~768 resident workgroups).
 // The price of the hot counter was 16 us per kernel (488 draws at ~33 ns apiece).
+// HIP does not promise that start order (CU masks, partition modes, other streams' kernels holding the CUs, a later ROCm: ADVICE r04), so the classes are a fast
+// path with a way out, not an assumption: every wait below is BOUNDED (kSortSpinBound polls); a tile whose wait expires raises the pass's fault word and stops
+// waiting (everybody has published before waiting, so every workgroup still ends), the host sees the word behind the sort (radix_sort_fault) and runs the sort
+// again with ONE class -- the deadlock-free form above, whatever the start order.
 template <typename Word>
 __device__ __forceinline__ int draw_tile(Word* tickets, int classes) {
   const int c = (int)(blockIdx.x % (unsigned)classes);
@@ -99,7 +107,7 @@ inline size_t radix_sort_groups(int n) { return (((size_t)n + kSortTile - 1) / k
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(256) radix_onesweep_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift,
                                                              const unsigned* __restrict__ digit_hist /*[class][.][256], at this pass*/, unsigned* __restrict__ state, int num_groups,
-                                                             unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+                                                             unsigned* __restrict__ keys_out, int* __restrict__ vals_out, int ticket_classes) {
   __shared__ int wave_count[4][256];   // elements of the digit in the wave's range; later: where the wave's elements of the digit start inside the tile
   __shared__ unsigned tile_count[256];
   __shared__ int out_delta[256];       // global position of the digit's first element of this tile - its position inside the tile
@@ -108,7 +116,10 @@ __global__ void __launch_bounds__(256) radix_onesweep_kernel(const unsigned* __r
   __shared__ int svals[kSortTile];
   __shared__ int tile_id;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) tile_id = draw_tile(state, kSortTicketClasses);  // a tile's predecessors have always been started
+  if (threadIdx.x == 0) {
+    tile_id = draw_tile(state, ticket_classes < 0 ? -ticket_classes : ticket_classes);  // a tile's predecessors have been started (one class: always; more: see draw_tile)
+    if (ticket_classes < 0 && tile_id == 0) __hip_atomic_store(state + kSortFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // test hook
+  }
   for (int k = threadIdx.x; k < 4 * 256; k += 256) (&wave_count[0][0])[k] = 0;
   tile_count[threadIdx.x] = 0;
   __syncthreads();
@@ -199,16 +210,25 @@ __global__ void __launch_bounds__(256) radix_onesweep_kernel(const unsigned* __r
     }
     // (b) elements with this digit in the tiles in front
     unsigned prefix = 0;
+    int polls = 0;  // (per thread, over all its waits)
     auto take = [&](int e, unsigned w) {
       const unsigned* src = entry_word(e);
       if (e < group) {
         while ((w >> 26) != (unsigned)kSortGroup) {  // a tile of that group has not added its counts yet
+          if (++polls > kSortSpinBound) {            // ... and may never: its workgroup cannot start while we hold the CU (see draw_tile). Give up, say so.
+            __hip_atomic_store(state + kSortFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
           w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         prefix += w & 0x3ffffffu;
       } else {
         while ((w >> 31) == 0u) {
+          if (++polls > kSortSpinBound) {
+            __hip_atomic_store(state + kSortFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
           w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -258,8 +278,10 @@ __global__ void __launch_bounds__(256) radix_onesweep_kernel(const unsigned* __r
     if (pos < tile_n) {
       const unsigned k = skeys[pos];
       const int out = out_delta[(k >> shift) & 255u] + pos;
-      keys_out[out] = k;
-      vals_out[out] = svals[pos];
+      if ((unsigned)out < (unsigned)n) {  // (always, unless a wait expired above and the prefix is incomplete: the pass is void then, but it must not store outside the arrays)
+        keys_out[out] = k;
+        vals_out[out] = svals[pos];
+      }
     }
   }
   GP_SORT_STAMP(tile, 7);  // stores issued
@@ -277,8 +299,10 @@ inline unsigned* radix_sort_hist(unsigned* state, int n, int key_bits) { return 
 // sorted pairs ended up.  n < 2^30.
 // state: radix_sort_state_words32(n, key_bits) 32-bit words; zeroed = the caller has zeroed them on `s` (a build zeroes all its states with one fill);
 // hist_ready = the caller has also counted the digits into radix_sort_hist(state, n, key_bits) (needs zeroed)
+// ticket_classes: kSortTicketClasses, or 1 for the form that cannot deadlock whatever order the device starts workgroups in (negative: test hook, see above).
+// The caller checks radix_sort_fault_words behind the sort (the builds let their last kernel carry the words to the host) and sorts again with one class if set.
 inline int radix_sort_pairs(unsigned* keys_a, int* vals_a, unsigned* keys_b, int* vals_b, int n, int key_bits, bool vals_iota, unsigned* state, bool zeroed, bool hist_ready,
-                            hipStream_t s, bool* result_in_b) {
+                            hipStream_t s, bool* result_in_b, int ticket_classes = kSortTicketClasses) {
   *result_in_b = false;
   if (n <= 0) return GP_OK;
   if (n >= (1 << 30) || key_bits > 8 * kSortMaxPasses) return fail(GP_ERROR_INVALID_ARGUMENT, "radix_sort_pairs: n must be below 2^30 and the key at most 32 bits");
@@ -296,12 +320,31 @@ inline int radix_sort_pairs(unsigned* keys_a, int* vals_a, unsigned* keys_b, int
     unsigned* kout = in_a ? keys_b : keys_a;
     int* vout = in_a ? vals_b : vals_a;
     hipLaunchKernelGGL(radix_onesweep_kernel<0>, dim3(tiles), dim3(256), 0, s, kin, vin, n, 8 * p, (const unsigned*)(hist + 256 * p), state + (size_t)p * radix_sort_pass_words(n),
-                       groups, kout, vout);
+                       groups, kout, vout, ticket_classes);
     GP_HIP(hipGetLastError());
     in_a = !in_a;
     first = false;
   }
   *result_in_b = !in_a;
+  return GP_OK;
+}
+
+// device side: OR of the passes' fault words (for the kernel that reports a build's results to the host)
+__device__ __forceinline__ unsigned radix_sort_faults(const unsigned* __restrict__ state, unsigned pass_words, int passes) {
+  unsigned f = 0;
+  for (int p = 0; p < passes; p++) f |= __hip_atomic_load(state + (size_t)p * pass_words + kSortFaultWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f;
+}
+// host side, synchronous (callers without such a kernel): 1 when some pass of the sort gave up a wait
+inline int radix_sort_fault(const unsigned* state, int n, int key_bits, hipStream_t s, bool* fault) {
+  *fault = false;
+  const int passes = (key_bits + 7) / 8;
+  for (int p = 0; p < passes; p++) {
+    unsigned w = 0;
+    GP_HIP(hipMemcpyAsync(&w, state + (size_t)p * radix_sort_pass_words(n) + kSortFaultWord, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    if (w) *fault = true;
+  }
   return GP_OK;
 }
 

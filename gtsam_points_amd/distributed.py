@@ -153,6 +153,10 @@ class ShardedLinearizer:
         self.exchange = "none"
 
     def _decide(self):
+        """Which exchange the passes run: decided ONCE, by all ranks together (a fallback taken by the rank that saw an exception alone would leave the
+        ranks issuing different collectives).  all_gather needs the same plan on every rank (MIN over the ranks' own checks) AND a backend that accepts the in-place
+        form: the form is probed here, once, and the ranks agree on the outcome (MIN again) before the first real pass."""
+        import torch
         import torch.distributed as dist
 
         if not dist.is_initialized():
@@ -161,14 +165,22 @@ class ShardedLinearizer:
         rank = dist.get_rank(self.group)
         self._exchange = world > 1 or self.always_exchange
         rows = self.end - self.begin
-        gather_ok = self._want == "all_gather" and rows * world == self.total and self.begin == rank * rows
+        gather_ok = self._want == "all_gather" and rows > 0 and rows * world == self.total and self.begin == rank * rows
         if self._exchange and self._want == "all_gather":
-            # every rank must take the same branch: agree on the plan (one tiny all-reduce, once)
-            import torch
 
-            flag = torch.tensor([1 if gather_ok else 0], dtype=torch.int32, device=self.stacked.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            gather_ok = bool(flag.item())
+            def agreed(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.stacked.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                return bool(flag.item())
+
+            gather_ok = agreed(gather_ok)
+            if gather_ok:  # (every rank is here, or none)
+                try:
+                    dist.all_gather_into_tensor(self.stacked, self.own_rows, group=self.group)  # the probe: the stack's contents are overwritten by the pass anyway
+                    accepted = True
+                except (RuntimeError, ValueError, NotImplementedError):  # an argument check that rejects overlapping buffers: nothing was issued
+                    accepted = False
+                gather_ok = agreed(accepted)
         self.exchange = ("all_gather" if gather_ok else "all_reduce") if self._exchange else "none"
         return self._exchange
 
@@ -182,13 +194,7 @@ class ShardedLinearizer:
             self.issue(poses_local, self.own_rows)
         if exchange:
             if self.exchange == "all_gather":
-                try:
-                    dist.all_gather_into_tensor(self.stacked, self.own_rows, group=self.group)  # in place: the input is this rank's slot of the output
-                except (RuntimeError, ValueError, NotImplementedError):
-                    # a backend that refuses the in-place form (an argument check, raised on every rank alike before anything is issued): the all-reduce from now on;
-                    # this pass is repeated, since the stack was not zeroed for it
-                    self.exchange = "all_reduce"
-                    return self._run(poses_local)
+                dist.all_gather_into_tensor(self.stacked, self.own_rows, group=self.group)  # in place: the input is this rank's slot of the output
             else:
                 dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked

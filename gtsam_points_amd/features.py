@@ -60,7 +60,12 @@ def estimate_covariances_gpu(frame: PointCloudGPU, k_neighbors=10, cell_size=0.0
     short = C.c_int(0)
     _capi.check(lib.gp_estimate_covariances_ex(frame.ptr(frame.points_gpu), frame.size(), int(k_neighbors), float(cell_size), C.c_void_p(covs.data_ptr()), C.byref(short),
                                                int(structure), C.c_void_p(counters.data_ptr()) if counters is not None else None, stream), "gp_estimate_covariances_ex")
+    # the old covariance tensor goes back to torch's caching allocator, which hands same-size blocks out again: a packed source mirror keyed on its address must
+    # not survive it, and factors that cached the pointer must re-read it
+    frame._forget_mirrors("covs")
     frame.covs_gpu = covs
+    frame._host.pop("covs", None)  # the host copy (if any) described the previous covariances
+    frame.generation += 1
     return short.value
 
 

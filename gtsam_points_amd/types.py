@@ -164,7 +164,9 @@ class PointCloudGPU(OffloadableGPU):
 
     @staticmethod
     def from_device(points_gpu, covs_gpu=None, intensities_gpu=None):
-        """Adopt float32 device tensors that are already in the reference layout."""
+        """Adopt float32 device tensors that are already in the reference layout.
+        Contract: the library treats adopted arrays as IMMUTABLE while factors use them (it may keep a packed private copy of (points, covs), keyed on their
+        addresses: DESIGN 3). A caller that rewrites an adopted tensor in place calls `contents_changed()` afterwards."""
         pc = PointCloudGPU(device=str(points_gpu.device))
         pc.points_gpu = points_gpu
         pc.covs_gpu = covs_gpu
@@ -172,6 +174,13 @@ class PointCloudGPU(OffloadableGPU):
         pc.num_points = int(points_gpu.shape[0])
         pc.generation += 1
         return pc
+
+    def contents_changed(self, attrs=("points", "covs")):
+        """The caller rewrote device arrays of this cloud in place (same addresses, new contents): drop the library's packed mirrors of them and make every factor
+        re-read the cloud (generation bump) -- gp_source_mirror_invalidate, include/gtsam_points_hip.h."""
+        for a in attrs:
+            self._forget_mirrors(a)
+        self.generation += 1
 
     def add_intensities(self, intensities):
         self.intensities_gpu = self._upload(intensities if self._is_tensor(intensities) else np.asarray(intensities).reshape(-1, 1), 1)

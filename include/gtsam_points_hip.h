@@ -518,6 +518,15 @@ int gp_debug_expand_rigid(const double sums[32], const double pose[16], gp_linea
  * to its workgroups for a factor of n points and a GP_TUNE_BALANCE value, in tile-list order (XCD-major); *num_tiles = workgroups of the launch */
 int gp_debug_stream_plan(int n, int skew_permille, const int* xcd_weights_permille /* [8] or NULL = the library's table */, int capacity, int* begin, int* count,
                          int* num_tiles);
+/* host-side check hook (runs without a device): for an explicit shard assignment, *rows_per_shard = rows every rank contributes to the in-place ncclAllGather of a
+ * multi-device pass (0: the plan does not allow it -- unequal or non-contiguous shards -- and the pass all-reduces), and send_offset_doubles[k] = where shard k's send
+ * buffer starts inside the [F x width] stack, in doubles.  Runs the functions gp_vgicp_multi_batch_* itself uses. */
+int gp_debug_multi_gather_plan(const int* shard_of_factor, int num_factors, int num_shards, int width, int64_t* rows_per_shard, int64_t* send_offset_doubles);
+/* test hooks for the structure builds' sort fallback (gp_sort.hpp / gp_binning.hip; thread-local, no device state): the next `count` builds of this thread (voxel-map
+ * insert, k-NN structure) see their first radix sort report "a tile waited for a workgroup that was never started" and must rebuild through the one-class sort;
+ * gp_debug_sort_fallbacks = how many builds of this thread did so far. */
+int gp_debug_inject_sort_fault(int count);
+int gp_debug_sort_fallbacks(void);
 /* timeline hook (measurement): per-workgroup phase timestamps (s_memtime) of THIS batch's single-factor linearise into dev_buffer
  * ([2048][16] uint64: slots 0-7 phases, 8 HW_ID, 9 XCC_ID, 10 / 11 start / end on the device-wide clock; row 2047: the finalize kernel of the
  * synchronous call); NULL disables */

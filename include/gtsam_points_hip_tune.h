@@ -24,6 +24,11 @@ int gp_debug_calibration_stream(const float* points_dev, const float* covs_dev, 
 /* test hook for the stable radix sort behind the structure builds (gp_sort.hpp; tests/test_sort_gpu.py): argsort of n keys by their low key_bits bits.
  * keys_dev is overwritten; sorted keys -> keys_out_dev, original indices -> vals_out_dev.  Synchronous. */
 int gp_debug_sort_pairs(unsigned* keys_dev, int n, int key_bits, unsigned* keys_out_dev, int* vals_out_dev, gp_stream_t stream);
+/* the same with a chosen number of ticket classes (gp_sort.hpp: 32 = fast path resting on in-order workgroup start, 1 = the form that needs no such order, negative
+ * = test hook: tile 0 raises the fault word); *fault = 1 when a pass gave up a wait (output void). */
+int gp_debug_sort_pairs_ex(unsigned* keys_dev, int n, int key_bits, unsigned* keys_out_dev, int* vals_out_dev, int ticket_classes, int* fault, gp_stream_t stream);
+/* `workgroups` workgroups of 256 threads spinning for `microseconds` on `stream` (asynchronous): holds the CUs while something else runs on another stream */
+int gp_debug_occupy(double microseconds, int workgroups, gp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -168,3 +168,33 @@ def test_stream_plan_partitions_every_point_once():
                     rounds = [chunks[x, r : r + 32] for r in range(0, per, 32)]
                     for a_, bb in zip(rounds, rounds[1:]):
                         assert a_.min() >= bb.max() - 1, (n, skew, x)
+
+
+def test_gather_send_offsets_follow_the_plan_not_the_container():
+    """the in-place all-gather's send pointer of shard k must be k * rows * width doubles into the stack for EVERY shard (the shards live in a
+    std::deque: pointer differences between its elements mean nothing). gp_debug_multi_gather_plan runs the pass's own offset / plan functions on the host."""
+    import ctypes as C
+
+    import numpy as np
+
+    from gtsam_points_amd import _capi
+
+    lib = _capi.load()
+    for shards, rows in [(3, 5), (8, 512), (8, 1), (5, 7), (64, 3)]:
+        F = shards * rows
+        assign = np.repeat(np.arange(shards, dtype=np.int32), rows)
+        for width in (122, 1):
+            got_rows = C.c_int64(-1)
+            off = np.full(shards, -1, np.int64)
+            assert lib.gp_debug_multi_gather_plan(assign.ctypes.data, F, shards, width, C.byref(got_rows), off.ctypes.data) == 0
+            assert got_rows.value == rows
+            assert (off == np.arange(shards, dtype=np.int64) * rows * width).all(), (shards, rows, width, off)
+    # plans that must NOT gather: unequal shards, interleaved shards, shards out of rank order, more shards than factors
+    for assign, shards in [([0, 0, 0, 1, 1, 2], 3), ([0, 1, 2, 0, 1, 2], 3), ([1, 1, 0, 0, 2, 2], 3), ([0, 1], 3)]:
+        a = np.asarray(assign, np.int32)
+        got_rows = C.c_int64(-1)
+        off = np.zeros(shards, np.int64)
+        assert lib.gp_debug_multi_gather_plan(a.ctypes.data, len(assign), shards, 122, C.byref(got_rows), off.ctypes.data) == 0
+        assert got_rows.value == 0, assign
+    got_rows = C.c_int64()
+    assert lib.gp_debug_multi_gather_plan(np.asarray([0, 3], np.int32).ctypes.data, 2, 3, 122, C.byref(got_rows), np.zeros(3, np.int64).ctypes.data) != 0

@@ -133,7 +133,7 @@ def _worker_gather_refused(rank, world, port, ret):
     dist.all_gather_into_tensor = refuse
     try:
         a = lin.linearize(None).clone()
-        assert lin.exchange == "all_reduce"  # decided once; the pass was repeated with the zeroed stack
+        assert lin.exchange == "all_reduce"  # decided once, by all ranks together, before the first pass (the probe was refused)
         b = lin.linearize(None)
         assert torch.equal(a, b)
     finally:
@@ -177,3 +177,56 @@ def test_shard_plan_is_optimal_and_leaves_no_shard_empty():
     assert [e - b for b, e in partition_factors([32768] * 4096, 8)] == [512] * 8
     three = [e - b for b, e in partition_factors([32768] * 4096, 3)]
     assert max(three) == 1366 and sum(three) == 4096 and min(three) >= 1364
+
+
+def _c4_records(ids):
+    """synthetic stand-in for a shard's records: row f holds f + c / 1000 in column c -- a wrong slot, a row moved twice or a row left zero all show"""
+    ids = np.asarray(list(ids), dtype=np.float64)
+    return ids[:, None] + np.arange(RECORD_DOUBLES, dtype=np.float64)[None, :] / 1000.0 if len(ids) else np.zeros((0, RECORD_DOUBLES))
+
+
+def _worker_c4(rank, world, port, total, want, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))  # a hung rank fails the test, it does not eat the lease
+    begin, end = partition_factors([32768] * total, world)[rank]
+
+    def issue(_poses, view):
+        view.copy_(torch.from_numpy(_c4_records(range(begin, end))))
+
+    lin = ShardedLinearizer(total, (begin, end), "cpu", issue, exchange=want)
+    a = lin.linearize(None).clone()
+    b = lin.linearize(None)
+    assert torch.equal(a, b)
+    ret[rank] = (lin.exchange, a.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,want,expect", [
+    (4, 4096, "all_gather", "all_gather"),   # the C4 plan on 4 ranks: 1024 contiguous rows each
+    (8, 4096, "all_gather", "all_gather"),   # ... on 8: 512 each (BASELINE configs[3])
+    (8, 4099, "all_gather", "all_reduce"),   # a factor count the ranks do not divide: every rank falls back together
+    (4, 3, "all_gather", "all_reduce"),      # fewer factors than ranks: an empty shard takes part in the collective
+    (8, 4096, "all_reduce", "all_reduce"),
+])
+def test_c4_shaped_plan_gloo_world4_and_world8(world, total, want, expect):
+    """the C4-shaped exchange ([F x 122] f64 stack, gp_shard_plan's contiguous ranges) over 4 and 8 ranks, incl. a non-divisible factor count and
+    an empty shard: every rank ends with every row, all ranks agree on the exchange they ran (loop being sharded: cuda/nonlinear_factor_set_gpu.cpp:64-139)"""
+    port = 35500 + (os.getpid() * 7 + world * 131 + total) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_c4, args=(world, port, total, want, ret), nprocs=world, join=True)
+    ref = _c4_records(range(total))
+    for r in range(world):
+        assert ret[r][0] == expect, (r, ret[r][0])
+        assert np.array_equal(ret[r][1], ref), r
+
+
+def test_zero_factors_is_not_a_gather():
+    """total_factors == 0 passes `rows * world == total` with own_rows None; the gather check requires rows > 0 (single process, no group: no exchange at all)"""
+    lin = ShardedLinearizer(0, (0, 0), "cpu", lambda _p, _v: None, exchange="all_gather")
+    out = lin.linearize(None)
+    assert out.shape == (0, RECORD_DOUBLES) and lin.exchange == "none"

@@ -236,3 +236,44 @@ def test_in_argument_launch_ignores_xcd_chunk(gpu, kitti00):
             recs.append(out.copy())
         assert np.array_equal(recs[0], recs[1]) and np.array_equal(recs[0], recs[2]), it
     lib.gp_vgicp_batch_destroy(b)
+
+
+def test_reestimated_covariances_do_not_join_a_stale_mirror(gpu, kitti00):
+    """estimate_covariances_gpu replaces frame.covs_gpu; torch's caching allocator hands the freed block out again at the same address, so a factor
+    created afterwards could join the packed mirror of the OLD covariances. The frame forgets its mirrors and bumps its generation: old and new factor both
+    linearise with the new covariances; PointCloudGPU.contents_changed() does the same for tensors rewritten in place."""
+    import torch
+
+    from gtsam_points_amd.features import estimate_covariances_gpu
+
+    tgt = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"])
+    vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+    vm.insert(tgt)
+    delta = expmap([0.01, -0.02, 0.015, 0.10, -0.05, 0.03])
+    src = gpu.PointCloudGPU(kitti00["source_points"], kitti00["source_covs"])
+    f_old = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    L_old = _lin(gpu, f_old, delta)  # builds the mirror of (points, k = 10 covariances)
+    gen = src.generation
+    for k in (5, 20):  # same-size tensors: the allocator recycles the block that was just freed
+        estimate_covariances_gpu(src, k_neighbors=k)
+    torch.cuda.synchronize()
+    assert src.generation > gen
+    covs_new = src.covs_gpu.cpu().numpy()
+    f_new = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    L_new = _lin(gpu, f_new, delta)
+    f_plain = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src).set_tuning(MIRROR, 0)
+    L_plain = _lin(gpu, f_plain, delta)
+    for k in BLOCKS:
+        assert np.array_equal(getattr(L_new, k), getattr(L_plain, k)), k
+    assert not np.array_equal(L_new.H_source, L_old.H_source)
+    om = oracle.OracleVoxelMap(0.5)
+    om.insert(kitti00["target_points"], kitti00["target_covs"])
+    Lo = oracle.OracleVGICPFactor(om, kitti00["source_points"], covs_new, 2).linearize(delta)
+    assert_linearized_close(L_new, Lo, PARITY_TOL, "re-estimated covariances")
+    # in place, through the wrapper's own hook
+    src.covs_gpu.copy_(torch.from_numpy(np.ascontiguousarray(kitti00["source_covs"].reshape(-1, 9))).to(src.covs_gpu.device))
+    torch.cuda.synchronize()
+    src.contents_changed()
+    L_back = _lin(gpu, gpu.IntegratedVGICPFactorGPU(0, 1, vm, src), delta)
+    for k in BLOCKS:
+        assert np.array_equal(getattr(L_back, k), getattr(L_old, k)), k

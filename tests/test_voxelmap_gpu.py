@@ -263,6 +263,43 @@ def test_binned_build_is_bit_reproducible_and_matches_the_hashed_build(gpu, kitt
     assert np.array_equal(da["intensities"], h.download()["intensities"][idx])
 
 
+def test_build_survives_a_sort_that_gives_up(gpu, kitti00):
+    """the builds' radix sort waits on tiles with smaller indices, which rests on the device starting workgroups in blockIdx order; a sort that finds a
+    predecessor missing for too long raises a fault word instead of spinning for ever, and the build runs again through the one-class sort.  The test hook makes the
+    first sort of the next build report exactly that: the map and the k-NN covariances built through the fallback equal the ordinary ones bit for bit."""
+    import torch
+
+    from gtsam_points_amd.features import estimate_covariances_gpu
+
+    lib = gpu.load()
+    cloud = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"])
+
+    def build():
+        vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+        vm.insert(cloud)
+        return vm
+
+    a = build()
+    before = lib.gp_debug_sort_fallbacks()
+    gpu._capi.check(lib.gp_debug_inject_sort_fault(1), "inject")
+    b = build()
+    assert lib.gp_debug_sort_fallbacks() == before + 1
+    c = build()  # the hook is spent
+    assert lib.gp_debug_sort_fallbacks() == before + 1
+    ref = a.download_f64()
+    for other in (b, c):
+        for x, y in zip(ref, other.download_f64()):
+            assert np.array_equal(x, y)
+    q = gpu.PointCloudGPU(kitti00["source_points"])
+    estimate_covariances_gpu(q, k_neighbors=10)
+    want = q.covs_gpu.clone()
+    gpu._capi.check(lib.gp_debug_inject_sort_fault(1), "inject")
+    estimate_covariances_gpu(q, k_neighbors=10)
+    torch.cuda.synchronize()
+    assert lib.gp_debug_sort_fallbacks() == before + 2
+    assert torch.equal(want, q.covs_gpu)
+
+
 def test_non_finite_points_are_skipped(gpu, kitti00):
     """LiDAR clouds contain NaN / inf returns: they belong to no voxel (the reference floors them into undefined coordinates)"""
     p = kitti00["target_points"].copy()
