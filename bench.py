@@ -49,6 +49,32 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
 
 
+class PhaseGuard:
+    """Time-box of a phase (VERDICT r04 #5d): a rank that hangs in a collective or a rendezvous must fail in about two minutes, not sit on the lease.  A timer thread
+    that finds the phase still open says which one on stderr and ends the PROCESS (os._exit: a hung RCCL call cannot be interrupted from Python); torchrun then tears
+    the other ranks down."""
+
+    def __init__(self, seconds, name):
+        self.seconds, self.name, self._timer = float(seconds), name, None
+
+    def __enter__(self):
+        import threading
+
+        def expire():
+            sys.stderr.write(json.dumps(dict(error=f"bench.py: phase '{self.name}' exceeded its {self.seconds:.0f} s time box on rank {os.environ.get('RANK', '0')}; aborting")) + "\n")
+            sys.stderr.flush()
+            os._exit(124)
+
+        self._timer = threading.Timer(self.seconds, expire)
+        self._timer.daemon = True
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._timer.cancel()
+        return False
+
+
 KERNEL_NAMES = {
     12: "vgicp_stream_kernel<linearise, non-temporal source stream, in-argument descriptor> (gp_vgicp_stream.hpp): 1024 workgroups, balanced chunk plan",
     8: "vgicp_pipeline_kernel<look-ahead> (gp_vgicp_tile.hpp)",
@@ -89,7 +115,61 @@ def _load_traffic():
         return None, None
 
 
-def run_c4_inlib(lib, gpa, _capi, synthetic, torch, home_device, steps):
+def measure_traffic(args):
+    """roofline.traffic measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md's HBM section prescribes) over a small child run of this file (--pmc-child: 7 fused steps of the same workload + a calibration stream of known
+    48 N bytes in the tile kernel's own access pattern), read side scaled on the calibration stream (rocprofv3's FETCH_SIZE prices a 128-B request at 64 B on gfx950:
+    DESIGN.md 6).  Never raises; returns {} / {"error": ...} when rocprofv3 is absent or a pass fails, and the committed figure is quoted instead."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return dict(error="rocprofv3 not on PATH")
+    means = {}
+    try:
+        t0 = time.time()
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(prefix="gp_pmc_", dir="/tmp") as tmp:
+                cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                       "--source-points", str(args.source_points), "--target-points", str(args.target_points), "--resolution", str(args.resolution)]
+                env = dict(os.environ, TMPDIR="/tmp")
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd="/tmp", env=env)
+                acc = defaultdict(list)
+                for dirpath, _dirs, files in os.walk(tmp):
+                    for fn in files:
+                        if fn.endswith("counter_collection.csv"):
+                            with open(os.path.join(dirpath, fn)) as f:
+                                for row in csv.DictReader(f):
+                                    if row.get("Counter_Name") == ctr:
+                                        acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+                if not acc:
+                    return dict(error=f"rocprofv3 --pmc {ctr}: no counter rows (exit code {p.returncode}): {p.stderr[-300:]}")
+                means[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+        def find(d, needle):
+            for k, v in d.items():
+                if needle in k:
+                    return v
+            return None
+
+        calib, tile_f, tile_w = find(means["FETCH_SIZE"], "calibration_stream_kernel"), find(means["FETCH_SIZE"], "vgicp_stream_kernel"), find(means["WRITE_SIZE"], "vgicp_stream_kernel")
+        if not calib or not tile_f:
+            return dict(error="the profiled child ran no calibration / stream kernel")
+        scale = 48.0 * args.source_points / (calib[0] * 1024.0)
+        return dict(tile_kernel_hbm_bytes_per_launch=int(tile_f[0] * 1024.0 * scale + (tile_w[0] if tile_w else 0.0) * 1024.0), fetch_size_kib=round(tile_f[0], 1),
+                    write_size_kib=round(tile_w[0], 1) if tile_w else None, launches=tile_f[1], calibration_fetch_kib=round(calib[0], 1), fetch_scale=round(scale, 4),
+                    seconds=round(time.time() - t0, 1),
+                    source="measured in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only) over a child run of 7 fused steps of the same "
+                           "workload; read side scaled on a calibration stream of known bytes (fetch_scale); per launch of vgicp_stream_kernel")
+    except Exception as exc:
+        return dict(error=f"{type(exc).__name__}: {exc}")
+
+
+def run_c4_inlib(lib, gpa, _capi, synthetic, torch, home_device, steps, max_devices=0):
     """The same 4096-factor configuration through the IN-LIBRARY sharded path a C++ optimizer process would use
     (gp_vgicp_multi_batch_*: ONE process drives every visible device, ncclCommInitAll, one ncclAllReduce of the [4096 x 122] f64
     stack per linearise; replaces the per-factor loop of src/gtsam_points/cuda/nonlinear_factor_set_gpu.cpp:64-139).  Only run
@@ -97,6 +177,8 @@ def run_c4_inlib(lib, gpa, _capi, synthetic, torch, home_device, steps):
     from gtsam_points_amd.distributed import MultiDeviceBatch, partition_factors
 
     ndev = torch.cuda.device_count()
+    if max_devices > 0:
+        ndev = min(ndev, max_devices)
     try:
         t_setup = time.time()
         pairs = synthetic.c4_factor_pairs()
@@ -200,37 +282,42 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(3):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.c4_steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # the exchange alone, both forms: zeroing + all-reduce of the stacked records, and the in-place all-gather (when the plan qualifies); HIP events on the stream they are issued on
-    ar_ms, ag_ms = 0.0, None
-    if dist_on:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist_on:  # set-up is host work of uneven length (casting the submaps): meet first, so that the box below times collectives only
+        with PhaseGuard(600.0, "c4 set-up rendezvous"):
+            dist.barrier()
+    guard = PhaseGuard(args.phase_seconds if dist_on else 900.0, "c4 steps and exchange")
+    with guard:
+        for _ in range(3):
+            step()
         barrier()
-        e0.record(stream)
-        for _ in range(10):
-            sharded.stacked.zero_()
-            dist.all_reduce(sharded.stacked, op=dist.ReduceOp.SUM)
-        e1.record(stream)
-        e1.synchronize()
-        ar_ms = e0.elapsed_time(e1) / 10
-        if sharded.exchange == "all_gather":
-            try:
-                barrier()
-                e0.record(stream)
-                for _ in range(10):
-                    dist.all_gather_into_tensor(sharded.stacked, sharded.own_rows)
-                e1.record(stream)
-                e1.synchronize()
-                ag_ms = e0.elapsed_time(e1) / 10
-            except (RuntimeError, ValueError, NotImplementedError):
-                ag_ms = None
+        t0 = time.perf_counter()
+        for _ in range(args.c4_steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # the exchange alone, both forms: zeroing + all-reduce of the stacked records, and the in-place all-gather (when the plan qualifies); HIP events on the stream they are issued on
+        ar_ms, ag_ms = 0.0, None
+        if dist_on:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            e0.record(stream)
+            for _ in range(10):
+                sharded.stacked.zero_()
+                dist.all_reduce(sharded.stacked, op=dist.ReduceOp.SUM)
+            e1.record(stream)
+            e1.synchronize()
+            ar_ms = e0.elapsed_time(e1) / 10
+            if sharded.exchange == "all_gather":
+                try:
+                    barrier()
+                    e0.record(stream)
+                    for _ in range(10):
+                        dist.all_gather_into_tensor(sharded.stacked, sharded.own_rows)
+                    e1.record(stream)
+                    e1.synchronize()
+                    ag_ms = e0.elapsed_time(e1) / 10
+                except (RuntimeError, ValueError, NotImplementedError):
+                    ag_ms = None
     ms_total, ms_main, ms_fin = C.c_float(), C.c_float(), C.c_float()
     alg = 0
     if n_local:
@@ -284,6 +371,44 @@ def run_c4(args, lib, gpa, _capi, synthetic, torch, dist, rank, world, device, s
 
 
 BLOCKS = ["H_target", "H_source", "H_target_source", "b_target", "b_source"]
+
+
+def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, truth, values0, sptr, device, cores, kind):
+    """configs.lm_*: the reference's LM cadence (bench_lm.py; levenberg_marquardt_ext.cpp:107-143,188-392) over a graph of VGICP factors -- per iteration host to host, by
+    phase, on the GPU path (batched linearise, records stay in HBM, block-sparse LL^T on the device; and the same with a host-side numpy solve) and over the checker's CPU
+    factors (the reference's own IntegratedVGICPFactor when oracle/_ref is built) as cpu_baseline.  truth None: the CPU run's result is the reference the GPU run is held to."""
+    import bench_lm
+
+    cg = bench_lm.CpuGraph(cpu_factors, pairs, num_poses, fixed=0)
+    res_cpu = bench_lm.run_lm(cg, values0, max_iterations=30)
+    gate_ref = truth if truth is not None else res_cpu["values"]
+    cpu = bench_lm.summarize(res_cpu, cg, gate_ref, "cpu")
+    out = dict(workload=workload, cadence="linearize(values) -> [solve (A + lambda I) dx = b -> retract -> error(new values) on the linearisation's correspondences] until accepted; "
+               "lambda 1e-5, x10 / /10, minModelFidelity 1e-3, relativeErrorTol 1e-5 (GTSAM defaults; levenberg_marquardt_ext.cpp:188-392)",
+               gate="max over poses, relative to the fixed pose: rotation < 0.015 rad, translation < 0.15 m (test_matching_cost_factors.cpp:227) against "
+               + ("the generator's ground truth" if truth is not None else "the CPU run's result (real scans: no ground truth)"))
+    for solver in ("device", "host"):
+        gg = bench_lm.GpuGraph(gpa, gpu_factors, pairs, num_poses, fixed=0, solver=solver, stream=sptr, device=device)
+        bench_lm.run_lm(gg, values0, max_iterations=30)  # warm-up: first-use table builds, allocations
+        best = None
+        for _ in range(3):
+            r = bench_lm.run_lm(gg, values0, max_iterations=30)
+            if best is None or r["seconds"] < best["seconds"]:
+                best = r
+        obj = bench_lm.summarize(best, gg, gate_ref, f"gpu, {solver} solve")
+        gg.sync_phases = True
+        split = bench_lm.summarize(bench_lm.run_lm(gg, values0, max_iterations=30), gg, gate_ref, "split")
+        obj["ms_per_iteration_by_phase"] = split["ms_per_iteration_by_phase"]
+        obj["dominant_phase"] = split["dominant_phase"]
+        obj["phase_note"] = ("phases from a run that waits for the linearise before the solve is issued (the un-synchronised run queues the solver's kernels behind it: its "
+                             "ms_per_iteration is the figure of merit); glue = numpy pose algebra of the harness (relative poses, retract), not library time")
+        obj["pose_vs_cpu_run"] = dict(zip(("rotation_rad", "translation_m"), [round(max(x), 6) for x in zip(*[bench_lm.pose_error(best["values"][k], res_cpu["values"][k]) for k in range(num_poses)])]))
+        gg.close()
+        out["gpu_device_solve" if solver == "device" else "gpu_host_solve"] = obj
+    cpu.update(cores=cores, kind=kind, sample="the whole loop once: every factor linearised / evaluated in turn with all host threads, numpy dense solve")
+    out["cpu_baseline"] = cpu
+    out["speedup_per_iteration"] = round(cpu["ms_per_iteration"] / out["gpu_device_solve"]["ms_per_iteration"], 1)
+    return out
 
 
 def _parity(L, Lo):
@@ -368,6 +493,12 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
             cpu_baseline=dict(value=round(npts / cpu_ms * 1e3, 1), unit="point-correspondences/s", cores=cores, kind=kind, ms=round(cpu_ms, 3), ms_1thread=round(cpu1_ms, 3),
                               sample="10 full linearize() passes of the same factor (the reference's default is 1 thread: ms_1thread)"),
             parity_vs_reference=_parity(gpa.LinearizedSystem6.from_doubles(recs[0]), Lo), inlier_fraction=round(float(recs[0, 0]) / npts, 4))
+        if not args.no_lm:
+            try:
+                out["lm_c1"] = run_lm_config("BASELINE configs[0] as an optimisation: scan 000001 registered to the map of scan 000000 from the identity (one factor, one free pose)",
+                                             gpa, [f], [fo], [(0, 1)], 2, None, np.stack([np.eye(4), np.eye(4)]), sptr, device, cores, kind)
+            except Exception as exc:  # the headline must survive an optional leg
+                out["lm_c1"] = dict(error=f"{type(exc).__name__}: {exc}")
         del f, vm, tgt, src
 
     # ---- C3: 256-factor submap graph, ONE batched call ----
@@ -409,6 +540,24 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
                           sample=f"{len(sample)} of the 256 factors (every 8th), one linearize() each after a warm-up, {cores} threads per factor, sequential over factors "
                                  "as graph_.linearize does; scaled x8"),
         parity_vs_reference_max=worst, parity_factors_checked=len(sample), inlier_fraction=round(float(recs[:, 0].sum()) / npts, 4), setup_s=round(t_setup, 1))
+    if not args.no_lm:
+        try:
+            n_sub = len(g["clouds"])
+            for t in range(n_sub):
+                if t not in omaps and any(p[0] == t for p in g["pairs"]):
+                    omaps[t] = VoxelMap(1.0)
+                    omaps[t].insert(*g["clouds"][t])
+            cpu_factors = [VGICP(omaps[t], g["clouds"][s_][0], g["clouds"][s_][1], cores) for t, s_ in g["pairs"]]
+            truth = np.stack(g["stations"][:n_sub])
+            import bench_lm
+
+            v0 = truth @ bench_lm.expmap_many(np.random.default_rng(8191).uniform(-0.1, 0.1, (n_sub, 6)))  # ground truth o Expmap(U(-0.1, 0.1)^6), seed 8191: the reference tests' noise
+            v0[0] = truth[0]
+            out["lm_c3"] = run_lm_config("BASELINE configs[2] as an optimisation: the 256-factor / 64-submap graph from ground truth o Expmap(U(-0.1, 0.1)^6) (seed 8191), pose 0 held",
+                                         gpa, factors, cpu_factors, g["pairs"], n_sub, truth, v0, sptr, device, cores, kind)
+            del cpu_factors
+        except Exception as exc:
+            out["lm_c3"] = dict(error=f"{type(exc).__name__}: {exc}")
     del factors, maps, clouds
 
     # ---- C5: k-NN covariance estimation (k = 10) + IntegratedGICPFactor linearise, 1 M points ----
@@ -564,6 +713,12 @@ def main():
                     help="untimed: run the step for this long before the W warm-up steps, so that the timed steps see the device's settled power state (0 = off)")
     ap.add_argument("--no-big-source", action="store_true", help="skip the 8 M-point source (beyond the Infinity Cache) object")
     ap.add_argument("--no-mirror", action="store_true", help="A/B: stream the caller's 12 + 36 B per point instead of the packed 36-B mirror (GP_TUNE_SOURCE_MIRROR 0)")
+    ap.add_argument("--phase-seconds", type=float, default=120.0, help="N > 1: time box of every distributed phase (rendezvous, warm-up, timed steps, c4): a hung rank ends the job")
+    ap.add_argument("--no-cold", action="store_true", help="skip the ms_per_step_cold leg (the K timed steps without the device wake-up in front: round 3's protocol)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (rocprofv3 --pmc passes of a small child run); the committed figure is quoted instead")
+    ap.add_argument("--no-lm", action="store_true", help="skip configs.lm_c3 / lm_c1 (one Levenberg-Marquardt loop per graph, per-iteration cost by phase)")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) the small run the --pmc passes profile: 5 fused steps + the calibration stream, no output line")
+    ap.add_argument("--inlib-devices", type=int, default=0, help="(internal) devices the --c4-inlib-only leg drives (0 = all visible)")
     args = ap.parse_args()
 
     import torch
@@ -584,7 +739,7 @@ def main():
         torch.cuda.set_device(0)
         lib = gpa.load()
         _capi.check(lib.gp_set_device(0), "gp_set_device")
-        print(json.dumps(run_c4_inlib(lib, gpa, _capi, synthetic, torch, torch.device("cuda:0"), max(args.c4_steps // 3, 5))), flush=True)
+        print(json.dumps(run_c4_inlib(lib, gpa, _capi, synthetic, torch, torch.device("cuda:0"), max(args.c4_steps // 3, 5), args.inlib_devices)), flush=True)
         return
     dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node; lets a 1-GPU box rehearse N > 1
     torch.cuda.set_device(dev_index)
@@ -596,11 +751,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        import datetime
+
         backend = os.environ.get("GP_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; "gloo" only for the 1-GPU rehearsal
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        box = datetime.timedelta(seconds=args.phase_seconds)  # the collectives' own time-out (the watchdog aborts the process); PhaseGuard is the belt to these braces
+        with PhaseGuard(args.phase_seconds, "process group rendezvous"):
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=box)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=box)
 
     import gtsam_points_amd as gpa
     from gtsam_points_amd import _capi, synthetic
@@ -670,38 +829,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:  # the run the --pmc passes profile (measure_traffic): a few fused steps + the calibration stream of known bytes, nothing else
+        for _ in range(7):
+            step()
+        barrier()
+        _capi.check(_capi.load_tune().gp_debug_calibration_stream(src.ptr(src.points_gpu), src.ptr(src.covs_gpu), args.source_points, 5, C.c_void_p(stream.cuda_stream)), "calibration")
+        torch.cuda.synchronize()
+        lib.gp_vgicp_batch_destroy(batch)
+        return None
+
+    def timed_steps(label):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
+        with PhaseGuard(args.phase_seconds if dist_on else 600.0, label):
+            for _ in range(args.warmup):
+                step()
+            barrier()
+            lib.gp_vgicp_batch_device_times(batch, 1, None, None, None)  # reset: the kernel's own time stamps of the timed steps only
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el = time.perf_counter() - t0
+            n_, su_, ku_ = C.c_double(), C.c_double(), C.c_double()
+            lib.gp_vgicp_batch_device_times(batch, 0, C.byref(n_), C.byref(su_), C.byref(ku_))
+            if dist_on:
+                te = torch.tensor([el], dtype=torch.float64, device=device)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                el = float(te.item())
+        return el, n_, su_, ku_
+
+    # ms_per_step_cold (VERDICT r04 #7): the same W + K protocol with NOTHING in front -- the device as seconds of host-side set-up left it, round 3's protocol --
+    # so that rounds stay comparable whatever the wake-up below does
+    cold = None
+    if not args.no_cold:
+        el_c, n_c, su_c, ku_c = timed_steps("timed steps (cold)")
+        cold = dict(ms_per_step=round(el_c / args.steps * 1e3, 5), stream_us=round(su_c.value, 3) if n_c.value >= args.steps else None,
+                    fused_kernel_us=round(ku_c.value, 3) if n_c.value >= args.steps else None)
     # device wake-up (untimed, before the W warm-up steps): seconds of host-side set-up leave the device in a low power state, and it takes ~10 ms of work before the
     # step settles -- scripts/r04_warm.py: 11.6-11.9 us for the first 400-600 steps behind 2 s of idle, 10.9-11.0 us from then on (profiles/r04_warm.jsonl).  An optimizer
     # loop runs in the settled state; the same synchronous step is run for --device-warmup-ms first
     t_wake, wake_steps = time.perf_counter(), 0
-    if dist_on:
-        # a step holds a collective: every rank must run the SAME number of them -- a count, not a clock (~60 us per N > 1 step)
-        for _ in range(int(args.device_warmup_ms * 1e3 / 60.0)):
-            step()
-            wake_steps += 1
-            if wake_steps % 25 == 0:
-                torch.cuda.synchronize()
-    else:
-        while (time.perf_counter() - t_wake) * 1e3 < args.device_warmup_ms:
-            step()
-            wake_steps += 1
-            if wake_steps % 25 == 0:
-                torch.cuda.synchronize()  # (the timed region is bracketed by device synchronisations: the wake-up runs the same pattern)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    dev_steps, dev_stream_us, dev_kernel_us = C.c_double(), C.c_double(), C.c_double()
-    lib.gp_vgicp_batch_device_times(batch, 1, None, None, None)  # reset: the kernel's own time stamps of the timed steps only
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.gp_vgicp_batch_device_times(batch, 0, C.byref(dev_steps), C.byref(dev_stream_us), C.byref(dev_kernel_us))
-    if dist_on:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    with PhaseGuard(args.phase_seconds if dist_on else 600.0, "device wake-up"):
+        if dist_on:
+            # a step holds a collective: every rank must run the SAME number of them -- a count, not a clock (~60 us per N > 1 step)
+            for _ in range(int(args.device_warmup_ms * 1e3 / 60.0)):
+                step()
+                wake_steps += 1
+                if wake_steps % 25 == 0:
+                    torch.cuda.synchronize()
+        else:
+            while (time.perf_counter() - t_wake) * 1e3 < args.device_warmup_ms:
+                step()
+                wake_steps += 1
+                if wake_steps % 25 == 0:
+                    torch.cuda.synchronize()  # (the timed region is bracketed by device synchronisations: the wake-up runs the same pattern)
+    elapsed, dev_steps, dev_stream_us, dev_kernel_us = timed_steps("timed steps")
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.source_points * args.steps / elapsed
 
@@ -714,13 +896,25 @@ def main():
     actual_bytes = int(lib.gp_vgicp_batch_actual_bytes(batch))
     mirrored = C.c_int(-1)
     lib.gp_vgicp_batch_get_tuning(batch, _capi.GP_TUNE_EFFECTIVE_MIRROR, C.byref(mirrored))
-    in_step = dev_steps.value >= args.steps and dev_stream_us.value > 0
-    kernel_ms = dev_stream_us.value * 1e-3 if in_step else ms_main.value
+    in_step = dev_steps.value >= args.steps and dev_stream_us.value > 0 and dev_kernel_us.value > 0
+    # `frac` is quoted on the WHOLE kernel the step dispatches -- first workgroup started .. the last part's sums on their way to the host, by the
+    # kernel's own 100 MHz stamps over the K timed steps -- not on its streaming slice (kept as frac_streaming)
+    streaming_ms = dev_stream_us.value * 1e-3 if in_step else ms_main.value
+    kernel_ms = dev_kernel_us.value * 1e-3 if in_step else ms_main.value
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     split = _load_split()
 
     def _frac(ms):
         return round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms else None
+
+    traffic, traffic_source = _load_traffic()
+    traffic_detail = None
+    if rank == 0 and world == 1 and not dist_on and not args.no_traffic:
+        measured = measure_traffic(args)
+        if measured.get("tile_kernel_hbm_bytes_per_launch"):
+            traffic, traffic_source, traffic_detail = measured["tile_kernel_hbm_bytes_per_launch"], measured["source"], measured
+        else:
+            traffic_source = f"{traffic_source}; in-run measurement unavailable ({measured.get('error', 'no counters')})"
 
     roofline = dict(
         bound="hbm",
@@ -729,10 +923,15 @@ def main():
         peak=HBM_PEAK_GBS,
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 5),
-        frac_note=("frac is quoted on the kernel as the timed steps ran it (VERDICT r02: not the best launch pattern).  Round 2's line quoted the back-to-back figure: like for like, "
-                   "in step 0.51 (r02) -> this frac, back to back 0.57 (r02) -> frac_back_to_back") if in_step else None,
-        traffic=_load_traffic()[0],
-        traffic_source=_load_traffic()[1],
+        frac_note=("frac = algorithmic bytes / the WHOLE fused kernel as the timed steps ran it (first workgroup started .. last part's sums handed to the host; the kernel's own "
+                   "100 MHz stamps, mean over the K steps).  Rounds 3-4 quoted the streaming slice under this name: that is frac_streaming now (r04: 0.613 streaming / 0.546 whole kernel)")
+        if in_step else "no fused steps in this configuration: frac is the tile kernel back to back under HIP events",
+        frac_streaming=_frac(streaming_ms) if in_step else None,
+        streaming_ms=round(streaming_ms, 5) if in_step else None,
+        streaming_note="first workgroup started .. last partial row in: the part of the kernel the algorithmic bytes belong to (rounds 3-4's `frac`)" if in_step else None,
+        traffic=traffic,
+        traffic_source=traffic_source,
+        traffic_detail=traffic_detail,
         algorithmic_bytes=alg_bytes,
         algorithmic_bytes_note="SURVEY.md 8(d), reference-layout accounting (48 B per source point + the reference's bucket table and voxel arrays): internal repacking does not change it",
         source_stream=("packed private mirror: 36 B per point (12 B point + the 6 floats of the symmetric covariance), three 12-B LDS-DMA rows per 64-point chunk" if mirrored.value == 1
@@ -740,13 +939,13 @@ def main():
         actual_bytes=actual_bytes,
         actual_bytes_note="what the launch requests with perfect reuse of the lookup structures: the source stream as read + 16 B per 4x4x4-voxel block of the map's box + 64-B records + pose and record",
         frac_actual=round(actual_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        frac_fused_kernel=(round(alg_bytes / (dev_kernel_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if in_step and dev_kernel_us.value > 0 else None),
+        frac_fused_kernel=(round(alg_bytes / (dev_kernel_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if in_step else None),
         kernel_ms=round(kernel_ms, 5),
-        kernel_ms_source=(f"measured in THIS run inside the {args.steps} timed steps: the streaming part of the fused kernel (first workgroup started .. last partial row in) on the "
+        kernel_ms_source=(f"measured in THIS run inside the {args.steps} timed steps: the whole fused kernel (first workgroup started .. last part's sums on their way to the host) on the "
                           "device's 100 MHz constant clock, stamped by the kernel itself (gp_vgicp_batch_device_times); mean over the steps") if in_step
         else "measured in THIS run: HIP events over back-to-back tile-kernel launches on the launch stream (no fused steps in this configuration)",
         fused_kernel_ms=round(dev_kernel_us.value * 1e-3, 5) if in_step else None,
-        fused_kernel_note="first workgroup started .. last part's sums on their way to the host: the streaming part + the finalize tail of the last eight workgroups" if in_step else None,
+        fused_kernel_note="= kernel_ms: the streaming part + the finalize tail of the last eight workgroups" if in_step else None,
         kernel_ms_back_to_back=round(ms_main.value, 5),
         frac_back_to_back=_frac(ms_main.value),
         kernel_ms_back_to_back_source="HIP events on the launch stream over back-to-back launches of the tile kernel (two-kernel form), this run: the kernel at the device's sustained state",
@@ -755,10 +954,12 @@ def main():
         rocprof_kernel_ms_mean=split.get("all_ms"),
         rocprof_frac_mean=_frac(split.get("all_ms")),
         rocprof_fused_kernel_ms_in_step=split.get("fused_in_step_ms"),
+        rocprof_frac_fused_in_step=_frac(split.get("fused_in_step_ms")),
         rocprof_source=split.get("source"),
         step_finalize=args.finalize if not dist_on else "device-resident records (two kernels)",
         finalize_kernel_ms=round(ms_fin.value, 5),
         device_pass_ms=round(ms_total.value, 5),
+        cold=cold,
     )
 
     if os.environ.get("GP_BENCH_CALIBRATE"):  # PMC passes only: known-byte-count stream for FETCH_SIZE calibration
@@ -834,6 +1035,8 @@ def main():
             steps=args.steps,
             warmup=args.warmup,
             ms_per_step=round(ms_per_step, 5),
+            ms_per_step_cold=cold["ms_per_step"] if cold else None,
+            ms_per_step_cold_note="the same W + K steps measured BEFORE the untimed device wake-up (config.device_warmup), i.e. with --device-warmup-ms 0: rounds 1-3's protocol",
             higher_is_better=True,
             scaling="weak",
             vs_baseline=None,
@@ -865,11 +1068,28 @@ def main():
             big_source=big_source,
             setup=dict(generate_s=round(t_gen, 2), voxelmap_build_s=round(t_map, 4)),
         )
-        print(json.dumps(result), flush=True)
     lib.gp_vgicp_batch_destroy(batch)
     if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+        with PhaseGuard(args.phase_seconds, "process group teardown"):
+            dist.barrier()
+            dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and result.get("c4") is not None and not args.no_c4_inlib:
+            # VERDICT r04 #5c: the in-library path a C++ optimizer process uses (ONE process drives N devices, no collective: every shard's finalize stores its records into
+            # one host-pinned stack) beside the torch.distributed step, per N.  Run when the ranks are gone (the process group is destroyed, their devices idle), in a process
+            # of its own with a time limit: neither a hang nor a crash of it may take the line with it
+            import subprocess
+
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--c4-inlib-only", "--inlib-devices", str(world), "--c4-steps", str(args.c4_steps)],
+                                   capture_output=True, text=True, timeout=240)
+                lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                result["c4"]["inlib"] = json.loads(lines[-1]) if lines else dict(error=f"no result (exit code {p.returncode}): {p.stderr[-400:]}")
+            except subprocess.TimeoutExpired:
+                result["c4"]["inlib"] = dict(error="the in-library multi-device leg did not finish within 240 s and was stopped")
+            except Exception as exc:
+                result["c4"]["inlib"] = dict(error=f"{type(exc).__name__}: {exc}")
+        print(json.dumps(result), flush=True)
     return result
 
 

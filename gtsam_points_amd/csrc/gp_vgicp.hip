@@ -456,6 +456,7 @@ struct gp_vgicp_tuning {
                                   // and hands them to the host (InlinePoses: fused finalize) -- no finalize launch.  (The first form of this knob, finalize
                                   // workgroups on a second stream waiting for the counters, cost +10 us per step: profiles/r03_overlap_finalize.jsonl)
   int balance = kDefaultSkewPermille;  // stream kernel, one large factor: how much more a dispatch round takes than the next, in 1/1000 of the mean share (0 = flat)
+  int experiment = 0;             // GP_TUNE_EXPERIMENT: measurement instantiations of the stream kernel (gp_vgicp_stream.hpp, EXP), 0 = the product kernel
   int source_mirror = 1;          // stream family: stream the sources' packed mirrors (36 B per point, gp::SourceMirror) when every factor of the batch has one; 0 = the caller's arrays
 };
 
@@ -888,6 +889,12 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
           else GP_LAUNCH_STREAM(false, true, false, false, true);
         }
       }
+    } else if (inl.use && MODE == gp::MODE_LIN && b->tuning.experiment && b->planned && b->packed && b->nt && !b->any_sv) {
+      // measurement instantiations (GP_TUNE_EXPERIMENT): the headline's shape only -- planned single factor, packed non-temporal stream, no surface validation
+      if constexpr (MODE == gp::MODE_LIN) {
+        if (b->tuning.experiment == 1) hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, true, true, false, true, false, 1>), GP_ARGS);
+        else hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, true, true, false, true, false, 2>), GP_ARGS);
+      }
     } else if (inl.use) {
       if (b->any_sv) GP_LAUNCH_STREAM_S(true, true);
       else GP_LAUNCH_STREAM_S(true, false);
@@ -1075,6 +1082,10 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
     case GP_TUNE_SOURCE_MIRROR:
       t->source_mirror = value ? 1 : 0;
       return GP_OK;
+    case GP_TUNE_EXPERIMENT:
+      if (value < 0 || value > 2) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_EXPERIMENT: 0 (off), 1 (block-grid warm-up), 2 (f32 covariance rotation: breaks parity, timing only)");
+      t->experiment = value;
+      return GP_OK;
     case GP_TUNE_BALANCE:
       if (value < -1 || value > 600) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_BALANCE: -1 (automatic), 0 (flat) .. 600 (per mille of the mean share per dispatch round)");
       t->balance = value;
@@ -1123,6 +1134,7 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
     case GP_TUNE_TILE_CHUNKS: *value = b->tuning.tile_chunks; return GP_OK;
     case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
     case GP_TUNE_SOURCE_MIRROR: *value = b->tuning.source_mirror; return GP_OK;
+    case GP_TUNE_EXPERIMENT: *value = b->tuning.experiment; return GP_OK;
     case GP_TUNE_EFFECTIVE_MIRROR: *value = b->table_dirty ? -1 : (b->packed ? 1 : 0); return GP_OK;  // does the built table stream the packed mirrors?
     default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
   }

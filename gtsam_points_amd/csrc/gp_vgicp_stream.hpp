@@ -138,7 +138,10 @@ __device__ __forceinline__ void finalize_part_error(const double* __restrict__ p
   asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(flag), "v"(seq) : "memory");
 }
 
-template <int MODE, bool NT, bool INL, bool SV, bool PK, bool TRACE = false>
+// EXP (measurement instantiations of round 5, never the default; GP_TUNE_EXPERIMENT selects them for a synchronous planned single-factor linearise):
+//   1 = every workgroup touches its share of the map's block grid right behind its first request, so that an XCD's L2 holds the whole grid (1 MB for the headline map)
+//       by the time the first hop 1 asks for it (VERDICT r04 #1b: the cold first chunk);  2 = R C_A R^T in f32 (accumulate_core2<ROT32>: the upper bound of #1c)
+template <int MODE, bool NT, bool INL, bool SV, bool PK, bool TRACE = false, int EXP = 0>
 __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                                double* __restrict__ partials) {
@@ -166,9 +169,11 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   FactorDesc f;
   WaveWork ww;
   int factor_idx = 0, row;
+  int wgs_per_xcd = 0;  // (EXP 1)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (INL) {
     PlanFields pf = plan_fields(inl.plan, bx, bq);
+    wgs_per_xcd = pf.gx;
     int tile_points = inl.tile_points, fn = inl.factor.n;
     const float* fpts = inl.factor.points;
     const float* fcov = inl.factor.covs;
@@ -264,6 +269,17 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   const GP_GLOBAL char* gblocks = uniform_ptr((const GP_GLOBAL char*)f.map.gblocks);
   const GP_GLOBAL char* records = uniform_ptr((const GP_GLOBAL char*)f.map.records);
 
+  v4i warm = {0, 0, 0, 0};
+  if constexpr (EXP == 1) {
+    // workgroup q of an XCD asks for bytes [(k * wgs + q) * 4096 + 16 tid, + 16) of the grid, k = 0 .. 3: 2 MB per XCD at 128 workgroups.  Behind the points'
+    // request in the queue; both are retired by the vmcnt(0) in front of the first transform
+    const unsigned gbytes = gd0 * gd1 * gd2 * 16u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned off = ((unsigned)(k * wgs_per_xcd + bq) * 256u + threadIdx.x) * 16u;
+      if (off < gbytes) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(warm) : "v"(off), "s"(gblocks) : "memory");
+    }
+  }
   // the translation lives in vector registers: a VOP3 instruction reads ONE scalar operand (gp_vgicp_tile2.hpp)
   double tvx, tvy, tvz;
   asm volatile("v_mov_b64 %0, %1" : "=v"(tvx) : "s"(Tl.tx));
@@ -366,6 +382,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     // points first: only chunk 0's points (and normals) are in flight, so the first transform and hop 1 do not queue behind everybody's
     // covariances; those follow hop 1 (they are needed behind hop 2), the head of chunk 1 goes out before hop 2 and its covariances behind it
     vm_wait<0>();
+    if constexpr (EXP == 1) asm volatile("" : : "v"(warm));  // (the registers the warm-up loads land in stay reserved until here)
     GP_TRACE(1);
     front_ring(0, Pc);  // in flight: H0
     dma_cov(0, 0);
@@ -393,7 +410,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
         dma_head(j + 2, par);
         dma_cov(j + 2, par);
       }
-      if (hit) accumulate_core2<MODE>(Tl, a, c01, c23, c45, Pc.ex + head.x, Pc.ey + head.y, Pc.ez + head.z, Pc.qx, Pc.qy, Pc.qz, acc);
+      if (hit) accumulate_core2<MODE, EXP == 2>(Tl, a, c01, c23, c45, Pc.ex + head.x, Pc.ey + head.y, Pc.ez + head.z, Pc.qx, Pc.qy, Pc.qz, acc);
       if constexpr (TRACE) {
         if (j == 0) GP_TRACE(3);
         if (j == 1) GP_TRACE(5);

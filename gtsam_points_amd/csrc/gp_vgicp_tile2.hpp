@@ -217,12 +217,35 @@ __device__ __forceinline__ void vm_wait_rec(v4f& head, v2d& c01, v2d& c23, v2d& 
 // `#pragma clang fp contract(off)` + explicit fused multiply-adds in exactly the places hipcc's contraction had put them.  Two cheaper forms were measured and
 // dropped: cofactors x (1 / det) in f32 (-1 % cycles; the record moved 6e-8 against the round-2 kernel), and the sums' products added straight into the
 // accumulators (see below).
-template <int MODE>
+// ROT32 (measurement only, round 5: the upper bound of what ANY cheaper form of R C_A R^T could buy -- VERDICT r04 #1c): the rotation of the source covariance in
+// plain f32.  It breaks the parity contract (3e-5 on H) and is never selected by the product; profiles/r05_kernel_experiments.txt has what it measured.
+template <int MODE, bool ROT32 = false>
 __device__ __forceinline__ void accumulate_core2(const Pose& Tl, const double* a, const v2d& c01, const v2d& c23, const v2d& c45, float RX, float RY, float RZ, float QX,
                                                  float QY, float QZ, float* acc) {
 #pragma clang fp contract(off)
   float M0, M1, M2, M3, M4, M5;
-  {
+  if constexpr (ROT32) {
+    const float r00 = (float)Tl.r00, r01 = (float)Tl.r01, r02 = (float)Tl.r02, r10 = (float)Tl.r10, r11 = (float)Tl.r11, r12 = (float)Tl.r12, r20 = (float)Tl.r20,
+                r21 = (float)Tl.r21, r22 = (float)Tl.r22;
+    const float a00 = (float)a[0], a01 = (float)a[1], a02 = (float)a[2], a11 = (float)a[3], a12 = (float)a[4], a22 = (float)a[5];
+    const auto d3 = [](float x0, float y0, float x1, float y1, float x2, float y2) { return __builtin_fmaf(x2, y2, __builtin_fmaf(x1, y1, x0 * y0)); };
+    const float rc00 = d3(r00, a00, r01, a01, r02, a02), rc01 = d3(r00, a01, r01, a11, r02, a12), rc02 = d3(r00, a02, r01, a12, r02, a22);
+    const float rc10 = d3(r10, a00, r11, a01, r12, a02), rc11 = d3(r10, a01, r11, a11, r12, a12), rc12 = d3(r10, a02, r11, a12, r12, a22);
+    const float rc20 = d3(r20, a00, r21, a01, r22, a02), rc21 = d3(r20, a01, r21, a11, r22, a12), rc22 = d3(r20, a02, r21, a12, r22, a22);
+    const double s00 = c01.x + (double)d3(rc00, r00, rc01, r01, rc02, r02), s01 = c01.y + (double)d3(rc00, r10, rc01, r11, rc02, r12);
+    const double s02 = c23.x + (double)d3(rc00, r20, rc01, r21, rc02, r22), s11 = c23.y + (double)d3(rc10, r10, rc11, r11, rc12, r12);
+    const double s12 = c45.x + (double)d3(rc10, r20, rc11, r21, rc12, r22), s22 = c45.y + (double)d3(rc20, r20, rc21, r21, rc22, r22);
+    const double i00 = __builtin_fma(s11, s22, -(s12 * s12)), i01 = __builtin_fma(s02, s12, -(s01 * s22)), i02 = __builtin_fma(s01, s12, -(s02 * s11));
+    const double det = __builtin_fma(s02, i02, __builtin_fma(s01, i01, s00 * i00));
+    double x = __builtin_amdgcn_rcp(det);
+    x = x * __builtin_fma(-det, x, 2.0);
+    M0 = (float)(i00 * x);
+    M1 = (float)(i01 * x);
+    M2 = (float)(i02 * x);
+    M3 = (float)(__builtin_fma(s00, s22, -(s02 * s02)) * x);
+    M4 = (float)(__builtin_fma(s01, s02, -(s00 * s12)) * x);
+    M5 = (float)(__builtin_fma(s00, s11, -(s01 * s01)) * x);
+  } else {
     const double a00 = a[0], a01 = a[1], a02 = a[2], a11 = a[3], a12 = a[4], a22 = a[5];
     const auto dot3 = [](double x0, double y0, double x1, double y1, double x2, double y2) { return __builtin_fma(x2, y2, __builtin_fma(x1, y1, x0 * y0)); };
     const auto dot3p = [](double c, double x0, double y0, double x1, double y1, double x2, double y2) { return __builtin_fma(x2, y2, __builtin_fma(x1, y1, __builtin_fma(x0, y0, c))); };

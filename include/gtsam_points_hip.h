@@ -486,6 +486,8 @@ enum {
                                    symmetric covariance, chunk-major; built once per cloud at the first table build, shared by all factors on the cloud, only from
                                    covariances that are symmetric to the last bit -- records are bit-identical to 0 = the caller's arrays (12 + 36 B per point) */
   GP_TUNE_EFFECTIVE_MIRROR = 22,/* read-only: 1 when the batch's current table streams the packed mirrors (-1 before the first pass) */
+  GP_TUNE_EXPERIMENT = 23,      /* measurement only: instantiations of the stream kernel built for an A/B of round 5 (1 = block-grid warm-up, 2 = f32 covariance rotation,
+                                   which BREAKS the parity contract); applies to a synchronous planned single-factor linearise, 0 (default) = the product kernel */
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */
