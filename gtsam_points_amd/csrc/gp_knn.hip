@@ -381,12 +381,15 @@ __device__ __forceinline__ unsigned long long cube_mask(unsigned mx, unsigned my
 
 // max_shells: how many shells beyond the first one that reaches the box this call may walk before it gives up (returns false: the
 // caller retries on a coarser level); returns true when the search is complete (bound met, or every point seen)
+constexpr int kDeferShell = 2;      // (covariance search with the cooperative pass) a query with fewer than k points within this many cells of its cell is deferred
 constexpr int kRangeCap = 16;       // candidate ranges a lane collects before it scans them (flat scan of knn_query_bins)
 constexpr int kFlatWidth = 4;       // candidates whose loads a lane has in flight per trip of the flat scan (8: 16 registers spilled, 0.748 vs 0.754 ms per call: no gain)
 constexpr int kRangeStride = 128;   // int2 entries between two slots of one lane's list = threads of the workgroups that use it
 
+// (round 5: a query the fine shells cannot settle -- knn_query_any's `sparse` -- is not continued on the coarser levels lane by lane but handed to covariance_far_kernel)
 template <int KMAX, bool FULL, bool FLAT = false>
-__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top, int max_shells, int2* rl = nullptr) {
+__device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, double qy, double qz, TopK<KMAX, FULL>& top, int max_shells, int2* rl = nullptr,
+                                               bool* sparse = nullptr) {
   const double ux = qx * g.inv_h, uy = qy * g.inv_h, uz = qz * g.inv_h;
   if (!(fabs(ux) < 1.0e9 && fabs(uy) < 1.0e9 && fabs(uz) < 1.0e9)) return true;  // non-finite query: no neighbours
   const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
@@ -508,7 +511,17 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
       b0[a] = x0 >> 2;
       b1[a] = x1 >> 2;
     }
-    if (any) {
+    // Round 5: NEAR CELLS FIRST for the queries that reach shell 1 with a list that is not full (own cell < k points).  Next to a dense surface those were the launch's
+    // longest waves after the far field: with no bound yet they collected all 26 neighbours in walk order and scanned 250-470 candidates per lane, the far corner cells in
+    // full before the near face cell had filled the list (profiles/r04_c5_wavelog.txt: 500-545 us per wave against a mean of 107).  They walk the shell TWICE: pass 0
+    // takes the cells whose box lies within half a cell edge of the query (the octant it leans to: <= 7 cells), the list is scanned, and pass 1 meets the rest with the
+    // k-th distance those brought -- most of it fails the box test below before its range is even looked up.  Queries whose list is full walk once, as before (walking
+    // everybody twice: the same lists, 5 % more wave time; one walk with the near ranges sorted to the front of the 16-entry list: no gain, the near cell is often not
+    // among the first 16 -- profiles/r05_c5_near_first.txt).  Same candidates, same k smallest; only exact ties in distance could tell the visiting orders apart.
+    const int passes = (FLAT && r == 1 && top.count() < top.k) ? 2 : 1;
+    const float near2 = 0.25f * h2f;
+    if (any)
+     for (int pass = 0; pass < passes; pass++) {
       // only blocks that touch the shell are visited: a z-slab of blocks that lies inside the previous cube along z contributes
       // its y-border rows, and such a row its two x-border blocks (surface, not volume, per shell)
       for (int bz = b0[2]; bz <= b1[2]; bz++) {
@@ -539,6 +552,7 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
                 const float rx = (float)(4 * bx + (bit & 3) - c[0]) - fxf, ry = (float)(4 * by + ((bit >> 2) & 3) - c[1]) - fyf, rz = (float)(4 * bz + (bit >> 4) - c[2]) - fzf;
                 const float ex = fmaxf(fmaxf(rx, -rx - 1.0f), 0.0f), ey = fmaxf(fmaxf(ry, -ry - 1.0f), 0.0f), ez = fmaxf(fmaxf(rz, -rz - 1.0f), 0.0f);
                 box2 = (ex * ex + ey * ey + ez * ez) * h2f * 0.9999f;
+                if (passes == 2 && (box2 <= near2) != (pass == 0)) continue;  // (not this pass's)
                 if (box2 > accept) continue;
               }
               const int ord = raw.z + __popcll(bits & ((1ull << bit) - 1ull));
@@ -550,11 +564,21 @@ __device__ __forceinline__ bool knn_query_bins(const BinGridView& g, double qx, 
           }
         }
       }
-    }
+      if constexpr (FLAT) {
+        if (pass + 1 < passes) flush_ranges();
+      }
+     }
     if constexpr (FLAT) flush_ranges();
     const double safe = (double)r * g.h + face;
     const bool done = top.worst() <= safe * safe   // every unvisited point is farther than the current k-th (or than max_sq_dist)
                       || top.count() >= g.n;         // the whole cloud has been seen (clouds smaller than k)
+    // (round 5: fewer than k points within kDeferShell cells of the query's cell -- the cells are the wrong tool here, and one lane walking on keeps its wave's other
+    // 63 waiting: the caller hands the query to covariance_far_kernel)
+    if (sparse && !done && r >= kDeferShell && r < rlast && top.count() < top.k) {
+      *sparse = true;
+      return false;
+    }
+
     if (done || r == rlast) {
       if (g.counters) {
 #ifdef GP_KNN_WAVELOG  // per-wave rows instead of the global counters (which serialise the launch): sum and maximum over the lanes of the candidates, the last shell
@@ -798,7 +822,8 @@ struct SearchView {
 // stage 0: cell shells 0 .. 4 (occupied cells only: work-efficient while the neighbourhood is a few cells wide); stage 1: superblock
 // shells -- blocks as cells, those beyond the current k-th distance skipped -- until the bound is met or the box is exhausted
 template <int KMAX, bool FULL = false, bool FLAT = false>
-__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX, FULL>& top, bool skip_fine = false, int2* rl = nullptr) {
+__device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, double qy, double qz, int want, TopK<KMAX, FULL>& top, bool skip_fine = false, int2* rl = nullptr,
+                                              bool* sparse = nullptr) {
   if (g.binned) {
     const int k = top.k;
     const double bound = top.worst();  // the caller's max_sq_dist (nothing has been pushed yet)
@@ -820,11 +845,16 @@ __device__ __forceinline__ void knn_query_any(const SearchView& g, double qx, do
     bool settled = false;
     for (int l = 0; l < g.binned && !settled; l++) {
       if (l > 0) top.init(k, bound);
-      settled = knn_query_bins<KMAX, FULL, FLAT>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : g.fine_shells, rl);
+      settled = knn_query_bins<KMAX, FULL, FLAT>(g.bins[l], qx, qy, qz, top, (l + 1 < g.binned && !skip_fine) ? 1 : g.fine_shells, rl, (l + 1 == g.binned) ? sparse : nullptr);
+      if (sparse && *sparse) return;
     }
     GP_WL_ALL(5, (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(!settled)));
     GP_WL(1, __builtin_amdgcn_s_memrealtime());
     if (settled) return;
+    if (sparse) {  // round 5: what the fine shells do not settle is searched by a whole wave (covariance_far_kernel), not by this lane with 63 others waiting
+      *sparse = true;
+      return;
+    }
     // round 4: sparse neighbourhoods (the far field of a LiDAR scan: one point per cell) first try the BLOCKS as cells -- shells 0 .. block_stage of a grid four
     // times as coarse, 27 entries for the first two, a few points each -- before they start over on the superblocks, whose first shell alone scans every point
     // within 4-12 m of the query: those queries were the launch's tail (a hundred 64-query chunks of 350-460 us in a launch whose balanced length was 334 us)
@@ -1057,11 +1087,355 @@ __global__ void __launch_bounds__(256) heavy_first_order_kernel(const int* __res
 // the second pass of the tiled kernel below for the queries it left over (todo_list != nullptr: the *todo_count positions listed)
 // MIN_WAVES = 4 (k <= 10): registers capped at 128 for four waves per SIMD instead of three: 1.41 -> 1.28 ms per 1 M points (round 2).
 // FULL: k == KMAX, the list is always full: straight-line insertion (TopK<KMAX, true>)
+__device__ __forceinline__ void todo_append(bool flag, int pos, int* __restrict__ todo_list, int* __restrict__ todo_count) {
+  const unsigned long long m = __ballot(flag);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(todo_count, __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1, 64);
+  if (flag) todo_list[base + __popcll(m & ((1ull << lane) - 1ull))] = pos;
+}
+
+// ---- sparse neighbourhoods: SIXTEEN LANES PER QUERY (round 5) ----------------------------------------------------------------------
+// A query the fine shells do not settle (the far field of a LiDAR scan: ring spacing of a metre, one point per 0.25 m cell) used to go on lane by lane: blocks as cells,
+// then superblocks -- a chain of dependent loads on ONE lane while 63 wait: 400-600 us per wave against a mean of 110 (profiles/r05_c5_wavelog.txt), the tail of the
+// launch.  Here kFarLanes lanes share one query (four queries per wave).  Such queries are few (0.1-1.5 % of a cloud), so the kernel runs at a fraction of a wave per
+// SIMD and nothing hides a load's latency: what counts is the NUMBER OF DEPENDENT ROUND TRIPS, and every stage asks for everything it needs at once.
+//   blocks -> candidates (far_process): a list of <= 128 blocks (4 x 4 x 4 cells: 1 m for the covariance structure), eight per lane: the eight block entries in one
+//            trip, the sixteen cell_start words in the next, the (first point, length) ranges into LDS; then the CANDIDATES -- not the blocks -- are dealt to the lanes
+//            (candidate o of the concatenated ranges to lane o % 16: one dense block does not leave fifteen lanes idle), eight loads in flight per lane;
+//   phase A  the 5 x 5 x 5 blocks around the query's block: one list;
+//   phase B  cube shells of SUPERBLOCKS (4 x 4 x 4 blocks, one 64-bit occupancy mask each) around the query's superblock, the masks dealt to the lanes four at a time:
+//            empty space costs one 8-byte load per 64 m^3; occupied blocks outside phase A's cube and not farther than the group's best k-th distance so far are
+//            appended to the list (LDS counter), which is processed whenever it is full and at the end of the shell.
+// Every lane keeps the k best of what it scanned (exact f64 distances, strict '<' like KnnResult::push).  After phase A / a shell the group is done when k of its
+// candidates lie within the safe radius (R units + the distance to the nearest face of the query's own unit: every unvisited point is farther) -- the stopping rule of the
+// per-lane search, counted with ballots instead of read off a merged list -- or when the grid is exhausted.  Then the group merges its lists once: k rounds of "smallest
+// head" (a group-wide minimum each; ties: smaller original index), which yields the neighbours in ascending order, the order covariance_from_neighbours sums them in.
+// Exact like the per-lane search: the neighbour set is the k smallest distances either way.
+constexpr int kFarBlockShells = 2, kFarLanes = 16, kFarList = 128, kFarPer = kFarList / kFarLanes, kFarMasks = 4;
+struct FarGroupLds {
+  int2 range[kFarList];  // (first point, points) per listed block
+  int blk[kFarList];     // linear block index (phase B)
+  int count;
+  int pad_[3];
+};
+template <int KMAX>
+__global__ void __launch_bounds__(64) covariance_far_kernel(BinGridView g, const float* __restrict__ points, int k, float* __restrict__ covs, int* __restrict__ num_short,
+                                                             const int* __restrict__ far_list, const float* __restrict__ far_bound, const int* __restrict__ far_count) {
+  constexpr int kGroups = 64 / kFarLanes;
+  // these few waves are chains of dependent round trips with short bursts of arithmetic in between, and they run beside the other launch's waves (four per SIMD, busy
+  // with list insertions): at equal issue priority every burst takes four times as long -- the kernel measured 350 us beside the light queries' launch, 190 alone
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ FarGroupLds lds_all[kGroups];  // (one wave per workgroup: a 256-register wave finds a place where a four-wave workgroup waits for four at once)
+  const int lane = threadIdx.x & 63, sub = lane % kFarLanes, grp = lane / kFarLanes;
+  FarGroupLds& L = lds_all[grp];
+  const unsigned long long gmask = ((1ull << kFarLanes) - 1ull) << (grp * kFarLanes);
+  const int groups = (int)gridDim.x * kGroups, count = *far_count;
+  constexpr double kInf = 1.7976931348623157e308;
+  auto wave_sync = [] {  // LDS traffic of a wave is ordered; this keeps the compiler from moving LDS accesses across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int w0 = (int)blockIdx.x * kGroups; w0 < count; w0 += groups) {  // (wave-uniform trip count; a group without a query idles through it)
+    const int w = w0 + grp;
+    const bool active = w < count;
+    const int t = far_list[active ? w : w0];
+    // what the per-lane search knew when it gave up: its k-th distance (rounded up; +inf when it had found fewer than k) -- nothing farther can be a neighbour, so
+    // blocks beyond it are not even listed (a noise point a metre above a dense surface: without it phase A scanned 6000-8000 candidates, profiles/r05_c5_farlog.txt)
+    const double known = (double)far_bound[active ? w : w0];
+    double bound = known;  // nothing farther than this can be a neighbour: what the per-lane search knew, then the group's exact k-th distance after every stage
+    const float4 self = g.sorted[t];
+    const int i = __float_as_int(self.w);
+    const double qx = (double)self.x, qy = (double)self.y, qz = (double)self.z;
+    const double B = 4.0 * g.h, inv_B = 0.25 * g.inv_h;
+    // block coordinates RELATIVE to the grid's first block (what the superblock masks are indexed by); the query is a point of the cloud: inside the grid
+    const double ux = qx * inv_B - (double)g.geom.lo[0], uy = qy * inv_B - (double)g.geom.lo[1], uz = qz * inv_B - (double)g.geom.lo[2];
+    const int c[3] = {fast_floor(ux), fast_floor(uy), fast_floor(uz)};
+    const double fx = ux - (double)c[0], fy = uy - (double)c[1], fz = uz - (double)c[2];
+    const double face = fmin(fmin(fmin(fx, 1.0 - fx), fmin(fy, 1.0 - fy)), fmin(fz, 1.0 - fz)) * B;
+    const int dim[3] = {g.geom.dim[0], g.geom.dim[1], g.geom.dim[2]};
+    const double ox = (double)g.geom.lo[0] * B, oy = (double)g.geom.lo[1] * B, oz = (double)g.geom.lo[2] * B;  // corner of block (0, 0, 0)
+    TopK<KMAX, false> top;
+    top.init(k, kInf);
+#ifdef GP_KNN_WAVELOG  // rows of 8 words per far query behind the per-wave rows: start | phase A done | phase B done | merged | candidates of the group | shells of B | settled in A
+    unsigned long long* fl = (g.counters && active) ? g.counters + 8 + 8 * ((size_t)(g.n + 63) / 64 + 2) + 8 * (size_t)w : nullptr;
+    if (fl && sub == 0) fl[0] = __builtin_amdgcn_s_memrealtime();
+    unsigned far_cands = 0, far_bshells = 0;
+#endif
+    // the blocks listed for this group (nb <= kFarList; block index of list position j from `block_of(j)`) -> their points through the lanes' lists.
+    // Wave-convergent: every lane of the wave calls it, groups without work pass nb = 0
+    auto far_process = [&](int nb, auto block_of, auto block_wanted) {
+      int4 raw[kFarPer];
+      bool wanted[kFarPer];
+#pragma unroll
+      for (int q = 0; q < kFarPer; q++) {
+        const int j = sub * kFarPer + q;
+        wanted[q] = j < nb && block_wanted(j);
+        raw[q] = *reinterpret_cast<const int4*>(g.blocks + (wanted[q] ? block_of(j) : 0));  // (unconditional: the eight loads are in flight together)
+      }
+      int pb[kFarPer], pe[kFarPer];
+#pragma unroll
+      for (int q = 0; q < kFarPer; q++) {
+        const unsigned long long bits = ((unsigned long long)(unsigned)raw[q].y << 32) | (unsigned long long)(unsigned)raw[q].x;
+        const bool valid = wanted[q] && bits != 0ull;
+        pb[q] = g.cell_start[valid ? raw[q].z : 0];
+        pe[q] = valid ? g.cell_start[raw[q].z + __popcll(bits)] : pb[q];
+      }
+      int mine = 0;
+#pragma unroll
+      for (int q = 0; q < kFarPer; q++) {
+        const int len = wanted[q] ? pe[q] - pb[q] : 0;
+        L.range[sub * kFarPer + q] = make_int2(pb[q], len);
+        mine += len;
+      }
+      int total = mine;
+#pragma unroll
+      for (int off = kFarLanes / 2; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+      wave_sync();
+#ifdef GP_KNN_WAVELOG
+      far_cands += (unsigned)total;
+#endif
+      // candidate o of the concatenated ranges -> lane o % kFarLanes; a lane's ordinals ascend, so its cursor over the ranges only moves forward
+      int rj = 0, rc = 0;  // range under the cursor, candidates in front of it
+      int2 cur = L.range[0];
+      constexpr int kFarCand = 4;  // candidates in flight per lane
+      for (int o = sub; __builtin_amdgcn_ballot_w64(o < total) != 0ull; o += kFarLanes * kFarCand) {
+        int pp[kFarCand];
+        bool ok[kFarCand];
+#pragma unroll
+        for (int q = 0; q < kFarCand; q++) {
+          const int oq = o + q * kFarLanes;
+          ok[q] = oq < total;
+          if (ok[q]) {
+            while (oq >= rc + cur.y) {
+              rc += cur.y;
+              rj++;
+              cur = L.range[rj];
+            }
+            pp[q] = cur.x + (oq - rc);
+          } else {
+            pp[q] = 0;
+          }
+        }
+        float4 v[kFarCand];
+#pragma unroll
+        for (int q = 0; q < kFarCand; q++) v[q] = g.sorted[pp[q]];
+#pragma unroll
+        for (int q = 0; q < kFarCand; q++)
+          if (ok[q]) {
+            const double ex = (double)v[q].x - qx, ey = (double)v[q].y - qy, ez = (double)v[q].z - qz;
+            const double d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 <= bound) top.push(__float_as_int(v[q].w), d2);
+          }
+      }
+      wave_sync();  // (the list may be refilled)
+    };
+    // k candidates of the group within `safe`?  (a lane holds its k best: one that has k within the radius settles it alone)
+    auto settled_within = [&](double safe, bool live) {
+      const double safe2 = safe * safe;
+      int within = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX; j++) within += __popcll(__builtin_amdgcn_ballot_w64(live && j < k && top.idx[j] >= 0 && top.d[j] <= safe2) & gmask);
+      return within >= k;
+    };
+    // the k smallest of the group's lists, ascending (ties: smaller index): k rounds of "smallest head", a group-wide minimum each -> fin.idx (group-uniform), the
+    // group's exact k-th distance in `kth` (+inf while it holds fewer than k); returns how many there are.  ~4 us: once per shell, not per block
+    int fin_i[KMAX];
+    double kth = kInf;
+    auto merge = [&]() -> int {
+#pragma unroll
+      for (int r = 0; r < KMAX; r++) fin_i[r] = -1;
+      kth = kInf;
+      int head = 0, n_have = 0;
+#pragma unroll
+      for (int r = 0; r < KMAX; r++) {
+        double cur = kInf;
+        int cur_i = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < KMAX; j++)
+          if (head == j && j < k && top.idx[j] >= 0) cur = top.d[j], cur_i = top.idx[j];
+        double m = cur;
+#pragma unroll
+        for (int off = kFarLanes / 2; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+        int mi = cur == m ? cur_i : 0x7fffffff;
+#pragma unroll
+        for (int off = kFarLanes / 2; off > 0; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
+        if (r < k && mi != 0x7fffffff) {
+          fin_i[r] = mi;
+          n_have = r + 1;
+          if (r == k - 1) kth = m;
+          if (cur == m && cur_i == mi) head++;  // (every candidate was scanned by exactly one lane: one winner)
+        }
+      }
+      return n_have;
+    };
+    int have = 0;
+    bool done = !active;
+    auto box2 = [&](int bx, int by, int bz) {  // squared distance of a block's box from the query
+      const double bx0 = ox + (double)bx * B, by0 = oy + (double)by * B, bz0 = oz + (double)bz * B;
+      const double ddx = fmax(fmax(bx0 - qx, qx - (bx0 + B)), 0.0), ddy = fmax(fmax(by0 - qy, qy - (by0 + B)), 0.0), ddz = fmax(fmax(bz0 - qz, qz - (bz0 + B)), 0.0);
+      return ddx * ddx + ddy * ddy + ddz * ddz;
+    };
+    // ---- phase A: the blocks around the query's block: the 3 x 3 x 3 cube, then -- with the bound that brought -- the shell around it.  One list each ----
+    {
+      int ra_max = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) ra_max = max(ra_max, max(c[a], dim[a] - 1 - c[a]));  // the shell that covers the grid
+      static_assert((2 * kFarBlockShells + 1) * (2 * kFarBlockShells + 1) * (2 * kFarBlockShells + 1) <= kFarList, "a cube of phase A is one list");
+      for (int R = 1; R <= kFarBlockShells; R++) {
+        const int x0 = max(c[0] - R, 0), x1 = min(c[0] + R, dim[0] - 1), y0 = max(c[1] - R, 0), y1 = min(c[1] + R, dim[1] - 1), z0 = max(c[2] - R, 0), z1 = min(c[2] + R, dim[2] - 1);
+        const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+        far_process(
+          done ? 0 : nx * ny * nz, [&](int j) { return ((size_t)(z0 + j / (nx * ny)) * (size_t)dim[1] + (size_t)(y0 + (j / nx) % ny)) * (size_t)dim[0] + (size_t)(x0 + j % nx); },
+          [&](int j) {
+            const int bx = x0 + j % nx, by = y0 + (j / nx) % ny, bz = z0 + j / (nx * ny);
+            return (R == 1 || max(max(abs(bx - c[0]), abs(by - c[1])), abs(bz - c[2])) == R) && box2(bx, by, bz) <= bound;  // (not the cube of the step before)
+          });
+        const bool ok = settled_within((double)R * B + face, !done);
+        if (!done && (ok || R >= ra_max)) done = true;
+        if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {  // somebody goes on: the exact k-th distance so far prunes what follows
+          have = merge();
+          bound = fmin(bound, kth);
+        }
+      }
+    }
+#ifdef GP_KNN_WAVELOG
+    if (fl && sub == 0) fl[1] = __builtin_amdgcn_s_memrealtime(), fl[6] = done ? 1 : 0;
+#endif
+    // ---- phase B: shells of superblocks (blocks outside phase A's cube) ----
+    if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+      const double S = 4.0 * B;
+      const int cs[3] = {c[0] >> 2, c[1] >> 2, c[2] >> 2};
+      const double fsx = (ux - 4.0 * (double)cs[0]) * 0.25, fsy = (uy - 4.0 * (double)cs[1]) * 0.25, fsz = (uz - 4.0 * (double)cs[2]) * 0.25;
+      const double sface = fmin(fmin(fmin(fsx, 1.0 - fsx), fmin(fsy, 1.0 - fsy)), fmin(fsz, 1.0 - fsz)) * S;
+      int rs_max = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) rs_max = max(rs_max, max(cs[a], g.sdim[a] - 1 - cs[a]));
+      for (int R = 0; __builtin_amdgcn_ballot_w64(!done) != 0ull; R++) {  // (the wave goes on while any of its groups does; a group ends at rs_max at the latest)
+        // the SURFACE of the cube of radius R, enumerated directly (an outlier tens of metres from everything walks six shells: the cube's 2197 positions at R = 6 are
+        // 866 on the surface): the two z-faces, (2R + 1)^2 positions each, then 2R - 1 slabs with the 8R positions of their rim
+        const int side = 2 * R + 1, face_n = side * side, rim_n = 8 * R;
+        const int total = done ? 0 : (R == 0 ? 1 : 2 * face_n + (side - 2) * rim_n);
+        auto shell_pos = [&](int e, int& dx, int& dy, int& dz) {
+          if (R == 0) {
+            dx = dy = dz = 0;
+          } else if (e < 2 * face_n) {
+            const int f = e / face_n, r = e % face_n;
+            dz = f ? R : -R;
+            dx = r % side - R;
+            dy = r / side - R;
+          } else {
+            const int r = e - 2 * face_n, slab = r / rim_n, pos = r % rim_n, edge = pos / (2 * R), off = pos % (2 * R);
+            dz = slab - R + 1;
+            dx = edge == 0 ? -R + off : (edge == 1 ? R : (edge == 2 ? R - off : -R));
+            dy = edge == 0 ? -R : (edge == 1 ? -R + off : (edge == 2 ? R : R - off));
+          }
+        };
+        int e = sub;                        // next position of the shell this lane looks at (stride kFarLanes)
+        unsigned long long rest[kFarMasks];  // occupied blocks of the lane's current masks that are still to be listed
+        unsigned long long spos[kFarMasks];  // their superblocks, packed (x | y << 21 | z << 42: a grid has < 2^24 blocks)
+#pragma unroll
+        for (int q = 0; q < kFarMasks; q++) rest[q] = 0ull, spos[q] = 0;
+        bool lane_more = e < total;
+        while (__builtin_amdgcn_ballot_w64(lane_more) != 0ull) {  // rounds of: fill the group's list (<= kFarList blocks), process it
+          // (`bound`: the group's exact k-th distance as of the last stage -- a block farther away than that holds nothing of interest)
+          if (sub == 0) L.count = 0;
+          wave_sync();
+          bool full = false;
+          while (lane_more && !full) {
+            bool any_rest = false;
+#pragma unroll
+            for (int q = 0; q < kFarMasks; q++) any_rest = any_rest || rest[q] != 0ull;
+            if (!any_rest) {  // the next kFarMasks masks of this lane's positions, requested together
+              if (e >= total) {
+                lane_more = false;
+                break;
+              }
+#pragma unroll
+              for (int q = 0; q < kFarMasks; q++) {
+                const int eq = e + q * kFarLanes;
+                int dx = 0, dy = 0, dz = 0;
+                shell_pos(eq < total ? eq : 0, dx, dy, dz);
+                const int x = cs[0] + dx, y = cs[1] + dy, z = cs[2] + dz;
+                const bool in = eq < total && x >= 0 && x < g.sdim[0] && y >= 0 && y < g.sdim[1] && z >= 0 && z < g.sdim[2];
+                const unsigned long long mask = g.super[in ? ((size_t)z * (size_t)g.sdim[1] + (size_t)y) * (size_t)g.sdim[0] + (size_t)x : 0];
+                rest[q] = in ? mask : 0ull;
+                spos[q] = (unsigned long long)(unsigned)x | ((unsigned long long)(unsigned)y << 21) | ((unsigned long long)(unsigned)z << 42);
+              }
+              e += kFarMasks * kFarLanes;
+            }
+#pragma unroll
+            for (int q = 0; q < kFarMasks; q++) {
+              while (rest[q] != 0ull && !full) {
+                const int bit = __ffsll((long long)rest[q]) - 1;
+                const int bx = 4 * (int)(spos[q] & 0x1fffffull) + (bit & 3), by = 4 * (int)((spos[q] >> 21) & 0x1fffffull) + ((bit >> 2) & 3), bz = 4 * (int)(spos[q] >> 42) + (bit >> 4);
+                bool want = max(max(abs(bx - c[0]), abs(by - c[1])), abs(bz - c[2])) > kFarBlockShells;  // (else: phase A scanned it)
+                if (want) want = box2(bx, by, bz) <= bound;
+                if (want) {
+                  const int slot = atomicAdd(&L.count, 1);
+                  if (slot >= kFarList) {  // the list is full: this block waits for the next round
+                    full = true;
+                    break;
+                  }
+                  L.blk[slot] = (bz * dim[1] + by) * dim[0] + bx;
+                }
+                rest[q] &= rest[q] - 1ull;
+              }
+            }
+          }
+          wave_sync();
+          const int nb = done ? 0 : min(L.count, kFarList);
+          wave_sync();
+          far_process(nb, [&](int j) { return (size_t)L.blk[j]; }, [](int) { return true; });
+        }
+#ifdef GP_KNN_WAVELOG
+        if (!done) far_bshells++;
+#endif
+        const bool ok = settled_within((double)R * S + sface, !done);
+        if (!done && (ok || R >= rs_max)) done = true;
+        if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+          have = merge();
+          bound = fmin(bound, kth);
+        }
+      }
+    }
+#ifdef GP_KNN_WAVELOG
+    if (fl && sub == 0) fl[2] = __builtin_amdgcn_s_memrealtime(), fl[5] = far_bshells;
+#endif
+    // ---- the k smallest of the group's lists, ascending (ties: smaller index) ----
+    have = merge();
+#ifdef GP_KNN_WAVELOG
+    if (fl && sub == 0) fl[3] = __builtin_amdgcn_s_memrealtime(), fl[4] = far_cands;
+#endif
+    if (active && sub == 0) {
+      float* out = covs + 9 * (size_t)i;
+      if (have < k) {
+        atomicAdd(num_short, 1);
+        for (int j = 0; j < 9; j++) out[j] = (j % 4 == 0) ? 1.0f : 0.0f;
+      } else {
+        TopK<KMAX, false> fin;
+        fin.init(k, kInf);
+#pragma unroll
+        for (int r = 0; r < KMAX; r++) fin.idx[r] = fin_i[r];
+        covariance_from_neighbours<KMAX, false>(fin, points, k, out);
+      }
+    }
+  }
+}
+
+// far_list / far_count (optional): queries whose neighbourhood is sparse (knn_query_bins, `sparse`) are not searched lane by lane -- one lane walking hundreds of
+// empty blocks holds its 63 neighbours for 400-600 us, the launch's tail (profiles/r05_c5_wavelog_near_first.txt) -- but appended here for covariance_far_kernel
 template <int KMAX, int MIN_WAVES = 1, bool FULL = false>
 __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g, const float* __restrict__ points, int n, int k, float* __restrict__ covs,
-                                                         int* __restrict__ num_short, const int* __restrict__ todo_list, const int* __restrict__ todo_count) {
+                                                         int* __restrict__ num_short, const int* __restrict__ todo_list, const int* __restrict__ todo_count,
+                                                         int* __restrict__ far_list = nullptr, int* __restrict__ far_count = nullptr, float* __restrict__ far_bound = nullptr,
+                                                         const int* __restrict__ todo_begin = nullptr) {
   int t = blockIdx.x * 128 + threadIdx.x;
-  if (todo_list) {
+  if (todo_list) {  // positions [*todo_begin, *todo_count) of the list (round 5: the heavy part and the rest are two launches on two streams)
+    if (todo_begin) t += *todo_begin;
     if (t >= *todo_count) return;
     t = todo_list[t];
   }
@@ -1079,7 +1453,24 @@ __global__ void __launch_bounds__(128, MIN_WAVES) covariance_kernel(SearchView g
     static_assert(kRangeStride == 128, "one list per thread of this kernel's workgroups");
     rl = range_lists + threadIdx.x;
   }
-  knn_query_any<KMAX, FULL, FULL>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr, rl);
+  bool sparse = false;
+  knn_query_any<KMAX, FULL, FULL>(g, qx, qy, qz, 2 * k, top, todo_list != nullptr, rl, far_list ? &sparse : nullptr);
+  if (far_list) {
+    // (position in the cell-sorted array and the k-th distance found so far, rounded up; one atomic per wave)
+    const unsigned long long m = __ballot(sparse);
+    if (m != 0ull) {
+      const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == first) base = atomicAdd(far_count, __popcll(m));
+      base = __shfl(base, first, 64);
+      if (sparse) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        far_list[slot] = t;
+        far_bound[slot] = __double2float_ru(top.worst());
+      }
+    }
+    if (sparse) return;
+  }
   float* out = covs + 9 * (size_t)i;
   if (top.count() < k) {
     atomicAdd(num_short, 1);
@@ -1163,15 +1554,6 @@ struct TopF {
 
 // appends the sorted positions of the lanes with `flag` to todo_list (one atomic per wave; the order of the list does not matter:
 // every leftover query writes its own output slot)
-__device__ __forceinline__ void todo_append(bool flag, int pos, int* __restrict__ todo_list, int* __restrict__ todo_count) {
-  const unsigned long long m = __ballot(flag);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(todo_count, __popcll(m));
-  base = __shfl(base, __ffsll((long long)m) - 1, 64);
-  if (flag) todo_list[base + __popcll(m & ((1ull << lane) - 1ull))] = pos;
-}
 
 // Scan kernel.  The scan loop is an LDS broadcast read, an f32 distance, a compare and a 2-byte LDS append for the lanes whose
 // candidate passes.  What passes is pushed into the lane's f32 top list only when a queue is full or the chunk ends -- then every lane
@@ -1665,6 +2047,33 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 
 // structure: GP_TUNE_KNN_STRUCTURE value (0 binned + per-lane search, 1 hashed multi-level grid, 3 row-tiled covariance pass first, 4 two binned
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
+namespace gp {
+// a per-thread, per-device side stream with the two events that fork it off a caller's stream and join it back (created once, never destroyed)
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  static int get(SideStream* out) {
+    static thread_local SideStream cache[16];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return fail(GP_ERROR_HIP, "SideStream: no current device");
+    SideStream& c = cache[d];
+    if (!c.stream) {
+      // the LOWEST priority the device offers: what runs on the side stream fills the slots the caller's stream leaves free, it does not compete for them
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0, (void)hipGetLastError();
+      if (hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        c = SideStream{};
+        return fail(GP_ERROR_HIP, "SideStream: cannot create the side stream");
+      }
+    }
+    *out = c;
+    return GP_OK;
+  }
+};
+}  // namespace gp
+
 static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
                                   bool synchronise, gp_point_grid_t** out, const gp::FillJob caller_zero = gp::FillJob{}, bool* caller_zero_applied = nullptr);
 int gp_point_grid_create_ex(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, gp_point_grid_t** out) {
@@ -1685,7 +2094,8 @@ static int point_grid_create_impl(const float* points_dev, int n, double cell_si
     }
   } report{caller_zero_applied, &caller_zero_done};
   if (!points_dev || n < 0 || !(cell_size > 0.0) || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create: bad arguments");
-  if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure != 6 && structure < 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4, 6} (>= 16: staging experiment)");
+  if (structure != 0 && structure != 1 && structure != 3 && structure != 4 && structure != 6 && structure != 7 && structure < 16)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_point_grid_create_ex: structure in {0, 1, 3, 4, 6, 7} (>= 16: staging experiment)");
   auto* g = new gp_point_grid;
   g->stream = (hipStream_t)stream;
   g->structure = structure;
@@ -1844,6 +2254,8 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
   bool zeroed = false;
   GP_TRY(point_grid_create_impl(points_dev, n, cell_size > 0.0 ? cell_size : 0.25, structure, counters_dev, stream, true, false, &g, gp::fill_job(d_short.ptr, zero_bytes, 0u), &zeroed));
   const bool heavy_first = g->binned && g->structure != 6 && g->structure != 3 && !g->bin_levels.empty() && g->bin_levels[0]->bins.cell_of.ptr;
+  // round 5: sparse neighbourhoods are handed to covariance_far_kernel (one wave per query); structure 7 = round 4's search (every query lane by lane) for the A/B
+  const bool coop_far = heavy_first && g->structure == 0 && g->bin_levels.size() == 1 && k <= 10;
   int rc = GP_OK;
   if (rc == GP_OK) {
     if (!zeroed) (void)hipMemsetAsync(d_short.ptr, 0, zero_bytes, s);
@@ -1886,17 +2298,55 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
         }
       }
     }
+    gp::DeviceArray far;  // positions (cell-sorted array) of the queries left to the cooperative kernel + their k-th distances so far; the count is word 1 of the zeroed block
+    int *d_far = nullptr, *d_far_count = nullptr;
+    float* d_far_bound = nullptr;
+    if (nq > 0 && rc == GP_OK && coop_far) {
+      rc = far.alloc_async((sizeof(int) + sizeof(float)) * (size_t)nq, s);
+      if (rc == GP_OK) d_far = far.as<int>(), d_far_bound = reinterpret_cast<float*>(far.as<int>() + nq), d_far_count = d_short.as<int>() + 1;
+    }
     if (nq > 0 && rc == GP_OK) {
       constexpr int cov_waves = 4;      // registers capped at 128 for four waves per SIMD (uncapped, three waves: 1.41 vs 1.28 ms, round 2)
       constexpr bool cov_full = true;   // k = 10: the straight-line insertion of full lists (profiles/r03_c5_straightline.txt)
-      if (k == 10 && cov_waves == 4 && cov_full)  // (capped at 96 registers for five waves per SIMD: 41 spilled, 1.08 vs 1.07 ms -- no gain)
-        hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
-      else if (k <= 10 && cov_waves == 4)
-        hipLaunchKernelGGL((gp::covariance_kernel<10, 4>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
-      else if (k <= 10)
-        hipLaunchKernelGGL((gp::covariance_kernel<10, 1>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
-      else
-        hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_todo ? d_todo + nq : nullptr);
+      const int* d_count = d_todo ? d_todo + nq : nullptr;
+      gp::SideStream side;
+      if (d_far && k == 10 && gp::SideStream::get(&side) == GP_OK) {
+        // Round 5: TWO launches of the same kernel on two streams.  The heavy part of the order (own-cell population < k: the only queries that can turn out sparse)
+        // runs on `s` with the deferral, covariance_far_kernel behind it; the rest runs beside it on a side stream.  The far kernel is a few hundred waves bound by
+        // the latency of its round trips (150-200 us for 0.15 % of the queries): behind ONE launch it would be added to the call, here it runs under the other
+        // launch's waves.  Both cover the whole order with their grids and leave by the counts on the device (the split is not known to the host).
+        const int* d_heavy = d_todo + nq + 1;
+        bool forked = hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess;
+        hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_heavy, d_far, d_far_count, d_far_bound,
+                           (const int*)nullptr);
+        hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, forked ? side.stream : s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_count,
+                           (int*)nullptr, (int*)nullptr, (float*)nullptr, d_heavy);
+        const unsigned far_wgs = (unsigned)std::min<long long>(((long long)nq + 3) / 4, 8192);  // one wave = four queries per workgroup
+        hipLaunchKernelGGL(gp::covariance_far_kernel<10>, dim3(far_wgs), dim3(64), 0, s, v.bins[0], points_dev, k, covs_dev, d_short.as<int>(), (const int*)d_far, (const float*)d_far_bound,
+                           (const int*)d_far_count);
+        if (forked && (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(s, side.join, 0) != hipSuccess)) {
+          (void)hipStreamSynchronize(side.stream);  // (the join could not be queued: wait for the side stream here, the call is synchronous anyway)
+        }
+      } else {
+        if (k == 10 && cov_waves == 4 && cov_full)  // (capped at 96 registers for five waves per SIMD: 41 spilled, 1.08 vs 1.07 ms -- no gain)
+          hipLaunchKernelGGL((gp::covariance_kernel<10, 4, true>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_count, d_far, d_far_count, d_far_bound,
+                             (const int*)nullptr);
+        else if (k <= 10 && cov_waves == 4)
+          hipLaunchKernelGGL((gp::covariance_kernel<10, 4>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_count, d_far, d_far_count, d_far_bound,
+                             (const int*)nullptr);
+        else if (k <= 10)
+          hipLaunchKernelGGL((gp::covariance_kernel<10, 1>), grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_count, d_far, d_far_count, d_far_bound,
+                             (const int*)nullptr);
+        else
+          hipLaunchKernelGGL(gp::covariance_kernel<32>, grid, block, 0, s, v, points_dev, nq, k, covs_dev, d_short.as<int>(), d_todo, d_count, (int*)nullptr, (int*)nullptr, (float*)nullptr,
+                             (const int*)nullptr);
+        if (d_far) {
+          // a fixed grid (the count stays on the device): 4 waves per workgroup, 4 queries per wave, every group of 16 lanes takes queries w, w + groups, ... of the list
+          const unsigned far_wgs = (unsigned)std::min<long long>(((long long)nq + 3) / 4, 8192);
+          hipLaunchKernelGGL(gp::covariance_far_kernel<10>, dim3(far_wgs), dim3(64), 0, s, v.bins[0], points_dev, k, covs_dev, d_short.as<int>(), (const int*)d_far, (const float*)d_far_bound,
+                             (const int*)d_far_count);
+        }
+      }
     }
     // the count of short queries comes back through a host-mapped word, behind a one-thread kernel whose flag the host polls (a D2H copy is a copy kernel + the
     // stream synchronisation's wake-up: ~10 us more)

@@ -495,7 +495,8 @@ enum {
                                    (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding box is too large for the block
                                    grid); 3 = as 0 with the row-tiled covariance pass in front of the per-lane search (exact, measured slower:
                                    DESIGN.md section 4.8); 4 = as 0 with a second binned level between the cells and the superblocks; 6 = as 0 with the covariance queries in plain
-                                   cell-sorted order (round 3) instead of heavy-first (own-cell population < k first: round 4), for the A/B; >= 16: staging experiment of round 4,
+                                   cell-sorted order (round 3) instead of heavy-first (own-cell population < k first: round 4), for the A/B; 7 = as 0 without round 5's
+                                   cooperative pass (covariance_far_kernel: sparse neighbourhoods searched by one wave per query), i.e. round 4's search, for the A/B; >= 16: staging experiment of round 4,
                                    16 | fine shells << 4 | shells of blocks << 8 (measured: no effect, profiles/r04_c5_staging.jsonl) */
 };
 int gp_vgicp_batch_set_tuning(gp_vgicp_batch_t* batch, int key, int value);

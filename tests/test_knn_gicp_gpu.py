@@ -134,3 +134,50 @@ def test_binned_and_hashed_structures_agree(gpu, kitti00):
     idx3, d3, nf3 = gpu.KdTreeGPU(gpu.PointCloudGPU(p3), cell_size=0.1).knn_search(q[:500], 10)
     oidx3, od3 = oracle.OracleKdTree(p3).knn(q[:500], 10, num_threads=4)
     assert np.abs(d3 - od3).max() < 1e-9
+
+
+def _cov_rel(a, b):
+    a, b = a.reshape(len(a), -1).astype(np.float64), b.reshape(len(b), -1).astype(np.float64)
+    return np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)
+
+
+def test_sparse_neighbourhoods_go_through_the_cooperative_pass(gpu, kitti00):
+    """Round 5: queries with fewer than k points within a cell edge of their cell (the far field of a scan) are searched by one WAVE each
+    (covariance_far_kernel: the blocks of a cube shell dealt to the lanes, the lanes' lists merged after every shell) instead of one lane walking empty space.
+    Exact like the per-lane search: (i) a cloud that is ALL far field -- uniform points a metre apart -- against the oracle's kd-tree covariances; (ii) GP_TUNE_KNN_STRUCTURE
+    7 (round 4's search, every query lane by lane) gives the same covariances on a real scan and on the sparse cloud; (iii) outliers tens of metres from everything (past
+    the kernel's eight block shells: the superblock walk on one lane) and a neighbour count below the list size; semantics: features/covariance_estimation.cpp:18-77,
+    ann/knn_result.hpp:89-109."""
+    rng = np.random.default_rng(17)
+    sparse = rng.uniform(-40.0, 40.0, size=(30_000, 3)).astype(np.float32)  # ~0.06 points per m^3 ... one point per ~2.6 m cube: every query is "sparse"
+    sparse[:, 2] *= 0.1  # (a slab: neighbours within a few metres)
+    outliers = np.array([[300.0, 0.0, 0.0], [0.0, -250.0, 3.0], [305.0, 1.0, 0.5]], np.float32)
+    cloud = np.concatenate([sparse, outliers])
+    ref, _ = oracle.estimate_covariances(cloud, 10, 4)
+    got = {}
+    for structure in (0, 7):
+        fr = gpu.PointCloudGPU(cloud)
+        assert gpu.estimate_covariances_gpu(fr, 10, structure=structure) == 0
+        got[structure] = fr.download("covs")
+        rel = _cov_rel(got[structure], ref)
+        assert np.median(rel) < 2e-7 and (rel < 1e-5).mean() > 0.995, (structure, np.median(rel), (rel < 1e-5).mean())
+    rel07 = _cov_rel(got[0], got[7])
+    assert (rel07 < 1e-6).mean() > 0.999, (rel07 < 1e-6).mean()  # the same neighbour sets (exact ties at rank k aside)
+    # a real scan: near field through the per-lane search, far field through the cooperative pass -- against round 4's search
+    res = {}
+    for structure in (0, 7):
+        fr = gpu.PointCloudGPU(kitti00["target_points"])
+        assert gpu.estimate_covariances_gpu(fr, 10, structure=structure) == 0
+        res[structure] = fr.download("covs")
+    rel = _cov_rel(res[0], res[7])
+    assert (rel < 1e-6).mean() > 0.999, (rel < 1e-6).mean()
+    # k below the list size, and a cloud with fewer than k points in reach of the cooperative pass
+    for k in (3, 7):
+        fr = gpu.PointCloudGPU(cloud)
+        assert gpu.estimate_covariances_gpu(fr, k) == 0
+        refk, _ = oracle.estimate_covariances(cloud, k, 4)
+        relk = _cov_rel(fr.download("covs"), refk)
+        assert np.median(relk) < 2e-7 and (relk < 1e-5).mean() > 0.99, (k, np.median(relk))
+    few = gpu.PointCloudGPU(cloud[:7])
+    assert gpu.estimate_covariances_gpu(few, 10) == 7
+    np.testing.assert_array_equal(few.download("covs")[3], np.eye(3, dtype=np.float32))
