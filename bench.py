@@ -871,12 +871,20 @@ def main():
     t_wake, wake_steps = time.perf_counter(), 0
     with PhaseGuard(args.phase_seconds if dist_on else 600.0, "device wake-up"):
         if dist_on:
-            # a step holds a collective: every rank must run the SAME number of them -- a count, not a clock (~60 us per N > 1 step)
-            for _ in range(int(args.device_warmup_ms * 1e3 / 60.0)):
-                step()
-                wake_steps += 1
-                if wake_steps % 25 == 0:
-                    torch.cuda.synchronize()
+            # a step holds a collective: every rank must run the SAME number of them.  Chunks of 50 steps; after each the ranks agree (MAX over ranks of the time spent so
+            # far: one tiny collective, untimed phase) whether the wake-up has lasted --device-warmup-ms -- a count alone (5000 steps at the ~60 us of an RCCL step) took
+            # minutes with a slow backend (the gloo rehearsal on one GPU: profiles/r05_rehearsal_n*.log) and tripped the phase's time box
+            spent = torch.zeros(1, dtype=torch.float64, device=device)
+            while wake_steps < 5000 and args.device_warmup_ms > 0:
+                for _ in range(50):
+                    step()
+                    wake_steps += 1
+                    if wake_steps % 25 == 0:
+                        torch.cuda.synchronize()
+                spent[0] = (time.perf_counter() - t_wake) * 1e3
+                dist.all_reduce(spent, op=dist.ReduceOp.MAX)
+                if float(spent.item()) >= args.device_warmup_ms:
+                    break
         else:
             while (time.perf_counter() - t_wake) * 1e3 < args.device_warmup_ms:
                 step()
