@@ -442,6 +442,7 @@ struct gp_voxelmap {
   int glo[3] = {0, 0, 0}, gdim[3] = {0, 0, 0};
   bool has_grid = false;
   bool force_hashed_build = false;  // gp_voxelmap_set_tuning(GP_TUNE_MAP_BUILD): the next insert() uses the hashed build
+  int bucket_load_percent = 33;     // GP_TUNE_BUCKET_LOAD: the binned build enters the reference's doubling sequence at the first size that holds the voxels at this load factor
 
   // offloaded copies (OffloadableGPU)
   bool offloaded = false;

@@ -580,8 +580,10 @@ static int insert_binned(gp_voxelmap* m, gp::PointBins& bins, const float* point
   // the bucket table of the first insertion attempt (below) is allocated here already: the statistics kernel fills it with "empty" on its way (gp_host.hpp, FillJob)
   // the doubling sequence is entered where the voxels fit at a load factor <= 1/3: at 1/2 .. 2/3 some probe chain among 10^5 voxels exceeds max_bucket_scan_count almost
   // surely, and the failed attempt (fill + insertion + a synchronisation) was 45 us of the 2 M-point build (profiles/r04_build_timeline.txt)
+  // (GP_TUNE_BUCKET_LOAD, per map: 33 % by default = up to twice the entries of round 3's 1.5 V, 16 B each -- 4.2 MB instead of 2.1 MB for the 73.7 k voxels of the
+  // bench map; info.num_buckets / memory_usage_gpu report it.  The reference's own sequence starts at init_num_buckets and doubles until the drop rate is met.)
   int64_t num_buckets = m->init_num_buckets;
-  while (num_buckets < 3 * (int64_t)V) num_buckets *= 2;
+  while (num_buckets * (int64_t)m->bucket_load_percent < 100 * (int64_t)V) num_buckets *= 2;
   if (num_buckets > (int64_t(1) << 30)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_insert: bucket table would exceed 2^30 entries");
   GP_TRY(m->buckets.ensure_pooled(sizeof(gp_voxel_bucket) * (size_t)num_buckets, s));
   static_assert(sizeof(gp_voxel_bucket) == 16, "FillJob granules");
@@ -1038,7 +1040,12 @@ int gp_voxelmap_has_block_grid(const gp_voxelmap_t* map) { return map && map->ha
 // per map: GP_TUNE_MAP_BUILD = 1 builds with the reference-shaped hashed scheme (the fallback of clouds too large for the block grid; A/B and tests)
 int gp_voxelmap_set_tuning(gp_voxelmap_t* map, int key, int value) {
   if (!map) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_set_tuning: null map");
-  if (key != GP_TUNE_MAP_BUILD) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_set_tuning: GP_TUNE_MAP_BUILD is the only key of a voxel map");
+  if (key == GP_TUNE_BUCKET_LOAD) {
+    if (value < 5 || value > 90) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_set_tuning: GP_TUNE_BUCKET_LOAD is a load factor in per cent, 5 .. 90");
+    ext(map)->bucket_load_percent = value;
+    return GP_OK;
+  }
+  if (key != GP_TUNE_MAP_BUILD) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_voxelmap_set_tuning: the keys of a voxel map are GP_TUNE_MAP_BUILD and GP_TUNE_BUCKET_LOAD");
   map->force_hashed_build = value != 0;
   return GP_OK;
 }

@@ -491,6 +491,9 @@ enum {
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */
+  GP_TUNE_BUCKET_LOAD = 24,     /* gp_voxelmap (binned build): load factor in per cent (5 .. 90, default 33) at which the reference-visible bucket table enters the reference's doubling
+                                   sequence (gaussian_voxelmap_gpu.cu:269-291).  At 50 .. 67 % some probe chain among 10^5 voxels exceeds max_bucket_scan_count almost surely and the failed
+                                   attempt costs a fill + an insertion pass + a wait; 33 % means up to twice the entries (16 B each) of a table sized at 67 % */
   GP_TUNE_KNN_STRUCTURE = 32    /* search structures (gp_point_grid, gp_estimate_covariances_ex, gp_gicp_factor): 0 = binned structure, per-lane search
                                    (default); 1 = hashed multi-level grid (also the fallback of clouds whose bounding box is too large for the block
                                    grid); 3 = as 0 with the row-tiled covariance pass in front of the per-lane search (exact, measured slower:

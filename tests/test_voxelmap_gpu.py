@@ -363,3 +363,25 @@ def test_one_voxel_with_many_points_and_a_cloud_in_one_cell(gpu):
         idx = np.array([order[tuple(x)] for x in coords.tolist()])
         np.testing.assert_array_equal(num_points, on[idx])
         assert np.abs(means - omean[idx]).max() < 1e-6 and np.abs(covs64 - ocov[idx]).max() < 1e-12
+
+
+def test_bucket_load_factor_is_a_tunable_of_the_map(gpu, kitti00):
+    """the binned build enters the reference's bucket-table doubling sequence (gaussian_voxelmap_gpu.cu:269-291) at the first size that holds the voxels at
+    GP_TUNE_BUCKET_LOAD per cent (default 33); info.num_buckets says what was taken, and the lookups through the reference-visible table still find every voxel."""
+    lib = gpu.load()
+    cloud = gpu.PointCloudGPU(kitti00["target_points"], kitti00["target_covs"])
+    sizes, overlaps = {}, {}
+    for load in (33, 67, 10):
+        vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+        gpu._capi.check(lib.gp_voxelmap_set_tuning(vm._h, gpu._capi.GP_TUNE_BUCKET_LOAD, load), "gp_voxelmap_set_tuning")
+        vm.insert(cloud)
+        info = vm.voxelmap_info
+        sizes[load] = info.num_buckets
+        assert info.num_buckets * load >= 100 * info.num_voxels
+        b = vm.download()["buckets"]
+        used = b[b[:, 3] >= 0]
+        assert len(b) == info.num_buckets and sorted(used[:, 3].tolist()) == list(range(info.num_voxels))  # every voxel sits in exactly one bucket (test_voxelmap.cpp:245,272)
+        overlaps[load] = len(used)
+    assert sizes[10] >= sizes[33] >= sizes[67]
+    vm = gpu.GaussianVoxelMapGPU(0.5)
+    assert lib.gp_voxelmap_set_tuning(vm._h, gpu._capi.GP_TUNE_BUCKET_LOAD, 3) != 0
