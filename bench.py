@@ -472,6 +472,14 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
         tgt, src = gpa.PointCloudGPU(tp, device=device), gpa.PointCloudGPU(sp, device=device)
         gpa.estimate_covariances_gpu(tgt, 10)
         gpa.estimate_covariances_gpu(src, 10)
+        kitti_cov_ts = []
+        for fr in (tgt, src, tgt, src, tgt, src, tgt):  # (alternating clouds, as for C5 below: a call does not find its own scratch arrays waiting)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            gpa.estimate_covariances_gpu(fr, 10)
+            if fr is tgt:
+                kitti_cov_ts.append(time.perf_counter() - t)
+        kitti_cov_ms = float(np.median(kitti_cov_ts)) * 1e3
         vm = gpa.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
         vm.insert(tgt)
         f = gpa.IntegratedVGICPFactorGPU(0, 1, vm, src, stream=sptr)
@@ -490,6 +498,7 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
         out["C1"] = dict(
             workload="BASELINE configs[0]: two full data/kitti_00 scans (124,668 / 124,605 pts), covariances k=10 from gp_estimate_covariances, 0.5 m voxels, single linearise",
             points=npts, num_voxels=vm.voxelmap_info.num_voxels, ms=round(ms_copy, 5), ms_view=round(ms_view, 5), corr_per_s=round(npts / ms_copy * 1e3, 1), roofline=roof,
+            covariances_ms=round(kitti_cov_ms, 4),
             cpu_baseline=dict(value=round(npts / cpu_ms * 1e3, 1), unit="point-correspondences/s", cores=cores, kind=kind, ms=round(cpu_ms, 3), ms_1thread=round(cpu1_ms, 3),
                               sample="10 full linearize() passes of the same factor (the reference's default is 1 thread: ms_1thread)"),
             parity_vs_reference=_parity(gpa.LinearizedSystem6.from_doubles(recs[0]), Lo), inlier_fraction=round(float(recs[0, 0]) / npts, 4))
@@ -607,7 +616,10 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
     out["C5"] = dict(
         workload="BASELINE configs[4]: k-NN covariance estimation (k=10, exact) + IntegratedGICPFactor linearise, 1 M source pts vs 1 M target pts",
         points=1_000_000,
-        covariances=dict(ms=round(cov_ms, 4), ms_target_cloud=round(cov_tgt_ms, 4), points_per_s=round(1e6 / cov_ms * 1e3, 1), num_short=int(short), roofline=cov_roof,
+        covariances=dict(ms=round(cov_ms, 4), ms_target_cloud=round(cov_tgt_ms, 4), ms_kitti_scan=(out.get("C1") or {}).get("covariances_ms"),
+                         clouds_note="ms: the config's cloud (the 1 M-point C2 source); ms_target_cloud: the denser, map-like sampling of the same scene (1 M points); ms_kitti_scan: a real "
+                                     "124,668-point scan (data/kitti_00/000000.bin), most of it far field -- round 4: 0.74 / 1.23-1.31 / 0.74 ms (profiles/r05_c5_ab.jsonl)",
+                         points_per_s=round(1e6 / cov_ms * 1e3, 1), num_short=int(short), roofline=cov_roof,
                          cpu_baseline=dict(value=round(1e6 / cov_cpu_ms * 1e3, 1), unit="points/s", cores=cores, kind=kind, ms=round(cov_cpu_ms, 2),
                                            sample="one estimate_covariances pass over the same 1 M points (kd-tree build + 10-NN + eigen-regularisation; the 3x3 eigen-solver under the "
                                                   "reference code is the stand-in Jacobi iteration of oracle/ref_shim, not Eigen's closed form)"),
