@@ -1122,7 +1122,9 @@ struct FarGroupLds {
   int pad_[3];
 };
 template <int KMAX>
-__global__ void __launch_bounds__(64) covariance_far_kernel(BinGridView g, const float* __restrict__ points, int k, float* __restrict__ covs, int* __restrict__ num_short,
+// (four waves per SIMD = 128 registers, 560 B of scratch per lane: uncapped -- 256 registers, no scratch -- the kernel is 20 % faster ALONE (190 vs 240 us), but beside the
+// other launch, whose waves hold a quarter of a SIMD's registers each, a 256-register wave waits until two of them on one SIMD have retired: profiles/r05_c5_summary.txt)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) covariance_far_kernel(BinGridView g, const float* __restrict__ points, int k, float* __restrict__ covs, int* __restrict__ num_short,
                                                              const int* __restrict__ far_list, const float* __restrict__ far_bound, const int* __restrict__ far_count) {
   constexpr int kGroups = 64 / kFarLanes;
   // these few waves are chains of dependent round trips with short bursts of arithmetic in between, and they run beside the other launch's waves (four per SIMD, busy
@@ -1167,7 +1169,9 @@ __global__ void __launch_bounds__(64) covariance_far_kernel(BinGridView g, const
 #endif
     // the blocks listed for this group (nb <= kFarList; block index of list position j from `block_of(j)`) -> their points through the lanes' lists.
     // Wave-convergent: every lane of the wave calls it, groups without work pass nb = 0
+    int fresh = 0;  // candidates the group has scanned since its lists were last merged (group-uniform)
     auto far_process = [&](int nb, auto block_of, auto block_wanted) {
+      if (__builtin_amdgcn_ballot_w64(nb > 0) == 0ull) return;  // (an empty shell -- an outlier walks several: no round trips for nothing)
       int4 raw[kFarPer];
       bool wanted[kFarPer];
 #pragma unroll
@@ -1195,6 +1199,7 @@ __global__ void __launch_bounds__(64) covariance_far_kernel(BinGridView g, const
 #pragma unroll
       for (int off = kFarLanes / 2; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
       wave_sync();
+      fresh += total;
 #ifdef GP_KNN_WAVELOG
       far_cands += (unsigned)total;
 #endif
@@ -1296,9 +1301,10 @@ __global__ void __launch_bounds__(64) covariance_far_kernel(BinGridView g, const
           });
         const bool ok = settled_within((double)R * B + face, !done);
         if (!done && (ok || R >= ra_max)) done = true;
-        if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {  // somebody goes on: the exact k-th distance so far prunes what follows
+        if (__builtin_amdgcn_ballot_w64(!done && fresh > 0) != 0ull) {  // somebody goes on with new candidates: the exact k-th distance so far prunes what follows
           have = merge();
           bound = fmin(bound, kth);
+          fresh = 0;
         }
       }
     }
@@ -1396,9 +1402,10 @@ __global__ void __launch_bounds__(64) covariance_far_kernel(BinGridView g, const
 #endif
         const bool ok = settled_within((double)R * S + sface, !done);
         if (!done && (ok || R >= rs_max)) done = true;
-        if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(!done && fresh > 0) != 0ull) {  // (a shell that brought nothing leaves the bound as it is: no merge)
           have = merge();
           bound = fmin(bound, kth);
+          fresh = 0;
         }
       }
     }
