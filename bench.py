@@ -405,7 +405,7 @@ def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, tru
                "lambda 1e-5, x10 / /10, minModelFidelity 1e-3, relativeErrorTol 1e-5 (GTSAM defaults; levenberg_marquardt_ext.cpp:188-392)",
                gate="max over poses, relative to the fixed pose: rotation < 0.015 rad, translation < 0.15 m (test_matching_cost_factors.cpp:227) against "
                + ("the generator's ground truth" if truth is not None else "the CPU run's result (real scans: no ground truth)"))
-    for solver in ("device", "host"):
+    for solver in ("device", "device-three-calls", "host"):  # device = the damped build + solve as one call (gp_*_system_step); -three-calls = round 4's build / download / solve
         gg = bench_lm.GpuGraph(gpa, gpu_factors, pairs, num_poses, fixed=0, solver=solver, stream=sptr, device=device)
         bench_lm.run_lm(gg, values0, max_iterations=30)  # warm-up: first-use table builds, allocations
         best = None
@@ -422,7 +422,7 @@ def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, tru
                              "ms_per_iteration is the figure of merit); glue = numpy pose algebra of the harness (relative poses, retract), not library time")
         obj["pose_vs_cpu_run"] = dict(zip(("rotation_rad", "translation_m"), [round(max(x), 6) for x in zip(*[bench_lm.pose_error(best["values"][k], res_cpu["values"][k]) for k in range(num_poses)])]))
         gg.close()
-        out["gpu_device_solve" if solver == "device" else "gpu_host_solve"] = obj
+        out[{"device": "gpu_device_solve", "device-three-calls": "gpu_device_solve_three_calls", "host": "gpu_host_solve"}[solver]] = obj
     cpu.update(cores=cores, kind=kind, sample=f"the whole loop once: every factor linearised / evaluated in turn with {cores} threads (the count a probe chose, pick_cpu_threads), numpy dense solve")
     out["cpu_baseline"] = cpu
     out["speedup_per_iteration"] = round(cpu["ms_per_iteration"] / out["gpu_device_solve"]["ms_per_iteration"], 1)
@@ -614,6 +614,15 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
     cov_ms = float(np.median(ts)) * 1e3
     cov_tgt_ms = float(np.median(ts_tgt)) * 1e3
     kt = gpa.features.covariance_kernel_times(src, 10) if hasattr(gpa.features, "covariance_kernel_times") else None
+    side = None
+    try:  # which of its candidate side streams the covariance call uses beside the stream it was called on (the null stream here), and what the pipe probe measured for each
+        delays, chosen = (C.c_float * 4)(), C.c_int(-1)
+        _capi.check(lib.gp_debug_side_stream_probe(None, delays, C.byref(chosen)), "gp_debug_side_stream_probe")
+        side = dict(probe_delay_us=[round(float(x), 1) for x in delays], chosen=chosen.value,
+                    note="delay between the first workgroup of a device-filling grid on the caller's stream and a wave on the candidate stream: ~1 us = another dispatch pipe, "
+                         "tens of us = the same pipe (the second covariance launch would start when the first is fully placed: +0.07 ms per call, DESIGN.md 4.8)")
+    except Exception as exc:
+        side = dict(error=f"{type(exc).__name__}: {exc}")
     got = src.download("covs").astype(np.float64)
     cov_fn = refcapi.ref_estimate_covariances if use_ref else (lambda p, k_, c: oracle.estimate_covariances(p, k_, c)[0])
     cores = pick_cpu_threads(avail, lambda c: c, lambda c: cov_fn(d["source_points"][:100_000], 10, c))  # (probe on a tenth of the cloud)
@@ -649,7 +658,7 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream):
         covariances=dict(ms=round(cov_ms, 4), ms_target_cloud=round(cov_tgt_ms, 4), ms_kitti_scan=(out.get("C1") or {}).get("covariances_ms"),
                          clouds_note="ms: the config's cloud (the 1 M-point C2 source); ms_target_cloud: the denser, map-like sampling of the same scene (1 M points); ms_kitti_scan: a real "
                                      "124,668-point scan (data/kitti_00/000000.bin), most of it far field -- round 4: 0.74 / 1.23-1.31 / 0.74 ms (profiles/r05_c5_ab.jsonl)",
-                         points_per_s=round(1e6 / cov_ms * 1e3, 1), num_short=int(short), roofline=cov_roof,
+                         points_per_s=round(1e6 / cov_ms * 1e3, 1), num_short=int(short), roofline=cov_roof, side_stream=side,
                          cpu_baseline=dict(value=round(1e6 / cov_cpu_ms * 1e3, 1), unit="points/s", cores=cores_cov, cores_available=avail, kind=kind, ms=round(cov_cpu_ms, 2),
                                            sample="one estimate_covariances pass over the same 1 M points (kd-tree build + 10-NN + eigen-regularisation; the 3x3 eigen-solver under the "
                                                   "reference code is the stand-in Jacobi iteration of oracle/ref_shim, not Eigen's closed form)"),

@@ -135,12 +135,13 @@ class GpuGraph(_Graph):
         self.rec_ptr = C.c_void_p(self.rec_dev.data_ptr())
         self.errs = np.zeros(F)
         self.rec_host = np.zeros((F, _capi.LINEARIZED6_DOUBLES))
-        if solver == "device":
+        if solver in ("device", "device-three-calls"):
             self.sys = gpa.SparseLinearSystemGPU(self.num_slots, self.factor_slots, ordering="auto", stream=stream) if self.num_slots > 1 else gpa.DenseLinearSystemGPU(
                 self.num_slots, self.factor_slots, stream=stream)
             self._download = self._lib.gp_sparse_system_download if self.num_slots > 1 else self._lib.gp_dense_system_download
         self.b = np.zeros(6 * self.num_slots)
         self.c = np.zeros(1)
+        self.x = np.zeros(6 * self.num_slots)
         self.poses_lin = None
         self.sync_phases = False  # True: wait for the linearise before the solve is issued, so that the phase split is the device's, not the queue's
         torch.cuda.synchronize()
@@ -153,7 +154,7 @@ class GpuGraph(_Graph):
     def linearize(self, values):
         """-> total error at `values`; the system (records) stays where the solver wants it"""
         self.poses_lin = _poses16(self.deltas(values))
-        if self.solver == "device":
+        if self.solver != "host":
             self._capi.check(self._lib.gp_vgicp_batch_issue_linearize(self.batch, self.poses_lin.ctypes.data, self.rec_ptr), "gp_vgicp_batch_issue_linearize")
             # (no synchronisation: the solver's build is ordered behind it on the same stream; the error comes back with b, below)
             if self.sync_phases:
@@ -165,7 +166,9 @@ class GpuGraph(_Graph):
 
     def solve(self, lam):
         """-> (dx, b, error at the linearisation point)"""
-        if self.solver == "device":
+        if self.solver == "device":  # buildDampedSystem + solve as ONE call with one wait (gp_sparse_system_step / gp_dense_system_step)
+            return self.sys.step(self.rec_dev, lam=lam, out=(self.x, self.b, self.c))
+        if self.solver == "device-three-calls":  # (round 4's form, kept for the A/B: build, download of b and c, solve -- two waits, four copies)
             self.sys.build(self.rec_dev, lam=lam)
             self._capi.check(self._download(self.sys._h, None, self.b.ctypes.data, self.c.ctypes.data), "system_download")
             return self.sys.solve(), self.b, float(self.c[0])

@@ -114,6 +114,7 @@ _SIGNATURES = {
     "gp_dense_system_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "gp_dense_system_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_dense_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_dense_system_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_sparse_system_destroy": (C.c_int, [C.c_void_p]),
     "gp_sparse_system_size": (C.c_int, [C.c_void_p]),
@@ -121,6 +122,7 @@ _SIGNATURES = {
     "gp_sparse_system_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "gp_sparse_system_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_sparse_system_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_symbolic": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gp_sparse_symbolic_schedule": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gp_cloud_upload_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -195,6 +197,7 @@ _SIGNATURES = {
     "gp_debug_expand_rigid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_debug_stream_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "gp_debug_multi_gather_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
+    "gp_debug_side_stream_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "gp_debug_inject_sort_fault": (C.c_int, [C.c_int]),
     "gp_debug_sort_fallbacks": (C.c_int, []),
     "gp_trim_device_cache": (C.c_int, []),

@@ -2055,31 +2055,127 @@ int gp_point_grid_create(const float* points_dev, int n, double cell_size, gp_st
 // structure: GP_TUNE_KNN_STRUCTURE value (0 binned + per-lane search, 1 hashed multi-level grid, 3 row-tiled covariance pass first, 4 two binned
 // levels); counters_dev: device buffer of 8 uint64 work counters (measurement) or null
 namespace gp {
-// a per-thread, per-device side stream with the two events that fork it off a caller's stream and join it back (created once, never destroyed)
-struct SideStream {
+// ---- the side stream of gp_estimate_covariances: a hardware queue that does NOT share a dispatch pipe with the caller's ----
+// Two kernels on two HIP streams overlap only when their hardware queues sit on different pipes of the command processor: a pipe dispatches ONE grid at a time, and a
+// grid with more workgroups than the device holds keeps its pipe until its last workgroup has been placed.  Measured (profiles/r05_c5_queue_pipes.txt): with the
+// caller on queue 1 and the side stream on queue 3 the second covariance launch starts 8 us after the first; on queue 5 (the same process after bench.py's C4 phase had
+// taken queues 2-4) it starts when the first launch's last workgroup is placed, 100 / 160 us later on the two 1 M-point clouds -- 0.07 ms per call.  HIP does not say
+// which queue a stream gets, so the library asks the device: up to four low-priority streams are created (each gets a queue of its own from the runtime's pool for that
+// priority), and for every caller stream each candidate is probed ONCE -- a grid of 6144 workgroups that holds two LDS-bound workgroups per CU for ~5 us each on the
+// caller's stream, and one wave on the candidate that reports how long after the grid's first workgroup it got to run (~1 us on another pipe, the grid's whole dispatch
+// on the same one).  The candidate with the shortest delay serves that caller stream from then on (per thread and device; ~0.4 ms once).
+__global__ void __launch_bounds__(256) pipe_probe_hog_kernel(unsigned long long* __restrict__ words, int ticks) {
+  __shared__ float pad[12 * 1024];  // 48 KB: three workgroups per CU (160 KB of LDS), the wave slots stay free for the probe's wave
+  pad[threadIdx.x * 48] = (float)threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(words, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+  if (pad[(threadIdx.x * 48 + 7) % (12 * 1024)] < -1.0f) words[2] = 1;  // (keeps the array)
+}
+__global__ void __launch_bounds__(64) pipe_probe_stamp_kernel(unsigned long long* __restrict__ words) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long seen = 0;
+  while ((seen = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < 200000ull) __builtin_amdgcn_s_sleep(4);  // (<= 2 ms)
+  words[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+struct SideStreamHandles {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  static int get(SideStream* out) {
-    static thread_local SideStream cache[16];
+};
+struct SideStream : SideStreamHandles {
+  static constexpr int kCandidates = 4, kCallers = 16;
+  struct PerDevice {
+    SideStreamHandles cand[kCandidates];
+    int num = 0;
+    unsigned long long* words = nullptr;  // device: [0] first workgroup of the hog started, [1] the probe's wave ran, [2] unused
+    struct Choice {
+      hipStream_t caller;
+      int index;
+      float delay_us[kCandidates];
+    } chosen[kCallers];
+    int num_chosen = 0;
+    bool created = false;
+  };
+  static PerDevice* device_state() {
+    static thread_local PerDevice cache[16];
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return fail(GP_ERROR_HIP, "SideStream: no current device");
-    SideStream& c = cache[d];
-    if (!c.stream) {
-      // the LOWEST priority the device offers: what runs on the side stream fills the slots the caller's stream leaves free, it does not compete for them
-      int least = 0, greatest = 0;
-      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0, (void)hipGetLastError();
-      if (hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) {
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return nullptr;
+    return &cache[d];
+  }
+  static void create(PerDevice& c) {
+    c.created = true;
+    // the LOWEST priority the device offers: what runs on the side stream fills the slots the caller's stream leaves free, it does not compete for them
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0, (void)hipGetLastError();
+    for (int i = 0; i < kCandidates; i++) {
+      SideStreamHandles n;
+      if (hipStreamCreateWithPriority(&n.stream, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&n.join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
-        c = SideStream{};
-        return fail(GP_ERROR_HIP, "SideStream: cannot create the side stream");
+        break;
       }
+      c.cand[c.num++] = n;
     }
-    *out = c;
+    if (c.num > 1 && hipMalloc(&c.words, 4 * sizeof(unsigned long long)) != hipSuccess) (void)hipGetLastError(), c.words = nullptr;
+  }
+  // delay (us) between the first workgroup of a pipe-filling grid on `caller` and a wave on the candidate; < 0: the probe did not run
+  static float probe(PerDevice& c, hipStream_t caller, const SideStreamHandles& n) {
+    unsigned long long h[2] = {0, 0};
+    if (hipMemsetAsync(c.words, 0, 4 * sizeof(unsigned long long), caller) != hipSuccess || hipEventRecord(n.fork, caller) != hipSuccess ||
+        hipStreamWaitEvent(n.stream, n.fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1.f;
+    }
+    hipLaunchKernelGGL(pipe_probe_hog_kernel, dim3(6144), dim3(256), 0, caller, c.words, 500);
+    hipLaunchKernelGGL(pipe_probe_stamp_kernel, dim3(1), dim3(64), 0, n.stream, c.words);
+    if (hipEventRecord(n.join, n.stream) != hipSuccess || hipStreamWaitEvent(caller, n.join, 0) != hipSuccess) (void)hipStreamSynchronize(n.stream);
+    if (hipStreamSynchronize(caller) != hipSuccess || hipMemcpy(h, c.words, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || h[0] == 0 || h[1] == 0) {
+      (void)hipGetLastError();
+      return -1.f;
+    }
+    return h[1] >= h[0] ? (float)(h[1] - h[0]) / 100.f : 0.f;  // 100 MHz
+  }
+  static int get(hipStream_t caller, SideStream* out, const PerDevice::Choice** report = nullptr) {
+    PerDevice* c = device_state();
+    if (!c) return fail(GP_ERROR_HIP, "SideStream: no current device");
+    if (!c->created) create(*c);
+    if (c->num == 0) return fail(GP_ERROR_HIP, "SideStream: cannot create the side stream");
+    for (int i = 0; i < c->num_chosen; i++)
+      if (c->chosen[i].caller == caller) {
+        static_cast<SideStreamHandles&>(*out) = c->cand[c->chosen[i].index];
+        if (report) *report = &c->chosen[i];
+        return GP_OK;
+      }
+    PerDevice::Choice pick{caller, 0, {-1.f, -1.f, -1.f, -1.f}};
+    if (c->words && c->num_chosen < kCallers) {
+      for (int i = 0; i < c->num; i++) {
+        // (two probes, the smaller delay: a first launch on a new queue pays for the queue)
+        const float a = probe(*c, caller, c->cand[i]), b = probe(*c, caller, c->cand[i]);
+        pick.delay_us[i] = a < 0.f ? b : b < 0.f ? a : std::min(a, b);
+        if (pick.delay_us[i] >= 0.f && (pick.delay_us[pick.index] < 0.f || pick.delay_us[i] < pick.delay_us[pick.index] - 2.f)) pick.index = i;  // (ties within 2 us: the earlier one)
+      }
+      c->chosen[c->num_chosen++] = pick;
+      if (report) *report = &c->chosen[c->num_chosen - 1];
+    }
+    static_cast<SideStreamHandles&>(*out) = c->cand[pick.index];
     return GP_OK;
   }
 };
 }  // namespace gp
+
+// measurement / tests: the side stream gp_estimate_covariances uses beside `caller` on the current device -- the delays (us) the pipe probe measured for the (up to four)
+// candidate streams (< 0: not probed) and the index of the one in use
+int gp_debug_side_stream_probe(gp_stream_t caller, float delays_us[4], int* chosen) {
+  gp::SideStream side;
+  const gp::SideStream::PerDevice::Choice* report = nullptr;
+  GP_TRY(gp::SideStream::get((hipStream_t)caller, &side, &report));
+  for (int i = 0; i < 4; i++)
+    if (delays_us) delays_us[i] = report ? report->delay_us[i] : -1.f;
+  if (chosen) *chosen = report ? report->index : 0;
+  return GP_OK;
+}
 
 static int point_grid_create_impl(const float* points_dev, int n, double cell_size, int structure, unsigned long long* counters_dev, gp_stream_t stream, bool keep_cell_of,
                                   bool synchronise, gp_point_grid_t** out, const gp::FillJob caller_zero = gp::FillJob{}, bool* caller_zero_applied = nullptr);
@@ -2317,7 +2413,7 @@ int gp_estimate_covariances_ex(const float* points_dev, int n, int k, double cel
       constexpr bool cov_full = true;   // k = 10: the straight-line insertion of full lists (profiles/r03_c5_straightline.txt)
       const int* d_count = d_todo ? d_todo + nq : nullptr;
       gp::SideStream side;
-      if (d_far && k == 10 && gp::SideStream::get(&side) == GP_OK) {
+      if (d_far && k == 10 && gp::SideStream::get(s, &side) == GP_OK) {
         // Round 5: TWO launches of the same kernel on two streams.  The heavy part of the order (own-cell population < k: the only queries that can turn out sparse)
         // runs on `s` with the deferral, covariance_far_kernel behind it; the rest runs beside it on a side stream.  The far kernel is a few hundred waves bound by
         // the latency of its round trips (150-200 us for 0.15 % of the queries): behind ONE launch it would be added to the call, here it runs under the other

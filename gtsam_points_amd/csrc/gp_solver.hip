@@ -237,6 +237,20 @@ __global__ void __launch_bounds__(kSolveThreads) chol_solve_kernel(const double*
   for (int i = t; i < n; i += kSolveThreads) x[i] = y[i];
 }
 
+// the last launch of gp_dense_system_step: x, b, c and the status word to where the host reads them (b is not touched by the factorisation)
+__global__ void __launch_bounds__(256) dense_step_end_kernel(const double* __restrict__ x, const double* __restrict__ b, const double* __restrict__ c, const int* __restrict__ status, int n,
+                                                             double* __restrict__ out_host) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    out_host[i] = x[i];
+    out_host[n + i] = b[i];
+  }
+  if (i == 0) {
+    out_host[2 * (size_t)n] = *c;
+    out_host[2 * (size_t)n + 1] = (double)*status;
+  }
+}
+
 }  // namespace gp
 
 constexpr int kMaxSlots = 2048;  // 12288 unknowns: 96 KB of LDS for the substitution vector, 1.2 GB for the dense matrix
@@ -247,6 +261,7 @@ struct gp_dense_system {
   std::vector<gp::BlockDest> dests;
   std::vector<gp::Contribution> contribs;
   gp::DeviceArray d_dests, d_contribs, A, b, c, x, status, prior, Ldiag;
+  gp::PinnedArray pinned;  // gp_dense_system_step: x [n] | b [n] | c | status, written by the step's last kernel
   bool built = false;
 };
 
@@ -354,9 +369,8 @@ int gp_dense_system_download(const gp_dense_system_t* s, double* A_host, double*
   return GP_OK;
 }
 
-// DenseLinearSolver::solve(A, b): A x = b by LL^T.  A is overwritten by its factor (build again before the next solve).
-int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_out) {
-  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_solve: build the system first");
+// the factorisation and the two substitutions on the system's stream (status cleared in front)
+static int launch_dense_solve(gp_dense_system_t* s) {
   const int P = s->num_slots, n = s->n;
   double* A = s->A.as<double>();
   GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
@@ -373,6 +387,14 @@ int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_ou
   GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gp::chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)n)));
   hipLaunchKernelGGL(gp::chol_solve_kernel, dim3(1), dim3(gp::kSolveThreads), sizeof(double) * (size_t)n, s->stream, A, s->Ldiag.as<double>(), n, P, s->b.as<double>(),
                      s->x.as<double>());
+  return GP_OK;
+}
+
+// DenseLinearSolver::solve(A, b): A x = b by LL^T.  A is overwritten by its factor (build again before the next solve).
+int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_out) {
+  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_solve: build the system first");
+  const int n = s->n;
+  GP_TRY(launch_dense_solve(s));
   GP_HIP(hipGetLastError());
   s->built = false;
   int h_status = 0;
@@ -381,6 +403,29 @@ int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_ou
   if (x_host) GP_HIP(hipMemcpyAsync(x_host, s->x.ptr, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
   GP_HIP(hipStreamSynchronize(s->stream));
   if (h_status != 0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_dense_system_solve: the system is not positive definite (indeterminate linear system)");
+  return GP_OK;
+}
+
+// buildDampedSystem + solve (levenberg_marquardt_ext.cpp:146-161, 200-220) in one stream-ordered pass and ONE synchronisation: gp_dense_system_build, _download(b, c) and _solve
+// without the waits and copies between them; x, b, c and the status arrive through one pinned block written by the last kernel.  Bit-identical to the three calls.
+// b_host / c_host are valid also when the system is indeterminate.
+int gp_dense_system_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                         const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
+  if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_step: null system");
+  const size_t n = (size_t)s->n;
+  GP_TRY(s->pinned.ensure(sizeof(double) * (2 * n + 2)));
+  GP_TRY(gp_dense_system_build(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host));
+  GP_TRY(launch_dense_solve(s));
+  double* h = s->pinned.as<double>();
+  hipLaunchKernelGGL(gp::dense_step_end_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), (const double*)s->b.as<double>(),
+                     (const double*)s->c.as<double>(), (const int*)s->status.as<int>(), s->n, h);
+  GP_HIP(hipGetLastError());
+  s->built = false;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
+  if (c_host) *c_host = h[2 * n];
+  if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_dense_system_step: the system is not positive definite (indeterminate linear system)");
+  if (x_host) memcpy(x_host, h, sizeof(double) * n);
   return GP_OK;
 }
 

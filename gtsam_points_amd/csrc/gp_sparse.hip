@@ -417,11 +417,47 @@ struct SparseContribution {
   int factor, take;
 };
 
-// A's blocks into their places in L's storage (fill blocks stay zero) + b, one 64-lane workgroup per destination, factor order
+// what gp_sparse_system_step folds into the assembly (one launch for: assemble, damp, b and c handed to the host, the status word cleared)
+struct SparseStepExtras {
+  double lambda, min_diag, max_diag;
+  int diagonal;
+  const double* prior_diag;  // elimination order, may be null
+  const int* perm;           // elimination order -> slot
+  double* b_slots_host;      // pinned: b in slot order
+  double* c_dev;
+  double* c_host;            // pinned
+  int* status;
+  int num_factors, num_dests;
+};
+
+// A's blocks into their places in L's storage (every block of L has a destination: fill blocks have an empty contribution list and become zero) + b, one 64-lane
+// workgroup per destination, factor order.  STEP: the damping of sparse_damp_kernel applied to the diagonal as it is written (same operations in the same order:
+// bit-identical), b also stored in slot order where the host reads it, and one extra workgroup that sums the errors (sparse_sum_errors_kernel's order) and clears the status
+template <bool STEP>
 __global__ void __launch_bounds__(64) sparse_assemble_kernel(const SparseDest* __restrict__ dests, const SparseContribution* __restrict__ contribs,
-                                                             const double* __restrict__ records, double* __restrict__ L, double* __restrict__ b) {
-  const SparseDest d = dests[blockIdx.x];
+                                                             const double* __restrict__ records, double* __restrict__ L, double* __restrict__ b, const SparseStepExtras ex) {
   const int t = threadIdx.x;
+  if (STEP && (int)blockIdx.x == ex.num_dests) {
+    // c = sum of the factors' errors: 256 strided partial sums folded pairwise, exactly as sparse_sum_errors_kernel's 256 threads do (lane t carries threads t, t + 64, t + 128, t + 192)
+    __shared__ double part[256];
+    for (int q = 0; q < 4; q++) {
+      double s = 0.0;
+      for (int f = t + 64 * q; f < ex.num_factors; f += 256) s += records[122 * (size_t)f + 1];
+      part[t + 64 * q] = s;
+    }
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      for (int i = t; i < w; i += 64) part[i] += part[i + w];
+      __syncthreads();
+    }
+    if (t == 0) {
+      *ex.c_dev = part[0];
+      *ex.c_host = part[0];
+      *ex.status = 0;
+    }
+    return;
+  }
+  const SparseDest d = dests[blockIdx.x];
   if (t < 36) {
     const int r = t % 6, c = t / 6;
     double s = 0.0;
@@ -440,6 +476,11 @@ __global__ void __launch_bounds__(64) sparse_assemble_kernel(const SparseDest* _
       }
       s += v;
     }
+    if (STEP && d.diag_col >= 0 && r == c && (ex.lambda > 0.0 || ex.prior_diag)) {
+      double add = ex.diagonal ? __dmul_rn(ex.lambda, fmin(fmax(s, ex.min_diag), ex.max_diag)) : ex.lambda;  // (explicit roundings: no contraction here or in sparse_damp_kernel)
+      if (ex.prior_diag) add = __dadd_rn(add, ex.prior_diag[6 * (size_t)d.diag_col + r]);
+      s = __dadd_rn(s, add);
+    }
     L[36 * (size_t)d.block + t] = s;
   } else if (t < 42 && d.diag_col >= 0) {
     const int r = t - 36;
@@ -450,6 +491,7 @@ __global__ void __launch_bounds__(64) sparse_assemble_kernel(const SparseDest* _
       s -= q.take == STAKE_HT ? rec[SREC_BT + r] : rec[SREC_BS + r];  // g = -b (integrated_matching_cost_factor.cpp:49)
     }
     b[6 * (size_t)d.diag_col + r] = s;
+    if (STEP) ex.b_slots_host[6 * (size_t)ex.perm[d.diag_col] + r] = s;
   }
 }
 
@@ -459,9 +501,9 @@ __global__ void __launch_bounds__(256) sparse_damp_kernel(double* __restrict__ L
   if (i >= n) return;
   double* p = L + 36 * (size_t)colptr[i / 6] + 7 * (i % 6);
   const double d = *p;
-  double add = diagonal ? lambda * fmin(fmax(d, min_diag), max_diag) : lambda;
-  if (prior_diag) add += prior_diag[i];
-  *p = d + add;
+  double add = diagonal ? __dmul_rn(lambda, fmin(fmax(d, min_diag), max_diag)) : lambda;
+  if (prior_diag) add = __dadd_rn(add, prior_diag[i]);
+  *p = __dadd_rn(d, add);
 }
 
 struct SparseView {
@@ -867,6 +909,19 @@ __global__ void __launch_bounds__(256) sparse_unpermute_kernel(const double* __r
   if (i < 6 * P) x_slots[6 * (size_t)perm[i / 6] + i % 6] = x_elim[i];
 }
 
+// the last launch of gp_sparse_system_step: x in slot order on the device and where the host reads it, and the status word beside it
+__global__ void __launch_bounds__(256) sparse_step_end_kernel(const double* __restrict__ x_elim, const int* __restrict__ perm, int P, double* __restrict__ x_slots,
+                                                              double* __restrict__ x_slots_host, const int* __restrict__ status, double* __restrict__ status_host) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 6 * P) {
+    const double v = x_elim[i];
+    const size_t to = 6 * (size_t)perm[i / 6] + i % 6;
+    x_slots[to] = v;
+    x_slots_host[to] = v;
+  }
+  if (i == 0) *status_host = (double)*status;
+}
+
 __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __restrict__ records, int num_factors, double* __restrict__ c_out) {
   __shared__ double part[256];
   double s = 0.0;
@@ -889,6 +944,7 @@ struct gp_sparse_system {
   std::vector<gp::SparseDest> dests;
   std::vector<gp::SparseContribution> contribs;
   gp::DeviceArray d_dests, d_contribs, d_int, L, y, x, x_slots, c, status, prior;
+  gp::PinnedArray pinned;  // gp_sparse_system_step: x [n] | b [n] | c | status, written by the step's kernels, read by the host behind ONE synchronisation
   gp::SparseView view{};
   const int* d_perm = nullptr;
   bool built = false;
@@ -945,7 +1001,7 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     const int* e = S.rowidx.data() + S.colptr[k + 1];
     return (int)(std::lower_bound(b, e, i) - S.rowidx.data());
   };
-  for (int k = 0; k < P; k++) lists[S.colptr[k]];  // every diagonal block exists
+  for (int p = 0; p < nnzL; p++) lists[p];  // every block of L is a destination: diagonal blocks carry b, fill blocks get an empty list and are written as zeros (no memset per build)
   for (int f = 0; f < num_factors; f++) {
     const int st = factor_slots[2 * f], ss = factor_slots[2 * f + 1];
     const int it = st >= 0 ? S.iperm[st] : -1, is = ss >= 0 ? S.iperm[ss] : -1;
@@ -1036,10 +1092,9 @@ int gp_sparse_system_build(gp_sparse_system_t* s, const gp_linearized6* records_
                            const double* prior_diag_host) {
   if (!s || (!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_build: bad arguments");
   const gp::SparseSymbolic& S = s->sym;
-  GP_HIP(hipMemsetAsync(s->L.ptr, 0, sizeof(double) * 36 * (size_t)S.colptr[S.P], s->stream));
-  GP_HIP(hipMemsetAsync(s->y.ptr, 0, sizeof(double) * (size_t)s->n, s->stream));
-  hipLaunchKernelGGL(gp::sparse_assemble_kernel, dim3((unsigned)s->dests.size()), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
-                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>());
+  // (no memsets: the destination list covers every block of L and every entry of y)
+  hipLaunchKernelGGL(gp::sparse_assemble_kernel<false>, dim3((unsigned)s->dests.size()), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
+                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), gp::SparseStepExtras{});
   hipLaunchKernelGGL(gp::sparse_sum_errors_kernel, dim3(1), dim3(256), 0, s->stream, reinterpret_cast<const double*>(records_dev), s->num_factors, s->c.as<double>());
   const double* prior = nullptr;
   std::vector<double> permuted;
@@ -1092,12 +1147,9 @@ int gp_sparse_system_download(const gp_sparse_system_t* s, double* A_host, doubl
   return GP_OK;
 }
 
-// SparseLinearSolver::solve(A, b): A x = b by block-sparse LL^T.  The assembled blocks are overwritten by the factor (build again
-// before the next solve).  x in slot order.
-int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_out) {
-  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_solve: build the system first");
+// the numeric phase on the system's stream: factorisation + forward substitution level by level, backward substitution the same levels in reverse
+static void launch_factor_and_substitutions(gp_sparse_system_t* s) {
   const gp::SparseSymbolic& S = s->sym;
-  GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
   // one launch per level of the schedule (level 0: the subtrees; then the chains of separator columns, level by level), the backward
   // substitution the same levels in reverse
   const int levels = (int)S.level_ptr.size() - 1;
@@ -1117,6 +1169,15 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
     const int first = S.level_ptr[l], count = S.level_ptr[l + 1] - first;
     if (count > 0) hipLaunchKernelGGL(gp::sparse_backsolve_kernel, dim3(count), dim3(64), 0, s->stream, s->view, first);
   }
+}
+
+// SparseLinearSolver::solve(A, b): A x = b by block-sparse LL^T.  The assembled blocks are overwritten by the factor (build again
+// before the next solve).  x in slot order.
+int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_out) {
+  if (!s || !s->built) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_solve: build the system first");
+  const gp::SparseSymbolic& S = s->sym;
+  GP_HIP(hipMemsetAsync(s->status.ptr, 0, sizeof(int), s->stream));
+  launch_factor_and_substitutions(s);
   hipLaunchKernelGGL(gp::sparse_unpermute_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), s->d_perm, S.P, s->x_slots.as<double>());
   GP_HIP(hipGetLastError());
   s->built = false;
@@ -1126,6 +1187,44 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
   if (x_host) GP_HIP(hipMemcpyAsync(x_host, s->x_slots.ptr, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
   GP_HIP(hipStreamSynchronize(s->stream));
   if (h_status != 0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_solve: the system is not positive definite (indeterminate linear system)");
+  return GP_OK;
+}
+
+// One damped step of the optimizer's inner loop in ONE stream-ordered pass and ONE synchronisation: buildDampedSystem + solve (levenberg_marquardt_ext.cpp:146-161, 200-220),
+// i.e. gp_sparse_system_build, gp_sparse_system_download(b, c) and gp_sparse_system_solve without the two waits and the four copies between them.  2 + 2 x levels launches:
+// the assembly (damping applied as the diagonal is written; b, c stored where the host reads them; status cleared), the levels, x (slot order) + status to the host.
+// Bit-identical to the three calls.  b_host / c_host are valid also when the system turns out indeterminate (the optimizer raises lambda and tries again).
+int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
+  if (!s || (!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_step: bad arguments");
+  const gp::SparseSymbolic& S = s->sym;
+  const size_t n = (size_t)s->n;
+  GP_TRY(s->pinned.ensure(sizeof(double) * (2 * n + 2)));
+  double* h = s->pinned.as<double>();
+  std::vector<double> permuted;
+  gp::SparseStepExtras ex{};
+  ex.lambda = lambda, ex.min_diag = min_diagonal, ex.max_diag = max_diagonal, ex.diagonal = diagonal_damping;
+  if (prior_diag_host) {
+    permuted.resize(n);
+    for (int k = 0; k < S.P; k++)
+      for (int r = 0; r < 6; r++) permuted[6 * (size_t)k + r] = prior_diag_host[6 * (size_t)S.perm[k] + r];
+    GP_HIP(hipMemcpyAsync(s->prior.ptr, permuted.data(), sizeof(double) * n, hipMemcpyHostToDevice, s->stream));  // (`permuted` outlives it: the call ends with a synchronisation)
+    ex.prior_diag = s->prior.as<double>();
+  }
+  ex.perm = s->d_perm, ex.b_slots_host = h + n, ex.c_dev = s->c.as<double>(), ex.c_host = h + 2 * n, ex.status = s->status.as<int>();
+  ex.num_factors = s->num_factors, ex.num_dests = (int)s->dests.size();
+  hipLaunchKernelGGL(gp::sparse_assemble_kernel<true>, dim3((unsigned)s->dests.size() + 1), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
+                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), ex);
+  launch_factor_and_substitutions(s);
+  hipLaunchKernelGGL(gp::sparse_step_end_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), s->d_perm, S.P, s->x_slots.as<double>(), h,
+                     (const int*)s->status.as<int>(), h + 2 * n + 1);
+  GP_HIP(hipGetLastError());
+  s->built = false;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
+  if (c_host) *c_host = h[2 * n];
+  if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_step: the system is not positive definite (indeterminate linear system)");
+  if (x_host) memcpy(x_host, h, sizeof(double) * n);
   return GP_OK;
 }
 

@@ -92,6 +92,25 @@ class DenseLinearSystemGPU:
         _capi.check(self._lib.gp_dense_system_solve(self._h, x.ctypes.data, None), "gp_dense_system_solve")
         return x
 
+    def step(self, records_dev, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, prior_diag=None, out=None):
+        """build + download(b, c) + solve as ONE call with one synchronisation (gp_dense_system_step): -> (x, b, c); the optimizer's tryLambda
+        (levenberg_marquardt_ext.cpp:188-260).  out: optional (x, b, c) float64 arrays to fill ([n], [n], [1]) instead of new ones.  Raises GPError (indeterminate) when the
+        damped system is not positive definite; out's b and c are filled even then."""
+        if tuple(records_dev.shape) != (len(self.factor_slots), _capi.LINEARIZED6_DOUBLES) or not records_dev.is_contiguous():
+            raise ValueError("records_dev must be a contiguous [num_factors, 122] float64 device tensor")
+        prior = None
+        if prior_diag is not None:
+            prior = np.ascontiguousarray(prior_diag, dtype=np.float64)
+            if prior.shape != (self.size,):
+                raise ValueError("prior_diag must have 6 * num_slots entries")
+        x, b, c = out if out is not None else (np.zeros(self.size), np.zeros(self.size), np.zeros(1))
+        _capi.check(
+            self._lib.gp_dense_system_step(self._h, C.c_void_p(records_dev.data_ptr()), float(lam), int(bool(diagonal_damping)), float(min_diagonal), float(max_diagonal),
+                                            prior.ctypes.data if prior is not None else None, x.ctypes.data, b.ctypes.data, c.ctypes.data),
+            "gp_dense_system_step",
+        )
+        return x, b, float(c[0])
+
 
 def sparse_symbolic(num_slots, factor_slots, ordering=0):
     """The symbolic phase of SparseLinearSystemGPU alone (host code, no device needed): dict(perm, parent, nnz_a_blocks,
@@ -168,3 +187,22 @@ class SparseLinearSystemGPU:
         x = np.zeros(self.size)
         _capi.check(self._lib.gp_sparse_system_solve(self._h, x.ctypes.data, None), "gp_sparse_system_solve")
         return x
+
+    def step(self, records_dev, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, prior_diag=None, out=None):
+        """build + download(b, c) + solve as ONE call with one synchronisation (gp_sparse_system_step): -> (x, b, c); the optimizer's tryLambda
+        (levenberg_marquardt_ext.cpp:188-260).  out: optional (x, b, c) float64 arrays to fill ([n], [n], [1]) instead of new ones.  Raises GPError (indeterminate) when the
+        damped system is not positive definite; out's b and c are filled even then."""
+        if tuple(records_dev.shape) != (len(self.factor_slots), _capi.LINEARIZED6_DOUBLES) or not records_dev.is_contiguous():
+            raise ValueError("records_dev must be a contiguous [num_factors, 122] float64 device tensor")
+        prior = None
+        if prior_diag is not None:
+            prior = np.ascontiguousarray(prior_diag, dtype=np.float64)
+            if prior.shape != (self.size,):
+                raise ValueError("prior_diag must have 6 * num_slots entries")
+        x, b, c = out if out is not None else (np.zeros(self.size), np.zeros(self.size), np.zeros(1))
+        _capi.check(
+            self._lib.gp_sparse_system_step(self._h, C.c_void_p(records_dev.data_ptr()), float(lam), int(bool(diagonal_damping)), float(min_diagonal), float(max_diagonal),
+                                            prior.ctypes.data if prior is not None else None, x.ctypes.data, b.ctypes.data, c.ctypes.data),
+            "gp_sparse_system_step",
+        )
+        return x, b, float(c[0])

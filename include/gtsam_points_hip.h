@@ -398,6 +398,11 @@ int gp_dense_system_build(gp_dense_system_t* sys, const gp_linearized6* records_
 int gp_dense_system_download(const gp_dense_system_t* sys, double* A_host, double* b_host, double* c_host);
 /* x (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
 int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev);
+/* One damped step of the optimizer's inner loop (LevenbergMarquardtOptimizerExt::tryLambda: buildDampedSystem + solve, optimizers/levenberg_marquardt_ext.cpp:146-161, 200-220)
+ * as ONE call with ONE synchronisation: build + download(b, c) + solve, bit-identical to the three calls.  x_host [n], b_host [n] (the undamped gradient side the optimizer's
+ * model-fidelity test needs), c_host [1]; any may be NULL.  GP_ERROR_INDETERMINATE if not positive definite: b_host / c_host are valid, x_host is not written. */
+int gp_dense_system_step(gp_dense_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                         const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 
 /* ---- the same step, block-sparse: SparseLinearSystemBuilder<6> + SparseLinearSolver ----
  * SparseLinearSystemBuilder<BLOCK_SIZE> (include/gtsam_points/optimizers/linear_system_builder.hpp:41-72): A as a lower-triangular
@@ -425,6 +430,9 @@ int gp_sparse_system_build(gp_sparse_system_t* sys, const gp_linearized6* record
 int gp_sparse_system_download(const gp_sparse_system_t* sys, double* A_host, double* b_host, double* c_host);
 /* x in slot order (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
 int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_dev);
+/* gp_dense_system_step's block-sparse form: 2 + 2 x levels launches (the assembly applies the damping and hands b, c to the host; the last kernel hands over x), one wait */
+int gp_sparse_system_step(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 /* the symbolic phase alone (pure host code, no device needed): elimination order perm[k] = slot eliminated k-th, elimination tree
  * parent[k] (-1 = root), block counts and the schedule; any output pointer may be NULL */
 int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
@@ -528,6 +536,10 @@ int gp_debug_stream_plan(int n, int skew_permille, const int* xcd_weights_permil
  * multi-device pass (0: the plan does not allow it -- unequal or non-contiguous shards -- and the pass all-reduces), and send_offset_doubles[k] = where shard k's send
  * buffer starts inside the [F x width] stack, in doubles.  Runs the functions gp_vgicp_multi_batch_* itself uses. */
 int gp_debug_multi_gather_plan(const int* shard_of_factor, int num_factors, int num_shards, int width, int64_t* rows_per_shard, int64_t* send_offset_doubles);
+/* gp_estimate_covariances runs its second launch on a low-priority side stream; two streams overlap only when their hardware queues sit on different dispatch pipes, so
+ * the library probes (once per caller stream, thread and device) up to four candidate streams and keeps the one whose queue does not wait for the caller's grid
+ * (gp_knn.hip, SideStream).  This returns the measured delays in microseconds (< 0 = not probed) and the index of the stream in use beside `caller`. */
+int gp_debug_side_stream_probe(gp_stream_t caller, float delays_us[4], int* chosen);
 /* test hooks for the structure builds' sort fallback (gp_sort.hpp / gp_binning.hip; thread-local, no device state): the next `count` builds of this thread (voxel-map
  * insert, k-NN structure) see their first radix sort report "a tile waited for a workgroup that was never started" and must rebuild through the one-class sort;
  * gp_debug_sort_fallbacks = how many builds of this thread did so far. */

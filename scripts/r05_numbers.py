@@ -128,8 +128,11 @@ def lm():
         if "error" in o or not o:
             out.append(f"| {name} | — | — | {o.get('error', 'not run')} | | | | | |")
             continue
-        for leg, label in (("gpu_device_solve", "GPU, records stay in HBM, block-sparse LLᵀ on the device"), ("gpu_host_solve", "GPU linearise / error, numpy solve on the host (Python system builder: its time is under `linearise`)"),
+        for leg, label in (("gpu_device_solve", "GPU, records stay in HBM, damped build + block-sparse LLᵀ as ONE call (`gp_sparse_system_step` / `gp_dense_system_step`)"),
+                           ("gpu_device_solve_three_calls", "… the same as round 4's three calls (build, download of b and c, solve: two waits, four copies)"), ("gpu_host_solve", "GPU linearise / error, numpy solve on the host (Python system builder: its time is under `linearise`)"),
                            ("cpu_baseline", f"the reference's CPU factor ({o['cpu_baseline']['cores']} threads) + numpy solve")):
+            if leg not in o:
+                continue
             x = o[leg]
             ph = x["ms_per_iteration_by_phase"]
             out.append(f"| {name} | {label} | {x['iterations']} ({x['inner_iterations']}) | **{x['ms_per_iteration']:.4f}** | {ph['linearize']:.4f} | {ph['solve']:.4f} | {ph['error']:.4f} | {ph['glue']:.4f} | "

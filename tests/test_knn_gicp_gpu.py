@@ -204,3 +204,37 @@ def test_cooperative_pass_with_duplicate_points_and_clusters(gpu):
         # (degenerate neighbourhoods -- a point and its two copies among the ten: rank-deficient sample covariances, where the eigenvector of the reference's closed form is
         # itself arbitrary -- are excluded by the same 1e-5 / fraction rule as test_covariances_match_oracle)
         assert np.median(rel) < 1e-6 and (rel < 1e-5).mean() > 0.9, (structure, np.median(rel), (rel < 1e-5).mean())
+
+
+def test_side_stream_is_the_candidate_that_does_not_wait_for_the_callers_grid(gpu):
+    """gp_estimate_covariances' second launch overlaps the first only when the two streams' hardware queues sit on different dispatch pipes; the library probes its candidate
+    streams once per caller stream and keeps the one with the shortest delay (gp_knn.hip, SideStream).  The choice is the probe's minimum, it is made once, and the covariances do
+    not depend on it (bit-identical between a call on the null stream and one on a stream of the caller's)."""
+    import ctypes as C
+
+    import torch
+
+    from gtsam_points_amd import _capi
+
+    lib = _capi.load()
+    for stream in (None, torch.cuda.Stream()):
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        delays, chosen = (C.c_float * 4)(), C.c_int(-1)
+        _capi.check(lib.gp_debug_side_stream_probe(sp, delays, C.byref(chosen)), "gp_debug_side_stream_probe")
+        d = list(delays)
+        assert 0 <= chosen.value < 4 and any(x >= 0 for x in d), d
+        probed = [x for x in d if x >= 0]
+        assert d[chosen.value] >= 0 and d[chosen.value] <= min(probed) + 2.0, (d, chosen.value)
+        again, chosen2 = (C.c_float * 4)(), C.c_int(-1)
+        _capi.check(lib.gp_debug_side_stream_probe(sp, again, C.byref(chosen2)), "gp_debug_side_stream_probe")
+        assert list(again) == d and chosen2.value == chosen.value  # probed once per caller stream
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-20, 20, (60_000, 3)) * [1, 1, 0.05], rng.uniform(-60, 60, (3_000, 3))]).astype(np.float32)
+    a = gpu.PointCloudGPU(pts)
+    gpu.estimate_covariances_gpu(a, 10)
+    b = gpu.PointCloudGPU(pts)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        gpu.estimate_covariances_gpu(b, 10, stream=s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(a.download("covs"), b.download("covs"))

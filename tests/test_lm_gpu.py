@@ -38,7 +38,7 @@ def test_gpu_lm_reaches_the_gate_and_the_cpu_result(gpu, kitti07):
     res_cpu = bench_lm.run_lm(cg, v0, max_iterations=30)
     assert bench_lm.summarize(res_cpu, cg, truth, "cpu")["gate_met"]
     results = {}
-    for solver in ("device", "host"):
+    for solver in ("device", "device-three-calls", "host"):
         gg = bench_lm.GpuGraph(gpu, factors, pairs, n, fixed=0, solver=solver)
         res = bench_lm.run_lm(gg, v0, max_iterations=30)
         s = bench_lm.summarize(res, gg, truth, solver)
@@ -54,6 +54,7 @@ def test_gpu_lm_reaches_the_gate_and_the_cpu_result(gpu, kitti07):
         assert again["errors"] == res["errors"]  # bit-reproducible, with or without the wait between linearise and solve
         results[solver] = res
         gg.close()
+    assert results["device"]["errors"] == results["device-three-calls"]["errors"] and np.array_equal(results["device"]["values"], results["device-three-calls"]["values"])  # one call = the three
     for k in range(n):
         ang, tr = bench_lm.pose_error(results["device"]["values"][k], results["host"]["values"][k])
         assert ang < 1e-7 and tr < 1e-6

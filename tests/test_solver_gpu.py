@@ -291,3 +291,46 @@ def test_sparse_lm_reaches_the_alignment_gate(gpu, kitti07):
     for k in range(1, 5):
         ang, trans = pose_error(np.linalg.inv(values[0]) @ values[k], np.linalg.inv(gt[0]) @ gt[k])
         assert ang < 0.015 and trans < 0.15, (k, ang, trans)
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse-nd", "sparse-amd1", "sparse-natural"])
+def test_step_is_build_download_solve_in_one_call(gpu, kind):
+    """gp_*_system_step (the optimizer's tryLambda, levenberg_marquardt_ext.cpp:188-260, as one call with one wait) returns the same x, b, c bit for bit as
+    build -> download -> solve, with every damping form and a prior; an indeterminate system is reported and still hands over b and c"""
+    import torch
+
+    rng = np.random.default_rng(5)
+    P = 40
+    pairs = [(-1, 0)] + [(i, i + d) for i in range(P) for d in (1, 2, 5) if i + d < P]
+    rec = _random_records(pairs, rng)
+    rec_dev = torch.from_numpy(rec).cuda()
+
+    def make():
+        return gpu.DenseLinearSystemGPU(P, pairs) if kind == "dense" else gpu.SparseLinearSystemGPU(P, pairs, ordering=kind.split("-")[1])
+
+    three, one = make(), make()
+    prior = rng.uniform(0.0, 2.0, 6 * P)
+    for lam, diag, pr in [(0.0, False, None), (1e-3, False, None), (10.0, True, None), (1e-2, False, prior), (0.5, True, prior)]:
+        three.build(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)
+        _, b3, c3 = three.download()
+        x3 = three.solve()
+        x1, b1, c1 = one.step(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)
+        assert np.array_equal(x1, x3) and np.array_equal(b1, b3) and c1 == c3, (lam, diag, pr is not None)
+    # the caller's arrays are filled in place, call after call
+    out = (np.zeros(6 * P), np.zeros(6 * P), np.zeros(1))
+    for lam in (1e-3, 1e-1):
+        x1, b1, c1 = one.step(rec_dev, lam=lam, out=out)
+        assert x1 is out[0] and np.array_equal(x1, three.build(rec_dev, lam=lam).solve())
+    # gauge freedom: indeterminate, reported; b and c arrive all the same
+    free_pairs = [(i, i + 1) for i in range(P - 1)]
+    rec_f = _random_records(free_pairs, rng)
+    rec_f[:, 2:110] *= 0.0  # no curvature at all: the first pivot is zero
+    rec_f_dev = torch.from_numpy(rec_f).cuda()
+    free = gpu.DenseLinearSystemGPU(P, free_pairs) if kind == "dense" else gpu.SparseLinearSystemGPU(P, free_pairs, ordering=kind.split("-")[1])
+    out = (np.full(6 * P, 7.0), np.zeros(6 * P), np.zeros(1))
+    with pytest.raises(gpu.GPError):
+        free.step(rec_f_dev, out=out)
+    _, bh, ch = _host_system(rec_f, free_pairs, P)
+    assert np.abs(out[1] - bh).max() <= 1e-12 * np.abs(bh).max() and abs(out[2][0] - ch) <= 1e-12 * abs(ch) and np.all(out[0] == 7.0)
+    x, _, _ = free.step(rec_f_dev, lam=1.0)  # ... and lambda cures it: (0 + I) x = b
+    assert np.abs(x - bh).max() <= 1e-12 * np.abs(bh).max()
