@@ -1236,6 +1236,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if (d2 <= bound) top.push(__float_as_int(v[q].w), d2);
           }
       }
+      // a lane that holds k candidates bounds the group's k-th distance with its own (its list is a subset of the group's): `bound` tightens after EVERY list, without a
+      // merge, and prunes the rest of the shell (the kitti scan's far kernel 230 -> 192 us; profiles/r05_c5_summary.txt item 6)
+      double lane_kth = top.worst();
+#pragma unroll
+      for (int off = kFarLanes / 2; off > 0; off >>= 1) lane_kth = fmin(lane_kth, __shfl_xor(lane_kth, off, 64));
+      bound = fmin(bound, lane_kth);
       wave_sync();  // (the list may be refilled)
     };
     // k candidates of the group within `safe`?  (a lane holds its k best: one that has k within the radius settles it alone)
@@ -1395,6 +1401,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
           wave_sync();
           const int nb = done ? 0 : min(L.count, kFarList);
           wave_sync();
+          // (Scanning an unbounded group's nearest blocks first -- eight at a time until it holds k candidates, the rest against that bound -- cuts an outlier's candidates
+          // from 1500 to 350 per lane and not its time: the 160-260 us of such a query are the ~35 dependent mask trips of five empty shells, not the surface behind them.
+          // Measured and removed: profiles/r05_c5_summary.txt item 7.)
           far_process(nb, [&](int j) { return (size_t)L.blk[j]; }, [](int) { return true; });
         }
 #ifdef GP_KNN_WAVELOG
