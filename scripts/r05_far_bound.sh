@@ -2,7 +2,7 @@
 # (libgtsam_points_hip_prev.so): wall per call, bit-identity of the covariances (scripts/r05_c5.py), the far queries' lives (scripts/r05_c5_farlog.py), the kernels' spans.
 set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-O=$GRAFT_REPO_ROOT/gpurun_out/r05m; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r05n; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 for rep in 1 2 3; do
   timeout 200 python scripts/r05_c5.py --lib libgtsam_points_hip_prev.so 2>/dev/null | grep '^{' >> $O/ab.jsonl

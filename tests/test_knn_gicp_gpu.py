@@ -206,6 +206,36 @@ def test_cooperative_pass_with_duplicate_points_and_clusters(gpu):
         assert np.median(rel) < 1e-6 and (rel < 1e-5).mean() > 0.9, (structure, np.median(rel), (rel < 1e-5).mean())
 
 
+def test_cooperative_pass_skips_empty_shells_and_finds_what_lies_behind_them(gpu):
+    """covariance_far_kernel does not walk shells of superblocks (4 m) that the hyperblock masks (16 m) say are empty.  Isolated points with a few neighbours a shell away, then
+    NOTHING for 15-30 m, then a wall: the ten neighbours straddle the gap; walls at several distances put the first occupied shell at radii 3 .. 9 and beyond what the hyperblock
+    masks cover (a point 70 m from the wall).  Against the oracle's kd-tree covariances and round 4's lane-by-lane search (structure 7)."""
+    rng = np.random.default_rng(29)
+    parts = []
+    for i, gap in enumerate([13.0, 18.0, 22.0, 27.0, 33.0, 38.0, 70.0]):
+        origin = np.array([400.0 * i, 0.0, 0.0])
+        yz = rng.uniform(-6.0, 6.0, size=(1500, 2))
+        wall = np.column_stack([np.full(len(yz), gap) + rng.normal(0.0, 0.02, len(yz)), yz])  # a wall `gap` metres from the lonely points
+        lonely = rng.normal(0.0, 0.3, size=(3, 3))                                            # three lonely points ...
+        near = lonely[:1] + rng.normal(0.0, 0.2, size=(4, 3)) + [0.0, 4.5, 0.0]               # ... and four more a superblock away: fewer than k together
+        parts += [origin + wall, origin + lonely, origin + near]
+    cloud = np.concatenate(parts).astype(np.float32)
+    cloud = cloud[rng.permutation(len(cloud))]
+    ref, _ = oracle.estimate_covariances(cloud, 10, 4)
+    got = {}
+    for structure in (0, 7):
+        fr = gpu.PointCloudGPU(cloud)
+        assert gpu.estimate_covariances_gpu(fr, 10, structure=structure) == 0
+        got[structure] = fr.download("covs")
+        rel = _cov_rel(got[structure], ref)
+        assert np.median(rel) < 1e-6 and (rel < 1e-5).mean() > 0.995, (structure, np.median(rel), (rel < 1e-5).mean())
+    lonely_idx = np.where(np.abs(cloud[:, 0] - 400.0 * np.round(cloud[:, 0] / 400.0)) < 8.0)[0]  # the points in front of the walls
+    assert len(lonely_idx) == 7 * 7
+    rel = _cov_rel(got[0][lonely_idx], ref[lonely_idx])
+    assert (rel < 1e-5).all(), rel.max()  # every one of them reaches across its gap
+    assert (_cov_rel(got[0], got[7]) < 1e-6).mean() > 0.999
+
+
 def test_side_stream_is_the_candidate_that_does_not_wait_for_the_callers_grid(gpu):
     """gp_estimate_covariances' second launch overlaps the first only when the two streams' hardware queues sit on different dispatch pipes; the library probes its candidate
     streams once per caller stream and keeps the one with the shortest delay (gp_knn.hip, SideStream).  The choice is the probe's minimum, it is made once, and the covariances do
