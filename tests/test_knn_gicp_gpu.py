@@ -207,9 +207,10 @@ def test_cooperative_pass_with_duplicate_points_and_clusters(gpu):
 
 
 def test_cooperative_pass_skips_empty_shells_and_finds_what_lies_behind_them(gpu):
-    """covariance_far_kernel does not walk shells of superblocks (4 m) that the hyperblock masks (16 m) say are empty.  Isolated points with a few neighbours a shell away, then
-    NOTHING for 15-30 m, then a wall: the ten neighbours straddle the gap; walls at several distances put the first occupied shell at radii 3 .. 9 and beyond what the hyperblock
-    masks cover (a point 70 m from the wall).  Against the oracle's kd-tree covariances and round 4's lane-by-lane search (structure 7)."""
+    """Isolated points with a few neighbours a superblock (4 m) away, then NOTHING for 13-70 m, then a wall: the ten neighbours straddle the gap, covariance_far_kernel walks
+    3 .. 17 shells of superblocks most of which are empty, and the stopping rule must not fire on the near handful.  (Written for a variant that skipped empty shells through a
+    coarser occupancy level -- measured, no faster, removed: profiles/r05_c5_summary.txt item 8 -- and kept: it holds any walk to the oracle's kd-tree covariances and to round 4's
+    lane-by-lane search, structure 7.)"""
     rng = np.random.default_rng(29)
     parts = []
     for i, gap in enumerate([13.0, 18.0, 22.0, 27.0, 33.0, 38.0, 70.0]):
