@@ -2104,7 +2104,7 @@ struct SideStream : SideStreamHandles {
       int index;
       float delay_us[kCandidates];
     } chosen[kCallers];
-    int num_chosen = 0;
+    int num_chosen = 0, next_evicted = 0;
     bool created = false;
   };
   static PerDevice* device_state() {
@@ -2158,15 +2158,17 @@ struct SideStream : SideStreamHandles {
         return GP_OK;
       }
     PerDevice::Choice pick{caller, 0, {-1.f, -1.f, -1.f, -1.f}};
-    if (c->words && c->num_chosen < kCallers) {
+    if (c->words) {
       for (int i = 0; i < c->num; i++) {
         // (two probes, the smaller delay: a first launch on a new queue pays for the queue)
         const float a = probe(*c, caller, c->cand[i]), b = probe(*c, caller, c->cand[i]);
         pick.delay_us[i] = a < 0.f ? b : b < 0.f ? a : std::min(a, b);
         if (pick.delay_us[i] >= 0.f && (pick.delay_us[pick.index] < 0.f || pick.delay_us[i] < pick.delay_us[pick.index] - 2.f)) pick.index = i;  // (ties within 2 us: the earlier one)
       }
-      c->chosen[c->num_chosen++] = pick;
-      if (report) *report = &c->chosen[c->num_chosen - 1];
+      // (a full table forgets its oldest entry: a caller stream handle may be long gone, or be probed again if it is not)
+      const int slot = c->num_chosen < kCallers ? c->num_chosen++ : c->next_evicted++ % kCallers;
+      c->chosen[slot] = pick;
+      if (report) *report = &c->chosen[slot];
     }
     static_cast<SideStreamHandles&>(*out) = c->cand[pick.index];
     return GP_OK;

@@ -259,6 +259,12 @@ def test_side_stream_is_the_candidate_that_does_not_wait_for_the_callers_grid(gp
         again, chosen2 = (C.c_float * 4)(), C.c_int(-1)
         _capi.check(lib.gp_debug_side_stream_probe(sp, again, C.byref(chosen2)), "gp_debug_side_stream_probe")
         assert list(again) == d and chosen2.value == chosen.value  # probed once per caller stream
+    # more caller streams than the per-thread table holds (16): the oldest entries make room, every caller still gets a probed choice
+    many = [torch.cuda.Stream() for _ in range(20)]
+    for st in many:
+        delays, chosen = (C.c_float * 4)(), C.c_int(-1)
+        _capi.check(lib.gp_debug_side_stream_probe(C.c_void_p(st.cuda_stream), delays, C.byref(chosen)), "gp_debug_side_stream_probe")
+        assert list(delays)[chosen.value] >= 0
     rng = np.random.default_rng(3)
     pts = np.concatenate([rng.uniform(-20, 20, (60_000, 3)) * [1, 1, 0.05], rng.uniform(-60, 60, (3_000, 3))]).astype(np.float32)
     a = gpu.PointCloudGPU(pts)
