@@ -752,9 +752,10 @@ def main():
     ap.add_argument("--c4-steps", type=int, default=30)
     ap.add_argument("--c4-exchange", choices=["all_gather", "all_reduce"], default="all_gather",
                     help="the c4 step's collective: all_gather = in place, half the bytes, no zeroing (falls back to the all-reduce when the shards are not equal contiguous ranges)")
-    ap.add_argument("--exchange", choices=["all_gather", "all_reduce"], default="all_gather",
-                    help="N > 1 headline step: the collective that exchanges the ranks' records (all_gather = in place, every row moved once, no zeroing of the stack: the default; "
-                         "all_reduce = the north star's wording: sum over the zeroed stack; falls back to it when the backend refuses the in-place gather)")
+    ap.add_argument("--exchange", choices=["peer", "all_gather", "all_reduce"], default="peer",
+                    help="N > 1 headline step: how the ranks' records are exchanged.  peer (default) = every rank stores its record straight into every peer's buffer over xGMI and "
+                         "flags its arrival, one single-workgroup kernel per step (csrc/gp_peer.hip; validated against known rows first, every rank falls back to all_gather together "
+                         "when the buffers cannot be shared); all_gather = RCCL, in place, every row moved once; all_reduce = the north star's wording: sum over the zeroed stack")
     ap.add_argument("--no-c4-inlib", action="store_true", help="skip the single-process multi-device leg of c4 (run in a subprocess by the N = 1 run when it sees > 1 device)")
     ap.add_argument("--c4-inlib-only", action="store_true", help="(internal) run only the single-process multi-device leg of c4 and print its JSON object")
     ap.add_argument("--finalize", choices=["fused", "two-kernel"], default="fused",
@@ -862,17 +863,26 @@ def main():
         pose_ptr = C.c_void_p(pose.ctypes.data)
         row_ptr = {}
 
-        def issue(poses_local, view):  # (pose array and row view are the same objects every step: their addresses are taken once)
-            if not row_ptr:
-                row_ptr[0] = C.c_void_p(view.data_ptr())
-            if issue_linearize(batch, pose_ptr, row_ptr[0]) != 0:
+        def issue(poses_local, view):  # (the row views are few objects -- one, or the peer exchange's two generations: their addresses are taken once)
+            p = row_ptr.get(id(view))
+            if p is None:
+                p = row_ptr[id(view)] = (C.c_void_p(view.data_ptr()), view)  # (the view is kept: its id stays its own)
+            if issue_linearize(batch, pose_ptr, p[0]) != 0:
                 _capi.check(1, "gp_vgicp_batch_issue_linearize")
 
-        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue, always_exchange=True, exchange=args.exchange)
+        sharded = ShardedLinearizer(world, (rank, rank + 1), device, issue, always_exchange=True, exchange=args.exchange, host_out=host_out)
+        with PhaseGuard(args.phase_seconds, "exchange set-up"):  # (the first pass decides the exchange, collectively: buffers shared and validated, or the fall-back agreed)
+            sharded.linearize(pose)
+            torch.cuda.synchronize()
+            sharded.check()
+        delivers = sharded.delivers_to_host
 
         def step():
-            stacked = sharded.linearize(pose)  # local kernels into the rank's row, ONE RCCL collective over xGMI (in-place all-gather; --exchange all_reduce: zero + all-reduce)
-            host_out.copy_(stacked, non_blocking=True)
+            # local kernels into the rank's row, then ONE exchange: direct stores into the peers' buffers over xGMI (the exchange kernel also fills host_out), or one RCCL
+            # collective (in-place all-gather; --exchange all_reduce: zero + all-reduce) and a D2H copy
+            stacked = sharded.linearize(pose)
+            if not delivers:
+                host_out.copy_(stacked, non_blocking=True)
             stream.synchronize()
 
     def barrier():
@@ -901,6 +911,8 @@ def main():
                 step()
             barrier()
             el = time.perf_counter() - t0
+            if dist_on:
+                sharded.check()  # (peer exchange: a peer that did not arrive within the kernel's time box is an error, not a stale stack)
             n_, su_, ku_ = C.c_double(), C.c_double(), C.c_double()
             lib.gp_vgicp_batch_device_times(batch, 0, C.byref(n_), C.byref(su_), C.byref(ku_))
             if dist_on:
@@ -1109,8 +1121,10 @@ def main():
                 num_voxels=info.num_voxels,
                 num_buckets=info.num_buckets,
                 inlier_fraction=round(rec.num_inliers / args.source_points, 4),
-                parallelism=f"{world} x 1 factor/GPU; RCCL {sharded.exchange} of stacked [N x 122] f64 records" if dist_on else "1 GPU",
-                exchange=(f"torch.distributed backend {dist.get_backend()}, world {world}, {sharded.exchange}" if dist_on else None),
+                parallelism=(f"{world} x 1 factor/GPU; " + ("direct stores of the [N x 122] f64 records into every peer's buffer over xGMI (gp_peer_exchange)" if sharded.exchange == "peer"
+                                                             else f"RCCL {sharded.exchange} of stacked [N x 122] f64 records")) if dist_on else "1 GPU",
+                exchange=(f"torch.distributed backend {dist.get_backend()}, world {world}, {sharded.exchange}" + (f" (peer exchange not taken: {sharded.peer_note})" if sharded.peer_note else "")
+                          if dist_on else None),
                 step="poses (host) -> tile kernel -> finalize kernel -> [N>1: ONE RCCL collective over the stacked records: in-place all-gather, or --exchange all_reduce] -> records in host memory, synchronised",
                 device_warmup=dict(ms=args.device_warmup_ms, steps=wake_steps,
                                    note="untimed, before the W warm-up steps: the same step run back to back until the device's power state has settled (the first ~10 ms of work "
@@ -1129,6 +1143,7 @@ def main():
     lib.gp_vgicp_batch_destroy(batch)
     if dist_on:
         with PhaseGuard(args.phase_seconds, "process group teardown"):
+            sharded.close()  # (peer exchange: the peers' buffers are unmapped behind a barrier)
             dist.barrier()
             dist.destroy_process_group()
     if rank == 0:

@@ -197,6 +197,14 @@ _SIGNATURES = {
     "gp_debug_expand_rigid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_debug_stream_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "gp_debug_multi_gather_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
+    "gp_peer_exchange_handle_bytes": (C.c_int, []),
+    "gp_peer_exchange_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "gp_peer_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gp_peer_exchange_rows": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gp_peer_exchange_begin": (C.c_int, [C.c_void_p]),
+    "gp_peer_exchange_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_peer_exchange_check": (C.c_int, [C.c_void_p]),
+    "gp_peer_exchange_destroy": (C.c_int, [C.c_void_p]),
     "gp_debug_side_stream_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "gp_debug_inject_sort_fault": (C.c_int, [C.c_int]),
     "gp_debug_sort_fallbacks": (C.c_int, []),

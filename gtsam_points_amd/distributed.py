@@ -8,10 +8,22 @@ records.  Each slot is written by exactly one rank, so the sum is exact (x + 0 +
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): the stack is tiny (4096 factors -> 4.0 MB f64), so the collective
 is latency-bound; it is issued once per linearise on the compute stream's successor, never per factor.
+
+Round 5: exchange="peer" -- for small stacks (the headline: one record per GPU) every rank stores its rows straight into every peer's buffer over xGMI and flags
+its arrival (gp_peer_exchange_*, csrc/gp_peer.hip): one single-workgroup kernel per step instead of a collective library's ring.  The buffers' IPC handles travel
+once through torch.distributed; the form is validated against the all-gather before it is used and every rank falls back together when anything fails.
 """
 import numpy as np
 
 RECORD_DOUBLES = 122  # gp_linearized6
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 def partition_factors(weights, world_size):
@@ -131,12 +143,15 @@ class ShardedLinearizer:
                                        stacked buffer (on GPUs: gp_vgicp_batch_issue_linearize with out_dev = view pointer)
     """
 
-    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False, exchange="all_reduce"):
+    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False, exchange="all_reduce", host_out=None):
         """stream: the torch.cuda.Stream the `issue` callback launches its kernels on (a torch.cuda.ExternalStream around the
         batch's hipStream_t when the batch owns its stream).  The zeroing of the stack, the kernels and the collective are then
         all ordered on that one stream; None = torch's current stream (CPU / gloo, or a batch created on torch's stream).
         exchange: "all_reduce" (the north star's: sum over the zeroed stack, any partition) or "all_gather" (in place, no zeroing, half the bytes: needs EQUAL
-        contiguous shards in rank order -- every rank passes the same total and its own [rank * n, (rank + 1) * n) -- and falls back to the all-reduce otherwise)."""
+        contiguous shards in rank order -- every rank passes the same total and its own [rank * n, (rank + 1) * n) -- and falls back to the all-reduce otherwise) or
+        "peer" (direct stores into every peer's buffer over xGMI, csrc/gp_peer.hip: the same plan as the all-gather, at most 8192 doubles per rank, 16 ranks; validated
+        against the all-gather once, falls back to it -- all ranks together -- when the buffers cannot be shared or the validation fails).
+        host_out: optional pinned [F_total x 122] f64 tensor; with the peer exchange the exchange kernel itself fills it (no D2H copy), see `delivers_to_host`."""
         import torch
 
         self.total = int(total_factors)
@@ -149,6 +164,11 @@ class ShardedLinearizer:
         # (a step is tens of microseconds: what does not change from call to call is looked up once)
         self.own_rows = self.stacked[self.begin : self.end] if self.end > self.begin else None
         self._want = exchange
+        self.host_out = host_out
+        self._px = None            # gp_peer_exchange handle when the peer form runs
+        self._px_stack = None      # its two generations as torch views [2][F_total x 122] into the library's buffer
+        self._px_own = None        # ... and this rank's rows of each
+        self.peer_note = None      # why the peer form was not taken (None: not asked for, or taken)
         self._exchange = None  # None = not decided yet: torch.distributed may be initialised after this object; decided by the first pass that finds it up
         self.exchange = "none"
 
@@ -165,8 +185,14 @@ class ShardedLinearizer:
         rank = dist.get_rank(self.group)
         self._exchange = world > 1 or self.always_exchange
         rows = self.end - self.begin
-        gather_ok = self._want == "all_gather" and rows > 0 and rows * world == self.total and self.begin == rank * rows
-        if self._exchange and self._want == "all_gather":
+        want_gather = self._want in ("all_gather", "peer")  # (the peer form needs the all-gather's plan and falls back to it)
+        gather_ok = want_gather and rows > 0 and rows * world == self.total and self.begin == rank * rows
+        if self._exchange and self._want == "peer":
+            self._setup_peer(world, rank, rows, gather_ok)
+            if self._px is not None:
+                self.exchange = "peer"
+                return self._exchange
+        if self._exchange and want_gather:
 
             def agreed(ok):
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.stacked.device)
@@ -188,6 +214,8 @@ class ShardedLinearizer:
         import torch.distributed as dist
 
         exchange = self._exchange if self._exchange is not None else self._decide()
+        if exchange and self.exchange == "peer":
+            return self._run_peer(poses_local)
         if exchange and self.exchange == "all_reduce":
             self.stacked.zero_()
         if self.own_rows is not None:
@@ -198,6 +226,131 @@ class ShardedLinearizer:
             else:
                 dist.all_reduce(self.stacked, op=dist.ReduceOp.SUM, group=self.group)
         return self.stacked
+
+    # ---- the peer form (gp_peer_exchange_*) ----
+    @property
+    def delivers_to_host(self):
+        """True when a pass leaves the complete stack in `host_out` by itself (the peer exchange with a host_out tensor): synchronise the stream, call check(), read host_out"""
+        return self._px is not None and self.host_out is not None
+
+    def check(self):
+        """after the stream's synchronisation: raises when a peer did not arrive within the exchange kernel's time box (peer form; a no-op otherwise)"""
+        if self._px is not None:
+            from . import _capi
+
+            _capi.check(_capi.load().gp_peer_exchange_check(self._px), "gp_peer_exchange_check")
+
+    def _stream_ptr(self):
+        import ctypes as C
+
+        import torch
+
+        st = self.stream if self.stream is not None else torch.cuda.current_stream(self.stacked.device)
+        return C.c_void_p(st.cuda_stream)
+
+    def _setup_peer(self, world, rank, rows, plan_ok):
+        """creates the buffers, exchanges their IPC handles, maps the peers, validates three exchanges against known rows; every decision is taken by all ranks together"""
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _capi
+
+        lib = _capi.load()
+        dev = self.stacked.device
+
+        def agreed(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(flag.item())
+
+        row_doubles = rows * RECORD_DOUBLES
+        if not agreed(plan_ok and dev.type == "cuda" and 0 < row_doubles <= 8192 and world <= 16):
+            self.peer_note = "plan not eligible (equal contiguous shards in rank order, <= 8192 doubles per rank, <= 16 ranks, CUDA device)"
+            return
+        px, ok, why = C.c_void_p(), True, None
+        nbytes = int(lib.gp_peer_exchange_handle_bytes())
+        handle = (C.c_char * nbytes)()
+        try:
+            _capi.check(lib.gp_peer_exchange_create(world, rank, row_doubles, C.byref(px), handle), "gp_peer_exchange_create")
+        except Exception as exc:  # (no IPC on this stack, no fine-grained memory ...)
+            ok, why = False, f"create: {exc}"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ok, bytes(handle.raw)), group=self.group)  # (always: every rank takes part, whatever its own outcome)
+        ok_all = all(g[0] for g in gathered)
+        if ok_all:
+            try:
+                blob = b"".join(g[1] for g in gathered)
+                _capi.check(lib.gp_peer_exchange_connect(px, blob), "gp_peer_exchange_connect")
+            except Exception as exc:
+                ok, why = False, f"connect: {exc}"
+        ok_all = agreed(ok_all and ok)
+        if ok_all:
+            # the two generations of the library's stack as torch tensors (the batch's kernels write this rank's rows through them)
+            views = []
+            for gen in (0, 1):
+                ptr = int(lib.gp_peer_exchange_rows(px, gen))
+
+                class _Raw:
+                    __cuda_array_interface__ = dict(shape=(self.total, RECORD_DOUBLES), typestr="<f8", data=(ptr, False), version=2, strides=None)
+
+                views.append(torch.as_tensor(_Raw(), device=dev))
+            # validation: three exchanges of rows every rank can predict, through a pinned host stack
+            probe_host = torch.zeros((self.total, RECORD_DOUBLES), dtype=torch.float64).pin_memory()
+            good = True
+            try:
+                for step in range(3):
+                    gen = int(lib.gp_peer_exchange_begin(px))
+                    mine = torch.arange(self.begin, self.end, dtype=torch.float64, device=dev)[:, None] * 1000.0 + torch.arange(RECORD_DOUBLES, dtype=torch.float64, device=dev)[None, :] + 0.5 * step
+                    with torch.cuda.stream(self.stream) if self.stream is not None else _nullcontext():
+                        views[gen][self.begin : self.end].copy_(mine)
+                        _capi.check(lib.gp_peer_exchange_finish(px, self._stream_ptr(), C.c_void_p(probe_host.data_ptr())), "gp_peer_exchange_finish")
+                    torch.cuda.synchronize(dev)
+                    _capi.check(lib.gp_peer_exchange_check(px), "gp_peer_exchange_check")
+                    want = torch.arange(self.total, dtype=torch.float64)[:, None] * 1000.0 + torch.arange(RECORD_DOUBLES, dtype=torch.float64)[None, :] + 0.5 * step
+                    good = good and bool(torch.equal(probe_host, want)) and bool(torch.equal(views[gen].cpu(), want))
+            except Exception as exc:
+                good, why = False, f"validation: {exc}"
+            ok_all = agreed(good)
+            if ok_all:
+                self._px, self._px_stack = px, views
+                self._px_own = [v[self.begin : self.end] for v in views]  # (the same two objects every step: callers may key on them)
+                return
+            why = why or "validation: the stack did not carry every rank's rows"
+        self.peer_note = why or "a peer could not share its buffer"
+        if px:
+            try:
+                dist.barrier(group=self.group)  # (nobody unmaps a buffer a peer's validation kernel may still write)
+            finally:
+                lib.gp_peer_exchange_destroy(px)
+
+    def _run_peer(self, poses_local):
+        import ctypes as C
+
+        from . import _capi
+
+        lib = _capi.load()
+        gen = int(lib.gp_peer_exchange_begin(self._px))
+        stack = self._px_stack[gen]
+        if self.end > self.begin:
+            self.issue(poses_local, self._px_own[gen])
+        _capi.check(lib.gp_peer_exchange_finish(self._px, self._stream_ptr(), C.c_void_p(self.host_out.data_ptr()) if self.host_out is not None else None), "gp_peer_exchange_finish")
+        return stack
+
+    def close(self):
+        """unmaps the peers' buffers (collective: every rank calls it)"""
+        if self._px is not None:
+            import torch
+            import torch.distributed as dist
+
+            from . import _capi
+
+            torch.cuda.synchronize(self.stacked.device)
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            _capi.load().gp_peer_exchange_destroy(self._px)
+            self._px, self._px_stack, self._px_own = None, None, None
 
     def linearize(self, poses_local):
         """Returns the stacked [F_total x 122] tensor holding every rank's records (device-resident)."""

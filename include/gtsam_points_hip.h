@@ -343,6 +343,26 @@ int gp_vgicp_multi_batch_compute_error(gp_vgicp_multi_batch_t* mb, const double*
 /* HIP-event times of the last pass: the slowest shard's kernels, and what followed them (all-reduce + D2H, or the host gather) */
 int gp_vgicp_multi_batch_last_timing(const gp_vgicp_multi_batch_t* mb, float* ms_compute, float* ms_exchange);
 
+/* ---- the exchange of the one-process-per-GPU form as direct stores over xGMI (gp_peer.hip; no reference counterpart: the reference has no multi-GPU code) ----
+ * Every rank needs every rank's records (north_star: "all-reduce of the stacked H blocks").  For small exchanges -- the headline's 8 x 976 B -- a collective library is all
+ * latency; here every rank stores its rows straight into a buffer of every peer (mapped through hipIpc handles the caller exchanges once), flags its arrival, waits for the
+ * peers' flags and hands the complete [world][row_doubles] stack to the host: one single-workgroup kernel per step and rank.  row_doubles <= 8192, world <= 16.
+ *   create   allocates this rank's buffer on the current device and writes its IPC handle (gp_peer_exchange_handle_bytes() bytes) to handle_out
+ *   connect  handles = [world][handle bytes] in rank order (the own entry is ignored): maps the peers' buffers
+ *   rows     this rank's [world][row_doubles] f64 stack of generation 0 / 1 on the device (two generations alternate; a rank's own rows go to row `rank`)
+ *   begin    starts a step: returns the generation (0 / 1) whose stack this step fills
+ *   finish   behind the kernels that wrote the rank's rows, on the same stream: the exchange kernel; host_out_pinned (may be NULL) = pinned [world][row_doubles] f64
+ *   check    after the stream's synchronisation: GP_OK, or an error when a peer did not arrive within the kernel's time box (2 s) */
+typedef struct gp_peer_exchange gp_peer_exchange_t;
+int gp_peer_exchange_handle_bytes(void);
+int gp_peer_exchange_create(int world, int rank, int row_doubles, gp_peer_exchange_t** out, void* handle_out);
+int gp_peer_exchange_connect(gp_peer_exchange_t* px, const void* handles);
+void* gp_peer_exchange_rows(gp_peer_exchange_t* px, int generation);
+int gp_peer_exchange_begin(gp_peer_exchange_t* px);
+int gp_peer_exchange_finish(gp_peer_exchange_t* px, gp_stream_t stream, double* host_out_pinned);
+int gp_peer_exchange_check(const gp_peer_exchange_t* px);
+int gp_peer_exchange_destroy(gp_peer_exchange_t* px);
+
 /* ---- exact k-NN, covariance estimation, GICP (BASELINE configs[4]; CPU-only upstream) ----
  * KdTree::knn_search (ann/small_kdtree.hpp:437-474, KnnResult ann/knn_result.hpp:36-117), estimate_covariances
  * (features/covariance_estimation.cpp:18-77), IntegratedGICPFactor (factors/impl/integrated_gicp_factor_impl.hpp:132-296) */
