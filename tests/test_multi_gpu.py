@@ -165,6 +165,7 @@ def test_bench_step_through_rccl_with_one_rank(gpu):
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     r = json.loads(line)
     assert r["n_gpus"] == 1 and "nccl" in r["config"]["exchange"]
+    assert r["config"]["exchange"].endswith("peer"), r["config"]["exchange"]  # the headline's exchange: direct stores into the peers' buffers (here: none), handles exchanged over the nccl group
     par = r["parity_vs_oracle"]
     assert par["num_inliers_equal"] and max(par[k] for k in ["H_target", "H_source", "H_target_source", "b_target", "b_source", "error"]) < 1e-6
     assert r["c4"]["factors"] == 4096 and r["c4"]["allreduce_ms"] > 0 and 0.3 < r["c4"]["inlier_fraction"] < 0.9
