@@ -230,3 +230,35 @@ def test_zero_factors_is_not_a_gather():
     lin = ShardedLinearizer(0, (0, 0), "cpu", lambda _p, _v: None, exchange="all_gather")
     out = lin.linearize(None)
     assert out.shape == (0, RECORD_DOUBLES) and lin.exchange == "none"
+
+
+def _worker_peer_on_cpu(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 6
+    begin, end = partition_factors([1000] * n, world)[rank]
+
+    def issue(_poses, view):
+        view.copy_(torch.from_numpy(_c4_records(range(begin, end))))
+
+    lin = ShardedLinearizer(n, (begin, end), "cpu", issue, exchange="peer")
+    a = lin.linearize(None).clone()
+    ret[rank] = (lin.exchange, lin.peer_note, lin.delivers_to_host, a.numpy())
+    lin.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_is_a_gpu_form_and_falls_back_collectively_on_cpu():
+    """exchange="peer" (direct stores into the peers' device buffers, csrc/gp_peer.hip) on CPU tensors: every rank agrees that the plan is not eligible and takes the all-gather"""
+    world = 2
+    port = 39500 + os.getpid() % 1500
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_peer_on_cpu, args=(world, port, ret), nprocs=world, join=True)
+    ref = _c4_records(range(6))
+    for r in range(world):
+        exchange, note, delivers, rows = ret[r]
+        assert exchange == "all_gather" and note and not delivers, ret[r][:3]
+        assert np.array_equal(rows, ref)
