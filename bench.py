@@ -8,8 +8,9 @@ Workload (config.workload): BASELINE.json configs[1] -- ONE VGICP factor per GPU
 2 M-point GaussianVoxelMap at 0.5 m (gtsam_points_amd.synthetic.make_c2_workload; rank r uses seed 42 + r).
 A "step" is one linearize() pass as the optimizer sees it.  N = 1: gp_vgicp_batch_linearize -- the pose rides in the kernel arguments, ONE launch (the
 tile kernel's last workgroups finalize, --finalize two-kernel for tile kernel + finalize kernel), records into host memory, the host polls completion
-words.  N > 1: pose -> tile kernel -> finalize kernel -> ONE RCCL collective over the stacked [N x 122] f64 record buffer over xGMI (in-place all-gather;
---exchange all_reduce: zeroed stack + all-reduce) -> D2H -> sync.
+words.  N > 1: pose -> tile kernel -> finalize kernel -> ONE exchange of the ranks' records over xGMI -> sync: by default every rank stores its record straight into every
+peer's buffer and flags its arrival (one single-workgroup kernel, which also writes the complete [N x 122] f64 stack to pinned host memory: csrc/gp_peer.hip; validated
+before use, all ranks fall back together); --exchange all_gather / all_reduce: ONE RCCL collective over the stacked record buffer (in place / zeroed stack + sum) -> D2H.
 Inputs (source cloud, voxel map) are resident in HBM before the timed region.  value = N * 1e6 * K / elapsed.
 Weak scaling: per-GPU work is fixed as N grows.
 
