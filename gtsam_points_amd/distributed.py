@@ -319,10 +319,13 @@ class ShardedLinearizer:
                 return
             why = why or "validation: the stack did not carry every rank's rows"
         self.peer_note = why or "a peer could not share its buffer"
-        if px:
-            try:
-                dist.barrier(group=self.group)  # (nobody unmaps a buffer a peer's validation kernel may still write)
-            finally:
+        # (every rank is here -- the decisions above were collective -- including those whose own buffer was never created: the barrier is everybody's;
+        # nobody unmaps a buffer a peer's validation kernel may still write)
+        torch.cuda.synchronize(dev)
+        try:
+            dist.barrier(group=self.group)
+        finally:
+            if px:
                 lib.gp_peer_exchange_destroy(px)
 
     def _run_peer(self, poses_local):

@@ -19,7 +19,7 @@ def _rows(ids, step):
     return ids[:, None] * 1000.0 + np.arange(RECORD, dtype=np.float64)[None, :] + 0.25 * step
 
 
-def _worker(rank, world, port, rows, want, steps, ret):
+def _worker(rank, world, port, rows, want, steps, ret, sabotage=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -28,6 +28,10 @@ def _worker(rank, world, port, rows, want, steps, ret):
     from gtsam_points_amd.distributed import ShardedLinearizer
 
     torch.cuda.set_device(0)
+    if sabotage and rank == 1:  # one rank cannot create / map the buffers: everybody must notice and fall back, nobody may hang
+        from gtsam_points_amd import _capi
+
+        setattr(_capi.load(), sabotage, lambda *a: 4)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     total = world * rows
     begin, end = rank * rows, (rank + 1) * rows
@@ -76,5 +80,18 @@ def test_peer_exchange_falls_back_together_when_the_plan_does_not_qualify():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, rows, "peer", 3, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r][0] == "all_gather" and ret[r][1], ret[r]
+
+
+@pytest.mark.parametrize("sabotage", ["gp_peer_exchange_create", "gp_peer_exchange_connect"])
+def test_peer_exchange_falls_back_together_when_one_rank_cannot_share(sabotage):
+    """a rank whose buffer cannot be created (no IPC, no fine-grained memory) or that cannot map a peer's: the set-up's decisions are collective -- every rank takes the
+    all-gather, the records are the same, and the clean-up's barrier is everybody's (also the rank's that never had a buffer)"""
+    world = 3
+    port = 40500 + (os.getpid() + len(sabotage)) % 1500
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, 1, "peer", 4, ret, sabotage), nprocs=world, join=True)
     for r in range(world):
         assert ret[r][0] == "all_gather" and ret[r][1], ret[r]
