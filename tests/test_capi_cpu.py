@@ -198,3 +198,20 @@ def test_gather_send_offsets_follow_the_plan_not_the_container():
         assert got_rows.value == 0, assign
     got_rows = C.c_int64()
     assert lib.gp_debug_multi_gather_plan(np.asarray([0, 3], np.int32).ctypes.data, 2, 3, 122, C.byref(got_rows), np.zeros(3, np.int64).ctypes.data) != 0
+
+
+def test_peer_exchange_rejects_bad_plans_without_a_device():
+    """gp_peer_exchange_create (csrc/gp_peer.hip): the limits of the direct-store exchange are checked before anything touches a device -- world 1 .. 16, a rank inside it,
+    1 .. 8192 doubles per rank, a place for the IPC handle; the handle is hipIpcMemHandle_t's 64 bytes"""
+    import ctypes as C
+
+    from gtsam_points_amd import _capi
+
+    lib = _capi.load()
+    assert lib.gp_peer_exchange_handle_bytes() == 64
+    handle = (C.c_char * 64)()
+    for world, rank, rows, h in [(0, 0, 122, handle), (17, 0, 122, handle), (4, 4, 122, handle), (4, -1, 122, handle), (4, 0, 0, handle), (4, 0, 8193, handle), (4, 0, 122, None)]:
+        px = C.c_void_p()
+        assert lib.gp_peer_exchange_create(world, rank, rows, C.byref(px), h) == 1 and not px.value  # (GP_ERROR_INVALID_ARGUMENT), (world, rank, rows)
+    assert lib.gp_peer_exchange_begin(None) == -1 and lib.gp_peer_exchange_rows(None, 0) is None
+    assert lib.gp_peer_exchange_finish(None, None, None) == 1 and lib.gp_peer_exchange_destroy(None) == 0
