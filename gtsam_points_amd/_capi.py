@@ -202,6 +202,7 @@ _SIGNATURES = {
     "gp_peer_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_peer_exchange_rows": (C.c_void_p, [C.c_void_p, C.c_int]),
     "gp_peer_exchange_begin": (C.c_int, [C.c_void_p]),
+    "gp_peer_exchange_set_timeout_ms": (C.c_int, [C.c_void_p, C.c_double]),
     "gp_peer_exchange_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_peer_exchange_check": (C.c_int, [C.c_void_p]),
     "gp_peer_exchange_destroy": (C.c_int, [C.c_void_p]),

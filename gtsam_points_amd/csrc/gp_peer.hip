@@ -21,13 +21,15 @@
 namespace gp {
 constexpr int kPeerMaxWorld = 16;
 constexpr int kPeerMaxRowDoubles = 8192;        // per rank and step: small, latency-bound exchanges (larger ones are bandwidth: the collective library's job)
-constexpr unsigned long long kPeerWaitTicks = 200000000ull;  // 2 s on the 100 MHz clock: a peer that has not arrived by then is not coming
+constexpr unsigned long long kPeerWaitTicksDefault = 200000000ull;  // 2 s on the 100 MHz clock: a peer that has not arrived by then is not coming (gp_peer_exchange_set_timeout_ms)
+constexpr unsigned long long kPeerPoison = ~0ull;                   // arrival word of a rank that gave up: its peers fail in the SAME step instead of the next one
 
 struct PeerView {
   int world, rank, row_doubles;
-  unsigned long long seq;
+  unsigned long long seq, wait_ticks;
   double* rows[kPeerMaxWorld];              // [world][row_doubles] of this step's generation: [rank] = own buffer, the others = the peers' buffers (mapped)
   unsigned long long* arrived[kPeerMaxWorld];  // [world] arrival words of this step's generation, same indexing
+  unsigned long long* arrived_other[kPeerMaxWorld];  // ... and of the other generation (only written when this rank gives up)
   double* host_out;                         // pinned [world][row_doubles], may be null
   unsigned long long* host_done;            // pinned: the sequence number when the stack is complete; ~0 when a peer did not arrive
 };
@@ -49,8 +51,10 @@ __global__ void __launch_bounds__(256) peer_exchange_kernel(const PeerView v) {
   if (t < v.world && t != v.rank) {
     __hip_atomic_store(v.arrived[t] + v.rank, v.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(v.arrived[v.rank] + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != v.seq) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kPeerWaitTicks) {
+    for (;;) {
+      const unsigned long long a = __hip_atomic_load(v.arrived[v.rank] + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a == v.seq) break;
+      if (a == kPeerPoison || __builtin_amdgcn_s_memrealtime() - t0 > v.wait_ticks) {  // the peer gave up, or never came
         failed = 1;
         break;
       }
@@ -58,6 +62,12 @@ __global__ void __launch_bounds__(256) peer_exchange_kernel(const PeerView v) {
     }
   }
   __syncthreads();
+  // a rank that gives up says so in every peer's arrival word (its own word of this step is already out, so without this the peers would complete the step and
+  // fail only in the next one); the words stay poisoned: the exchange is broken for good and every later step fails at once on every rank
+  if (failed && t < v.world && t != v.rank) {
+    __hip_atomic_store(v.arrived[t] + v.rank, kPeerPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(v.arrived_other[t]) + v.rank, kPeerPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   // 4. the stack to the host
   if (v.host_out && !failed)
@@ -70,16 +80,23 @@ __global__ void __launch_bounds__(256) peer_exchange_kernel(const PeerView v) {
 
 struct gp_peer_exchange {
   int world = 0, rank = 0, row_doubles = 0, device = 0;
-  unsigned long long seq = 0;
+  unsigned long long seq = 0, wait_ticks = gp::kPeerWaitTicksDefault;
   void* own = nullptr;                       // [2][world][row_doubles] f64, then [2][kPeerMaxWorld] arrival words
   void* peer[gp::kPeerMaxWorld] = {};        // the peers' `own`, mapped into this process (peer[rank] = own)
   bool opened[gp::kPeerMaxWorld] = {};
+  const double* validated_host = nullptr;    // the last host_out that was found to be pinned host memory
   gp::PinnedArray done;                      // [1] sequence number of the last finished exchange
   size_t rows_bytes() const { return sizeof(double) * 2 * (size_t)world * (size_t)row_doubles; }
   size_t total_bytes() const { return rows_bytes() + sizeof(unsigned long long) * 2 * gp::kPeerMaxWorld; }
   double* rows_of(void* base, int gen) const { return reinterpret_cast<double*>(base) + (size_t)gen * world * row_doubles; }
   unsigned long long* arrived_of(void* base, int gen) const {
     return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(base) + rows_bytes()) + (size_t)gen * gp::kPeerMaxWorld;
+  }
+  ~gp_peer_exchange() {  // (every error path of create / connect ends here: nothing is leaked)
+    for (int p = 0; p < world; p++)
+      if (opened[p] && peer[p]) (void)hipIpcCloseMemHandle(peer[p]);
+    if (own) (void)hipFree(own);
+    (void)hipGetLastError();
   }
 };
 
@@ -111,7 +128,6 @@ int gp_peer_exchange_create(int world, int rank, int row_doubles, gp_peer_exchan
   hipIpcMemHandle_t h;
   if (hipIpcGetMemHandle(&h, px->own) != hipSuccess) {
     (void)hipGetLastError();
-    (void)hipFree(px->own);
     return gp::fail(GP_ERROR_HIP, "gp_peer_exchange_create: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this stack)");
   }
   memcpy(handle_out, &h, sizeof(h));
@@ -139,27 +155,45 @@ int gp_peer_exchange_connect(gp_peer_exchange_t* px, const void* handles) {
   return GP_OK;
 }
 
+// The step's sequence number advances in gp_peer_exchange_finish, when the exchange kernel has been launched -- not here (a caller whose own kernels fail
+// between begin and finish must not leave this rank one generation ahead of its peers for good).  begin only names the generation the NEXT exchange will use.
 int gp_peer_exchange_begin(gp_peer_exchange_t* px) {
   if (!px) return -1;
-  px->seq++;
-  return (int)(px->seq & 1ull);
+  return (int)((px->seq + 1) & 1ull);
+}
+
+int gp_peer_exchange_set_timeout_ms(gp_peer_exchange_t* px, double ms) {
+  if (!px || !(ms > 0.0) || ms > 3.6e6) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_peer_exchange_set_timeout_ms: 0 < ms <= 3.6e6");
+  px->wait_ticks = (unsigned long long)(ms * 1e5);  // 100 MHz constant clock
+  return GP_OK;
 }
 
 int gp_peer_exchange_finish(gp_peer_exchange_t* px, gp_stream_t stream, double* host_out_pinned) {
-  if (!px || px->seq == 0) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_peer_exchange_finish: call gp_peer_exchange_begin first");
+  if (!px) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_peer_exchange_finish: null");
   for (int p = 0; p < px->world; p++)
     if (!px->peer[p]) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_peer_exchange_finish: connect the peers first");
+  if (host_out_pinned && host_out_pinned != px->validated_host) {  // the kernel stores world x row_doubles doubles through this pointer: it must be host memory the device can address (pinned / registered)
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, host_out_pinned) != hipSuccess || attr.type != hipMemoryTypeHost) {
+      (void)hipGetLastError();
+      return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_peer_exchange_finish: host_out must be pinned host memory of world x row_doubles doubles");
+    }
+    px->validated_host = host_out_pinned;  // (asked once per buffer: a step is tens of microseconds)
+  }
   gp::PeerView v{};
-  v.world = px->world, v.rank = px->rank, v.row_doubles = px->row_doubles, v.seq = px->seq;
-  const int gen = (int)(px->seq & 1ull);
+  const unsigned long long seq = px->seq + 1;
+  v.world = px->world, v.rank = px->rank, v.row_doubles = px->row_doubles, v.seq = seq, v.wait_ticks = px->wait_ticks;
+  const int gen = (int)(seq & 1ull);
   for (int p = 0; p < px->world; p++) {
     v.rows[p] = px->rows_of(px->peer[p], gen);
     v.arrived[p] = px->arrived_of(px->peer[p], gen);
+    v.arrived_other[p] = px->arrived_of(px->peer[p], gen ^ 1);
   }
   v.host_out = host_out_pinned;
   v.host_done = px->done.as<unsigned long long>();
   hipLaunchKernelGGL(gp::peer_exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v);
   GP_HIP(hipGetLastError());
+  px->seq = seq;  // (launched: the step exists)
   return GP_OK;
 }
 
@@ -179,11 +213,7 @@ void* gp_peer_exchange_rows(gp_peer_exchange_t* px, int generation) {
 int gp_peer_exchange_destroy(gp_peer_exchange_t* px) {
   if (!px) return GP_OK;
   (void)hipDeviceSynchronize();
-  for (int p = 0; p < px->world; p++)
-    if (px->opened[p] && px->peer[p]) (void)hipIpcCloseMemHandle(px->peer[p]);
-  if (px->own) (void)hipFree(px->own);
-  (void)hipGetLastError();
-  delete px;
+  delete px;  // (the destructor unmaps the peers and frees the buffer)
   return GP_OK;
 }
 

@@ -50,6 +50,55 @@ def partition_factors(weights, world_size):
     return out
 
 
+def record_digests(rows):
+    """SHA-256 of every [122] f64 record of `rows` ([n x 122] host array): what the ranks tell one another about the records they computed"""
+    import hashlib
+
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    return [hashlib.sha256(rows[i].tobytes()).hexdigest() for i in range(rows.shape[0])]
+
+
+def verify_exchanged_stack(stack_host, own_rows_host, begin, end, group=None):
+    """Is the exchanged stack, on EVERY rank, bit for bit what the ranks computed?  Collective (every rank calls it; works on any backend: objects only).
+      stack_host     [F_total x 122] f64 host array: the stack this rank holds after the exchange
+      own_rows_host  [(end - begin) x 122] f64: the records this rank computed by itself, NOT taken from the stack
+    Every rank publishes the SHA-256 of its own records (all_gather_object), checks all rows of its stack against the digests of the rank that owns them, and the
+    verdicts are gathered again so that every rank returns the same answer: (verified, {rank: [bad global rows]} for the ranks that found any).
+    A row nobody claims, or claimed twice, fails.  Without an initialised process group the check is local (one rank)."""
+    import torch.distributed as dist
+
+    stack = np.ascontiguousarray(stack_host, dtype=np.float64)
+    mine = (int(begin), int(end), record_digests(own_rows_host))
+    if int(end) - int(begin) != len(mine[2]):
+        raise ValueError("verify_exchanged_stack: own_rows_host must hold end - begin records")
+    up = dist.is_available() and dist.is_initialized()
+    if up:
+        claims = [None] * dist.get_world_size(group)
+        dist.all_gather_object(claims, mine, group=group)
+        me = dist.get_rank(group)
+    else:
+        claims, me = [mine], 0
+    want = [None] * stack.shape[0]
+    bad = set()
+    for b, e, digests in claims:
+        for k, dg in zip(range(b, e), digests):
+            if not (0 <= k < len(want)) or want[k] is not None:
+                bad.add(min(max(k, 0), len(want) - 1))  # out of range, or two owners
+            else:
+                want[k] = dg
+    got = record_digests(stack)
+    bad.update(k for k in range(len(want)) if want[k] is None or want[k] != got[k])
+    verdict = sorted(bad)
+    if up:
+        verdicts = [None] * len(claims)
+        dist.all_gather_object(verdicts, verdict, group=group)
+    else:
+        verdicts = [verdict]
+    by_rank = {r: v for r, v in enumerate(verdicts) if v}
+    del me
+    return (not by_rank), by_rank
+
+
 class MultiDeviceBatch:
     """gp_vgicp_multi_batch_*: a factor list sharded over the GPUs of one node from ONE process (the form a C++ optimizer
     process uses; `ShardedLinearizer` below is the one-process-per-GPU form bench.py is launched in).
@@ -143,7 +192,7 @@ class ShardedLinearizer:
                                        stacked buffer (on GPUs: gp_vgicp_batch_issue_linearize with out_dev = view pointer)
     """
 
-    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False, exchange="all_reduce", host_out=None):
+    def __init__(self, total_factors, slot_range, device, issue, group=None, stream=None, always_exchange=False, exchange="all_reduce", host_out=None, peer_timeout_ms=None):
         """stream: the torch.cuda.Stream the `issue` callback launches its kernels on (a torch.cuda.ExternalStream around the
         batch's hipStream_t when the batch owns its stream).  The zeroing of the stack, the kernels and the collective are then
         all ordered on that one stream; None = torch's current stream (CPU / gloo, or a batch created on torch's stream).
@@ -151,8 +200,20 @@ class ShardedLinearizer:
         contiguous shards in rank order -- every rank passes the same total and its own [rank * n, (rank + 1) * n) -- and falls back to the all-reduce otherwise) or
         "peer" (direct stores into every peer's buffer over xGMI, csrc/gp_peer.hip: the same plan as the all-gather, at most 8192 doubles per rank, 16 ranks; validated
         against the all-gather once, falls back to it -- all ranks together -- when the buffers cannot be shared or the validation fails).
-        host_out: optional pinned [F_total x 122] f64 tensor; with the peer exchange the exchange kernel itself fills it (no D2H copy), see `delivers_to_host`."""
+        host_out: optional pinned [F_total x 122] f64 tensor; with the peer exchange the exchange kernel itself fills it (no D2H copy), see `delivers_to_host`.
+        peer_timeout_ms: the time box a rank's exchange kernel waits for its peers (peer form; default 2000 ms -- a rank skew above it is an ERROR there, where a
+        collective would wait: raise it under a debugger).  A rank that gives up poisons its peers' arrival words: all ranks fail in the same step, check() raises, and
+        the exchange stays broken (build a new ShardedLinearizer with exchange="all_gather").
+        The peer form maps the peers' buffers: call close() on every rank (collective) when done; an object dropped without it unmaps on its own, without the barrier."""
         import torch
+
+        if host_out is not None:  # the peer form's kernel stores F_total x 122 doubles through its raw pointer (ADVICE r05): refuse anything that is not exactly that
+            if not (isinstance(host_out, torch.Tensor) and host_out.dtype == torch.float64 and tuple(host_out.shape) == (int(total_factors), RECORD_DOUBLES)
+                    and host_out.is_contiguous() and host_out.device.type == "cpu"):
+                raise ValueError(f"host_out must be a contiguous float64 host tensor of shape ({int(total_factors)}, {RECORD_DOUBLES})")
+            if exchange == "peer" and torch.device(device).type == "cuda" and not host_out.is_pinned():
+                raise ValueError("host_out must be pinned memory for the peer exchange (torch.Tensor.pin_memory())")
+        self.peer_timeout_ms = float(peer_timeout_ms) if peer_timeout_ms else None
 
         self.total = int(total_factors)
         self.begin, self.end = int(slot_range[0]), int(slot_range[1])
@@ -314,6 +375,8 @@ class ShardedLinearizer:
                 good, why = False, f"validation: {exc}"
             ok_all = agreed(good)
             if ok_all:
+                if self.peer_timeout_ms:
+                    _capi.check(lib.gp_peer_exchange_set_timeout_ms(px, self.peer_timeout_ms), "gp_peer_exchange_set_timeout_ms")
                 self._px, self._px_stack = px, views
                 self._px_own = [v[self.begin : self.end] for v in views]  # (the same two objects every step: callers may key on them)
                 return
@@ -334,8 +397,8 @@ class ShardedLinearizer:
         from . import _capi
 
         lib = _capi.load()
-        gen = int(lib.gp_peer_exchange_begin(self._px))
-        stack = self._px_stack[gen]
+        gen = int(lib.gp_peer_exchange_begin(self._px))  # (names the generation; the step advances in finish, once the exchange kernel is launched: an `issue` that
+        stack = self._px_stack[gen]                      #  raises leaves this rank in step with its peers)
         if self.end > self.begin:
             self.issue(poses_local, self._px_own[gen])
         _capi.check(lib.gp_peer_exchange_finish(self._px, self._stream_ptr(), C.c_void_p(self.host_out.data_ptr()) if self.host_out is not None else None), "gp_peer_exchange_finish")
@@ -354,6 +417,17 @@ class ShardedLinearizer:
                 dist.barrier(group=self.group)
             _capi.load().gp_peer_exchange_destroy(self._px)
             self._px, self._px_stack, self._px_own = None, None, None
+
+    def __del__(self):  # (last resort: no barrier here -- close() is the collective form)
+        px = getattr(self, "_px", None)
+        if px is not None:
+            try:
+                from . import _capi
+
+                _capi.load().gp_peer_exchange_destroy(px)
+            except Exception:
+                pass
+            self._px = None
 
     def linearize(self, poses_local):
         """Returns the stacked [F_total x 122] tensor holding every rank's records (device-resident)."""

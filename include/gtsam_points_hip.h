@@ -350,15 +350,21 @@ int gp_vgicp_multi_batch_last_timing(const gp_vgicp_multi_batch_t* mb, float* ms
  *   create   allocates this rank's buffer on the current device and writes its IPC handle (gp_peer_exchange_handle_bytes() bytes) to handle_out
  *   connect  handles = [world][handle bytes] in rank order (the own entry is ignored): maps the peers' buffers
  *   rows     this rank's [world][row_doubles] f64 stack of generation 0 / 1 on the device (two generations alternate; a rank's own rows go to row `rank`)
- *   begin    starts a step: returns the generation (0 / 1) whose stack this step fills
+ *   begin    names the generation (0 / 1) whose stack the NEXT exchange fills; does not advance the step (a caller whose own kernels fail between begin and finish
+ *            leaves the exchange where it was)
  *   finish   behind the kernels that wrote the rank's rows, on the same stream: the exchange kernel; host_out_pinned (may be NULL) = pinned [world][row_doubles] f64
- *   check    after the stream's synchronisation: GP_OK, or an error when a peer did not arrive within the kernel's time box (2 s) */
+ *            (checked: pageable or device memory is GP_ERROR_INVALID_ARGUMENT).  The step's sequence number advances here, once the kernel is launched
+ *   check    after the stream's synchronisation: GP_OK, or an error when a peer did not arrive within the kernel's time box.  A rank that gives up poisons its
+ *            arrival words at every peer, so all ranks fail in the same step; the exchange is then broken for good (destroy it, fall back to a collective)
+ *   set_timeout_ms   the time box a rank waits for its peers (default 2000 ms; a rank skew above it -- a debugger, a long GC pause -- is an error here where a
+ *            collective would wait) */
 typedef struct gp_peer_exchange gp_peer_exchange_t;
 int gp_peer_exchange_handle_bytes(void);
 int gp_peer_exchange_create(int world, int rank, int row_doubles, gp_peer_exchange_t** out, void* handle_out);
 int gp_peer_exchange_connect(gp_peer_exchange_t* px, const void* handles);
 void* gp_peer_exchange_rows(gp_peer_exchange_t* px, int generation);
 int gp_peer_exchange_begin(gp_peer_exchange_t* px);
+int gp_peer_exchange_set_timeout_ms(gp_peer_exchange_t* px, double ms);
 int gp_peer_exchange_finish(gp_peer_exchange_t* px, gp_stream_t stream, double* host_out_pinned);
 int gp_peer_exchange_check(const gp_peer_exchange_t* px);
 int gp_peer_exchange_destroy(gp_peer_exchange_t* px);
