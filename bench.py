@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--budget-seconds", type=float, default=45.0, help="wall-clock budget of the whole run: an optional leg starts only while its estimate still fits")
     ap.add_argument("--detail", action="store_true", help="run every optional leg whatever it costs (no budget; the LM legs with the full CPU loop and all three solvers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU baseline: seconds of repeated linearize() passes (bounded sample)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU baseline: seconds of repeated linearize() passes (bounded sample)")
     ap.add_argument("--kernel-iters", type=int, default=50)
     ap.add_argument("--no-c4", action="store_true", help="skip the sharded 4096-factor configuration (BASELINE configs[3])")
     ap.add_argument("--c4-steps", type=int, default=30)
@@ -602,18 +602,18 @@ def main():
             cpu_baseline = dict(
                 value=round(args.source_points / med, 1), unit="point-correspondences/s", cores=cores, cores_available=avail, kind="reference" if use_ref else "port",
                 sample=f"{len(times)} linearize() passes, {cores} threads", ms_per_linearize=round(med * 1e3, 3), ms_per_linearize_1thread=round(float(np.median(t1)) * 1e3, 3),
-                cores_note="threads chosen by a probe over {all, 1/2, 1/4, 32, 16} of the threads the box reports (pick_cpu_threads): the count that serves the reference's code best",
+                cores_note="threads chosen by a probe over {all, 1/2, 32, 16} of the threads the box reports (pick_cpu_threads): the count that serves the reference's code best",
                 sample_note=f"{len(times)} full linearize() passes of the same 1M-pt factor (median {med * 1e3:.2f} ms); 1 thread: {np.median(t1) * 1e3:.2f} ms over {len(t1)} passes")
         del fo, om
 
     # ---- optional legs, most valuable first, while the budget lasts ----
     single = rank == 0 and world == 1 and not dist_on
     traffic_detail = rocprof_detail = None
-    if single and not args.no_rocprof and want("rocprof", 9.0):
+    if single and not args.no_rocprof and want("rocprof", 5.0):
         rocprof_detail = measure_rocprof(args)
         if rocprof_detail.get("avg_ms"):
             roofline.update(rocprof_avg_ms=rocprof_detail["avg_ms"], rocprof_calls=rocprof_detail["calls"], frac_rocprof=_frac(rocprof_detail["avg_ms"]))
-    if single and not args.no_traffic and want("traffic", 10.0):
+    if single and not args.no_traffic and want("traffic", 8.5):
         traffic_detail = measure_traffic(args)
         if traffic_detail.get("hbm_bytes_per_launch"):
             roofline.update(traffic=traffic_detail["hbm_bytes_per_launch"], traffic_source=traffic_detail["source"])
@@ -622,10 +622,10 @@ def main():
     configs = big_source = c4 = None
     if single and not args.no_configs:
         try:
-            configs = bench_detail.run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream, want=want)
+            configs = bench_detail.run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream, want=want, target_cloud=tgt if args.target_points == 2_000_000 else None)
         except Exception as exc:  # the headline must survive an optional leg
             configs = dict(error=f"{type(exc).__name__}: {exc}")
-    if single and not args.no_configs and not args.no_big_source and want("big_source", 7.0):
+    if single and not args.no_configs and not args.no_big_source and want("big_source", 6.0):
         try:
             big_source = bench_detail.run_big_source(args, lib, gpa, _capi, synthetic, torch, device, stream)
         except Exception as exc:  # (memory on a shared box)
