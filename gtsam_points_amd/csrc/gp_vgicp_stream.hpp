@@ -50,12 +50,14 @@ struct WaveWork {
 
 // a workgroup's points [begin, begin + count) -> its four waves: the full chunks are dealt as evenly as they go (the first `extra` waves take
 // one more), the points behind the last full chunk go to the last wave
+template <int W = 4>
 __device__ __forceinline__ WaveWork split_tile(int begin, int count, int wave) {
-  const int chunks = count >> 6, base = chunks >> 2, extra = chunks & 3;
+  static_assert(W == 4 || W == 8 || W == 16, "waves per workgroup");
+  const int chunks = count >> 6, base = chunks / W, extra = chunks % W;  // (W is a power of two: shift and mask)
   WaveWork ww;
   ww.first = (size_t)begin + (size_t)(wave * base + (wave < extra ? wave : extra)) * kChunkPoints;
   ww.n = base + (wave < extra ? 1 : 0);
-  ww.tail = wave == 3 ? (count & 63) : 0;
+  ww.tail = wave == W - 1 ? (count & 63) : 0;
   return ww;
 }
 
@@ -89,7 +91,9 @@ __device__ __forceinline__ void finalize_part_rows(const double* __restrict__ pa
   // read past this CU's L1 and the XCD's L2 view of other XCDs' lines (sc1), all of a lane's rows requested in one batch
   const unsigned long long* base = reinterpret_cast<const unsigned long long*>(partials + (size_t)row_begin * ACC_STRIDE + comp);
   double total = 0.0;
-  for (int t0 = slice; t0 < row_count; t0 += 32 * kSlices) {
+  // (wide workgroups, W > 4: the first four waves do what the 256 threads of the narrow form do -- the same order, the same bits as the split finalize kernel --
+  // the others only meet them at the barrier)
+  for (int t0 = slice; t0 < row_count && wave < 4; t0 += 32 * kSlices) {
     double v[32];
 #pragma unroll
     for (int k = 0; k < 32; k++) {
@@ -105,7 +109,7 @@ __device__ __forceinline__ void finalize_part_rows(const double* __restrict__ pa
   }
   total += __shfl_xor(total, 32, 64);  // the wave's two slices
   if (tr && threadIdx.x == 0) tr[14] = __builtin_amdgcn_s_memrealtime();
-  if (lane < 32) wsum[wave * 32 + lane] = total;
+  if (lane < 32 && wave < 4) wsum[wave * 32 + lane] = total;
   __syncthreads();
   if (wave != 0) return;
   // the record slot and the completion word are host-mapped (uncached on this side): the sums go out as system-scope stores, the word follows
@@ -126,11 +130,11 @@ __device__ __forceinline__ void finalize_part_error(const double* __restrict__ p
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long* base = reinterpret_cast<const unsigned long long*>(partials + (size_t)row_begin * ACC_STRIDE + ACC_ERR);
   double s = 0.0;
-  for (int t = threadIdx.x; t < row_count; t += 256)
+  for (int t = threadIdx.x; t < row_count && wave < 4; t += 256)  // (wide workgroups: the first four waves, as above)
     s += __builtin_bit_cast(double, __hip_atomic_load(base + (size_t)t * ACC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) wsum[wave] = s;
+  if (lane == 0 && wave < 4) wsum[wave] = s;
   __syncthreads();
   if (threadIdx.x != 0) return;
   const double total = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
@@ -141,8 +145,11 @@ __device__ __forceinline__ void finalize_part_error(const double* __restrict__ p
 // EXP (measurement instantiations of round 5, never the default; GP_TUNE_EXPERIMENT selects them for a synchronous planned single-factor linearise):
 //   1 = every workgroup touches its share of the map's block grid right behind its first request, so that an XCD's L2 holds the whole grid (1 MB for the headline map)
 //       by the time the first hop 1 asks for it (VERDICT r04 #1b: the cold first chunk);  2 = R C_A R^T in f32 (accumulate_core2<ROT32>: the upper bound of #1c)
-template <int MODE, bool NT, bool INL, bool SV, bool PK, bool TRACE = false, int EXP = 0>
-__global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
+// W (round 6): waves per workgroup.  4 = the product geometry (1024 workgroups of 256 threads for a planned launch, four per compute unit);
+//   16 = ONE 1024-thread workgroup per compute unit (256 workgroups: a quarter of the dispatches, partial rows and arrivals; the sixteen waves' sums meet in LDS in
+//   a fixed pairwise tree), 8 = two per compute unit.  Same waves, same rings, same per-wave schedule: only who shares a row changes.
+template <int MODE, bool NT, bool INL, bool SV, bool PK, bool TRACE = false, int EXP = 0, int W = 4>
+__global__ void __launch_bounds__(64 * W, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,
                                                                double* __restrict__ partials) {
   static_assert(MODE == MODE_LIN || MODE == MODE_ERR, "rigid linearise and error evaluation");
@@ -158,7 +165,8 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   constexpr int kRingBytes = 2 * kChunkSlotBytes + 2 * kNrmSlotBytes;
   constexpr int kWaveBytes = kRingBytes > kWaveLdsBytes ? kRingBytes : kWaveLdsBytes;  // 10 KB for the unpacked stream with normals, else 8.5 KB (the reduction's)
   static_assert(kWaveBytes >= kWaveLdsBytes, "the reduction needs 8.5 KB of the wave's region");
-  __shared__ __attribute__((aligned(16))) char smem[4 * kWaveBytes];
+  static_assert(W * kWaveBytes <= 160 * 1024, "one workgroup's rings must fit the compute unit's LDS");
+  __shared__ __attribute__((aligned(16))) char smem[W * kWaveBytes];
   const unsigned long long t_begin = INL ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz constant clock; used by the fused form's own time stamps (below)
   // ---- what the first source request needs, in as few dependent scalar-load round trips as possible.  The in-argument form reads every field
   // it may need -- the plan's entries for this workgroup included -- up front and pins them with an empty asm: left alone, hipcc sinks those loads
@@ -200,7 +208,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     f.normals = fnrm;
     f.packed = fpk;
     row = tile_idx;
-    ww = split_tile(begin, count, wave);
+    ww = split_tile<W>(begin, count, wave);
   } else {
     if (inl.xcd_chunk > 0) {
       const int c = inl.xcd_chunk;
@@ -214,7 +222,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
     f = factors[tile.factor];
     factor_idx = tile.factor;
     row = tile.row;
-    ww = split_tile(__builtin_amdgcn_readfirstlane(tile.begin), __builtin_amdgcn_readfirstlane(tile.count), wave);
+    ww = split_tile<W>(__builtin_amdgcn_readfirstlane(tile.begin), __builtin_amdgcn_readfirstlane(tile.count), wave);
   }
   unsigned long long* trace = TRACE ? inl.trace : nullptr;
   GP_TRACE(0);
@@ -506,11 +514,23 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
   if (threadIdx.x < ACC_STRIDE) {
     double sum = 0.0;
     if (threadIdx.x < (MODE == MODE_ERR ? 2 : ACC_SIZE)) {
-      const double* w0 = reinterpret_cast<const double*>(smem + 1 * kWaveBytes - 32 * 8);
-      const double* w1 = reinterpret_cast<const double*>(smem + 2 * kWaveBytes - 32 * 8);
-      const double* w2 = reinterpret_cast<const double*>(smem + 3 * kWaveBytes - 32 * 8);
-      const double* w3 = reinterpret_cast<const double*>(smem + 4 * kWaveBytes - 32 * 8);
-      sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
+      if constexpr (W == 4) {
+        const double* w0 = reinterpret_cast<const double*>(smem + 1 * kWaveBytes - 32 * 8);
+        const double* w1 = reinterpret_cast<const double*>(smem + 2 * kWaveBytes - 32 * 8);
+        const double* w2 = reinterpret_cast<const double*>(smem + 3 * kWaveBytes - 32 * 8);
+        const double* w3 = reinterpret_cast<const double*>(smem + 4 * kWaveBytes - 32 * 8);
+        sum = (w0[threadIdx.x] + w1[threadIdx.x]) + (w2[threadIdx.x] + w3[threadIdx.x]);
+      } else {  // fixed pairwise tree over the W waves in wave order: ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)) ...
+        double v[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) v[k] = reinterpret_cast<const double*>(smem + (k + 1) * kWaveBytes - 32 * 8)[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < W; w <<= 1) {
+#pragma unroll
+          for (int k = 0; k < W; k += 2 * w) v[k] += v[k + w];
+        }
+        sum = v[0];
+      }
     }
     GP_GLOBAL double* dst = (GP_GLOBAL double*)partials + (size_t)row * ACC_STRIDE + threadIdx.x;
     if (inl.arrive) {
@@ -526,7 +546,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
       unsigned long long* tr = nullptr;
       if constexpr (TRACE) tr = trace ? trace + (size_t)tile_idx * 16 : nullptr;
       const int part = row / inl.rows_per_part;
-      int* const last = reinterpret_cast<int*>(smem + 4 * kWaveBytes - 32 * 8 - 16);  // below wave 3's sums: nothing lives there any more
+      int* const last = reinterpret_cast<int*>(smem + W * kWaveBytes - 32 * 8 - 16);  // below the last wave's sums: nothing lives there any more
       if (threadIdx.x == 0) {
         if (tr) tr[12] = __builtin_amdgcn_s_memrealtime();
         // one counter per part, 4 KB apart: device-scope atomics on ONE line retire at ~12 ns apiece (MI355X_MICROARCH.md, fanin), 1024 of them would be 12 us
@@ -545,7 +565,7 @@ __global__ void __launch_bounds__(256, 4) vgicp_stream_kernel(const FactorDesc* 
                              *reinterpret_cast<const unsigned long long*>(last + 2));
       }
     }
-  } else if (inl.arrive) {
+  } else if (W == 4 && inl.arrive) {  // (wide workgroups exist for planned single-factor launches only: the host never arms this form for them)
     // fused finalize by FACTOR (synchronous batched calls, small single factors): the workgroup that stores a factor's last row sums the factor's rows and
     // expands them into the record -- rigid_slice_total / rigid_wave_tree / rigid_expand_wave in the order of vgicp_finalize_rigid_kernel<1024>, whose 32
     // slices of rows are taken four to a thread here -- and hands record and completion word to the host while the other factors' tiles are still running:
