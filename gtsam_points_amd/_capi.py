@@ -225,7 +225,6 @@ GP_TUNE_TEST_ARRIVAL_SKEW = 20
 GP_TUNE_SOURCE_MIRROR, GP_TUNE_EFFECTIVE_MIRROR = 21, 22
 GP_TUNE_EXPERIMENT = 23
 GP_TUNE_BUCKET_LOAD = 24
-GP_TUNE_WG_WAVES, GP_TUNE_EFFECTIVE_WG_WAVES = 25, 26
 GP_TUNE_MAP_BUILD, GP_TUNE_KNN_STRUCTURE = 16, 32
 KERNEL_FAMILIES = [GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_STREAM]
 

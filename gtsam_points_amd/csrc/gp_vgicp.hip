@@ -457,7 +457,6 @@ struct gp_vgicp_tuning {
                                   // workgroups on a second stream waiting for the counters, cost +10 us per step: profiles/r03_overlap_finalize.jsonl)
   int balance = kDefaultSkewPermille;  // stream kernel, one large factor: how much more a dispatch round takes than the next, in 1/1000 of the mean share (0 = flat)
   int experiment = 0;             // GP_TUNE_EXPERIMENT: measurement instantiations of the stream kernel (gp_vgicp_stream.hpp, EXP), 0 = the product kernel
-  int wg_waves = 4;               // GP_TUNE_WG_WAVES: waves per workgroup of a planned single-factor launch of the stream family (4, 8, 16; round 6: measurement of the wide geometries)
   int source_mirror = 1;          // stream family: stream the sources' packed mirrors (36 B per point, gp::SourceMirror) when every factor of the batch has one; 0 = the caller's arrays
 };
 
@@ -491,7 +490,6 @@ struct gp_vgicp_batch {
   bool nt = false;        // source stream non-temporal (tuning.source_policy resolved)
   bool any_sv = false;    // some factor validates surfaces
   bool packed = false;    // every factor streams its packed mirror (vgicp_stream_kernel<PK>)
-  int wg_waves = 4;       // waves per workgroup the planned launch runs with (tuning.wg_waves where its instantiation exists, else 4)
   bool planned = false;   // stream kernel, one large factor: the tile list is a balanced StreamPlan (else fixed tiles of tile_points)
   gp::StreamPlan plan{};  // ... how the chunks are dealt (also written into the tile table)
   unsigned long long* trace = nullptr;  // timeline build of the tile kernel: [2048][16] uint64 device buffer (gp_vgicp_batch_set_trace_buffer)
@@ -571,6 +569,7 @@ struct PoseSource {
 // 1 + (mean offset - offset) / 6 us: the table below (mean of the two boxes' offsets).  Last end 12.8 -> 11.8-11.9 us in the traced build.
 // GP_TUNE_XCD_WEIGHT_0 + x overrides.
 constexpr int kXcdWeightPermille[gp::kNumXCD] = {1090, 1070, 1045, 1025, 905, 935, 950, 980};
+// waves = waves per workgroup: 4 in the product; the 8- / 16-wave geometries of round 6 (gp_vgicp_stream.hpp, W) were planned through the same function
 int make_stream_plan(int n, int skew_permille, const int* xcd_weights, gp::StreamPlan* p, int max_wgs = kResidentWorkgroups, int waves = 4) {
   const int C = n / gp::kChunkPoints;
   max_wgs = std::min(max_wgs, kResidentWorkgroups * 4 / waves);  // one resident round: 16 waves per compute unit
@@ -716,12 +715,7 @@ int build_table(gp_vgicp_batch* b) {
   b->planned = fam == GP_KERNEL_STREAM && F == 1 && descs[0].n >= kPlanMinPoints;
   if (b->planned) {
     // one large factor: the balanced plan; the table holds the same tiles the in-argument launch derives from the plan (plan_tile)
-    // wide workgroups (round 6): instantiated for the headline's shape only -- packed non-temporal stream, no surface validation -- and from 16 chunks per wave-slot
-    // of a full launch up, so that the fused finalize still has its parts (the geometry must not depend on anything but n where bit-identity across variants is
-    // promised: the measurement knob is off by default)
-    b->wg_waves = 4;
-    if (b->tuning.wg_waves != 4 && b->packed && !b->any_sv && descs[0].n >= 64 * b->tuning.wg_waves * (kResidentWorkgroups * 4 / b->tuning.wg_waves)) b->wg_waves = b->tuning.wg_waves;
-    const int G = make_stream_plan(descs[0].n, b->tuning.balance, b->tuning.xcd_weights_set ? b->tuning.xcd_weights : nullptr, &b->plan, b->tuning.max_wgs, b->wg_waves);
+    const int G = make_stream_plan(descs[0].n, b->tuning.balance, b->tuning.xcd_weights_set ? b->tuning.xcd_weights : nullptr, &b->plan, b->tuning.max_wgs);
     b->ppt = 4;
     b->tile_points = 0;
     descs[0].tile_begin = 0;
@@ -860,8 +854,7 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
   // the reference-shaped kernels (the 92-sum path included) keep the contiguous map
   // ... and so does every in-argument launch of the stream kernel (its fixed-tile branch knows no other map)
   const int chunk = (fam == GP_KERNEL_REFERENCE || single_plan || (fam == GP_KERNEL_STREAM && ps.inl.use)) ? 0 : b->tuning.xcd_chunk;
-  const bool wide = single_plan && b->wg_waves > 4 && fam == GP_KERNEL_STREAM && MODE != gp::MODE_LIN_GENERAL;  // (build_table: packed stream, no surface validation)
-  const dim3 grid_dim(grid_tiles(b->num_tiles, chunk)), block(wide ? 64 * b->wg_waves : gp::kBlockThreads);
+  const dim3 grid_dim(grid_tiles(b->num_tiles, chunk)), block(gp::kBlockThreads);
   const gp::FactorDesc* fd = b->d_factors.as<gp::FactorDesc>();
   const gp::TileDesc* td = b->d_tiles.as<gp::TileDesc>();
   gp::InlinePoses inl = ps.inl;
@@ -888,22 +881,7 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       else GP_LAUNCH_STREAM(false, INL, SV, false, false);           \
     }                                                                \
   } while (0)
-    if (wide) {
-      // round 6 measurement geometries: 8- / 16-wave workgroups, <MODE, NT, INL, SV = false, PK = true, TRACE = false, EXP = 0, W>
-#define GP_LAUNCH_WIDE(WW)                                                                                                      \
-  do {                                                                                                                          \
-    if (b->nt) {                                                                                                                \
-      if (inl.use) hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, true, true, false, true, false, 0, WW>), GP_ARGS);         \
-      else hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, true, false, false, true, false, 0, WW>), GP_ARGS);                \
-    } else {                                                                                                                    \
-      if (inl.use) hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, false, true, false, true, false, 0, WW>), GP_ARGS);        \
-      else hipLaunchKernelGGL((gp::vgicp_stream_kernel<MODE, false, false, false, true, false, 0, WW>), GP_ARGS);               \
-    }                                                                                                                           \
-  } while (0)
-      if (b->wg_waves == 16) GP_LAUNCH_WIDE(16);
-      else GP_LAUNCH_WIDE(8);
-#undef GP_LAUNCH_WIDE
-    } else if (traced && !b->any_sv) {
+    if (traced && !b->any_sv) {
       if constexpr (MODE == gp::MODE_LIN) {
         if (b->packed) {
           if (b->nt) GP_LAUNCH_STREAM(true, true, false, true, true);
@@ -1106,10 +1084,6 @@ static int apply_tuning(gp_vgicp_tuning* t, int key, int value) {
     case GP_TUNE_SOURCE_MIRROR:
       t->source_mirror = value ? 1 : 0;
       return GP_OK;
-    case GP_TUNE_WG_WAVES:
-      if (value != 4 && value != 8 && value != 16) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_WG_WAVES: 4, 8 or 16 waves per workgroup");
-      t->wg_waves = value;
-      return GP_OK;
     case GP_TUNE_EXPERIMENT:
       if (value < 0 || value > 2) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "GP_TUNE_EXPERIMENT: 0 (off), 1 (block-grid warm-up), 2 (f32 covariance rotation: breaks parity, timing only)");
       t->experiment = value;
@@ -1163,8 +1137,6 @@ int gp_vgicp_batch_get_tuning(const gp_vgicp_batch_t* b, int key, int* value) {
     case GP_TUNE_EFFECTIVE_KERNEL: *value = b->table_dirty ? -1 : b->family; return GP_OK;  // what the last table build resolved GP_TUNE_KERNEL to
     case GP_TUNE_SOURCE_MIRROR: *value = b->tuning.source_mirror; return GP_OK;
     case GP_TUNE_EXPERIMENT: *value = b->tuning.experiment; return GP_OK;
-    case GP_TUNE_WG_WAVES: *value = b->tuning.wg_waves; return GP_OK;
-    case GP_TUNE_EFFECTIVE_WG_WAVES: *value = b->table_dirty ? -1 : (b->planned ? b->wg_waves : 4); return GP_OK;
     case GP_TUNE_EFFECTIVE_MIRROR: *value = b->table_dirty ? -1 : (b->packed ? 1 : 0); return GP_OK;  // does the built table stream the packed mirrors?
     default: return gp::fail(GP_ERROR_INVALID_ARGUMENT, "unknown GP_TUNE_* key");
   }

@@ -148,6 +148,9 @@ __device__ __forceinline__ void finalize_part_error(const double* __restrict__ p
 // W (round 6): waves per workgroup.  4 = the product geometry (1024 workgroups of 256 threads for a planned launch, four per compute unit);
 //   16 = ONE 1024-thread workgroup per compute unit (256 workgroups: a quarter of the dispatches, partial rows and arrivals; the sixteen waves' sums meet in LDS in
 //   a fixed pairwise tree), 8 = two per compute unit.  Same waves, same rings, same per-wave schedule: only who shares a row changes.
+//   MEASURED AND NOT ADOPTED (profiles/r06_wg_geometry.jsonl, r06_wg_geometry_kernel_stats.csv; commit 1af148a carries the launch code and the GP_TUNE_WG_WAVES knob):
+//   in step, alternating, whole fused kernel 12.40-12.46 us (W = 4) / 12.41 (16) / 12.40-12.51 (8); rocprofv3 averages 14.09 / 14.23 / 13.95 us -- the fused tail is a
+//   latency chain (row store -> arrival -> loads -> sums over PCIe), not a count of rows or dispatches.  Only W = 4 is instantiated.
 template <int MODE, bool NT, bool INL, bool SV, bool PK, bool TRACE = false, int EXP = 0, int W = 4>
 __global__ void __launch_bounds__(64 * W, 4) vgicp_stream_kernel(const FactorDesc* __restrict__ factors, const TileDesc* __restrict__ tiles, int num_tiles,
                                                                const double* __restrict__ poses_lin, const double* __restrict__ poses_eval, const InlinePoses inl,

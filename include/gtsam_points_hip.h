@@ -525,10 +525,6 @@ enum {
   GP_TUNE_TIMING = 7,           /* measurement: 1 = gp_vgicp_batch_linearize brackets its two kernels with HIP events (gp_vgicp_batch_last_kernel_ms) */
   GP_TUNE_MAP_BUILD = 16,       /* gp_voxelmap: 1 = reference-shaped hashed build (atomicCAS claims + atomic sums; also the fallback of clouds whose
                                    bounding box is too large for the block grid), 0 = binned deterministic build (default) */
-  GP_TUNE_WG_WAVES = 25,        /* stream family, one large factor (planned launch, packed stream, no surface validation, >= 262144 points): waves per workgroup, 4 (default:
-                                   1024 workgroups of 256 threads), 8 or 16 (ONE 1024-thread workgroup per compute unit: a quarter of the dispatches, partial rows and arrivals).
-                                   Round 6 measurement knob (profiles/r06_wg_geometry.jsonl); records differ between geometries at the 1e-16 level, each is bit-reproducible */
-  GP_TUNE_EFFECTIVE_WG_WAVES = 26, /* read-only: the waves per workgroup the batch's current table launches with (-1 before the first pass) */
   GP_TUNE_BUCKET_LOAD = 24,     /* gp_voxelmap (binned build): load factor in per cent (5 .. 90, default 33) at which the reference-visible bucket table enters the reference's doubling
                                    sequence (gaussian_voxelmap_gpu.cu:269-291).  At 50 .. 67 % some probe chain among 10^5 voxels exceeds max_bucket_scan_count almost surely and the failed
                                    attempt costs a fill + an insertion pass + a wait; 33 % means up to twice the entries (16 B each) of a table sized at 67 % */

@@ -2,6 +2,7 @@
 the kernel's own 100 MHz stamps inside the steps (streaming part, whole fused kernel), host wall per step; per geometry also fused == two-kernel bit for bit, the error
 evaluation against the 4-wave form, and the relative difference of the record to the 4-wave record (different partition: ~1e-16).  One JSON object per line.
 Run under `rocprofv3 --kernel-trace --stats` for the profiler's per-kernel averages (the geometries are different instantiations, so one run separates them).
+Needs the library of commit 1af148a (GP_TUNE_WG_WAVES = 25 and the W = 8 / 16 instantiations were removed again: not adopted).
 Usage: python scripts/r06/wg_geometry.py [--points N] [--steps K] [--reps R]"""
 import ctypes as C
 import json
@@ -44,14 +45,14 @@ for rep in range(REPS):
         batch, s = C.c_void_p(), C.c_void_p()
         lib.gp_stream_create(C.byref(s))
         _capi.check(lib.gp_vgicp_batch_create(arr, 1, s, C.byref(batch)), "batch")
-        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, _capi.GP_TUNE_WG_WAVES, waves), "wg waves")
+        _capi.check(lib.gp_vgicp_batch_set_tuning(batch, 25, waves), "wg waves")
         lin = lib.gp_vgicp_batch_linearize
         pp, op = C.c_void_p(pose.ctypes.data), C.c_void_p(out.ctypes.data)
         t_w = time.perf_counter()
         while time.perf_counter() - t_w < 0.2:
             _capi.check(lin(batch, pp, op), "linearize")
         eff = C.c_int(-1)
-        lib.gp_vgicp_batch_get_tuning(batch, _capi.GP_TUNE_EFFECTIVE_WG_WAVES, C.byref(eff))
+        lib.gp_vgicp_batch_get_tuning(batch, 26, C.byref(eff))
         if ref is None:
             ref = out.copy()
         rel = float(np.abs(out - ref).max() / np.abs(ref).max())
