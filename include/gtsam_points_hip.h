@@ -470,8 +470,8 @@ int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_
 /* ---- per-handle tuning (not part of the reference API) --------------------------------------------------------------------------
  * Every knob below belongs to ONE batch / factor / map / search structure; the library keeps no process-global switches, so two
  * handles driven from two threads never see each other's settings (thread-compatible per handle, re-entrant across
- * handles; tests/test_vgicp_gpu.py::test_two_threads_two_batches).  The library reads ONE environment variable, GP_KNN_DEBUG: when set, the structure builds print
- * their host-side timing split to stderr; nothing that is computed or launched depends on the environment (the A/B variables of rounds 2-3 are gone).
+ * handles; tests/test_vgicp_gpu.py::test_two_threads_two_batches).  The library reads NO environment variable (no getenv in csrc/): nothing that is
+ * computed, launched or printed depends on the environment (the A/B variables of rounds 2-3 and GP_KNN_DEBUG are gone; tests/test_capi_cpu.py greps for it).
  *
  * GP_TUNE_KERNEL selects the tile-kernel family of a VGICP batch.  M = (C_B + R C_A R^T)^-1, the transform and the residual are f64
  * in every family; "f32 outer products" computes what follows the inverse in f32 (measured parity vs the CPU factor <= 1e-7
@@ -482,11 +482,8 @@ int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_
  *   GP_KERNEL_LOOKAHEAD  round-2 pipeline kernel (block grid, f32 outer products, look-ahead lookup): maps with >= 2^26 voxels
  *   GP_KERNEL_STREAM     third generation (csrc/gp_vgicp_stream.hpp): per-wave chunk streams, balanced single-factor launches,
  *                        surface validation inside the ring.  Default.
- * Environment switches read once at first use (A/B only): GP_POSES_ZERO_COPY=0 (synchronous batched calls upload poses with
- * hipMemcpyAsync instead of letting the kernels read the pinned staging buffer), GP_FINALIZE_PARTS=n (workgroups sharing the finalize
- * of a synchronous single-factor call, default 8), GP_FINALIZE_NARROW=0 (those workgroups with 1024 instead of 256 threads),
- * GP_FINALIZE_HOST_EXPAND=0 (they expand the 6x6 blocks themselves instead of handing their sums to the host), GP_GICP_SPLIT=0 (GICP
- * factor: fused search + algebra kernel instead of the correspondence kernel + algebra kernel). */
+ * (The A/B switches of rounds 2-3 -- poses by copy engine, finalize parts / width / host expansion, the fused GICP kernel -- were measured, decided and removed:
+ *  profiles/r02_*, r03_*, DESIGN.md.) */
 enum {
   GP_KERNEL_REFERENCE = 0,
   GP_KERNEL_HASHED = 2,

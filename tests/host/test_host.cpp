@@ -100,6 +100,15 @@ public:
   std::shared_ptr<IntegratedVGICPFactorGPU> inner;
 };
 
+// a factor the GPU set must decline (isam2_ext.cpp:110-116: `if (hook->add(f)) ... else f->linearize(theta)`)
+class HostOnlyFactor : public gtsam::NonlinearFactor {
+public:
+  HostOnlyFactor() : gtsam::NonlinearFactor(gtsam::KeyVector{1}) {}
+  size_t dim() const override { return 6; }
+  double error(const gtsam::Values&) const override { return 0.0; }
+  gtsam::GaussianFactor::shared_ptr linearize(const gtsam::Values&) const override { return nullptr; }
+};
+
 int main() {
   int ndev = 0;
   CHECK(gp_device_count(&ndev) == GP_OK && ndev > 0);
@@ -382,6 +391,50 @@ int main() {
     }
     CHECK(covered == 10 && worst == 3);
     gp_shard_plan_destroy(plan);
+  }
+  // the ISAM2Ext cadence through the REFERENCE's LinearizationHook (isam2_ext.cpp; the optimizer itself needs GTSAM's ISAM2 and is not compiled here):
+  //   :52        a default-constructed hook (one set per registered factory), empty
+  //   :88-129    clear(); per candidate factor add(factor) -> true: a GPU factor, kept for the batched pass; false: the caller linearises it on the host;
+  //              then calc_linear_factors(theta) returns the GPU factors' Hessians IN THE ORDER OF THE ADDS
+  //   :434       clear_counts()
+  //   :451-454   clear(); add(graph); linearize(theta); error(estimate)   (:236-238, :480-482, :494-497 are the same calls)
+  //   :504-505   linearization_count() / evaluation_count() into the result
+  {
+    LinearizationHook ihook;
+    CHECK(ihook.size() == 0);
+    ihook.clear();
+    gtsam::NonlinearFactor::shared_ptr host_only = std::make_shared<HostOnlyFactor>();
+    std::vector<int> gpu_indices;
+    std::vector<gtsam::NonlinearFactor::shared_ptr> candidates = {factor_b, host_only, factor};
+    for (int idx = 0; idx < 3; idx++)
+      if (ihook.add(candidates[(size_t)idx])) gpu_indices.push_back(idx);
+    CHECK(gpu_indices.size() == 2 && gpu_indices[0] == 0 && gpu_indices[1] == 2 && ihook.size() == 2);  // the host-only factor was declined
+    auto lin = ihook.calc_linear_factors(values);
+    CHECK(lin.size() == 2);
+    auto h0 = std::dynamic_pointer_cast<gtsam::HessianFactor>(lin[0]);
+    auto h1 = std::dynamic_pointer_cast<gtsam::HessianFactor>(lin[1]);
+    CHECK(h0 && h1 && h0->binary && !h1->binary);  // add order: the binary factor first, then the unary one
+    CHECK(h0->f == ref_lin->f);
+    for (int k = 0; k < 36; k++) CHECK(h0->G11.data()[k] == ref_lin->G11.data()[k] && h0->G22.data()[k] == ref_lin->G22.data()[k] && h0->G12.data()[k] == ref_lin->G12.data()[k]);
+    CHECK(ihook.linearization_count() > 0);
+    ihook.clear_counts();
+    CHECK(ihook.linearization_count() == 0 && ihook.evaluation_count() == 0);
+    ihook.clear();
+    CHECK(ihook.size() == 0);
+    gtsam::NonlinearFactorGraph all;
+    all.push_back(factor);
+    all.push_back(host_only);
+    all.push_back(factor_b);
+    ihook.add(all);
+    CHECK(ihook.size() == 2);
+    ihook.linearize(values);
+    ihook.error(values);
+    CHECK(ihook.linearization_count() == 2 && ihook.evaluation_count() == 2);
+    const double e_cached = factor_b->error(values);  // (consumes the value the batched pass left: integrated_vgicp_factor_gpu.cpp:166-170)
+    CHECK(std::fabs(e_cached - ref_lin->f) <= 1e-9 * std::fabs(ref_lin->f));
+    (void)factor->error(values);
+    (void)factor->linearize(values);
+    (void)factor_b->linearize(values);
   }
   roundrobin.sync_all();
   std::printf("HOST_TEST_OK\n");

@@ -215,3 +215,21 @@ def test_peer_exchange_rejects_bad_plans_without_a_device():
         assert lib.gp_peer_exchange_create(world, rank, rows, C.byref(px), h) == 1 and not px.value  # (GP_ERROR_INVALID_ARGUMENT), (world, rank, rows)
     assert lib.gp_peer_exchange_begin(None) == -1 and lib.gp_peer_exchange_rows(None, 0) is None
     assert lib.gp_peer_exchange_finish(None, None, None) == 1 and lib.gp_peer_exchange_destroy(None) == 0
+
+
+def test_the_product_reads_no_environment_variable():
+    """the boundary header once documented environment switches the library no longer has.  No getenv in the product's translation units (the tune library
+    gp_microbench.hip is measurement code, linked separately), and the header says so instead of listing switches."""
+    import glob
+    import re
+
+    csrc = os.path.join(ROOT, "gtsam_points_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(ROOT, "gtsam_points_amd", "host", "*"))):
+        if os.path.basename(path) == "gp_microbench.hip":
+            continue
+        text = open(path, encoding="utf-8", errors="replace").read()
+        assert not re.search(r"\bgetenv\s*\(", text), path
+    header = open(os.path.join(ROOT, "include", "gtsam_points_hip.h"), encoding="utf-8").read()
+    assert "reads NO environment variable" in header
+    for gone in ("GP_POSES_ZERO_COPY", "GP_FINALIZE_PARTS", "GP_FINALIZE_NARROW", "GP_FINALIZE_HOST_EXPAND", "GP_GICP_SPLIT"):
+        assert gone not in header, gone
