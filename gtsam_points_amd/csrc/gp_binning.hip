@@ -205,8 +205,17 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
   __shared__ unsigned long long wave_sum[4];
   __shared__ unsigned long long tile_prefix;
   const int tile = blockIdx.x;
-  // a sort pass that gave up a wait (gp_sort.hpp, draw_tile) voids this build: the host must learn it even if the garbage keys leave no thread to report the counts
-  if (tile == 0 && threadIdx.x == 0 && radix_sort_faults(sort_state, sort_pass_words, sort_passes)) host_counts[11] = 1;
+  // A sort pass that gave up a wait (gp_sort.hpp, draw_tile) voids this build: its output has holes -- whatever the pooled buffer held -- and NOTHING may be indexed with
+  // such keys (`blocks[kk >> 6]`, `occ_blocks[bo]`, `cell_start[ord]` below were, out of bounds, before the host had seen the fault).  Every tile asks first
+  // (the passes are complete: same answer everywhere, scalar loads) and leaves; tile 0 tells the host, which builds again through the one-class sort.
+  if (radix_sort_faults(sort_state, sort_pass_words, sort_passes)) {
+    if (tile == 0 && threadIdx.x == 0) {
+      host_counts[11] = 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      host_counts[HostWords::kFlag] = seq;
+    }
+    return;
+  }
   GP_SORT_STAMP(tile, 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)tile * kCellsTile + (long long)threadIdx.x * kCellsPerThread;
@@ -296,7 +305,6 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
   if (end_at >= 0) {
     cell_start[cells_end] = end_at;
     host_counts[8] = end_at, host_counts[9] = cells_end, host_counts[10] = blocks_end;
-    if (radix_sort_faults(sort_state, sort_pass_words, sort_passes)) host_counts[11] = 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counts are in host memory before the flag is stored (HostWords::wait_flag)
     host_counts[HostWords::kFlag] = seq;
   }
@@ -306,11 +314,15 @@ __global__ void __launch_bounds__(256) bins_cells_kernel(const unsigned* __restr
 
 namespace {
 thread_local int g_inject_sort_faults = 0;  // test hook: the next so many builds of this thread see a faulted sort (gp_debug_inject_sort_fault)
+thread_local bool g_inject_corrupt = false;  // ... whose first tile also leaves garbage keys behind (count < 0)
 thread_local int g_sort_fallbacks = 0;      // builds of this thread that went through the one-class sort
 int bin_points_once(const float* points_dev, int n, double inv_cell, hipStream_t s, PointBins* bins, bool* too_large, int ticket_classes, bool* sort_fault);
 }  // namespace
 
-void inject_sort_faults(int count) { g_inject_sort_faults = count; }
+void inject_sort_faults(int count) {
+  g_inject_sort_faults = count < 0 ? -count : count;
+  g_inject_corrupt = count < 0;
+}
 int sort_fallbacks() { return g_sort_fallbacks; }
 
 int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, PointBins* bins, bool* too_large) {
@@ -318,7 +330,7 @@ int bin_points(const float* points_dev, int n, double inv_cell, hipStream_t s, P
   int classes = kSortTicketClasses;
   if (g_inject_sort_faults > 0) {
     g_inject_sort_faults--;
-    classes = -kSortTicketClasses;
+    classes = -kSortTicketClasses - (g_inject_corrupt ? kSortCorruptHook : 0);
   }
   GP_TRY(bin_points_once(points_dev, n, inv_cell, s, bins, too_large, classes, &fault));
   if (!fault) return GP_OK;
@@ -466,7 +478,7 @@ int bin_points_once(const float* points_dev, int n, double inv_cell, hipStream_t
 
 extern "C" {
 int gp_debug_inject_sort_fault(int count) {
-  gp::inject_sort_faults(count < 0 ? 0 : count);
+  gp::inject_sort_faults(count);
   return GP_OK;
 }
 int gp_debug_sort_fallbacks(void) { return gp::sort_fallbacks(); }

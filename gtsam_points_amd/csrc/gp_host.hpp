@@ -406,6 +406,7 @@ struct HostSlots {
   }
 };
 
+void release_side_streams();  // gp_knn.hip (SideStream): what gp_trim_device_cache releases beside the parked blocks
 }  // namespace gp
 
 // TempBufferManager (cuda/stream_temp_buffer_roundrobin.cu:11-47)

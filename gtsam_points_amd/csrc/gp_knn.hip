@@ -2070,9 +2070,12 @@ namespace gp {
 // caller on queue 1 and the side stream on queue 3 the second covariance launch starts 8 us after the first; on queue 5 (the same process after bench.py's C4 phase had
 // taken queues 2-4) it starts when the first launch's last workgroup is placed, 100 / 160 us later on the two 1 M-point clouds -- 0.07 ms per call.  HIP does not say
 // which queue a stream gets, so the library asks the device: up to four low-priority streams are created (each gets a queue of its own from the runtime's pool for that
-// priority), and for every caller stream each candidate is probed ONCE -- a grid of 6144 workgroups that holds two LDS-bound workgroups per CU for ~5 us each on the
-// caller's stream, and one wave on the candidate that reports how long after the grid's first workgroup it got to run (~1 us on another pipe, the grid's whole dispatch
-// on the same one).  The candidate with the shortest delay serves that caller stream from then on (per thread and device; ~0.4 ms once).
+// priority), and the candidates are probed ONCE per host thread and device, beside the first caller stream that thread brings -- a grid of 6144 workgroups that holds two
+// LDS-bound workgroups per CU for ~5 us each on the caller's stream, and one wave on the candidate that reports how long after the grid's first workgroup it got to run
+// (~1 us on another pipe, the grid's whole dispatch on the same one).  The candidate with the shortest delay serves the thread's calls on that device from then on
+// (~0.4 ms once).  Round 5 probed per caller stream (a 16-entry table keyed on the raw handle): an application that cycles streams re-paid 0.4 ms per new handle to save
+// 0.07 ms per call, and a recycled handle inherited a stale choice -- a later caller stream on another pipe now simply keeps the first choice (correct either
+// way: the choice only decides whether the two launches overlap).  gp_trim_device_cache() releases the thread's candidate streams, events and probe words.
 __global__ void __launch_bounds__(256) pipe_probe_hog_kernel(unsigned long long* __restrict__ words, int ticks) {
   __shared__ float pad[12 * 1024];  // 48 KB: three workgroups per CU (160 KB of LDS), the wave slots stay free for the probe's wave
   pad[threadIdx.x * 48] = (float)threadIdx.x;
@@ -2094,7 +2097,7 @@ struct SideStreamHandles {
   hipEvent_t fork = nullptr, join = nullptr;
 };
 struct SideStream : SideStreamHandles {
-  static constexpr int kCandidates = 4, kCallers = 16;
+  static constexpr int kCandidates = 4;
   struct PerDevice {
     SideStreamHandles cand[kCandidates];
     int num = 0;
@@ -2103,10 +2106,23 @@ struct SideStream : SideStreamHandles {
       hipStream_t caller;
       int index;
       float delay_us[kCandidates];
-    } chosen[kCallers];
-    int num_chosen = 0, next_evicted = 0;
+    } chosen{nullptr, 0, {-1.f, -1.f, -1.f, -1.f}};
+    bool probed = false;
     bool created = false;
   };
+  // releases what this thread holds for the current device (gp_trim_device_cache): the next covariance call creates and probes again
+  static void release() {
+    PerDevice* c = device_state();
+    if (!c || !c->created) return;
+    for (int i = 0; i < c->num; i++) {
+      if (c->cand[i].stream) (void)hipStreamSynchronize(c->cand[i].stream), (void)hipStreamDestroy(c->cand[i].stream);
+      if (c->cand[i].fork) (void)hipEventDestroy(c->cand[i].fork);
+      if (c->cand[i].join) (void)hipEventDestroy(c->cand[i].join);
+    }
+    if (c->words) (void)hipFree(c->words);
+    (void)hipGetLastError();
+    *c = PerDevice{};
+  }
   static PerDevice* device_state() {
     static thread_local PerDevice cache[16];
     int d = 0;
@@ -2151,13 +2167,13 @@ struct SideStream : SideStreamHandles {
     if (!c) return fail(GP_ERROR_HIP, "SideStream: no current device");
     if (!c->created) create(*c);
     if (c->num == 0) return fail(GP_ERROR_HIP, "SideStream: cannot create the side stream");
-    for (int i = 0; i < c->num_chosen; i++)
-      if (c->chosen[i].caller == caller) {
-        static_cast<SideStreamHandles&>(*out) = c->cand[c->chosen[i].index];
-        if (report) *report = &c->chosen[i];
-        return GP_OK;
-      }
+    if (c->probed) {
+      static_cast<SideStreamHandles&>(*out) = c->cand[c->chosen.index];
+      if (report) *report = &c->chosen;
+      return GP_OK;
+    }
     PerDevice::Choice pick{caller, 0, {-1.f, -1.f, -1.f, -1.f}};
+    c->probed = true;  // (once per thread and device, whatever comes of it)
     if (c->words) {
       for (int i = 0; i < c->num; i++) {
         // (two probes, the smaller delay: a first launch on a new queue pays for the queue)
@@ -2165,15 +2181,14 @@ struct SideStream : SideStreamHandles {
         pick.delay_us[i] = a < 0.f ? b : b < 0.f ? a : std::min(a, b);
         if (pick.delay_us[i] >= 0.f && (pick.delay_us[pick.index] < 0.f || pick.delay_us[i] < pick.delay_us[pick.index] - 2.f)) pick.index = i;  // (ties within 2 us: the earlier one)
       }
-      // (a full table forgets its oldest entry: a caller stream handle may be long gone, or be probed again if it is not)
-      const int slot = c->num_chosen < kCallers ? c->num_chosen++ : c->next_evicted++ % kCallers;
-      c->chosen[slot] = pick;
-      if (report) *report = &c->chosen[slot];
     }
+    c->chosen = pick;
+    if (report) *report = &c->chosen;
     static_cast<SideStreamHandles&>(*out) = c->cand[pick.index];
     return GP_OK;
   }
 };
+void release_side_streams() { SideStream::release(); }  // (gp_trim_device_cache, gp_runtime.hip; declared in gp_host.hpp)
 }  // namespace gp
 
 // measurement / tests: the side stream gp_estimate_covariances uses beside `caller` on the current device -- the delays (us) the pipe probe measured for the (up to four)

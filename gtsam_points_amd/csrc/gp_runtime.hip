@@ -72,6 +72,7 @@ int gp_device_synchronize(void) {
 
 int gp_trim_device_cache(void) {
   gp::BlockCache::get().trim();
+  gp::release_side_streams();  // gp_knn.hip: the calling thread's candidate side streams, events and probe words on the current device
   return GP_OK;
 }
 

@@ -41,7 +41,10 @@ constexpr int kSortTicketClasses = 32;
 constexpr int kSortFaultWord = 64;      // word of a pass's ticket line ([0 .. 31] tickets) that a tile whose wait expired sets to 1
 constexpr int kSortSpinBound = 200000;  // polls (>= ~1 us each: a sleep + a round trip to the coherence point) before a tile gives up: ~0.2 - 0.5 s
 // radix_onesweep_kernel's `ticket_classes` argument: kSortTicketClasses (fast path), 1 (deadlock-free), or a NEGATIVE class count = test hook: tile 0 raises the
-// fault word as if its wait had expired (tests/test_sort_gpu.py drives the fallback with it)
+// fault word as if its wait had expired (tests/test_sort_gpu.py drives the fallback with it); beyond -kSortCorruptHook (the class count is the remainder) tile 0 ALSO
+// leaves what a real expired wait leaves -- keys that are not the input's (all-ones patterns far outside any cell range) in its part of the output -- so that the
+// consumers of a voided sort are tested against real garbage, not only against the fault word (gp_binning.hip indexed its block grid with such keys)
+constexpr int kSortCorruptHook = 1000;
 constexpr int kSortHistClasses = 16;
 
 // LDS histograms of all passes' digits for a key the caller has in a register (the kernel that PRODUCES the keys counts them: no pass over the keys for it)
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(256) radix_onesweep_kernel(const unsigned* __r
   __shared__ int tile_id;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
-    tile_id = draw_tile(state, ticket_classes < 0 ? -ticket_classes : ticket_classes);  // a tile's predecessors have been started (one class: always; more: see draw_tile)
+    tile_id = draw_tile(state, ticket_classes < 0 ? (-ticket_classes) % kSortCorruptHook : ticket_classes);  // a tile's predecessors have been started (one class: always; more: see draw_tile)
     if (ticket_classes < 0 && tile_id == 0) __hip_atomic_store(state + kSortFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // test hook
   }
   for (int k = threadIdx.x; k < 4 * 256; k += 256) (&wave_count[0][0])[k] = 0;
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(256) radix_onesweep_kernel(const unsigned* __r
       const unsigned k = skeys[pos];
       const int out = out_delta[(k >> shift) & 255u] + pos;
       if ((unsigned)out < (unsigned)n) {  // (always, unless a wait expired above and the prefix is incomplete: the pass is void then, but it must not store outside the arrays)
-        keys_out[out] = k;
+        keys_out[out] = (ticket_classes <= -kSortCorruptHook && tile == 0) ? (0xfffffff0u | (unsigned)(pos & 15)) : k;  // (test hook: garbage where a voided pass leaves holes)
         vals_out[out] = svals[pos];
       }
     }

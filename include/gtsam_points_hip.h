@@ -62,7 +62,8 @@ int gp_get_device(int* device);
 int gp_device_name(int device, char* name, size_t name_len);    /* cuda_device_names() */
 int gp_device_synchronize(void);                                /* cuda/cuda_device_sync.cu */
 /* Scratch and structure arrays are stream-ordered pool blocks; released ones are parked in a bounded per-thread cache (<= 96 blocks,
- * <= 4 GiB) and re-used by the next build on the same stream.  This returns the calling thread's parked blocks to the pool. */
+ * <= 4 GiB) and re-used by the next build on the same stream.  This returns the calling thread's parked blocks to the pool, and releases the (up to four) side
+ * streams + events gp_estimate_covariances keeps per host thread and device: a long-lived pool thread that is done with a device calls it once. */
 int gp_trim_device_cache(void);
 int gp_stream_create(gp_stream_t* stream);                      /* cuda/cuda_stream.cu (cudaStreamNonBlocking) */
 int gp_stream_destroy(gp_stream_t stream);
@@ -560,11 +561,12 @@ int gp_debug_stream_plan(int n, int skew_permille, const int* xcd_weights_permil
  * buffer starts inside the [F x width] stack, in doubles.  Runs the functions gp_vgicp_multi_batch_* itself uses. */
 int gp_debug_multi_gather_plan(const int* shard_of_factor, int num_factors, int num_shards, int width, int64_t* rows_per_shard, int64_t* send_offset_doubles);
 /* gp_estimate_covariances runs its second launch on a low-priority side stream; two streams overlap only when their hardware queues sit on different dispatch pipes, so
- * the library probes (once per caller stream, thread and device) up to four candidate streams and keeps the one whose queue does not wait for the caller's grid
+ * the library probes (once per host thread and device, beside the first caller stream) up to four candidate streams and keeps the one whose queue does not wait for the caller's grid
  * (gp_knn.hip, SideStream).  This returns the measured delays in microseconds (< 0 = not probed) and the index of the stream in use beside `caller`. */
 int gp_debug_side_stream_probe(gp_stream_t caller, float delays_us[4], int* chosen);
 /* test hooks for the structure builds' sort fallback (gp_sort.hpp / gp_binning.hip; thread-local, no device state): the next `count` builds of this thread (voxel-map
  * insert, k-NN structure) see their first radix sort report "a tile waited for a workgroup that was never started" and must rebuild through the one-class sort;
+ * count < 0: the next |count| builds, and the faulted sort also leaves garbage keys (far outside every cell range) in part of its output, as a really expired wait does.
  * gp_debug_sort_fallbacks = how many builds of this thread did so far. */
 int gp_debug_inject_sort_fault(int count);
 int gp_debug_sort_fallbacks(void);
