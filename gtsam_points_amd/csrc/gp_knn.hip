@@ -2188,7 +2188,7 @@ struct SideStream : SideStreamHandles {
     return GP_OK;
   }
 };
-void release_side_streams() { SideStream::release(); }  // (gp_trim_device_cache, gp_runtime.hip; declared in gp_host.hpp)
+extern "C++" void release_side_streams() { SideStream::release(); }  // (gp_trim_device_cache, gp_runtime.hip; declared in gp_host.hpp)
 }  // namespace gp
 
 // measurement / tests: the side stream gp_estimate_covariances uses beside `caller` on the current device -- the delays (us) the pipe probe measured for the (up to four)

@@ -298,6 +298,22 @@ def test_build_survives_a_sort_that_gives_up(gpu, kitti00):
     torch.cuda.synchronize()
     assert lib.gp_debug_sort_fallbacks() == before + 2
     assert torch.equal(want, q.covs_gpu)
+    # a voided sort leaves HOLES, i.e. arbitrary keys: the hook's negative form also writes keys far outside every cell range into the first tile's part of
+    # the output.  The cell kernel must not index anything with them (it did: blocks[key >> 6]); the rebuilt map is the same map, bit for bit, and so are the covariances
+    gpu._capi.check(lib.gp_debug_inject_sort_fault(-1), "inject (corrupting)")
+    d = build()
+    assert lib.gp_debug_sort_fallbacks() == before + 3
+    for x, y in zip(ref, d.download_f64()):
+        assert np.array_equal(x, y)
+    gpu._capi.check(lib.gp_debug_inject_sort_fault(-1), "inject (corrupting)")
+    estimate_covariances_gpu(q, k_neighbors=10)
+    torch.cuda.synchronize()
+    assert lib.gp_debug_sort_fallbacks() == before + 4
+    assert torch.equal(want, q.covs_gpu)
+    e = build()  # (and nothing is left behind: the next build is the fast path again)
+    assert lib.gp_debug_sort_fallbacks() == before + 4
+    for x, y in zip(ref, e.download_f64()):
+        assert np.array_equal(x, y)
 
 
 def test_non_finite_points_are_skipped(gpu, kitti00):
