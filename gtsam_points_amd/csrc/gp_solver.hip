@@ -406,7 +406,8 @@ int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_ou
   return GP_OK;
 }
 
-// buildDampedSystem + solve (levenberg_marquardt_ext.cpp:146-161, 200-220) in one stream-ordered pass and ONE synchronisation: gp_dense_system_build, _download(b, c) and _solve
+// buildDampedSystem + solve (levenberg_marquardt_ext.cpp:146-161, 200-220) in one stream-ordered pass and ONE synchronisation (TWO when prior_diag_host is given: the
+// build waits once more so that the caller's pageable prior array may go away -- ADVICE r05): gp_dense_system_build, _download(b, c) and _solve
 // without the waits and copies between them; x, b, c and the status arrive through one pinned block written by the last kernel.  Bit-identical to the three calls.
 // b_host / c_host are valid also when the system is indeterminate.
 int gp_dense_system_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,

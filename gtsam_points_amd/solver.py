@@ -93,7 +93,7 @@ class DenseLinearSystemGPU:
         return x
 
     def step(self, records_dev, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, prior_diag=None, out=None):
-        """build + download(b, c) + solve as ONE call with one synchronisation (gp_dense_system_step): -> (x, b, c); the optimizer's tryLambda
+        """build + download(b, c) + solve as ONE call with one synchronisation -- two with a prior_diag -- (gp_dense_system_step): -> (x, b, c); the optimizer's tryLambda
         (levenberg_marquardt_ext.cpp:188-260).  out: optional (x, b, c) float64 arrays to fill ([n], [n], [1]) instead of new ones.  Raises GPError (indeterminate) when the
         damped system is not positive definite; out's b and c are filled even then."""
         if tuple(records_dev.shape) != (len(self.factor_slots), _capi.LINEARIZED6_DOUBLES) or not records_dev.is_contiguous():
@@ -103,13 +103,26 @@ class DenseLinearSystemGPU:
             prior = np.ascontiguousarray(prior_diag, dtype=np.float64)
             if prior.shape != (self.size,):
                 raise ValueError("prior_diag must have 6 * num_slots entries")
-        x, b, c = out if out is not None else (np.zeros(self.size), np.zeros(self.size), np.zeros(1))
+        x, b, c = _step_out(out, self.size)
         _capi.check(
             self._lib.gp_dense_system_step(self._h, C.c_void_p(records_dev.data_ptr()), float(lam), int(bool(diagonal_damping)), float(min_diagonal), float(max_diagonal),
                                             prior.ctypes.data if prior is not None else None, x.ctypes.data, b.ctypes.data, c.ctypes.data),
             "gp_dense_system_step",
         )
         return x, b, float(c[0])
+
+
+def _step_out(out, n):
+    """(x, b, c) buffers of a step() call: the C entry points memcpy n, n and 1 doubles into them through their raw pointers, so anything that is not a
+    C-contiguous float64 array of exactly that shape is refused here"""
+    if out is None:
+        return np.zeros(n), np.zeros(n), np.zeros(1)
+    if len(out) != 3:
+        raise ValueError("out must be (x, b, c)")
+    for arr, shape, name in zip(out, ((n,), (n,), (1,)), "xbc"):
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.shape == shape and arr.flags.c_contiguous and arr.flags.writeable):
+            raise ValueError(f"out[{name}] must be a writable C-contiguous float64 array of shape {shape}")
+    return out
 
 
 def sparse_symbolic(num_slots, factor_slots, ordering=0):
@@ -199,7 +212,7 @@ class SparseLinearSystemGPU:
             prior = np.ascontiguousarray(prior_diag, dtype=np.float64)
             if prior.shape != (self.size,):
                 raise ValueError("prior_diag must have 6 * num_slots entries")
-        x, b, c = out if out is not None else (np.zeros(self.size), np.zeros(self.size), np.zeros(1))
+        x, b, c = _step_out(out, self.size)
         _capi.check(
             self._lib.gp_sparse_system_step(self._h, C.c_void_p(records_dev.data_ptr()), float(lam), int(bool(diagonal_damping)), float(min_diagonal), float(max_diagonal),
                                             prior.ctypes.data if prior is not None else None, x.ctypes.data, b.ctypes.data, c.ctypes.data),

@@ -426,7 +426,7 @@ int gp_dense_system_download(const gp_dense_system_t* sys, double* A_host, doubl
 /* x (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
 int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev);
 /* One damped step of the optimizer's inner loop (LevenbergMarquardtOptimizerExt::tryLambda: buildDampedSystem + solve, optimizers/levenberg_marquardt_ext.cpp:146-161, 200-220)
- * as ONE call with ONE synchronisation: build + download(b, c) + solve, bit-identical to the three calls.  x_host [n], b_host [n] (the undamped gradient side the optimizer's
+ * as ONE call with ONE synchronisation (the dense form with a prior_diag_host: two): build + download(b, c) + solve, bit-identical to the three calls.  x_host [n], b_host [n] (the undamped gradient side the optimizer's
  * model-fidelity test needs), c_host [1]; any may be NULL.  GP_ERROR_INDETERMINATE if not positive definite: b_host / c_host are valid, x_host is not written. */
 int gp_dense_system_step(gp_dense_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host);

@@ -233,3 +233,20 @@ def test_the_product_reads_no_environment_variable():
     assert "reads NO environment variable" in header
     for gone in ("GP_POSES_ZERO_COPY", "GP_FINALIZE_PARTS", "GP_FINALIZE_NARROW", "GP_FINALIZE_HOST_EXPAND", "GP_GICP_SPLIT"):
         assert gone not in header, gone
+
+
+def test_solver_step_refuses_out_buffers_it_would_overrun():
+    """step(out=(x, b, c)) hands raw pointers to a C entry point that memcpy's n, n, 1 doubles: dtype, shape, contiguity are checked first (host code)"""
+    import numpy as np
+
+    from gtsam_points_amd.solver import _step_out
+
+    n = 12
+    x, b, c = _step_out(None, n)
+    assert x.shape == (n,) and b.shape == (n,) and c.shape == (1,)
+    good = (np.zeros(n), np.zeros(n), np.zeros(1))
+    assert _step_out(good, n) is good
+    for bad in [(np.zeros(n, np.float32), np.zeros(n), np.zeros(1)), (np.zeros(n - 1), np.zeros(n), np.zeros(1)), (np.zeros(2 * n)[::2], np.zeros(n), np.zeros(1)),
+                (np.zeros(n), np.zeros(n), np.zeros(2)), (np.zeros(n), np.zeros(n)), (list(range(n)), np.zeros(n), np.zeros(1))]:
+        with pytest.raises(ValueError):
+            _step_out(bad, n)
