@@ -563,6 +563,21 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream, want=No
                         compulsory_bytes=48 * 1_000_000, hbm_frac_of_compulsory=round(48e6 / (cov_ms * 1e-3) / 8e12, 5))
         if kt:
             cov_roof.update(kt)
+        # a fraction for the covariance call.  Bound = VALU issue: the call's three launches execute a fixed number of vector-ALU wave-instructions on
+        # this cloud (rocprofv3 --pmc SQ_INSTS_VALU per launch, profiles/r06_c5_pmc.json: counted once, the code and the cloud are the same here), every one of which
+        # holds a SIMD's issue port for four clocks; peak = 1024 SIMDs x 2.4 GHz / 4.  achieved = those instructions / THIS run's wall per call (structure build included)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_c5_pmc.json")) as f_pmc:
+                pmc = json.load(f_pmc)["launches"]
+            per_call = sum((2.0 if name.startswith("covariance_kernel") else 1.0) * (v["counters"]["SQ_INSTS_VALU"] + 3.0 * v["counters"].get("SQ_INSTS_VALU_TRANS_F64", 0.0)) for name, v in pmc.items())
+            peak = 1024 * 2.4e9 / 4.0
+            cov_roof.update(bound="valu-issue", unit="G wave-instructions/s", achieved=round(per_call / (cov_ms * 1e-3) / 1e9, 2), peak=round(peak / 1e9, 1),
+                            frac=round(per_call / (cov_ms * 1e-3) / peak, 4), valu_wave_instructions_per_call=int(per_call),
+                            frac_by_launch={name: v.get("frac_valu_issue") for name, v in pmc.items()},
+                            frac_source="instructions per call from profiles/r06_c5_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, transcendentals x4; the heavy and the light "
+                                        "launch of covariance_kernel counted once each) / this run's wall per call; frac_by_launch: each launch against its own rocprofv3 duration")
+        except Exception as exc:  # (the profile is evidence, not a dependency)
+            cov_roof.update(frac=None, frac_source=f"profiles/r06_c5_pmc.json not readable: {exc}")
         out["C5"] = dict(
             workload="BASELINE configs[4]: k-NN covariance estimation (k=10, exact) + IntegratedGICPFactor linearise, 1 M source pts vs 1 M target pts",
             points=1_000_000,
