@@ -389,6 +389,21 @@ static int critical_columns(const SparseSymbolic& S) {
   return crit;
 }
 
+// the one-launch step of small graphs (sparse_small_step_kernel below): one 1024-thread workgroup, up to sixteen work lists of a level side by side
+constexpr int kSmallThreads = 1024, kSmallTeams = 16;
+constexpr int kSmallTeamDoubles = 152;  // per team: D[6][7] | rhs[6] | v[6] (backward) | pad 2 | part: rpart[16][6] (forward) / bpart[6][6] (backward)
+// LDS bytes that step needs for a symbolic factorisation: L's blocks, y, x, the teams' scratch, the error partials, the index lists (0: the factor does not qualify)
+static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_out = nullptr) {
+  const size_t P = (size_t)S.P, nnzL = (size_t)S.colptr[S.P];
+  const size_t words = S.colptr.size() + S.rowidx.size() + S.upd_ptr.size() + S.upd_a.size() + S.upd_b.size() + S.row_ptr.size() + S.row_blk.size() + S.row_col.size() +
+                       S.work_ptr.size() + S.work_cols.size();
+  if (arena_words_out) *arena_words_out = words;
+  if (P > 128) return 0;  // (row lists stay below the staged kernel's 128-block stage, which the one-launch form assumes)
+  const size_t bytes = sizeof(double) * (36 * nnzL + 12 * P + (size_t)kSmallTeams * kSmallTeamDoubles + 256) + sizeof(int) * words + 64;
+  return bytes <= 160 * 1024 - 256 ? bytes : 0;
+}
+static bool small_step_fits(const SparseSymbolic& S) { return small_step_lds_bytes(S) != 0; }
+
 // ordering = 4 (automatic): nested dissection and minimum degree with slack are both tried and the schedule with the shorter critical path
 // (then the smaller factor) is kept -- band-like graphs want the dissection (separators side by side), graphs with random loop closures and
 // grids the minimum degree (less fill AND a shorter path); the symbolic phase is host code run once per graph
@@ -398,7 +413,12 @@ static int sparse_symbolic(int num_slots, const int* factor_slots, int num_facto
   GP_TRY(sparse_symbolic_with(num_slots, factor_slots, num_factors, 1, &a));
   GP_TRY(sparse_symbolic_with(num_slots, factor_slots, num_factors, 3, &b));
   const int ca = critical_columns(a), cb = critical_columns(b);
-  const bool take_b = cb < ca || (cb == ca && b.colptr[num_slots] < a.colptr[num_slots]);
+  bool take_b = cb < ca || (cb == ca && b.colptr[num_slots] < a.colptr[num_slots]);
+  // round 6: a factor that fits one compute unit's LDS is solved by ONE launch with every operand in LDS (sparse_small_step_kernel: ~2 us per column instead of 6-8), which
+  // outweighs a shorter critical path in columns -- BASELINE configs[2]'s graph: dissection 21 columns / 522 blocks (150 KB: does not fit), minimum degree 34 columns /
+  // 305 blocks (fits).  Between two that qualify, or two that do not, the rule above stands.
+  const bool fa = small_step_fits(a), fb = small_step_fits(b);
+  if (fa != fb) take_b = fb;
   *out = take_b ? std::move(b) : std::move(a);
   return GP_OK;
 }
@@ -935,6 +955,317 @@ __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __
   if (threadIdx.x == 0) *c_out = part[0];
 }
 
+
+// ---- ONE launch per damped step for SMALL graphs (round 6) ---------------------------------------------------------------------------------------------
+// The multi-launch step above costs 0.21 ms on BASELINE configs[2]'s graph (63 free poses, 256 factors) and its launches are NOT the cost: the kernels' own time is
+// (profiles/r06_solver_kernel_stats.csv).  A column of the factorisation is a chain -- product indices -> operand blocks -> 6 x 6 Cholesky -> triangular solves -- and
+// every link is a round trip to L2 behind a workgroup barrier: 6-8 us per column, 21-34 columns on the critical path.  For a graph whose whole factor fits the LDS of one
+// compute unit (<= ~440 blocks of 288 B; the index lists beside it) ONE 1024-thread workgroup does the whole step with every operand in LDS:
+//   phase 0  the index lists into LDS; the assembly (sparse_assemble_kernel<true>'s sums, in its order, damping included) straight into the LDS copy of L; b, c to the host
+//   phase 1  the schedule's levels one after the other; the work lists of a level side by side, each with a TEAM of 1024 / lists threads (whole waves), in lock step:
+//            round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward substitution by the team's first wave, barrier, the blocks below, barrier
+//   phase 2  the backward substitution, levels and columns in reverse, two barriers per round
+//   phase 3  x in slot order to the device array and the host, the status word
+// Every scalar is computed by the SAME sequence of operations as in sparse_factor_kernel<256> (lists of level 0) / sparse_factor_staged_kernel<1024> (levels above: the
+// slice partials with G and `per` derived from the column's size exactly as there) / sparse_backsolve_kernel, so the step is bit-identical to the multi-launch form
+// (tests/test_solver_gpu.py::test_one_launch_step_is_bit_identical); only where the operands live and which thread computes what differ.
+struct SparseSmallView {
+  const SparseDest* dests;
+  const SparseContribution* contribs;
+  const int* arena;       // global copy of the index lists below, `arena_words` ints, copied to LDS first
+  const int* level_ptr;   // [num_levels + 1] -> work lists (global; read once per level)
+  int arena_words, num_levels, P, nnzL, num_dests;
+  int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols;  // offsets (ints) inside the arena
+  const int* perm;        // elimination order -> slot (global)
+  double* x_slots;        // device, slot order
+  double* x_slots_host;   // pinned
+  double* status_host;    // pinned
+};
+__global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const SparseSmallView V, const double* __restrict__ records, const SparseStepExtras ex) {
+  extern __shared__ __attribute__((aligned(16))) double small_lds[];
+  double* Ls = small_lds;                                   // [nnzL][36]
+  double* ys = Ls + 36 * (size_t)V.nnzL;                    // [6 P]
+  double* xs = ys + 6 * (size_t)V.P;                        // [6 P]
+  double* scr = xs + 6 * (size_t)V.P;                       // [kSmallTeams][kSmallTeamDoubles]
+  double* cpart = scr + kSmallTeams * kSmallTeamDoubles;    // [256]: the error sum's partials
+  int* idx = reinterpret_cast<int*>(cpart + 256);           // the index lists
+  __shared__ int bad;
+  const int t = threadIdx.x;
+  const int* colptr = idx + V.o_colptr;
+  const int* rowidx = idx + V.o_rowidx;
+  const int* upd_ptr = idx + V.o_upd_ptr;
+  const int* upd_a = idx + V.o_upd_a;
+  const int* upd_b = idx + V.o_upd_b;
+  const int* row_ptr = idx + V.o_row_ptr;
+  const int* row_blk = idx + V.o_row_blk;
+  const int* row_col = idx + V.o_row_col;
+  const int* work_ptr = idx + V.o_work_ptr;
+  const int* work_cols = idx + V.o_work_cols;
+  // ---- phase 0 ----
+  if (t == 0) bad = 0;
+  for (int i = t; i < V.arena_words; i += kSmallThreads) idx[i] = V.arena[i];
+  // the assembly: one thread per (destination, lane 0 .. 41) of sparse_assemble_kernel's 64-lane workgroups (lanes 42 .. 63 do nothing there)
+  for (int item = t; item < 42 * V.num_dests; item += kSmallThreads) {
+    const SparseDest d = V.dests[item / 42];
+    const int l = item % 42;
+    if (l < 36) {
+      const int r = l % 6, c = l / 6;
+      double s = 0.0;
+      for (int k = 0; k < d.count; k++) {
+        const SparseContribution q = V.contribs[d.begin + k];
+        const double* rec = records + 122 * (size_t)q.factor;
+        double v;
+        if (q.take == STAKE_HT) {
+          v = rec[SREC_HT + c * 6 + r];
+        } else if (q.take == STAKE_HS) {
+          v = rec[SREC_HS + c * 6 + r];
+        } else if (q.take == STAKE_HTS) {
+          v = rec[SREC_HTS + c * 6 + r];
+        } else {
+          v = rec[SREC_HTS + r * 6 + c];
+        }
+        s += v;
+      }
+      if (d.diag_col >= 0 && r == c && (ex.lambda > 0.0 || ex.prior_diag)) {
+        double add = ex.diagonal ? __dmul_rn(ex.lambda, fmin(fmax(s, ex.min_diag), ex.max_diag)) : ex.lambda;
+        if (ex.prior_diag) add = __dadd_rn(add, ex.prior_diag[6 * (size_t)d.diag_col + r]);
+        s = __dadd_rn(s, add);
+      }
+      Ls[36 * (size_t)d.block + l] = s;
+    } else if (d.diag_col >= 0) {
+      const int r = l - 36;
+      double s = 0.0;
+      for (int k = 0; k < d.count; k++) {
+        const SparseContribution q = V.contribs[d.begin + k];
+        const double* rec = records + 122 * (size_t)q.factor;
+        s -= q.take == STAKE_HT ? rec[SREC_BT + r] : rec[SREC_BS + r];
+      }
+      ys[6 * (size_t)d.diag_col + r] = s;
+      ex.b_slots_host[6 * (size_t)ex.perm[d.diag_col] + r] = s;
+    }
+  }
+  // c = sum of the factors' errors, sparse_sum_errors_kernel's order: 256 strided partial sums folded pairwise
+  if (t < 256) {
+    double s = 0.0;
+    for (int f = t; f < ex.num_factors; f += 256) s += records[122 * (size_t)f + 1];
+    cpart[t] = s;
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) cpart[t] += cpart[t + w];
+    __syncthreads();
+  }
+  if (t == 0) {
+    *ex.c_dev = cpart[0];
+    *ex.c_host = cpart[0];
+  }
+  // ---- phase 1: factorisation + forward substitution ----
+  for (int lvl = 0; lvl < V.num_levels; lvl++) {
+    const int first = V.level_ptr[lvl], nlists = V.level_ptr[lvl + 1] - first;
+    const bool staged = lvl > 0;
+    for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {  // (more than sixteen lists in a level: sixteen at a time)
+      const int nb_lists = min(kSmallTeams, nlists - b0);
+      const int T = (kSmallThreads / nb_lists) & ~63;     // threads per team: whole waves
+      const int team = t / T, j = t % T;
+      const bool member = team < nb_lists;
+      const int list = first + b0 + (member ? team : 0);
+      const int w0 = work_ptr[list], len = member ? work_ptr[list + 1] - w0 : 0;
+      int rounds = 0;
+      for (int q = 0; q < nb_lists; q++) rounds = max(rounds, work_ptr[first + b0 + q + 1] - work_ptr[first + b0 + q]);
+      double* S = scr + (size_t)(member ? team : 0) * kSmallTeamDoubles;
+      double (*D)[7] = reinterpret_cast<double (*)[7]>(S);
+      double* rhs = S + 42;
+      double (*rpart)[6] = reinterpret_cast<double (*)[6]>(S + 56);
+      for (int rd = 0; rd < rounds; rd++) {
+        const bool on = member && rd < len;
+        const int k = on ? work_cols[w0 + rd] : 0;
+        const int base = colptr[k], nb = colptr[k + 1] - base;
+        const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
+        if (on) {
+          // 1. gather: one thread per entry of the column's blocks
+          if (!staged) {
+            for (int e = j; e < 36 * nb; e += T) {
+              const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
+              double acc = Ls[36 * (size_t)d + (e % 36)];
+              for (int u = upd_ptr[d]; u < upd_ptr[d + 1]; u++) {
+                const double* A = Ls + 36 * (size_t)upd_a[u];
+                const double* B = Ls + 36 * (size_t)upd_b[u];
+#pragma unroll
+                for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * B[c + 6 * q];
+              }
+              if (d == base) D[r][c] = acc;
+              else Ls[36 * (size_t)d + (e % 36)] = acc;
+            }
+            if (j < 6) {  // right-hand side of the forward substitution: b_k - sum_j L_kj y_j, in list order
+              const int r = j;
+              double acc = ys[6 * (size_t)k + r];
+              for (int u = rb; u < rb + nrow; u++) {
+                const double* A = Ls + 36 * (size_t)row_blk[u];
+                const double* yj = ys + 6 * (size_t)row_col[u];
+#pragma unroll
+                for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * yj[q];
+              }
+              rhs[r] = acc;
+            }
+          } else {
+            // the staged kernel's sums: the product list of a block row in G contiguous slices, each summed from zero, met in slice order (G and `per` as there)
+            const int R = 6 * nb;
+            int G = 1024 / R;
+            G = G < 1 ? 1 : (G > 8 ? 8 : G);
+            for (int e = j; e < 36 * nb; e += T) {
+              const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
+              const int ub = upd_ptr[d], ulen = upd_ptr[d + 1] - ub;
+              const int per = (ulen + G - 1) / G;
+              double v = Ls[36 * (size_t)d + (e % 36)];
+              for (int g = 0; g < G; g++) {
+                double acc = 0.0;
+                const int ue = min(ub + ulen, ub + g * per + per);
+                for (int u = ub + g * per; u < ue; u++) {
+                  const double* A = Ls + 36 * (size_t)upd_a[u];
+                  const double* B = Ls + 36 * (size_t)upd_b[u];
+#pragma unroll
+                  for (int m = 0; m < 6; m++) acc -= A[r + 6 * m] * B[c + 6 * m];
+                }
+                v += acc;
+              }
+              if (d == base) D[r][c] = v;
+              else Ls[36 * (size_t)d + (e % 36)] = v;
+            }
+            for (int jj = j; jj < 96; jj += T) {  // right-hand side: sixteen slices of the row list (a team may be one wave: 64 threads)
+              const int r = jj % 6, g = jj / 6;
+              const int per = (nrow + 15) / 16;
+              double a = 0.0;
+              for (int q = g * per; q < min(nrow, (g + 1) * per); q++) {
+                const double* A = Ls + 36 * (size_t)row_blk[rb + q];
+                const double* yj = ys + 6 * (size_t)row_col[rb + q];
+#pragma unroll
+                for (int m = 0; m < 6; m++) a -= A[r + 6 * m] * yj[m];
+              }
+              rpart[g][r] = a;
+            }
+          }
+        }
+        __syncthreads();
+        // 2. the diagonal block: 6 x 6 Cholesky by the team's first wave (lane = (row, column)), then y_k = L_kk^-1 rhs
+        if (on && j < 64) {
+          if (staged && j < 6) {
+            double a = ys[6 * (size_t)k + j];
+            for (int g = 0; g < 16; g++) a += rpart[g][j];
+            rhs[j] = a;
+          }
+          const int r = j % 6, c = j / 6;
+          for (int p = 0; p < 6; p++) {
+            double piv = D[p][p];
+            if (!(piv > 0.0)) {
+              if (j == 0) bad = 1;
+              piv = 1.0;
+            }
+            const double l = sqrt(piv);
+            GP_WAVE_SYNC_LDS();
+            if (j < 36 && c == p && r >= p) D[r][p] = r == p ? l : D[r][p] / l;
+            GP_WAVE_SYNC_LDS();
+            if (j < 36 && c > p && r >= c) D[r][c] -= D[r][p] * D[c][p];
+            GP_WAVE_SYNC_LDS();
+          }
+          if (j == 0) {
+            for (int i = 0; i < 6; i++) {
+              double sum = rhs[i];
+              for (int q = 0; q < i; q++) sum -= D[i][q] * rhs[q];
+              rhs[i] = sum / D[i][i];
+            }
+          }
+        }
+        __syncthreads();
+        if (on) {
+          if (j < 36) Ls[36 * (size_t)base + j] = (j % 6) >= (j / 6) ? D[j % 6][j / 6] : 0.0;
+          if (j >= 36 && j < 42) ys[6 * (size_t)k + (j - 36)] = rhs[j - 36];
+          // 3. the blocks below: L_ik = B_ik L_kk^-T, one thread per (block, row)
+          for (int e = j; e < 6 * (nb - 1); e += T) {
+            double* Bk = Ls + 36 * (size_t)(base + 1 + e / 6);
+            const int r = e % 6;
+            double o[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              double sum = Bk[r + 6 * c];
+#pragma unroll
+              for (int q = 0; q < 6; q++)
+                if (q < c) sum -= o[q] * D[c][q];
+              o[c] = sum / D[c][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // ---- phase 2: backward substitution, levels and columns in reverse ----
+  for (int lvl = V.num_levels - 1; lvl >= 0; lvl--) {
+    const int first = V.level_ptr[lvl], nlists = V.level_ptr[lvl + 1] - first;
+    for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {
+      const int nb_lists = min(kSmallTeams, nlists - b0);
+      const int T = (kSmallThreads / nb_lists) & ~63;
+      const int team = t / T, j = t % T;
+      const bool member = team < nb_lists;
+      const int list = first + b0 + (member ? team : 0);
+      const int w0 = work_ptr[list], len = member ? work_ptr[list + 1] - w0 : 0;
+      int rounds = 0;
+      for (int q = 0; q < nb_lists; q++) rounds = max(rounds, work_ptr[first + b0 + q + 1] - work_ptr[first + b0 + q]);
+      double* S = scr + (size_t)(member ? team : 0) * kSmallTeamDoubles;
+      double* vv = S + 48;
+      double (*bpart)[6] = reinterpret_cast<double (*)[6]>(S + 56);
+      for (int rd = 0; rd < rounds; rd++) {
+        const bool on = member && rd < len;
+        const int k = on ? work_cols[w0 + len - 1 - rd] : 0;
+        const int base = colptr[k], nb = colptr[k + 1] - base;
+        if (on && j < 36) {
+          const int c = j % 6, slice = j / 6;
+          double acc = 0.0;
+          for (int p = 1 + slice; p < nb; p += 6) {
+            const double* A = Ls + 36 * (size_t)(base + p);
+            const double* xi = xs + 6 * (size_t)rowidx[base + p];
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc += A[q + 6 * c] * xi[q];
+          }
+          bpart[slice][c] = acc;
+        }
+        __syncthreads();
+        if (on && j < 64) {
+          if (j < 6) {
+            double sum = ys[6 * (size_t)k + j];
+            for (int sl = 0; sl < 6; sl++) sum -= bpart[sl][j];
+            vv[j] = sum;
+          }
+          GP_WAVE_SYNC_LDS();
+          if (j == 0) {
+            const double* Dk = Ls + 36 * (size_t)base;
+            double xk[6];
+            for (int i = 5; i >= 0; i--) {
+              double sum = vv[i];
+              for (int q = i + 1; q < 6; q++) sum -= Dk[q + 6 * i] * xk[q];
+              xk[i] = sum / Dk[i + 6 * i];
+            }
+            for (int i = 0; i < 6; i++) xs[6 * (size_t)k + i] = xk[i];
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // ---- phase 3 ----
+  for (int i = t; i < 6 * V.P; i += kSmallThreads) {
+    const double v = xs[i];
+    const size_t to = 6 * (size_t)V.perm[i / 6] + i % 6;
+    V.x_slots[to] = v;
+    V.x_slots_host[to] = v;
+  }
+  if (t == 0) {
+    *ex.status = bad;
+    *V.status_host = (double)bad;
+  }
+}
+
 }  // namespace gp
 
 struct gp_sparse_system {
@@ -948,7 +1279,13 @@ struct gp_sparse_system {
   gp::SparseView view{};
   const int* d_perm = nullptr;
   bool built = false;
+  // the one-launch step of small graphs (sparse_small_step_kernel): eligible when factor + index lists fit one compute unit's LDS
+  bool small_ok = false, one_launch = false;
+  size_t small_lds_bytes = 0;
+  gp::DeviceArray d_small_arena, d_level_ptr;
+  gp::SparseSmallView small{};
 };
+
 
 extern "C" {
 
@@ -1064,8 +1401,50 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
   s->view.y = s->y.as<double>();
   s->view.x = s->x.as<double>();
   s->view.status = s->status.as<int>();
+  // the one-launch step (small graphs): its own copy of the index lists it walks, in the order of SparseSmallView's offsets, and the levels
+  size_t small_words = 0;
+  s->small_lds_bytes = gp::small_step_lds_bytes(S, &small_words);
+  if (s->small_lds_bytes) {
+    const std::vector<int>* sa[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols};
+    std::vector<int> arena;
+    arena.reserve(small_words);
+    int off[10];
+    for (int i = 0; i < 10; i++) {
+      off[i] = (int)arena.size();
+      arena.insert(arena.end(), sa[i]->begin(), sa[i]->end());
+    }
+    if ((rc = s->d_small_arena.alloc(sizeof(int) * std::max<size_t>(arena.size(), 1))) || (rc = s->d_level_ptr.alloc(sizeof(int) * S.level_ptr.size()))) return rc;
+    GP_HIP(hipMemcpy(s->d_small_arena.ptr, arena.data(), sizeof(int) * arena.size(), hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(s->d_level_ptr.ptr, S.level_ptr.data(), sizeof(int) * S.level_ptr.size(), hipMemcpyHostToDevice));
+    gp::SparseSmallView& V = s->small;
+    V.dests = s->d_dests.as<gp::SparseDest>();
+    V.contribs = s->d_contribs.as<gp::SparseContribution>();
+    V.arena = s->d_small_arena.as<int>();
+    V.level_ptr = s->d_level_ptr.as<int>();
+    V.arena_words = (int)arena.size(), V.num_levels = (int)S.level_ptr.size() - 1, V.P = P, V.nnzL = nnzL, V.num_dests = (int)s->dests.size();
+    V.o_colptr = off[0], V.o_rowidx = off[1], V.o_upd_ptr = off[2], V.o_upd_a = off[3], V.o_upd_b = off[4], V.o_row_ptr = off[5], V.o_row_blk = off[6], V.o_row_col = off[7];
+    V.o_work_ptr = off[8], V.o_work_cols = off[9];
+    V.perm = s->d_perm;
+    V.x_slots = s->x_slots.as<double>();
+    // (more than 64 KB of dynamic LDS per workgroup has to be asked for; a runtime that refuses leaves the multi-launch step in charge)
+    // (the attribute belongs to the FUNCTION, not to this system: every system asks for the same ceiling, so that one created later never lowers what an earlier one needs)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gp::sparse_small_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess) {
+      s->small_ok = true;
+      s->one_launch = true;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   *out = s.release();
   return GP_OK;
+}
+
+// the one-launch step (sparse_small_step_kernel): 1 = gp_sparse_system_step uses it when the system qualifies (default), 0 = the multi-launch form; returns what the
+// next step will run (1 / 0).  The two are bit-identical; the switch exists for the test that says so and for A/B timing.
+int gp_sparse_system_set_one_launch(gp_sparse_system_t* s, int enable) {
+  if (!s) return 0;
+  s->one_launch = enable != 0 && s->small_ok;
+  return s->one_launch ? 1 : 0;
 }
 
 int gp_sparse_system_destroy(gp_sparse_system_t* s) {
@@ -1213,6 +1592,21 @@ int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_d
   }
   ex.perm = s->d_perm, ex.b_slots_host = h + n, ex.c_dev = s->c.as<double>(), ex.c_host = h + 2 * n, ex.status = s->status.as<int>();
   ex.num_factors = s->num_factors, ex.num_dests = (int)s->dests.size();
+  if (s->one_launch) {
+    // small graph: the whole step in ONE launch, every operand in the LDS of one compute unit (sparse_small_step_kernel)
+    gp::SparseSmallView V = s->small;
+    V.x_slots_host = h;
+    V.status_host = h + 2 * n + 1;
+    hipLaunchKernelGGL(gp::sparse_small_step_kernel, dim3(1), dim3(gp::kSmallThreads), s->small_lds_bytes, s->stream, V, reinterpret_cast<const double*>(records_dev), ex);
+    GP_HIP(hipGetLastError());
+    s->built = false;
+    GP_HIP(hipStreamSynchronize(s->stream));
+    if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
+    if (c_host) *c_host = h[2 * n];
+    if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_step: the system is not positive definite (indeterminate linear system)");
+    if (x_host) memcpy(x_host, h, sizeof(double) * n);
+    return GP_OK;
+  }
   hipLaunchKernelGGL(gp::sparse_assemble_kernel<true>, dim3((unsigned)s->dests.size() + 1), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
                      s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), ex);
   launch_factor_and_substitutions(s);

@@ -169,6 +169,11 @@ class SparseLinearSystemGPU:
     def size(self):
         return 6 * self.num_slots
 
+    def set_one_launch(self, enable=True):
+        """step() of a system whose factor fits one compute unit's LDS (<= 128 poses, <= ~440 blocks of L) runs as ONE launch by default; False selects the multi-launch
+        form (bit-identical: the switch is for the test that says so and for timing).  Returns what the next step() runs (True: one launch)."""
+        return bool(self._lib.gp_sparse_system_set_one_launch(self._h, 1 if enable else 0))
+
     def info(self):
         na, nl, bp, ns, nt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
         _capi.check(self._lib.gp_sparse_system_info(self._h, C.byref(na), C.byref(nl), C.byref(bp), C.byref(ns), C.byref(nt)), "gp_sparse_system_info")

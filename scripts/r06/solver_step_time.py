@@ -1,5 +1,6 @@
 """Round 6: what ONE damped step (gp_sparse_system_step) costs on the C3 graph's structure (64 poses, pose 0 held: 63 slots, 256 factors i -> i+1..i+4 and
-back) and on C1's (one free pose), per ordering; run under `rocprofv3 --kernel-trace --stats` for the per-kernel durations.  One JSON object per line."""
+back), on C1's (one free pose) and others, per ordering, as ONE launch (sparse_small_step_kernel, where the factor fits one compute unit's LDS) and in the multi-launch form;
+run under `rocprofv3 --kernel-trace --stats` for the per-kernel durations.  One JSON object per line."""
 import json
 import os
 import sys
@@ -32,28 +33,35 @@ def graph(n):
     return [(a - 1, b - 1) for a, b in pairs]  # pose 0 held: slot -1
 
 
-for name, n in (("C3 (64 poses)", 64), ("C1 (2 poses)", 2), ("128 poses", 128), ("16 poses", 16)):
+def timed(sp, rec_dev, out):
+    for _ in range(20):
+        sp.step(rec_dev, lam=1e-5, out=out)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(200):
+        t = time.perf_counter()
+        sp.step(rec_dev, lam=1e-5, out=out)
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e3, float(np.min(ts)) * 1e3, out[0].copy()
+
+
+for name, n in (("C3 (64 poses)", 64), ("C1 (2 poses)", 2), ("96 poses", 96), ("128 poses", 128), ("16 poses", 16)):
     slots = graph(n)
     rec = records(slots)
     rec_dev = torch.from_numpy(rec).cuda()
-    ref = None
     for o in ORDERINGS:
         sp = gpa.SparseLinearSystemGPU(n - 1, slots, ordering=o)
         out = (np.zeros(sp.size), np.zeros(sp.size), np.zeros(1))
-        for _ in range(20):
-            sp.step(rec_dev, lam=1e-5, out=out)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(200):
-            t = time.perf_counter()
-            sp.step(rec_dev, lam=1e-5, out=out)
-            ts.append(time.perf_counter() - t)
-        x = out[0].copy()
-        # against numpy on the downloaded system
+        row = dict(graph=name, ordering=o)
+        x_one = None
+        if sp.set_one_launch(True):
+            med, mn, x_one = timed(sp, rec_dev, out)
+            row.update(one_launch_ms=round(med, 4), one_launch_ms_min=round(mn, 4))
+        sp.set_one_launch(False)
+        med, mn, x = timed(sp, rec_dev, out)
+        row.update(multi_launch_ms=round(med, 4), multi_launch_ms_min=round(mn, 4), bit_identical=bool(np.array_equal(x, x_one)) if x_one is not None else None)
         A, b, c = sp.build(rec_dev, lam=1e-5).download()
         xr = np.linalg.solve(A, b)
-        if ref is None:
-            ref = x
         sym = gpa.solver.sparse_symbolic(n - 1, slots, gpa.SparseLinearSystemGPU.ORDERINGS[o])
-        print(json.dumps(dict(graph=name, ordering=o, step_ms=round(float(np.median(ts)) * 1e3, 4), step_ms_min=round(float(np.min(ts)) * 1e3, 4), levels=sym["num_levels"], critical_columns=sym["critical_columns"],
-                              lists=sym["num_lists"], l_blocks=sym["nnz_l_blocks"], rel_err_vs_numpy=float(np.abs(x - xr).max() / np.abs(xr).max()))), flush=True)
+        row.update(levels=sym["num_levels"], critical_columns=sym["critical_columns"], lists=sym["num_lists"], l_blocks=sym["nnz_l_blocks"], rel_err_vs_numpy=float(np.abs(x - xr).max() / np.abs(xr).max()))
+        print(json.dumps(row), flush=True)

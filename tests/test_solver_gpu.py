@@ -334,3 +334,75 @@ def test_step_is_build_download_solve_in_one_call(gpu, kind):
     assert np.abs(out[1] - bh).max() <= 1e-12 * np.abs(bh).max() and abs(out[2][0] - ch) <= 1e-12 * abs(ch) and np.all(out[0] == 7.0)
     x, _, _ = free.step(rec_f_dev, lam=1.0)  # ... and lambda cures it: (0 + I) x = b
     assert np.abs(x - bh).max() <= 1e-12 * np.abs(bh).max()
+
+
+def _c3_like_slots(n):
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, min(i + 5, n))]
+    pairs = (pairs + [(j, i) for i, j in pairs])[: 4 * n]
+    return [(a - 1, b - 1) for a, b in pairs]  # pose 0 held
+
+
+@pytest.mark.parametrize("ordering", ["auto", "natural", "nd", "amd", "amd1"])
+@pytest.mark.parametrize("graph", ["c3:64", "c1:2", "band:16", "band:100", "chain:128", "freechain:40", "isolated"])
+def test_one_launch_step_is_bit_identical(gpu, graph, ordering):
+    """a system whose factor fits the LDS of one compute unit runs its damped step as ONE launch (sparse_small_step_kernel: assembly, damping, the levels of the
+    block-sparse LL^T, both substitutions, x / b / c / status to the host).  Same operations in the same order as the multi-launch form: x, b, c bit for bit, with every
+    damping form and a prior, for BASELINE configs[2]'s graph (64 poses, 256 factors), configs[0]'s (one free pose) and others; against numpy as well."""
+    import torch
+
+    rng = np.random.default_rng(17)
+    kind, _, num = graph.partition(":")
+    if kind == "c3" or kind == "c1":
+        n = int(num)
+        slots, P = _c3_like_slots(n), n - 1
+    elif kind == "band":
+        P = int(num)
+        slots = [(-1, 0)] + [(i, i + d) for i in range(P) for d in (1, 2, 5) if i + d < P]
+    elif kind == "chain":
+        P = int(num)
+        slots = [(-1, 0)] + [(i, i + 1) for i in range(P - 1)]
+    elif kind == "freechain":  # no pose held: more than sixteen one-column subtrees under the minimum-degree orderings (teams of one wave, two batches per level)
+        P = int(num)
+        slots = [(i, i + 1) for i in range(P - 1)]
+    else:
+        P = 12
+        slots = [(-1, 0), (0, 1), (1, 2), (-1, 5), (5, 6), (6, 7), (7, 5), (-1, 11), (-1, 3), (3, 4), (-1, 8), (8, 9), (9, 10)]
+    rec = _random_records(slots, rng)
+    rec_dev = torch.from_numpy(rec).cuda()
+    one, multi = gpu.SparseLinearSystemGPU(P, slots, ordering=ordering), gpu.SparseLinearSystemGPU(P, slots, ordering=ordering)
+    if not one.set_one_launch(True):
+        sym = gpu.solver.sparse_symbolic(P, slots, gpu.SparseLinearSystemGPU.ORDERINGS[ordering])
+        assert sym["nnz_l_blocks"] > 380, sym  # (only a factor too large for the LDS may decline: the dissection of the 64-pose band graph, 522 blocks)
+        pytest.skip(f"{sym['nnz_l_blocks']} blocks of L do not fit one compute unit's LDS: multi-launch only")
+    assert multi.set_one_launch(False) is False
+    prior = rng.uniform(0.0, 2.0, 6 * P)
+    Ah, bh, ch = _host_system(rec, slots, P)
+    for lam, diag, pr in [(1e-5, False, None), (0.0, False, None), (1e-3, False, None), (10.0, True, None), (1e-2, False, prior), (0.5, True, prior)]:
+        x1, b1, c1 = one.step(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)
+        xm, bm, cm = multi.step(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)
+        assert np.array_equal(x1, xm) and np.array_equal(b1, bm) and c1 == cm, (lam, diag, pr is not None, float(np.abs(x1 - xm).max()))
+        damp = lam * np.diag(np.clip(np.diag(Ah), 1e-6, 1e32)) if diag else lam * np.eye(6 * P)
+        if kind != "freechain" or lam > 0.0 or pr is not None:  # (the free chain's undamped system has the gauge freedom: both forms factor it alike, numpy has no say)
+            want = np.linalg.solve(Ah + damp + (np.diag(pr) if pr is not None else 0.0), bh)
+            assert np.linalg.norm(x1 - want) <= 1e-7 * np.linalg.norm(want)
+        assert np.abs(b1 - bh).max() <= 1e-12 * np.abs(bh).max() and abs(c1 - ch) <= 1e-12 * abs(ch)
+    # twice the same: nothing is left in the system between steps
+    again = one.step(rec_dev, lam=1e-5)[0]
+    assert np.array_equal(again, multi.step(rec_dev, lam=1e-5)[0])
+    # an indeterminate system is reported by both forms alike, b and c arrive all the same
+    rec0 = rec.copy()
+    rec0[:, 2:110] = 0.0
+    rec0_dev = torch.from_numpy(rec0).cuda()
+    for sysm in (one, multi):
+        out = (np.full(6 * P, 7.0), np.zeros(6 * P), np.zeros(1))
+        with pytest.raises(gpu.GPError):
+            sysm.step(rec0_dev, out=out)
+        assert np.all(out[0] == 7.0) and np.abs(out[1] - bh).max() <= 1e-12 * np.abs(bh).max()
+    assert np.array_equal(one.step(rec0_dev, lam=1.0)[0], multi.step(rec0_dev, lam=1.0)[0])
+
+
+def test_one_launch_step_declines_a_factor_that_does_not_fit(gpu):
+    P = 512
+    slots = [(-1, 0)] + [(i, i + d) for i in range(P) for d in (1, 2, 7) if i + d < P]
+    sp = gpu.SparseLinearSystemGPU(P, slots)
+    assert sp.set_one_launch(True) is False  # 512 poses: the multi-launch schedule stays in charge
