@@ -124,6 +124,7 @@ _SIGNATURES = {
     "gp_sparse_system_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_set_one_launch": (C.c_int, [C.c_void_p, C.c_int]),
+    "gp_debug_sparse_step_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gp_sparse_symbolic": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gp_sparse_symbolic_schedule": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gp_cloud_upload_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

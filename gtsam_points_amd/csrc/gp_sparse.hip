@@ -48,6 +48,7 @@ struct SparseSymbolic {
   std::vector<int> level_ptr;            // [num_levels + 1] -> work lists: level 0 = the subtrees, level l >= 1 = the top chains whose children are all in lower levels
   int num_subtrees = 0;
   long long nnzA = 0;
+  long long num_contribs = 0;  // entries of the assembly's contribution list: one per factor side with a slot + one per factor with two slots
 };
 
 // nested dissection by BFS bisection: order = nd(A) ++ nd(B) ++ separator
@@ -202,6 +203,11 @@ static int sparse_symbolic_with(int num_slots, const int* factor_slots, int num_
   for (auto& v : adj) {
     std::sort(v.begin(), v.end());
     v.erase(std::unique(v.begin(), v.end()), v.end());
+  }
+  S.num_contribs = 0;
+  for (int f = 0; f < num_factors; f++) {
+    const int a = factor_slots[2 * f], b = factor_slots[2 * f + 1];
+    S.num_contribs += (a >= 0) + (b >= 0) + (a >= 0 && b >= 0);
   }
   S.perm.resize(P);
   if (ordering == 1) {
@@ -391,15 +397,18 @@ static int critical_columns(const SparseSymbolic& S) {
 
 // the one-launch step of small graphs (sparse_small_step_kernel below): one 1024-thread workgroup, up to sixteen work lists of a level side by side
 constexpr int kSmallThreads = 1024, kSmallTeams = 16;
-constexpr int kSmallTeamDoubles = 152;  // per team: D[6][7] | rhs[6] | v[6] (backward) | pad 2 | part: rpart[16][6] (forward) / bpart[6][6] (backward)
+constexpr int kSmallTeamDoubles = 158;  // per team: D[6][7] | rhs[6] | v[6] (backward) | pad 2 | part: rpart[16][6] (forward) / bpart[6][6] (backward) | dinv[6]
 // LDS bytes that step needs for a symbolic factorisation: L's blocks, y, x, the teams' scratch, the error partials, the index lists (0: the factor does not qualify)
 static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_out = nullptr) {
   const size_t P = (size_t)S.P, nnzL = (size_t)S.colptr[S.P];
+  // (the assembly's lists: one destination per block of L, 4 ints; at most one contribution per block of A and factor side -- nnzA bounds the blocks, every factor
+  //  adds up to three contributions: counted exactly by the caller that has the factor list, bounded here by 3 x the products of A's structure is not possible, so the
+  //  symbolic phase records the contribution count it will need: S.num_contribs)
   const size_t words = S.colptr.size() + S.rowidx.size() + S.upd_ptr.size() + S.upd_a.size() + S.upd_b.size() + S.row_ptr.size() + S.row_blk.size() + S.row_col.size() +
-                       S.work_ptr.size() + S.work_cols.size();
+                       S.work_ptr.size() + S.work_cols.size() + 4 * nnzL + 2 * (size_t)S.num_contribs + 4;
   if (arena_words_out) *arena_words_out = words;
   if (P > 128) return 0;  // (row lists stay below the staged kernel's 128-block stage, which the one-launch form assumes)
-  const size_t bytes = sizeof(double) * (36 * nnzL + 12 * P + (size_t)kSmallTeams * kSmallTeamDoubles + 256) + sizeof(int) * words + 64;
+  const size_t bytes = sizeof(double) * (36 * nnzL + 24 * P + (size_t)kSmallTeams * kSmallTeamDoubles + 256) + sizeof(int) * words + 64;
   return bytes <= 160 * 1024 - 256 ? bytes : 0;
 }
 static bool small_step_fits(const SparseSymbolic& S) { return small_step_lds_bytes(S) != 0; }
@@ -448,6 +457,7 @@ struct SparseStepExtras {
   double* c_host;            // pinned
   int* status;
   int num_factors, num_dests;
+  double* diag0;             // [6 P], elimination order: the assembled (damped) diagonal of A, the scale a pivot is held against (kPivotTolerance)
 };
 
 // A's blocks into their places in L's storage (every block of L has a destination: fill blocks have an empty contribution list and become zero) + b, one 64-lane
@@ -502,6 +512,7 @@ __global__ void __launch_bounds__(64) sparse_assemble_kernel(const SparseDest* _
       s = __dadd_rn(s, add);
     }
     L[36 * (size_t)d.block + t] = s;
+    if (d.diag_col >= 0 && r == c) ex.diag0[6 * (size_t)d.diag_col + r] = s;
   } else if (t < 42 && d.diag_col >= 0) {
     const int r = t - 36;
     double s = 0.0;
@@ -516,7 +527,7 @@ __global__ void __launch_bounds__(64) sparse_assemble_kernel(const SparseDest* _
 }
 
 __global__ void __launch_bounds__(256) sparse_damp_kernel(double* __restrict__ L, const int* __restrict__ colptr, int n, double lambda, int diagonal, double min_diag,
-                                                          double max_diag, const double* __restrict__ prior_diag /*elimination order*/) {
+                                                          double max_diag, const double* __restrict__ prior_diag /*elimination order*/, double* __restrict__ diag0) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double* p = L + 36 * (size_t)colptr[i / 6] + 7 * (i % 6);
@@ -524,6 +535,7 @@ __global__ void __launch_bounds__(256) sparse_damp_kernel(double* __restrict__ L
   double add = diagonal ? __dmul_rn(lambda, fmin(fmax(d, min_diag), max_diag)) : lambda;
   if (prior_diag) add = __dadd_rn(add, prior_diag[i]);
   *p = __dadd_rn(d, add);
+  diag0[i] = *p;
 }
 
 struct SparseView {
@@ -541,6 +553,8 @@ struct SparseView {
   double* L;      // [nnzL][36], column-major 6x6 blocks
   double* y;      // [6 P] forward-substituted right-hand side (in: b), elimination order
   double* x;      // [6 P] solution, elimination order
+  double* dinv;   // [6 P] reciprocals of L's diagonal, written with every factored column (the substitutions multiply by them)
+  const double* diag0;  // [6 P] the assembled diagonal of A (what a pivot is compared with)
   int* status;    // != 0: a pivot was not positive
 };
 
@@ -554,11 +568,137 @@ struct SparseView {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
   } while (0)
 
+// ---- the 6 x 6 pieces every numeric kernel below shares (round 6) ------------------------------------------------------------------------------------------------------
+// A column of the factorisation is ONE dependent chain -- gather -> 6 x 6 Cholesky -> forward substitution / the blocks below -- and rounds 1-5 spent it on IEEE f64
+// divisions and square roots (18 divisions + 6 square roots per column on the chain, ~300 clocks each) and on LDS round trips between them: 6-8 us per column whether
+// the operands sat in L2 or in LDS (profiles/r06_solver_step_time_one.jsonl).  Now a pivot costs one reciprocal square root (hardware estimate + two Newton steps, ~1 ulp)
+// and everything that divided by a diagonal entry multiplies by the stored reciprocal; the substitutions run out of registers.  All four kernels call THESE functions, so
+// the one-launch step and the multi-launch form stay bit-identical by construction.
+__device__ __forceinline__ double rsqrt_f64(double x) {  // x > 0
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {  // y <- y + y (1/2 - (x / 2) y^2)
+    const double e = __builtin_fma(-(hx * y), y, 0.5);
+    y = __builtin_fma(y, e, y);
+  }
+  return y;
+}
+// ONE wave, all 64 lanes call (lane j < 36 = entry (r, c) = (j % 6, j / 6)): the lower triangle of D (LDS, row stride 7) becomes its Cholesky factor, dinv[p] = 1 / L_pp.
+// A pivot that is not positive raises *bad and is replaced by 1 (the caller reports an indeterminate system).
+// The entries live in the lanes' registers between the one read and the one write of D: a pivot is broadcast with v_readlane, the two column entries an update needs come
+// through ds_bpermute -- no LDS round trip + wait per step (the LDS form measured 480 clocks per pivot: scripts/r06/solver_trace.py).
+__device__ __forceinline__ double lane_bcast_f64(double v, const int src_lane /* compile-time constant after unrolling */) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, src_lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src_lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+// A pivot must exceed kPivotTolerance x the diagonal entry of A it came from (scale6: the column's six assembled diagonal entries).  Rounds 1-5 asked for piv > 0: whether
+// a SINGULAR system (gauge freedom: no pose held) was reported then depended on the sign rounding left on a pivot of magnitude ~1e-13 A_pp; GTSAM's own Cholesky treats
+// pivots below a threshold as zero (base/cholesky.cpp: zeroPivotThreshold) for the same reason.  1e-11 relative: a system conditioned worse than that has no digits left.
+constexpr double kPivotTolerance = 1e-11;
+__device__ __forceinline__ void chol6_wave(double (*D)[7], double* dinv, const int j, int* bad, const double* scale6) {
+  const int r = j % 6, c = j / 6;
+  double a = j < 36 ? D[r][c] : 0.0;
+  double dv[6], sc[6];
+#pragma unroll
+  for (int p = 0; p < 6; p++) sc[p] = scale6[p];
+  bool any_bad = false;
+#pragma unroll
+  for (int p = 0; p < 6; p++) {
+    double piv = lane_bcast_f64(a, 7 * p);  // D[p][p]: wave-uniform
+    if (!(piv > kPivotTolerance * sc[p])) {
+      any_bad = true;
+      piv = 1.0;
+    }
+    const double rl = rsqrt_f64(piv);
+    const double l = piv * rl;
+    dv[p] = rl;
+    if (j < 36 && c == p && r >= p) a = r == p ? l : a * rl;
+    // the column just scaled: entry (r, p) for the lane's row, entry (c, p) for its column (every lane asks: the shuffles are wave-wide)
+    const double arp = __shfl(a, (r + 6 * p) & 63, 64), acp = __shfl(a, (c + 6 * p) & 63, 64);
+    if (j < 36 && c > p && r >= c) a = __builtin_fma(-arp, acp, a);
+  }
+  if (j < 36) D[r][c] = a;
+  if (j == 36) {
+#pragma unroll
+    for (int p = 0; p < 6; p++) dinv[p] = dv[p];
+  }
+  if (j == 0 && any_bad) *bad = 1;
+  GP_WAVE_SYNC_LDS();
+}
+// ONE lane: rhs <- L^-1 rhs by forward substitution, out of registers (every operand is requested before the chain starts)
+__device__ __forceinline__ void forward6(double (*D)[7], const double* dinv, double* rhs) {
+  double d[6][6], iv[6], y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    iv[i] = dinv[i];
+    y[i] = rhs[i];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      if (q < i) d[i][q] = D[i][q];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double sum = y[i];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      if (q < i) sum = __builtin_fma(-d[i][q], y[q], sum);
+    y[i] = sum * iv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) rhs[i] = y[i];
+}
+// ONE lane: row r of a block below the diagonal, B <- B L^-T (forward substitution along the row); Bk = the block, column-major
+__device__ __forceinline__ void trsm_row6(double* Bk, const int r, double (*D)[7], const double* dinv) {
+  double d[6][6], iv[6], o[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    iv[c] = dinv[c];
+    o[c] = Bk[r + 6 * c];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      if (q < c) d[c][q] = D[c][q];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    double sum = o[c];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      if (q < c) sum = __builtin_fma(-o[q], d[c][q], sum);
+    o[c] = sum * iv[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
+}
+// ONE lane: x_k = L_kk^-T v by backward substitution; Dk = the factored diagonal block, column-major; dinv_k = the reciprocals of its diagonal
+__device__ __forceinline__ void back6(const double* Dk, const double* dinv_k, const double* v, double* xk_out) {
+  double d[6][6], iv[6], xk[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    iv[i] = dinv_k[i];
+    xk[i] = v[i];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      if (q > i) d[q][i] = Dk[q + 6 * i];  // (L^T)_{iq} = L_{qi}
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double sum = xk[i];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      if (q > i) sum = __builtin_fma(-d[q][i], xk[q], sum);
+    xk[i] = sum * iv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) xk_out[i] = xk[i];
+}
+
 // left-looking block Cholesky of the columns of work list (first_list + blockIdx.x), in elimination order
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) sparse_factor_kernel(SparseView S, int first_list) {
   __shared__ double D[6][7];   // diagonal block (row stride 7: the column sweeps below are conflict-free), becomes L_kk
-  __shared__ double rhs[6];
+  __shared__ double rhs[6], dinv[6];
   __shared__ int bad;
   const int list = first_list + blockIdx.x;
   const int t = threadIdx.x;
@@ -643,49 +783,17 @@ __global__ void __launch_bounds__(THREADS) sparse_factor_kernel(SparseView S, in
       rhs[r] = acc;
     }
     __syncthreads();
-    // 2. the diagonal block: 6x6 Cholesky by the first wave (lane = (row, column)), then y_k = L_kk^-1 rhs
+    // 2. the diagonal block: 6x6 Cholesky by the first wave (chol6_wave), then y_k = L_kk^-1 rhs by one lane out of registers
     if (t < 64) {
-      const int r = t % 6, c = t / 6;
-      for (int j = 0; j < 6; j++) {
-        double piv = D[j][j];
-        if (!(piv > 0.0)) {
-          if (t == 0) bad = 1;
-          piv = 1.0;
-        }
-        const double l = sqrt(piv);
-        GP_WAVE_SYNC_LDS();
-        if (t < 36 && c == j && r >= j) D[r][j] = r == j ? l : D[r][j] / l;
-        GP_WAVE_SYNC_LDS();
-        if (t < 36 && c > j && r >= c) D[r][c] -= D[r][j] * D[c][j];
-        GP_WAVE_SYNC_LDS();
-      }
-      if (t == 0) {
-        for (int i = 0; i < 6; i++) {
-          double s = rhs[i];
-          for (int q = 0; q < i; q++) s -= D[i][q] * rhs[q];
-          rhs[i] = s / D[i][i];
-        }
-      }
+      chol6_wave(D, dinv, t, &bad, S.diag0 + 6 * (size_t)k);
+      if (t == 0) forward6(D, dinv, rhs);
     }
     __syncthreads();
     if (t < 36) S.L[36 * (size_t)base + t] = (t % 6) >= (t / 6) ? D[t % 6][t / 6] : 0.0;
     if (t >= 64 && t < 70) S.y[6 * (size_t)k + (t - 64)] = rhs[t - 64];
-    // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row): forward substitution along the row
-    for (int e = t; e < 6 * (nb - 1); e += THREADS) {
-      double* Bk = S.L + 36 * (size_t)(base + 1 + e / 6);
-      const int r = e % 6;
-      double o[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = Bk[r + 6 * c];
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-          if (q < c) s -= o[q] * D[c][q];
-        o[c] = s / D[c][c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
-    }
+    if (t >= 70 && t < 76) S.dinv[6 * (size_t)k + (t - 70)] = dinv[t - 70];
+    // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row): forward substitution along the row (trsm_row6)
+    for (int e = t; e < 6 * (nb - 1); e += THREADS) trsm_row6(S.L + 36 * (size_t)(base + 1 + e / 6), e % 6, D, dinv);
     __syncthreads();  // the next column of this list reads these blocks (same compute unit: global writes are visible after the barrier)
   }
   if (t == 0 && bad) atomicOr(S.status, 1);
@@ -709,7 +817,7 @@ __global__ void __launch_bounds__(THREADS) sparse_factor_staged_kernel(SparseVie
   __shared__ double part[THREADS][6];      // slice partials: [row item * G + slice][c]
   __shared__ double rpart[16][6];
   __shared__ double D[6][7];
-  __shared__ double rhs[6];
+  __shared__ double rhs[6], dinv[6];
   __shared__ int bad;
   const int list = first_list + blockIdx.x;
   const int t = threadIdx.x;
@@ -835,49 +943,17 @@ __global__ void __launch_bounds__(THREADS) sparse_factor_staged_kernel(SparseVie
       }
     }
     __syncthreads();
-    // 2. the diagonal block: 6x6 Cholesky by the first wave (lane = (row, column)), then y_k = L_kk^-1 rhs
+    // 2. the diagonal block: 6x6 Cholesky by the first wave (chol6_wave), then y_k = L_kk^-1 rhs by one lane out of registers
     if (t < 64) {
-      const int r = t % 6, c = t / 6;
-      for (int j = 0; j < 6; j++) {
-        double piv = D[j][j];
-        if (!(piv > 0.0)) {
-          if (t == 0) bad = 1;
-          piv = 1.0;
-        }
-        const double l = sqrt(piv);
-        GP_WAVE_SYNC_LDS();
-        if (t < 36 && c == j && r >= j) D[r][j] = r == j ? l : D[r][j] / l;
-        GP_WAVE_SYNC_LDS();
-        if (t < 36 && c > j && r >= c) D[r][c] -= D[r][j] * D[c][j];
-        GP_WAVE_SYNC_LDS();
-      }
-      if (t == 0) {
-        for (int i = 0; i < 6; i++) {
-          double s = rhs[i];
-          for (int q = 0; q < i; q++) s -= D[i][q] * rhs[q];
-          rhs[i] = s / D[i][i];
-        }
-      }
+      chol6_wave(D, dinv, t, &bad, S.diag0 + 6 * (size_t)k);
+      if (t == 0) forward6(D, dinv, rhs);
     }
     __syncthreads();
     if (t < 36) S.L[36 * (size_t)base + t] = (t % 6) >= (t / 6) ? D[t % 6][t / 6] : 0.0;
     if (t >= 64 && t < 70) S.y[6 * (size_t)k + (t - 64)] = rhs[t - 64];
-    // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row)
-    for (int e = t; e < 6 * (nb - 1); e += THREADS) {
-      double* Bk = S.L + 36 * (size_t)(base + 1 + e / 6);
-      const int r = e % 6;
-      double o[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = Bk[r + 6 * c];
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-          if (q < c) s -= o[q] * D[c][q];
-        o[c] = s / D[c][c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
-    }
+    if (t >= 70 && t < 76) S.dinv[6 * (size_t)k + (t - 70)] = dinv[t - 70];
+    // 3. the blocks below: L_ik = B_ik L_kk^-T, one lane per (block, row): forward substitution along the row (trsm_row6)
+    for (int e = t; e < 6 * (nb - 1); e += THREADS) trsm_row6(S.L + 36 * (size_t)(base + 1 + e / 6), e % 6, D, dinv);
     __syncthreads();  // the next column of this list reads these blocks (same compute unit: global writes are visible after the barrier)
   }
   if (t == 0 && bad) atomicOr(S.status, 1);
@@ -910,16 +986,7 @@ __global__ void __launch_bounds__(64) sparse_backsolve_kernel(SparseView S, int 
       v[t] = s;
     }
     __syncthreads();
-    if (t == 0) {
-      const double* Dk = S.L + 36 * (size_t)base;
-      double xk[6];
-      for (int i = 5; i >= 0; i--) {
-        double s = v[i];
-        for (int q = i + 1; q < 6; q++) s -= Dk[q + 6 * i] * xk[q];  // (L^T)_{iq} = L_{qi}
-        xk[i] = s / Dk[i + 6 * i];
-      }
-      for (int i = 0; i < 6; i++) S.x[6 * (size_t)k + i] = xk[i];
-    }
+    if (t == 0) back6(S.L + 36 * (size_t)base, S.dinv + 6 * (size_t)k, v, S.x + 6 * (size_t)k);
     __syncthreads();  // x_k is read by the next columns of this list (one wave per workgroup: the barrier is free)
   }
 }
@@ -969,6 +1036,39 @@ __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __
 // Every scalar is computed by the SAME sequence of operations as in sparse_factor_kernel<256> (lists of level 0) / sparse_factor_staged_kernel<1024> (levels above: the
 // slice partials with G and `per` derived from the column's size exactly as there) / sparse_backsolve_kernel, so the step is bit-identical to the multi-launch form
 // (tests/test_solver_gpu.py::test_one_launch_step_is_bit_identical); only where the operands live and which thread computes what differ.
+// acc - sum over the products u in [u, ue) of (row r of block upd_a[u]) . (row c of block upd_b[u]), subtracted in list order; operands in LDS.  Four products' indices,
+// then their 48 operands, are requested together (one entry's products are a chain of dependent LDS round trips otherwise: 800 clocks per product measured)
+__device__ __forceinline__ double small_sub_products(double acc, const int* upd_a, const int* upd_b, int u, const int ue, const double* Ls, const int r, const int c) {
+  constexpr int kBatch = 4;
+  for (; u < ue; u += kBatch) {
+    int ia[kBatch], ib[kBatch];
+#pragma unroll
+    for (int w = 0; w < kBatch; w++) {
+      const int uu = u + w < ue ? u + w : ue - 1;  // (a short tail repeats the last product's operands and skips its subtraction)
+      ia[w] = upd_a[uu];
+      ib[w] = upd_b[uu];
+    }
+    double av[kBatch][6], bv[kBatch][6];
+#pragma unroll
+    for (int w = 0; w < kBatch; w++) {
+      const double* A = Ls + 36 * (size_t)ia[w];
+      const double* B = Ls + 36 * (size_t)ib[w];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        av[w][q] = A[r + 6 * q];
+        bv[w][q] = B[c + 6 * q];
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < kBatch; w++)
+      if (u + w < ue) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc -= av[w][q] * bv[w][q];
+      }
+  }
+  return acc;
+}
+
 struct SparseSmallView {
   const SparseDest* dests;
   const SparseContribution* contribs;
@@ -976,17 +1076,23 @@ struct SparseSmallView {
   const int* level_ptr;   // [num_levels + 1] -> work lists (global; read once per level)
   int arena_words, num_levels, P, nnzL, num_dests;
   int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols;  // offsets (ints) inside the arena
+  int o_dests, o_contribs;  // the assembly's destination and contribution lists ride in the arena as well (4 / 2 ints each): one bulk copy instead of two dependent round
+                            // trips to L2 in front of every value (the assembly measured 40 us of a 190 us step that way)
   const int* perm;        // elimination order -> slot (global)
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
   double* status_host;    // pinned
+  unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] assembled, [2] factored, [3] substituted, [4] end,
+                              // [8 + 4 r + {0, 1, 2, 3}]: round r < 14 of the first level: start, gathered, diagonal done, blocks below done; null = off
 };
 __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const SparseSmallView V, const double* __restrict__ records, const SparseStepExtras ex) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* Ls = small_lds;                                   // [nnzL][36]
   double* ys = Ls + 36 * (size_t)V.nnzL;                    // [6 P]
   double* xs = ys + 6 * (size_t)V.P;                        // [6 P]
-  double* scr = xs + 6 * (size_t)V.P;                       // [kSmallTeams][kSmallTeamDoubles]
+  double* dis = xs + 6 * (size_t)V.P;                       // [6 P] reciprocals of L's diagonal
+  double* d0s = dis + 6 * (size_t)V.P;                      // [6 P] the assembled diagonal of A (the pivots' scale)
+  double* scr = d0s + 6 * (size_t)V.P;                      // [kSmallTeams][kSmallTeamDoubles]
   double* cpart = scr + kSmallTeams * kSmallTeamDoubles;    // [256]: the error sum's partials
   int* idx = reinterpret_cast<int*>(cpart + 256);           // the index lists
   __shared__ int bad;
@@ -1002,29 +1108,39 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   const int* work_ptr = idx + V.o_work_ptr;
   const int* work_cols = idx + V.o_work_cols;
   // ---- phase 0 ----
+#define GP_SMALL_STAMP(i)                                                       \
+  do {                                                                          \
+    if (V.trace && t == 0) V.trace[i] = __builtin_amdgcn_s_memtime();           \
+  } while (0)
+  GP_SMALL_STAMP(0);
   if (t == 0) bad = 0;
   for (int i = t; i < V.arena_words; i += kSmallThreads) idx[i] = V.arena[i];
   // the assembly: one thread per (destination, lane 0 .. 41) of sparse_assemble_kernel's 64-lane workgroups (lanes 42 .. 63 do nothing there)
+  __syncthreads();
+  const SparseDest* dests_l = reinterpret_cast<const SparseDest*>(idx + V.o_dests);
+  const SparseContribution* contribs_l = reinterpret_cast<const SparseContribution*>(idx + V.o_contribs);
   for (int item = t; item < 42 * V.num_dests; item += kSmallThreads) {
-    const SparseDest d = V.dests[item / 42];
+    const SparseDest d = dests_l[item / 42];
     const int l = item % 42;
     if (l < 36) {
       const int r = l % 6, c = l / 6;
       double s = 0.0;
-      for (int k = 0; k < d.count; k++) {
-        const SparseContribution q = V.contribs[d.begin + k];
-        const double* rec = records + 122 * (size_t)q.factor;
-        double v;
-        if (q.take == STAKE_HT) {
-          v = rec[SREC_HT + c * 6 + r];
-        } else if (q.take == STAKE_HS) {
-          v = rec[SREC_HS + c * 6 + r];
-        } else if (q.take == STAKE_HTS) {
-          v = rec[SREC_HTS + c * 6 + r];
-        } else {
-          v = rec[SREC_HTS + r * 6 + c];
+      // (eight contributions' descriptors, then their eight values, requested together and added in list order: one thread walks a dozen destinations, and taken
+      //  one at a time every value is two dependent round trips to L2 -- the assembly measured 40 us of the step that way)
+      for (int k0 = 0; k0 < d.count; k0 += 8) {
+        SparseContribution q[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) q[w] = contribs_l[d.begin + (k0 + w < d.count ? k0 + w : d.count - 1)];
+        double v[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+          const double* rec = records + 122 * (size_t)q[w].factor;
+          const int off = q[w].take == STAKE_HT ? SREC_HT + c * 6 + r : q[w].take == STAKE_HS ? SREC_HS + c * 6 + r : q[w].take == STAKE_HTS ? SREC_HTS + c * 6 + r : SREC_HTS + r * 6 + c;
+          v[w] = rec[off];
         }
-        s += v;
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+          if (k0 + w < d.count) s += v[w];
       }
       if (d.diag_col >= 0 && r == c && (ex.lambda > 0.0 || ex.prior_diag)) {
         double add = ex.diagonal ? __dmul_rn(ex.lambda, fmin(fmax(s, ex.min_diag), ex.max_diag)) : ex.lambda;
@@ -1032,13 +1148,20 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
         s = __dadd_rn(s, add);
       }
       Ls[36 * (size_t)d.block + l] = s;
+      if (d.diag_col >= 0 && r == c) d0s[6 * (size_t)d.diag_col + r] = s;
     } else if (d.diag_col >= 0) {
       const int r = l - 36;
       double s = 0.0;
-      for (int k = 0; k < d.count; k++) {
-        const SparseContribution q = V.contribs[d.begin + k];
-        const double* rec = records + 122 * (size_t)q.factor;
-        s -= q.take == STAKE_HT ? rec[SREC_BT + r] : rec[SREC_BS + r];
+      for (int k0 = 0; k0 < d.count; k0 += 8) {
+        SparseContribution q[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) q[w] = contribs_l[d.begin + (k0 + w < d.count ? k0 + w : d.count - 1)];
+        double v[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) v[w] = (records + 122 * (size_t)q[w].factor)[q[w].take == STAKE_HT ? SREC_BT + r : SREC_BS + r];
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+          if (k0 + w < d.count) s -= v[w];
       }
       ys[6 * (size_t)d.diag_col + r] = s;
       ex.b_slots_host[6 * (size_t)ex.perm[d.diag_col] + r] = s;
@@ -1059,6 +1182,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     *ex.c_dev = cpart[0];
     *ex.c_host = cpart[0];
   }
+  GP_SMALL_STAMP(1);
   // ---- phase 1: factorisation + forward substitution ----
   for (int lvl = 0; lvl < V.num_levels; lvl++) {
     const int first = V.level_ptr[lvl], nlists = V.level_ptr[lvl + 1] - first;
@@ -1076,23 +1200,21 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
       double (*D)[7] = reinterpret_cast<double (*)[7]>(S);
       double* rhs = S + 42;
       double (*rpart)[6] = reinterpret_cast<double (*)[6]>(S + 56);
+      double* dinv = S + 152;
       for (int rd = 0; rd < rounds; rd++) {
         const bool on = member && rd < len;
         const int k = on ? work_cols[w0 + rd] : 0;
         const int base = colptr[k], nb = colptr[k + 1] - base;
         const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
+        const bool stamp = lvl == 0 && b0 == 0 && rd < 14;
+        if (stamp) GP_SMALL_STAMP(8 + 4 * rd);
         if (on) {
           // 1. gather: one thread per entry of the column's blocks
           if (!staged) {
             for (int e = j; e < 36 * nb; e += T) {
               const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
               double acc = Ls[36 * (size_t)d + (e % 36)];
-              for (int u = upd_ptr[d]; u < upd_ptr[d + 1]; u++) {
-                const double* A = Ls + 36 * (size_t)upd_a[u];
-                const double* B = Ls + 36 * (size_t)upd_b[u];
-#pragma unroll
-                for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * B[c + 6 * q];
-              }
+              acc = small_sub_products(acc, upd_a, upd_b, upd_ptr[d], upd_ptr[d + 1], Ls, r, c);
               if (d == base) D[r][c] = acc;
               else Ls[36 * (size_t)d + (e % 36)] = acc;
             }
@@ -1118,14 +1240,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
               const int per = (ulen + G - 1) / G;
               double v = Ls[36 * (size_t)d + (e % 36)];
               for (int g = 0; g < G; g++) {
-                double acc = 0.0;
-                const int ue = min(ub + ulen, ub + g * per + per);
-                for (int u = ub + g * per; u < ue; u++) {
-                  const double* A = Ls + 36 * (size_t)upd_a[u];
-                  const double* B = Ls + 36 * (size_t)upd_b[u];
-#pragma unroll
-                  for (int m = 0; m < 6; m++) acc -= A[r + 6 * m] * B[c + 6 * m];
-                }
+                const double acc = small_sub_products(0.0, upd_a, upd_b, ub + g * per, min(ub + ulen, ub + g * per + per), Ls, r, c);
                 v += acc;
               }
               if (d == base) D[r][c] = v;
@@ -1146,6 +1261,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
           }
         }
         __syncthreads();
+        if (stamp) GP_SMALL_STAMP(8 + 4 * rd + 1);
         // 2. the diagonal block: 6 x 6 Cholesky by the team's first wave (lane = (row, column)), then y_k = L_kk^-1 rhs
         if (on && j < 64) {
           if (staged && j < 6) {
@@ -1153,53 +1269,25 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
             for (int g = 0; g < 16; g++) a += rpart[g][j];
             rhs[j] = a;
           }
-          const int r = j % 6, c = j / 6;
-          for (int p = 0; p < 6; p++) {
-            double piv = D[p][p];
-            if (!(piv > 0.0)) {
-              if (j == 0) bad = 1;
-              piv = 1.0;
-            }
-            const double l = sqrt(piv);
-            GP_WAVE_SYNC_LDS();
-            if (j < 36 && c == p && r >= p) D[r][p] = r == p ? l : D[r][p] / l;
-            GP_WAVE_SYNC_LDS();
-            if (j < 36 && c > p && r >= c) D[r][c] -= D[r][p] * D[c][p];
-            GP_WAVE_SYNC_LDS();
-          }
-          if (j == 0) {
-            for (int i = 0; i < 6; i++) {
-              double sum = rhs[i];
-              for (int q = 0; q < i; q++) sum -= D[i][q] * rhs[q];
-              rhs[i] = sum / D[i][i];
-            }
-          }
+          GP_WAVE_SYNC_LDS();  // (rhs is complete before lane 0 reads it)
+          chol6_wave(D, dinv, j, &bad, d0s + 6 * (size_t)k);
+          if (j == 0) forward6(D, dinv, rhs);
         }
         __syncthreads();
+        if (stamp) GP_SMALL_STAMP(8 + 4 * rd + 2);
         if (on) {
           if (j < 36) Ls[36 * (size_t)base + j] = (j % 6) >= (j / 6) ? D[j % 6][j / 6] : 0.0;
           if (j >= 36 && j < 42) ys[6 * (size_t)k + (j - 36)] = rhs[j - 36];
+          if (j >= 42 && j < 48) dis[6 * (size_t)k + (j - 42)] = dinv[j - 42];
           // 3. the blocks below: L_ik = B_ik L_kk^-T, one thread per (block, row)
-          for (int e = j; e < 6 * (nb - 1); e += T) {
-            double* Bk = Ls + 36 * (size_t)(base + 1 + e / 6);
-            const int r = e % 6;
-            double o[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-              double sum = Bk[r + 6 * c];
-#pragma unroll
-              for (int q = 0; q < 6; q++)
-                if (q < c) sum -= o[q] * D[c][q];
-              o[c] = sum / D[c][c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
-          }
+          for (int e = j; e < 6 * (nb - 1); e += T) trsm_row6(Ls + 36 * (size_t)(base + 1 + e / 6), e % 6, D, dinv);
         }
         __syncthreads();
+        if (stamp) GP_SMALL_STAMP(8 + 4 * rd + 3);
       }
     }
   }
+  GP_SMALL_STAMP(2);
   // ---- phase 2: backward substitution, levels and columns in reverse ----
   for (int lvl = V.num_levels - 1; lvl >= 0; lvl--) {
     const int first = V.level_ptr[lvl], nlists = V.level_ptr[lvl + 1] - first;
@@ -1238,21 +1326,13 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
             vv[j] = sum;
           }
           GP_WAVE_SYNC_LDS();
-          if (j == 0) {
-            const double* Dk = Ls + 36 * (size_t)base;
-            double xk[6];
-            for (int i = 5; i >= 0; i--) {
-              double sum = vv[i];
-              for (int q = i + 1; q < 6; q++) sum -= Dk[q + 6 * i] * xk[q];
-              xk[i] = sum / Dk[i + 6 * i];
-            }
-            for (int i = 0; i < 6; i++) xs[6 * (size_t)k + i] = xk[i];
-          }
+          if (j == 0) back6(Ls + 36 * (size_t)base, dis + 6 * (size_t)k, vv, xs + 6 * (size_t)k);
         }
         __syncthreads();
       }
     }
   }
+  GP_SMALL_STAMP(3);
   // ---- phase 3 ----
   for (int i = t; i < 6 * V.P; i += kSmallThreads) {
     const double v = xs[i];
@@ -1264,6 +1344,8 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     *ex.status = bad;
     *V.status_host = (double)bad;
   }
+  GP_SMALL_STAMP(4);
+#undef GP_SMALL_STAMP
 }
 
 }  // namespace gp
@@ -1274,7 +1356,7 @@ struct gp_sparse_system {
   hipStream_t stream = nullptr;
   std::vector<gp::SparseDest> dests;
   std::vector<gp::SparseContribution> contribs;
-  gp::DeviceArray d_dests, d_contribs, d_int, L, y, x, x_slots, c, status, prior;
+  gp::DeviceArray d_dests, d_contribs, d_int, L, y, x, x_slots, c, status, prior, dinv, diag0;
   gp::PinnedArray pinned;  // gp_sparse_system_step: x [n] | b [n] | c | status, written by the step's kernels, read by the host behind ONE synchronisation
   gp::SparseView view{};
   const int* d_perm = nullptr;
@@ -1379,7 +1461,8 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
   if ((rc = s->d_int.alloc(sizeof(int) * packed.size())) || (rc = s->d_dests.alloc(sizeof(gp::SparseDest) * s->dests.size())) ||
       (rc = s->d_contribs.alloc(sizeof(gp::SparseContribution) * std::max<size_t>(s->contribs.size(), 1))) || (rc = s->L.alloc(sizeof(double) * 36 * (size_t)nnzL)) ||
       (rc = s->y.alloc(sizeof(double) * (size_t)s->n)) || (rc = s->x.alloc(sizeof(double) * (size_t)s->n)) || (rc = s->x_slots.alloc(sizeof(double) * (size_t)s->n)) ||
-      (rc = s->c.alloc(sizeof(double))) || (rc = s->status.alloc(sizeof(int))) || (rc = s->prior.alloc(sizeof(double) * (size_t)s->n)))
+      (rc = s->c.alloc(sizeof(double))) || (rc = s->status.alloc(sizeof(int))) || (rc = s->prior.alloc(sizeof(double) * (size_t)s->n)) ||
+      (rc = s->dinv.alloc(sizeof(double) * (size_t)s->n)) || (rc = s->diag0.alloc(sizeof(double) * (size_t)s->n)))
     return rc;
   GP_HIP(hipMemcpy(s->d_int.ptr, packed.data(), sizeof(int) * packed.size(), hipMemcpyHostToDevice));
   GP_HIP(hipMemcpy(s->d_dests.ptr, s->dests.data(), sizeof(gp::SparseDest) * s->dests.size(), hipMemcpyHostToDevice));
@@ -1400,6 +1483,8 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
   s->view.L = s->L.as<double>();
   s->view.y = s->y.as<double>();
   s->view.x = s->x.as<double>();
+  s->view.dinv = s->dinv.as<double>();
+  s->view.diag0 = s->diag0.as<double>();
   s->view.status = s->status.as<int>();
   // the one-launch step (small graphs): its own copy of the index lists it walks, in the order of SparseSmallView's offsets, and the levels
   size_t small_words = 0;
@@ -1413,6 +1498,13 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
       off[i] = (int)arena.size();
       arena.insert(arena.end(), sa[i]->begin(), sa[i]->end());
     }
+    static_assert(sizeof(gp::SparseDest) == 4 * sizeof(int) && sizeof(gp::SparseContribution) == 2 * sizeof(int), "the assembly's lists ride in the int arena");
+    while (arena.size() & 3) arena.push_back(0);  // (16-byte alignment of the destination records that follow: they are read as one 128-bit LDS access)
+    const int off_dests = (int)arena.size();
+    arena.insert(arena.end(), reinterpret_cast<const int*>(s->dests.data()), reinterpret_cast<const int*>(s->dests.data() + s->dests.size()));
+    const int off_contribs = (int)arena.size();
+    arena.insert(arena.end(), reinterpret_cast<const int*>(s->contribs.data()), reinterpret_cast<const int*>(s->contribs.data() + s->contribs.size()));
+    if (arena.size() > small_words) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: internal: the one-launch step's index arena outgrew its estimate");
     if ((rc = s->d_small_arena.alloc(sizeof(int) * std::max<size_t>(arena.size(), 1))) || (rc = s->d_level_ptr.alloc(sizeof(int) * S.level_ptr.size()))) return rc;
     GP_HIP(hipMemcpy(s->d_small_arena.ptr, arena.data(), sizeof(int) * arena.size(), hipMemcpyHostToDevice));
     GP_HIP(hipMemcpy(s->d_level_ptr.ptr, S.level_ptr.data(), sizeof(int) * S.level_ptr.size(), hipMemcpyHostToDevice));
@@ -1424,6 +1516,7 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     V.arena_words = (int)arena.size(), V.num_levels = (int)S.level_ptr.size() - 1, V.P = P, V.nnzL = nnzL, V.num_dests = (int)s->dests.size();
     V.o_colptr = off[0], V.o_rowidx = off[1], V.o_upd_ptr = off[2], V.o_upd_a = off[3], V.o_upd_b = off[4], V.o_row_ptr = off[5], V.o_row_blk = off[6], V.o_row_col = off[7];
     V.o_work_ptr = off[8], V.o_work_cols = off[9];
+    V.o_dests = off_dests, V.o_contribs = off_contribs;
     V.perm = s->d_perm;
     V.x_slots = s->x_slots.as<double>();
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for; a runtime that refuses leaves the multi-launch step in charge)
@@ -1441,6 +1534,13 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
 
 // the one-launch step (sparse_small_step_kernel): 1 = gp_sparse_system_step uses it when the system qualifies (default), 0 = the multi-launch form; returns what the
 // next step will run (1 / 0).  The two are bit-identical; the switch exists for the test that says so and for A/B timing.
+// measurement hook: the one-launch step's thread 0 leaves shader-clock stamps in dev_buffer (64 uint64; SparseSmallView::trace); null = off
+int gp_debug_sparse_step_trace(gp_sparse_system_t* s, unsigned long long* dev_buffer) {
+  if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_sparse_step_trace: null");
+  s->small.trace = dev_buffer;
+  return GP_OK;
+}
+
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* s, int enable) {
   if (!s) return 0;
   s->one_launch = enable != 0 && s->small_ok;
@@ -1473,7 +1573,11 @@ int gp_sparse_system_build(gp_sparse_system_t* s, const gp_linearized6* records_
   const gp::SparseSymbolic& S = s->sym;
   // (no memsets: the destination list covers every block of L and every entry of y)
   hipLaunchKernelGGL(gp::sparse_assemble_kernel<false>, dim3((unsigned)s->dests.size()), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
-                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), gp::SparseStepExtras{});
+                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), [&] {
+                       gp::SparseStepExtras e0{};
+                       e0.diag0 = s->diag0.as<double>();
+                       return e0;
+                     }());
   hipLaunchKernelGGL(gp::sparse_sum_errors_kernel, dim3(1), dim3(256), 0, s->stream, reinterpret_cast<const double*>(records_dev), s->num_factors, s->c.as<double>());
   const double* prior = nullptr;
   std::vector<double> permuted;
@@ -1486,7 +1590,7 @@ int gp_sparse_system_build(gp_sparse_system_t* s, const gp_linearized6* records_
   }
   if (lambda > 0.0 || prior) {
     hipLaunchKernelGGL(gp::sparse_damp_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->L.as<double>(), s->view.colptr, s->n, lambda, diagonal_damping,
-                       min_diagonal, max_diagonal, prior);
+                       min_diagonal, max_diagonal, prior, s->diag0.as<double>());
   }
   GP_HIP(hipGetLastError());
   if (prior_diag_host) GP_HIP(hipStreamSynchronize(s->stream));  // `permuted` goes away
@@ -1592,6 +1696,7 @@ int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_d
   }
   ex.perm = s->d_perm, ex.b_slots_host = h + n, ex.c_dev = s->c.as<double>(), ex.c_host = h + 2 * n, ex.status = s->status.as<int>();
   ex.num_factors = s->num_factors, ex.num_dests = (int)s->dests.size();
+  ex.diag0 = s->diag0.as<double>();
   if (s->one_launch) {
     // small graph: the whole step in ONE launch, every operand in the LDS of one compute unit (sparse_small_step_kernel)
     gp::SparseSmallView V = s->small;

@@ -45,23 +45,28 @@ def timed(sp, rec_dev, out):
     return float(np.median(ts)) * 1e3, float(np.min(ts)) * 1e3, out[0].copy()
 
 
-for name, n in (("C3 (64 poses)", 64), ("C1 (2 poses)", 2), ("96 poses", 96), ("128 poses", 128), ("16 poses", 16)):
-    slots = graph(n)
-    rec = records(slots)
-    rec_dev = torch.from_numpy(rec).cuda()
-    for o in ORDERINGS:
-        sp = gpa.SparseLinearSystemGPU(n - 1, slots, ordering=o)
-        out = (np.zeros(sp.size), np.zeros(sp.size), np.zeros(1))
-        row = dict(graph=name, ordering=o)
-        x_one = None
-        if sp.set_one_launch(True):
-            med, mn, x_one = timed(sp, rec_dev, out)
-            row.update(one_launch_ms=round(med, 4), one_launch_ms_min=round(mn, 4))
-        sp.set_one_launch(False)
-        med, mn, x = timed(sp, rec_dev, out)
-        row.update(multi_launch_ms=round(med, 4), multi_launch_ms_min=round(mn, 4), bit_identical=bool(np.array_equal(x, x_one)) if x_one is not None else None)
-        A, b, c = sp.build(rec_dev, lam=1e-5).download()
-        xr = np.linalg.solve(A, b)
-        sym = gpa.solver.sparse_symbolic(n - 1, slots, gpa.SparseLinearSystemGPU.ORDERINGS[o])
-        row.update(levels=sym["num_levels"], critical_columns=sym["critical_columns"], lists=sym["num_lists"], l_blocks=sym["nnz_l_blocks"], rel_err_vs_numpy=float(np.abs(x - xr).max() / np.abs(xr).max()))
-        print(json.dumps(row), flush=True)
+def main():
+    for name, n in (("C3 (64 poses)", 64), ("C1 (2 poses)", 2), ("96 poses", 96), ("128 poses", 128), ("16 poses", 16)):
+        slots = graph(n)
+        rec = records(slots)
+        rec_dev = torch.from_numpy(rec).cuda()
+        for o in ORDERINGS:
+            sp = gpa.SparseLinearSystemGPU(n - 1, slots, ordering=o)
+            out = (np.zeros(sp.size), np.zeros(sp.size), np.zeros(1))
+            row = dict(graph=name, ordering=o)
+            x_one = None
+            if sp.set_one_launch(True):
+                med, mn, x_one = timed(sp, rec_dev, out)
+                row.update(one_launch_ms=round(med, 4), one_launch_ms_min=round(mn, 4))
+            sp.set_one_launch(False)
+            med, mn, x = timed(sp, rec_dev, out)
+            row.update(multi_launch_ms=round(med, 4), multi_launch_ms_min=round(mn, 4), bit_identical=bool(np.array_equal(x, x_one)) if x_one is not None else None)
+            A, b, c = sp.build(rec_dev, lam=1e-5).download()
+            xr = np.linalg.solve(A, b)
+            sym = gpa.solver.sparse_symbolic(n - 1, slots, gpa.SparseLinearSystemGPU.ORDERINGS[o])
+            row.update(levels=sym["num_levels"], critical_columns=sym["critical_columns"], lists=sym["num_lists"], l_blocks=sym["nnz_l_blocks"], rel_err_vs_numpy=float(np.abs(x - xr).max() / np.abs(xr).max()))
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -372,7 +372,7 @@ def test_one_launch_step_is_bit_identical(gpu, graph, ordering):
     one, multi = gpu.SparseLinearSystemGPU(P, slots, ordering=ordering), gpu.SparseLinearSystemGPU(P, slots, ordering=ordering)
     if not one.set_one_launch(True):
         sym = gpu.solver.sparse_symbolic(P, slots, gpu.SparseLinearSystemGPU.ORDERINGS[ordering])
-        assert sym["nnz_l_blocks"] > 380, sym  # (only a factor too large for the LDS may decline: the dissection of the 64-pose band graph, 522 blocks)
+        assert sym["nnz_l_blocks"] > 340, sym  # (only a factor too large for the LDS may decline: the dissection of the 64-pose band graph, 522 blocks; a 128-pose chain's 369)
         pytest.skip(f"{sym['nnz_l_blocks']} blocks of L do not fit one compute unit's LDS: multi-launch only")
     assert multi.set_one_launch(False) is False
     prior = rng.uniform(0.0, 2.0, 6 * P)
