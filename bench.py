@@ -684,6 +684,13 @@ def main():
                 json.dump(_clean(result), f, indent=1, allow_nan=False)
         except OSError as exc:  # (a read-only tree: the line still goes out)
             sys.stderr.write(f"bench.py: could not write {args.detail_file}: {exc}\n")
+        # the record is the LAST stdout line: whatever a C library still holds in its stdio buffer (RCCL prints a version banner through printf, which would otherwise be
+        # flushed at process exit, BEHIND this line) goes out first
+        try:
+            sys.stdout.flush()
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(compact_line(result), flush=True)
     return result
 

@@ -165,7 +165,8 @@ def test_bench_step_through_rccl_with_one_rank(gpu):
            "--cpu-seconds", "1", "--c4-steps", "2", "--no-configs", "--kernel-iters", "5", "--budget-seconds", "600", "--detail-file", detail]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = p.stdout.rstrip("\n").splitlines()[-1]  # the LAST stdout line is the record
+    line = p.stdout.rstrip("\n").splitlines()[-1]  # the LAST stdout line is the record (RCCL's printf banner, flushed at exit, must not come behind it)
+    assert line.startswith("{"), p.stdout[-600:]
     assert len(line.encode()) < 4096
     r = json.loads(line)
     # the contract's collective by default (VERDICT r05 #2a): RCCL all-reduce; the other forms timed in the same job; every form's stack verified bit for bit
