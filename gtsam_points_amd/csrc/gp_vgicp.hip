@@ -728,7 +728,8 @@ int build_table(gp_vgicp_batch* b) {
     descs[0].tile_count = G;
   } else {
     int ppt = kPipelineChunks;  // the hashed-line-table, reference-shaped and f64 kernels exist for 1024-point tiles only
-    if (fam == GP_KERNEL_LOOKAHEAD || fam == GP_KERNEL_STREAM) {
+    if (fam == GP_KERNEL_STREAM) {  // (round 6: the LOOKAHEAD family keeps its 1024-point tiles -- it exists for maps of >= 2^26 voxels, where no batch is small;
+                                    //  its 512- / 256-point instantiations went with that: VERDICT r05 #8)
       // per batch: the largest tile that still fills 3/4 of the chip's resident workgroups, so that a 15 k-point scan is not left to 15 workgroups
       ppt = 1;
       for (int cand : {4, 2}) {
@@ -913,17 +914,9 @@ int launch_tiles(gp_vgicp_batch* b, const PoseSource& ps, double* partials) {
       GP_LAUNCH_PIPE(true, 4, false, false, false);
     } else if (fam == GP_KERNEL_GRID_F64) {
       GP_LAUNCH_PIPE(false, 4, true, false, false);
-    } else if (MODE == gp::MODE_LIN && b->ppt >= 2) {  // GP_KERNEL_LOOKAHEAD, linearise
-      if constexpr (MODE == gp::MODE_LIN) {
-        if (b->ppt == 4) GP_LAUNCH_PIPE(true, 4, true, true, true);
-        else GP_LAUNCH_PIPE(true, 2, true, true, true);
-      }
-    } else if (b->ppt == 1) {
-      GP_LAUNCH_PIPE(true, 1, true, true, false);
-    } else if (b->ppt == 2) {
-      GP_LAUNCH_PIPE(true, 2, true, true, false);
-    } else {
-      GP_LAUNCH_PIPE(true, 4, true, true, false);
+    } else {  // GP_KERNEL_LOOKAHEAD: 1024-point tiles; the linearise with the look-ahead lookup, the error evaluation without
+      if constexpr (MODE == gp::MODE_LIN) GP_LAUNCH_PIPE(true, 4, true, true, true);
+      else GP_LAUNCH_PIPE(true, 4, true, true, false);
     }
 #undef GP_LAUNCH_PIPE
   }
