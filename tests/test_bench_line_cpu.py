@@ -99,7 +99,8 @@ def test_a_line_that_would_not_fit_is_refused():
 
 def test_recorded_lines_of_this_round_meet_the_contract():
     """every bench line committed under profiles/ this round (the builder's runs of the driver's command) is one the driver can parse"""
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_*.json")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_run*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r06_bench_rehearsal*.json")))
+    assert paths, "the round's bench lines are committed under profiles/"
     for path in paths:
         lines = [l for l in open(path) if l.startswith("{")]
         if not lines:
@@ -113,3 +114,7 @@ def test_recorded_lines_of_this_round_meet_the_contract():
             assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["bound"] == "hbm" and r["kernel"] == "vgicp_stream_kernel"
             assert b["cpu_baseline"]["kind"] in ("reference", "port") and b["cpu_baseline"]["cores"] >= 1
             assert b["parity_max"] < 1e-5 and b["parity_inliers_equal"] is True and b["parity_ok"] is True
+            assert r["frac_rocprof"] is not None and r["traffic"] is not None  # (measured in the run: rocprofv3 child passes)
+        else:  # the N > 1 line: the contract's collective, every form timed and verified, rank 0's row held to the oracle
+            assert b["config"]["exchange"] == "all_reduce" and b["exchange_verified"] is True and set(b["exchange_ms"]) == {"all_reduce", "all_gather", "peer"}
+            assert b["rccl_world"] == b["n_gpus"] and b["parity_ok"] is True and b["cpu_baseline"] is None
