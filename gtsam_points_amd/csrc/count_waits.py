@@ -15,7 +15,7 @@ itself.  Two things can silently break that, and both are checked here per insta
                          fault on the GPU box).  Counted, walking the text in layout order: instructions outside asm blocks that read or
                          write a register of a load still in flight (in-order retirement: an asm `s_waitcnt vmcnt(N)` retires all but the
                          N youngest requests; LDS-DMA requests have no destination registers but take part in the count).
-tests/test_build_cpu.py wants 0 for both."""
+tests/test_build_cpu.py wants 0 for both -- and so does the BUILD: this script exits non-zero (the Makefile stops) when either count is not 0 for some instantiation."""
 import re
 import sys
 
@@ -78,5 +78,16 @@ for line in open(sys.argv[1]):
         touches[name] += 1
         if len(examples[name]) < 3:
             examples[name].append(code)
+bad = []
 for k in sorted(waits):
     print(f"{k} compiler_vmcnt_waits {waits[k]} inflight_reg_touches {touches[k]} idle_vmcnt_waits {idle[k]}" + ("   e.g. " + " | ".join(examples[k]) if examples[k] else ""))
+    if waits[k] or touches[k]:
+        bad.append(k)
+# the guarantee is "this compiler": a build whose compiler places a wait or a copy where the hand count forbids it must FAIL, not wait for a test
+if not waits:
+    sys.stderr.write("count_waits.py: no vgicp_stream_kernel instantiation found in the device assembly\n")
+    sys.exit(2)
+if bad:
+    sys.stderr.write("count_waits.py: the hand-counted vmcnt schedule of gp_vgicp_stream.hpp does not hold with this compiler for:\n  " + "\n  ".join(bad)
+                     + "\n(compiler_vmcnt_waits / inflight_reg_touches must be 0; validated with the compiler named in gp_vgicp_stream.hpp)\n")
+    sys.exit(1)

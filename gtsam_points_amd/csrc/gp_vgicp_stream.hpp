@@ -383,6 +383,8 @@ __global__ void __launch_bounds__(64 * W, 4) vgicp_stream_kernel(const FactorDes
   v4f head;
   v2d c01, c23, c45;
   double a[6];
+  // (The counts below were validated with HIP 7.2.26015 / AMD clang 22.0.0git roc-7.2.0.  They are a property of the COMPILED code: csrc/count_waits.py walks the device
+  //  assembly of every instantiation at build time and the Makefile stops when a compiler-placed wait or register touch appears inside the schedule.)
   // HAZARD the schedule below is built around: the destination registers of an asm-issued load hold nothing until the matching s_waitcnt, but
   // the compiler believes they are defined at the issue.  Any copy it places between the two -- a phi at a loop back-edge, or the operand copy in
   // front of one of TWO alternative wait statements -- reads the registers before the data lands (round 3: exactly that, wild record offsets,

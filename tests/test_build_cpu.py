@@ -55,3 +55,28 @@ def test_stream_kernel_has_no_compiler_vmcnt_waits():
         # no instruction outside the asm blocks may read or write the destination registers of an asm-issued load that is still in flight
         # (csrc/count_waits.py): the round-3 memory fault was a phi copy of such registers at a loop back-edge
         assert row[3] == "inflight_reg_touches" and int(touches) == 0, row
+
+
+def test_count_waits_fails_the_build_on_a_violation(tmp_path):
+    """the vmcnt schedule's guard is part of the BUILD (count_waits.py exits non-zero, the Makefile stops), not only of this test file: an instruction
+    the compiler places on a register of a load still in flight, a compiler-tracked vmcnt wait inside the schedule, or an assembly without the kernel each fail it"""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(RES), "count_waits.py")
+
+    def run(text):
+        f = tmp_path / "k.s"
+        f.write_text(text)
+        return subprocess.run([sys.executable, script, str(f)], capture_output=True, text=True)
+
+    head = "_ZN2gp19vgicp_stream_kernelILi0EEEvv:\n#ASMSTART\nglobal_load_dwordx4 v[1:4], v5, s[0:1]\n#ASMEND\n"
+    ok = run(head + "v_add_f32 v9, v9, v8\n#ASMSTART\ns_waitcnt vmcnt(0)\n#ASMEND\nv_add_f32 v1, v1, v2\n.Lfunc_end0:\n")
+    assert ok.returncode == 0 and "inflight_reg_touches 0" in ok.stdout, ok.stderr
+    touch = run(head + "v_add_f32 v1, v1, v2\n.Lfunc_end0:\n")
+    assert touch.returncode == 1 and "inflight_reg_touches 1" in touch.stdout and "does not hold" in touch.stderr
+    wait = run(head + "s_waitcnt vmcnt(0)\n.Lfunc_end0:\n")
+    assert wait.returncode == 1 and "compiler_vmcnt_waits 1" in wait.stdout
+    assert run("some_other_kernel:\ns_endpgm\n").returncode == 2
+    mk = open(os.path.join(os.path.dirname(RES), "Makefile")).read()
+    assert "count_waits.py $(HERE)gp_vgicp.device.s > $@ ||" in mk  # the recipe stops on a non-zero exit
