@@ -340,6 +340,23 @@ def _median_ms(call, iters):
     return float(np.median(ts)) * 1e3
 
 
+def _map_build_traffic(points, ms):
+    """roofline.traffic of the map build: HBM bytes per build from the committed counter passes (profiles/r06_map_build_pmc.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE
+    summed over the build's kernels, scripts/r06/map_build_pmc.sh) -- the same cloud and code as here; None when the profile is absent or of another size"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_map_build_pmc.json")) as f:
+            p = json.load(f)
+        if p["run"]["points"] != points:
+            return dict(traffic=None)
+        t = int(p["traffic_bytes_per_build"])
+        return dict(traffic=t, traffic_read=int(p["read_bytes"]), traffic_written=int(p["written_bytes"]), frac_traffic=round(t / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    traffic_source="profiles/r06_map_build_pmc.json: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 correction) + WRITE_SIZE over every kernel of a build, separate passes; "
+                                   "NOT measured in this run (same cloud, same code); 3.7 x the algorithmic bytes: the points are read three times (bounding box, keys, statistics) "
+                                   "and the 22-bit sort moves key + index three times")
+    except Exception:
+        return dict(traffic=None)
+
+
 def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream, want=None, target_cloud=None):
     """BASELINE configs[0], [2], [4] (C1, C3, C5 of SURVEY.md 8(d)) under the driver's clock, leg by leg: want(name, estimated_seconds) -> bool decides whether a leg still
     fits the caller's time budget (None = run everything); every object carries the `seconds` its leg took.  GPU side = the product's synchronous entry
@@ -619,7 +636,7 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream, want=No
                      "occupancy-block grid, per-voxel statistics in f64, reference-visible bucket table)",
             points=nt, num_voxels=int(vmb.voxelmap_info.num_voxels), ms=round(mb_ms, 4), ms_min=round(float(np.min(ts[5:])) * 1e3, 4), points_per_s=round(nt / mb_ms * 1e3, 1),
             roofline=dict(bound="hbm", achieved=round(48.0 * nt / (mb_ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(48.0 * nt / (mb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                          algorithmic_bytes=48 * nt, traffic=None,
+                          algorithmic_bytes=48 * nt, **_map_build_traffic(nt, mb_ms),
                           note="48 B per point read once (SURVEY.md 8(d), voxel-map build); host wall of the whole call (10 launches, three points where the host waits), not one kernel: the build is "
                                "a chain of latency-bound kernels at this size (DESIGN.md section 4.4)"))
         return round(time.time() - t_leg, 1)
