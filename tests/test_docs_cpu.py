@@ -1,4 +1,4 @@
-"""The numbers quoted in DESIGN.md / README.md / BASELINE.md are generated from the committed profiles/ files (scripts/r05_numbers.py --write pastes round 5's between
+"""The numbers quoted in DESIGN.md / README.md / BASELINE.md / docs/HISTORY.md are generated from the committed profiles/ files (scripts/r06_numbers.py --write pastes round 6's, scripts/r05_numbers.py --write round 5's between
 <!-- r05:NAME:begin/end --> markers; round 4's blocks that DESIGN.md keeps for comparison come from scripts/r04_numbers.py): this test regenerates the blocks and holds the
 documents to them, so that a number cannot be typed by hand or go stale behind a new evidence run."""
 import importlib.util
@@ -19,7 +19,7 @@ def _generator(name):
 def _check(tag, gen):
     blocks = {name: fn() for name, fn in gen.SECTIONS.items()}
     seen = set()
-    for doc in ("DESIGN.md", "README.md", "BASELINE.md"):
+    for doc in ("DESIGN.md", "README.md", "BASELINE.md", "docs/HISTORY.md"):
         text = open(os.path.join(ROOT, doc), encoding="utf-8").read()
         for name, want in blocks.items():
             for m in re.finditer(r"<!-- %s:%s:begin -->\n(.*?)\n<!-- %s:%s:end -->" % (tag, name, tag, name), text, re.S):
@@ -30,11 +30,13 @@ def _check(tag, gen):
 
 def test_documents_quote_the_committed_profiles():
     seen = _check("r05", _generator("r05_numbers"))
-    for need in [("DESIGN.md", "headline"), ("DESIGN.md", "results"), ("DESIGN.md", "lm"), ("DESIGN.md", "c5"), ("README.md", "results"), ("BASELINE.md", "results"), ("BASELINE.md", "headline"),
-                 ("BASELINE.md", "lm")]:
+    for need in [("docs/HISTORY.md", "headline"), ("docs/HISTORY.md", "results"), ("docs/HISTORY.md", "lm"), ("docs/HISTORY.md", "c5"), ("BASELINE.md", "results"), ("BASELINE.md", "headline"), ("BASELINE.md", "lm")]:
         assert need in seen, need
-    seen4 = _check("r04", _generator("r04_numbers"))  # (the round-4 tables DESIGN.md keeps beside round 5's)
-    assert ("DESIGN.md", "headline") in seen4 and ("DESIGN.md", "results") in seen4
+    seen4 = _check("r04", _generator("r04_numbers"))  # (the round-4 tables: docs/HISTORY.md since round 6)
+    assert ("docs/HISTORY.md", "headline") in seen4 and ("docs/HISTORY.md", "results") in seen4
+    seen6 = _check("r06", _generator("r06_numbers"))  # this round
+    for need in [("DESIGN.md", "headline"), ("DESIGN.md", "results"), ("DESIGN.md", "lm"), ("DESIGN.md", "solver"), ("README.md", "results"), ("BASELINE.md", "results"), ("BASELINE.md", "headline")]:
+        assert need in seen6, need
 
 
 def test_the_bench_line_in_profiles_meets_the_contract():
