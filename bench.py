@@ -486,22 +486,50 @@ def main():
 
     # ---- N > 1: the other exchange forms in the same job, and the bit-for-bit check of every form's exchanged stack ----
     exchange_ms, exchange_verified, verify_detail, exchange_notes = None, None, None, None
+    if dist_on and rank == 0:
+        # from here on the phases are optional and, across devices, run for the first time on the driver's node: if one of them hangs and the job is torn down, the headline
+        # measured above still leaves as the job's last stdout line (bench_detail.register_last_resort; not printed by a job that ends normally)
+        bench_detail.register_last_resort(compact_line(dict(
+            metric=METRIC, value=round(value, 1), unit="point-correspondences/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 5),
+            ms_per_step_cold=cold["ms_per_step"] if cold else None, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+            config=dict(workload="BASELINE configs[1]: single VGICP factor per GPU, 1M synthetic source pts vs 2M-pt GaussianVoxelMap @0.5 m", source_points=args.source_points, target_points=args.target_points,
+                        resolution=args.resolution, num_voxels=info.num_voxels, num_buckets=info.num_buckets, exchange=sharded.exchange, device_warmup_ms=args.device_warmup_ms, device_warmup_steps=wake_steps),
+            roofline=dict(bound="hbm", kernel="vgicp_stream_kernel", peak=HBM_PEAK_GBS, unit="GB/s"), cpu_baseline=None, parity_vs_oracle=None, backend=dist.get_backend(), rccl_world=dist.get_world_size(),
+            exchange_ms={args.exchange: round(ms_per_step, 5)}, legs_skipped=["everything behind the headline"], run_seconds=round(time.time() - t_run, 1))))
     if dist_on:
         from gtsam_points_amd.distributed import verify_exchanged_stack
 
         exchange_ms, exchange_notes = {args.exchange: round(ms_per_step, 5)}, {}
         forms = [args.exchange] if args.no_exchange_forms else [args.exchange] + [f for f in ("all_reduce", "all_gather", "peer") if f != args.exchange]
+        def all_agree(ok):  # (one tiny collective: every rank takes the same branch behind a failure)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
         for form in forms[1:]:
+            # A form that fails -- buffers that cannot be shared, a peer that does not arrive within the exchange kernel's time box (which poisons every rank's next wait: all
+            # ranks fail in the same place, behind the steps' barrier) -- must not take the headline's line with it: the ranks agree, the form reads null, the reason goes to the
+            # detail file.  (A rank that HANGS is the phase guard's business.)
+            s_f, why = None, None
             try:
-                s = sharded_by_form[form] = make_sharded(form)
-                if s.exchange != form:  # (a form every rank fell back from together: the reason is in the detail file, the line carries null)
-                    exchange_notes[form] = f"ran as {s.exchange}: {s.peer_note or 'the plan or the backend does not take this form'}"
-                    exchange_ms[form] = None
-                    continue
-                el_f, _, _, _ = timed_steps(f"timed steps ({form})", make_step(s), s)
+                s_f = make_sharded(form)
+                if s_f.exchange != form:  # (a form every rank fell back from together)
+                    why = f"ran as {s_f.exchange}: {s_f.peer_note or 'the plan or the backend does not take this form'}"
+                else:
+                    el_f, _, _, _ = timed_steps(f"timed steps ({form})", make_step(s_f), s_f)
+            except Exception as exc:
+                why = f"{type(exc).__name__}: {exc}"
+            if all_agree(why is None):
+                sharded_by_form[form] = s_f
                 exchange_ms[form] = round(el_f / args.steps * 1e3, 5)
-            except Exception as exc:  # (collective decisions inside make_sharded keep the ranks together; an exception here is a local failure and ends the job loudly)
-                raise RuntimeError(f"exchange form {form}: {exc}") from exc
+            else:
+                exchange_ms[form] = None
+                exchange_notes[form] = why or "failed on another rank"
+                if s_f is not None:
+                    try:
+                        s_f.close()
+                    except Exception:
+                        pass
         # what this rank computed, by itself: the batch's kernels into a private buffer, no exchange (the kernels are bit-reproducible: tests/test_vgicp_gpu.py)
         own = torch.zeros((1, REC), dtype=torch.float64, device=device)
         issue(pose, own)
@@ -513,10 +541,14 @@ def main():
                 if exchange_ms.get(form) is None:
                     continue
                 host_out.zero_()
-                make_step(s)()
-                s.check()
+                err = None
+                try:
+                    make_step(s)()
+                    s.check()
+                except Exception as exc:  # (the stack stays zero: the verification below fails for this form on every rank, which is the right verdict)
+                    err = f"{type(exc).__name__}: {exc}"
                 ok, bad = verify_exchanged_stack(out_np, own_host, rank, rank + 1)
-                verify_detail[form] = dict(verified=ok, bad_rows_by_rank=bad)
+                verify_detail[form] = dict(verified=ok, bad_rows_by_rank=bad, error=err)
                 exchange_verified = exchange_verified and ok
         step()  # (host_out holds the headline form's stack again)
 
@@ -691,9 +723,17 @@ def main():
             C.CDLL(None).fflush(None)
         except Exception:
             pass
+        bench_detail.register_last_resort(None)  # (the job ended normally: the real line follows)
         print(compact_line(result), flush=True)
     return result
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as exc:  # (an exception behind the measured headline of an N > 1 job: the registered line still leaves -- bench_detail.register_last_resort)
+        if not isinstance(exc, SystemExit) or exc.code not in (0, None):
+            import bench_detail as _bd
+
+            _bd.emit_last_resort(f"{type(exc).__name__}: {exc}")
+        raise

@@ -24,6 +24,44 @@ BENCH_PY = os.path.join(ROOT, "bench.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
 
+# The record a job leaves when it dies in an OPTIONAL phase (round 6): once the headline is measured, rank 0 registers the compact line of what it has; a phase that exceeds
+# its time box, or a SIGTERM from the launcher tearing the job down because another rank gave up, prints that line as the job's last stdout line before the process ends --
+# an untested exchange form that hangs on real hardware must not cost the run its headline.  In a job that ends normally nothing of this is printed.
+_LAST_RESORT = {"line": None}
+
+
+def register_last_resort(line):
+    """line: the compact JSON text to print if the job is torn down from here on (None: nothing); installs the SIGTERM hook once"""
+    import signal
+
+    first = _LAST_RESORT["line"] is None and "hooked" not in _LAST_RESORT
+    _LAST_RESORT["line"] = line
+    if first and line is not None:
+        _LAST_RESORT["hooked"] = True
+
+        def on_term(_sig, _frm):
+            emit_last_resort("SIGTERM")
+            os._exit(143)
+
+        try:
+            signal.signal(signal.SIGTERM, on_term)
+        except Exception:  # (not the main thread: the phase guard still prints)
+            pass
+
+
+def emit_last_resort(why):
+    line = _LAST_RESORT.get("line")
+    if line:
+        _LAST_RESORT["line"] = None
+        try:
+            obj = json.loads(line)
+            obj["aborted"] = str(why)[:96]
+            sys.stdout.write(json.dumps(obj, allow_nan=False, separators=(",", ":")) + "\n")
+            sys.stdout.flush()
+        except Exception:
+            pass
+
+
 class PhaseGuard:
     """Time-box of a phase (VERDICT r04 #5d): a rank that hangs in a collective or a rendezvous must fail in about two minutes, not sit on the lease.  A timer thread
     that finds the phase still open says which one on stderr and ends the PROCESS (os._exit: a hung RCCL call cannot be interrupted from Python); torchrun then tears
@@ -38,6 +76,7 @@ class PhaseGuard:
         def expire():
             sys.stderr.write(json.dumps(dict(error=f"bench.py: phase '{self.name}' exceeded its {self.seconds:.0f} s time box on rank {os.environ.get('RANK', '0')}; aborting")) + "\n")
             sys.stderr.flush()
+            emit_last_resort(f"phase '{self.name}' exceeded its time box")
             os._exit(124)
 
         self._timer = threading.Timer(self.seconds, expire)

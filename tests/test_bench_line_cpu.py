@@ -118,3 +118,40 @@ def test_recorded_lines_of_this_round_meet_the_contract():
         else:  # the N > 1 line: the contract's collective, every form timed and verified, rank 0's row held to the oracle
             assert b["config"]["exchange"] == "all_reduce" and b["exchange_verified"] is True and set(b["exchange_ms"]) == {"all_reduce", "all_gather", "peer"}
             assert b["rccl_world"] == b["n_gpus"] and b["parity_ok"] is True and b["cpu_baseline"] is None
+
+
+def test_last_resort_line_is_printed_when_a_phase_expires_and_only_then(tmp_path):
+    """an optional N > 1 phase that hangs on hardware nobody could test on must not cost the job its headline: rank 0 registers the compact line once the headline is
+    measured; a phase guard that expires (or a SIGTERM from the launcher) prints it -- marked `aborted` -- as the last stdout line; a normal end prints nothing extra"""
+    import subprocess
+    import textwrap
+
+    full = dict(metric=bench.METRIC, value=1.0, unit="point-correspondences/s", n_gpus=2, steps=20, warmup=5, ms_per_step=0.05, ms_per_step_cold=None, higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="f64", data="synthetic", config=dict(workload="w", exchange="all_reduce"), roofline=dict(bound="hbm"), cpu_baseline=None, parity_vs_oracle=None)
+    line = bench.compact_line(full)
+    prog = textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench_detail
+        bench_detail.register_last_resort({line!r})
+        mode = sys.argv[1]
+        if mode == "expire":
+            with bench_detail.PhaseGuard(0.3, "peer exchange"):
+                time.sleep(5)
+        elif mode == "term":
+            import os, signal
+            os.kill(os.getpid(), signal.SIGTERM)
+            time.sleep(5)
+        else:
+            bench_detail.register_last_resort(None)
+            print("the real line")
+    """)
+    f = tmp_path / "p.py"
+    f.write_text(prog)
+    for mode, rc in (("expire", 124), ("term", 143)):
+        p = subprocess.run([sys.executable, str(f), mode], capture_output=True, text=True, timeout=60)
+        assert p.returncode == rc, (mode, p.returncode, p.stderr[-300:])
+        b = _strict(p.stdout.rstrip("\n").splitlines()[-1])
+        assert b["value"] == 1.0 and b["n_gpus"] == 2 and "aborted" in b and len(p.stdout.strip().splitlines()) == 1
+    p = subprocess.run([sys.executable, str(f), "normal"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "the real line"
