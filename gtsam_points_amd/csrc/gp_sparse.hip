@@ -401,14 +401,11 @@ constexpr int kSmallTeamDoubles = 158;  // per team: D[6][7] | rhs[6] | v[6] (ba
 // LDS bytes that step needs for a symbolic factorisation: L's blocks, y, x, the teams' scratch, the error partials, the index lists (0: the factor does not qualify)
 static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_out = nullptr) {
   const size_t P = (size_t)S.P, nnzL = (size_t)S.colptr[S.P];
-  // (the assembly's lists: one destination per block of L, 4 ints; at most one contribution per block of A and factor side -- nnzA bounds the blocks, every factor
-  //  adds up to three contributions: counted exactly by the caller that has the factor list, bounded here by 3 x the products of A's structure is not possible, so the
-  //  symbolic phase records the contribution count it will need: S.num_contribs)
   const size_t words = S.colptr.size() + S.rowidx.size() + S.upd_ptr.size() + S.upd_a.size() + S.upd_b.size() + S.row_ptr.size() + S.row_blk.size() + S.row_col.size() +
-                       S.work_ptr.size() + S.work_cols.size() + 4 * nnzL + 2 * (size_t)S.num_contribs + 4;
+                       S.work_ptr.size() + S.work_cols.size() + 2;
   if (arena_words_out) *arena_words_out = words;
   if (P > 128) return 0;  // (row lists stay below the staged kernel's 128-block stage, which the one-launch form assumes)
-  const size_t bytes = sizeof(double) * (36 * nnzL + 24 * P + (size_t)kSmallTeams * kSmallTeamDoubles + 256) + sizeof(int) * words + 64;
+  const size_t bytes = sizeof(double) * (36 * nnzL + 24 * P + (size_t)kSmallTeams * kSmallTeamDoubles) + sizeof(int) * words + 64;
   return bytes <= 160 * 1024 - 256 ? bytes : 0;
 }
 static bool small_step_fits(const SparseSymbolic& S) { return small_step_lds_bytes(S) != 0; }
@@ -650,12 +647,14 @@ __device__ __forceinline__ void forward6(double (*D)[7], const double* dinv, dou
   for (int i = 0; i < 6; i++) rhs[i] = y[i];
 }
 // ONE lane: row r of a block below the diagonal, B <- B L^-T (forward substitution along the row); Bk = the block, column-major
+// (RM: the block is stored row-major -- the one-launch step's LDS copy -- instead of column-major: same operands, same operations)
+template <bool RM = false>
 __device__ __forceinline__ void trsm_row6(double* Bk, const int r, double (*D)[7], const double* dinv) {
   double d[6][6], iv[6], o[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     iv[c] = dinv[c];
-    o[c] = Bk[r + 6 * c];
+    o[c] = RM ? Bk[6 * r + c] : Bk[r + 6 * c];
 #pragma unroll
     for (int q = 0; q < 6; q++)
       if (q < c) d[c][q] = D[c][q];
@@ -669,9 +668,10 @@ __device__ __forceinline__ void trsm_row6(double* Bk, const int r, double (*D)[7
     o[c] = sum * iv[c];
   }
 #pragma unroll
-  for (int c = 0; c < 6; c++) Bk[r + 6 * c] = o[c];
+  for (int c = 0; c < 6; c++) (RM ? Bk[6 * r + c] : Bk[r + 6 * c]) = o[c];
 }
 // ONE lane: x_k = L_kk^-T v by backward substitution; Dk = the factored diagonal block, column-major; dinv_k = the reciprocals of its diagonal
+template <bool RM = false>
 __device__ __forceinline__ void back6(const double* Dk, const double* dinv_k, const double* v, double* xk_out) {
   double d[6][6], iv[6], xk[6];
 #pragma unroll
@@ -680,7 +680,7 @@ __device__ __forceinline__ void back6(const double* Dk, const double* dinv_k, co
     xk[i] = v[i];
 #pragma unroll
     for (int q = 0; q < 6; q++)
-      if (q > i) d[q][i] = Dk[q + 6 * i];  // (L^T)_{iq} = L_{qi}
+      if (q > i) d[q][i] = RM ? Dk[6 * q + i] : Dk[q + 6 * i];  // (L^T)_{iq} = L_{qi}
   }
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
@@ -1023,19 +1023,22 @@ __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __
 }
 
 
-// ---- ONE launch per damped step for SMALL graphs (round 6) ---------------------------------------------------------------------------------------------
+// ---- the damped step of a SMALL graph: the assembly + ONE launch for everything behind it (round 6) -----------------------------------------------------
 // The multi-launch step above costs 0.21 ms on BASELINE configs[2]'s graph (63 free poses, 256 factors) and its launches are NOT the cost: the kernels' own time is
 // (profiles/r06_solver_kernel_stats.csv).  A column of the factorisation is a chain -- product indices -> operand blocks -> 6 x 6 Cholesky -> triangular solves -- and
-// every link is a round trip to L2 behind a workgroup barrier: 6-8 us per column, 21-34 columns on the critical path.  For a graph whose whole factor fits the LDS of one
-// compute unit (<= ~440 blocks of 288 B; the index lists beside it) ONE 1024-thread workgroup does the whole step with every operand in LDS:
-//   phase 0  the index lists into LDS; the assembly (sparse_assemble_kernel<true>'s sums, in its order, damping included) straight into the LDS copy of L; b, c to the host
+// every link is a round trip to L2 behind a workgroup barrier.  For a graph whose whole factor fits the LDS of one compute unit (<= ~400 blocks of 288 B; the index
+// lists beside it) ONE 1024-thread workgroup factors and solves with every operand in LDS:
+//   phase 0  the index lists and the ASSEMBLED system (L's blocks, b, the diagonal) from global memory into LDS: coalesced, ~3 us.  The assembly itself stays
+//            sparse_assemble_kernel<true>, one 64-lane workgroup per block of L across the whole chip, in the launch in front: it is a gather of 8-byte values out of the
+//            factors' records, and ONE compute unit's vector-memory path needs 40 us for it (measured: the first form of this kernel assembled in place, with its lists in
+//            LDS and sixteen loads in flight per thread: 30 - 45 us against the assembly kernel's 6.5)
 //   phase 1  the schedule's levels one after the other; the work lists of a level side by side, each with a TEAM of 1024 / lists threads (whole waves), in lock step:
 //            round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward substitution by the team's first wave, barrier, the blocks below, barrier
 //   phase 2  the backward substitution, levels and columns in reverse, two barriers per round
 //   phase 3  x in slot order to the device array and the host, the status word
 // Every scalar is computed by the SAME sequence of operations as in sparse_factor_kernel<256> (lists of level 0) / sparse_factor_staged_kernel<1024> (levels above: the
 // slice partials with G and `per` derived from the column's size exactly as there) / sparse_backsolve_kernel, so the step is bit-identical to the multi-launch form
-// (tests/test_solver_gpu.py::test_one_launch_step_is_bit_identical); only where the operands live and which thread computes what differ.
+// (tests/test_solver_gpu.py::test_one_launch_step_is_bit_identical); only where the operands live (row-major blocks in LDS) and which thread computes what differ.
 // acc - sum over the products u in [u, ue) of (row r of block upd_a[u]) . (row c of block upd_b[u]), subtracted in list order; operands in LDS.  Four products' indices,
 // then their 48 operands, are requested together (one entry's products are a chain of dependent LDS round trips otherwise: 800 clocks per product measured)
 __device__ __forceinline__ double small_sub_products(double acc, const int* upd_a, const int* upd_b, int u, const int ue, const double* Ls, const int r, const int c) {
@@ -1051,12 +1054,14 @@ __device__ __forceinline__ double small_sub_products(double acc, const int* upd_
     double av[kBatch][6], bv[kBatch][6];
 #pragma unroll
     for (int w = 0; w < kBatch; w++) {
-      const double* A = Ls + 36 * (size_t)ia[w];
-      const double* B = Ls + 36 * (size_t)ib[w];
+      // (the LDS copy holds its blocks ROW-major: a row is 48 contiguous, 16-byte-aligned bytes = three 128-bit reads instead of six 64-bit ones)
+      const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)ia[w] + 6 * r);
+      const double2* B = reinterpret_cast<const double2*>(Ls + 36 * (size_t)ib[w] + 6 * c);
 #pragma unroll
-      for (int q = 0; q < 6; q++) {
-        av[w][q] = A[r + 6 * q];
-        bv[w][q] = B[c + 6 * q];
+      for (int q = 0; q < 3; q++) {
+        const double2 x = A[q], y = B[q];
+        av[w][2 * q] = x.x, av[w][2 * q + 1] = x.y;
+        bv[w][2 * q] = y.x, bv[w][2 * q + 1] = y.y;
       }
     }
 #pragma unroll
@@ -1070,22 +1075,21 @@ __device__ __forceinline__ double small_sub_products(double acc, const int* upd_
 }
 
 struct SparseSmallView {
-  const SparseDest* dests;
-  const SparseContribution* contribs;
+  const double* L_global;      // [nnzL][36] column-major: the assembled (damped) blocks
+  const double* y_global;      // [6 P] b, elimination order
+  const double* diag0_global;  // [6 P] the assembled diagonal
   const int* arena;       // global copy of the index lists below, `arena_words` ints, copied to LDS first
   const int* level_ptr;   // [num_levels + 1] -> work lists (global; read once per level)
-  int arena_words, num_levels, P, nnzL, num_dests;
+  int arena_words, num_levels, P, nnzL;
   int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols;  // offsets (ints) inside the arena
-  int o_dests, o_contribs;  // the assembly's destination and contribution lists ride in the arena as well (4 / 2 ints each): one bulk copy instead of two dependent round
-                            // trips to L2 in front of every value (the assembly measured 40 us of a 190 us step that way)
   const int* perm;        // elimination order -> slot (global)
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
   double* status_host;    // pinned
-  unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] assembled, [2] factored, [3] substituted, [4] end,
+  unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] assembled, [2] factored, [3] substituted, [4] end, [5] index lists in LDS, [6] thread 0's destinations assembled,
                               // [8 + 4 r + {0, 1, 2, 3}]: round r < 14 of the first level: start, gathered, diagonal done, blocks below done; null = off
 };
-__global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const SparseSmallView V, const double* __restrict__ records, const SparseStepExtras ex) {
+__global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const SparseSmallView V, int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* Ls = small_lds;                                   // [nnzL][36]
   double* ys = Ls + 36 * (size_t)V.nnzL;                    // [6 P]
@@ -1093,8 +1097,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   double* dis = xs + 6 * (size_t)V.P;                       // [6 P] reciprocals of L's diagonal
   double* d0s = dis + 6 * (size_t)V.P;                      // [6 P] the assembled diagonal of A (the pivots' scale)
   double* scr = d0s + 6 * (size_t)V.P;                      // [kSmallTeams][kSmallTeamDoubles]
-  double* cpart = scr + kSmallTeams * kSmallTeamDoubles;    // [256]: the error sum's partials
-  int* idx = reinterpret_cast<int*>(cpart + 256);           // the index lists
+  int* idx = reinterpret_cast<int*>(scr + kSmallTeams * kSmallTeamDoubles);  // the index lists
   __shared__ int bad;
   const int t = threadIdx.x;
   const int* colptr = idx + V.o_colptr;
@@ -1115,73 +1118,22 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   GP_SMALL_STAMP(0);
   if (t == 0) bad = 0;
   for (int i = t; i < V.arena_words; i += kSmallThreads) idx[i] = V.arena[i];
-  // the assembly: one thread per (destination, lane 0 .. 41) of sparse_assemble_kernel's 64-lane workgroups (lanes 42 .. 63 do nothing there)
-  __syncthreads();
-  const SparseDest* dests_l = reinterpret_cast<const SparseDest*>(idx + V.o_dests);
-  const SparseContribution* contribs_l = reinterpret_cast<const SparseContribution*>(idx + V.o_contribs);
-  for (int item = t; item < 42 * V.num_dests; item += kSmallThreads) {
-    const SparseDest d = dests_l[item / 42];
-    const int l = item % 42;
-    if (l < 36) {
-      const int r = l % 6, c = l / 6;
-      double s = 0.0;
-      // (eight contributions' descriptors, then their eight values, requested together and added in list order: one thread walks a dozen destinations, and taken
-      //  one at a time every value is two dependent round trips to L2 -- the assembly measured 40 us of the step that way)
-      for (int k0 = 0; k0 < d.count; k0 += 8) {
-        SparseContribution q[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) q[w] = contribs_l[d.begin + (k0 + w < d.count ? k0 + w : d.count - 1)];
-        double v[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) {
-          const double* rec = records + 122 * (size_t)q[w].factor;
-          const int off = q[w].take == STAKE_HT ? SREC_HT + c * 6 + r : q[w].take == STAKE_HS ? SREC_HS + c * 6 + r : q[w].take == STAKE_HTS ? SREC_HTS + c * 6 + r : SREC_HTS + r * 6 + c;
-          v[w] = rec[off];
-        }
-#pragma unroll
-        for (int w = 0; w < 8; w++)
-          if (k0 + w < d.count) s += v[w];
-      }
-      if (d.diag_col >= 0 && r == c && (ex.lambda > 0.0 || ex.prior_diag)) {
-        double add = ex.diagonal ? __dmul_rn(ex.lambda, fmin(fmax(s, ex.min_diag), ex.max_diag)) : ex.lambda;
-        if (ex.prior_diag) add = __dadd_rn(add, ex.prior_diag[6 * (size_t)d.diag_col + r]);
-        s = __dadd_rn(s, add);
-      }
-      Ls[36 * (size_t)d.block + l] = s;
-      if (d.diag_col >= 0 && r == c) d0s[6 * (size_t)d.diag_col + r] = s;
-    } else if (d.diag_col >= 0) {
-      const int r = l - 36;
-      double s = 0.0;
-      for (int k0 = 0; k0 < d.count; k0 += 8) {
-        SparseContribution q[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) q[w] = contribs_l[d.begin + (k0 + w < d.count ? k0 + w : d.count - 1)];
-        double v[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) v[w] = (records + 122 * (size_t)q[w].factor)[q[w].take == STAKE_HT ? SREC_BT + r : SREC_BS + r];
-#pragma unroll
-        for (int w = 0; w < 8; w++)
-          if (k0 + w < d.count) s -= v[w];
-      }
-      ys[6 * (size_t)d.diag_col + r] = s;
-      ex.b_slots_host[6 * (size_t)ex.perm[d.diag_col] + r] = s;
+  // the assembled system, written by sparse_assemble_kernel<true> in the launch in front of this one (b and c are already with the host): L's blocks -- column-major in
+  // global memory, ROW-major in this copy --, b, and the assembled diagonal the pivots are held against.  Coalesced 8-byte reads, four in flight per thread.
+  {
+    const int nL = 36 * V.nnzL;
+#pragma unroll 4
+    for (int i = t; i < nL; i += kSmallThreads) {
+      const int blk = i / 36, e = i % 36;
+      Ls[36 * (size_t)blk + 6 * (e % 6) + e / 6] = V.L_global[i];
+    }
+    for (int i = t; i < 6 * V.P; i += kSmallThreads) {
+      ys[i] = V.y_global[i];
+      d0s[i] = V.diag0_global[i];
     }
   }
-  // c = sum of the factors' errors, sparse_sum_errors_kernel's order: 256 strided partial sums folded pairwise
-  if (t < 256) {
-    double s = 0.0;
-    for (int f = t; f < ex.num_factors; f += 256) s += records[122 * (size_t)f + 1];
-    cpart[t] = s;
-  }
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) cpart[t] += cpart[t + w];
-    __syncthreads();
-  }
-  if (t == 0) {
-    *ex.c_dev = cpart[0];
-    *ex.c_host = cpart[0];
-  }
+  GP_SMALL_STAMP(5);  // lists and system are in LDS
   GP_SMALL_STAMP(1);
   // ---- phase 1: factorisation + forward substitution ----
   for (int lvl = 0; lvl < V.num_levels; lvl++) {
@@ -1211,21 +1163,48 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
         if (on) {
           // 1. gather: one thread per entry of the column's blocks
           if (!staged) {
+            // (measured and removed, round 6: letting the team's idle waves subtract the next column's products of all source columns but this one while the first wave
+            //  factors the diagonal block -- bit-identical, and no faster: a round's gather is ~2300 clocks with NO products at all)
             for (int e = j; e < 36 * nb; e += T) {
               const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
-              double acc = Ls[36 * (size_t)d + (e % 36)];
+              double acc = Ls[36 * (size_t)d + 6 * r + c];
               acc = small_sub_products(acc, upd_a, upd_b, upd_ptr[d], upd_ptr[d + 1], Ls, r, c);
               if (d == base) D[r][c] = acc;
-              else Ls[36 * (size_t)d + (e % 36)] = acc;
+              else Ls[36 * (size_t)d + 6 * r + c] = acc;
             }
             if (j < 6) {  // right-hand side of the forward substitution: b_k - sum_j L_kj y_j, in list order
               const int r = j;
               double acc = ys[6 * (size_t)k + r];
-              for (int u = rb; u < rb + nrow; u++) {
-                const double* A = Ls + 36 * (size_t)row_blk[u];
-                const double* yj = ys + 6 * (size_t)row_col[u];
+              // (four blocks of the row requested together, subtracted in list order: one at a time every block is two dependent LDS round trips + six dependent
+              //  multiply-adds on the round's critical path -- the stamps showed the gather growing with the row list, not with the product lists)
+              int u = rb;
+              const int ue = rb + nrow;
+              for (; u < ue; u += 4) {
+                int ib[4], ic[4];
 #pragma unroll
-                for (int q = 0; q < 6; q++) acc -= A[r + 6 * q] * yj[q];
+                for (int w = 0; w < 4; w++) {
+                  const int uu = u + w < ue ? u + w : ue - 1;
+                  ib[w] = row_blk[uu];
+                  ic[w] = row_col[uu];
+                }
+                double av[4][6], yv[4][6];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                  const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)ib[w] + 6 * r);
+                  const double2* Y = reinterpret_cast<const double2*>(ys + 6 * (size_t)ic[w]);
+#pragma unroll
+                  for (int q = 0; q < 3; q++) {
+                    const double2 x = A[q], y2 = Y[q];
+                    av[w][2 * q] = x.x, av[w][2 * q + 1] = x.y;
+                    yv[w][2 * q] = y2.x, yv[w][2 * q + 1] = y2.y;
+                  }
+                }
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+                  if (u + w < ue) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) acc -= av[w][q] * yv[w][q];
+                  }
               }
               rhs[r] = acc;
             }
@@ -1238,23 +1217,23 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
               const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
               const int ub = upd_ptr[d], ulen = upd_ptr[d + 1] - ub;
               const int per = (ulen + G - 1) / G;
-              double v = Ls[36 * (size_t)d + (e % 36)];
+              double v = Ls[36 * (size_t)d + 6 * r + c];
               for (int g = 0; g < G; g++) {
                 const double acc = small_sub_products(0.0, upd_a, upd_b, ub + g * per, min(ub + ulen, ub + g * per + per), Ls, r, c);
                 v += acc;
               }
               if (d == base) D[r][c] = v;
-              else Ls[36 * (size_t)d + (e % 36)] = v;
+              else Ls[36 * (size_t)d + 6 * r + c] = v;
             }
             for (int jj = j; jj < 96; jj += T) {  // right-hand side: sixteen slices of the row list (a team may be one wave: 64 threads)
               const int r = jj % 6, g = jj / 6;
               const int per = (nrow + 15) / 16;
               double a = 0.0;
               for (int q = g * per; q < min(nrow, (g + 1) * per); q++) {
-                const double* A = Ls + 36 * (size_t)row_blk[rb + q];
+                const double* A = Ls + 36 * (size_t)row_blk[rb + q] + 6 * r;
                 const double* yj = ys + 6 * (size_t)row_col[rb + q];
 #pragma unroll
-                for (int m = 0; m < 6; m++) a -= A[r + 6 * m] * yj[m];
+                for (int m = 0; m < 6; m++) a -= A[m] * yj[m];
               }
               rpart[g][r] = a;
             }
@@ -1276,11 +1255,11 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
         __syncthreads();
         if (stamp) GP_SMALL_STAMP(8 + 4 * rd + 2);
         if (on) {
-          if (j < 36) Ls[36 * (size_t)base + j] = (j % 6) >= (j / 6) ? D[j % 6][j / 6] : 0.0;
+          if (j < 36) Ls[36 * (size_t)base + 6 * (j % 6) + j / 6] = (j % 6) >= (j / 6) ? D[j % 6][j / 6] : 0.0;
           if (j >= 36 && j < 42) ys[6 * (size_t)k + (j - 36)] = rhs[j - 36];
           if (j >= 42 && j < 48) dis[6 * (size_t)k + (j - 42)] = dinv[j - 42];
           // 3. the blocks below: L_ik = B_ik L_kk^-T, one thread per (block, row)
-          for (int e = j; e < 6 * (nb - 1); e += T) trsm_row6(Ls + 36 * (size_t)(base + 1 + e / 6), e % 6, D, dinv);
+          for (int e = j; e < 6 * (nb - 1); e += T) trsm_row6<true>(Ls + 36 * (size_t)(base + 1 + e / 6), e % 6, D, dinv);
         }
         __syncthreads();
         if (stamp) GP_SMALL_STAMP(8 + 4 * rd + 3);
@@ -1314,7 +1293,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
             const double* A = Ls + 36 * (size_t)(base + p);
             const double* xi = xs + 6 * (size_t)rowidx[base + p];
 #pragma unroll
-            for (int q = 0; q < 6; q++) acc += A[q + 6 * c] * xi[q];
+            for (int q = 0; q < 6; q++) acc += A[6 * q + c] * xi[q];
           }
           bpart[slice][c] = acc;
         }
@@ -1326,7 +1305,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
             vv[j] = sum;
           }
           GP_WAVE_SYNC_LDS();
-          if (j == 0) back6(Ls + 36 * (size_t)base, dis + 6 * (size_t)k, vv, xs + 6 * (size_t)k);
+          if (j == 0) back6<true>(Ls + 36 * (size_t)base, dis + 6 * (size_t)k, vv, xs + 6 * (size_t)k);
         }
         __syncthreads();
       }
@@ -1341,7 +1320,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     V.x_slots_host[to] = v;
   }
   if (t == 0) {
-    *ex.status = bad;
+    *status = bad;
     *V.status_host = (double)bad;
   }
   GP_SMALL_STAMP(4);
@@ -1498,25 +1477,20 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
       off[i] = (int)arena.size();
       arena.insert(arena.end(), sa[i]->begin(), sa[i]->end());
     }
-    static_assert(sizeof(gp::SparseDest) == 4 * sizeof(int) && sizeof(gp::SparseContribution) == 2 * sizeof(int), "the assembly's lists ride in the int arena");
-    while (arena.size() & 3) arena.push_back(0);  // (16-byte alignment of the destination records that follow: they are read as one 128-bit LDS access)
-    const int off_dests = (int)arena.size();
-    arena.insert(arena.end(), reinterpret_cast<const int*>(s->dests.data()), reinterpret_cast<const int*>(s->dests.data() + s->dests.size()));
-    const int off_contribs = (int)arena.size();
-    arena.insert(arena.end(), reinterpret_cast<const int*>(s->contribs.data()), reinterpret_cast<const int*>(s->contribs.data() + s->contribs.size()));
+    if (arena.size() & 1) arena.push_back(0);
     if (arena.size() > small_words) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_create: internal: the one-launch step's index arena outgrew its estimate");
     if ((rc = s->d_small_arena.alloc(sizeof(int) * std::max<size_t>(arena.size(), 1))) || (rc = s->d_level_ptr.alloc(sizeof(int) * S.level_ptr.size()))) return rc;
     GP_HIP(hipMemcpy(s->d_small_arena.ptr, arena.data(), sizeof(int) * arena.size(), hipMemcpyHostToDevice));
     GP_HIP(hipMemcpy(s->d_level_ptr.ptr, S.level_ptr.data(), sizeof(int) * S.level_ptr.size(), hipMemcpyHostToDevice));
     gp::SparseSmallView& V = s->small;
-    V.dests = s->d_dests.as<gp::SparseDest>();
-    V.contribs = s->d_contribs.as<gp::SparseContribution>();
+    V.L_global = s->L.as<double>();
+    V.y_global = s->y.as<double>();
+    V.diag0_global = s->diag0.as<double>();
     V.arena = s->d_small_arena.as<int>();
     V.level_ptr = s->d_level_ptr.as<int>();
-    V.arena_words = (int)arena.size(), V.num_levels = (int)S.level_ptr.size() - 1, V.P = P, V.nnzL = nnzL, V.num_dests = (int)s->dests.size();
+    V.arena_words = (int)arena.size(), V.num_levels = (int)S.level_ptr.size() - 1, V.P = P, V.nnzL = nnzL;
     V.o_colptr = off[0], V.o_rowidx = off[1], V.o_upd_ptr = off[2], V.o_upd_a = off[3], V.o_upd_b = off[4], V.o_row_ptr = off[5], V.o_row_blk = off[6], V.o_row_col = off[7];
     V.o_work_ptr = off[8], V.o_work_cols = off[9];
-    V.o_dests = off_dests, V.o_contribs = off_contribs;
     V.perm = s->d_perm;
     V.x_slots = s->x_slots.as<double>();
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for; a runtime that refuses leaves the multi-launch step in charge)
@@ -1698,11 +1672,14 @@ int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_d
   ex.num_factors = s->num_factors, ex.num_dests = (int)s->dests.size();
   ex.diag0 = s->diag0.as<double>();
   if (s->one_launch) {
-    // small graph: the whole step in ONE launch, every operand in the LDS of one compute unit (sparse_small_step_kernel)
+    // small graph: the assembly as it is (one workgroup per block of L across the chip: a gather of 8-byte values, which ONE compute unit's vector memory path takes
+    // 40 us for), then factorisation and both substitutions in ONE launch with every operand in the LDS of one compute unit (sparse_small_step_kernel)
+    hipLaunchKernelGGL(gp::sparse_assemble_kernel<true>, dim3((unsigned)s->dests.size() + 1), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
+                       s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), ex);
     gp::SparseSmallView V = s->small;
     V.x_slots_host = h;
     V.status_host = h + 2 * n + 1;
-    hipLaunchKernelGGL(gp::sparse_small_step_kernel, dim3(1), dim3(gp::kSmallThreads), s->small_lds_bytes, s->stream, V, reinterpret_cast<const double*>(records_dev), ex);
+    hipLaunchKernelGGL(gp::sparse_small_step_kernel, dim3(1), dim3(gp::kSmallThreads), s->small_lds_bytes, s->stream, V, s->status.as<int>());
     GP_HIP(hipGetLastError());
     s->built = false;
     GP_HIP(hipStreamSynchronize(s->stream));

@@ -457,10 +457,11 @@ int gp_sparse_system_build(gp_sparse_system_t* sys, const gp_linearized6* record
 int gp_sparse_system_download(const gp_sparse_system_t* sys, double* A_host, double* b_host, double* c_host);
 /* x in slot order (host and / or device copy, either may be NULL); consumes the built system.  GP_ERROR_INDETERMINATE if not positive definite. */
 int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_dev);
-/* gp_dense_system_step's block-sparse form, one wait.  A system whose factor and index lists fit the LDS of one compute unit (<= 128 poses, <= ~440 blocks of L: BASELINE
- * configs[2]'s 64-pose graph does) is assembled, damped, factored and solved by ONE launch of one 1024-thread workgroup with every operand in LDS
- * (sparse_small_step_kernel); larger ones take 2 + 2 x levels launches (the assembly applies the damping and hands b, c to the host; the last kernel hands over x).  The two
- * forms are bit-identical; gp_sparse_system_set_one_launch(sys, 0) selects the multi-launch form for a qualifying system (returns what the next step runs: 1 / 0). */
+/* gp_dense_system_step's block-sparse form, one wait.  The assembly kernel applies the damping and hands b, c to the host.  A system whose factor and index lists fit the
+ * LDS of one compute unit (<= 128 poses, <= ~400 blocks of L: BASELINE configs[2]'s 64-pose graph does) is then factored and solved -- all levels, both substitutions, x
+ * and status to the host -- by ONE launch of one 1024-thread workgroup with every operand in LDS (sparse_small_step_kernel): two launches per step; larger systems take
+ * 2 + 2 x levels launches.  The two forms are bit-identical; gp_sparse_system_set_one_launch(sys, 0) selects the multi-launch form for a qualifying system (returns what
+ * the next step runs: 1 / 0). */
 int gp_sparse_system_step(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                           const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* sys, int enable);

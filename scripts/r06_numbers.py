@@ -136,7 +136,7 @@ def lm():
         if "error" in o or not o:
             out.append(f"| {name} | — | — | {o.get('error', 'not run')} | | | | | |")
             continue
-        for leg, label in (("gpu_device_solve", "GPU, records stay in HBM, damped build + block-sparse LLᵀ as ONE call and — round 6 — ONE launch (`gp_sparse_system_step`)"), ("gpu_host_solve", "GPU linearise / error, numpy solve on the host"),
+        for leg, label in (("gpu_device_solve", "GPU, records stay in HBM, damped build + block-sparse LLᵀ as ONE call — round 6: the assembly + ONE launch (`gp_sparse_system_step`)"), ("gpu_host_solve", "GPU linearise / error, numpy solve on the host"),
                            ("cpu_baseline", f"the reference's CPU factor ({o['cpu_baseline']['cores']} threads) + numpy solve: {o['cpu_baseline'].get('sample', '')[:60]}")):
             if leg not in o:
                 continue
@@ -152,7 +152,7 @@ def lm():
 
 def solver():
     rows = jl("r06_solver_step_time.jsonl")
-    out = ["| graph (structure of the damped system) | ordering | levels / critical columns / blocks of L | ONE launch (`sparse_small_step_kernel`) ms | multi-launch ms | bit-identical |", "|---|---|---|---|---|---|"]
+    out = ["| graph (structure of the damped system) | ordering | levels / critical columns / blocks of L | assembly + ONE launch (`sparse_small_step_kernel`) ms | multi-launch ms | bit-identical |", "|---|---|---|---|---|---|"]
     for x in rows:
         if x["ordering"] not in ("auto", "natural"):
             continue
