@@ -1,6 +1,6 @@
 """Round 6: every number DESIGN.md / README.md / BASELINE.md quote for this round is generated from the committed profiles/r06_* files by this script and pasted between
 the `<!-- r06:NAME:begin -->` / `<!-- r06:NAME:end -->` markers of those documents (no hand-typed figures; tests/test_docs_cpu.py regenerates and compares).
-Sources: profiles/r06_bench_run{1,2,3}.json = the LAST stdout line of three runs of the driver's command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`),
+Sources: profiles/r06_bench_run{1..6}.json = the LAST stdout line of six runs of the driver's command on two boxes (`python3 bench.py --gpus 1 --steps 20 --warmup 5`),
 r06_bench_detail_run1.json = the detail file of run 1, r06_bench_kernel_stats*.csv = rocprofv3 --kernel-trace --stats of the headline protocol,
 r06_bench_rehearsal_n2.json = the N = 2 launch on one GPU (gloo), r06_solver_step_time.jsonl, r06_wg_geometry*.jsonl / .csv, r06_c5_pmc.json, r06_map_build_pmc.json.
 Usage: python scripts/r06_numbers.py [--write]"""
@@ -47,7 +47,7 @@ def rng(vals, fmt="{:.2f}"):
 
 
 def runs():
-    return [jl(f"r06_bench_run{i}.json")[-1] for i in (1, 2, 3) if jl(f"r06_bench_run{i}.json")]
+    return [jl(f"r06_bench_run{i}.json")[-1] for i in (1, 2, 3, 4, 5, 6) if jl(f"r06_bench_run{i}.json")]  # (1 - 3 and 4 - 6: two evidence calls = two boxes of the pool)
 
 
 def headline():
@@ -56,7 +56,7 @@ def headline():
     st, st_nw, st_2k = (stats(f"r06_bench_kernel_stats{s}.csv", "vgicp_stream_kernel") for s in ("", "_no_warmup", "_two_kernel"))
     out = ["| what (C2 headline: 1 M source points vs the 2 M-point map at 0.5 m; algorithmic bytes 56.03 MB) | µs | fraction of 8 TB/s on algorithmic bytes | source |", "|---|---|---|---|"]
     out.append(f"| **the WHOLE fused kernel inside the driver command's timed steps** (first workgroup started → last part's sums on their way to the host; the kernel's own 100 MHz stamps) — `roofline.frac` | "
-               f"**{rng([x['roofline']['kernel_ms'] * 1e3 for x in rs])}** | **{rng([x['roofline']['frac'] for x in rs], '{:.3f}')}** | `profiles/r06_bench_run{{1,2,3}}.json` (the last stdout line of three runs of `bench.py --gpus 1 --steps 20 --warmup 5` on one box) |")
+               f"**{rng([x['roofline']['kernel_ms'] * 1e3 for x in rs])}** | **{rng([x['roofline']['frac'] for x in rs], '{:.3f}')}** | `profiles/r06_bench_run{{1..6}}.json` (the last stdout line of six runs of `bench.py --gpus 1 --steps 20 --warmup 5`: runs 1 – 3 on one box of the pool, 4 – 6 on another; the slower box is 1 – 3) |")
     out.append(f"| its streaming part (→ last partial row in) — `frac_streaming` | {rng([x['roofline']['streaming_ms'] * 1e3 for x in rs])} | {rng([x['roofline']['frac_streaming'] for x in rs], '{:.3f}')} | same |")
     out.append(f"| **rocprofv3 `--kernel-trace --stats` average of the kernel, measured IN the run** (a child run of the headline protocol: wake-up + W + K steps; dispatch → end signal) — `roofline.rocprof_avg_ms`, `frac_rocprof` | "
                f"{rng([x['roofline']['rocprof_avg_ms'] * 1e3 for x in rs])} (n = {rng([x['roofline']['rocprof_calls'] for x in rs], '{:.0f}')}) | {rng([x['roofline']['frac_rocprof'] for x in rs], '{:.3f}')} | same |")
@@ -66,7 +66,7 @@ def headline():
         out.append(f"| … with `--device-warmup-ms 0` ({st_nw['calls']} dispatches: 25 + 25 fused steps + the back-to-back loop) | {st_nw['avg_us']:.2f} | {frac(st_nw['avg_us']):.3f} | `profiles/r06_bench_kernel_stats_no_warmup.csv` |")
     if st_2k:
         out.append(f"| … with `--finalize two-kernel` (the stream kernel without its fused tail, inside steps) | {st_2k['avg_us']:.2f} | {frac(st_2k['avg_us']):.3f} | `profiles/r06_bench_kernel_stats_two_kernel.csv` |")
-    out.append(f"| stream kernel back to back (HIP events on the launch stream, two-kernel form) | {rng([x['roofline']['kernel_ms_back_to_back'] * 1e3 for x in rs])} | {rng([x['roofline']['frac_back_to_back'] for x in rs], '{:.3f}')} | `profiles/r06_bench_run{{1,2,3}}.json` |")
+    out.append(f"| stream kernel back to back (HIP events on the launch stream, two-kernel form) | {rng([x['roofline']['kernel_ms_back_to_back'] * 1e3 for x in rs])} | {rng([x['roofline']['frac_back_to_back'] for x in rs], '{:.3f}')} | `profiles/r06_bench_run{{1..6}}.json` |")
     out.append(f"| fabric traffic per launch, measured IN THE RUN (two `rocprofv3 --pmc` passes over a child run; FETCH_SIZE calibrated on a stream of known bytes + WRITE_SIZE) — `roofline.traffic` | "
                f"{rng([x['roofline']['traffic'] / 1e6 for x in rs])} MB ({rng([x['roofline']['traffic'] / ALG for x in rs])} × the algorithmic bytes: the 36-B packed mirror) | — | same |")
     wg = jl("r06_wg_geometry.jsonl")
@@ -145,7 +145,7 @@ def lm():
             out.append(f"| {name} | {label} | {x['iterations']} ({x['inner_iterations']}) | **{x['ms_per_iteration']:.4f}** | {ph['linearize']:.4f} | {ph['solve']:.4f} | {ph['error']:.4f} | {ph['glue']:.4f} | "
                        f"{'met' if x['gate_met'] else 'NOT met'}: {x['max_rotation_error_rad']:.5f} rad / {x['max_translation_error_m']:.4f} m |")
     out.append("")
-    out.append(f"Across the three runs of the driver's command: C3 {rng([x['legs'].get('lm_c3_ms_iter') for x in rs], '{:.3f}')} ms per iteration (solve {rng([x['legs'].get('lm_c3_solve_ms') for x in rs], '{:.3f}')}), "
+    out.append(f"Across the six runs of the driver's command: C3 {rng([x['legs'].get('lm_c3_ms_iter') for x in rs], '{:.3f}')} ms per iteration (solve {rng([x['legs'].get('lm_c3_solve_ms') for x in rs], '{:.3f}')}), "
                f"C1 {rng([x['legs'].get('lm_c1_ms_iter') for x in rs], '{:.3f}')}.  Round 5's driver run: C3 0.451 (solve 0.226).")
     return "\n".join(out)
 
