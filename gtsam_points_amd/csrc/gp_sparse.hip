@@ -48,7 +48,6 @@ struct SparseSymbolic {
   std::vector<int> level_ptr;            // [num_levels + 1] -> work lists: level 0 = the subtrees, level l >= 1 = the top chains whose children are all in lower levels
   int num_subtrees = 0;
   long long nnzA = 0;
-  long long num_contribs = 0;  // entries of the assembly's contribution list: one per factor side with a slot + one per factor with two slots
 };
 
 // nested dissection by BFS bisection: order = nd(A) ++ nd(B) ++ separator
@@ -203,11 +202,6 @@ static int sparse_symbolic_with(int num_slots, const int* factor_slots, int num_
   for (auto& v : adj) {
     std::sort(v.begin(), v.end());
     v.erase(std::unique(v.begin(), v.end()), v.end());
-  }
-  S.num_contribs = 0;
-  for (int f = 0; f < num_factors; f++) {
-    const int a = factor_slots[2 * f], b = factor_slots[2 * f + 1];
-    S.num_contribs += (a >= 0) + (b >= 0) + (a >= 0 && b >= 0);
   }
   S.perm.resize(P);
   if (ordering == 1) {
@@ -1086,7 +1080,7 @@ struct SparseSmallView {
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
   double* status_host;    // pinned
-  unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] assembled, [2] factored, [3] substituted, [4] end, [5] index lists in LDS, [6] thread 0's destinations assembled,
+  unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] = [5] lists and system in LDS, [2] factored, [3] substituted, [4] end,
                               // [8 + 4 r + {0, 1, 2, 3}]: round r < 14 of the first level: start, gathered, diagonal done, blocks below done; null = off
 };
 __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const SparseSmallView V, int* __restrict__ status) {

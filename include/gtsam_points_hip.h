@@ -465,8 +465,8 @@ int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_de
 int gp_sparse_system_step(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                           const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* sys, int enable);
-/* measurement hook: thread 0 of the one-launch step stamps its phases (s_memtime) into dev_buffer (64 uint64: [0] start, [1] assembled, [2] factored, [3] substituted, [4] end,
- * [8 + 4 r + 0..3] round r < 14 of the first level: start / gathered / diagonal block done / blocks below done); NULL = off */
+/* measurement hook: thread 0 of sparse_small_step_kernel stamps its phases (s_memtime) into dev_buffer (64 uint64: [0] start, [1] lists and system in LDS, [2] factored,
+ * [3] substituted, [4] end, [8 + 4 r + 0..3] round r < 14 of the first level: start / gathered / diagonal block done / blocks below done); NULL = off */
 int gp_debug_sparse_step_trace(gp_sparse_system_t* sys, unsigned long long* dev_buffer);
 /* the symbolic phase alone (pure host code, no device needed): elimination order perm[k] = slot eliminated k-th, elimination tree
  * parent[k] (-1 = root), block counts and the schedule; any output pointer may be NULL */

@@ -30,4 +30,4 @@ for n in (64, 16):
     lib.gp_debug_sparse_step_trace(sp._h, None)
     ph = [int(w[i] - w[0]) for i in range(7)]
     rounds = [[int(w[8 + 4 * r + q] - w[8 + 4 * r]) for q in range(1, 4)] + [int(w[8 + 4 * (r + 1)] - w[8 + 4 * r]) if r < 13 and w[8 + 4 * (r + 1)] else None] for r in range(14) if w[8 + 4 * r]]
-    print(json.dumps(dict(poses=n, phase_clocks=dict(system_in_lds=ph[5], assembled=ph[1], factored=ph[2], substituted=ph[3], end=ph[4]), first_level_rounds_clocks_gather_diag_below_next=rounds)))
+    print(json.dumps(dict(poses=n, phase_clocks=dict(system_in_lds=ph[5], factored=ph[2], substituted=ph[3], end=ph[4]), first_level_rounds_clocks_gather_diag_below_next=rounds)))
