@@ -406,3 +406,43 @@ def test_one_launch_step_declines_a_factor_that_does_not_fit(gpu):
     slots = [(-1, 0)] + [(i, i + d) for i in range(P) for d in (1, 2, 7) if i + d < P]
     sp = gpu.SparseLinearSystemGPU(P, slots)
     assert sp.set_one_launch(True) is False  # 512 poses: the multi-launch schedule stays in charge
+
+
+def test_one_launch_step_fuzz_against_the_multi_launch_form(gpu):
+    """randomised soak of the LDS-resident step: 60 random pose graphs (a spanning tree + random loop closures + unary factors, 1 .. 110 poses, slots shuffled, some poses held
+    fixed), every ordering in turn: where the factor fits, x / b / c are the multi-launch form's bit for bit, and x solves the host-assembled system"""
+    import torch
+
+    rng = np.random.default_rng(2026)
+    orderings = ["auto", "natural", "nd", "amd", "amd1"]
+    ran = 0
+    for trial in range(60):
+        P = int(rng.integers(1, 111))
+        perm = rng.permutation(P)
+        slots = [(-1, int(perm[0]))]  # one pose tied to a fixed one: the system is regular
+        for k in range(1, P):
+            slots.append((int(perm[rng.integers(0, k)]), int(perm[k])))  # spanning tree
+        for _ in range(int(rng.integers(0, P // 2 + 2))):
+            a, b = rng.integers(0, P, 2)
+            if a != b:
+                slots.append((int(a), int(b)))
+        for _ in range(int(rng.integers(0, 3))):
+            slots.append((-1, int(rng.integers(0, P))))
+        rec = _random_records(slots, rng)
+        rec_dev = torch.from_numpy(rec).cuda()
+        o = orderings[trial % len(orderings)]
+        one, multi = gpu.SparseLinearSystemGPU(P, slots, ordering=o), gpu.SparseLinearSystemGPU(P, slots, ordering=o)
+        if not one.set_one_launch(True):
+            continue
+        multi.set_one_launch(False)
+        lam = float(10.0 ** rng.uniform(-6, 0))
+        diag = bool(trial % 3 == 0)
+        x1, b1, c1 = one.step(rec_dev, lam=lam, diagonal_damping=diag)
+        xm, bm, cm = multi.step(rec_dev, lam=lam, diagonal_damping=diag)
+        assert np.array_equal(x1, xm) and np.array_equal(b1, bm) and c1 == cm, (trial, P, o, len(slots))
+        Ah, bh, _ = _host_system(rec, slots, P)
+        damp = lam * np.diag(np.clip(np.diag(Ah), 1e-6, 1e32)) if diag else lam * np.eye(6 * P)
+        want = np.linalg.solve(Ah + damp, bh)
+        assert np.linalg.norm(x1 - want) <= 1e-8 * np.linalg.norm(want), (trial, P, o)
+        ran += 1
+    assert ran >= 40  # (most random graphs of this size fit one compute unit's LDS)
