@@ -181,6 +181,57 @@ class GpuGraph(_Graph):
         return float(self.errs.sum())
 
 
+class GpuTrialGraph(_Graph):
+    """round 6: the values live in device memory (gp_lm_graph_*, csrc/gp_lm.hip) -- linearize() issues the batch's linearise at them, solve() is the whole trial (damped
+    step + retract + error evaluation at the trial values, ONE wait), retract() / error() hand back what the trial already computed.  Same cadence, same tests, driven by
+    the same run_lm; `native_loop` runs the library's own loop (gp_lm_graph_optimize) instead."""
+
+    name = "gpu-trial"
+
+    def __init__(self, gpa, factors, pairs, num_poses, fixed=0, stream=None):
+        super().__init__(pairs, num_poses, fixed)
+        self.g = gpa.LevenbergMarquardtGraphGPU(factors, self.pairs, num_poses, fixed=(fixed,), stream=stream)
+        self.sync_phases = False
+        self._trial = None
+        self._trial_error = None
+
+    def close(self):
+        self.g.close()
+
+    def linearize(self, values):
+        if values is self._trial and self._trial is not None:
+            self.g.accept()
+        else:
+            self.g.set_values(values)
+        self._trial = None
+        self.g.linearize()
+        if self.sync_phases:
+            self.g.sync()
+        return None
+
+    def solve(self, lam):
+        dx, b, c, e, v = self.g.try_lambda(lam, want_values=True)
+        self._trial, self._trial_error = v, e
+        return dx, b, c
+
+    def retract(self, values, dx):
+        return self._trial
+
+    def error(self, values):
+        assert values is self._trial
+        return self._trial_error
+
+    def native_loop(self, values0, max_iterations=30):
+        """-> run_lm's dict from ONE call of gp_lm_graph_optimize (no per-phase split: the loop never returns to the interpreter)"""
+        self.g.set_values(values0)
+        self.g.sync()
+        t0 = time.perf_counter()
+        values, s = self.g.optimize(max_iterations=max_iterations)
+        total = time.perf_counter() - t0
+        return dict(values=values, iterations=s["iterations"], inner_iterations=s["inner_iterations"], errors=[], steps=[], seconds=total,
+                    phases=dict(linearize=0.0, solve=total, error=0.0, glue=0.0), final_error=s["final_error"], final_lambda=s["final_lambda"])
+
+
 class CpuGraph(_Graph):
     """cpu_factors[k]: linearize(delta) -> Linearized6 and error(delta) (= evaluate on the state of the last linearize, integrated_matching_cost_factor.cpp:32-35); sequential over factors"""
 

@@ -19,7 +19,7 @@ from .factors import (  # noqa: F401
     pose_inverse,
 )
 from .features import IntegratedGICPFactorGPU, KdTreeGPU, estimate_covariances_gpu  # noqa: F401
-from .solver import DenseLinearSystemGPU, SparseLinearSystemGPU, linearize_on_device, sparse_symbolic  # noqa: F401
+from .solver import DenseLinearSystemGPU, LevenbergMarquardtGraphGPU, SparseLinearSystemGPU, linearize_on_device, sparse_symbolic  # noqa: F401
 from .types import GaussianVoxelMapGPU, PointCloudGPU, merge_frames_gpu, overlap_gpu  # noqa: F401
 
 __all__ = [
@@ -41,6 +41,7 @@ __all__ = [
     "overlap_gpu",
     "merge_frames_gpu",
     "DenseLinearSystemGPU",
+    "LevenbergMarquardtGraphGPU",
     "SparseLinearSystemGPU",
     "sparse_symbolic",
     "linearize_on_device",

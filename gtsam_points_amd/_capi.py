@@ -212,8 +212,41 @@ _SIGNATURES = {
     "gp_debug_inject_sort_fault": (C.c_int, [C.c_int]),
     "gp_debug_sort_fallbacks": (C.c_int, []),
     "gp_trim_device_cache": (C.c_int, []),
+    "gp_vgicp_batch_issue_linearize_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "gp_vgicp_batch_issue_compute_error_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_vgicp_batch_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gp_dense_system_issue_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "gp_dense_system_finish_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_dense_system_device_solution": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "gp_sparse_system_issue_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "gp_sparse_system_finish_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_sparse_system_device_solution": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    # the optimizer's trial with the values in device memory (gp_lm.hip)
+    "gp_lm_params_default": (None, [C.c_void_p]),
+    "gp_lm_graph_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "gp_lm_graph_destroy": (C.c_int, [C.c_void_p]),
+    "gp_lm_graph_num_variables": (C.c_int, [C.c_void_p]),
+    "gp_lm_graph_set_values": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gp_lm_graph_get_values": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gp_lm_graph_linearize": (C.c_int, [C.c_void_p]),
+    "gp_lm_graph_try_lambda": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_lm_graph_accept": (C.c_int, [C.c_void_p]),
+    "gp_lm_graph_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gp_lm_graph_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
+
+class LmParams(C.Structure):
+    """gp_lm_params (include/gtsam_points_hip.h): GTSAM's LevenbergMarquardtParams fields the loop reads"""
+
+    _fields_ = [("lambda_initial", C.c_double), ("lambda_factor", C.c_double), ("lambda_upper_bound", C.c_double), ("lambda_lower_bound", C.c_double),
+                ("relative_error_tol", C.c_double), ("absolute_error_tol", C.c_double), ("min_model_fidelity", C.c_double), ("min_diagonal", C.c_double),
+                ("max_diagonal", C.c_double), ("max_iterations", C.c_int), ("diagonal_damping", C.c_int)]
+
+
+class LmSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("inner_iterations", C.c_int), ("gave_up", C.c_int), ("reserved_", C.c_int), ("final_error", C.c_double), ("final_lambda", C.c_double)]
+
 
 # tuning keys / kernel families of include/gtsam_points_hip.h
 GP_KERNEL_REFERENCE, GP_KERNEL_HASHED, GP_KERNEL_GRID_F64, GP_KERNEL_LOOKAHEAD, GP_KERNEL_STREAM = 0, 2, 3, 8, 12

@@ -1,0 +1,348 @@
+// gp_lm.hip -- one Levenberg-Marquardt trial over a graph of pairwise VGICP factors WITHOUT the host in the middle (round 6).
+//
+// The reference's optimizer drives its GPU factors from the host (optimizers/levenberg_marquardt_ext.cpp): iterate() :352-392 hands `values` to
+// linearization_hook_->linearize (cuda/nonlinear_factor_set_gpu.cpp:64-101: poses up, kernels, records down), tryLambda() :188-350 builds the damped system, solves,
+// retracts ON THE HOST (:239), hands the new values to linearization_hook_->error (:245, nonlinear_factor_set_gpu.cpp:103-139: poses up, kernels, errors down) and
+// decides.  Two waits, two uploads and the pose algebra of every factor per trial -- fine beside a 1.5 s CPU linearise, 0.13 ms of a 0.39 ms iteration here
+// (BASELINE configs[2]: 256 factors over 64 poses).
+//
+// Here the VALUES live in device memory beside the records:
+//   gp_lm_graph_linearize    the batch's linearise at the relative poses of the current values (a device table: gp_vgicp_batch_issue_linearize_dev) -> records in HBM
+//   gp_lm_graph_try_lambda   the damped step (gp_sparse_system_issue_step / gp_dense_system_issue_step), then ONE small kernel that retracts the current values by
+//                            the step's x where the step left it (Pose3::retract = T Expmap(xi), (omega, v) order) and writes the trial values and every factor's
+//                            relative pose, then the batch's error evaluation on the linearisation's correspondences at those (gp_vgicp_batch_issue_compute_error_dev):
+//                            four-five launches queued back to back, ONE wait; x, b, c, the trial's error and the trial values reach the host through pinned memory
+//   gp_lm_graph_accept       the trial values become the current ones (their relative poses are already in place for the next linearise): a pointer swap
+//   gp_lm_graph_optimize     the reference's cadence over those three (tryLambda's tests :262-292, decreaseLambda / increaseLambda with the GTSAM defaults)
+// Pose arithmetic on the device = the formulas of gtsam::Pose3 (Expmap with the closed-form V, compose, inverse() * other) in f64; the host-side harness
+// (bench_lm.py) computes the same with numpy, and the two agree to rounding (tests/test_lm_gpu.py).
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "gp_host.hpp"
+#include "gp_vgicp_shared.hpp"
+
+namespace gp {
+
+struct Rigid {
+  double R[9];  // row-major
+  double t[3];
+};
+
+__device__ __forceinline__ Rigid load_rigid(const double* __restrict__ p /*column-major 4x4*/) {
+  Rigid T;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) T.R[r * 3 + c] = p[c * 4 + r];
+  T.t[0] = p[12], T.t[1] = p[13], T.t[2] = p[14];
+  return T;
+}
+
+__device__ __forceinline__ void store_rigid(const Rigid& T, double* __restrict__ p) {
+  for (int c = 0; c < 3; c++) {
+    for (int r = 0; r < 3; r++) p[c * 4 + r] = T.R[r * 3 + c];
+    p[c * 4 + 3] = 0.0;
+  }
+  p[12] = T.t[0], p[13] = T.t[1], p[14] = T.t[2], p[15] = 1.0;
+}
+
+// T * Expmap(xi), xi = (omega, v): gtsam::Pose3::Expmap (R = I + A W + B W^2, t = (I + B W + C W^2) v; series below theta = 1e-8) composed from the right
+__device__ Rigid retract_rigid(const Rigid& T, const double* __restrict__ xi) {
+  const double wx = xi[0], wy = xi[1], wz = xi[2];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+  double A, B, C;
+  if (th < 1e-8) {
+    A = 1.0 - th2 / 6.0, B = 0.5 - th2 / 24.0, C = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    const double s = sin(th), c = cos(th);
+    A = s / th, B = (1.0 - c) / th2, C = (th - s) / (th2 * th);
+  }
+  const double W[9] = {0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0};
+  double W2[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) W2[r * 3 + c] = W[r * 3] * W[c] + W[r * 3 + 1] * W[3 + c] + W[r * 3 + 2] * W[6 + c];
+  double E[9], V[9];
+  for (int i = 0; i < 9; i++) {
+    const double id = (i % 4 == 0) ? 1.0 : 0.0;
+    E[i] = id + A * W[i] + B * W2[i];
+    V[i] = id + B * W[i] + C * W2[i];
+  }
+  const double te[3] = {V[0] * xi[3] + V[1] * xi[4] + V[2] * xi[5], V[3] * xi[3] + V[4] * xi[4] + V[5] * xi[5], V[6] * xi[3] + V[7] * xi[4] + V[8] * xi[5]};
+  Rigid out;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) out.R[r * 3 + c] = T.R[r * 3] * E[c] + T.R[r * 3 + 1] * E[3 + c] + T.R[r * 3 + 2] * E[6 + c];
+    out.t[r] = T.R[r * 3] * te[0] + T.R[r * 3 + 1] * te[1] + T.R[r * 3 + 2] * te[2] + T.t[r];
+  }
+  return out;
+}
+
+// inverse(Tt) * Ts: the relative pose a pairwise factor is evaluated at (integrated_matching_cost_factor.cpp:28-31: delta = target^-1 source)
+__device__ __forceinline__ Rigid between_rigid(const Rigid& Tt, const Rigid& Ts) {
+  Rigid D;
+  const double d[3] = {Ts.t[0] - Tt.t[0], Ts.t[1] - Tt.t[1], Ts.t[2] - Tt.t[2]};
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) D.R[r * 3 + c] = Tt.R[r] * Ts.R[c] + Tt.R[3 + r] * Ts.R[3 + c] + Tt.R[6 + r] * Ts.R[6 + c];
+    D.t[r] = Tt.R[r] * d[0] + Tt.R[3 + r] * d[1] + Tt.R[6 + r] * d[2];
+  }
+  return D;
+}
+
+struct LmPoseView {
+  const double* values;   // [N][16] the current values
+  const int* pairs;       // [F][2] (target pose, source pose)
+  const int* slot;        // [N] variable slot of a pose, < 0 = held
+  const double* x;        // [6 * slots] the step in slot order, or null = no step (relative poses of `values` themselves)
+  const int* status;      // the step's status word: != 0 = indeterminate, the trial is the current values
+  double* values_out;     // [N][16] device, may be null
+  double* values_host;    // [N][16] pinned, may be null
+  double* deltas_out;     // [F][16]
+  int F, N;
+};
+
+// thread i: factor i's relative pose at the (retracted) values, and pose i's (retracted) value.  A pose shared by several factors is retracted by each of them
+// from the same operands with the same instructions: the same bits everywhere.
+__global__ void __launch_bounds__(256) lm_poses_kernel(const LmPoseView v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool step = v.x != nullptr && *v.status == 0;
+  auto value = [&](int k) {
+    Rigid T = load_rigid(v.values + 16 * (size_t)k);
+    const int s = v.slot[k];
+    return (step && s >= 0) ? retract_rigid(T, v.x + 6 * (size_t)s) : T;
+  };
+  if (i < v.F) {
+    const Rigid D = between_rigid(value(v.pairs[2 * i]), value(v.pairs[2 * i + 1]));
+    store_rigid(D, v.deltas_out + 16 * (size_t)i);
+  }
+  if (i < v.N && (v.values_out || v.values_host)) {
+    const Rigid T = value(i);
+    double p[16];
+    store_rigid(T, p);
+    for (int k = 0; k < 16; k++) {
+      if (v.values_out) v.values_out[16 * (size_t)i + k] = p[k];
+      if (v.values_host) v.values_host[16 * (size_t)i + k] = p[k];
+    }
+  }
+}
+
+}  // namespace gp
+
+struct gp_lm_graph {
+  gp_vgicp_batch_t* batch = nullptr;  // not owned
+  gp_sparse_system_t* sparse = nullptr;
+  gp_dense_system_t* dense = nullptr;
+  hipStream_t stream = nullptr;
+  int F = 0, N = 0, slots = 0;
+  std::vector<int> slot;
+  gp::DeviceArray d_pairs, d_slot, d_values[2], d_deltas[2], d_records;
+  gp::PinnedArray h_values[2], h_errors;
+  int cur = 0;                 // d_values[cur] / d_deltas[cur] / h_values[cur] are the current values; [1 - cur] the last trial's
+  bool have_values = false, linearized = false, tried = false;
+  bool rigid = true;           // every value handed to set_values was orthonormal to 1e-9 (retracts keep them so): the rigid kernels, as the host-pose entry points would choose
+  const double* x_dev = nullptr;
+  const int* status_dev = nullptr;
+};
+
+namespace {
+
+int launch_poses(gp_lm_graph* g, int from, int to, bool step) {
+  gp::LmPoseView v{};
+  v.values = g->d_values[from].as<double>();
+  v.pairs = g->d_pairs.as<int>();
+  v.slot = g->d_slot.as<int>();
+  v.x = step ? g->x_dev : nullptr;
+  v.status = g->status_dev;
+  v.values_out = step ? g->d_values[to].as<double>() : nullptr;
+  v.values_host = step ? g->h_values[to].as<double>() : nullptr;
+  v.deltas_out = g->d_deltas[to].as<double>();
+  v.F = g->F, v.N = g->N;
+  const int n = std::max(g->F, g->N);
+  hipLaunchKernelGGL(gp::lm_poses_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, v);
+  GP_HIP(hipGetLastError());
+  return GP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gp_lm_graph_destroy(gp_lm_graph_t* g) {
+  if (!g) return GP_OK;
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->sparse) gp_sparse_system_destroy(g->sparse);
+  if (g->dense) gp_dense_system_destroy(g->dense);
+  delete g;
+  return GP_OK;
+}
+
+int gp_lm_graph_create(gp_vgicp_batch_t* batch, const int* pose_pairs, int num_poses, const unsigned char* pose_fixed, int ordering, gp_lm_graph_t** out) {
+  if (!out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_create: null out");
+  *out = nullptr;
+  const int F = batch ? gp_vgicp_batch_size(batch) : 0;
+  if (!batch || F <= 0 || !pose_pairs || num_poses < 2) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_create: a batch of >= 1 factors, pose_pairs [F][2], >= 2 poses");
+  auto* g = new gp_lm_graph;
+  g->batch = batch, g->F = F, g->N = num_poses;
+  g->slot.assign((size_t)num_poses, -1);
+  for (int i = 0; i < num_poses; i++)
+    if (!pose_fixed || !pose_fixed[i]) g->slot[i] = g->slots++;
+  std::vector<int> factor_slots(2 * (size_t)F);
+  int rc = GP_OK;
+  for (int f = 0; f < F && rc == GP_OK; f++) {
+    const int t = pose_pairs[2 * f], s = pose_pairs[2 * f + 1];
+    if (t < 0 || t >= num_poses || s < 0 || s >= num_poses || t == s) rc = gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_create: pose_pairs entries must be two different poses in [0, num_poses)");
+    else factor_slots[2 * f] = g->slot[t], factor_slots[2 * f + 1] = g->slot[s];
+  }
+  if (rc == GP_OK && g->slots == 0) rc = gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_create: every pose is held");
+  gp_stream_t st = nullptr;
+  if (rc == GP_OK) rc = gp_vgicp_batch_stream(batch, &st);
+  g->stream = (hipStream_t)st;
+  // one free pose: the dense step (a 6 x 6 system); else the block-sparse one
+  if (rc == GP_OK) rc = g->slots == 1 ? gp_dense_system_create(1, factor_slots.data(), F, st, &g->dense) : gp_sparse_system_create(g->slots, factor_slots.data(), F, ordering, st, &g->sparse);
+  if (rc == GP_OK) rc = g->sparse ? gp_sparse_system_device_solution(g->sparse, &g->x_dev, &g->status_dev) : gp_dense_system_device_solution(g->dense, &g->x_dev, &g->status_dev);
+  const size_t vb = sizeof(double) * 16 * (size_t)num_poses, db = sizeof(double) * 16 * (size_t)F;
+  for (int k = 0; k < 2 && rc == GP_OK; k++) {
+    if ((rc = g->d_values[k].alloc(vb)) || (rc = g->d_deltas[k].alloc(db)) || (rc = g->h_values[k].ensure(vb))) break;
+  }
+  if (rc == GP_OK) rc = g->d_pairs.alloc(sizeof(int) * 2 * (size_t)F);
+  if (rc == GP_OK) rc = g->d_slot.alloc(sizeof(int) * (size_t)num_poses);
+  if (rc == GP_OK) rc = g->d_records.alloc(sizeof(gp_linearized6) * (size_t)F);
+  if (rc == GP_OK) rc = g->h_errors.ensure(sizeof(double) * (size_t)F);
+  if (rc == GP_OK && hipMemcpy(g->d_pairs.ptr, pose_pairs, sizeof(int) * 2 * (size_t)F, hipMemcpyHostToDevice) != hipSuccess) rc = gp::fail(GP_ERROR_HIP, "gp_lm_graph_create: upload of the pairs");
+  if (rc == GP_OK && hipMemcpy(g->d_slot.ptr, g->slot.data(), sizeof(int) * (size_t)num_poses, hipMemcpyHostToDevice) != hipSuccess) rc = gp::fail(GP_ERROR_HIP, "gp_lm_graph_create: upload of the slots");
+  if (rc != GP_OK) {
+    gp_lm_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return GP_OK;
+}
+
+int gp_lm_graph_num_variables(const gp_lm_graph_t* g) { return g ? 6 * g->slots : 0; }
+
+int gp_lm_graph_set_values(gp_lm_graph_t* g, const double* values_host) {
+  if (!g || !values_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_set_values: null");
+  GP_HIP(hipStreamSynchronize(g->stream));  // (a trial in flight still writes the pinned values)
+  g->rigid = true;
+  for (int i = 0; i < g->N; i++) g->rigid = g->rigid && gp::pose_is_rigid(values_host + 16 * (size_t)i);
+  memcpy(g->h_values[g->cur].ptr, values_host, sizeof(double) * 16 * (size_t)g->N);
+  GP_HIP(hipMemcpyAsync(g->d_values[g->cur].ptr, g->h_values[g->cur].ptr, sizeof(double) * 16 * (size_t)g->N, hipMemcpyHostToDevice, g->stream));
+  GP_TRY(launch_poses(g, g->cur, g->cur, false));
+  g->have_values = true, g->linearized = false, g->tried = false;
+  return GP_OK;
+}
+
+int gp_lm_graph_get_values(gp_lm_graph_t* g, double* values_host) {
+  if (!g || !values_host || !g->have_values) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_get_values: no values");
+  memcpy(values_host, g->h_values[g->cur].ptr, sizeof(double) * 16 * (size_t)g->N);
+  return GP_OK;
+}
+
+int gp_lm_graph_linearize(gp_lm_graph_t* g) {
+  if (!g || !g->have_values) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_linearize: set the values first");
+  GP_TRY(gp_vgicp_batch_issue_linearize_dev(g->batch, g->d_deltas[g->cur].as<double>(), g->rigid ? 1 : 0, g->d_records.as<gp_linearized6>()));
+  g->linearized = true, g->tried = false;
+  return GP_OK;
+}
+
+int gp_lm_graph_records(gp_lm_graph_t* g, const gp_linearized6** records_dev, const double** relative_poses_dev) {
+  if (!g) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_records: null graph");
+  if (records_dev) *records_dev = g->d_records.as<gp_linearized6>();
+  if (relative_poses_dev) *relative_poses_dev = g->d_deltas[g->cur].as<double>();
+  return GP_OK;
+}
+
+int gp_lm_graph_try_lambda(gp_lm_graph_t* g, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal, double* x_host, double* b_host, double* c_host,
+                           double* new_error, double* new_values_host) {
+  if (!g || !g->linearized) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_try_lambda: linearize first");
+  const gp_linearized6* rec = g->d_records.as<gp_linearized6>();
+  const int to = 1 - g->cur;
+  if (g->sparse) GP_TRY(gp_sparse_system_issue_step(g->sparse, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr));
+  else GP_TRY(gp_dense_system_issue_step(g->dense, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr));
+  int rc = launch_poses(g, g->cur, to, true);
+  if (rc == GP_OK) rc = gp_vgicp_batch_issue_compute_error_dev(g->batch, g->d_deltas[g->cur].as<double>(), g->d_deltas[to].as<double>(), g->h_errors.as<double>());
+  // (the step is collected whatever happened behind it: its wait is the call's ONE wait)
+  const int rs = g->sparse ? gp_sparse_system_finish_step(g->sparse, x_host, b_host, c_host) : gp_dense_system_finish_step(g->dense, x_host, b_host, c_host);
+  if (rc != GP_OK) return rc;
+  g->tried = rs == GP_OK;
+  if (rs != GP_OK) return rs;  // GP_ERROR_INDETERMINATE: b, c valid; no trial
+  if (new_error) {
+    double e = 0.0;
+    const double* he = g->h_errors.as<double>();
+    for (int f = 0; f < g->F; f++) e += he[f];
+    *new_error = e;
+  }
+  if (new_values_host) memcpy(new_values_host, g->h_values[to].ptr, sizeof(double) * 16 * (size_t)g->N);
+  return GP_OK;
+}
+
+int gp_lm_graph_accept(gp_lm_graph_t* g) {
+  if (!g || !g->tried) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_accept: no successful trial to accept");
+  g->cur = 1 - g->cur;
+  g->tried = false, g->linearized = false;
+  return GP_OK;
+}
+
+int gp_lm_graph_optimize(gp_lm_graph_t* g, const gp_lm_params* params, gp_lm_summary* summary) {
+  if (!g || !g->have_values || !summary) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_optimize: set the values first; summary must not be null");
+  gp_lm_params p;
+  gp_lm_params_default(&p);
+  if (params) p = *params;
+  if (!(p.lambda_initial > 0.0) || !(p.lambda_factor > 1.0) || p.max_iterations < 0 || p.diagonal_damping)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_optimize: lambda_initial > 0, lambda_factor > 1, lambda I damping only (drive gp_lm_graph_try_lambda yourself for the diagonal form)");
+  const size_t n = 6 * (size_t)g->slots;
+  std::vector<double> x(n), b(n);
+  double lam = p.lambda_initial, err = std::numeric_limits<double>::quiet_NaN();
+  *summary = gp_lm_summary{};
+  bool stop = false;
+  for (int it = 0; it < p.max_iterations && !stop; it++) {
+    summary->iterations++;
+    GP_TRY(gp_lm_graph_linearize(g));
+    for (;;) {  // tryLambda until a step is taken or the search ends (levenberg_marquardt_ext.cpp:188-350)
+      summary->inner_iterations++;
+      double c = 0.0, new_err = 0.0;
+      const int rc = gp_lm_graph_try_lambda(g, lam, p.diagonal_damping, p.min_diagonal, p.max_diagonal, x.data(), b.data(), &c, &new_err, nullptr);
+      if (rc != GP_OK && rc != GP_ERROR_INDETERMINATE) return rc;
+      err = c;  // the cost at the linearisation point comes back with the step, solved or not (the GPU factor keeps the linearise's error)
+      bool accepted = false;
+      if (rc == GP_OK) {
+        double bx = 0.0, xx = 0.0;
+        for (size_t i = 0; i < n; i++) bx += b[i] * x[i], xx += x[i] * x[i];
+        const double lin_change = 0.5 * bx + 0.5 * lam * xx;  // old - new linearised error of (A + lambda I) dx = b  (:226-230)
+        if (lin_change >= 0.0) {
+          const double change = err - new_err;
+          accepted = lin_change > std::numeric_limits<double>::epsilon() * err && change / lin_change > p.min_model_fidelity;  // (:262-268)
+          if (std::fabs(change) < p.relative_error_tol * err) stop = true;                                                     // (:271-278)
+        }
+        if (accepted) {
+          const double prev = err;
+          GP_TRY(gp_lm_graph_accept(g));
+          err = new_err;
+          lam /= p.lambda_factor;
+          if (lam < p.lambda_lower_bound) lam = p.lambda_lower_bound;
+          if (std::fabs(prev - err) < p.absolute_error_tol || std::fabs(prev - err) / std::max(prev, 1e-300) < p.relative_error_tol) stop = true;  // optimize() :394-430
+          break;
+        }
+      }
+      if (stop) break;
+      lam *= p.lambda_factor;
+      if (lam >= p.lambda_upper_bound) {
+        stop = true;
+        summary->gave_up = 1;
+        break;
+      }
+    }
+  }
+  summary->final_error = err;
+  summary->final_lambda = lam;
+  return GP_OK;
+}
+
+void gp_lm_params_default(gp_lm_params* p) {
+  if (!p) return;
+  p->lambda_initial = 1e-5, p->lambda_factor = 10.0, p->lambda_upper_bound = 1e5, p->lambda_lower_bound = 0.0;
+  p->relative_error_tol = 1e-5, p->absolute_error_tol = 1e-5, p->min_model_fidelity = 1e-3;
+  p->min_diagonal = 1e-6, p->max_diagonal = 1e32;
+  p->max_iterations = 100, p->diagonal_damping = 0;
+}
+
+}  // extern "C"

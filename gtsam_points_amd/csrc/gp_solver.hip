@@ -263,6 +263,7 @@ struct gp_dense_system {
   gp::DeviceArray d_dests, d_contribs, A, b, c, x, status, prior, Ldiag;
   gp::PinnedArray pinned;  // gp_dense_system_step: x [n] | b [n] | c | status, written by the step's last kernel
   bool built = false;
+  bool step_in_flight = false;  // gp_dense_system_issue_step went out, gp_dense_system_finish_step has not collected it
 };
 
 extern "C" {
@@ -410,8 +411,9 @@ int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_ou
 // build waits once more so that the caller's pageable prior array may go away -- ADVICE r05): gp_dense_system_build, _download(b, c) and _solve
 // without the waits and copies between them; x, b, c and the status arrive through one pinned block written by the last kernel.  Bit-identical to the three calls.
 // b_host / c_host are valid also when the system is indeterminate.
-int gp_dense_system_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
-                         const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
+// the step's device work, queued on the system's stream (a prior diagonal is uploaded by gp_dense_system_build: its own synchronisation)
+int gp_dense_system_issue_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                               const double* prior_diag_host) {
   if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_step: null system");
   const size_t n = (size_t)s->n;
   GP_TRY(s->pinned.ensure(sizeof(double) * (2 * n + 2)));
@@ -422,11 +424,34 @@ int gp_dense_system_step(gp_dense_system_t* s, const gp_linearized6* records_dev
                      (const double*)s->c.as<double>(), (const int*)s->status.as<int>(), s->n, h);
   GP_HIP(hipGetLastError());
   s->built = false;
+  s->step_in_flight = true;
+  return GP_OK;
+}
+
+int gp_dense_system_finish_step(gp_dense_system_t* s, double* x_host, double* b_host, double* c_host) {
+  if (!s || !s->step_in_flight) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_finish_step: no step was issued");
+  const size_t n = (size_t)s->n;
+  const double* h = s->pinned.as<double>();
+  s->step_in_flight = false;
   GP_HIP(hipStreamSynchronize(s->stream));
   if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
   if (c_host) *c_host = h[2 * n];
   if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_dense_system_step: the system is not positive definite (indeterminate linear system)");
   if (x_host) memcpy(x_host, h, sizeof(double) * n);
+  return GP_OK;
+}
+
+int gp_dense_system_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                         const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
+  GP_TRY(gp_dense_system_issue_step(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host));
+  return gp_dense_system_finish_step(s, x_host, b_host, c_host);
+}
+
+// gp_sparse_system_device_solution's dense form
+int gp_dense_system_device_solution(gp_dense_system_t* s, const double** x_dev, const int** status_dev) {
+  if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_device_solution: null system");
+  if (x_dev) *x_dev = s->x.as<double>();
+  if (status_dev) *status_dev = s->status.as<int>();
   return GP_OK;
 }
 

@@ -1336,6 +1336,8 @@ struct gp_sparse_system {
   bool built = false;
   // the one-launch step of small graphs (sparse_small_step_kernel): eligible when factor + index lists fit one compute unit's LDS
   bool small_ok = false, one_launch = false;
+  bool step_in_flight = false;        // gp_sparse_system_issue_step went out, gp_sparse_system_finish_step has not collected it
+  std::vector<double> prior_staged;  // the permuted prior diagonal of the step in flight (source of its H2D copy)
   size_t small_lds_bytes = 0;
   gp::DeviceArray d_small_arena, d_level_ptr;
   gp::SparseSmallView small{};
@@ -1645,56 +1647,72 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
 // i.e. gp_sparse_system_build, gp_sparse_system_download(b, c) and gp_sparse_system_solve without the two waits and the four copies between them.  2 + 2 x levels launches:
 // the assembly (damping applied as the diagonal is written; b, c stored where the host reads them; status cleared), the levels, x (slot order) + status to the host.
 // Bit-identical to the three calls.  b_host / c_host are valid also when the system turns out indeterminate (the optimizer raises lambda and tries again).
-int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
-                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
+// the step's device work, queued on the system's stream: nothing waits here
+int gp_sparse_system_issue_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                                const double* prior_diag_host) {
   if (!s || (!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_step: bad arguments");
   const gp::SparseSymbolic& S = s->sym;
   const size_t n = (size_t)s->n;
   GP_TRY(s->pinned.ensure(sizeof(double) * (2 * n + 2)));
   double* h = s->pinned.as<double>();
-  std::vector<double> permuted;
   gp::SparseStepExtras ex{};
   ex.lambda = lambda, ex.min_diag = min_diagonal, ex.max_diag = max_diagonal, ex.diagonal = diagonal_damping;
   if (prior_diag_host) {
-    permuted.resize(n);
+    s->prior_staged.resize(n);  // (outlives the copy: the next issue waits for the step in flight first -- gp_sparse_system_finish_step)
     for (int k = 0; k < S.P; k++)
-      for (int r = 0; r < 6; r++) permuted[6 * (size_t)k + r] = prior_diag_host[6 * (size_t)S.perm[k] + r];
-    GP_HIP(hipMemcpyAsync(s->prior.ptr, permuted.data(), sizeof(double) * n, hipMemcpyHostToDevice, s->stream));  // (`permuted` outlives it: the call ends with a synchronisation)
+      for (int r = 0; r < 6; r++) s->prior_staged[6 * (size_t)k + r] = prior_diag_host[6 * (size_t)S.perm[k] + r];
+    GP_HIP(hipMemcpyAsync(s->prior.ptr, s->prior_staged.data(), sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
     ex.prior_diag = s->prior.as<double>();
   }
   ex.perm = s->d_perm, ex.b_slots_host = h + n, ex.c_dev = s->c.as<double>(), ex.c_host = h + 2 * n, ex.status = s->status.as<int>();
   ex.num_factors = s->num_factors, ex.num_dests = (int)s->dests.size();
   ex.diag0 = s->diag0.as<double>();
+  hipLaunchKernelGGL(gp::sparse_assemble_kernel<true>, dim3((unsigned)s->dests.size() + 1), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
+                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), ex);
   if (s->one_launch) {
     // small graph: the assembly as it is (one workgroup per block of L across the chip: a gather of 8-byte values, which ONE compute unit's vector memory path takes
     // 40 us for), then factorisation and both substitutions in ONE launch with every operand in the LDS of one compute unit (sparse_small_step_kernel)
-    hipLaunchKernelGGL(gp::sparse_assemble_kernel<true>, dim3((unsigned)s->dests.size() + 1), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
-                       s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), ex);
     gp::SparseSmallView V = s->small;
     V.x_slots_host = h;
     V.status_host = h + 2 * n + 1;
     hipLaunchKernelGGL(gp::sparse_small_step_kernel, dim3(1), dim3(gp::kSmallThreads), s->small_lds_bytes, s->stream, V, s->status.as<int>());
-    GP_HIP(hipGetLastError());
-    s->built = false;
-    GP_HIP(hipStreamSynchronize(s->stream));
-    if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
-    if (c_host) *c_host = h[2 * n];
-    if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_step: the system is not positive definite (indeterminate linear system)");
-    if (x_host) memcpy(x_host, h, sizeof(double) * n);
-    return GP_OK;
+  } else {
+    launch_factor_and_substitutions(s);
+    hipLaunchKernelGGL(gp::sparse_step_end_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), s->d_perm, S.P, s->x_slots.as<double>(), h,
+                       (const int*)s->status.as<int>(), h + 2 * n + 1);
   }
-  hipLaunchKernelGGL(gp::sparse_assemble_kernel<true>, dim3((unsigned)s->dests.size() + 1), dim3(64), 0, s->stream, s->d_dests.as<gp::SparseDest>(),
-                     s->d_contribs.as<gp::SparseContribution>(), reinterpret_cast<const double*>(records_dev), s->L.as<double>(), s->y.as<double>(), ex);
-  launch_factor_and_substitutions(s);
-  hipLaunchKernelGGL(gp::sparse_step_end_kernel, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const double*)s->x.as<double>(), s->d_perm, S.P, s->x_slots.as<double>(), h,
-                     (const int*)s->status.as<int>(), h + 2 * n + 1);
   GP_HIP(hipGetLastError());
   s->built = false;
+  s->step_in_flight = true;
+  return GP_OK;
+}
+
+// waits for the stream and hands over what the step's kernels left in the pinned buffer
+int gp_sparse_system_finish_step(gp_sparse_system_t* s, double* x_host, double* b_host, double* c_host) {
+  if (!s || !s->step_in_flight) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_finish_step: no step was issued");
+  const size_t n = (size_t)s->n;
+  const double* h = s->pinned.as<double>();
+  s->step_in_flight = false;
   GP_HIP(hipStreamSynchronize(s->stream));
   if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
   if (c_host) *c_host = h[2 * n];
   if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_step: the system is not positive definite (indeterminate linear system)");
   if (x_host) memcpy(x_host, h, sizeof(double) * n);
+  return GP_OK;
+}
+
+int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
+  GP_TRY(gp_sparse_system_issue_step(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host));
+  return gp_sparse_system_finish_step(s, x_host, b_host, c_host);
+}
+
+// where an issued step leaves its result ON THE DEVICE: x in slot order and the status word (!= 0: indeterminate, x is not to be used) -- for a consumer queued
+// behind the step on the same stream (the device-side retract of gp_lm.hip)
+int gp_sparse_system_device_solution(gp_sparse_system_t* s, const double** x_slots_dev, const int** status_dev) {
+  if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_device_solution: null system");
+  if (x_slots_dev) *x_slots_dev = s->x_slots.as<double>();
+  if (status_dev) *status_dev = s->status.as<int>();
   return GP_OK;
 }
 

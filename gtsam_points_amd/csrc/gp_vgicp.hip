@@ -1416,6 +1416,37 @@ int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* b, const double* poses_
   return launch_error(b, ps, out_dev);
 }
 
+// the same two passes with the poses ALREADY in device memory (double[F][16] per table, column-major -- what a device-side retract produces, gp_lm.hip): no staging,
+// no H2D copy, nothing for the host to wait on before the next call.  rigid: the caller vouches that every 3x3 block is orthonormal to 1e-9 (what the host-pose entry
+// points test for themselves, poses_are_rigid): the 29-sum kernel + adjoint expansion; 0 = the 92-sum kernel, exact for any 3x3 block.  Any F (a single factor reads its descriptor and pose from the
+// tables like the batch's other members: the in-argument form needs the pose on the host).
+int gp_vgicp_batch_issue_linearize_dev(gp_vgicp_batch_t* b, const double* poses_dev, int rigid, gp_linearized6* out_dev) {
+  if (!b || !poses_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_linearize_dev: null");
+  if (table_is_stale(b)) GP_TRY(build_table(b));
+  if (b->factors.empty()) return GP_OK;
+  PoseSource ps;
+  ps.d_lin = poses_dev;
+  ps.inl.use = 0;
+  return launch_linearize(b, ps, out_dev, rigid != 0);
+}
+
+int gp_vgicp_batch_issue_compute_error_dev(gp_vgicp_batch_t* b, const double* poses_lin_dev, const double* poses_eval_dev, double* out_dev) {
+  if (!b || !poses_lin_dev || !poses_eval_dev || !out_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_compute_error_dev: null");
+  if (table_is_stale(b)) GP_TRY(build_table(b));
+  if (b->factors.empty()) return GP_OK;
+  PoseSource ps;
+  ps.d_lin = poses_lin_dev;
+  ps.d_eval = poses_eval_dev;
+  ps.inl.use = 0;
+  return launch_error(b, ps, out_dev);
+}
+
+int gp_vgicp_batch_stream(const gp_vgicp_batch_t* b, gp_stream_t* out) {
+  if (!b || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_stream: null");
+  *out = (gp_stream_t)b->stream;
+  return GP_OK;
+}
+
 int gp_vgicp_batch_sync(gp_vgicp_batch_t* b) {
   if (!b) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "null batch");
   GP_HIP(hipStreamSynchronize(b->stream));

@@ -224,3 +224,91 @@ class SparseLinearSystemGPU:
             "gp_sparse_system_step",
         )
         return x, b, float(c[0])
+
+
+class LevenbergMarquardtGraphGPU:
+    """The optimizer's trial with the VALUES in device memory (gp_lm_graph_*, csrc/gp_lm.hip): what LevenbergMarquardtOptimizerExt does with its GPU factor set
+    per trial (optimizers/levenberg_marquardt_ext.cpp: linearization_hook_->linearize(values) :352-392, buildDampedSystem + solve + retract + linearization_hook_->error(newValues)
+    :188-350) as linearize() / try_lambda() / accept(), one wait per trial; optimize() runs the reference's loop over them natively.
+
+    factors: IntegratedVGICPFactorGPU objects; pairs[i] = (target pose, source pose) of factor i, poses 0..num_poses-1; fixed: indices of held poses.
+    values are [num_poses, 4, 4] float64 arrays (rigid)."""
+
+    def __init__(self, factors, pairs, num_poses, fixed=(0,), ordering="auto", stream=None):
+        self._lib = _capi.load()
+        self.factors = list(factors)  # (kept alive: the batch holds their handles)
+        F = len(self.factors)
+        self.pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        if len(self.pairs) != F:
+            raise ValueError(f"{F} factors, {len(self.pairs)} pose pairs")
+        self.num_poses = int(num_poses)
+        held = np.zeros(self.num_poses, dtype=np.uint8)
+        held[list(fixed)] = 1
+        self._batch, self._h = C.c_void_p(), C.c_void_p()
+        arr = (C.c_void_p * F)(*[f._h.value for f in self.factors])
+        _capi.check(self._lib.gp_vgicp_batch_create(arr, F, stream, C.byref(self._batch)), "gp_vgicp_batch_create")
+        try:
+            _capi.check(self._lib.gp_lm_graph_create(self._batch, self.pairs.ctypes.data, self.num_poses, held.ctypes.data, SparseLinearSystemGPU.ORDERINGS[ordering], C.byref(self._h)), "gp_lm_graph_create")
+        except Exception:
+            self._lib.gp_vgicp_batch_destroy(self._batch)
+            self._batch = None
+            raise
+        self.n = self._lib.gp_lm_graph_num_variables(self._h)
+        self._x, self._b, self._c, self._e = np.zeros(self.n), np.zeros(self.n), np.zeros(1), np.zeros(1)
+        self._v = np.zeros((self.num_poses, 16))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gp_lm_graph_destroy(self._h)
+            self._h = None
+        if getattr(self, "_batch", None):
+            self._lib.gp_vgicp_batch_destroy(self._batch)
+            self._batch = None
+
+    __del__ = close
+
+    @staticmethod
+    def _to16(values):
+        v = np.asarray(values, dtype=np.float64)
+        return np.ascontiguousarray(v.transpose(0, 2, 1)).reshape(len(v), 16)
+
+    def set_values(self, values):
+        v = self._to16(values)
+        if v.shape != (self.num_poses, 16):
+            raise ValueError(f"values must be [{self.num_poses}, 4, 4]")
+        _capi.check(self._lib.gp_lm_graph_set_values(self._h, v.ctypes.data), "gp_lm_graph_set_values")
+
+    def values(self):
+        _capi.check(self._lib.gp_lm_graph_get_values(self._h, self._v.ctypes.data), "gp_lm_graph_get_values")
+        return self._v.reshape(self.num_poses, 4, 4).transpose(0, 2, 1).copy()
+
+    def linearize(self):
+        """asynchronous: records at the current values stay in HBM"""
+        _capi.check(self._lib.gp_lm_graph_linearize(self._h), "gp_lm_graph_linearize")
+
+    def sync(self):
+        _capi.check(self._lib.gp_vgicp_batch_sync(self._batch), "gp_vgicp_batch_sync")
+
+    def try_lambda(self, lam, diagonal=False, min_diagonal=1e-6, max_diagonal=1e32, want_values=False):
+        """-> (dx, b, cost at the linearisation point, cost at the trial values[, trial values]); GPError (code 5) on an indeterminate system.
+        The arrays are the object's own buffers: valid until the next call."""
+        _capi.check(self._lib.gp_lm_graph_try_lambda(self._h, float(lam), int(bool(diagonal)), float(min_diagonal), float(max_diagonal), self._x.ctypes.data, self._b.ctypes.data,
+                                                     self._c.ctypes.data, self._e.ctypes.data, self._v.ctypes.data if want_values else None), "gp_lm_graph_try_lambda")
+        out = (self._x, self._b, float(self._c[0]), float(self._e[0]))
+        return out + (self._v.reshape(self.num_poses, 4, 4).transpose(0, 2, 1).copy(),) if want_values else out
+
+    def accept(self):
+        _capi.check(self._lib.gp_lm_graph_accept(self._h), "gp_lm_graph_accept")
+
+    def optimize(self, values=None, **params):
+        """the reference's loop, natively; params: fields of gp_lm_params (GTSAM's defaults otherwise).  -> (values, summary dict)"""
+        if values is not None:
+            self.set_values(values)
+        p, s = _capi.LmParams(), _capi.LmSummary()
+        self._lib.gp_lm_params_default(C.byref(p))
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown parameter {k}")
+            setattr(p, k, v)
+        _capi.check(self._lib.gp_lm_graph_optimize(self._h, C.byref(p), C.byref(s)), "gp_lm_graph_optimize")
+        return self.values(), {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved_"}

@@ -291,6 +291,12 @@ int64_t gp_vgicp_batch_actual_bytes(gp_vgicp_batch_t* batch);
 int gp_vgicp_batch_issue_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_dev);
 int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* batch, const double* poses_lin_host, const double* poses_eval_host, double* out_dev);
 int gp_vgicp_batch_sync(gp_vgicp_batch_t* batch);
+/* the two asynchronous passes with the pose tables ALREADY in device memory (double[F][16] each, column-major: what the device-side retract of gp_lm_graph_* produces):
+ * nothing is staged or copied, the host has nothing to wait for.  Same kernels, same records.  rigid != 0: the caller vouches that every 3x3 block is orthonormal to
+ * 1e-9 -- the test the host-pose entry points make themselves to choose between the 29-sum kernel + adjoint expansion and the 92-sum kernel that is exact for any block */
+int gp_vgicp_batch_issue_linearize_dev(gp_vgicp_batch_t* batch, const double* poses_dev, int rigid, gp_linearized6* out_dev);
+int gp_vgicp_batch_issue_compute_error_dev(gp_vgicp_batch_t* batch, const double* poses_lin_dev, const double* poses_eval_dev, double* out_dev);
+int gp_vgicp_batch_stream(const gp_vgicp_batch_t* batch, gp_stream_t* out); /* the stream the batch was created on */
 /* synchronous: upload poses, compute, download F records into out_host */
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_host);
 /* the same pass without the copy into a caller array: *out_view points at the F records where the kernels stored them (the
@@ -431,6 +437,14 @@ int gp_dense_system_solve(gp_dense_system_t* sys, double* x_host, double* x_dev)
 int gp_dense_system_step(gp_dense_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 
+/* gp_dense_system_step in two halves: issue queues the step's kernels on the system's stream and returns; finish waits for the stream and hands over x / b / c
+ * (GP_ERROR_INDETERMINATE as the one call).  Work queued on the same stream between the two -- a consumer of the solution where the step leaves it ON THE DEVICE
+ * (gp_dense_system_device_solution: x [n] in slot order, the status word: != 0 = indeterminate, x is not to be used) -- shares the step's one wait (gp_lm_graph_try_lambda). */
+int gp_dense_system_issue_step(gp_dense_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                               const double* prior_diag_host);
+int gp_dense_system_finish_step(gp_dense_system_t* sys, double* x_host, double* b_host, double* c_host);
+int gp_dense_system_device_solution(gp_dense_system_t* sys, const double** x_dev, const int** status_dev);
+
 /* ---- the same step, block-sparse: SparseLinearSystemBuilder<6> + SparseLinearSolver ----
  * SparseLinearSystemBuilder<BLOCK_SIZE> (include/gtsam_points/optimizers/linear_system_builder.hpp:41-72): A as a lower-triangular
  *   block-sparse matrix in a given ordering, b, c;  SparseLinearSolver::solve(A, b) (optimizers/linear_solver.hpp:24-29), called from
@@ -465,9 +479,56 @@ int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_de
 int gp_sparse_system_step(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                           const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* sys, int enable);
+/* gp_sparse_system_step in two halves, as gp_dense_system_issue_step / _finish_step / _device_solution (prior_diag_host is copied by issue: the caller's array is free on return) */
+int gp_sparse_system_issue_step(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                                const double* prior_diag_host);
+int gp_sparse_system_finish_step(gp_sparse_system_t* sys, double* x_host, double* b_host, double* c_host);
+int gp_sparse_system_device_solution(gp_sparse_system_t* sys, const double** x_slots_dev, const int** status_dev);
 /* measurement hook: thread 0 of sparse_small_step_kernel stamps its phases (s_memtime) into dev_buffer (64 uint64: [0] start, [1] lists and system in LDS, [2] factored,
  * [3] substituted, [4] end, [8 + 4 r + 0..3] round r < 14 of the first level: start / gathered / diagonal block done / blocks below done); NULL = off */
 int gp_debug_sparse_step_trace(gp_sparse_system_t* sys, unsigned long long* dev_buffer);
+/* ---- one Levenberg-Marquardt trial without the host in the middle: the values live beside the records (gp_lm.hip) ----
+ * The reference's optimizer (optimizers/levenberg_marquardt_ext.cpp) hands `values` to its GPU factor set twice per trial -- linearization_hook_->linearize(values)
+ * (iterate(), :352-392 -> cuda/nonlinear_factor_set_gpu.cpp:64-101) and linearization_hook_->error(newValues) (tryLambda(), :245 -> :103-139) -- and retracts on the host
+ * between them (:239).  A gp_lm_graph keeps the N poses in device memory: batch member i is the pairwise factor between poses pose_pairs[2 i] (target) and
+ * pose_pairs[2 i + 1] (source) and is evaluated at target^-1 source (integrated_matching_cost_factor.cpp:28-31); pose_fixed[i] != 0 holds pose i (NULL = none held:
+ * the gauge is then the caller's problem, the step reports GP_ERROR_INDETERMINATE); the free poses take the variable slots 0, 1, ... in pose order.  The graph builds
+ * its own damped system on the batch's stream (one free pose: the dense 6 x 6 step; else block-sparse in `ordering`, gp_sparse_system_create) and does NOT own the batch.
+ *   set_values   values_host = double[N][16], column-major 4x4 (all orthonormal to 1e-9: the rigid kernels serve the graph from then on; else the general ones);  get_values: the current values (after accept: the accepted trial's, as the device computed them)
+ *   linearize    asynchronous: the batch's linearise at the current values' relative poses -> records in HBM
+ *   try_lambda   damped step + retract (Pose3::retract: T Expmap(xi), xi = (omega, v) = the step's six entries of the pose's slot) + the batch's error evaluation on the
+ *                linearisation's correspondences at the trial values: queued back to back, ONE wait.  x_host [6 slots], b_host [6 slots], c_host (the cost at the
+ *                linearisation point), new_error (the cost at the trial values), new_values_host [N][16]; any may be NULL.  GP_ERROR_INDETERMINATE: b / c valid, no trial.
+ *   accept       the last successful trial's values become the current ones (a swap: their relative poses are already in place); linearize again before the next trial
+ *   optimize     the reference's loop over the three: GTSAM's LevenbergMarquardtParams defaults in gp_lm_params_default; lambda I damping only (diagonalDamping = false) */
+typedef struct gp_lm_graph gp_lm_graph_t;
+typedef struct gp_lm_params {
+  double lambda_initial, lambda_factor, lambda_upper_bound, lambda_lower_bound; /* 1e-5, 10, 1e5, 0 */
+  double relative_error_tol, absolute_error_tol, min_model_fidelity;            /* 1e-5, 1e-5, 1e-3 */
+  double min_diagonal, max_diagonal;                                            /* 1e-6, 1e32 (diagonal damping only) */
+  int max_iterations, diagonal_damping;                                         /* 100, 0 */
+} gp_lm_params;
+typedef struct gp_lm_summary {
+  int iterations, inner_iterations; /* linearisations, trials */
+  int gave_up;                      /* lambda reached lambda_upper_bound */
+  int reserved_;
+  double final_error, final_lambda;
+} gp_lm_summary;
+void gp_lm_params_default(gp_lm_params* params);
+int gp_lm_graph_create(gp_vgicp_batch_t* batch, const int* pose_pairs, int num_poses, const unsigned char* pose_fixed, int ordering, gp_lm_graph_t** out);
+int gp_lm_graph_destroy(gp_lm_graph_t* graph);
+int gp_lm_graph_num_variables(const gp_lm_graph_t* graph); /* 6 x free poses */
+int gp_lm_graph_set_values(gp_lm_graph_t* graph, const double* values_host);
+int gp_lm_graph_get_values(gp_lm_graph_t* graph, double* values_host);
+int gp_lm_graph_linearize(gp_lm_graph_t* graph);
+int gp_lm_graph_try_lambda(gp_lm_graph_t* graph, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal, double* x_host, double* b_host, double* c_host,
+                           double* new_error, double* new_values_host);
+int gp_lm_graph_accept(gp_lm_graph_t* graph);
+int gp_lm_graph_optimize(gp_lm_graph_t* graph, const gp_lm_params* params, gp_lm_summary* summary);
+/* for checkers: the records of the last linearise and the relative poses of the current values, where they lie in device memory (valid until the graph is destroyed;
+ * contents as of the work queued so far on the batch's stream) */
+int gp_lm_graph_records(gp_lm_graph_t* graph, const gp_linearized6** records_dev, const double** relative_poses_dev);
+
 /* the symbolic phase alone (pure host code, no device needed): elimination order perm[k] = slot eliminated k-th, elimination tree
  * parent[k] (-1 = root), block counts and the schedule; any output pointer may be NULL */
 int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, int ordering, int* perm_out, int* parent_out, int64_t* nnz_a_blocks, int64_t* nnz_l_blocks,
