@@ -321,7 +321,7 @@ def pick_cpu_threads(avail, make, run, reps=3):
     return next(c for c, t in timed if t <= 1.15 * fastest)  # (ascending counts: of those within 15 % of the fastest, the one with the fewest threads -- the steadiest)
 
 
-def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, truth, values0, sptr, device, cores, kind, cpu_max_iterations=30, solvers=("device", "host")):
+def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, truth, values0, sptr, device, cores, kind, cpu_max_iterations=30, solvers=("device", "host", "trial", "native")):
     """configs.lm_*: the reference's LM cadence (bench_lm.py; levenberg_marquardt_ext.cpp:107-143,188-392) over a graph of VGICP factors -- per iteration host to host, by
     phase, on the GPU path (batched linearise, records stay in HBM, block-sparse LL^T on the device; and the same with a host-side numpy solve) and over the checker's CPU
     factors (the reference's own IntegratedVGICPFactor when oracle/_ref is built) as cpu_baseline.  truth None: the CPU run's result is the reference the GPU run is held to.
@@ -338,7 +338,7 @@ def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, tru
                "lambda 1e-5, x10 / /10, minModelFidelity 1e-3, relativeErrorTol 1e-5 (GTSAM defaults; levenberg_marquardt_ext.cpp:188-392)",
                gate="max over poses, relative to the fixed pose: rotation < 0.015 rad, translation < 0.15 m (test_matching_cost_factors.cpp:227) against "
                + ("the generator's ground truth" if truth is not None else "the CPU run's result (real scans: no ground truth)"))
-    for solver in solvers:
+    for solver in [x for x in solvers if x not in ("trial", "native")]:
         gg = bench_lm.GpuGraph(gpa, gpu_factors, pairs, num_poses, fixed=0, solver=solver, stream=sptr, device=device)
         bench_lm.run_lm(gg, values0, max_iterations=30)  # warm-up: first-use table builds, allocations
         best = None
@@ -357,9 +357,32 @@ def run_lm_config(workload, gpa, gpu_factors, cpu_factors, pairs, num_poses, tru
             obj["pose_vs_cpu_run"] = dict(zip(("rotation_rad", "translation_m"), [round(max(x), 6) for x in zip(*[bench_lm.pose_error(best["values"][k], res_cpu["values"][k]) for k in range(num_poses)])]))
         gg.close()
         out[{"device": "gpu_device_solve", "device-three-calls": "gpu_device_solve_three_calls", "host": "gpu_host_solve"}[solver]] = obj
+    if "trial" in solvers or "native" in solvers:
+        # round 6: the values in device memory (gp_lm_graph_*): linearise | damped step + retract + error evaluation behind ONE wait
+        tg = bench_lm.GpuTrialGraph(gpa, gpu_factors, pairs, num_poses, fixed=0, stream=sptr)
+        bench_lm.run_lm(tg, values0, max_iterations=30)
+        if "trial" in solvers:
+            best = min((bench_lm.run_lm(tg, values0, max_iterations=30) for _ in range(3)), key=lambda r: r["seconds"])
+            obj = bench_lm.summarize(best, tg, gate_ref, "gpu, trial on the device (gp_lm_graph_linearize / _try_lambda / _accept driven by the interpreter)")
+            tg.sync_phases = True
+            split = bench_lm.summarize(bench_lm.run_lm(tg, values0, max_iterations=30), tg, gate_ref, "split")
+            tg.sync_phases = False
+            obj["ms_per_iteration_by_phase"] = split["ms_per_iteration_by_phase"]
+            obj["phase_note"] = "solve = damped step + retract + error evaluation at the trial values, one wait (the error phase is inside it); linearize = its issue + the wait the split run adds"
+            out["gpu_device_trial"] = obj
+        if "native" in solvers:
+            tg.native_loop(values0, max_iterations=30)
+            best = min((tg.native_loop(values0, max_iterations=30) for _ in range(5)), key=lambda r: r["seconds"])
+            obj = bench_lm.summarize(best, tg, gate_ref, "gpu, the library's own loop (gp_lm_graph_optimize: the reference's cadence over the same three calls, no interpreter inside)")
+            obj.pop("ms_per_iteration_by_phase", None)
+            obj.pop("dominant_phase", None)
+            if not bounded:
+                obj["pose_vs_cpu_run"] = dict(zip(("rotation_rad", "translation_m"), [round(max(x), 6) for x in zip(*[bench_lm.pose_error(best["values"][k], res_cpu["values"][k]) for k in range(num_poses)])]))
+            out["gpu_native_loop"] = obj
+        tg.close()
     cpu.update(cores=cores, kind=kind, sample=(f"the first {cpu_max_iterations} iterations of the loop" if bounded else "the whole loop once") + f": every factor linearised / evaluated in turn with {cores} threads (the count a probe chose, pick_cpu_threads), numpy dense solve")
     out["cpu_baseline"] = cpu
-    out["speedup_per_iteration"] = round(cpu["ms_per_iteration"] / out["gpu_device_solve"]["ms_per_iteration"], 1)
+    out["speedup_per_iteration"] = round(cpu["ms_per_iteration"] / out["gpu_native_loop" if "gpu_native_loop" in out else "gpu_device_solve"]["ms_per_iteration"], 1)
     return out
 
 
@@ -552,7 +575,7 @@ def run_configs(args, lib, gpa, _capi, synthetic, torch, device, stream, want=No
                 out["lm_c3"] = run_lm_config("BASELINE configs[2] as an optimisation: the 256-factor / 64-submap graph from ground truth o Expmap(U(-0.1, 0.1)^6) (seed 8191), pose 0 held",
                                              gpa, factors, cpu_factors, g["pairs"], n_sub, truth, v0, sptr, device, cores, kind,
                                              cpu_max_iterations=30 if getattr(args, "lm_full_cpu", False) else 2,
-                                             solvers=("device", "device-three-calls", "host") if getattr(args, "lm_full_cpu", False) else ("device", "host"))
+                                             solvers=("device", "device-three-calls", "host", "trial", "native") if getattr(args, "lm_full_cpu", False) else ("device", "host", "trial", "native"))
                 del cpu_factors
             except Exception as exc:
                 out["lm_c3"] = dict(error=f"{type(exc).__name__}: {exc}")

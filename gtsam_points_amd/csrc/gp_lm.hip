@@ -11,7 +11,9 @@
 //   gp_lm_graph_try_lambda   the damped step (gp_sparse_system_issue_step / gp_dense_system_issue_step), then ONE small kernel that retracts the current values by
 //                            the step's x where the step left it (Pose3::retract = T Expmap(xi), (omega, v) order) and writes the trial values and every factor's
 //                            relative pose, then the batch's error evaluation on the linearisation's correspondences at those (gp_vgicp_batch_issue_compute_error_dev):
-//                            four-five launches queued back to back, ONE wait; x, b, c, the trial's error and the trial values reach the host through pinned memory
+//                            launches queued back to back, ONE wait -- a poll of the error evaluation's completion words, not hipStreamSynchronize -- with the
+//                            linearise at the trial values already queued behind them (speculation: an accepted step finds it running); x, b, c, the trial's
+//                            error and the trial values reach the host through pinned memory
 //   gp_lm_graph_accept       the trial values become the current ones (their relative poses are already in place for the next linearise): a pointer swap
 //   gp_lm_graph_optimize     the reference's cadence over those three (tryLambda's tests :262-292, decreaseLambda / increaseLambda with the GTSAM defaults)
 // Pose arithmetic on the device = the formulas of gtsam::Pose3 (Expmap with the closed-form V, compose, inverse() * other) in f64; the host-side harness
@@ -134,11 +136,17 @@ struct gp_lm_graph {
   hipStream_t stream = nullptr;
   int F = 0, N = 0, slots = 0;
   std::vector<int> slot;
-  gp::DeviceArray d_pairs, d_slot, d_values[2], d_deltas[2], d_records;
-  gp::PinnedArray h_values[2], h_errors;
+  gp::DeviceArray d_pairs, d_slot, d_values[2], d_deltas[2], d_records[2];
+  gp::PinnedArray h_values[2];
   int cur = 0;                 // d_values[cur] / d_deltas[cur] / h_values[cur] are the current values; [1 - cur] the last trial's
   bool have_values = false, linearized = false, tried = false;
   bool rigid = true;           // every value handed to set_values was orthonormal to 1e-9 (retracts keep them so): the rigid kernels, as the host-pose entry points would choose
+  // speculation: behind a trial's error evaluation the linearise AT THE TRIAL VALUES is queued into the other record buffer, so that an accepted step -- the common
+  // case -- finds its linearisation already running while the host still decides; a rejected one leaves the records of the linearisation point untouched for the next
+  // lambda (the queued linearise is 50 us of device time thrown away).  Same kernels on the same operands either way: results do not depend on it.
+  int rec = 0;                 // d_records[rec]: the records of the current linearisation point
+  bool speculate = true, spec_pending = false /* [1 - rec] is being written at the last trial's values */, spec_valid = false /* [rec] already holds the current values' records */;
+  std::vector<double> errors;
   const double* x_dev = nullptr;
   const int* status_dev = nullptr;
 };
@@ -205,8 +213,8 @@ int gp_lm_graph_create(gp_vgicp_batch_t* batch, const int* pose_pairs, int num_p
   }
   if (rc == GP_OK) rc = g->d_pairs.alloc(sizeof(int) * 2 * (size_t)F);
   if (rc == GP_OK) rc = g->d_slot.alloc(sizeof(int) * (size_t)num_poses);
-  if (rc == GP_OK) rc = g->d_records.alloc(sizeof(gp_linearized6) * (size_t)F);
-  if (rc == GP_OK) rc = g->h_errors.ensure(sizeof(double) * (size_t)F);
+  for (int k = 0; k < 2 && rc == GP_OK; k++) rc = g->d_records[k].alloc(sizeof(gp_linearized6) * (size_t)F);
+  g->errors.assign((size_t)F, 0.0);
   if (rc == GP_OK && hipMemcpy(g->d_pairs.ptr, pose_pairs, sizeof(int) * 2 * (size_t)F, hipMemcpyHostToDevice) != hipSuccess) rc = gp::fail(GP_ERROR_HIP, "gp_lm_graph_create: upload of the pairs");
   if (rc == GP_OK && hipMemcpy(g->d_slot.ptr, g->slot.data(), sizeof(int) * (size_t)num_poses, hipMemcpyHostToDevice) != hipSuccess) rc = gp::fail(GP_ERROR_HIP, "gp_lm_graph_create: upload of the slots");
   if (rc != GP_OK) {
@@ -215,6 +223,14 @@ int gp_lm_graph_create(gp_vgicp_batch_t* batch, const int* pose_pairs, int num_p
   }
   *out = g;
   return GP_OK;
+}
+
+// 0: no linearise is queued ahead of the host's decision (measurement / A-B; results are the same bits either way).  Returns the previous setting.
+int gp_lm_graph_set_speculation(gp_lm_graph_t* g, int enable) {
+  if (!g) return 0;
+  const int was = g->speculate ? 1 : 0;
+  g->speculate = enable != 0;
+  return was;
 }
 
 int gp_lm_graph_num_variables(const gp_lm_graph_t* g) { return g ? 6 * g->slots : 0; }
@@ -227,7 +243,7 @@ int gp_lm_graph_set_values(gp_lm_graph_t* g, const double* values_host) {
   memcpy(g->h_values[g->cur].ptr, values_host, sizeof(double) * 16 * (size_t)g->N);
   GP_HIP(hipMemcpyAsync(g->d_values[g->cur].ptr, g->h_values[g->cur].ptr, sizeof(double) * 16 * (size_t)g->N, hipMemcpyHostToDevice, g->stream));
   GP_TRY(launch_poses(g, g->cur, g->cur, false));
-  g->have_values = true, g->linearized = false, g->tried = false;
+  g->have_values = true, g->linearized = false, g->tried = false, g->spec_pending = false, g->spec_valid = false;
   return GP_OK;
 }
 
@@ -239,14 +255,16 @@ int gp_lm_graph_get_values(gp_lm_graph_t* g, double* values_host) {
 
 int gp_lm_graph_linearize(gp_lm_graph_t* g) {
   if (!g || !g->have_values) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_linearize: set the values first");
-  GP_TRY(gp_vgicp_batch_issue_linearize_dev(g->batch, g->d_deltas[g->cur].as<double>(), g->rigid ? 1 : 0, g->d_records.as<gp_linearized6>()));
+  if (!g->spec_valid)  // (else: queued behind the accepted trial's error evaluation)
+    GP_TRY(gp_vgicp_batch_issue_linearize_dev(g->batch, g->d_deltas[g->cur].as<double>(), g->rigid ? 1 : 0, g->d_records[g->rec].as<gp_linearized6>()));
+  g->spec_valid = false;
   g->linearized = true, g->tried = false;
   return GP_OK;
 }
 
 int gp_lm_graph_records(gp_lm_graph_t* g, const gp_linearized6** records_dev, const double** relative_poses_dev) {
   if (!g) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_records: null graph");
-  if (records_dev) *records_dev = g->d_records.as<gp_linearized6>();
+  if (records_dev) *records_dev = g->d_records[g->rec].as<gp_linearized6>();
   if (relative_poses_dev) *relative_poses_dev = g->d_deltas[g->cur].as<double>();
   return GP_OK;
 }
@@ -254,21 +272,32 @@ int gp_lm_graph_records(gp_lm_graph_t* g, const gp_linearized6** records_dev, co
 int gp_lm_graph_try_lambda(gp_lm_graph_t* g, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal, double* x_host, double* b_host, double* c_host,
                            double* new_error, double* new_values_host) {
   if (!g || !g->linearized) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_try_lambda: linearize first");
-  const gp_linearized6* rec = g->d_records.as<gp_linearized6>();
+  const gp_linearized6* rec = g->d_records[g->rec].as<gp_linearized6>();
   const int to = 1 - g->cur;
+  g->spec_pending = false, g->tried = false;
   if (g->sparse) GP_TRY(gp_sparse_system_issue_step(g->sparse, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr));
   else GP_TRY(gp_dense_system_issue_step(g->dense, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr));
   int rc = launch_poses(g, g->cur, to, true);
-  if (rc == GP_OK) rc = gp_vgicp_batch_issue_compute_error_dev(g->batch, g->d_deltas[g->cur].as<double>(), g->d_deltas[to].as<double>(), g->h_errors.as<double>());
-  // (the step is collected whatever happened behind it: its wait is the call's ONE wait)
-  const int rs = g->sparse ? gp_sparse_system_finish_step(g->sparse, x_host, b_host, c_host) : gp_dense_system_finish_step(g->dense, x_host, b_host, c_host);
+  if (rc == GP_OK) rc = gp_vgicp_batch_issue_compute_error_dev_begin(g->batch, g->d_deltas[g->cur].as<double>(), g->d_deltas[to].as<double>());
+  if (rc != GP_OK) {  // the step went out: collect it (its own wait) before the error is reported
+    if (g->sparse) (void)gp_sparse_system_finish_step(g->sparse, nullptr, nullptr, nullptr);
+    else (void)gp_dense_system_finish_step(g->dense, nullptr, nullptr, nullptr);
+    return rc;
+  }
+  bool spec = false;
+  if (g->speculate) spec = gp_vgicp_batch_issue_linearize_dev(g->batch, g->d_deltas[to].as<double>(), g->rigid ? 1 : 0, g->d_records[1 - g->rec].as<gp_linearized6>()) == GP_OK;
+  // the call's ONE wait: the completion words of the error evaluation (everything in front of it on the stream -- the step, the trial values -- is then complete and
+  // its pinned results are readable; the speculative linearise behind it is not waited for)
+  rc = gp_vgicp_batch_compute_error_dev_end(g->batch, g->errors.data());
+  const int rs = g->sparse ? (rc == GP_OK ? gp_sparse_system_collect_step(g->sparse, x_host, b_host, c_host) : gp_sparse_system_finish_step(g->sparse, x_host, b_host, c_host))
+                           : (rc == GP_OK ? gp_dense_system_collect_step(g->dense, x_host, b_host, c_host) : gp_dense_system_finish_step(g->dense, x_host, b_host, c_host));
   if (rc != GP_OK) return rc;
-  g->tried = rs == GP_OK;
-  if (rs != GP_OK) return rs;  // GP_ERROR_INDETERMINATE: b, c valid; no trial
+  if (rs != GP_OK) return rs;  // GP_ERROR_INDETERMINATE: b, c valid; no trial (the kernel behind the step left the trial values = the current ones)
+  g->tried = true;
+  g->spec_pending = spec;
   if (new_error) {
     double e = 0.0;
-    const double* he = g->h_errors.as<double>();
-    for (int f = 0; f < g->F; f++) e += he[f];
+    for (int f = 0; f < g->F; f++) e += g->errors[(size_t)f];
     *new_error = e;
   }
   if (new_values_host) memcpy(new_values_host, g->h_values[to].ptr, sizeof(double) * 16 * (size_t)g->N);
@@ -278,6 +307,8 @@ int gp_lm_graph_try_lambda(gp_lm_graph_t* g, double lambda, int diagonal_damping
 int gp_lm_graph_accept(gp_lm_graph_t* g) {
   if (!g || !g->tried) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_lm_graph_accept: no successful trial to accept");
   g->cur = 1 - g->cur;
+  if (g->spec_pending) g->rec = 1 - g->rec, g->spec_valid = true;
+  g->spec_pending = false;
   g->tried = false, g->linearized = false;
   return GP_OK;
 }

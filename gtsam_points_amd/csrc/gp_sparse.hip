@@ -1688,18 +1688,22 @@ int gp_sparse_system_issue_step(gp_sparse_system_t* s, const gp_linearized6* rec
 }
 
 // waits for the stream and hands over what the step's kernels left in the pinned buffer
-int gp_sparse_system_finish_step(gp_sparse_system_t* s, double* x_host, double* b_host, double* c_host) {
+static int finish_step(gp_sparse_system_t* s, double* x_host, double* b_host, double* c_host, bool wait) {
   if (!s || !s->step_in_flight) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_finish_step: no step was issued");
   const size_t n = (size_t)s->n;
   const double* h = s->pinned.as<double>();
   s->step_in_flight = false;
-  GP_HIP(hipStreamSynchronize(s->stream));
+  if (wait) GP_HIP(hipStreamSynchronize(s->stream));
   if (b_host) memcpy(b_host, h + n, sizeof(double) * n);
   if (c_host) *c_host = h[2 * n];
   if (h[2 * n + 1] != 0.0) return gp::fail(GP_ERROR_INDETERMINATE, "gp_sparse_system_step: the system is not positive definite (indeterminate linear system)");
   if (x_host) memcpy(x_host, h, sizeof(double) * n);
   return GP_OK;
 }
+
+int gp_sparse_system_finish_step(gp_sparse_system_t* s, double* x_host, double* b_host, double* c_host) { return finish_step(s, x_host, b_host, c_host, true); }
+// ... for a caller that has SEEN the stream pass the step (a completion word of work it queued behind the step on the same stream): no wait of its own
+int gp_sparse_system_collect_step(gp_sparse_system_t* s, double* x_host, double* b_host, double* c_host) { return finish_step(s, x_host, b_host, c_host, false); }
 
 int gp_sparse_system_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                           const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {

@@ -1441,6 +1441,37 @@ int gp_vgicp_batch_issue_compute_error_dev(gp_vgicp_batch_t* b, const double* po
   return launch_error(b, ps, out_dev);
 }
 
+// ... and the error evaluation as a SYNCHRONOUS call: the finalize kernel hands the F sums and a completion word each to the host (pinned), and the call polls the words
+// (wait_done) instead of going through hipStreamSynchronize -- everything queued in front of it on the batch's stream is complete when it returns, whatever else was
+// queued BEHIND it in the meantime is not waited for (gp_lm.hip queues the next linearise there)
+int gp_vgicp_batch_compute_error_dev(gp_vgicp_batch_t* b, const double* poses_lin_dev, const double* poses_eval_dev, double* out_host) {
+  if (!b || !poses_lin_dev || !poses_eval_dev || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_compute_error_dev: null");
+  GP_TRY(gp_vgicp_batch_issue_compute_error_dev_begin(b, poses_lin_dev, poses_eval_dev));
+  return gp_vgicp_batch_compute_error_dev_end(b, out_host);
+}
+
+// the two halves of the call above: begin launches (and returns the moment the kernels are queued), end polls and copies.  One begin at a time per batch.
+int gp_vgicp_batch_issue_compute_error_dev_begin(gp_vgicp_batch_t* b, const double* poses_lin_dev, const double* poses_eval_dev) {
+  if (!b || !poses_lin_dev || !poses_eval_dev) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_issue_compute_error_dev_begin: null");
+  if (table_is_stale(b)) GP_TRY(build_table(b));
+  if (b->factors.empty()) return GP_OK;
+  PoseSource ps;
+  ps.d_lin = poses_lin_dev;
+  ps.d_eval = poses_eval_dev;
+  ps.inl.use = 0;
+  const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+  return launch_error(b, ps, static_cast<double*>(b->h_out_dev), done);
+}
+
+int gp_vgicp_batch_compute_error_dev_end(gp_vgicp_batch_t* b, double* out_host) {
+  if (!b || !out_host) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_compute_error_dev_end: null");
+  const size_t F = b->factors.size();
+  if (F == 0) return GP_OK;
+  GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, b->seq, b->stream, spin_budget_us(b) + 400));  // (+ the damped step queued in front of it)
+  memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
+  return GP_OK;
+}
+
 int gp_vgicp_batch_stream(const gp_vgicp_batch_t* b, gp_stream_t* out) {
   if (!b || !out) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_vgicp_batch_stream: null");
   *out = (gp_stream_t)b->stream;

@@ -300,6 +300,10 @@ class LevenbergMarquardtGraphGPU:
     def accept(self):
         _capi.check(self._lib.gp_lm_graph_accept(self._h), "gp_lm_graph_accept")
 
+    def set_speculation(self, enable):
+        """queue the linearise at the trial values behind each trial (default on; same results either way) -> previous setting"""
+        return bool(self._lib.gp_lm_graph_set_speculation(self._h, int(bool(enable))))
+
     def optimize(self, values=None, **params):
         """the reference's loop, natively; params: fields of gp_lm_params (GTSAM's defaults otherwise).  -> (values, summary dict)"""
         if values is not None:

@@ -296,6 +296,11 @@ int gp_vgicp_batch_sync(gp_vgicp_batch_t* batch);
  * 1e-9 -- the test the host-pose entry points make themselves to choose between the 29-sum kernel + adjoint expansion and the 92-sum kernel that is exact for any block */
 int gp_vgicp_batch_issue_linearize_dev(gp_vgicp_batch_t* batch, const double* poses_dev, int rigid, gp_linearized6* out_dev);
 int gp_vgicp_batch_issue_compute_error_dev(gp_vgicp_batch_t* batch, const double* poses_lin_dev, const double* poses_eval_dev, double* out_dev);
+/* ... and the error evaluation as a synchronous call that POLLS the finalize kernel's completion words (pinned) instead of synchronising the stream: on return everything
+ * queued in front of it on the batch's stream is complete, work queued behind it meanwhile is not waited for.  _begin / _end: the same in two halves (one begin at a time). */
+int gp_vgicp_batch_compute_error_dev(gp_vgicp_batch_t* batch, const double* poses_lin_dev, const double* poses_eval_dev, double* out_host);
+int gp_vgicp_batch_issue_compute_error_dev_begin(gp_vgicp_batch_t* batch, const double* poses_lin_dev, const double* poses_eval_dev);
+int gp_vgicp_batch_compute_error_dev_end(gp_vgicp_batch_t* batch, double* out_host);
 int gp_vgicp_batch_stream(const gp_vgicp_batch_t* batch, gp_stream_t* out); /* the stream the batch was created on */
 /* synchronous: upload poses, compute, download F records into out_host */
 int gp_vgicp_batch_linearize(gp_vgicp_batch_t* batch, const double* poses_host, gp_linearized6* out_host);
@@ -444,6 +449,8 @@ int gp_dense_system_issue_step(gp_dense_system_t* sys, const gp_linearized6* rec
                                const double* prior_diag_host);
 int gp_dense_system_finish_step(gp_dense_system_t* sys, double* x_host, double* b_host, double* c_host);
 int gp_dense_system_device_solution(gp_dense_system_t* sys, const double** x_dev, const int** status_dev);
+/* finish_step for a caller that has SEEN the stream pass the step (a completion word of work it queued behind the step): no wait of its own */
+int gp_dense_system_collect_step(gp_dense_system_t* sys, double* x_host, double* b_host, double* c_host);
 
 /* ---- the same step, block-sparse: SparseLinearSystemBuilder<6> + SparseLinearSolver ----
  * SparseLinearSystemBuilder<BLOCK_SIZE> (include/gtsam_points/optimizers/linear_system_builder.hpp:41-72): A as a lower-triangular
@@ -484,6 +491,7 @@ int gp_sparse_system_issue_step(gp_sparse_system_t* sys, const gp_linearized6* r
                                 const double* prior_diag_host);
 int gp_sparse_system_finish_step(gp_sparse_system_t* sys, double* x_host, double* b_host, double* c_host);
 int gp_sparse_system_device_solution(gp_sparse_system_t* sys, const double** x_slots_dev, const int** status_dev);
+int gp_sparse_system_collect_step(gp_sparse_system_t* sys, double* x_host, double* b_host, double* c_host);
 /* measurement hook: thread 0 of sparse_small_step_kernel stamps its phases (s_memtime) into dev_buffer (64 uint64: [0] start, [1] lists and system in LDS, [2] factored,
  * [3] substituted, [4] end, [8 + 4 r + 0..3] round r < 14 of the first level: start / gathered / diagonal block done / blocks below done); NULL = off */
 int gp_debug_sparse_step_trace(gp_sparse_system_t* sys, unsigned long long* dev_buffer);
@@ -497,7 +505,7 @@ int gp_debug_sparse_step_trace(gp_sparse_system_t* sys, unsigned long long* dev_
  *   set_values   values_host = double[N][16], column-major 4x4 (all orthonormal to 1e-9: the rigid kernels serve the graph from then on; else the general ones);  get_values: the current values (after accept: the accepted trial's, as the device computed them)
  *   linearize    asynchronous: the batch's linearise at the current values' relative poses -> records in HBM
  *   try_lambda   damped step + retract (Pose3::retract: T Expmap(xi), xi = (omega, v) = the step's six entries of the pose's slot) + the batch's error evaluation on the
- *                linearisation's correspondences at the trial values: queued back to back, ONE wait.  x_host [6 slots], b_host [6 slots], c_host (the cost at the
+ *                linearisation's correspondences at the trial values: queued back to back, ONE wait (a poll of the evaluation's completion words).  x_host [6 slots], b_host [6 slots], c_host (the cost at the
  *                linearisation point), new_error (the cost at the trial values), new_values_host [N][16]; any may be NULL.  GP_ERROR_INDETERMINATE: b / c valid, no trial.
  *   accept       the last successful trial's values become the current ones (a swap: their relative poses are already in place); linearize again before the next trial
  *   optimize     the reference's loop over the three: GTSAM's LevenbergMarquardtParams defaults in gp_lm_params_default; lambda I damping only (diagonalDamping = false) */
@@ -524,6 +532,9 @@ int gp_lm_graph_linearize(gp_lm_graph_t* graph);
 int gp_lm_graph_try_lambda(gp_lm_graph_t* graph, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal, double* x_host, double* b_host, double* c_host,
                            double* new_error, double* new_values_host);
 int gp_lm_graph_accept(gp_lm_graph_t* graph);
+/* speculation (on by default): behind a trial's error evaluation the linearise at the TRIAL values is queued into a second record buffer, so that an accepted step finds
+ * its linearisation already running while the host decides (a rejected one wastes that launch); 0 = off.  Same bits either way.  Returns the previous setting. */
+int gp_lm_graph_set_speculation(gp_lm_graph_t* graph, int enable);
 int gp_lm_graph_optimize(gp_lm_graph_t* graph, const gp_lm_params* params, gp_lm_summary* summary);
 /* for checkers: the records of the last linearise and the relative poses of the current values, where they lie in device memory (valid until the graph is destroyed;
  * contents as of the work queued so far on the batch's stream) */

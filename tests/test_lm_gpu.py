@@ -155,6 +155,24 @@ def test_trial_on_the_device_follows_the_host_driven_loop(gpu, kitti07, rigid):
     assert nat["final_error"] == res["final_error"] and np.array_equal(nat["values"], res["values"])
     again = tg.native_loop(v0, max_iterations=30)
     assert np.array_equal(again["values"], nat["values"])  # bit-reproducible
+    # speculation (the linearise at the trial values queued behind every trial) changes no bit: the loop without it, and a REJECTED trial -- two trials in a row from
+    # the same linearisation, then the accepted one's next linearisation -- with and without
+    assert tg.g.set_speculation(False) is True
+    plain = tg.native_loop(v0, max_iterations=30)
+    assert plain["final_error"] == nat["final_error"] and np.array_equal(plain["values"], nat["values"])
+    seq = {}
+    for spec in (True, False):
+        tg.g.set_speculation(spec)
+        tg.g.set_values(v0)
+        tg.g.linearize()
+        a = [np.array(x, copy=True) for x in tg.g.try_lambda(1e-5)]
+        b2 = [np.array(x, copy=True) for x in tg.g.try_lambda(1e-1)]  # (the first one is dropped: as a rejected step would be)
+        tg.g.accept()
+        tg.g.linearize()
+        c2 = [np.array(x, copy=True) for x in tg.g.try_lambda(1e-3)]
+        seq[spec] = a + b2 + c2 + [tg.g.values()]
+    assert all(np.array_equal(x, y) for x, y in zip(seq[True], seq[False]))
+    assert not np.array_equal(seq[True][0], seq[True][4])  # (the two lambdas gave different steps)
     gg.close()
     tg.close()
 
