@@ -239,6 +239,7 @@ _SIGNATURES = {
     "gp_lm_graph_accept": (C.c_int, [C.c_void_p]),
     "gp_lm_graph_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_lm_graph_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "gp_debug_sparse_work_lists": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_time_linearize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 

@@ -389,8 +389,9 @@ static int critical_columns(const SparseSymbolic& S) {
   return crit;
 }
 
-// the one-launch step of small graphs (sparse_small_step_kernel below): one 1024-thread workgroup, up to sixteen work lists of a level side by side
-constexpr int kSmallThreads = 1024, kSmallTeams = 16;
+// the one-launch step of small graphs (sparse_small_step_kernel below): one 512-thread workgroup (eight waves of up to 256 registers: the wave form's rows live in registers;
+// at 1024 threads the 128-register cap spilled them), up to eight work lists of a level side by side
+constexpr int kSmallThreads = 512, kSmallTeams = 8;
 constexpr int kSmallTeamDoubles = 158;  // per team: D[6][7] | rhs[6] | v[6] (backward) | pad 2 | part: rpart[16][6] (forward) / bpart[6][6] (backward) | dinv[6]
 // LDS bytes that step needs for a symbolic factorisation: L's blocks, y, x, the teams' scratch, the error partials, the index lists (0: the factor does not qualify)
 static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_out = nullptr) {
@@ -400,7 +401,7 @@ static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_
   if (arena_words_out) *arena_words_out = words;
   if (P > 128) return 0;  // (row lists stay below the staged kernel's 128-block stage, which the one-launch form assumes)
   const size_t bytes = sizeof(double) * (36 * nnzL + 24 * P + (size_t)kSmallTeams * kSmallTeamDoubles) + sizeof(int) * words + 64;
-  return bytes <= 160 * 1024 - 256 ? bytes : 0;
+  return bytes <= 160 * 1024 - 1024 ? bytes : 0;
 }
 static bool small_step_fits(const SparseSymbolic& S) { return small_step_lds_bytes(S) != 0; }
 
@@ -1021,14 +1022,16 @@ __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __
 // The multi-launch step above costs 0.21 ms on BASELINE configs[2]'s graph (63 free poses, 256 factors) and its launches are NOT the cost: the kernels' own time is
 // (profiles/r06_solver_kernel_stats.csv).  A column of the factorisation is a chain -- product indices -> operand blocks -> 6 x 6 Cholesky -> triangular solves -- and
 // every link is a round trip to L2 behind a workgroup barrier.  For a graph whose whole factor fits the LDS of one compute unit (<= ~400 blocks of 288 B; the index
-// lists beside it) ONE 1024-thread workgroup factors and solves with every operand in LDS:
+// lists beside it) ONE 512-thread workgroup factors and solves with every operand in LDS:
 //   phase 0  the index lists and the ASSEMBLED system (L's blocks, b, the diagonal) from global memory into LDS: coalesced, ~3 us.  The assembly itself stays
 //            sparse_assemble_kernel<true>, one 64-lane workgroup per block of L across the whole chip, in the launch in front: it is a gather of 8-byte values out of the
 //            factors' records, and ONE compute unit's vector-memory path needs 40 us for it (measured: the first form of this kernel assembled in place, with its lists in
 //            LDS and sixteen loads in flight per thread: 30 - 45 us against the assembly kernel's 6.5)
-//   phase 1  the schedule's levels one after the other; the work lists of a level side by side, each with a TEAM of 1024 / lists threads (whole waves), in lock step:
-//            round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward substitution by the team's first wave, barrier, the blocks below, barrier
-//   phase 2  the backward substitution, levels and columns in reverse, two barriers per round
+//   phase 1  the schedule's levels one after the other, the work lists of a level side by side.  Level 0 (the independent subtrees): a list per WAVE, which walks its
+//            columns without any barrier (small_wave_column, below).  Levels above (separator chains, whose columns gather hundreds of products): each list with a TEAM
+//            of 512 / lists threads (whole waves), in lock step: round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward substitution by the
+//            team's first wave, barrier, the blocks below, barrier.  (gp_sparse_system_set_one_launch(sys, 2): the team form for level 0 too, as first built.)
+//   phase 2  the backward substitution, levels and columns in reverse: a list per wave, no barrier inside a list (the team form: two barriers per round)
 //   phase 3  x in slot order to the device array and the host, the status word
 // Every scalar is computed by the SAME sequence of operations as in sparse_factor_kernel<256> (lists of level 0) / sparse_factor_staged_kernel<1024> (levels above: the
 // slice partials with G and `per` derived from the column's size exactly as there) / sparse_backsolve_kernel, so the step is bit-identical to the multi-launch form
@@ -1068,6 +1071,173 @@ __device__ __forceinline__ double small_sub_products(double acc, const int* upd_
   return acc;
 }
 
+// ---- a column by ONE wave (round 6, second form of the one-launch step) ------------------------------------------------------------------------------------------
+// The team form below spends a round's 7900 clocks mostly WAITING: three workgroup barriers, one wave factoring the diagonal block while the others idle, lanes exchanging
+// entries through LDS.  Here a work list belongs to one wave, which walks its columns with no barrier at all (the next column's operands were written by the same wave),
+// and a lane owns a whole ROW of the column's panel -- lanes 0-5 the rows of the diagonal block, lanes 6-11 the six entries of the forward substitution's right-hand side
+// while they are gathered (then lane 6 holds them as one row), lanes 12.. the rows of the blocks below -- with its six entries in registers:
+//  1. gather: lane (row r of block d) subtracts, product by product in list order, (row r of block upd_a) . (row c of block upd_b) for its six c; the right-hand-side
+//     lanes run the same loop over the row list with y in the place of block upd_b (one "row").  Per entry: the team form's and the multi-launch kernels' arithmetic.
+//  2. the panel is swept right-looking, pivot by pivot: 1 / sqrt(pivot) and the diagonal block's column p are wave-uniform (v_readlane), every row scales its entry p and
+//     updates its entries c > p from its own registers.  Entry by entry that is the SAME sequence of operations on the same operands as chol6_wave (diagonal block),
+//     trsm_row6 (blocks below) and forward6 (right-hand side) -- fma(-x_rp, L_cp, x_rc) for p ascending, then x_rc * (1 / L_cc) -- so the factor is bit-identical to the
+//     team form's and the multi-launch kernels'.  More than 52 rows below the diagonal: further passes of 64 rows with the pivots' scalars kept.
+// Measured (scripts/r06/solver_trace.py, BASELINE configs[2]'s graph: two lists of 29 / 30 columns): a column 6600 clocks (gather 3700, panel 1550, write-back 1050)
+// against the team form's 7900; a lone wave issues an instruction every ~4.5 clocks whatever it is, so what a column costs is its instruction count.  Three
+// re-formulations of the gather were built and measured no better -- entries dealt three to a lane (4900 clocks: the index chain per turn), a static per-lane program of
+// operand offsets in device memory (3600; with the next column's words prefetched 4800: the words' way from L2 is longer than a turn) -- and were removed.
+__device__ __forceinline__ void small_wave_column(const int k, const int lane, double* Ls, double* ys, double* dis, const double* d0s, const int* colptr, const int* upd_ptr,
+                                                  const int* upd_a, const int* upd_b, const int* row_ptr, const int* row_blk, const int* row_col, int* bad,
+                                                  unsigned long long* stamp) {
+  const int base = colptr[k], nb = colptr[k + 1] - base;
+  const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
+  const int rows = 6 * nb + 6;  // 6 (diagonal block) + 6 (right-hand-side entries; lane 6 becomes the row) + 6 (nb - 1)
+  double rl[6], pl[6], lcp[6][6], sc[6];
+#pragma unroll
+  for (int p = 0; p < 6; p++) sc[p] = d0s[6 * (size_t)k + p];
+  bool any_bad = false;
+  for (int c0 = 0; c0 < rows; c0 += 64) {
+    const int i = c0 + lane;
+    const bool act = i < rows, is_rhs = i >= 6 && i < 12;
+    const int ib = i < 12 ? 0 : (i - 12) / 6 + 1;
+    const int r = i < 6 ? i : (i < 12 ? i - 6 : (i - 12) % 6);
+    const int d = base + ib;
+    // ---- gather ----
+    double a[6];
+    const int* la = is_rhs ? row_blk : upd_a;
+    const int* lb = is_rhs ? row_col : upd_b;
+    int u = !act ? 0 : (is_rhs ? rb : upd_ptr[d]);
+    const int ue = !act ? 0 : (is_rhs ? rb + nrow : upd_ptr[d + 1]);
+    const double* bbase = is_rhs ? ys : Ls;
+    const int bblock = is_rhs ? 6 : 36, brow = is_rhs ? 0 : 6;  // doubles between the "blocks" / rows of the second operand (y: one row)
+    if (act && !is_rhs) {
+      const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)d + 6 * r);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double2 x = A[q];
+        a[2 * q] = x.x, a[2 * q + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; c++) a[c] = 0.0;
+      if (act) a[0] = ys[6 * (size_t)k + r];
+    }
+    constexpr int kBatch = 2;
+    for (; u < ue; u += kBatch) {
+      double av[kBatch][6], bv[kBatch][6][6];
+#pragma unroll
+      for (int w = 0; w < kBatch; w++) {
+        const int uu = u + w < ue ? u + w : ue - 1;  // (a short tail repeats the last product's operands and skips its subtraction)
+        const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)la[uu] + 6 * r);
+        const double* Bb = bbase + (size_t)bblock * lb[uu];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const double2 x = A[q];
+          av[w][2 * q] = x.x, av[w][2 * q + 1] = x.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const double2* B = reinterpret_cast<const double2*>(Bb + brow * c);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const double2 y = B[q];
+            bv[w][c][2 * q] = y.x, bv[w][c][2 * q + 1] = y.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < kBatch; w++)
+        if (u + w < ue) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) a[c] -= av[w][q] * bv[w][c][q];
+          }
+        }
+    }
+    if (c0 == 0) {
+      // the right-hand side's six entries (lanes 6-11, entry 0 each) become lane 6's row
+      double rh[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) rh[q] = lane_bcast_f64(a[0], 6 + q);
+      if (lane == 6) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] = rh[q];
+      }
+    }
+    if (stamp && c0 == 0) stamp[1] = __builtin_amdgcn_s_memtime();
+    // ---- the panel, pivot by pivot ----
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+      if (c0 == 0) {
+        double piv = lane_bcast_f64(a[p], p);
+        if (!(piv > kPivotTolerance * sc[p])) {
+          any_bad = true;
+          piv = 1.0;
+        }
+        rl[p] = rsqrt_f64(piv);
+        pl[p] = piv * rl[p];
+      }
+      a[p] = (i == p) ? pl[p] : a[p] * rl[p];
+      if (c0 == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+          if (c > p) lcp[c][p] = lane_bcast_f64(a[p], c);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++)
+        if (c > p) a[c] = __builtin_fma(-a[p], lcp[c][p], a[c]);
+    }
+    if (stamp && c0 == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+    // ---- back to LDS ----
+    if (act && i < 6) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) Ls[36 * (size_t)base + 6 * r + c] = c <= r ? a[c] : 0.0;
+    } else if (act && i == 6) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) ys[6 * (size_t)k + c] = a[c];
+    } else if (act && i >= 12) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) Ls[36 * (size_t)d + 6 * r + c] = a[c];
+    }
+    if (c0 == 0 && lane == 7) {
+#pragma unroll
+      for (int p = 0; p < 6; p++) dis[6 * (size_t)k + p] = rl[p];
+    }
+  }
+  if (any_bad && lane == 0) *bad = 1;
+  GP_WAVE_SYNC_LDS();  // (the next column of this wave reads what its other lanes have just written)
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+}
+
+// backward substitution of a column by ONE wave: the team form's operations (six slices of the blocks below, met in slice order, then back6) without its barriers
+__device__ __forceinline__ void small_wave_back_column(const int k, const int lane, const double* Ls, const double* ys, const double* dis, double* xs, const int* colptr,
+                                                       const int* rowidx, double* scratch /* [48]: this wave's */) {
+  const int base = colptr[k], nb = colptr[k + 1] - base;
+  double (*bpart)[6] = reinterpret_cast<double (*)[6]>(scratch);
+  double* vv = scratch + 36;
+  if (lane < 36) {
+    const int c = lane % 6, slice = lane / 6;
+    double acc = 0.0;
+    for (int p = 1 + slice; p < nb; p += 6) {
+      const double* A = Ls + 36 * (size_t)(base + p);
+      const double* xi = xs + 6 * (size_t)rowidx[base + p];
+#pragma unroll
+      for (int q = 0; q < 6; q++) acc += A[6 * q + c] * xi[q];
+    }
+    bpart[slice][c] = acc;
+  }
+  GP_WAVE_SYNC_LDS();
+  if (lane < 6) {
+    double sum = ys[6 * (size_t)k + lane];
+    for (int sl = 0; sl < 6; sl++) sum -= bpart[sl][lane];
+    vv[lane] = sum;
+  }
+  GP_WAVE_SYNC_LDS();
+  if (lane == 0) back6<true>(Ls + 36 * (size_t)base, dis + 6 * (size_t)k, vv, xs + 6 * (size_t)k);
+  GP_WAVE_SYNC_LDS();
+}
+
 struct SparseSmallView {
   const double* L_global;      // [nnzL][36] column-major: the assembled (damped) blocks
   const double* y_global;      // [6 P] b, elimination order
@@ -1080,6 +1250,7 @@ struct SparseSmallView {
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
   double* status_host;    // pinned
+  int wave_columns;           // 1: level 0's work lists (and every level's backward substitution) by one wave each, no barriers inside a list (small_wave_column); 0: the team form
   unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] = [5] lists and system in LDS, [2] factored, [3] substituted, [4] end,
                               // [8 + 4 r + {0, 1, 2, 3}]: round r < 14 of the first level: start, gathered, diagonal done, blocks below done; null = off
 };
@@ -1093,6 +1264,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   double* scr = d0s + 6 * (size_t)V.P;                      // [kSmallTeams][kSmallTeamDoubles]
   int* idx = reinterpret_cast<int*>(scr + kSmallTeams * kSmallTeamDoubles);  // the index lists
   __shared__ int bad;
+  __shared__ unsigned long long tr_lds[64];  // (the stamps stay in LDS until the end: a store to memory in front of a fence would be waited for, and measured)
   const int t = threadIdx.x;
   const int* colptr = idx + V.o_colptr;
   const int* rowidx = idx + V.o_rowidx;
@@ -1107,8 +1279,10 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   // ---- phase 0 ----
 #define GP_SMALL_STAMP(i)                                                       \
   do {                                                                          \
-    if (V.trace && t == 0) V.trace[i] = __builtin_amdgcn_s_memtime();           \
+    if (V.trace && t == 0) tr_lds[i] = __builtin_amdgcn_s_memtime();            \
   } while (0)
+  if (V.trace && t < 64) tr_lds[t] = 0;
+  __syncthreads();
   GP_SMALL_STAMP(0);
   if (t == 0) bad = 0;
   for (int i = t; i < V.arena_words; i += kSmallThreads) idx[i] = V.arena[i];
@@ -1133,8 +1307,23 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   for (int lvl = 0; lvl < V.num_levels; lvl++) {
     const int first = V.level_ptr[lvl], nlists = V.level_ptr[lvl + 1] - first;
     const bool staged = lvl > 0;
-    for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {  // (more than sixteen lists in a level: sixteen at a time)
+    for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {  // (more than eight lists in a level: eight at a time)
       const int nb_lists = min(kSmallTeams, nlists - b0);
+      if (!staged && V.wave_columns) {
+        // level 0: a work list per WAVE, no barrier between its columns (small_wave_column)
+        const int wv = t >> 6;
+        if (wv < nb_lists) {
+          const int list = first + b0 + wv;
+          int rd = 0;
+          for (int w = work_ptr[list]; w < work_ptr[list + 1]; w++, rd++) {
+            unsigned long long* st = (V.trace && t < 64 && b0 == 0 && rd < 14) ? tr_lds + 8 + 4 * rd : nullptr;
+            if (st && t == 0) st[0] = __builtin_amdgcn_s_memtime();
+            small_wave_column(work_cols[w], t & 63, Ls, ys, dis, d0s, colptr, upd_ptr, upd_a, upd_b, row_ptr, row_blk, row_col, &bad, t == 0 ? st : nullptr);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       const int T = (kSmallThreads / nb_lists) & ~63;     // threads per team: whole waves
       const int team = t / T, j = t % T;
       const bool member = team < nb_lists;
@@ -1266,6 +1455,16 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     const int first = V.level_ptr[lvl], nlists = V.level_ptr[lvl + 1] - first;
     for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {
       const int nb_lists = min(kSmallTeams, nlists - b0);
+      if (V.wave_columns) {
+        const int wv = t >> 6;
+        if (wv < nb_lists) {
+          const int list = first + b0 + wv;
+          for (int w = work_ptr[list + 1] - 1; w >= work_ptr[list]; w--)
+            small_wave_back_column(work_cols[w], t & 63, Ls, ys, dis, xs, colptr, rowidx, scr + (size_t)wv * kSmallTeamDoubles + 56);
+        }
+        __syncthreads();
+        continue;
+      }
       const int T = (kSmallThreads / nb_lists) & ~63;
       const int team = t / T, j = t % T;
       const bool member = team < nb_lists;
@@ -1318,6 +1517,8 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     *V.status_host = (double)bad;
   }
   GP_SMALL_STAMP(4);
+  if (V.trace && t == 0)
+    for (int i = 0; i < 64; i++) V.trace[i] = tr_lds[i];
 #undef GP_SMALL_STAMP
 }
 
@@ -1372,6 +1573,32 @@ int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_
   if (num_levels) *num_levels = levels;
   if (critical_columns) *critical_columns = gp::critical_columns(S);
   if (num_lists) *num_lists = S.level_ptr[levels];
+  return GP_OK;
+}
+
+// host-side check hook (no device needed): the work lists of the numeric phase -- per list its level, its number of columns, the block products its columns gather in
+// all and the most a single column gathers; arrays of `capacity` ints (num_lists from gp_sparse_symbolic_schedule)
+int gp_debug_sparse_work_lists(int num_slots, const int* factor_slots, int num_factors, int ordering, int capacity, int* level, int* columns, int* products, int* max_column_products) {
+  if (num_slots <= 0 || num_factors < 0 || (num_factors > 0 && !factor_slots) || ordering < 0 || ordering > 4 || !level || !columns || !products || !max_column_products)
+    return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_sparse_work_lists: bad arguments");
+  gp::SparseSymbolic S;
+  GP_TRY(gp::sparse_symbolic(num_slots, factor_slots, num_factors, ordering, &S));
+  const int levels = (int)S.level_ptr.size() - 1;
+  if (S.level_ptr[levels] > capacity) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_debug_sparse_work_lists: capacity too small");
+  for (int l = 0; l < levels; l++)
+    for (int w = S.level_ptr[l]; w < S.level_ptr[l + 1]; w++) {
+      level[w] = l;
+      columns[w] = S.work_ptr[w + 1] - S.work_ptr[w];
+      int sum = 0, mx = 0;
+      for (int q = S.work_ptr[w]; q < S.work_ptr[w + 1]; q++) {
+        const int k = S.work_cols[q];
+        const int n = S.upd_ptr[S.colptr[k + 1]] - S.upd_ptr[S.colptr[k]];
+        sum += n;
+        mx = std::max(mx, n);
+      }
+      products[w] = sum;
+      max_column_products[w] = mx;
+    }
   return GP_OK;
 }
 
@@ -1488,10 +1715,11 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     V.o_colptr = off[0], V.o_rowidx = off[1], V.o_upd_ptr = off[2], V.o_upd_a = off[3], V.o_upd_b = off[4], V.o_row_ptr = off[5], V.o_row_blk = off[6], V.o_row_col = off[7];
     V.o_work_ptr = off[8], V.o_work_cols = off[9];
     V.perm = s->d_perm;
+    V.wave_columns = 1;
     V.x_slots = s->x_slots.as<double>();
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for; a runtime that refuses leaves the multi-launch step in charge)
     // (the attribute belongs to the FUNCTION, not to this system: every system asks for the same ceiling, so that one created later never lowers what an earlier one needs)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gp::sparse_small_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gp::sparse_small_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess) {
       s->small_ok = true;
       s->one_launch = true;
     } else {
@@ -1514,7 +1742,8 @@ int gp_debug_sparse_step_trace(gp_sparse_system_t* s, unsigned long long* dev_bu
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* s, int enable) {
   if (!s) return 0;
   s->one_launch = enable != 0 && s->small_ok;
-  return s->one_launch ? 1 : 0;
+  s->small.wave_columns = enable == 2 ? 0 : 1;  // 2: the one-launch step's first form (teams of waves in lock step) -- kept for the bit-identity test and A/B timing
+  return s->one_launch ? (s->small.wave_columns ? 1 : 2) : 0;
 }
 
 int gp_sparse_system_destroy(gp_sparse_system_t* s) {

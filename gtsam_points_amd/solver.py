@@ -136,8 +136,11 @@ def sparse_symbolic(num_slots, factor_slots, ordering=0):
                                        C.byref(nt)), "gp_sparse_symbolic")
     lv, cc, wl = C.c_int(), C.c_int(), C.c_int()
     _capi.check(lib.gp_sparse_symbolic_schedule(int(num_slots), fs.ctypes.data, len(fs), int(ordering), C.byref(lv), C.byref(cc), C.byref(wl)), "gp_sparse_symbolic_schedule")
+    arr = [np.zeros(max(wl.value, 1), np.int32) for _ in range(4)]
+    _capi.check(lib.gp_debug_sparse_work_lists(int(num_slots), fs.ctypes.data, len(fs), int(ordering), len(arr[0]), *[a.ctypes.data for a in arr]), "gp_debug_sparse_work_lists")
+    lists = [dict(level=int(arr[0][i]), columns=int(arr[1][i]), products=int(arr[2][i]), max_column_products=int(arr[3][i])) for i in range(wl.value)]
     return dict(perm=perm, parent=parent, nnz_a_blocks=na.value, nnz_l_blocks=nl.value, num_subtrees=ns.value, top_columns=nt.value, num_levels=lv.value,
-                critical_columns=cc.value, num_lists=wl.value)
+                critical_columns=cc.value, num_lists=wl.value, work_lists=lists)
 
 
 class SparseLinearSystemGPU:
@@ -171,8 +174,9 @@ class SparseLinearSystemGPU:
 
     def set_one_launch(self, enable=True):
         """step() of a system whose factor fits one compute unit's LDS (<= 128 poses, <= ~440 blocks of L) runs as ONE launch by default; False selects the multi-launch
-        form (bit-identical: the switch is for the test that says so and for timing).  Returns what the next step() runs (True: one launch)."""
-        return bool(self._lib.gp_sparse_system_set_one_launch(self._h, 1 if enable else 0))
+        form, "teams" the one-launch step's first form (teams of waves in lock step instead of a work list per wave) -- all bit-identical: the switch is for the test that
+        says so and for timing.  Returns what the next step() runs (True: one launch)."""
+        return bool(self._lib.gp_sparse_system_set_one_launch(self._h, 2 if enable == "teams" else (1 if enable else 0)))
 
     def info(self):
         na, nl, bp, ns, nt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()

@@ -480,9 +480,10 @@ int gp_sparse_system_download(const gp_sparse_system_t* sys, double* A_host, dou
 int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_dev);
 /* gp_dense_system_step's block-sparse form, one wait.  The assembly kernel applies the damping and hands b, c to the host.  A system whose factor and index lists fit the
  * LDS of one compute unit (<= 128 poses, <= ~400 blocks of L: BASELINE configs[2]'s 64-pose graph does) is then factored and solved -- all levels, both substitutions, x
- * and status to the host -- by ONE launch of one 1024-thread workgroup with every operand in LDS (sparse_small_step_kernel): two launches per step; larger systems take
- * 2 + 2 x levels launches.  The two forms are bit-identical; gp_sparse_system_set_one_launch(sys, 0) selects the multi-launch form for a qualifying system (returns what
- * the next step runs: 1 / 0). */
+ * and status to the host -- by ONE launch of one 512-thread workgroup with every operand in LDS (sparse_small_step_kernel; the independent subtrees and the backward
+ * substitution one work list per wave with no barrier inside a list): two launches per step; larger systems take 2 + 2 x levels launches.  The forms are bit-identical;
+ * gp_sparse_system_set_one_launch(sys, 0) selects the multi-launch form for a qualifying system, 2 the one-launch step's first form (every list a team of waves in lock
+ * step), 1 the default; returns what the next step runs (0 / 2 / 1). */
 int gp_sparse_system_step(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
                           const double* prior_diag_host, double* x_host, double* b_host, double* c_host);
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* sys, int enable);
@@ -547,6 +548,9 @@ int gp_sparse_symbolic(int num_slots, const int* factor_slots, int num_factors, 
 /* the schedule of the numeric phase (pure host code): launch levels (level 0 = the independent subtrees, then the chains of separator columns level by
  * level, one workgroup per chain), the critical path in columns (sum over the levels of the longest work list) and the number of work lists */
 int gp_sparse_symbolic_schedule(int num_slots, const int* factor_slots, int num_factors, int ordering, int* num_levels, int* critical_columns, int* num_lists);
+/* ... and its work lists one by one (pure host code; arrays of `capacity` >= num_lists ints): the level a list runs in, its columns, the 6x6 block products its columns
+ * gather in all and the most a single column gathers */
+int gp_debug_sparse_work_lists(int num_slots, const int* factor_slots, int num_factors, int ordering, int capacity, int* level, int* columns, int* products, int* max_column_products);
 
 /* ---- per-handle tuning (not part of the reference API) --------------------------------------------------------------------------
  * Every knob below belongs to ONE batch / factor / map / search structure; the library keeps no process-global switches, so two
