@@ -520,6 +520,7 @@ struct gp_vgicp_batch {
   void* h_out_dev = nullptr;
   gp::PinnedArray h_done;  // one completion word per factor, written by the finalize kernel behind its record (synchronous calls poll it)
   void* h_done_dev = nullptr;
+  bool dev_error_fused = false;  // gp_vgicp_batch_issue_compute_error_dev_begin went out in the by-factor fused form
   unsigned long long seq = 0;
   bool table_dirty = true;
   std::vector<uint64_t> seen;  // per factor: its generation + its target map's generation when the table was built
@@ -1416,6 +1417,9 @@ int gp_vgicp_batch_issue_compute_error(gp_vgicp_batch_t* b, const double* poses_
   return launch_error(b, ps, out_dev);
 }
 
+static int clean_factor_arrivals(gp_vgicp_batch_t* b);
+static bool words_arrived(const gp_vgicp_batch_t* b, int count, unsigned long long seq);
+
 // the same two passes with the poses ALREADY in device memory (double[F][16] per table, column-major -- what a device-side retract produces, gp_lm.hip): no staging,
 // no H2D copy, nothing for the host to wait on before the next call.  rigid: the caller vouches that every 3x3 block is orthonormal to 1e-9 (what the host-pose entry
 // points test for themselves, poses_are_rigid): the 29-sum kernel + adjoint expansion; 0 = the 92-sum kernel, exact for any 3x3 block.  Any F (a single factor reads its descriptor and pose from the
@@ -1427,6 +1431,9 @@ int gp_vgicp_batch_issue_linearize_dev(gp_vgicp_batch_t* b, const double* poses_
   PoseSource ps;
   ps.d_lin = poses_dev;
   ps.inl.use = 0;
+  // (the by-factor fused finalize of the synchronous call was tried here too -- records written by the factors' last tile workgroups, no finalize launch -- and measured
+  //  4 us SLOWER on BASELINE configs[2]'s batch: 59 us against 49.6 + 5.0, the 256 factors' tails end later than one finalize kernel over all of them; the error
+  //  evaluation below keeps its fused form: 52 us against 49.5 + 9.2)
   return launch_linearize(b, ps, out_dev, rigid != 0);
 }
 
@@ -1460,6 +1467,36 @@ int gp_vgicp_batch_issue_compute_error_dev_begin(gp_vgicp_batch_t* b, const doub
   ps.d_eval = poses_eval_dev;
   ps.inl.use = 0;
   const gp::DoneFlags done{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+  const size_t F = b->factors.size();
+  b->dev_error_fused = false;
+  if (b->family == GP_KERNEL_STREAM && b->tuning.fused_finalize && !b->trace && !b->planned) {
+    // ONE launch, as the synchronous call's by-factor form (gp_vgicp_batch_compute_error): the factor's last tile workgroup adds its rows up and hands sum and word over
+    if (b->factor_arrive_count < F) {
+      const size_t bytes = sizeof(unsigned long long) * gp::kFactorArriveStride * F;
+      GP_TRY(b->d_factor_arrive.alloc(bytes));
+      GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, bytes));
+      b->factor_arrive_count = F;
+    }
+    double* partials = nullptr;
+    GP_TRY(partials_ptr(b, &partials));
+    GP_TRY(clean_factor_arrivals(b));
+    ps.inl.arrive = b->d_factor_arrive.as<unsigned long long>();
+    ps.inl.rows_per_part = 0;
+    ps.inl.num_rows = b->num_tiles;
+    ps.inl.fin_out = static_cast<double*>(b->h_out_dev);
+    ps.inl.fin_stride = 1;
+    ps.inl.fin_flags = done.flags;
+    ps.inl.fin_seq = done.seq;
+    b->factor_arrive_dirty = true;
+    GP_TRY(launch_tiles<gp::MODE_ERR>(b, ps, partials));
+    for (size_t i = 0; i < F; i++)
+      if (b->h_descs[i].tile_count == 0) {
+        static_cast<volatile double*>(b->h_out.ptr)[i] = 0.0;
+        static_cast<volatile unsigned long long*>(b->h_done.ptr)[i] = done.seq;
+      }
+    b->dev_error_fused = true;
+    return GP_OK;
+  }
   return launch_error(b, ps, static_cast<double*>(b->h_out_dev), done);
 }
 
@@ -1468,6 +1505,21 @@ int gp_vgicp_batch_compute_error_dev_end(gp_vgicp_batch_t* b, double* out_host) 
   const size_t F = b->factors.size();
   if (F == 0) return GP_OK;
   GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, b->seq, b->stream, spin_budget_us(b) + 400));  // (+ the damped step queued in front of it)
+  if (b->dev_error_fused) {
+    if (!words_arrived(b, (int)F, b->seq)) {  // (as gp_vgicp_batch_compute_error: a counter left dirty by a launch that did not run to its end -- the finalize kernel does the sums)
+      double* partials = nullptr;
+      GP_TRY(partials_ptr(b, &partials));
+      GP_HIP(hipStreamSynchronize(b->stream));
+      GP_HIP(hipMemset(b->d_factor_arrive.ptr, 0, sizeof(unsigned long long) * gp::kFactorArriveStride * F));
+      const gp::DoneFlags again{static_cast<unsigned long long*>(b->h_done_dev), ++b->seq};
+      hipLaunchKernelGGL(gp::vgicp_finalize_error_kernel, dim3((int)F), dim3(gp::kBlockThreads), 0, b->stream, b->d_factors.as<gp::FactorDesc>(), (const double*)partials,
+                         static_cast<double*>(b->h_out_dev), -1, again);
+      GP_HIP(hipGetLastError());
+      GP_TRY(gp::wait_done(static_cast<const unsigned long long*>(b->h_done.ptr), F, again.seq, b->stream, spin_budget_us(b)));
+    }
+    b->factor_arrive_dirty = false;
+    b->dev_error_fused = false;
+  }
   memcpy(out_host, b->h_out.ptr, sizeof(double) * F);
   return GP_OK;
 }

@@ -58,6 +58,9 @@ def main():
             if sp.set_one_launch(True):
                 med, mn, x_one = timed(sp, rec_dev, out)
                 row.update(one_launch_ms=round(med, 4), one_launch_ms_min=round(mn, 4))
+                if sp.set_one_launch("teams"):  # the one-launch step's first form: every list a team of waves in lock step
+                    med, mn, x_teams = timed(sp, rec_dev, out)
+                    row.update(one_launch_teams_ms=round(med, 4), teams_bit_identical=bool(np.array_equal(x_teams, x_one)))
             sp.set_one_launch(False)
             med, mn, x = timed(sp, rec_dev, out)
             row.update(multi_launch_ms=round(med, 4), multi_launch_ms_min=round(mn, 4), bit_identical=bool(np.array_equal(x, x_one)) if x_one is not None else None)

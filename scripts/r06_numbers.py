@@ -136,28 +136,36 @@ def lm():
         if "error" in o or not o:
             out.append(f"| {name} | — | — | {o.get('error', 'not run')} | | | | | |")
             continue
-        for leg, label in (("gpu_device_solve", "GPU, records stay in HBM, damped build + block-sparse LLᵀ as ONE call — round 6: the assembly + ONE launch (`gp_sparse_system_step`)"), ("gpu_host_solve", "GPU linearise / error, numpy solve on the host"),
+        for leg, label in (("gpu_native_loop", "**GPU, the values in device memory, the library's own loop** (`gp_lm_graph_optimize`: linearise | damped step + retract + error evaluation, ONE wait per trial)"),
+                           ("gpu_device_trial", "GPU, the values in device memory, the interpreter driving `gp_lm_graph_linearize` / `_try_lambda` / `_accept` (solve = the whole trial; linearise = its issue, + its wait in the split run)"),
+                           ("gpu_device_solve", "GPU, host-driven (rounds 4 – 5's form): poses up, linearise | `gp_sparse_system_step`, wait | numpy retract, poses up, error evaluation, wait"), ("gpu_host_solve", "GPU linearise / error, numpy solve on the host"),
                            ("cpu_baseline", f"the reference's CPU factor ({o['cpu_baseline']['cores']} threads) + numpy solve: {o['cpu_baseline'].get('sample', '')[:60]}")):
             if leg not in o:
                 continue
             x = o[leg]
-            ph = x["ms_per_iteration_by_phase"]
+            ph = x.get("ms_per_iteration_by_phase")
+            if not ph:  # (the library's loop never returns to the interpreter between its phases)
+                out.append(f"| {name} | {label} | {x['iterations']} ({x['inner_iterations']}) | **{x['ms_per_iteration']:.4f}** | — | — | — | — | "
+                           f"{'met' if x['gate_met'] else 'NOT met'}: {x['max_rotation_error_rad']:.5f} rad / {x['max_translation_error_m']:.4f} m |")
+                continue
             out.append(f"| {name} | {label} | {x['iterations']} ({x['inner_iterations']}) | **{x['ms_per_iteration']:.4f}** | {ph['linearize']:.4f} | {ph['solve']:.4f} | {ph['error']:.4f} | {ph['glue']:.4f} | "
                        f"{'met' if x['gate_met'] else 'NOT met'}: {x['max_rotation_error_rad']:.5f} rad / {x['max_translation_error_m']:.4f} m |")
     out.append("")
-    out.append(f"Across the six runs of the driver's command: C3 {rng([x['legs'].get('lm_c3_ms_iter') for x in rs], '{:.3f}')} ms per iteration (solve {rng([x['legs'].get('lm_c3_solve_ms') for x in rs], '{:.3f}')}), "
-               f"C1 {rng([x['legs'].get('lm_c1_ms_iter') for x in rs], '{:.3f}')}.  Round 5's driver run: C3 0.451 (solve 0.226).")
+    out.append(f"Across the runs of the driver's command: C3 **{rng([x['legs'].get('lm_c3_ms_iter') for x in rs], '{:.3f}')} ms per iteration** in the library's loop ({rng([x['legs'].get('lm_c3_trial_ms_iter') for x in rs], '{:.3f}')} with the interpreter "
+               f"driving the three calls, {rng([x['legs'].get('lm_c3_host_driven_ms_iter') for x in rs], '{:.3f}')} host-driven: solve {rng([x['legs'].get('lm_c3_solve_ms') for x in rs], '{:.3f}')}), C1 {rng([x['legs'].get('lm_c1_ms_iter') for x in rs], '{:.3f}')} "
+               f"({rng([x['legs'].get('lm_c1_host_driven_ms_iter') for x in rs], '{:.3f}')} host-driven).  Round 5's driver run: C3 0.451 (solve 0.226).  VERDICT r05 #4 asked for ≤ 0.30.")
     return "\n".join(out)
 
 
 def solver():
     rows = jl("r06_solver_step_time.jsonl")
-    out = ["| graph (structure of the damped system) | ordering | levels / critical columns / blocks of L | assembly + ONE launch (`sparse_small_step_kernel`) ms | multi-launch ms | bit-identical |", "|---|---|---|---|---|---|"]
+    out = ["| graph (structure of the damped system) | ordering | levels / critical columns / blocks of L | assembly + ONE launch (`sparse_small_step_kernel`: a work list per wave) ms | … its first form (teams of waves in lock step) ms | multi-launch ms | bit-identical |", "|---|---|---|---|---|---|---|"]
     for x in rows:
         if x["ordering"] not in ("auto", "natural"):
             continue
         out.append(f"| {x['graph']} | {x['ordering']} | {x['levels']} / {x['critical_columns']} / {x['l_blocks']} | " + (f"{x['one_launch_ms']:.4f}" if x.get("one_launch_ms") is not None else "does not fit the LDS") +
-                   f" | {x['multi_launch_ms']:.4f} | {x.get('bit_identical') if x.get('bit_identical') is not None else '—'} |")
+                   " | " + (f"{x['one_launch_teams_ms']:.4f}" if x.get("one_launch_teams_ms") is not None else "—") +
+                   f" | {x['multi_launch_ms']:.4f} | {(x.get('bit_identical') and x.get('teams_bit_identical', True)) if x.get('bit_identical') is not None else '—'} |")
     return "\n".join(out)
 
 
