@@ -1027,10 +1027,11 @@ __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __
 //            sparse_assemble_kernel<true>, one 64-lane workgroup per block of L across the whole chip, in the launch in front: it is a gather of 8-byte values out of the
 //            factors' records, and ONE compute unit's vector-memory path needs 40 us for it (measured: the first form of this kernel assembled in place, with its lists in
 //            LDS and sixteen loads in flight per thread: 30 - 45 us against the assembly kernel's 6.5)
-//   phase 1  the schedule's levels one after the other, the work lists of a level side by side.  Level 0 (the independent subtrees): a list per WAVE, which walks its
-//            columns without any barrier (small_wave_column, below).  Levels above (separator chains, whose columns gather hundreds of products): each list with a TEAM
+//   phase 1  the schedule's levels one after the other, the work lists of a level side by side.  Level 0 (the independent subtrees): up to four lists -- a team of
+//            8 / lists waves per list, which share a column's gather and meet through LDS words (small_entry_gather + small_panel_sweep, below); more lists -- a list per
+//            lone wave (small_wave_column); no workgroup barrier inside a list either way.  Levels above (separator chains, whose columns gather hundreds of products): each list with a TEAM
 //            of 512 / lists threads (whole waves), in lock step: round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward substitution by the
-//            team's first wave, barrier, the blocks below, barrier.  (gp_sparse_system_set_one_launch(sys, 2): the team form for level 0 too, as first built.)
+//            team's first wave, barrier, the blocks below, barrier.  (gp_sparse_system_set_one_launch(sys, 2): the lock-step form for level 0 too, as first built; 3: lone waves throughout.)
 //   phase 2  the backward substitution, levels and columns in reverse: a list per wave, no barrier inside a list (the team form: two barriers per round)
 //   phase 3  x in slot order to the device array and the host, the status word
 // Every scalar is computed by the SAME sequence of operations as in sparse_factor_kernel<256> (lists of level 0) / sparse_factor_staged_kernel<1024> (levels above: the
@@ -1210,6 +1211,126 @@ __device__ __forceinline__ void small_wave_column(const int k, const int lane, d
   if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 
+// ---- a column by a TEAM of waves without workgroup barriers (the product where a level has at most four lists) ---------------------------------------------------------
+// What a lone wave's column costs is its instruction count, and 3700 of its 6400 clocks are the gather.  Here the gather is dealt ENTRY by entry over the G >= 2 waves of
+// the list's team (G = 8 / lists: BASELINE configs[2]'s two lists get four waves each; one entry per lane, its products subtracted in list order in place -- the lock-step
+// form's arithmetic: small_sub_products; the right-hand side's six entries on the team's last wave, beside the blocks' entries, not behind them), the waves meet at a
+// counter in LDS, the team's first wave sweeps the panel row by row (small_panel_sweep: small_wave_column's second half) and releases the others through a sequence word.
+// No s_barrier: the other lists' teams run on at their own pace (all eight waves are resident: a wave that polls never keeps the wave it waits for from running).
+// Measured (scripts/r06/solver_forms.py, solver_trace.py): a column 6400 -> 4100 clocks (gather + meeting 1850, sweep 1850, release 160), the kernel 276 k -> 245 k.
+__device__ __forceinline__ void small_entry_gather(const int k, const int wt, const int G, const int lane, double* Ls, double* ys, const int* colptr, const int* upd_ptr,
+                                                   const int* upd_a, const int* upd_b, const int* row_ptr, const int* row_blk, const int* row_col) {
+  const int base = colptr[k], nb = colptr[k + 1] - base;
+  const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
+  // the blocks' entries: one per lane, wave by wave
+  for (int e = wt * 64 + lane; e < 36 * nb; e += 64 * G) {
+    const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
+    double* dst = Ls + 36 * (size_t)d + 6 * r + c;
+    *dst = small_sub_products(*dst, upd_a, upd_b, upd_ptr[d], upd_ptr[d + 1], Ls, r, c);
+  }
+  // the right-hand side's six entries: the team's LAST wave, lanes 58-63 (another instruction stream than the blocks' entries: beside them, where that wave holds none --
+  // a column of five blocks leaves the fourth wave of four free --, not behind them)
+  {
+    if (wt == G - 1 && lane >= 58) {
+      const int r = lane - 58;
+      double acc = ys[6 * (size_t)k + r];
+      int u = rb;
+      const int ue = rb + nrow;
+      for (; u < ue; u += 4) {
+        int ib[4], ic[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const int uu = u + w < ue ? u + w : ue - 1;
+          ib[w] = row_blk[uu];
+          ic[w] = row_col[uu];
+        }
+        double av[4][6], yv[4][6];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)ib[w] + 6 * r);
+          const double2* Y = reinterpret_cast<const double2*>(ys + 6 * (size_t)ic[w]);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const double2 x = A[q], y2 = Y[q];
+            av[w][2 * q] = x.x, av[w][2 * q + 1] = x.y;
+            yv[w][2 * q] = y2.x, yv[w][2 * q + 1] = y2.y;
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+          if (u + w < ue) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc -= av[w][q] * yv[w][q];
+          }
+      }
+      ys[6 * (size_t)k + r] = acc;
+    }
+  }
+}
+// the gathered panel of column k, row by row (lanes 0-5 the diagonal block, lane 6 the right-hand side, lanes 7.. the rows of the blocks below): small_wave_column's sweep
+__device__ __forceinline__ void small_panel_sweep(const int k, const int lane, double* Ls, double* ys, double* dis, const double* d0s, const int* colptr, int* bad) {
+  const int base = colptr[k], nb = colptr[k + 1] - base;
+  const int rows = 6 * nb + 1;
+  double rl[6], pl[6], lcp[6][6], sc[6];
+#pragma unroll
+  for (int p = 0; p < 6; p++) sc[p] = d0s[6 * (size_t)k + p];
+  bool any_bad = false;
+  for (int c0 = 0; c0 < rows; c0 += 64) {
+    const int i = c0 + lane;
+    const bool act = i < rows;
+    const int ib = i < 7 ? 0 : (i - 7) / 6 + 1;
+    const int r = i < 6 ? i : (i < 7 ? 0 : (i - 7) % 6);
+    double* row = i == 6 ? ys + 6 * (size_t)k : Ls + 36 * (size_t)(base + ib) + 6 * r;
+    double a[6];
+    if (act) {
+      const double2* A = reinterpret_cast<const double2*>(row);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double2 x = A[q];
+        a[2 * q] = x.x, a[2 * q + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; c++) a[c] = 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+      if (c0 == 0) {
+        double piv = lane_bcast_f64(a[p], p);
+        if (!(piv > kPivotTolerance * sc[p])) {
+          any_bad = true;
+          piv = 1.0;
+        }
+        rl[p] = rsqrt_f64(piv);
+        pl[p] = piv * rl[p];
+      }
+      a[p] = (i == p) ? pl[p] : a[p] * rl[p];
+      if (c0 == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+          if (c > p) lcp[c][p] = lane_bcast_f64(a[p], c);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++)
+        if (c > p) a[c] = __builtin_fma(-a[p], lcp[c][p], a[c]);
+    }
+#pragma unroll
+    for (int c = 1; c < 6; c++) a[c] = (i < c) ? 0.0 : a[c];  // (rows 0-5 of the first pass: the diagonal block's upper triangle is stored as zeros)
+    if (act) {
+      double2* O = reinterpret_cast<double2*>(row);
+#pragma unroll
+      for (int q = 0; q < 3; q++) O[q] = make_double2(a[2 * q], a[2 * q + 1]);
+    }
+    if (c0 == 0 && lane < 6) {
+      double v = rl[0];
+#pragma unroll
+      for (int p = 1; p < 6; p++) v = lane == p ? rl[p] : v;
+      dis[6 * (size_t)k + lane] = v;
+    }
+  }
+  if (any_bad && lane == 0) *bad = 1;
+}
+
 // backward substitution of a column by ONE wave: the team form's operations (six slices of the blocks below, met in slice order, then back6) without its barriers
 __device__ __forceinline__ void small_wave_back_column(const int k, const int lane, const double* Ls, const double* ys, const double* dis, double* xs, const int* colptr,
                                                        const int* rowidx, double* scratch /* [48]: this wave's */) {
@@ -1264,6 +1385,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   double* scr = d0s + 6 * (size_t)V.P;                      // [kSmallTeams][kSmallTeamDoubles]
   int* idx = reinterpret_cast<int*>(scr + kSmallTeams * kSmallTeamDoubles);  // the index lists
   __shared__ int bad;
+  __shared__ unsigned team_arrive[kSmallTeams], team_done[kSmallTeams];  // (third form) the teams' handshakes: monotonic within a launch
   __shared__ unsigned long long tr_lds[64];  // (the stamps stay in LDS until the end: a store to memory in front of a fence would be waited for, and measured)
   const int t = threadIdx.x;
   const int* colptr = idx + V.o_colptr;
@@ -1309,6 +1431,41 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     const bool staged = lvl > 0;
     for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {  // (more than eight lists in a level: eight at a time)
       const int nb_lists = min(kSmallTeams, nlists - b0);
+      if (!staged && V.wave_columns == 1 && nb_lists <= kSmallThreads / 128) {
+        // level 0, up to four lists side by side: a team of G >= 2 waves per list -- gather by all of them (small_entry_gather), panel sweep by the first
+        // (small_panel_sweep), two LDS handshakes per column, no workgroup barrier
+        const int G = (kSmallThreads / 64) / nb_lists;
+        const int wv = t >> 6, team = wv / G, wt = wv % G, lane = t & 63;
+        if (t < kSmallTeams) team_arrive[t] = 0, team_done[t] = 0;
+        __syncthreads();
+        if (team < nb_lists) {
+          const int list = first + b0 + team;
+          unsigned seq = 0;
+          int rd = 0;
+          for (int w = work_ptr[list]; w < work_ptr[list + 1]; w++, rd++) {
+            const int k = work_cols[w];
+            const bool st = V.trace && t == 0 && b0 == 0 && rd < 14;
+            if (st) tr_lds[8 + 4 * rd] = __builtin_amdgcn_s_memtime();
+            small_entry_gather(k, wt, G, lane, Ls, ys, colptr, upd_ptr, upd_a, upd_b, row_ptr, row_blk, row_col);
+            GP_WAVE_SYNC_LDS();
+            seq++;
+            if (lane == 0) __hip_atomic_fetch_add(&team_arrive[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wt == 0) {
+              while (__hip_atomic_load(&team_arrive[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq * (unsigned)G) __builtin_amdgcn_s_sleep(1);
+              if (st) tr_lds[8 + 4 * rd + 1] = __builtin_amdgcn_s_memtime();
+              small_panel_sweep(k, lane, Ls, ys, dis, d0s, colptr, &bad);
+              GP_WAVE_SYNC_LDS();
+              if (st) tr_lds[8 + 4 * rd + 2] = __builtin_amdgcn_s_memtime();
+              if (lane == 0) __hip_atomic_store(&team_done[team], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              while (__hip_atomic_load(&team_done[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+            }
+            if (st) tr_lds[8 + 4 * rd + 3] = __builtin_amdgcn_s_memtime();
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       if (!staged && V.wave_columns) {
         // level 0: a work list per WAVE, no barrier between its columns (small_wave_column)
         const int wv = t >> 6;
@@ -1742,8 +1899,8 @@ int gp_debug_sparse_step_trace(gp_sparse_system_t* s, unsigned long long* dev_bu
 int gp_sparse_system_set_one_launch(gp_sparse_system_t* s, int enable) {
   if (!s) return 0;
   s->one_launch = enable != 0 && s->small_ok;
-  s->small.wave_columns = enable == 2 ? 0 : 1;  // 2: the one-launch step's first form (teams of waves in lock step) -- kept for the bit-identity test and A/B timing
-  return s->one_launch ? (s->small.wave_columns ? 1 : 2) : 0;
+  s->small.wave_columns = enable == 2 ? 0 : (enable == 3 ? 3 : 1);  // 3: a list per (lone) wave whatever the number of lists  // 2: the one-launch step's first form (teams of waves in lock step) -- kept for the bit-identity test and A/B timing
+  return s->one_launch ? (s->small.wave_columns == 3 ? 3 : (s->small.wave_columns ? 1 : 2)) : 0;
 }
 
 int gp_sparse_system_destroy(gp_sparse_system_t* s) {

@@ -174,9 +174,10 @@ class SparseLinearSystemGPU:
 
     def set_one_launch(self, enable=True):
         """step() of a system whose factor fits one compute unit's LDS (<= 128 poses, <= ~440 blocks of L) runs as ONE launch by default; False selects the multi-launch
-        form, "teams" the one-launch step's first form (teams of waves in lock step instead of a work list per wave) -- all bit-identical: the switch is for the test that
+        form, "teams" the one-launch step's first form (every list a team of waves in lock step), "lone-waves" its second (a work list per wave; the default gives a list a team of
+        waves that meet without workgroup barriers where the level has at most four lists, and a lone wave otherwise) -- all bit-identical: the switch is for the test that
         says so and for timing.  Returns what the next step() runs (True: one launch)."""
-        return bool(self._lib.gp_sparse_system_set_one_launch(self._h, 2 if enable == "teams" else (1 if enable else 0)))
+        return bool(self._lib.gp_sparse_system_set_one_launch(self._h, 2 if enable == "teams" else (3 if enable == "lone-waves" else (1 if enable else 0))))
 
     def info(self):
         na, nl, bp, ns, nt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int()

@@ -61,6 +61,9 @@ def main():
                 if sp.set_one_launch("teams"):  # the one-launch step's first form: every list a team of waves in lock step
                     med, mn, x_teams = timed(sp, rec_dev, out)
                     row.update(one_launch_teams_ms=round(med, 4), teams_bit_identical=bool(np.array_equal(x_teams, x_one)))
+                if sp.set_one_launch("lone-waves"):  # ... its second: a work list per (lone) wave
+                    med, mn, x_lone = timed(sp, rec_dev, out)
+                    row.update(one_launch_lone_waves_ms=round(med, 4), lone_waves_bit_identical=bool(np.array_equal(x_lone, x_one)))
             sp.set_one_launch(False)
             med, mn, x = timed(sp, rec_dev, out)
             row.update(multi_launch_ms=round(med, 4), multi_launch_ms_min=round(mn, 4), bit_identical=bool(np.array_equal(x, x_one)) if x_one is not None else None)

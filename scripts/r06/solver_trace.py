@@ -18,7 +18,8 @@ for n in (64, 16):
     slots = graph(n)
     rec_dev = torch.from_numpy(records(slots)).cuda()
     sp = gpa.SparseLinearSystemGPU(n - 1, slots)
-    assert sp.set_one_launch(True)
+    FORM = sys.argv[1] if len(sys.argv) > 1 else True  # "teams" / "wave-teams": the other forms
+    assert sp.set_one_launch(FORM)
     tr = torch.zeros(64, dtype=torch.int64, device="cuda")
     out = (np.zeros(sp.size), np.zeros(sp.size), np.zeros(1))
     for _ in range(50):
@@ -30,4 +31,4 @@ for n in (64, 16):
     lib.gp_debug_sparse_step_trace(sp._h, None)
     ph = [int(w[i] - w[0]) for i in range(7)]
     rounds = [[int(w[8 + 4 * r + q] - w[8 + 4 * r]) for q in range(1, 4)] + [int(w[8 + 4 * (r + 1)] - w[8 + 4 * r]) if r < 13 and w[8 + 4 * (r + 1)] else None] for r in range(14) if w[8 + 4 * r]]
-    print(json.dumps(dict(poses=n, phase_clocks=dict(system_in_lds=ph[5], factored=ph[2], substituted=ph[3], end=ph[4]), first_level_rounds_clocks_gather_diag_below_next=rounds)))
+    print(json.dumps(dict(form=str(FORM), poses=n, phase_clocks=dict(system_in_lds=ph[5], factored=ph[2], substituted=ph[3], end=ph[4]), first_level_rounds_clocks_gather_diag_below_next=rounds)))

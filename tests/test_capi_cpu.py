@@ -250,3 +250,26 @@ def test_solver_step_refuses_out_buffers_it_would_overrun():
                 (np.zeros(n), np.zeros(n), np.zeros(2)), (np.zeros(n), np.zeros(n)), (list(range(n)), np.zeros(n), np.zeros(1))]:
         with pytest.raises(ValueError):
             _step_out(bad, n)
+
+
+def test_lm_params_default_and_argument_checks_without_a_device():
+    """gp_lm_params_default is host code (GTSAM's LevenbergMarquardtParams defaults the loop reads); the graph's entry points refuse null handles before touching a device"""
+    import ctypes as C
+
+    from gtsam_points_amd import _capi
+
+    lib = _capi.load()
+    p = _capi.LmParams()
+    lib.gp_lm_params_default(C.byref(p))
+    assert (p.lambda_initial, p.lambda_factor, p.lambda_upper_bound, p.lambda_lower_bound) == (1e-5, 10.0, 1e5, 0.0)  # LevenbergMarquardtParams.h defaults
+    assert (p.relative_error_tol, p.absolute_error_tol, p.min_model_fidelity) == (1e-5, 1e-5, 1e-3)
+    assert p.max_iterations == 100 and p.diagonal_damping == 0
+    assert C.sizeof(_capi.LmParams) == 80 and C.sizeof(_capi.LmSummary) == 32  # the header's layout
+    h = C.c_void_p()
+    assert lib.gp_lm_graph_create(None, None, 2, None, 4, C.byref(h)) == 1 and not h.value  # GP_ERROR_INVALID_ARGUMENT
+    assert lib.gp_lm_graph_num_variables(None) == 0 and lib.gp_lm_graph_destroy(None) == 0
+    for fn, args in ((lib.gp_lm_graph_linearize, (None,)), (lib.gp_lm_graph_accept, (None,)), (lib.gp_lm_graph_set_values, (None, None)),
+                     (lib.gp_lm_graph_try_lambda, (None, 1.0, 0, 1e-6, 1e32, None, None, None, None, None)), (lib.gp_lm_graph_optimize, (None, None, None))):
+        assert fn(*args) == 1
+    assert lib.gp_vgicp_batch_issue_linearize_dev(None, None, 1, None) == 1 and lib.gp_vgicp_batch_compute_error_dev(None, None, None, None) == 1
+    assert lib.gp_sparse_system_finish_step(None, None, None, None) == 1 and lib.gp_dense_system_collect_step(None, None, None, None) == 1

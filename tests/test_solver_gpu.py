@@ -375,8 +375,10 @@ def test_one_launch_step_is_bit_identical(gpu, graph, ordering):
         assert sym["nnz_l_blocks"] > 340, sym  # (only a factor too large for the LDS may decline: the dissection of the 64-pose band graph, 522 blocks; a 128-pose chain's 369)
         pytest.skip(f"{sym['nnz_l_blocks']} blocks of L do not fit one compute unit's LDS: multi-launch only")
     assert multi.set_one_launch(False) is False
-    teams = gpu.SparseLinearSystemGPU(P, slots, ordering=ordering)  # the one-launch step's first form: teams of waves in lock step instead of a work list per wave
+    teams = gpu.SparseLinearSystemGPU(P, slots, ordering=ordering)  # the one-launch step's first form: every list a team of waves in lock step
     assert teams.set_one_launch("teams") is True
+    lone = gpu.SparseLinearSystemGPU(P, slots, ordering=ordering)  # ... its second: a work list per lone wave (the default form teams waves up where a level has <= 4 lists)
+    assert lone.set_one_launch("lone-waves") is True
     prior = rng.uniform(0.0, 2.0, 6 * P)
     Ah, bh, ch = _host_system(rec, slots, P)
     for lam, diag, pr in [(1e-5, False, None), (0.0, False, None), (1e-3, False, None), (10.0, True, None), (1e-2, False, prior), (0.5, True, prior)]:
@@ -384,6 +386,7 @@ def test_one_launch_step_is_bit_identical(gpu, graph, ordering):
         xm, bm, cm = multi.step(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)
         assert np.array_equal(x1, xm) and np.array_equal(b1, bm) and c1 == cm, (lam, diag, pr is not None, float(np.abs(x1 - xm).max()))
         assert np.array_equal(teams.step(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)[0], xm)
+        assert np.array_equal(lone.step(rec_dev, lam=lam, diagonal_damping=diag, prior_diag=pr)[0], xm)
         damp = lam * np.diag(np.clip(np.diag(Ah), 1e-6, 1e32)) if diag else lam * np.eye(6 * P)
         if kind != "freechain" or lam > 0.0 or pr is not None:  # (the free chain's undamped system has the gauge freedom: both forms factor it alike, numpy has no say)
             want = np.linalg.solve(Ah + damp + (np.diag(pr) if pr is not None else 0.0), bh)
@@ -396,7 +399,7 @@ def test_one_launch_step_is_bit_identical(gpu, graph, ordering):
     rec0 = rec.copy()
     rec0[:, 2:110] = 0.0
     rec0_dev = torch.from_numpy(rec0).cuda()
-    for sysm in (one, multi, teams):
+    for sysm in (one, multi, teams, lone):
         out = (np.full(6 * P, 7.0), np.zeros(6 * P), np.zeros(1))
         with pytest.raises(gpu.GPError):
             sysm.step(rec0_dev, out=out)
