@@ -397,7 +397,7 @@ constexpr int kSmallTeamDoubles = 158;  // per team: D[6][7] | rhs[6] | v[6] (ba
 static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_out = nullptr) {
   const size_t P = (size_t)S.P, nnzL = (size_t)S.colptr[S.P];
   const size_t words = S.colptr.size() + S.rowidx.size() + S.upd_ptr.size() + S.upd_a.size() + S.upd_b.size() + S.row_ptr.size() + S.row_blk.size() + S.row_col.size() +
-                       S.work_ptr.size() + S.work_cols.size() + 2;
+                       S.work_ptr.size() + S.work_cols.size() + S.rowidx.size() /* the blocks' columns */ + 2;
   if (arena_words_out) *arena_words_out = words;
   if (P > 128) return 0;  // (row lists stay below the staged kernel's 128-block stage, which the one-launch form assumes)
   const size_t bytes = sizeof(double) * (36 * nnzL + 24 * P + (size_t)kSmallTeams * kSmallTeamDoubles) + sizeof(int) * words + 64;
@@ -1217,7 +1217,8 @@ __device__ __forceinline__ void small_wave_column(const int k, const int lane, d
 // form's arithmetic: small_sub_products; the right-hand side's six entries on the team's last wave, beside the blocks' entries, not behind them), the waves meet at a
 // counter in LDS, the team's first wave sweeps the panel row by row (small_panel_sweep: small_wave_column's second half) and releases the others through a sequence word.
 // No s_barrier: the other lists' teams run on at their own pace (all eight waves are resident: a wave that polls never keeps the wave it waits for from running).
-// Measured (scripts/r06/solver_forms.py, solver_trace.py): a column 6400 -> 4100 clocks (gather + meeting 1850, sweep 1850, release 160), the kernel 276 k -> 245 k.
+// Measured (scripts/r06/solver_forms.py, solver_trace.py): a column 6400 -> 4100 clocks (gather + meeting 1850, sweep 1850, release 160), the kernel 276 k -> 245 k;
+// pipelined (sparse_small_step_kernel: the other waves start the next column's older products during the sweep) 3650 clocks, 235 k.
 __device__ __forceinline__ void small_entry_gather(const int k, const int wt, const int G, const int lane, double* Ls, double* ys, const int* colptr, const int* upd_ptr,
                                                    const int* upd_a, const int* upd_b, const int* row_ptr, const int* row_blk, const int* row_col) {
   const int base = colptr[k], nb = colptr[k + 1] - base;
@@ -1266,6 +1267,42 @@ __device__ __forceinline__ void small_entry_gather(const int k, const int wt, co
       ys[6 * (size_t)k + r] = acc;
     }
   }
+}
+// the forward substitution's right-hand side of column k, entry r (on: this lane holds one): b_k[r] - sum over the row list of L_kj[r, :] . y_j, in list order, in place
+__device__ __forceinline__ void small_rhs_gather(const int k, const int r, const bool on, const double* Ls, double* ys, const int* row_ptr, const int* row_blk, const int* row_col) {
+  if (!on) return;
+  const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
+  double acc = ys[6 * (size_t)k + r];
+  int u = rb;
+  const int ue = rb + nrow;
+  for (; u < ue; u += 4) {
+    int ib[4], ic[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const int uu = u + w < ue ? u + w : ue - 1;
+      ib[w] = row_blk[uu];
+      ic[w] = row_col[uu];
+    }
+    double av[4][6], yv[4][6];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)ib[w] + 6 * r);
+      const double2* Y = reinterpret_cast<const double2*>(ys + 6 * (size_t)ic[w]);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double2 x = A[q], y2 = Y[q];
+        av[w][2 * q] = x.x, av[w][2 * q + 1] = x.y;
+        yv[w][2 * q] = y2.x, yv[w][2 * q + 1] = y2.y;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+      if (u + w < ue) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc -= av[w][q] * yv[w][q];
+      }
+  }
+  ys[6 * (size_t)k + r] = acc;
 }
 // the gathered panel of column k, row by row (lanes 0-5 the diagonal block, lane 6 the right-hand side, lanes 7.. the rows of the blocks below): small_wave_column's sweep
 __device__ __forceinline__ void small_panel_sweep(const int k, const int lane, double* Ls, double* ys, double* dis, const double* d0s, const int* colptr, int* bad) {
@@ -1366,7 +1403,7 @@ struct SparseSmallView {
   const int* arena;       // global copy of the index lists below, `arena_words` ints, copied to LDS first
   const int* level_ptr;   // [num_levels + 1] -> work lists (global; read once per level)
   int arena_words, num_levels, P, nnzL;
-  int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols;  // offsets (ints) inside the arena
+  int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols, o_blkcol;  // offsets (ints) inside the arena (blkcol: block -> its column)
   const int* perm;        // elimination order -> slot (global)
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
@@ -1398,6 +1435,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   const int* row_col = idx + V.o_row_col;
   const int* work_ptr = idx + V.o_work_ptr;
   const int* work_cols = idx + V.o_work_cols;
+  const int* blkcol = idx + V.o_blkcol;
   // ---- phase 0 ----
 #define GP_SMALL_STAMP(i)                                                       \
   do {                                                                          \
@@ -1438,6 +1476,77 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
         const int wv = t >> 6, team = wv / G, wt = wv % G, lane = t & 63;
         if (t < kSmallTeams) team_arrive[t] = 0, team_done[t] = 0;
         __syncthreads();
+        // pipelined (every column of the list leaves the team's first wave free of entries: 36 nb <= 64 (G - 1)): the first wave gathers the right-hand side and sweeps;
+        // the others gather the blocks' entries -- and, while the first wave sweeps column k, already the products of the NEXT column that do not come from column k
+        // (only the previous column of the list can still be in the making: every other source column was swept before it); the product from column k, last in its
+        // list, follows when the sweep is released.  Same products in the same order per entry: the same bits.
+        bool pipe = V.wave_columns == 1 && G >= 2 && team < nb_lists;
+        if (pipe) {
+          const int list = first + b0 + team;
+          for (int w = work_ptr[list]; w < work_ptr[list + 1]; w++) {
+            const int kk = work_cols[w];
+            if (36 * (colptr[kk + 1] - colptr[kk]) > 64 * (G - 1)) pipe = false;
+          }
+        }
+        if (pipe) {
+          const int list = first + b0 + team;
+          const int wb = work_ptr[list], we = work_ptr[list + 1];
+          if (wt == 0) {
+            unsigned seq = 0;
+            int rd = 0;
+            for (int w = wb; w < we; w++, rd++) {
+              const int k = work_cols[w];
+              const bool st = V.trace && t == 0 && b0 == 0 && rd < 14;
+              if (st) tr_lds[8 + 4 * rd] = __builtin_amdgcn_s_memtime();
+              small_rhs_gather(k, lane - 58, lane >= 58, Ls, ys, row_ptr, row_blk, row_col);
+              GP_WAVE_SYNC_LDS();
+              seq++;
+              while (__hip_atomic_load(&team_arrive[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq * (unsigned)(G - 1)) __builtin_amdgcn_s_sleep(1);
+              if (st) tr_lds[8 + 4 * rd + 1] = __builtin_amdgcn_s_memtime();
+              small_panel_sweep(k, lane, Ls, ys, dis, d0s, colptr, &bad);
+              GP_WAVE_SYNC_LDS();
+              if (st) tr_lds[8 + 4 * rd + 2] = __builtin_amdgcn_s_memtime();
+              if (lane == 0) __hip_atomic_store(&team_done[team], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (st) tr_lds[8 + 4 * rd + 3] = __builtin_amdgcn_s_memtime();
+            }
+          } else {
+            const int e = (wt - 1) * 64 + lane;
+            double acc = 0.0;
+            bool started = false;  // the entry's value and its older products are already in acc
+            unsigned seq = 0;
+            for (int w = wb; w < we; w++) {
+              const int k = work_cols[w], kprev = w > wb ? work_cols[w - 1] : -1;
+              const int base = colptr[k], nb = colptr[k + 1] - base;
+              const bool mine = e < 36 * nb;
+              const int d = base + (mine ? e / 36 : 0), r = (e % 36) % 6, c = (e % 36) / 6;
+              double* dst = Ls + 36 * (size_t)d + 6 * r + c;
+              const int u0 = upd_ptr[d], ue = upd_ptr[d + 1];
+              const bool tail = mine && ue > u0 && blkcol[upd_a[ue - 1]] == kprev;  // the last product comes from the column in the making
+              if (mine && !started) acc = small_sub_products(*dst, upd_a, upd_b, u0, ue - (tail ? 1 : 0), Ls, r, c);
+              if (seq > 0)
+                while (__hip_atomic_load(&team_done[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+              if (tail) acc = small_sub_products(acc, upd_a, upd_b, ue - 1, ue, Ls, r, c);
+              if (mine) *dst = acc;
+              GP_WAVE_SYNC_LDS();
+              seq++;
+              if (lane == 0) __hip_atomic_fetch_add(&team_arrive[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              started = false;
+              if (w + 1 < we) {  // the next column's older products, while the first wave sweeps this one
+                const int kn = work_cols[w + 1];
+                const int bn = colptr[kn], nbn = colptr[kn + 1] - bn;
+                if (e < 36 * nbn) {
+                  const int dn = bn + e / 36;
+                  const int v0 = upd_ptr[dn], ve = upd_ptr[dn + 1];
+                  const bool tn = ve > v0 && blkcol[upd_a[ve - 1]] == k;
+                  acc = small_sub_products(Ls[36 * (size_t)dn + 6 * r + c], upd_a, upd_b, v0, ve - (tn ? 1 : 0), Ls, r, c);
+                }
+                started = true;
+              }
+            }
+          }
+          __syncthreads();
+          continue;
+        }
         if (team < nb_lists) {
           const int list = first + b0 + team;
           unsigned seq = 0;
@@ -1849,11 +1958,14 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
   size_t small_words = 0;
   s->small_lds_bytes = gp::small_step_lds_bytes(S, &small_words);
   if (s->small_lds_bytes) {
-    const std::vector<int>* sa[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols};
+    std::vector<int> blkcol((size_t)nnzL);
+    for (int k = 0; k < P; k++)
+      for (int q = S.colptr[k]; q < S.colptr[k + 1]; q++) blkcol[(size_t)q] = k;
+    const std::vector<int>* sa[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols, &blkcol};
     std::vector<int> arena;
     arena.reserve(small_words);
-    int off[10];
-    for (int i = 0; i < 10; i++) {
+    int off[11];
+    for (int i = 0; i < 11; i++) {
       off[i] = (int)arena.size();
       arena.insert(arena.end(), sa[i]->begin(), sa[i]->end());
     }
@@ -1870,7 +1982,7 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     V.level_ptr = s->d_level_ptr.as<int>();
     V.arena_words = (int)arena.size(), V.num_levels = (int)S.level_ptr.size() - 1, V.P = P, V.nnzL = nnzL;
     V.o_colptr = off[0], V.o_rowidx = off[1], V.o_upd_ptr = off[2], V.o_upd_a = off[3], V.o_upd_b = off[4], V.o_row_ptr = off[5], V.o_row_blk = off[6], V.o_row_col = off[7];
-    V.o_work_ptr = off[8], V.o_work_cols = off[9];
+    V.o_work_ptr = off[8], V.o_work_cols = off[9], V.o_blkcol = off[10];
     V.perm = s->d_perm;
     V.wave_columns = 1;
     V.x_slots = s->x_slots.as<double>();
