@@ -18,6 +18,8 @@
 //   gp_lm_graph_optimize     the reference's cadence over those three (tryLambda's tests :262-292, decreaseLambda / increaseLambda with the GTSAM defaults)
 // Pose arithmetic on the device = the formulas of gtsam::Pose3 (Expmap with the closed-form V, compose, inverse() * other) in f64; the host-side harness
 // (bench_lm.py) computes the same with numpy, and the two agree to rounding (tests/test_lm_gpu.py).
+// Device: the graph is created on the device that is current (the batch's: gp_set_device first in a multi-device process), like the batch and the systems it builds.
+// Not thread-safe per handle, re-entrant across handles, like the rest of the library.
 #include <cmath>
 #include <cstring>
 #include <limits>

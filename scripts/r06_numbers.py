@@ -159,13 +159,21 @@ def lm():
 
 def solver():
     rows = jl("r06_solver_step_time.jsonl")
-    out = ["| graph (structure of the damped system) | ordering | levels / critical columns / blocks of L | assembly + ONE launch (`sparse_small_step_kernel`: a work list per wave) ms | … its first form (teams of waves in lock step) ms | multi-launch ms | bit-identical |", "|---|---|---|---|---|---|---|"]
+    out = ["| graph (structure of the damped system) | ordering | levels / critical columns / blocks of L | assembly + ONE launch (`sparse_small_step_kernel`; the product: a team of waves per list, pipelined) ms | … a lone wave per list ms | … its first form (teams of waves in lock step) ms | multi-launch ms | bit-identical |",
+           "|---|---|---|---|---|---|---|---|"]
     for x in rows:
         if x["ordering"] not in ("auto", "natural"):
             continue
-        out.append(f"| {x['graph']} | {x['ordering']} | {x['levels']} / {x['critical_columns']} / {x['l_blocks']} | " + (f"{x['one_launch_ms']:.4f}" if x.get("one_launch_ms") is not None else "does not fit the LDS") +
-                   " | " + (f"{x['one_launch_teams_ms']:.4f}" if x.get("one_launch_teams_ms") is not None else "—") +
-                   f" | {x['multi_launch_ms']:.4f} | {(x.get('bit_identical') and x.get('teams_bit_identical', True)) if x.get('bit_identical') is not None else '—'} |")
+        f = lambda k: f"{x[k]:.4f}" if x.get(k) is not None else "—"  # noqa: E731
+        same = (x.get("bit_identical") and x.get("teams_bit_identical", True) and x.get("lone_waves_bit_identical", True)) if x.get("bit_identical") is not None else "—"
+        out.append(f"| {x['graph']} | {x['ordering']} | {x['levels']} / {x['critical_columns']} / {x['l_blocks']} | " + (f"**{x['one_launch_ms']:.4f}**" if x.get("one_launch_ms") is not None else "does not fit the LDS") +
+                   f" | {f('one_launch_lone_waves_ms')} | {f('one_launch_teams_ms')} | {x['multi_launch_ms']:.4f} | {same} |")
+    tr = jl("r06_solver_trace.jsonl")
+    if tr:
+        out.append("")
+        out.append("Thread 0's stamps on configs[2]'s structure (`scripts/r06/solver_trace.py`, shader clocks): " + "; ".join(
+            f"{ {'True': 'the product', 'lone-waves': 'a lone wave per list', 'teams': 'teams in lock step'}.get(x['form'], x['form']) }: kernel {x['phase_clocks']['end'] / 1e3:.0f} k (factorisation {(x['phase_clocks']['factored'] - x['phase_clocks']['system_in_lds']) / 1e3:.0f} k, "
+            f"backward substitution {(x['phase_clocks']['substituted'] - x['phase_clocks']['factored']) / 1e3:.0f} k), a steady column {x['first_level_rounds_clocks_gather_diag_below_next'][8][3]}" for x in tr) + ".")
     return "\n".join(out)
 
 
