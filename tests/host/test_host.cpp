@@ -446,30 +446,35 @@ int main() {
     roundrobin.sync_all();
     auto f_bin = std::make_shared<IntegratedVGICPFactorGPU>(0, 1, voxels, source);
     auto f_un = std::make_shared<IntegratedVGICPFactorGPU>(world, 1, voxels, source);
+    gtsam::Values start;  // (`values` has been optimised by the loops above: start again from the perturbed pose)
+    start.insert(0, world);
+    start.insert(1, T_true * gtsam::Pose3::Expmap(xi6(0.03, -0.02, 0.04, 0.1, 0.08, -0.05)));
     LevenbergMarquardtGraphGPU lm({f_bin, f_un}, {0});
     CHECK(lm.dim() == 6 && lm.ordered_keys().size() == 2);
-    lm.set_values(values);
+    lm.set_values(start);
     lm.linearize();
     std::vector<double> dx, bvec;
     double c = 0.0, e_new = 0.0;
     CHECK(lm.try_lambda(1e-5, &dx, &bvec, &c, &e_new));
-    auto h_bin = std::dynamic_pointer_cast<gtsam::HessianFactor>(f_bin->linearize(values));
-    auto h_un = std::dynamic_pointer_cast<gtsam::HessianFactor>(f_un->linearize(values));
+    auto h_bin = std::dynamic_pointer_cast<gtsam::HessianFactor>(f_bin->linearize(start));
+    auto h_un = std::dynamic_pointer_cast<gtsam::HessianFactor>(f_un->linearize(start));
     CHECK(std::fabs(c - (h_bin->f + h_un->f)) <= 1e-9 * c);  // the cost at the linearisation point = the two factors' own
     CHECK(dx.size() == 6 && e_new < c);                      // the step decreases the cost on the frozen correspondences
     // the trial's error == the factors' own error() at the retracted values (pose 1 <- pose 1 * Expmap(dx))
     gtsam::Values trial;
     trial.insert(0, world);
-    trial.insert(1, values.at<gtsam::Pose3>(1).retract(xi6(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5])));
+    trial.insert(1, start.at<gtsam::Pose3>(1).retract(xi6(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5])));
     const double e_host = f_bin->error(trial) + f_un->error(trial);
     CHECK(std::fabs(e_new - e_host) <= 1e-8 * e_host);
     lm.accept();
     const gtsam::Values after_one = lm.values();
     CHECK((after_one.at<gtsam::Pose3>(1).matrix() - trial.at<gtsam::Pose3>(1).matrix()).norm() < 1e-12 && (after_one.at<gtsam::Pose3>(0).matrix() - world.matrix()).norm() == 0.0);
     // the library's loop from the start values: ends at the generator's pose
-    lm.set_values(values);
+    lm.set_values(start);
     const gp_lm_summary sum = lm.optimize();
-    CHECK(sum.iterations >= 2 && sum.inner_iterations >= sum.iterations && !sum.gave_up && sum.final_error < e_new);
+    std::printf("lm graph: %d iterations (%d trials), final error %.6g (start %.6g, first trial %.6g), lambda %.3g\n", sum.iterations, sum.inner_iterations, sum.final_error, c, e_new, sum.final_lambda);
+    // (final_error is measured on the LAST linearisation's correspondences, e_new on the first one's: they are not comparable; the start cost is an upper bound of both)
+    CHECK(sum.iterations >= 2 && sum.inner_iterations >= sum.iterations && !sum.gave_up && sum.final_error < c);
     const Eigen::Matrix4d E = T_true.inverse().matrix() * lm.values().at<gtsam::Pose3>(1).matrix();
     const double ang = std::acos(std::min(1.0, std::max(-1.0, (E.block<3, 3>(0, 0).trace() - 1.0) / 2.0))), tr = E.block<3, 1>(0, 3).norm();
     CHECK(ang < 0.015 && tr < 0.15);  // test_matching_cost_factors.cpp:227

@@ -209,3 +209,41 @@ def test_trial_graph_with_one_free_pose_and_without_a_gauge(gpu, kitti07):
     with pytest.raises(gpu.GPError, match="lambda I damping only"):
         free.optimize(diagonal_damping=1)
     free.close()
+
+
+def test_one_large_factor_through_the_device_pose_entry_points(gpu):
+    """a single factor of >= 65536 points is a PLANNED batch (its tile list is the balanced stream plan, its host-pose calls carry pose and descriptor in the kernel
+    arguments): the device-pose entry points read the same plan out of the tile table -- same records, same error, bit for bit -- and the LM graph over it converges"""
+    import ctypes as C
+
+    import torch
+    from gtsam_points_amd import _capi, synthetic
+
+    d = synthetic.make_pair(120000, 200000, seed=5)
+    tgt, src = gpu.PointCloudGPU(d["target_points"], d["target_covs"]), gpu.PointCloudGPU(d["source_points"], d["source_covs"])
+    vm = gpu.GaussianVoxelMapGPU(0.5, target_points_drop_rate=0.0)
+    vm.insert(tgt)
+    f = gpu.IntegratedVGICPFactorGPU(0, 1, vm, src)
+    lib = gpu.load()
+    delta = d["T_true"] @ synthetic.expmap([0.004, -0.002, 0.003, 0.03, -0.02, 0.025])
+    p_lin, p_eval = bench_lm._poses16(delta[None]), bench_lm._poses16(d["T_true"][None])
+    batch = C.c_void_p()
+    _capi.check(lib.gp_vgicp_batch_create((C.c_void_p * 1)(f._h.value), 1, None, C.byref(batch)), "batch")
+    rec = [torch.zeros((1, 122), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    err = [torch.zeros(1, dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    e_sync = np.zeros(1)
+    d_lin, d_eval = torch.from_numpy(p_lin).cuda(), torch.from_numpy(p_eval).cuda()
+    torch.cuda.synchronize()
+    _capi.check(lib.gp_vgicp_batch_issue_linearize(batch, p_lin.ctypes.data, C.c_void_p(rec[0].data_ptr())), "host pose")
+    _capi.check(lib.gp_vgicp_batch_issue_linearize_dev(batch, C.c_void_p(d_lin.data_ptr()), 1, C.c_void_p(rec[1].data_ptr())), "device pose")
+    _capi.check(lib.gp_vgicp_batch_issue_compute_error(batch, p_lin.ctypes.data, p_eval.ctypes.data, C.c_void_p(err[0].data_ptr())), "host pose")
+    _capi.check(lib.gp_vgicp_batch_issue_compute_error_dev(batch, C.c_void_p(d_lin.data_ptr()), C.c_void_p(d_eval.data_ptr()), C.c_void_p(err[1].data_ptr())), "device pose")
+    _capi.check(lib.gp_vgicp_batch_compute_error_dev(batch, C.c_void_p(d_lin.data_ptr()), C.c_void_p(d_eval.data_ptr()), e_sync.ctypes.data), "device pose, polled")
+    _capi.check(lib.gp_vgicp_batch_sync(batch), "sync")
+    lib.gp_vgicp_batch_destroy(batch)
+    assert rec[0][0, 0].item() > 100000 and torch.equal(rec[0], rec[1]) and torch.equal(err[0], err[1]) and e_sync[0] == err[0].item()
+    lm = gpu.LevenbergMarquardtGraphGPU([f], [(0, 1)], 2, fixed=(0,))
+    values, s = lm.optimize(np.stack([np.eye(4), delta]))
+    ang, tr = bench_lm.pose_error(values[1], d["T_true"])
+    assert s["iterations"] >= 2 and not s["gave_up"] and ang < 2e-3 and tr < 2e-2, (s, ang, tr)
+    lm.close()
