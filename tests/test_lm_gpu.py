@@ -247,3 +247,30 @@ def test_one_large_factor_through_the_device_pose_entry_points(gpu):
     ang, tr = bench_lm.pose_error(values[1], d["T_true"])
     assert s["iterations"] >= 2 and not s["gave_up"] and ang < 2e-3 and tr < 2e-2, (s, ang, tr)
     lm.close()
+
+
+def test_rejected_trials_take_the_same_path_in_both_loops(gpu, kitti07):
+    """model-fidelity bars the steps miss -- 1.99: some trials are dropped and lambda climbs before a step is taken; 3: every trial is dropped until lambda reaches its
+    upper bound and the loop gives up where it started -- each dropped trial with the speculative linearise behind it thrown away: the library's loop and the interpreter
+    driving its three calls take the same decisions and end on the same bits, with and without speculation"""
+    factors, pairs, truth, v0, keep = _kitti_graph(gpu, kitti07)
+    truth, v0 = _rigid(truth), _rigid(v0)
+    tg = bench_lm.GpuTrialGraph(gpu, factors, pairs, 5, fixed=0)
+    rejected = 0
+    for bar in (1.99, 3.0):  # (the factors' cost is r^T M r without the 1/2 of the quadratic model: a perfect step has fidelity 2)
+        res = bench_lm.run_lm(tg, v0, max_iterations=12, min_fidelity=bar)
+        rejected += res["inner_iterations"] - res["iterations"]
+        out = {}
+        for spec in (True, False):
+            tg.g.set_speculation(spec)
+            tg.g.set_values(v0)
+            values, s = tg.g.optimize(max_iterations=12, min_model_fidelity=bar)
+            out[spec] = values
+            assert s["iterations"] == res["iterations"] and s["inner_iterations"] == res["inner_iterations"], (bar, s, res["iterations"], res["inner_iterations"])
+            assert s["final_lambda"] == res["final_lambda"] and np.array_equal(values, res["values"]), (bar, s)
+        assert np.array_equal(out[True], out[False])
+        if bar > 2.0:
+            # (no step is ever taken: the search ends when lambda reaches its bound or -- tryLambda's other exit -- when a damped step no longer changes the cost)
+            assert res["iterations"] == 1 and res["inner_iterations"] >= 5 and np.array_equal(values, v0), (s, res["inner_iterations"])
+    assert rejected >= 5
+    tg.close()
