@@ -1305,12 +1305,29 @@ __device__ __forceinline__ void small_rhs_gather(const int k, const int r, const
   ys[6 * (size_t)k + r] = acc;
 }
 // the gathered panel of column k, row by row (lanes 0-5 the diagonal block, lane 6 the right-hand side, lanes 7.. the rows of the blocks below): small_wave_column's sweep
-__device__ __forceinline__ void small_panel_sweep(const int k, const int lane, double* Ls, double* ys, double* dis, const double* d0s, const int* colptr, int* bad) {
-  const int base = colptr[k], nb = colptr[k + 1] - base;
+// what the sweep of a column reads that does not depend on the gather: requested by the caller BEFORE it waits for the gathering waves
+struct SmallSweepHead {
+  int base, nb;
+  double sc[6];  // the assembled diagonal entries the pivots are held against
+};
+__device__ __forceinline__ SmallSweepHead small_sweep_head(const int k, const double* d0s, const int* colptr) {
+  SmallSweepHead h;
+  h.base = colptr[k];
+  h.nb = colptr[k + 1] - h.base;
+  const double2* d = reinterpret_cast<const double2*>(d0s + 6 * (size_t)k);
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const double2 x = d[q];
+    h.sc[2 * q] = x.x, h.sc[2 * q + 1] = x.y;
+  }
+  return h;
+}
+__device__ __forceinline__ void small_panel_sweep(const int k, const SmallSweepHead& head, const int lane, double* Ls, double* ys, double* dis, int* bad) {
+  const int base = head.base, nb = head.nb;
   const int rows = 6 * nb + 1;
   double rl[6], pl[6], lcp[6][6], sc[6];
 #pragma unroll
-  for (int p = 0; p < 6; p++) sc[p] = d0s[6 * (size_t)k + p];
+  for (int p = 0; p < 6; p++) sc[p] = head.sc[p];
   bool any_bad = false;
   for (int c0 = 0; c0 < rows; c0 += 64) {
     const int i = c0 + lane;
@@ -1501,9 +1518,10 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
               small_rhs_gather(k, lane - 58, lane >= 58, Ls, ys, row_ptr, row_blk, row_col);
               GP_WAVE_SYNC_LDS();
               seq++;
+              const SmallSweepHead head = small_sweep_head(k, d0s, colptr);
               while (__hip_atomic_load(&team_arrive[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq * (unsigned)(G - 1)) __builtin_amdgcn_s_sleep(1);
               if (st) tr_lds[8 + 4 * rd + 1] = __builtin_amdgcn_s_memtime();
-              small_panel_sweep(k, lane, Ls, ys, dis, d0s, colptr, &bad);
+              small_panel_sweep(k, head, lane, Ls, ys, dis, &bad);
               GP_WAVE_SYNC_LDS();
               if (st) tr_lds[8 + 4 * rd + 2] = __builtin_amdgcn_s_memtime();
               if (lane == 0) __hip_atomic_store(&team_done[team], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1560,9 +1578,10 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
             seq++;
             if (lane == 0) __hip_atomic_fetch_add(&team_arrive[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (wt == 0) {
+              const SmallSweepHead head = small_sweep_head(k, d0s, colptr);
               while (__hip_atomic_load(&team_arrive[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq * (unsigned)G) __builtin_amdgcn_s_sleep(1);
               if (st) tr_lds[8 + 4 * rd + 1] = __builtin_amdgcn_s_memtime();
-              small_panel_sweep(k, lane, Ls, ys, dis, d0s, colptr, &bad);
+              small_panel_sweep(k, head, lane, Ls, ys, dis, &bad);
               GP_WAVE_SYNC_LDS();
               if (st) tr_lds[8 + 4 * rd + 2] = __builtin_amdgcn_s_memtime();
               if (lane == 0) __hip_atomic_store(&team_done[team], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
