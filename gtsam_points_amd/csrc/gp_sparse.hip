@@ -1027,11 +1027,12 @@ __global__ void __launch_bounds__(256) sparse_sum_errors_kernel(const double* __
 //            sparse_assemble_kernel<true>, one 64-lane workgroup per block of L across the whole chip, in the launch in front: it is a gather of 8-byte values out of the
 //            factors' records, and ONE compute unit's vector-memory path needs 40 us for it (measured: the first form of this kernel assembled in place, with its lists in
 //            LDS and sixteen loads in flight per thread: 30 - 45 us against the assembly kernel's 6.5)
-//   phase 1  the schedule's levels one after the other, the work lists of a level side by side.  Level 0 (the independent subtrees): up to four lists -- a team of
-//            8 / lists waves per list, which share a column's gather and meet through LDS words (small_entry_gather + small_panel_sweep, below); more lists -- a list per
-//            lone wave (small_wave_column); no workgroup barrier inside a list either way.  Levels above (separator chains, whose columns gather hundreds of products): each list with a TEAM
-//            of 512 / lists threads (whole waves), in lock step: round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward substitution by the
-//            team's first wave, barrier, the blocks below, barrier.  (gp_sparse_system_set_one_launch(sys, 2): the lock-step form for level 0 too, as first built; 3: lone waves throughout.)
+//   phase 1  the schedule's levels one after the other, the work lists of a level side by side.  Up to four lists in a level -- a team of 8 / lists waves per list,
+//            which share a column's gather and meet through LDS words (small_entry_gather + small_panel_sweep, below; in level 0, the independent subtrees, pipelined:
+//            the next column's older products are gathered while the team's first wave sweeps); more lists -- level 0: a list per lone wave (small_wave_column), levels
+//            above (separator chains): a TEAM of 512 / lists threads in lock step, round r = the r-th column of every list -- gather, barrier, 6 x 6 Cholesky + forward
+//            substitution by the team's first wave, barrier, the blocks below, barrier.  (gp_sparse_system_set_one_launch(sys, 2): the lock-step form everywhere, as
+//            first built; 3: lone waves in level 0, lock step above.)
 //   phase 2  the backward substitution, levels and columns in reverse: a list per wave, no barrier inside a list (the team form: two barriers per round)
 //   phase 3  x in slot order to the device array and the host, the status word
 // Every scalar is computed by the SAME sequence of operations as in sparse_factor_kernel<256> (lists of level 0) / sparse_factor_staged_kernel<1024> (levels above: the
@@ -1219,55 +1220,6 @@ __device__ __forceinline__ void small_wave_column(const int k, const int lane, d
 // No s_barrier: the other lists' teams run on at their own pace (all eight waves are resident: a wave that polls never keeps the wave it waits for from running).
 // Measured (scripts/r06/solver_forms.py, solver_trace.py): a column 6400 -> 4100 clocks (gather + meeting 1850, sweep 1850, release 160), the kernel 276 k -> 245 k;
 // pipelined (sparse_small_step_kernel: the other waves start the next column's older products during the sweep) 3650 clocks, 235 k.
-__device__ __forceinline__ void small_entry_gather(const int k, const int wt, const int G, const int lane, double* Ls, double* ys, const int* colptr, const int* upd_ptr,
-                                                   const int* upd_a, const int* upd_b, const int* row_ptr, const int* row_blk, const int* row_col) {
-  const int base = colptr[k], nb = colptr[k + 1] - base;
-  const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
-  // the blocks' entries: one per lane, wave by wave
-  for (int e = wt * 64 + lane; e < 36 * nb; e += 64 * G) {
-    const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
-    double* dst = Ls + 36 * (size_t)d + 6 * r + c;
-    *dst = small_sub_products(*dst, upd_a, upd_b, upd_ptr[d], upd_ptr[d + 1], Ls, r, c);
-  }
-  // the right-hand side's six entries: the team's LAST wave, lanes 58-63 (another instruction stream than the blocks' entries: beside them, where that wave holds none --
-  // a column of five blocks leaves the fourth wave of four free --, not behind them)
-  {
-    if (wt == G - 1 && lane >= 58) {
-      const int r = lane - 58;
-      double acc = ys[6 * (size_t)k + r];
-      int u = rb;
-      const int ue = rb + nrow;
-      for (; u < ue; u += 4) {
-        int ib[4], ic[4];
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-          const int uu = u + w < ue ? u + w : ue - 1;
-          ib[w] = row_blk[uu];
-          ic[w] = row_col[uu];
-        }
-        double av[4][6], yv[4][6];
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-          const double2* A = reinterpret_cast<const double2*>(Ls + 36 * (size_t)ib[w] + 6 * r);
-          const double2* Y = reinterpret_cast<const double2*>(ys + 6 * (size_t)ic[w]);
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            const double2 x = A[q], y2 = Y[q];
-            av[w][2 * q] = x.x, av[w][2 * q + 1] = x.y;
-            yv[w][2 * q] = y2.x, yv[w][2 * q + 1] = y2.y;
-          }
-        }
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-          if (u + w < ue) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) acc -= av[w][q] * yv[w][q];
-          }
-      }
-      ys[6 * (size_t)k + r] = acc;
-    }
-  }
-}
 // the forward substitution's right-hand side of column k, entry r (on: this lane holds one): b_k[r] - sum over the row list of L_kj[r, :] . y_j, in list order, in place
 __device__ __forceinline__ void small_rhs_gather(const int k, const int r, const bool on, const double* Ls, double* ys, const int* row_ptr, const int* row_blk, const int* row_col) {
   if (!on) return;
@@ -1303,6 +1255,53 @@ __device__ __forceinline__ void small_rhs_gather(const int k, const int r, const
       }
   }
   ys[6 * (size_t)k + r] = acc;
+}
+// STAGED: the column belongs to a level above 0 -- the sums are those of sparse_factor_staged_kernel<1024>: an entry's product list in G contiguous slices, each summed
+// from zero, met in slice order (G = clamp(1024 / (6 blocks), 1, 8)); the right-hand side's row list in sixteen such slices
+template <bool STAGED>
+__device__ __forceinline__ void small_entry_gather(const int k, const int wt, const int G, const int lane, double* Ls, double* ys, const int* colptr, const int* upd_ptr,
+                                                   const int* upd_a, const int* upd_b, const int* row_ptr, const int* row_blk, const int* row_col) {
+  const int base = colptr[k], nb = colptr[k + 1] - base;
+  // the blocks' entries: one per lane, wave by wave
+  for (int e = wt * 64 + lane; e < 36 * nb; e += 64 * G) {
+    const int d = base + e / 36, r = (e % 36) % 6, c = (e % 36) / 6;
+    double* dst = Ls + 36 * (size_t)d + 6 * r + c;
+    if constexpr (!STAGED) {
+      *dst = small_sub_products(*dst, upd_a, upd_b, upd_ptr[d], upd_ptr[d + 1], Ls, r, c);
+    } else {
+      int Gs = 1024 / (6 * nb);
+      Gs = Gs < 1 ? 1 : (Gs > 8 ? 8 : Gs);
+      const int ub = upd_ptr[d], ulen = upd_ptr[d + 1] - ub;
+      const int per = (ulen + Gs - 1) / Gs;
+      double v = *dst;
+      for (int g = 0; g < Gs; g++) {
+        const double acc = small_sub_products(0.0, upd_a, upd_b, ub + g * per, min(ub + ulen, ub + g * per + per), Ls, r, c);
+        v += acc;
+      }
+      *dst = v;
+    }
+  }
+  // the right-hand side's six entries: the team's LAST wave, lanes 58-63 (another instruction stream than the blocks' entries: beside them, where that wave holds none --
+  // a column of five blocks leaves the fourth wave of four free --, not behind them)
+  if constexpr (!STAGED) {
+    small_rhs_gather(k, lane - 58, wt == G - 1 && lane >= 58, Ls, ys, row_ptr, row_blk, row_col);
+  } else if (wt == G - 1 && lane >= 58) {
+    const int r = lane - 58;
+    const int rb = row_ptr[k], nrow = row_ptr[k + 1] - rb;
+    const int per = (nrow + 15) / 16;
+    double t = ys[6 * (size_t)k + r];
+    for (int g = 0; g < 16; g++) {
+      double a = 0.0;
+      for (int q = g * per; q < min(nrow, (g + 1) * per); q++) {
+        const double* A = Ls + 36 * (size_t)row_blk[rb + q] + 6 * r;
+        const double* yj = ys + 6 * (size_t)row_col[rb + q];
+#pragma unroll
+        for (int m = 0; m < 6; m++) a -= A[m] * yj[m];
+      }
+      t += a;
+    }
+    ys[6 * (size_t)k + r] = t;
+  }
 }
 // the gathered panel of column k, row by row (lanes 0-5 the diagonal block, lane 6 the right-hand side, lanes 7.. the rows of the blocks below): small_wave_column's sweep
 // what the sweep of a column reads that does not depend on the gather: requested by the caller BEFORE it waits for the gathering waves
@@ -1486,7 +1485,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     const bool staged = lvl > 0;
     for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {  // (more than eight lists in a level: eight at a time)
       const int nb_lists = min(kSmallTeams, nlists - b0);
-      if (!staged && V.wave_columns == 1 && nb_lists <= kSmallThreads / 128) {
+      if (V.wave_columns == 1 && nb_lists <= kSmallThreads / 128) {
         // level 0, up to four lists side by side: a team of G >= 2 waves per list -- gather by all of them (small_entry_gather), panel sweep by the first
         // (small_panel_sweep), two LDS handshakes per column, no workgroup barrier
         const int G = (kSmallThreads / 64) / nb_lists;
@@ -1497,7 +1496,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
         // the others gather the blocks' entries -- and, while the first wave sweeps column k, already the products of the NEXT column that do not come from column k
         // (only the previous column of the list can still be in the making: every other source column was swept before it); the product from column k, last in its
         // list, follows when the sweep is released.  Same products in the same order per entry: the same bits.
-        bool pipe = V.wave_columns == 1 && G >= 2 && team < nb_lists;
+        bool pipe = !staged && V.wave_columns == 1 && G >= 2 && team < nb_lists;
         if (pipe) {
           const int list = first + b0 + team;
           for (int w = work_ptr[list]; w < work_ptr[list + 1]; w++) {
@@ -1513,7 +1512,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
             int rd = 0;
             for (int w = wb; w < we; w++, rd++) {
               const int k = work_cols[w];
-              const bool st = V.trace && t == 0 && b0 == 0 && rd < 14;
+              const bool st = V.trace && t == 0 && lvl == 0 && b0 == 0 && rd < 14;
               if (st) tr_lds[8 + 4 * rd] = __builtin_amdgcn_s_memtime();
               small_rhs_gather(k, lane - 58, lane >= 58, Ls, ys, row_ptr, row_blk, row_col);
               GP_WAVE_SYNC_LDS();
@@ -1571,9 +1570,10 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
           int rd = 0;
           for (int w = work_ptr[list]; w < work_ptr[list + 1]; w++, rd++) {
             const int k = work_cols[w];
-            const bool st = V.trace && t == 0 && b0 == 0 && rd < 14;
+            const bool st = V.trace && t == 0 && lvl == 0 && b0 == 0 && rd < 14;
             if (st) tr_lds[8 + 4 * rd] = __builtin_amdgcn_s_memtime();
-            small_entry_gather(k, wt, G, lane, Ls, ys, colptr, upd_ptr, upd_a, upd_b, row_ptr, row_blk, row_col);
+            if (staged) small_entry_gather<true>(k, wt, G, lane, Ls, ys, colptr, upd_ptr, upd_a, upd_b, row_ptr, row_blk, row_col);
+            else small_entry_gather<false>(k, wt, G, lane, Ls, ys, colptr, upd_ptr, upd_a, upd_b, row_ptr, row_blk, row_col);
             GP_WAVE_SYNC_LDS();
             seq++;
             if (lane == 0) __hip_atomic_fetch_add(&team_arrive[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

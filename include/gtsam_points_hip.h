@@ -480,8 +480,8 @@ int gp_sparse_system_download(const gp_sparse_system_t* sys, double* A_host, dou
 int gp_sparse_system_solve(gp_sparse_system_t* sys, double* x_host, double* x_dev);
 /* gp_dense_system_step's block-sparse form, one wait.  The assembly kernel applies the damping and hands b, c to the host.  A system whose factor and index lists fit the
  * LDS of one compute unit (<= 128 poses, <= ~400 blocks of L: BASELINE configs[2]'s 64-pose graph does) is then factored and solved -- all levels, both substitutions, x
- * and status to the host -- by ONE launch of one 512-thread workgroup with every operand in LDS (sparse_small_step_kernel; the independent subtrees by a team of waves
- * per work list that meets through LDS words, or a lone wave per list where a level has more than four; no workgroup barrier inside a list): two launches per step;
+ * and status to the host -- by ONE launch of one 512-thread workgroup with every operand in LDS (sparse_small_step_kernel; a team of waves per work list that meets
+ * through LDS words where a level has at most four lists -- no workgroup barrier inside a list --, else a lone wave per list / lock-step teams): two launches per step;
  * larger systems take 2 + 2 x levels launches.  The forms are bit-identical; gp_sparse_system_set_one_launch(sys, 0) selects the multi-launch form for a qualifying
  * system, 2 the one-launch step's first form (every list a team of waves in lock step), 3 its second (a lone wave per list throughout), 1 the default; returns what the
  * next step runs (0 / 2 / 3 / 1). */
