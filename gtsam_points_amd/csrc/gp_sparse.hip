@@ -397,7 +397,7 @@ constexpr int kSmallTeamDoubles = 158;  // per team: D[6][7] | rhs[6] | v[6] (ba
 static size_t small_step_lds_bytes(const SparseSymbolic& S, size_t* arena_words_out = nullptr) {
   const size_t P = (size_t)S.P, nnzL = (size_t)S.colptr[S.P];
   const size_t words = S.colptr.size() + S.rowidx.size() + S.upd_ptr.size() + S.upd_a.size() + S.upd_b.size() + S.row_ptr.size() + S.row_blk.size() + S.row_col.size() +
-                       S.work_ptr.size() + S.work_cols.size() + S.rowidx.size() /* the blocks' columns */ + 2;
+                       S.work_ptr.size() + S.work_cols.size() + S.rowidx.size() /* the blocks' columns */ + S.work_ptr.size() /* the lists' widest columns */ + 2;
   if (arena_words_out) *arena_words_out = words;
   if (P > 128) return 0;  // (row lists stay below the staged kernel's 128-block stage, which the one-launch form assumes)
   const size_t bytes = sizeof(double) * (36 * nnzL + 24 * P + (size_t)kSmallTeams * kSmallTeamDoubles) + sizeof(int) * words + 64;
@@ -1389,7 +1389,6 @@ __device__ __forceinline__ void small_wave_back_column(const int k, const int la
                                                        const int* rowidx, double* scratch /* [48]: this wave's */) {
   const int base = colptr[k], nb = colptr[k + 1] - base;
   double (*bpart)[6] = reinterpret_cast<double (*)[6]>(scratch);
-  double* vv = scratch + 36;
   if (lane < 36) {
     const int c = lane % 6, slice = lane / 6;
     double acc = 0.0;
@@ -1402,13 +1401,16 @@ __device__ __forceinline__ void small_wave_back_column(const int k, const int la
     bpart[slice][c] = acc;
   }
   GP_WAVE_SYNC_LDS();
+  double sum = 0.0;
   if (lane < 6) {
-    double sum = ys[6 * (size_t)k + lane];
+    sum = ys[6 * (size_t)k + lane];
     for (int sl = 0; sl < 6; sl++) sum -= bpart[sl][lane];
-    vv[lane] = sum;
   }
-  GP_WAVE_SYNC_LDS();
-  if (lane == 0) back6<true>(Ls + 36 * (size_t)base, dis + 6 * (size_t)k, vv, xs + 6 * (size_t)k);
+  // (the six sums go to lane 0 through v_readlane instead of through LDS: one write, one fence and one read less on every column's chain)
+  double v[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) v[q] = lane_bcast_f64(sum, q);
+  if (lane == 0) back6<true>(Ls + 36 * (size_t)base, dis + 6 * (size_t)k, v, xs + 6 * (size_t)k);
   GP_WAVE_SYNC_LDS();
 }
 
@@ -1419,7 +1421,7 @@ struct SparseSmallView {
   const int* arena;       // global copy of the index lists below, `arena_words` ints, copied to LDS first
   const int* level_ptr;   // [num_levels + 1] -> work lists (global; read once per level)
   int arena_words, num_levels, P, nnzL;
-  int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols, o_blkcol;  // offsets (ints) inside the arena (blkcol: block -> its column)
+  int o_colptr, o_rowidx, o_upd_ptr, o_upd_a, o_upd_b, o_row_ptr, o_row_blk, o_row_col, o_work_ptr, o_work_cols, o_blkcol, o_list_maxnb;  // offsets (ints) inside the arena (blkcol: block -> its column; list_maxnb: work list -> the most blocks a column of it has)
   const int* perm;        // elimination order -> slot (global)
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
@@ -1452,6 +1454,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
   const int* work_ptr = idx + V.o_work_ptr;
   const int* work_cols = idx + V.o_work_cols;
   const int* blkcol = idx + V.o_blkcol;
+  const int* list_maxnb = idx + V.o_list_maxnb;
   // ---- phase 0 ----
 #define GP_SMALL_STAMP(i)                                                       \
   do {                                                                          \
@@ -1496,14 +1499,7 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
         // the others gather the blocks' entries -- and, while the first wave sweeps column k, already the products of the NEXT column that do not come from column k
         // (only the previous column of the list can still be in the making: every other source column was swept before it); the product from column k, last in its
         // list, follows when the sweep is released.  Same products in the same order per entry: the same bits.
-        bool pipe = !staged && V.wave_columns == 1 && G >= 2 && team < nb_lists;
-        if (pipe) {
-          const int list = first + b0 + team;
-          for (int w = work_ptr[list]; w < work_ptr[list + 1]; w++) {
-            const int kk = work_cols[w];
-            if (36 * (colptr[kk + 1] - colptr[kk]) > 64 * (G - 1)) pipe = false;
-          }
-        }
+        const bool pipe = !staged && V.wave_columns == 1 && G >= 2 && team < nb_lists && 36 * list_maxnb[first + b0 + (team < nb_lists ? team : 0)] <= 64 * (G - 1);
         if (pipe) {
           const int list = first + b0 + team;
           const int wb = work_ptr[list], we = work_ptr[list + 1];
@@ -1980,11 +1976,14 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     std::vector<int> blkcol((size_t)nnzL);
     for (int k = 0; k < P; k++)
       for (int q = S.colptr[k]; q < S.colptr[k + 1]; q++) blkcol[(size_t)q] = k;
-    const std::vector<int>* sa[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols, &blkcol};
+    std::vector<int> list_maxnb(S.work_ptr.size() - 1, 0);
+    for (size_t l = 0; l + 1 < S.work_ptr.size(); l++)
+      for (int w = S.work_ptr[l]; w < S.work_ptr[l + 1]; w++) list_maxnb[l] = std::max(list_maxnb[l], S.colptr[S.work_cols[w] + 1] - S.colptr[S.work_cols[w]]);
+    const std::vector<int>* sa[] = {&S.colptr, &S.rowidx, &S.upd_ptr, &S.upd_a, &S.upd_b, &S.row_ptr, &S.row_blk, &S.row_col, &S.work_ptr, &S.work_cols, &blkcol, &list_maxnb};
     std::vector<int> arena;
     arena.reserve(small_words);
-    int off[11];
-    for (int i = 0; i < 11; i++) {
+    int off[12];
+    for (int i = 0; i < 12; i++) {
       off[i] = (int)arena.size();
       arena.insert(arena.end(), sa[i]->begin(), sa[i]->end());
     }
@@ -2001,7 +2000,7 @@ int gp_sparse_system_create(int num_slots, const int* factor_slots, int num_fact
     V.level_ptr = s->d_level_ptr.as<int>();
     V.arena_words = (int)arena.size(), V.num_levels = (int)S.level_ptr.size() - 1, V.P = P, V.nnzL = nnzL;
     V.o_colptr = off[0], V.o_rowidx = off[1], V.o_upd_ptr = off[2], V.o_upd_a = off[3], V.o_upd_b = off[4], V.o_row_ptr = off[5], V.o_row_blk = off[6], V.o_row_col = off[7];
-    V.o_work_ptr = off[8], V.o_work_cols = off[9], V.o_blkcol = off[10];
+    V.o_work_ptr = off[8], V.o_work_cols = off[9], V.o_blkcol = off[10], V.o_list_maxnb = off[11];
     V.perm = s->d_perm;
     V.wave_columns = 1;
     V.x_slots = s->x_slots.as<double>();
