@@ -1489,8 +1489,9 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     for (int b0 = 0; b0 < nlists; b0 += kSmallTeams) {  // (more than eight lists in a level: eight at a time)
       const int nb_lists = min(kSmallTeams, nlists - b0);
       if (V.wave_columns == 1 && nb_lists <= kSmallThreads / 128) {
-        // level 0, up to four lists side by side: a team of G >= 2 waves per list -- gather by all of them (small_entry_gather), panel sweep by the first
-        // (small_panel_sweep), two LDS handshakes per column, no workgroup barrier
+        // up to four lists side by side (any level): a team of G >= 2 waves per list -- gather by all of them (small_entry_gather), panel sweep by the first
+        // (small_panel_sweep), two LDS handshakes per column, no workgroup barrier inside the batch (teams that take different paths below meet at its end: s_barrier
+        // counts arrivals, not call sites)
         const int G = (kSmallThreads / 64) / nb_lists;
         const int wv = t >> 6, team = wv / G, wt = wv % G, lane = t & 63;
         if (t < kSmallTeams) team_arrive[t] = 0, team_done[t] = 0;
