@@ -217,6 +217,7 @@ _SIGNATURES = {
     "gp_vgicp_batch_compute_error_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_issue_compute_error_dev_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_vgicp_batch_compute_error_dev_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gp_dense_system_set_one_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "gp_dense_system_collect_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_collect_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_lm_graph_set_speculation": (C.c_int, [C.c_void_p, C.c_int]),

@@ -251,6 +251,103 @@ __global__ void __launch_bounds__(256) dense_step_end_kernel(const double* __res
   }
 }
 
+// ---- ONE free pose: the whole damped step in one launch (round 6) ----------------------------------------------------------------------------------------
+// BASELINE configs[0] as an optimisation (a scan onto a map: one free pose) runs gp_dense_system_step once per trial, and for a 6 x 6 system that step was nine stream
+// operations -- two memsets, assembly, error sum, damping, the status memset, the Cholesky launch, the substitutions, the hand-over: ~25 us of launch boundaries around
+// a microsecond of arithmetic.  One 64-thread workgroup does all of it with the arithmetic of the kernels above, operation for operation (assemble_kernel's sums in
+// contribution order, sum_errors_kernel's 256 strided partials and halving tree, damp_kernel, chol6, chol_solve_kernel's two substitutions with their empty sums), so
+// x, b, c and the status are the multi-launch path's bits (tests/test_solver_gpu.py::test_one_pose_dense_step_is_bit_identical).
+__global__ void __launch_bounds__(64) dense_one_pose_step_kernel(const BlockDest* __restrict__ dests, const Contribution* __restrict__ contribs, const double* __restrict__ records,
+                                                                 int num_factors, double lambda, int diagonal, double min_diag, double max_diag, double* __restrict__ A,
+                                                                 double* __restrict__ b, double* __restrict__ c_out, double* __restrict__ x, double* __restrict__ Ldiag,
+                                                                 int* __restrict__ status, double* __restrict__ out_host) {
+  __shared__ double part[256];
+  __shared__ double l[6][6], a0[6][6], bb[6], xx[6];
+  __shared__ int st;
+  const int t = threadIdx.x;
+  const BlockDest d = dests[0];
+  // sum_errors_kernel: thread i of 256 adds the errors of factors i, i + 256, ...; the halving tree part[i] += part[i + w], w = 128 .. 1
+  for (int i = t; i < 256; i += 64) {
+    double s = 0.0;
+    for (int f = i; f < num_factors; f += 256) s += records[122 * (size_t)f + 1];
+    part[i] = s;
+  }
+  // assemble_kernel
+  if (t < 36) {
+    const int r = t % 6, c = t / 6;
+    double s = 0.0;
+    for (int k = 0; k < d.count; k++) {
+      const Contribution q = contribs[d.begin + k];
+      const double* rec = records + 122 * (size_t)q.factor;
+      double v;
+      if (q.take == TAKE_HT) v = rec[REC_HT + c * 6 + r];
+      else if (q.take == TAKE_HS) v = rec[REC_HS + c * 6 + r];
+      else if (q.take == TAKE_HTS) v = rec[REC_HTS + c * 6 + r];
+      else v = rec[REC_HTS + r * 6 + c];
+      s += v;
+    }
+    a0[r][c] = s;
+  } else if (t < 42) {
+    const int r = t - 36;
+    double s = 0.0;
+    for (int k = 0; k < d.count; k++) {
+      const Contribution q = contribs[d.begin + k];
+      const double* rec = records + 122 * (size_t)q.factor;
+      s -= q.take == TAKE_HT ? rec[REC_BT + r] : rec[REC_BS + r];
+    }
+    bb[r] = s;
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    for (int i = t; i < w; i += 64) part[i] += part[i + w];
+    __syncthreads();
+  }
+  // damp_kernel (no prior: a step with one goes through the multi-launch path)
+  if (t < 6 && lambda > 0.0) {
+    const double dd = a0[t][t];
+    const double add = diagonal ? lambda * fmin(fmax(dd, min_diag), max_diag) : lambda;
+    a0[t][t] = dd + add;
+  }
+  __syncthreads();
+  if (t < 36) {
+    A[(size_t)(t / 6) * 6 + t % 6] = a0[t % 6][t / 6];  // column-major 6 x 6 (the upper triangle holds what the assembly left: the same sums, mirrored)
+    l[t % 6][t / 6] = a0[t % 6][t / 6];
+  }
+  if (t < 6) b[t] = bb[t];
+  __syncthreads();
+  if (t == 0) {
+    st = chol6(l) ? 0 : 1;  // chol_panel_kernel: status = k + 1
+    // chol_solve_kernel, P = 1: L y = b (the sum over earlier columns is empty: y - 0), then L^T x = y
+    double v[6];
+    for (int r = 0; r < 6; r++) {
+      double q = bb[r] - 0.0;
+      for (int p2 = 0; p2 < r; p2++) q -= l[r][p2] * v[p2];
+      v[r] = q / l[r][r];
+    }
+    double y[6];
+    for (int r = 0; r < 6; r++) y[r] = v[r];
+    for (int r = 5; r >= 0; r--) {
+      double q = y[r] - 0.0;
+      for (int p2 = r + 1; p2 < 6; p2++) q -= l[p2][r] * v[p2];
+      v[r] = q / l[r][r];
+    }
+    for (int r = 0; r < 6; r++) xx[r] = v[r];
+  }
+  __syncthreads();
+  if (t < 36) Ldiag[t] = (t % 6 >= t / 6) ? l[t % 6][t / 6] : 0.0;
+  if (t < 6) {
+    x[t] = xx[t];
+    out_host[t] = xx[t];
+    out_host[6 + t] = bb[t];
+  }
+  if (t == 0) {
+    *c_out = part[0];
+    *status = st;
+    out_host[12] = part[0];
+    out_host[13] = (double)st;
+  }
+}
+
 }  // namespace gp
 
 constexpr int kMaxSlots = 2048;  // 12288 unknowns: 96 KB of LDS for the substitution vector, 1.2 GB for the dense matrix
@@ -264,6 +361,7 @@ struct gp_dense_system {
   gp::PinnedArray pinned;  // gp_dense_system_step: x [n] | b [n] | c | status, written by the step's last kernel
   bool built = false;
   bool step_in_flight = false;  // gp_dense_system_issue_step went out, gp_dense_system_finish_step has not collected it
+  bool one_launch = true;       // a system of ONE pose runs its step as one launch (dense_one_pose_step_kernel); gp_dense_system_set_one_launch(sys, 0): the multi-launch form
 };
 
 extern "C" {
@@ -417,6 +515,16 @@ int gp_dense_system_issue_step(gp_dense_system_t* s, const gp_linearized6* recor
   if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_step: null system");
   const size_t n = (size_t)s->n;
   GP_TRY(s->pinned.ensure(sizeof(double) * (2 * n + 2)));
+  if (s->num_slots == 1 && !prior_diag_host && s->one_launch) {
+    if ((!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_step: bad arguments");
+    hipLaunchKernelGGL(gp::dense_one_pose_step_kernel, dim3(1), dim3(64), 0, s->stream, s->d_dests.as<gp::BlockDest>(), s->d_contribs.as<gp::Contribution>(),
+                       reinterpret_cast<const double*>(records_dev), s->num_factors, lambda, diagonal_damping, min_diagonal, max_diagonal, s->A.as<double>(), s->b.as<double>(),
+                       s->c.as<double>(), s->x.as<double>(), s->Ldiag.as<double>(), s->status.as<int>(), s->pinned.as<double>());
+    GP_HIP(hipGetLastError());
+    s->built = false;
+    s->step_in_flight = true;
+    return GP_OK;
+  }
   GP_TRY(gp_dense_system_build(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host));
   GP_TRY(launch_dense_solve(s));
   double* h = s->pinned.as<double>();
@@ -449,6 +557,13 @@ int gp_dense_system_step(gp_dense_system_t* s, const gp_linearized6* records_dev
                          const double* prior_diag_host, double* x_host, double* b_host, double* c_host) {
   GP_TRY(gp_dense_system_issue_step(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host));
   return gp_dense_system_finish_step(s, x_host, b_host, c_host);
+}
+
+// 0: a one-pose system's step takes the multi-launch path too (the bit-identity test, A/B timing); returns what the next step of this system runs (1: one launch)
+int gp_dense_system_set_one_launch(gp_dense_system_t* s, int enable) {
+  if (!s) return 0;
+  s->one_launch = enable != 0;
+  return (s->one_launch && s->num_slots == 1) ? 1 : 0;
 }
 
 // gp_sparse_system_device_solution's dense form

@@ -92,6 +92,10 @@ class DenseLinearSystemGPU:
         _capi.check(self._lib.gp_dense_system_solve(self._h, x.ctypes.data, None), "gp_dense_system_solve")
         return x
 
+    def set_one_launch(self, enable=True):
+        """a system of ONE pose runs step() as one launch (default); False: the multi-launch path (bit-identical: tests, A/B).  -> what the next step() runs"""
+        return bool(self._lib.gp_dense_system_set_one_launch(self._h, 1 if enable else 0))
+
     def step(self, records_dev, lam=0.0, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, prior_diag=None, out=None):
         """build + download(b, c) + solve as ONE call with one synchronisation -- two with a prior_diag -- (gp_dense_system_step): -> (x, b, c); the optimizer's tryLambda
         (levenberg_marquardt_ext.cpp:188-260).  out: optional (x, b, c) float64 arrays to fill ([n], [n], [1]) instead of new ones.  Raises GPError (indeterminate) when the

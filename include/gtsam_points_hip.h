@@ -449,6 +449,10 @@ int gp_dense_system_issue_step(gp_dense_system_t* sys, const gp_linearized6* rec
                                const double* prior_diag_host);
 int gp_dense_system_finish_step(gp_dense_system_t* sys, double* x_host, double* b_host, double* c_host);
 int gp_dense_system_device_solution(gp_dense_system_t* sys, const double** x_dev, const int** status_dev);
+/* a system of ONE pose (a scan registered onto a map) runs its step -- assembly, error sum, damping, 6 x 6 Cholesky, both substitutions, hand-over -- as ONE launch of one
+ * 64-thread workgroup, the multi-launch path's arithmetic operation for operation (bit-identical); 0 selects the multi-launch path (tests, A/B); returns what the next
+ * step runs (1 / 0).  A step with a prior_diag_host takes the multi-launch path. */
+int gp_dense_system_set_one_launch(gp_dense_system_t* sys, int enable);
 /* finish_step for a caller that has SEEN the stream pass the step (a completion word of work it queued behind the step): no wait of its own */
 int gp_dense_system_collect_step(gp_dense_system_t* sys, double* x_host, double* b_host, double* c_host);
 

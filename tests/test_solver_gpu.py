@@ -452,3 +452,40 @@ def test_one_launch_step_fuzz_against_the_multi_launch_form(gpu):
         assert np.linalg.norm(x1 - want) <= 1e-8 * np.linalg.norm(want), (trial, P, o)
         ran += 1
     assert ran >= 40  # (most random graphs of this size fit one compute unit's LDS)
+
+
+@pytest.mark.parametrize("num_factors", [1, 3, 300, 777])
+def test_one_pose_dense_step_is_bit_identical(gpu, num_factors):
+    """a system of ONE pose (BASELINE configs[0] as an optimisation: a scan onto a map) runs its damped step as ONE launch (dense_one_pose_step_kernel): x, b, c bit for bit
+    what the nine stream operations of the multi-launch path give -- unary factors on either side, every damping form, an indeterminate system -- and numpy's solve"""
+    import torch
+
+    rng = np.random.default_rng(5 + num_factors)
+    slots = [((-1, 0) if rng.random() < 0.6 else (0, -1)) for _ in range(num_factors)]
+    rec = _random_records(slots, rng, rows=12)
+    rec_dev = torch.from_numpy(rec).cuda()
+    one, multi = gpu.DenseLinearSystemGPU(1, slots), gpu.DenseLinearSystemGPU(1, slots)
+    assert one.set_one_launch(True) is True and multi.set_one_launch(False) is False
+    Ah, bh, ch = _host_system(rec, slots, 1)
+    for lam, diag in [(1e-5, False), (0.0, False), (1e-2, False), (3.0, True)]:
+        x1, b1, c1 = one.step(rec_dev, lam=lam, diagonal_damping=diag)
+        xm, bm, cm = multi.step(rec_dev, lam=lam, diagonal_damping=diag)
+        assert np.array_equal(x1, xm) and np.array_equal(b1, bm) and c1 == cm, (lam, diag, float(np.abs(x1 - xm).max()))
+        damp = lam * np.diag(np.clip(np.diag(Ah), 1e-6, 1e32)) if diag else lam * np.eye(6)
+        assert np.linalg.norm(x1 - np.linalg.solve(Ah + damp, bh)) <= 1e-9 * np.linalg.norm(x1)
+        assert np.abs(b1 - bh).max() <= 1e-12 * np.abs(bh).max() and abs(c1 - ch) <= 1e-12 * abs(ch)
+    # the three calls after a one-launch step still see a consistent system (A, b, c are left where build() leaves them)
+    x3 = one.build(rec_dev, lam=1e-3).solve()
+    assert np.array_equal(x3, multi.step(rec_dev, lam=1e-3)[0])
+    # a prior takes the multi-launch path in both
+    prior = rng.uniform(0.0, 2.0, 6)
+    assert np.array_equal(one.step(rec_dev, lam=1e-3, prior_diag=prior)[0], multi.step(rec_dev, lam=1e-3, prior_diag=prior)[0])
+    rec0 = rec.copy()
+    rec0[:, 2:110] = 0.0
+    rec0_dev = torch.from_numpy(rec0).cuda()
+    for sysm in (one, multi):
+        out = (np.full(6, 7.0), np.zeros(6), np.zeros(1))
+        with pytest.raises(gpu.GPError):
+            sysm.step(rec0_dev, out=out)
+        assert np.all(out[0] == 7.0) and np.abs(out[1] - bh).max() <= 1e-12 * np.abs(bh).max()
+    assert np.array_equal(one.step(rec0_dev, lam=1.0)[0], multi.step(rec0_dev, lam=1.0)[0])
