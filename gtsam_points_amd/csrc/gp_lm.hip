@@ -8,9 +8,9 @@
 //
 // Here the VALUES live in device memory beside the records:
 //   gp_lm_graph_linearize    the batch's linearise at the relative poses of the current values (a device table: gp_vgicp_batch_issue_linearize_dev) -> records in HBM
-//   gp_lm_graph_try_lambda   the damped step (gp_sparse_system_issue_step / gp_dense_system_issue_step), then ONE small kernel that retracts the current values by
-//                            the step's x where the step left it (Pose3::retract = T Expmap(xi), (omega, v) order) and writes the trial values and every factor's
-//                            relative pose, then the batch's error evaluation on the linearisation's correspondences at those (gp_vgicp_batch_issue_compute_error_dev):
+//   gp_lm_graph_try_lambda   the damped step (gp_sparse_system_issue_step / gp_dense_system_issue_step), then the retract of the current values by the step's x
+//                            (Pose3::retract = T Expmap(xi), (omega, v) order), which writes the trial values and every factor's relative pose -- as the EPILOGUE of
+//                            the step's own kernel where the step is one launch (gp_lm_poses.hpp), else one small kernel behind it (lm_poses_kernel) --, then the batch's error evaluation on the linearisation's correspondences at those (gp_vgicp_batch_issue_compute_error_dev):
 //                            launches queued back to back, ONE wait -- a poll of the error evaluation's completion words, not hipStreamSynchronize -- with the
 //                            linearise at the trial values already queued behind them (speculation: an accepted step finds it running); x, b, c, the trial's
 //                            error and the trial values reach the host through pinned memory
@@ -26,107 +26,13 @@
 #include <vector>
 
 #include "gp_host.hpp"
+#include "gp_lm_poses.hpp"
 #include "gp_vgicp_shared.hpp"
 
 namespace gp {
 
-struct Rigid {
-  double R[9];  // row-major
-  double t[3];
-};
-
-__device__ __forceinline__ Rigid load_rigid(const double* __restrict__ p /*column-major 4x4*/) {
-  Rigid T;
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) T.R[r * 3 + c] = p[c * 4 + r];
-  T.t[0] = p[12], T.t[1] = p[13], T.t[2] = p[14];
-  return T;
-}
-
-__device__ __forceinline__ void store_rigid(const Rigid& T, double* __restrict__ p) {
-  for (int c = 0; c < 3; c++) {
-    for (int r = 0; r < 3; r++) p[c * 4 + r] = T.R[r * 3 + c];
-    p[c * 4 + 3] = 0.0;
-  }
-  p[12] = T.t[0], p[13] = T.t[1], p[14] = T.t[2], p[15] = 1.0;
-}
-
-// T * Expmap(xi), xi = (omega, v): gtsam::Pose3::Expmap (R = I + A W + B W^2, t = (I + B W + C W^2) v; series below theta = 1e-8) composed from the right
-__device__ Rigid retract_rigid(const Rigid& T, const double* __restrict__ xi) {
-  const double wx = xi[0], wy = xi[1], wz = xi[2];
-  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-  double A, B, C;
-  if (th < 1e-8) {
-    A = 1.0 - th2 / 6.0, B = 0.5 - th2 / 24.0, C = 1.0 / 6.0 - th2 / 120.0;
-  } else {
-    const double s = sin(th), c = cos(th);
-    A = s / th, B = (1.0 - c) / th2, C = (th - s) / (th2 * th);
-  }
-  const double W[9] = {0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0};
-  double W2[9];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) W2[r * 3 + c] = W[r * 3] * W[c] + W[r * 3 + 1] * W[3 + c] + W[r * 3 + 2] * W[6 + c];
-  double E[9], V[9];
-  for (int i = 0; i < 9; i++) {
-    const double id = (i % 4 == 0) ? 1.0 : 0.0;
-    E[i] = id + A * W[i] + B * W2[i];
-    V[i] = id + B * W[i] + C * W2[i];
-  }
-  const double te[3] = {V[0] * xi[3] + V[1] * xi[4] + V[2] * xi[5], V[3] * xi[3] + V[4] * xi[4] + V[5] * xi[5], V[6] * xi[3] + V[7] * xi[4] + V[8] * xi[5]};
-  Rigid out;
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) out.R[r * 3 + c] = T.R[r * 3] * E[c] + T.R[r * 3 + 1] * E[3 + c] + T.R[r * 3 + 2] * E[6 + c];
-    out.t[r] = T.R[r * 3] * te[0] + T.R[r * 3 + 1] * te[1] + T.R[r * 3 + 2] * te[2] + T.t[r];
-  }
-  return out;
-}
-
-// inverse(Tt) * Ts: the relative pose a pairwise factor is evaluated at (integrated_matching_cost_factor.cpp:28-31: delta = target^-1 source)
-__device__ __forceinline__ Rigid between_rigid(const Rigid& Tt, const Rigid& Ts) {
-  Rigid D;
-  const double d[3] = {Ts.t[0] - Tt.t[0], Ts.t[1] - Tt.t[1], Ts.t[2] - Tt.t[2]};
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) D.R[r * 3 + c] = Tt.R[r] * Ts.R[c] + Tt.R[3 + r] * Ts.R[3 + c] + Tt.R[6 + r] * Ts.R[6 + c];
-    D.t[r] = Tt.R[r] * d[0] + Tt.R[3 + r] * d[1] + Tt.R[6 + r] * d[2];
-  }
-  return D;
-}
-
-struct LmPoseView {
-  const double* values;   // [N][16] the current values
-  const int* pairs;       // [F][2] (target pose, source pose)
-  const int* slot;        // [N] variable slot of a pose, < 0 = held
-  const double* x;        // [6 * slots] the step in slot order, or null = no step (relative poses of `values` themselves)
-  const int* status;      // the step's status word: != 0 = indeterminate, the trial is the current values
-  double* values_out;     // [N][16] device, may be null
-  double* values_host;    // [N][16] pinned, may be null
-  double* deltas_out;     // [F][16]
-  int F, N;
-};
-
-// thread i: factor i's relative pose at the (retracted) values, and pose i's (retracted) value.  A pose shared by several factors is retracted by each of them
-// from the same operands with the same instructions: the same bits everywhere.
 __global__ void __launch_bounds__(256) lm_poses_kernel(const LmPoseView v) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool step = v.x != nullptr && *v.status == 0;
-  auto value = [&](int k) {
-    Rigid T = load_rigid(v.values + 16 * (size_t)k);
-    const int s = v.slot[k];
-    return (step && s >= 0) ? retract_rigid(T, v.x + 6 * (size_t)s) : T;
-  };
-  if (i < v.F) {
-    const Rigid D = between_rigid(value(v.pairs[2 * i]), value(v.pairs[2 * i + 1]));
-    store_rigid(D, v.deltas_out + 16 * (size_t)i);
-  }
-  if (i < v.N && (v.values_out || v.values_host)) {
-    const Rigid T = value(i);
-    double p[16];
-    store_rigid(T, p);
-    for (int k = 0; k < 16; k++) {
-      if (v.values_out) v.values_out[16 * (size_t)i + k] = p[k];
-      if (v.values_host) v.values_host[16 * (size_t)i + k] = p[k];
-    }
-  }
+  lm_poses_thread(v, blockIdx.x * 256 + threadIdx.x, v.x, v.x != nullptr && *v.status != 0);
 }
 
 }  // namespace gp
@@ -155,7 +61,7 @@ struct gp_lm_graph {
 
 namespace {
 
-int launch_poses(gp_lm_graph* g, int from, int to, bool step) {
+gp::LmPoseView pose_view(gp_lm_graph* g, int from, int to, bool step) {
   gp::LmPoseView v{};
   v.values = g->d_values[from].as<double>();
   v.pairs = g->d_pairs.as<int>();
@@ -166,6 +72,11 @@ int launch_poses(gp_lm_graph* g, int from, int to, bool step) {
   v.values_host = step ? g->h_values[to].as<double>() : nullptr;
   v.deltas_out = g->d_deltas[to].as<double>();
   v.F = g->F, v.N = g->N;
+  return v;
+}
+
+int launch_poses(gp_lm_graph* g, int from, int to, bool step) {
+  const gp::LmPoseView v = pose_view(g, from, to, step);
   const int n = std::max(g->F, g->N);
   hipLaunchKernelGGL(gp::lm_poses_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, v);
   GP_HIP(hipGetLastError());
@@ -277,9 +188,12 @@ int gp_lm_graph_try_lambda(gp_lm_graph_t* g, double lambda, int diagonal_damping
   const gp_linearized6* rec = g->d_records[g->rec].as<gp_linearized6>();
   const int to = 1 - g->cur;
   g->spec_pending = false, g->tried = false;
-  if (g->sparse) GP_TRY(gp_sparse_system_issue_step(g->sparse, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr));
-  else GP_TRY(gp_dense_system_issue_step(g->dense, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr));
-  int rc = launch_poses(g, g->cur, to, true);
+  // (the one-launch steps retract the poses themselves, as their epilogue: gp_lm_poses.hpp; behind a multi-launch step lm_poses_kernel does)
+  bool fused = false;
+  const gp::LmPoseView pv = pose_view(g, g->cur, to, true);
+  if (g->sparse) GP_TRY(gp::sparse_issue_step_with_poses(g->sparse, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, pv, &fused));
+  else GP_TRY(gp::dense_issue_step_with_poses(g->dense, rec, lambda, diagonal_damping, min_diagonal, max_diagonal, pv, &fused));
+  int rc = fused ? GP_OK : launch_poses(g, g->cur, to, true);
   if (rc == GP_OK) rc = gp_vgicp_batch_issue_compute_error_dev_begin(g->batch, g->d_deltas[g->cur].as<double>(), g->d_deltas[to].as<double>());
   if (rc != GP_OK) {  // the step went out: collect it (its own wait) before the error is reported
     if (g->sparse) (void)gp_sparse_system_finish_step(g->sparse, nullptr, nullptr, nullptr);

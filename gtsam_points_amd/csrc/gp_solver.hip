@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "gp_host.hpp"
+#include "gp_lm_poses.hpp"
 
 namespace gp {
 
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256) dense_step_end_kernel(const double* __res
 __global__ void __launch_bounds__(64) dense_one_pose_step_kernel(const BlockDest* __restrict__ dests, const Contribution* __restrict__ contribs, const double* __restrict__ records,
                                                                  int num_factors, double lambda, int diagonal, double min_diag, double max_diag, double* __restrict__ A,
                                                                  double* __restrict__ b, double* __restrict__ c_out, double* __restrict__ x, double* __restrict__ Ldiag,
-                                                                 int* __restrict__ status, double* __restrict__ out_host) {
+                                                                 int* __restrict__ status, double* __restrict__ out_host, const LmPoseView epi, const int has_epi) {
   __shared__ double part[256];
   __shared__ double l[6][6], a0[6][6], bb[6], xx[6];
   __shared__ int st;
@@ -345,6 +346,10 @@ __global__ void __launch_bounds__(64) dense_one_pose_step_kernel(const BlockDest
     *status = st;
     out_host[12] = part[0];
     out_host[13] = (double)st;
+  }
+  if (has_epi) {  // the device-resident LM trial's poses (gp_lm_poses.hpp) while x is at hand: one launch less behind the step
+    const int n = max(epi.F, epi.N);
+    for (int i = t; i < n; i += 64) lm_poses_thread(epi, i, xx, st != 0);
   }
 }
 
@@ -510,8 +515,9 @@ int gp_dense_system_solve(gp_dense_system_t* s, double* x_host, double* x_dev_ou
 // without the waits and copies between them; x, b, c and the status arrive through one pinned block written by the last kernel.  Bit-identical to the three calls.
 // b_host / c_host are valid also when the system is indeterminate.
 // the step's device work, queued on the system's stream (a prior diagonal is uploaded by gp_dense_system_build: its own synchronisation)
-int gp_dense_system_issue_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
-                               const double* prior_diag_host) {
+static int issue_step_impl(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                           const double* prior_diag_host, const gp::LmPoseView* epi, bool* fused) {
+  if (fused) *fused = false;
   if (!s) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_step: null system");
   const size_t n = (size_t)s->n;
   GP_TRY(s->pinned.ensure(sizeof(double) * (2 * n + 2)));
@@ -519,7 +525,8 @@ int gp_dense_system_issue_step(gp_dense_system_t* s, const gp_linearized6* recor
     if ((!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_dense_system_step: bad arguments");
     hipLaunchKernelGGL(gp::dense_one_pose_step_kernel, dim3(1), dim3(64), 0, s->stream, s->d_dests.as<gp::BlockDest>(), s->d_contribs.as<gp::Contribution>(),
                        reinterpret_cast<const double*>(records_dev), s->num_factors, lambda, diagonal_damping, min_diagonal, max_diagonal, s->A.as<double>(), s->b.as<double>(),
-                       s->c.as<double>(), s->x.as<double>(), s->Ldiag.as<double>(), s->status.as<int>(), s->pinned.as<double>());
+                       s->c.as<double>(), s->x.as<double>(), s->Ldiag.as<double>(), s->status.as<int>(), s->pinned.as<double>(), epi ? *epi : gp::LmPoseView{}, epi ? 1 : 0);
+    if (fused) *fused = epi != nullptr;
     GP_HIP(hipGetLastError());
     s->built = false;
     s->step_in_flight = true;
@@ -534,6 +541,11 @@ int gp_dense_system_issue_step(gp_dense_system_t* s, const gp_linearized6* recor
   s->built = false;
   s->step_in_flight = true;
   return GP_OK;
+}
+
+int gp_dense_system_issue_step(gp_dense_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                               const double* prior_diag_host) {
+  return issue_step_impl(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host, nullptr, nullptr);
 }
 
 static int finish_step(gp_dense_system_t* s, double* x_host, double* b_host, double* c_host, bool wait) {
@@ -575,3 +587,10 @@ int gp_dense_system_device_solution(gp_dense_system_t* s, const double** x_dev, 
 }
 
 }  // extern "C"
+
+namespace gp {
+int dense_issue_step_with_poses(gp_dense_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                                const LmPoseView& poses, bool* fused) {
+  return issue_step_impl(sys, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr, &poses, fused);
+}
+}  // namespace gp

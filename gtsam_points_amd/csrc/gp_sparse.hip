@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "gp_host.hpp"
+#include "gp_lm_poses.hpp"
 
 namespace gp {
 
@@ -1426,6 +1427,8 @@ struct SparseSmallView {
   double* x_slots;        // device, slot order
   double* x_slots_host;   // pinned
   double* status_host;    // pinned
+  LmPoseView epi;             // has_epi: the retract of the device-resident LM trial as the kernel's epilogue (gp_lm_poses.hpp)
+  int has_epi;
   int wave_columns;           // 1: level 0's work lists (and every level's backward substitution) by one wave each, no barriers inside a list (small_wave_column); 0: the team form
   unsigned long long* trace;  // measurement (gp_debug_sparse_step_trace): shader-clock stamps of thread 0 -- [0] start, [1] = [5] lists and system in LDS, [2] factored, [3] substituted, [4] end,
                               // [8 + 4 r + {0, 1, 2, 3}]: round r < 14 of the first level: start, gathered, diagonal done, blocks below done; null = off
@@ -1793,6 +1796,13 @@ __global__ void __launch_bounds__(kSmallThreads) sparse_small_step_kernel(const 
     const size_t to = 6 * (size_t)V.perm[i / 6] + i % 6;
     V.x_slots[to] = v;
     V.x_slots_host[to] = v;
+    if (V.has_epi) ys[to] = v;  // (y is done with: the epilogue reads x in slot order from here)
+  }
+  if (V.has_epi) {
+    // the trial's poses (gp_lm.hip: lm_poses_kernel's work) while this workgroup still has x at hand: one launch less behind the step
+    __syncthreads();
+    const int n = max(V.epi.F, V.epi.N);
+    for (int i = t; i < n; i += kSmallThreads) lm_poses_thread(V.epi, i, ys, bad != 0);
   }
   if (t == 0) {
     *status = bad;
@@ -2165,8 +2175,8 @@ int gp_sparse_system_solve(gp_sparse_system_t* s, double* x_host, double* x_dev_
 // the assembly (damping applied as the diagonal is written; b, c stored where the host reads them; status cleared), the levels, x (slot order) + status to the host.
 // Bit-identical to the three calls.  b_host / c_host are valid also when the system turns out indeterminate (the optimizer raises lambda and tries again).
 // the step's device work, queued on the system's stream: nothing waits here
-int gp_sparse_system_issue_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
-                                const double* prior_diag_host) {
+static int issue_step_impl(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                           const double* prior_diag_host, const gp::LmPoseView* epi) {
   if (!s || (!records_dev && s->num_factors > 0) || !(lambda >= 0.0)) return gp::fail(GP_ERROR_INVALID_ARGUMENT, "gp_sparse_system_step: bad arguments");
   const gp::SparseSymbolic& S = s->sym;
   const size_t n = (size_t)s->n;
@@ -2192,6 +2202,8 @@ int gp_sparse_system_issue_step(gp_sparse_system_t* s, const gp_linearized6* rec
     gp::SparseSmallView V = s->small;
     V.x_slots_host = h;
     V.status_host = h + 2 * n + 1;
+    V.has_epi = epi ? 1 : 0;
+    if (epi) V.epi = *epi;
     hipLaunchKernelGGL(gp::sparse_small_step_kernel, dim3(1), dim3(gp::kSmallThreads), s->small_lds_bytes, s->stream, V, s->status.as<int>());
   } else {
     launch_factor_and_substitutions(s);
@@ -2202,6 +2214,11 @@ int gp_sparse_system_issue_step(gp_sparse_system_t* s, const gp_linearized6* rec
   s->built = false;
   s->step_in_flight = true;
   return GP_OK;
+}
+
+int gp_sparse_system_issue_step(gp_sparse_system_t* s, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                                const double* prior_diag_host) {
+  return issue_step_impl(s, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, prior_diag_host, nullptr);
 }
 
 // waits for the stream and hands over what the step's kernels left in the pinned buffer
@@ -2238,3 +2255,11 @@ int gp_sparse_system_device_solution(gp_sparse_system_t* s, const double** x_slo
 }
 
 }  // extern "C"
+
+namespace gp {
+int sparse_issue_step_with_poses(gp_sparse_system_t* sys, const gp_linearized6* records_dev, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                                 const LmPoseView& poses, bool* fused) {
+  *fused = sys && sys->one_launch;
+  return issue_step_impl(sys, records_dev, lambda, diagonal_damping, min_diagonal, max_diagonal, nullptr, *fused ? &poses : nullptr);
+}
+}  // namespace gp
