@@ -221,6 +221,7 @@ _SIGNATURES = {
     "gp_dense_system_collect_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_sparse_system_collect_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gp_lm_graph_set_speculation": (C.c_int, [C.c_void_p, C.c_int]),
+    "gp_lm_graph_set_one_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "gp_vgicp_batch_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "gp_dense_system_issue_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "gp_dense_system_finish_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -146,6 +146,13 @@ int gp_lm_graph_set_speculation(gp_lm_graph_t* g, int enable) {
   return was;
 }
 
+// the graph's own damped system: 0 = its multi-launch step (the retract then runs as lm_poses_kernel behind it), 1 = the one-launch step where the system qualifies
+// (default; the retract is its epilogue).  Bit-identical; for the test that says so and A/B timing.  Returns what the next trial runs (as gp_*_system_set_one_launch).
+int gp_lm_graph_set_one_launch(gp_lm_graph_t* g, int enable) {
+  if (!g) return 0;
+  return g->sparse ? gp_sparse_system_set_one_launch(g->sparse, enable) : gp_dense_system_set_one_launch(g->dense, enable);
+}
+
 int gp_lm_graph_num_variables(const gp_lm_graph_t* g) { return g ? 6 * g->slots : 0; }
 
 int gp_lm_graph_set_values(gp_lm_graph_t* g, const double* values_host) {

@@ -309,6 +309,10 @@ class LevenbergMarquardtGraphGPU:
     def accept(self):
         _capi.check(self._lib.gp_lm_graph_accept(self._h), "gp_lm_graph_accept")
 
+    def set_one_launch(self, enable=True):
+        """the graph's own damped system: False = its multi-launch step with the retract as a kernel of its own behind it (same bits) -> what the next trial runs"""
+        return int(self._lib.gp_lm_graph_set_one_launch(self._h, int(bool(enable))))
+
     def set_speculation(self, enable):
         """queue the linearise at the trial values behind each trial (default on; same results either way) -> previous setting"""
         return bool(self._lib.gp_lm_graph_set_speculation(self._h, int(bool(enable))))

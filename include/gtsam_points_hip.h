@@ -541,6 +541,9 @@ int gp_lm_graph_accept(gp_lm_graph_t* graph);
 /* speculation (on by default): behind a trial's error evaluation the linearise at the TRIAL values is queued into a second record buffer, so that an accepted step finds
  * its linearisation already running while the host decides (a rejected one wastes that launch); 0 = off.  Same bits either way.  Returns the previous setting. */
 int gp_lm_graph_set_speculation(gp_lm_graph_t* graph, int enable);
+/* the graph's own damped system: gp_sparse_system_set_one_launch / gp_dense_system_set_one_launch passed through (0: the multi-launch step, the retract as a kernel of
+ * its own behind it; default 1: the one-launch step where the system qualifies, the retract as its epilogue).  Same bits. */
+int gp_lm_graph_set_one_launch(gp_lm_graph_t* graph, int enable);
 int gp_lm_graph_optimize(gp_lm_graph_t* graph, const gp_lm_params* params, gp_lm_summary* summary);
 /* for checkers: the records of the last linearise and the relative poses of the current values, where they lie in device memory (valid until the graph is destroyed;
  * contents as of the work queued so far on the batch's stream) */

@@ -173,6 +173,11 @@ def test_trial_on_the_device_follows_the_host_driven_loop(gpu, kitti07, rigid):
         seq[spec] = a + b2 + c2 + [tg.g.values()]
     assert all(np.array_equal(x, y) for x, y in zip(seq[True], seq[False]))
     assert not np.array_equal(seq[True][0], seq[True][4])  # (the two lambdas gave different steps)
+    # the multi-launch step with the retract as a kernel of its own behind it (what a graph too large for the one-launch step runs): the same bits
+    assert tg.g.set_one_launch(False) == 0
+    multi = tg.native_loop(v0, max_iterations=30)
+    assert multi["final_error"] == nat["final_error"] and np.array_equal(multi["values"], nat["values"])
+    assert tg.g.set_one_launch(True) == 1
     gg.close()
     tg.close()
 
@@ -189,6 +194,8 @@ def test_trial_graph_with_one_free_pose_and_without_a_gauge(gpu, kitti07):
     np.testing.assert_allclose(res["values"], ref["values"], atol=1e-9)
     nat = tg.native_loop(v0, max_iterations=30)
     assert np.array_equal(nat["values"], res["values"])
+    assert tg.g.set_one_launch(False) == 0  # (the 6 x 6 system's nine-operation path, lm_poses_kernel behind it)
+    assert np.array_equal(tg.native_loop(v0, max_iterations=30)["values"], nat["values"])
     gg.close()
     tg.close()
     free = gpu.LevenbergMarquardtGraphGPU(factors, pairs, 2, fixed=())
