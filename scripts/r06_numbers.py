@@ -118,6 +118,11 @@ def results():
         t = mb["roofline"].get("traffic")
         out.append(f"| voxel-map build, 2 M pts @0.5 m | 2.0 M | {rng([x['legs'].get('map_build_ms') for x in rs], '{:.4f}')} | {mb['points_per_s']:.3g} pts/s | whole call {rng([x['legs'].get('map_build_frac') for x in rs], '{:.3f}')} of 8 TB/s on its 96 MB; counter traffic "
                    + (f"{t / 1e6:.0f} MB per build = {mb['roofline'].get('frac_traffic', 0):.3f} (`profiles/r06_map_build_pmc.txt`)" if t else "—") + " | bit-reproducible; = reference CPU map through save/load | — |")
+    fb = jf("r06_bench_detail_full_budget.json") if os.path.exists(os.path.join(ROOT, "profiles", "r06_bench_detail_full_budget.json")) else None
+    if fb and fb.get("c4"):
+        c4 = fb["c4"]
+        out.append(f"| C4: {c4['factors']} factors over 512 submaps of 32,768 pts, 1.0 m, ONE batched call on ONE GPU (the leg the 45 s default budget skips: `bench.py --budget-seconds 120`, `profiles/r06_bench_full_budget.json`, whole run {fb.get('run_seconds', 0):.0f} s) | "
+                   f"{c4['points_per_linearize'] / 1e6:.1f} M | {c4['ms_per_linearize']:.4f} | {c4['value']:.3g} corr/s | tile kernel {c4['tile_kernel_ms_slowest_rank'] * 1e3:.0f} µs; {c4['algorithmic_frac_per_gpu']:.2f} algorithmic (every source cloud serves 8 factors: not an HBM fraction) | = the C3 kernel | — |")
     reh = jl("r06_bench_rehearsal_n2.json")
     if reh:
         x = reh[-1]
